@@ -1,0 +1,217 @@
+"""Pin the CPU oracle (oracle/) against the golden vectors produced by the unmodified reference
+(tests/golden/make_golden.py).  CPU only.  Tolerance: restatement vs golden <= 1e-6 relative
+(same torch CPU kernels underneath) — SURVEY.md §8c."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, max_rel, rel_err
+from filler import fill_dict, grad_summary
+from oracle import graph, nets
+
+TOL = 1e-6
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def schnet_shapes(cfg):
+    F, G, L, C = cfg["hidden_channels"], cfg["num_gaussians"], cfg["num_interactions"], cfg["node_class"]
+    s = {"embedding.weight": (C, F)}
+    for l in range(L):
+        p = "interactions.%d." % l
+        s.update({p + "mlp.0.weight": (F, G), p + "mlp.0.bias": (F,), p + "mlp.2.weight": (F, F),
+                  p + "mlp.2.bias": (F,), p + "conv.lin1.weight": (F, F), p + "conv.lin2.weight": (F, F),
+                  p + "conv.lin2.bias": (F,), p + "lin.weight": (F, F), p + "lin.bias": (F,)})
+    s.update({"lin1.weight": (F, F), "lin1.bias": (F,), "lin2.weight": (F, F), "lin2.bias": (F,)})
+    return s
+
+
+def schnet_params(cfg, requires_grad=True):
+    P = fill_dict(schnet_shapes(cfg))
+    for v in P.values():
+        v.requires_grad_(requires_grad)
+    P["distance_expansion.offset"] = nets.smearing_constants(cfg["cutoff"], cfg["num_gaussians"])[0]
+    return P
+
+
+def ncsn_shapes(F):
+    return {"input_distance_mlp.layers.0.weight": (F, 1), "input_distance_mlp.layers.0.bias": (F,),
+            "input_distance_mlp.layers.1.weight": (1, F), "input_distance_mlp.layers.1.bias": (1,),
+            "output_mlp.layers.0.weight": (F, F + 1), "output_mlp.layers.0.bias": (F,),
+            "output_mlp.layers.1.weight": (F // 2, F), "output_mlp.layers.1.bias": (F // 2,),
+            "output_mlp.layers.2.weight": (1, F // 2), "output_mlp.layers.2.bias": (1,)}
+
+
+def ncsn_params(F, K, scale=1.0):
+    P = {k: (v * scale).requires_grad_() for k, v in fill_dict(ncsn_shapes(F)).items()}
+    P["sigmas"] = nets.ncsn_sigmas(10.0, 0.01, K)
+    return P
+
+
+def test_g1_smearing_and_coeff():
+    g = load_golden("g1_g2_smearing_ssp")
+    for r, G in [(10.0, 51), (5.0, 51), (10.0, 50)]:
+        key = "%g_%d" % (r, G)
+        off, coeff = nets.smearing_constants(r, G)
+        assert coeff == float(g["coeff_" + key])
+        assert torch.equal(off, t(g["offset_" + key]))
+        y = nets.gaussian_smearing(t(g["d_" + key]), off, coeff)
+        assert torch.equal(y, t(g["y_" + key]))
+    # the two scalars quoted in SURVEY §8a S4
+    assert abs(nets.smearing_constants(10.0, 51)[1] - (-12.4999996275)) < 1e-9
+    assert abs(nets.smearing_constants(5.0, 51)[1] - (-49.9999985099)) < 1e-9
+
+
+def test_g2_shifted_softplus():
+    g = load_golden("g1_g2_smearing_ssp")
+    assert nets.SSP_SHIFT == float(g["ssp_shift"])
+    assert torch.equal(nets.shifted_softplus(t(g["ssp_x"])), t(g["ssp_y"]))
+
+
+@pytest.mark.parametrize("r", [5.0, 10.0, 1.5])
+def test_g3_radius_graph_bit_exact(r):
+    g = load_golden("g3_radius_graph")
+    e = graph.radius_graph_np(g["positions"], r, g["batch"])
+    assert e.dtype == np.int64 and np.array_equal(e, g["edge_index_%g" % r])
+    pos = t(g["positions"])
+    w = (pos[t(e[0])] - pos[t(e[1])]).norm(dim=-1)
+    assert torch.equal(w, t(g["edge_weight_%g" % r]))
+
+
+def test_g3_cap_triggers_and_is_asymmetric():
+    g = load_golden("g3_radius_graph")
+    e = g["edge_index_10"]
+    deg = np.bincount(e[1], minlength=len(g["batch"]))
+    assert deg.max() == 33 and (deg == 32).sum() > 0
+    s = set(map(tuple, e.T.tolist()))
+    assert any((b, a) not in s for a, b in s)  # capped graph is not symmetric
+
+
+def test_collate_matches_reference_semantics():
+    g = load_golden("g5_ncsn_comb_K50_p5_last1")
+    sizes = np.bincount(g["batch"])
+    mols, off = [], 0
+    for n in sizes:
+        mols.append((g["x"][off:off + n], g["positions"][off:off + n]))
+        off += n
+    c = graph.collate_np(mols, "combination")
+    for k in ("x", "positions", "batch", "super_edge_index"):
+        assert np.array_equal(c[k], g[k]), k
+    assert graph.super_edges_np(1).shape == (2, 0)
+    assert graph.super_edges_np(3, "permutation").T.tolist() == [[0, 1], [0, 2], [1, 0], [1, 2], [2, 0], [2, 1]]
+
+
+@pytest.mark.parametrize("tag", ["reduced", "full_r5", "full_r10"])
+def test_g4_schnet_forward_and_grads(tag):
+    g = load_golden("g4_schnet_" + tag)
+    cfg = json.loads(str(g["cfg"]))
+    P = schnet_params(cfg)
+    out, h = nets.schnet_forward(P, t(g["x"])[:, 0], t(g["positions"]), t(g["batch"]), cfg["cutoff"],
+                                 cfg["num_interactions"], cfg["readout"], return_latent=True)
+    assert max_rel(out, g["out"]) < TOL and max_rel(h, g["h"]) < TOL
+    loss = (out ** 2).sum() + (h ** 2).sum() * 0.5
+    assert rel_err(loss, g["loss"]) < TOL
+    loss.backward()
+    for k in g:
+        if k.startswith("gsum/"):
+            assert rel_err(grad_summary(P[k[5:]].grad), g[k]) < 5e-6, k
+        if k.startswith("grad/"):
+            assert rel_err(P[k[5:]].grad, g[k]) < 5e-6, k
+
+
+@pytest.mark.parametrize("tag", ["comb_K50_p2", "comb_K30_p0.05", "comb_K50_p5_last1", "perm_K30_p10"])
+def test_g5_ncsn(tag):
+    g = load_golden("g5_ncsn_" + tag)
+    P = ncsn_params(128, int(g["K"]))
+    assert torch.equal(P["sigmas"], t(g["sigmas"]))
+    h = t(g["h"]).clone().requires_grad_()
+    loss = nets.ncsn_v03_forward(P, t(g["batch"]), t(g["super_edge_index"]), h, t(g["distance"]),
+                                 t(g["noise_level"]), t(g["distance_noise"]), float(g["anneal_power"]))
+    assert rel_err(loss, g["loss"]) < TOL
+    loss.backward()
+    assert rel_err(h.grad, g["grad_h"]) < 5e-6
+    for k in g:
+        if k.startswith("grad/"):
+            assert rel_err(P[k[5:]].grad, g[k]) < 5e-6, k
+
+
+def test_g5_last_graph_single_atom_quirk():
+    """NCSN.py:210-212: the mean divides by max(edge2graph)+1, which is B-1 when the last
+    molecule has one atom (no super-edges)."""
+    g = load_golden("g5_ncsn_comb_K50_p5_last1")
+    b, sei = t(g["batch"]), t(g["super_edge_index"])
+    assert int(b.max()) + 1 == 4 and int(b[sei[0]].max()) + 1 == 3
+
+
+@pytest.mark.parametrize("tag", ["reduced", "full"])
+def test_g6_do_ddm(tag):
+    g = load_golden("g6_ddm_" + tag)
+    cfg = json.loads(str(g["cfg"]))
+    F = cfg["hidden_channels"]
+    Pm, P1, P2 = schnet_params(cfg), ncsn_params(F, 50), ncsn_params(F, 50, 0.9)
+    loss = nets.do_ddm_schnet(Pm, P1, P2, t(g["x"]), t(g["positions"]), t(g["batch"]), t(g["super_edge_index"]),
+                              t(g["pos_noise"]), t(g["noise_level_1"]), t(g["dist_noise_1"]),
+                              t(g["noise_level_2"]), t(g["dist_noise_2"]), cfg["cutoff"],
+                              cfg["num_interactions"], 2, cfg["readout"])
+    assert rel_err(loss, g["loss"]) < TOL
+    loss.backward()
+    for k in g:
+        if k.startswith("gsum/") or k.startswith("grad/"):
+            _, m, name = k.split("/", 2)
+            grad = {"model": Pm, "ncsn1": P1, "ncsn2": P2}[m][name].grad
+            got = grad_summary(grad) if k.startswith("gsum/") else grad
+            assert rel_err(got, g[k]) < 2e-5, k
+
+
+def painn_params(cfg):
+    F, L, R, Z = cfg["n_atom_basis"], cfg["n_interactions"], cfg["n_rbf"], cfg["max_z"]
+    s = {"embedding.weight": (Z, F), "filter_net.weight": (L * 3 * F, R), "filter_net.bias": (L * 3 * F,)}
+    for i in range(L):
+        p = "interactions.%d.interatomic_context_net." % i
+        s.update({p + "0.weight": (F, F), p + "0.bias": (F,), p + "1.weight": (3 * F, F), p + "1.bias": (3 * F,)})
+    for i in range(L):
+        m = "mixing.%d." % i
+        s.update({m + "intraatomic_context_net.0.weight": (F, 2 * F), m + "intraatomic_context_net.0.bias": (F,),
+                  m + "intraatomic_context_net.1.weight": (3 * F, F), m + "intraatomic_context_net.1.bias": (3 * F,),
+                  m + "mu_channel_mix.weight": (2 * F, F)})
+    P = {k: v.requires_grad_() for k, v in fill_dict(s).items()}
+    off = torch.linspace(0.0, cfg["cutoff"], R)
+    P["radial_basis.offsets"] = off
+    P["radial_basis.widths"] = torch.abs(off[1] - off[0]) * torch.ones_like(off)
+    P["cutoff_fn.cutoff"] = torch.tensor([cfg["cutoff"]], dtype=torch.float32)
+    return P
+
+
+def test_g7_painn_forward_grads_and_ddm():
+    g = load_golden("g7_painn")
+    cfg = json.loads(str(g["cfg"]))
+    P = painn_params(cfg)
+    out, q = nets.painn_forward(P, t(g["x"]), t(g["positions_perturbed"]), t(g["radius_edge_index"]), t(g["batch"]),
+                                cfg["n_atom_basis"], cfg["n_interactions"], cfg["cutoff"], cfg["readout"],
+                                return_latent=True)
+    assert max_rel(out, g["out"]) < TOL and max_rel(q, g["q"]) < TOL
+    # padding_idx=0: hydrogens' embedding row gets no gradient (painn.py:174)
+    loss = (out ** 2).sum() + 0.5 * (q ** 2).sum()
+    loss.backward()
+    assert float(P["embedding.weight"].grad[0].abs().max()) == 0.0
+    for k in g:
+        if k.startswith("gsum/"):
+            assert rel_err(grad_summary(P[k[5:]].grad), g[k]) < 5e-6, k
+    d = load_golden("g7_painn_ddm")
+    for v in P.values():
+        v.grad = None
+    P1, P2 = ncsn_params(128, 50), ncsn_params(128, 50)
+    loss = nets.do_ddm_painn(P, P1, P2, t(g["x"]), t(g["positions"]), t(g["batch"]), t(g["radius_edge_index"]),
+                             t(g["super_edge_index"]), t(d["pos_noise"]), t(d["noise_level_1"]), t(d["dist_noise_1"]),
+                             t(d["noise_level_2"]), t(d["dist_noise_2"]), cfg["n_atom_basis"],
+                             cfg["n_interactions"], cfg["cutoff"], 2, cfg["readout"])
+    assert rel_err(loss, d["loss"]) < TOL
+    loss.backward()
+    for k in d:
+        if k.startswith("gsum/"):
+            _, m, name = k.split("/", 2)
+            assert rel_err(grad_summary({"model": P, "ncsn1": P1, "ncsn2": P2}[m][name].grad), d[k]) < 2e-5, k
