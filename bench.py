@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Headline benchmark: molecules/s of one DDM training step (2x SchNet forward on the clean and the
+perturbed view + 2x NCSN_version_03 + backward + Adam), bs = 1024 molecules per GPU, synthetic
+Molecule3D-shaped batches (n = 18 atoms, 5 A cutoff), fp32.  BASELINE.json configs[2] (the
+configuration the metric is quoted on); SURVEY.md §8(d) defines inputs, byte/flop model and protocol.
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+F, L, G, CUTOFF, K_LEVELS = 128, 6, 51, 5.0, 50
+HBM_PEAK = 8.0e12       # B/s, spec (MI355X_MICROARCH.md)
+FP32_PEAK = 157.3e12    # FLOP/s, vector == f32-MFMA rate
+# entry points whose launches are bracketed with HIP events inside the timed region
+TIMED = ("geossl_cfconv_filter_fwd", "geossl_cfconv_filter_bwd_hidden", "geossl_cfconv_filter_bwd_weights",
+         "geossl_ddm_loss_fwd", "geossl_ddm_loss_bwd_rows", "geossl_ddm_loss_bwd_weights", "geossl_linear_wgrad")
+
+
+def alg_model(n_atoms, n_edges, n_super):
+    """SURVEY.md §8(d) algorithmic bytes and flops per batch (reference formulation: directed edges E,
+    atoms N, super-edges S per view)."""
+    E, N, S = float(n_edges), float(n_atoms), float(n_super)
+    bytes_fwd_view = E * (228 + L * (4 * G + 20 + 12 * F)) + N * (28 + 4 * F * (8 * L + 6))
+    bytes_k5_view = S * (16 + 8 * F + 12)
+    step_bytes = 2 * 3 * (bytes_fwd_view + bytes_k5_view)
+    edge_fwd = 2 * G * F + 2 * F * F
+    edge_bwd = 2 * G * F + 4 * F * F
+    node_fwd = 3 * 2 * F * F
+    head_fwd = 2 * 2 * F * F
+    ncsn_fwd = 2 * (F + 1) * F + 2 * F * (F // 2) + F + 4 * F
+    step_flops = 2 * (E * L * (edge_fwd + edge_bwd) + N * (L * node_fwd + head_fwd) * 3 + S * ncsn_fwd * 3)
+    per_kernel = {
+        # (algorithmic flops, algorithmic bytes) of ONE launch, both views together
+        "geossl_cfconv_filter_fwd": (2 * E * L * edge_fwd, 2 * E * L * (4 * G + 4 + 4 * F)),
+        "geossl_cfconv_filter_bwd_hidden": (2 * E * L * 2 * F * F, 2 * E * L * (3 * 4 * F)),
+        "geossl_cfconv_filter_bwd_weights": (2 * E * L * (2 * F * F + 2 * G * F), 2 * E * L * (3 * 4 * F + 4 * G)),
+        "geossl_ddm_loss_fwd": (S * ncsn_fwd, S * (16 + 8 * F + 12)),
+        "geossl_ddm_loss_bwd_rows": (S * (2 * F * F + 2 * F * (F // 2)), S * (4 * F * 3)),
+        "geossl_ddm_loss_bwd_weights": (S * (2 * F * F + 2 * F * (F // 2)), S * (4 * F * 4)),
+        "geossl_linear_wgrad": (2 * N * (3 * L + 2) * 2 * F * F, 2 * N * (3 * L + 2) * 8 * F),
+    }
+    return step_bytes, step_flops, per_kernel
+
+
+def cpu_baseline(seed, n_mols=256, timed=2):
+    """The CPU oracle (pure-torch restatement pinned to the reference by golden vectors) on a bounded
+    sample of the same workload: DDM step fwd+bwd + Adam on `n_mols` molecules."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+    from geossl_amd.synthetic import draw_noise, make_batch
+    from helpers import ncsn_oracle_params, schnet_oracle_params, t
+    from oracle import nets
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = dict(hidden_channels=F, num_filters=F, num_interactions=L, num_gaussians=G, cutoff=CUTOFF, node_class=9,
+               readout="mean")
+    Pm, P1, P2 = schnet_oracle_params(cfg), ncsn_oracle_params(F, K_LEVELS), ncsn_oracle_params(F, K_LEVELS, 0.9)
+    params = [p for P in (Pm, P1, P2) for p in P.values() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=5e-4)
+    b = make_batch(n_mols, seed=seed, mode="A")
+    times = []
+    for it in range(1 + timed):
+        nz = draw_noise(b, seed + it)
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = nets.do_ddm_schnet(Pm, P1, P2, t(b["x"]), t(b["positions"]), t(b["batch"]), t(b["super_edge_index"]),
+                                  t(nz["pos_noise"]), t(nz["noise_level_1"]), t(nz["dist_noise_1"]),
+                                  t(nz["noise_level_2"]), t(nz["dist_noise_2"]), CUTOFF, L, 2, "mean")
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times[1:]))
+    return {"value": n_mols / med, "unit": "molecules/s", "cores": cores, "kind": "port",
+            "sample": "oracle DDM step (fwd+bwd+Adam) on %d of the 1024 molecules, 1 warm-up + %d timed steps, "
+                      "median %.2f s/step" % (n_mols, timed, med)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mols", type=int, default=1024, help="molecules per GPU per step")
+    ap.add_argument("--dataset-mols", type=int, default=100000, help="synthetic dataset size (config 3)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from geossl_amd import _lib
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.Geom3D.models import SchNet
+    from geossl_amd.NCSN import NCSN_version_03
+    from geossl_amd.parallel import init_distributed
+    from geossl_amd.synthetic import make_batch
+    import torch.distributed as dist
+
+    rank, local_rank, world = init_distributed()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    _lib.load()
+
+    torch.manual_seed(1234)  # identical initial weights on every rank
+    model = SchNet(hidden_channels=F, num_filters=F, num_interactions=L, num_gaussians=G, cutoff=CUTOFF,
+                   node_class=9, readout="mean").to(dev)
+    n1 = NCSN_version_03(F, 10.0, 0.01, K_LEVELS, "symmetry", 2).to(dev)
+    n2 = NCSN_version_03(F, 10.0, 0.01, K_LEVELS, "symmetry", 2).to(dev)
+    trainer = pg.DDMTrainer(model, n1, n2, lr=5e-4, mu=0.0, sigma=0.3, device_noise=True)
+
+    # pre-collated, device-resident batches: each rank owns its own molecules (weak scaling)
+    total_steps = args.warmup + args.steps
+    n_batches = max(1, min(args.dataset_mols // (args.mols * world), total_steps))
+    batches, shapes = [], []
+    for i in range(n_batches):
+        b = make_batch(args.mols, seed=1000 * (rank + 1) + i, mode="A")
+        bt = pg.Batch.from_numpy(b, dev)
+        bt.num_graphs  # cached python int
+        batches.append(bt)
+    # build the per-batch index structures once (part of collation, not of the step)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(777 + rank)
+
+    def draw(bt, step):
+        S, B = bt.super_edge_index.size(1), bt.num_graphs
+        return {
+            "noise_level_1": torch.randint(0, K_LEVELS, (B,), device=dev, generator=gen),
+            "dist_noise_1": torch.randn(S, 1, device=dev, generator=gen),
+            "noise_level_2": torch.randint(0, K_LEVELS, (B,), device=dev, generator=gen),
+            "dist_noise_2": torch.randn(S, 1, device=dev, generator=gen),
+            "pos_noise": torch.empty_like(bt.positions).normal_(0.0, 0.3, generator=gen),
+        }
+
+    def one_step(i):
+        bt = batches[i % n_batches]
+        return trainer.step(bt, draw(bt, i))
+
+    for i in range(args.warmup):
+        loss = one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    _lib.TIMERS = {k: [] for k in TIMED}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    timers, _lib.TIMERS = _lib.TIMERS, None
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final_loss = float(loss)
+
+    if rank == 0:
+        from geossl_amd import ops
+        bt = batches[0]
+        E = int(ops.radius_graph(bt.positions, CUTOFF, bt.batch).size(1))
+        N, S = bt.positions.size(0), bt.super_edge_index.size(1)
+        step_bytes, step_flops, per_kernel = alg_model(N, E, S)
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * args.mols * args.steps / elapsed
+        kern = {}
+        for name, evs in timers.items():
+            if evs:
+                ms = [a.elapsed_time(b) for a, b in evs]
+                calls_per_step = len(ms) / args.steps
+                kern[name] = (float(np.mean(ms)), calls_per_step)
+        dom = max(kern, key=lambda k: kern[k][0] * kern[k][1]) if kern else None
+        roof = None
+        if dom is not None:
+            fl, by = per_kernel[dom]
+            if dom.startswith("geossl_ddm") or dom == "geossl_linear_wgrad":
+                pass
+            dur = kern[dom][0] * 1e-3
+            ach_f, ach_b = fl / dur, by / dur
+            # the dense pair-row / super-edge-row kernels run on the f32 MFMA pipe: price them against it
+            roof = {"kernel": dom, "bound": "mfma", "achieved": ach_f / 1e12, "peak": FP32_PEAK / 1e12,
+                    "unit": "TFLOP/s", "frac": ach_f / FP32_PEAK, "traffic": None,
+                    "avg_launch_ms": kern[dom][0], "launches_per_step": kern[dom][1],
+                    "algorithmic_GBps": ach_b / 1e9, "hbm_frac": ach_b / HBM_PEAK}
+        per_gpu = value / world
+        out = {
+            "metric": "molecules/s/GPU SchNet+DDM fwd+bwd (QM9-sized, bs=1024); % HBM roofline",
+            "value": value, "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "pretrain_GeoSSL.py --GeoSSL_option=DDM step, SchNet F=128 L=6 G=51 cutoff=5A, "
+                                   "bs=%d molecules/GPU x n=18 atoms, %d pre-collated device-resident batches/GPU"
+                                   % (args.mols, n_batches),
+                       "molecules_per_gpu_per_step": args.mols, "atoms": N, "directed_edges": E, "super_edges": S,
+                       "parallelism": "dp%d" % world},
+            "roofline": roof,
+            "step_roofline": {"hbm_frac": step_bytes * (per_gpu / args.mols) / HBM_PEAK,
+                              "fp32_frac": step_flops * (per_gpu / args.mols) / FP32_PEAK,
+                              "alg_MB_per_mol": step_bytes / args.mols / 1e6,
+                              "alg_MFLOP_per_mol": step_flops / args.mols / 1e6},
+            "kernel_ms": {k: {"avg_ms": v[0], "per_step": v[1]} for k, v in kern.items()},
+            "final_loss": final_loss,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(seed=1000)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

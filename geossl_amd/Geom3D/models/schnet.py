@@ -1,0 +1,321 @@
+"""SchNet behind the reference's own interface (Geom3D/models/schnet.py), computed by the HIP path.
+
+Same constructor, ``forward(z, pos, batch=None, return_latent=False)`` signature, parameter
+registration order and ``state_dict`` keys as the reference class (schnet.py:16-135), including its
+quirks: the filter network is registered twice (``interactions.i.mlp`` and
+``interactions.i.conv.nn`` are one module, :141-148), ``mlp[2].bias`` keeps the default Linear
+init (:155-158), the head is Linear(F,F) -> ssp -> Linear(F,F) (:62-64).
+
+The arithmetic does not run in PyTorch: one autograd node wraps the whole message-passing stack and
+drives the kernels of libgeossl_hip.so (radius graph in pair-slot form, continuous-filter network
+for all blocks in one launch, neighbour aggregation, MFMA atom-row Linears, and the matching
+backward).  CUDA tensors only — there is no CPU fallback.
+"""
+import ctypes as C
+import math
+import os
+
+import torch
+from torch.nn import Embedding, Linear, ModuleList, Sequential
+
+from ... import _lib, ops
+from ..._lib import call, ptr, stream
+from ...layout import get_layout
+from ._atomic_mass import atomic_masses
+
+SUPPORTED_F = (32, 64, 128)
+
+
+class ShiftedSoftplus(torch.nn.Module):
+    """schnet.py:210-216.  Only evaluated inside the fused kernels; kept as a module so the
+    Sequential indices (mlp.0 / mlp.2) and the module tree match the reference."""
+
+    def __init__(self):
+        super().__init__()
+        self.shift = torch.log(torch.tensor(2.0)).item()
+
+    def forward(self, x):
+        raise RuntimeError("ShiftedSoftplus is fused into the HIP kernels and is not called on its own")
+
+
+class GaussianSmearing(torch.nn.Module):
+    """schnet.py:198-207: offset buffer + Python-double coeff from the fp32 grid spacing."""
+
+    def __init__(self, start=0.0, stop=5.0, num_gaussians=50):
+        super().__init__()
+        offset = torch.linspace(start, stop, num_gaussians)
+        self.coeff = -0.5 / (offset[1] - offset[0]).item() ** 2
+        self.register_buffer("offset", offset)
+
+    def forward(self, dist):
+        return ops.gaussian_smearing(dist, self.offset, self.coeff)
+
+
+class CFConv(torch.nn.Module):
+    """Parameter holder with the reference's names (schnet.py:170-183); message passing itself is
+    geossl_cfconv_filter_fwd + geossl_cfconv_aggregate."""
+
+    def __init__(self, in_channels, out_channels, num_filters, nn, cutoff):
+        super().__init__()
+        self.lin1 = Linear(in_channels, num_filters, bias=False)
+        self.lin2 = Linear(num_filters, out_channels)
+        self.nn = nn
+        self.cutoff = cutoff
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        torch.nn.init.xavier_uniform_(self.lin1.weight)
+        torch.nn.init.xavier_uniform_(self.lin2.weight)
+        self.lin2.bias.data.fill_(0)
+
+
+class InteractionBlock(torch.nn.Module):
+    def __init__(self, hidden_channels, num_gaussians, num_filters, cutoff):
+        super().__init__()
+        self.mlp = Sequential(Linear(num_gaussians, num_filters), ShiftedSoftplus(), Linear(num_filters, num_filters))
+        self.conv = CFConv(hidden_channels, hidden_channels, num_filters, self.mlp, cutoff)
+        self.act = ShiftedSoftplus()
+        self.lin = Linear(hidden_channels, hidden_channels)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # mirrors schnet.py:154-161 including the quirk that mlp[2].bias is never zeroed
+        torch.nn.init.xavier_uniform_(self.mlp[0].weight)
+        self.mlp[0].bias.data.fill_(0)
+        torch.nn.init.xavier_uniform_(self.mlp[2].weight)
+        self.conv.reset_parameters()
+        torch.nn.init.xavier_uniform_(self.lin.weight)
+        self.lin.bias.data.fill_(0)
+
+
+def _core_params(model):
+    ps = [model.embedding.weight]
+    for blk in model.interactions:
+        ps += [blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight, blk.mlp[2].bias, blk.conv.lin1.weight,
+               blk.conv.lin2.weight, blk.conv.lin2.bias, blk.lin.weight, blk.lin.bias]
+    ps += [model.lin1.weight, model.lin1.bias, model.lin2.weight, model.lin2.bias]
+    return ps
+
+
+class _SchNetCore(torch.autograd.Function):
+    """(z, pos) -> atom features after the head (schnet.py:89-101) as ONE autograd node."""
+
+    @staticmethod
+    def forward(ctx, z, pos, lay, cfg, *params):
+        L, F, G = cfg["L"], cfg["F"], cfg["G"]
+        dev = pos.device
+        N = pos.size(0)
+        training = any(ctx.needs_input_grad[4:])
+        ps = [p.detach().contiguous() for p in params]
+        emb_w, head = ps[0], ps[1 + 9 * L:]
+        layers = [ps[1 + 9 * l: 1 + 9 * (l + 1)] for l in range(L)]
+        st = stream()
+        # embedding (schnet.py:89); z is usually the strided view x[:, 0]
+        h = torch.empty(N, F, dtype=torch.float32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev) if cfg["debug"] else None
+        call("geossl_embedding_fwd", ptr(z), z.stride(0) if z.numel() else 1, ptr(emb_w), emb_w.size(0), N, F, ptr(h),
+             ptr(status), st)
+        if status is not None and int(status.item()):
+            raise IndexError("atom type out of range for the embedding table")
+        # radius graph + edge length + envelope (schnet.py:91-93,186)
+        pair_d, pair_c, pair_flag = ops.pair_geometry(pos, lay, cfg["cutoff"])
+        P = lay.P
+        # continuous-filter network of every block in one launch (schnet.py:94,187)
+        fw = _lib.FilterWeights()
+        for l, lp in enumerate(layers):
+            fw.w1[l], fw.b1[l], fw.w2[l], fw.b2[l] = ptr(lp[0]), ptr(lp[1]), ptr(lp[2]), ptr(lp[3])
+        Wf = torch.empty(L, P, F, dtype=torch.float32, device=dev)
+        T = torch.empty(L, P, F, dtype=torch.float32, device=dev) if training else None
+        if P > 0:
+            call("geossl_cfconv_filter_fwd", ptr(pair_d), ptr(pair_c), P, C.byref(fw), L, F, G, ptr(cfg["offset"]),
+                 cfg["coeff"], ptr(T), ptr(Wf), st)
+        hs, xs, aggs, ts = [], [], [], []
+        for l, lp in enumerate(layers):
+            x = ops.linear(h, lp[4])                                    # conv.lin1 (no bias)   :189
+            agg = ops.aggregate(x, Wf[l], pair_flag, lay)               # propagate(add)        :190
+            t = ops.linear(agg, lp[5], bias=lp[6], flags=_lib.EPI_SSP)  # conv.lin2 + act       :191,165
+            hn = ops.linear(t, lp[7], bias=lp[8], res=h)                # lin + residual        :166,97
+            if training:
+                hs.append(h); xs.append(x); aggs.append(agg); ts.append(t)
+            h = hn
+        u = ops.linear(h, head[0], bias=head[1], flags=_lib.EPI_SSP)    # lin1 + act            :99-100
+        hout = ops.linear(u, head[2], bias=head[3])                     # lin2                  :101
+        if training:
+            ctx.lay, ctx.cfg = lay, cfg
+            ctx.z = z
+            ctx.ps = ps
+            ctx.saved = dict(pair_d=pair_d, pair_c=pair_c, pair_flag=pair_flag, Wf=Wf, T=T, hs=hs, xs=xs, aggs=aggs,
+                             ts=ts, h_last=h, u=u)
+        return hout
+
+    @staticmethod
+    def backward(ctx, dhout):
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("gradient w.r.t. positions (force matching, finetune_md17.py:46) is not built "
+                                      "yet — SURVEY.md §8(f) N3")
+        cfg, lay, sv, ps = ctx.cfg, ctx.lay, ctx.saved, ctx.ps
+        L, F, G = cfg["L"], cfg["F"], cfg["G"]
+        dev = dhout.device
+        N = dhout.size(0)
+        st = stream()
+        emb_w, head = ps[0], ps[1 + 9 * L:]
+        layers = [ps[1 + 9 * l: 1 + 9 * (l + 1)] for l in range(L)]
+        grads = [torch.empty_like(p) for p in ps]
+        g_emb, g_head = grads[0], grads[1 + 9 * L:]
+        g_layers = [grads[1 + 9 * l: 1 + 9 * (l + 1)] for l in range(L)]
+        dh_out = dhout.contiguous()
+        probs = []  # (A = dY, B = X, dW, db)
+        # head: hout = u W2^T + b2, u = ssp(h W1^T + b1)
+        du = ops.linear(dh_out, head[2], transB=False, tprev=sv["u"])
+        dh = ops.linear(du, head[0], transB=False)
+        probs.append((dh_out, sv["u"], g_head[2], g_head[3]))
+        probs.append((du, sv["h_last"], g_head[0], g_head[1]))
+        daggs = [None] * L
+        keep = [dh_out, du]
+        for l in reversed(range(L)):
+            lp, gl = layers[l], g_layers[l]
+            dy = ops.linear(dh, lp[7], transB=False, tprev=sv["ts"][l])       # through lin and act
+            dagg = ops.linear(dy, lp[5], transB=False)                         # through conv.lin2
+            dx = ops.aggregate(dagg, sv["Wf"][l], sv["pair_flag"], lay, swap=True)  # transposed graph
+            dh_new = ops.linear(dx, lp[4], transB=False, res=dh)               # through conv.lin1 + residual
+            probs.append((dh, sv["ts"][l], gl[7], gl[8]))
+            probs.append((dy, sv["aggs"][l], gl[5], gl[6]))
+            probs.append((dx, sv["hs"][l], gl[4], None))
+            daggs[l] = dagg
+            keep += [dh, dy, dx]
+            dh = dh_new
+        # every atom-row weight gradient in one batched launch
+        ops.linear_wgrad(probs, N, F, F)
+        # embedding table
+        nfl = _lib.load().geossl_embedding_bwd_workspace_floats(emb_w.size(0), F)
+        ws = torch.empty(nfl, dtype=torch.float32, device=dev)
+        z = ctx.z
+        call("geossl_embedding_bwd", ptr(z), z.stride(0) if z.numel() else 1, ptr(dh), emb_w.size(0), N, F,
+             ptr(g_emb), ptr(ws), 0, st)
+        # continuous-filter network weights, all blocks at once
+        P = lay.P
+        if P > 0:
+            fw = _lib.FilterWeights()
+            gin = _lib.FilterGradIn()
+            gout = _lib.FilterGradOut()
+            for l, lp in enumerate(layers):
+                fw.w1[l], fw.b1[l], fw.w2[l], fw.b2[l] = ptr(lp[0]), ptr(lp[1]), ptr(lp[2]), ptr(lp[3])
+                gin.x[l], gin.dagg[l] = ptr(sv["xs"][l]), ptr(daggs[l])
+                gl = g_layers[l]
+                gout.dw1[l], gout.db1[l], gout.dw2[l], gout.db2[l] = ptr(gl[0]), ptr(gl[1]), ptr(gl[2]), ptr(gl[3])
+            dU = torch.empty(L, P, F, dtype=torch.float32, device=dev)
+            call("geossl_cfconv_filter_bwd_hidden", ptr(sv["pair_c"]), ptr(sv["pair_flag"]), ptr(lay.pair_i),
+                 ptr(lay.pair_j), P, C.byref(fw), C.byref(gin), L, F, ptr(sv["T"]), ptr(dU), st)
+            nfl = _lib.load().geossl_cfconv_filter_bwd_workspace_floats(P, L, F, G)
+            ws2 = torch.empty(nfl, dtype=torch.float32, device=dev)
+            call("geossl_cfconv_filter_bwd_weights", ptr(sv["pair_d"]), ptr(sv["pair_c"]), ptr(sv["pair_flag"]),
+                 ptr(lay.pair_i), ptr(lay.pair_j), P, C.byref(gin), L, F, G, ptr(cfg["offset"]), cfg["coeff"],
+                 ptr(sv["T"]), ptr(dU), C.byref(gout), ptr(ws2), 0, st)
+        else:
+            for gl in g_layers:
+                for k in range(4):
+                    gl[k].zero_()
+        ctx.saved = None
+        return (None, None, None, None) + tuple(grads)
+
+
+class _SegmentReduce(torch.autograd.Function):
+    """torch_scatter.scatter(h, batch, dim=0, reduce) for a sorted batch (schnet.py:115)."""
+
+    @staticmethod
+    def forward(ctx, h, lay, reduce):
+        ctx.lay, ctx.reduce = lay, reduce
+        return ops.segment_reduce(h.contiguous(), lay, reduce)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lay = ctx.lay
+        dh = torch.empty(lay.N, dout.size(1), dtype=torch.float32, device=dout.device)
+        call("geossl_segment_reduce_bwd", ptr(dout.contiguous()), ptr(lay.mol_ptr), lay.B, dout.size(1),
+             1 if ctx.reduce == "mean" else 0, ptr(dh), 0, stream())
+        return dh, None, None
+
+
+class SchNet(torch.nn.Module):
+    def __init__(self, hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=50, cutoff=10.0,
+                 node_class=None, readout="mean", dipole=False, mean=None, std=None, atomref=None):
+        super().__init__()
+        assert readout in ["add", "sum", "mean"]
+        self.hidden_channels = hidden_channels
+        self.num_filters = num_filters
+        self.num_interactions = num_interactions
+        self.num_gaussians = num_gaussians
+        self.cutoff = cutoff
+        self.readout = readout
+        self.dipole = dipole
+        self.readout = "add" if self.dipole else self.readout
+        self.mean = mean
+        self.std = std
+        self.scale = None
+
+        self.register_buffer("atomic_mass", atomic_masses())
+        self.embedding = Embedding(node_class, hidden_channels)
+        self.distance_expansion = GaussianSmearing(0.0, cutoff, num_gaussians)
+        self.interactions = ModuleList()
+        for _ in range(num_interactions):
+            self.interactions.append(InteractionBlock(hidden_channels, num_gaussians, num_filters, cutoff))
+        self.lin1 = Linear(hidden_channels, hidden_channels)
+        self.act = ShiftedSoftplus()
+        self.lin2 = Linear(hidden_channels, hidden_channels)
+        self.register_buffer("initial_atomref", atomref)
+        self.atomref = None
+        if atomref is not None:
+            self.atomref = Embedding(100, 1)
+            self.atomref.weight.data.copy_(atomref)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.embedding.reset_parameters()
+        for interaction in self.interactions:
+            interaction.reset_parameters()
+        torch.nn.init.xavier_uniform_(self.lin1.weight)
+        self.lin1.bias.data.fill_(0)
+        torch.nn.init.xavier_uniform_(self.lin2.weight)
+        self.lin2.bias.data.fill_(0)
+        if self.atomref is not None:
+            self.atomref.weight.data.copy_(self.initial_atomref)
+
+    def _check_supported(self):
+        F = self.hidden_channels
+        if self.num_filters != F or F not in SUPPORTED_F:
+            raise NotImplementedError("HIP path supports hidden_channels == num_filters in %s (got %d/%d)"
+                                      % (SUPPORTED_F, self.hidden_channels, self.num_filters))
+        if self.num_interactions > _lib.MAX_L or self.num_gaussians > 128:
+            raise NotImplementedError("HIP path supports <= %d interactions and <= 128 gaussians" % _lib.MAX_L)
+        if self.dipole:
+            raise NotImplementedError("dipole readout (schnet.py:103-107,117-118) is off the GeoSSL path")
+
+    def forward(self, z, pos, batch=None, return_latent=False, layout=None):
+        assert z.dim() == 1 and z.dtype == torch.long
+        _lib.require_cuda(z, pos, batch)
+        self._check_supported()
+        batch = torch.zeros_like(z) if batch is None else batch
+        lay = layout if layout is not None else get_layout(batch)
+        if lay.N != pos.size(0):
+            raise ValueError("layout does not match the number of atoms")
+        cfg = dict(L=self.num_interactions, F=self.hidden_channels, G=self.num_gaussians, cutoff=float(self.cutoff),
+                   offset=self.distance_expansion.offset, coeff=float(self.distance_expansion.coeff),
+                   debug=bool(os.environ.get("GEOSSL_DEBUG")))
+        if pos.dtype != torch.float32:
+            raise TypeError("positions must be float32")
+        h = _SchNetCore.apply(z, pos.contiguous(), lay, cfg, *_core_params(self))
+        if not self.dipole and self.mean is not None and self.std is not None:
+            h = h * self.std + self.mean
+        if not self.dipole and self.atomref is not None:
+            h = h + self.atomref(z)
+        out = _SegmentReduce.apply(h, lay, self.readout)
+        if self.scale is not None:
+            out = self.scale * out
+        if return_latent:
+            return out, h
+        return out
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(hidden_channels={self.hidden_channels}, "
+                f"num_filters={self.num_filters}, num_interactions={self.num_interactions}, "
+                f"num_gaussians={self.num_gaussians}, cutoff={self.cutoff})")

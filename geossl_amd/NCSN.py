@@ -1,0 +1,150 @@
+"""NCSN_version_03 — the denoising-distance-matching head — behind the reference's interface
+(examples/NCSN.py:9-43,168-220), computed by the HIP path (geossl_ddm_loss_*).
+
+``forward(data, node_feature, distance, debug=False)`` keeps the reference signature: ``data`` must
+expose ``.batch``, ``.super_edge_index`` and ``.num_graphs`` (NCSN.py:186-190).  The two random
+draws of the reference (``torch.randint`` :190, ``torch.randn_like`` :194) are made with the same
+torch calls by default, or can be injected with ``noise_level=`` / ``distance_noise=`` (parity
+tests, reproducible multi-GPU runs).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import call, ptr, stream
+from .layout import get_super_edge_layout
+
+
+class MultiLayerPerceptron(nn.Module):
+    """Parameter holder mirroring NCSN.py:9-31 (``layers`` ModuleList, xavier weights, zero bias)."""
+
+    def __init__(self, input_dim, hidden_dims, activation="relu", dropout=0):
+        super().__init__()
+        self.dims = [input_dim] + hidden_dims
+        self.activation = getattr(F, activation) if isinstance(activation, str) else None
+        self.dropout = nn.Dropout(dropout) if dropout else None
+        self.layers = nn.ModuleList()
+        for i in range(len(self.dims) - 1):
+            self.layers.append(nn.Linear(self.dims[i], self.dims[i + 1]))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for layer in self.layers:
+            nn.init.xavier_uniform_(layer.weight)
+            nn.init.constant_(layer.bias, 0.0)
+
+    def forward(self, input):
+        raise RuntimeError("the MLPs of NCSN_version_03 are fused into geossl_ddm_loss_fwd/bwd")
+
+
+def _head_params(m):
+    i, o = m.input_distance_mlp.layers, m.output_mlp.layers
+    return [i[0].weight, i[0].bias, i[1].weight, i[1].bias, o[0].weight, o[0].bias, o[1].weight, o[1].bias,
+            o[2].weight, o[2].bias]
+
+
+_FIELDS = ("in_w1", "in_b1", "in_w2", "in_b2", "o1_w", "o1_b", "o2_w", "o2_b", "o3_w", "o3_b")
+
+
+class _NcsnLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, distance, noise_level, distance_noise, sel, sigmas, anneal_power, out_scale, *params):
+        dev = h.device
+        S, Fd = sel.S, h.size(1)
+        training = ctx.needs_input_grad[0] or any(ctx.needs_input_grad[8:])
+        ps = [p.detach().contiguous() for p in params]
+        w = _lib.NcsnWeights()
+        for name, p in zip(_FIELDS, ps):
+            setattr(w, name, ptr(p))
+        w.sigmas = ptr(sigmas)
+        h = h.detach().contiguous()
+        loss_e = torch.empty(S, dtype=torch.float32, device=dev)
+        sv = None
+        saved = {}
+        if training:
+            saved = dict(a1=torch.empty(S, Fd, dtype=torch.float32, device=dev),
+                         a2=torch.empty(S, Fd // 2, dtype=torch.float32, device=dev),
+                         pd=torch.empty(S, dtype=torch.float32, device=dev),
+                         emb=torch.empty(S, dtype=torch.float32, device=dev),
+                         gscale=torch.empty(S, dtype=torch.float32, device=dev))
+            sv = _lib.NcsnSaved(*[ptr(saved[k]) for k in ("a1", "a2", "pd", "emb", "gscale")])
+        lib = _lib.load()
+        ws = torch.empty(max(int(lib.geossl_ddm_loss_fwd_workspace_floats(Fd)), 256), dtype=torch.float32, device=dev)
+        st = stream()
+        call("geossl_ddm_loss_fwd", ptr(h), ptr(sel.batch), ptr(sel.sei0), ptr(sel.sei1), S,
+             ptr(distance.contiguous()), ptr(noise_level.contiguous()), ptr(distance_noise.contiguous()), C.byref(w),
+             Fd, float(anneal_power), ptr(loss_e), C.byref(sv) if sv is not None else None, ptr(ws), st)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        ws2 = torch.empty(256, dtype=torch.float32, device=dev)
+        call("geossl_loss_reduce", ptr(loss_e), S, ptr(sel.stats), float(out_scale), ptr(loss), ptr(ws2), 0, st)
+        if training:
+            ctx.sel, ctx.ps, ctx.w, ctx.saved, ctx.h = sel, ps, w, saved, h
+            ctx.sigmas = sigmas
+            ctx.out_scale = float(out_scale)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        sel, ps, w, saved, h = ctx.sel, ctx.ps, ctx.w, ctx.saved, ctx.h
+        dev = h.device
+        S, Fd, N = sel.S, h.size(1), h.size(0)
+        st = stream()
+        sv = _lib.NcsnSaved(*[ptr(saved[k]) for k in ("a1", "a2", "pd", "emb", "gscale")])
+        dz1 = torch.empty(S, Fd, dtype=torch.float32, device=dev)
+        dfeat = torch.empty(S, Fd, dtype=torch.float32, device=dev)
+        demb = torch.empty(S, dtype=torch.float32, device=dev)
+        grow = torch.empty(S, dtype=torch.float32, device=dev)
+        gout = gout.contiguous().to(torch.float32)
+        call("geossl_ddm_loss_bwd_rows", C.byref(w), C.byref(sv), S, Fd, ptr(sel.stats), ctx.out_scale, ptr(gout),
+             ptr(dz1), ptr(dfeat), ptr(demb), ptr(grow), st)
+        grads = [torch.empty_like(p) for p in ps]
+        g = _lib.NcsnGrads(*[ptr(t) for t in grads])
+        nfl = _lib.load().geossl_ddm_loss_bwd_workspace_floats(S, Fd)
+        ws = torch.empty(nfl, dtype=torch.float32, device=dev)
+        call("geossl_ddm_loss_bwd_weights", ptr(h), ptr(sel.sei0), ptr(sel.sei1), S, Fd, C.byref(w), C.byref(sv),
+             ptr(dz1), ptr(demb), ptr(grow), C.byref(g), ptr(ws), 0, st)
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = torch.empty(N, Fd, dtype=torch.float32, device=dev)
+            call("geossl_incidence_gather", ptr(dfeat), ptr(sel.inc_ptr), ptr(sel.inc_idx), N, Fd, ptr(dh), 0, st)
+        ctx.saved = None
+        return (dh, None, None, None, None, None, None, None) + tuple(grads)
+
+
+class NCSN_version_03(torch.nn.Module):
+    def __init__(self, emb_dim, sigma_begin, sigma_end, num_noise_level, noise_type, anneal_power):
+        super().__init__()
+        self.anneal_power = anneal_power
+        self.noise_type = noise_type
+        self.input_distance_mlp = MultiLayerPerceptron(1, [emb_dim, 1], activation="relu")
+        self.output_mlp = MultiLayerPerceptron(1 + emb_dim, [emb_dim, emb_dim // 2, 1])
+        sigmas = torch.tensor(np.exp(np.linspace(np.log(sigma_begin), np.log(sigma_end), num_noise_level)),
+                              dtype=torch.float32)
+        self.sigmas = nn.Parameter(sigmas, requires_grad=False)  # (num_noise_level)
+        self.emb_dim = emb_dim
+
+    def forward(self, data, node_feature, distance, debug=False, noise_level=None, distance_noise=None,
+                out_scale=1.0):
+        self.device = self.sigmas.device
+        _lib.require_cuda(node_feature, distance, self.sigmas)
+        if self.emb_dim not in (32, 64, 128):
+            raise NotImplementedError("HIP path supports emb_dim in (32, 64, 128)")
+        if distance.requires_grad:
+            raise NotImplementedError("gradient w.r.t. distance/positions is not built (SURVEY.md §8(f) N3)")
+        num_graphs = data.num_graphs
+        sel = get_super_edge_layout(data.batch, data.super_edge_index, num_graphs)
+        if noise_level is None:  # NCSN.py:190
+            noise_level = torch.randint(0, self.sigmas.size(0), (num_graphs,), device=self.device)
+        if distance_noise is None:  # NCSN.py:194
+            distance_noise = torch.randn_like(distance)
+        if sel.S == 0:
+            raise ValueError("batch has no super edges (scatter_add over an empty index fails in the reference too)")
+        loss = _NcsnLoss.apply(node_feature, distance.view(-1), noise_level, distance_noise.view(-1), sel,
+                               self.sigmas.detach(), self.anneal_power, out_scale, *_head_params(self))
+        if debug:
+            print("loss", float(loss))
+        return loss

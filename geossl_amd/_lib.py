@@ -1,0 +1,167 @@
+"""ctypes binding of libgeossl_hip.so (C ABI in include/geossl_hip.h).
+
+There is no CPU fallback: if the library is missing this module raises, and every op refuses
+non-CUDA tensors.  PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgeossl_hip.so")
+
+MAX_L = 12
+TN_MAX = 32
+EPI_BIAS, EPI_SSP, EPI_RESIDUAL, EPI_MUL_DSSP = 1, 2, 4, 8
+
+vp = C.c_void_p
+i64 = C.c_int64
+i32 = C.c_int
+f32 = C.c_float
+
+
+class FilterWeights(C.Structure):
+    _fields_ = [("w1", vp * MAX_L), ("b1", vp * MAX_L), ("w2", vp * MAX_L), ("b2", vp * MAX_L)]
+
+
+class FilterGradIn(C.Structure):
+    _fields_ = [("x", vp * MAX_L), ("dagg", vp * MAX_L)]
+
+
+class FilterGradOut(C.Structure):
+    _fields_ = [("dw1", vp * MAX_L), ("db1", vp * MAX_L), ("dw2", vp * MAX_L), ("db2", vp * MAX_L)]
+
+
+class TnBatch(C.Structure):
+    _fields_ = [("A", vp * TN_MAX), ("B", vp * TN_MAX), ("dW", vp * TN_MAX), ("db", vp * TN_MAX)]
+
+
+class NcsnWeights(C.Structure):
+    _fields_ = [(k, vp) for k in ("in_w1", "in_b1", "in_w2", "in_b2", "o1_w", "o1_b", "o2_w", "o2_b", "o3_w", "o3_b",
+                                  "sigmas")]
+
+
+class NcsnGrads(C.Structure):
+    _fields_ = [(k, vp) for k in ("in_w1", "in_b1", "in_w2", "in_b2", "o1_w", "o1_b", "o2_w", "o2_b", "o3_w", "o3_b")]
+
+
+class NcsnSaved(C.Structure):
+    _fields_ = [(k, vp) for k in ("a1", "a2", "pd", "emb", "gscale")]
+
+
+P = C.POINTER
+# name -> (restype, argtypes); mirrors include/geossl_hip.h one to one
+PROTOTYPES = {
+    "geossl_abi_version": (i32, []),
+    "geossl_layout_build": (i32, [vp, i64, i64, vp, vp, vp, vp]),
+    "geossl_pair_index_fill": (i32, [vp, vp, i64, vp, vp, vp]),
+    "geossl_radius_graph_count": (i32, [vp, vp, i64, i32, f32, i32, vp, vp]),
+    "geossl_radius_graph_fill": (i32, [vp, vp, i64, i32, f32, i32, vp, vp, vp, vp, vp]),
+    "geossl_pair_geometry": (i32, [vp, vp, vp, i64, i32, f32, i32, f32, vp, vp, vp, vp]),
+    "geossl_rbf_fwd": (i32, [vp, i64, vp, i32, f32, vp, vp]),
+    "geossl_cfconv_filter_fwd": (i32, [vp, vp, i64, P(FilterWeights), i32, i32, i32, vp, f32, vp, vp, vp]),
+    "geossl_cfconv_filter_bwd_hidden": (i32, [vp, vp, vp, vp, i64, P(FilterWeights), P(FilterGradIn), i32, i32, vp, vp,
+                                              vp]),
+    "geossl_cfconv_filter_bwd_workspace_floats": (i64, [i64, i32, i32, i32]),
+    "geossl_cfconv_filter_bwd_weights": (i32, [vp, vp, vp, vp, vp, i64, P(FilterGradIn), i32, i32, i32, vp, f32, vp, vp,
+                                               P(FilterGradOut), vp, i32, vp]),
+    "geossl_cfconv_aggregate": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]),
+    "geossl_linear": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "geossl_tn_plan": (None, [i64, P(i32), P(i32)]),
+    "geossl_tn_workspace_floats": (i64, [i64, i32, i32, i32]),
+    "geossl_linear_wgrad": (i32, [P(TnBatch), i32, i64, i32, i32, vp, i32, vp]),
+    "geossl_embedding_fwd": (i32, [vp, i64, vp, i32, i64, i32, vp, vp, vp]),
+    "geossl_embedding_bwd_workspace_floats": (i64, [i32, i32]),
+    "geossl_embedding_bwd": (i32, [vp, i64, vp, i32, i64, i32, vp, vp, i32, vp]),
+    "geossl_segment_reduce_fwd": (i32, [vp, vp, i64, i32, i32, vp, vp]),
+    "geossl_segment_reduce_bwd": (i32, [vp, vp, i64, i32, i32, vp, i32, vp]),
+    "geossl_axpy": (i32, [vp, vp, f32, i64, vp, vp]),
+    "geossl_pair_distance": (i32, [vp, vp, vp, i64, vp, vp]),
+    "geossl_super_edge_ptr": (i32, [vp, vp, vp, i64, i64, vp, vp, vp]),
+    "geossl_incidence_count": (i32, [vp, vp, vp, vp, i64, vp, vp]),
+    "geossl_incidence_fill": (i32, [vp, vp, vp, vp, i64, vp, vp, vp]),
+    "geossl_ddm_loss_fwd_workspace_floats": (i64, [i32]),
+    "geossl_ddm_loss_fwd": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, P(NcsnWeights), i32, f32, vp, P(NcsnSaved), vp, vp]),
+    "geossl_loss_reduce_workspace_floats": (i64, [i64]),
+    "geossl_loss_reduce": (i32, [vp, i64, vp, f32, vp, vp, i32, vp]),
+    "geossl_ddm_loss_bwd_rows": (i32, [P(NcsnWeights), P(NcsnSaved), i64, i32, vp, f32, vp, vp, vp, vp, vp, vp]),
+    "geossl_ddm_loss_bwd_workspace_floats": (i64, [i64, i32]),
+    "geossl_ddm_loss_bwd_weights": (i32, [vp, vp, vp, i64, i32, P(NcsnWeights), P(NcsnSaved), vp, vp, vp, P(NcsnGrads),
+                                          vp, i32, vp]),
+    "geossl_incidence_gather": (i32, [vp, vp, vp, i64, i32, vp, i32, vp]),
+    "geossl_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, vp]),
+}
+
+_lib = None
+
+
+class GeosslHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and bind every prototype.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GeosslHipError(
+            "libgeossl_hip.so is not built (%s). Run `python -m geossl_amd.build` (needs hipcc); "
+            "there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.geossl_abi_version() != 1:
+        raise GeosslHipError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise GeosslHipError("%s failed with hipError %d" % (what, rc))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise GeosslHipError(
+                "geossl_amd runs on MI355X only: got a %s tensor. The HIP path has no CPU fallback." % t.device.type)
+
+
+# Optional per-entry-point HIP-event timing (bench.py): {entry point name: [(start_event, end_event), ...]}.
+# Events are recorded on the stream the kernels are launched on (torch's current stream).
+TIMERS = None
+
+
+def call(name, *args):
+    lib = load()
+    timers = TIMERS
+    if timers is not None and name in timers:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        timers[name].append((e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
+    check(rc, name)
+
+
+def fill_ptrs(arr, tensors):
+    for i, t in enumerate(tensors):
+        arr[i] = ptr(t)

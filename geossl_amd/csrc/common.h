@@ -1,0 +1,101 @@
+// Shared device helpers for the GeoSSL hot-path kernels (gfx950 / CDNA4 only).
+//
+// Tile vocabulary used by every dense kernel in this directory:
+//   * a wave (64 lanes) owns a 32-row strip of the problem ("pair rows", "atom rows",
+//     "super-edge rows") and all NC*32 output columns of it;
+//   * the contraction runs on v_mfma_f32_32x32x2_f32 (exact fp32, one rounding per product,
+//     bitwise a k-ordered fmaf chain) with the operand maps of the CDNA4 ISA:
+//         A: lane l holds A[row = l&31][k = 2*kk + (l>>5)]
+//         B: lane l holds B[k = 2*kk + (l>>5)][col = l&31]
+//         C/D: acc[reg], reg in [0,16): row = (reg&3) + 8*(reg>>2) + 4*(l>>5), col = l&31
+//   * the B operand (a weight matrix) lives in LDS as Bs[k][col] (row stride BS floats) so that the
+//     32 lanes of a half-wave read 32 consecutive floats (conflict-free ds_read_b32);
+//   * the A operand lives in a wave-private LDS tile, row-major with an XOR swizzle on the low five
+//     column bits (a_idx), which makes both the C-layout write (lanes = columns) and the A-fragment
+//     read (lanes = rows) conflict-free at a power-of-two row stride.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GEOSSL_MAX_LAYERS 12
+#define GEOSSL_PI_F 3.14159265358979323846f
+
+#define GEOSSL_CHECK_LAUNCH()                  \
+  do {                                         \
+    hipError_t e__ = hipGetLastError();        \
+    if (e__ != hipSuccess) return (int)e__;    \
+  } while (0)
+
+namespace geossl {
+
+__device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// swizzled index into a wave-private [32][AS] A tile (AS multiple of 32)
+__device__ __forceinline__ int a_idx(int row, int k, int AS) { return row * AS + (k ^ (row & 31)); }
+
+// ShiftedSoftplus (schnet.py:210-216): F.softplus(x) (beta 1, threshold 20) - fp32(log 2)
+#define GEOSSL_SSP_SHIFT 0.693147182464599609375f  // float(torch.log(torch.tensor(2.0)))
+__device__ __forceinline__ float ssp(float x) {
+  float sp = (x > 20.0f) ? x : log1pf(expf(x));
+  return sp - GEOSSL_SSP_SHIFT;
+}
+// d ssp / dx = sigmoid(x), recovered from the saved output t = ssp(x):
+// exp(-softplus(x)) = 1 - sigmoid(x)  =>  sigmoid(x) = 1 - 0.5*exp(-t)   (0.5 = exp(-log 2))
+__device__ __forceinline__ float dssp_from_out(float t) { return 1.0f - 0.5f * expf(-t); }
+
+// acc[c] += A(32 x K) * B(K x 32*NC); A from a swizzled wave-private LDS tile, B from LDS/global Bs[k][col].
+template <int NC, typename BPtr>
+__device__ __forceinline__ void mma_tile(f32x16 (&acc)[NC], const float* At, int AS, BPtr Bs, int BS, int K2,
+                                         int lane) {
+  const int j = lane & 31, kh = lane >> 5;
+  const float* arow = At + j * AS;
+#pragma unroll 4
+  for (int kk = 0; kk < K2; ++kk) {
+    const int k = 2 * kk + kh;
+    const float a = arow[k ^ j];
+    const float* bp = Bs + (size_t)k * BS + j;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[32 * c], acc[c], 0, 0, 0);
+  }
+}
+
+// write a wave's C-layout accumulators into its swizzled A tile (columns 32*c0 ...)
+template <int NC>
+__device__ __forceinline__ void acc_to_tile(const f32x16 (&acc)[NC], float* At, int AS, int lane) {
+  const int col = lane & 31;
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = c_row(r, lane);
+      At[a_idx(row, 32 * c + col, AS)] = acc[c][r];
+    }
+}
+
+// Load a torch-layout weight W[nout][ldw] (first K columns) transposed into Bs[k][n] (stride BS), zero padded
+// to KP rows / NP columns.  All threads of the block participate.
+__device__ __forceinline__ void load_weight_T(const float* __restrict__ W, int nout, int K, int ldw, float* Bs,
+                                              int BS, int KP, int NP, int tid, int nthreads) {
+  for (int i = tid; i < KP * NP; i += nthreads) {
+    const int n = i / KP, k = i - n * KP;  // consecutive threads -> consecutive k (coalesced global read)
+    Bs[k * BS + n] = (n < nout && k < K) ? W[(size_t)n * ldw + k] : 0.0f;
+  }
+}
+// Load W[nrows][ldw] (first K columns) as is into Bs[n][k] (stride BS), zero padded to NRP rows / KP columns.
+__device__ __forceinline__ void load_weight_N(const float* __restrict__ W, int nrows, int K, int ldw, float* Bs,
+                                              int BS, int NRP, int KP, int tid, int nthreads) {
+  for (int i = tid; i < NRP * KP; i += nthreads) {
+    const int n = i / KP, k = i - n * KP;
+    Bs[n * BS + k] = (n < nrows && k < K) ? W[(size_t)n * ldw + k] : 0.0f;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace geossl

@@ -1,0 +1,523 @@
+// Denoising-distance-matching head on super-edge rows: NCSN_version_03.forward (examples/NCSN.py:183-220) and its
+// backward, plus the flat-buffer Adam step (examples/pretrain_GeoSSL.py:258-260,343).
+//
+// A wave owns 32 super-edge rows.  Forward: gather h[u]+h[v] into a wave-private swizzled LDS tile, the scalar
+// distance embedding is folded into the accumulator init as a rank-1 term, GEMM1 (F -> F) runs against
+// output_mlp.layers.0.weight held in LDS, the relu'd result overwrites the tile, GEMM2 (F -> F/2) takes its B
+// fragments from a k-major copy of layers.1.weight in global memory (L1/L2 resident, 32 KB), the last layer
+// (F/2 -> 1) and the loss are per-row VALU work.  All random draws are inputs.
+#include "common.h"
+#include "geossl_hip.h"
+#include "tn.h"
+
+using namespace geossl;
+
+namespace {
+
+inline int grid1d(int64_t n, int block, int cap = 2048) {
+  int64_t g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+template <typename K>
+inline void allow_big_lds(K kernel) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+}
+
+// k-major copy of layers.1.weight: W2T[k][m] = o2_w[m][k], padded to HP columns
+__global__ void k_transpose_pad(const float* __restrict__ W, int rows, int cols, int HP, float* __restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cols * HP; i += gridDim.x * blockDim.x) {
+    const int k = i / HP, m = i - k * HP;
+    out[i] = m < rows ? W[(size_t)m * cols + k] : 0.0f;
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void k_ncsn_fwd(const float* __restrict__ h, const int64_t* __restrict__ batch,
+                                                  const int64_t* __restrict__ sei0, const int64_t* __restrict__ sei1,
+                                                  int S, const float* __restrict__ distance,
+                                                  const int64_t* __restrict__ noise_level,
+                                                  const float* __restrict__ dist_noise, GeosslNcsnWeights w,
+                                                  const float* __restrict__ W2T, float anneal_power,
+                                                  float* __restrict__ loss_e, GeosslNcsnSaved sv) {
+  constexpr int F = 32 * NC, H = F / 2, NC2 = (H + 31) / 32, HP = 32 * NC2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* W1s = smem;             // [F][F]: W1s[k][n] = o1_w[n][k]
+  float* At = W1s + F * F;       // 4 x [32][F]
+  float* b1s = At + 4 * 32 * F;  // [F]
+  float* wls = b1s + F;          // [F]  last column of o1_w (multiplies the distance embedding)
+  float* b2s = wls + F;          // [HP]
+  float* w3s = b2s + HP;         // [HP]
+  float* iw1 = w3s + HP;         // [F]
+  float* ib1 = iw1 + F;          // [F]
+  float* iw2 = ib1 + F;          // [F]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
+  load_weight_T(w.o1_w, F, F, F + 1, W1s, F, F, F, tid, 256);
+  for (int i = tid; i < F; i += 256) {
+    b1s[i] = w.o1_b[i];
+    wls[i] = w.o1_w[(size_t)i * (F + 1) + F];
+    iw1[i] = w.in_w1[i];
+    ib1[i] = w.in_b1[i];
+    iw2[i] = w.in_w2[i];
+  }
+  for (int i = tid; i < HP; i += 256) {
+    b2s[i] = i < H ? w.o2_b[i] : 0.0f;
+    w3s[i] = i < H ? w.o3_w[i] : 0.0f;
+  }
+  __syncthreads();
+  const float ib2 = w.in_b2[0], b3 = w.o3_b[0];
+  float* Aw = At + wave * 32 * F;
+  const int ntiles = (S + 127) / 128;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int r0 = t * 128 + wave * 32;
+    const int row = r0 + j;
+    const bool valid = row < S;
+    const int64_t u = valid ? sei0[row] : 0, v = valid ? sei1[row] : 0;
+    float sigma = 1.0f, d = 0.0f, eps = 0.0f;
+    if (valid) {
+      sigma = w.sigmas[noise_level[batch[u]]];  // NCSN.py:187,191-192
+      d = distance[row];
+      eps = dist_noise[row];
+    }
+    const float pd = __fadd_rn(d, __fmul_rn(eps, sigma));  // :196
+    // distance embedding (:197): MLP 1 -> F -> 1 with relu; each half-wave sums half of the hidden units
+    float e = 0.0f;
+    for (int k = kh * (F / 2); k < (kh + 1) * (F / 2); ++k) e = fmaf(iw2[k], fmaxf(fmaf(iw1[k], pd, ib1[k]), 0.0f), e);
+    e += __shfl_xor(e, 32, 64);
+    const float emb = e + ib2;
+    // gather h[u] + h[v] (:201-203) into the A tile
+    for (int rr = 0; rr < 32; ++rr) {
+      const int64_t uu = __shfl(u, rr, 64), vv = __shfl(v, rr, 64);
+      for (int n = lane; n < F; n += 64) Aw[a_idx(rr, n, F)] = h[uu * F + n] + h[vv * F + n];
+    }
+    __syncthreads();
+    f32x16 acc[NC];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float er = __shfl(emb, c_row(r, lane), 64);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c][r] = fmaf(er, wls[32 * c + j], b1s[32 * c + j]);
+    }
+    mma_tile<NC>(acc, Aw, F, W1s, F, F / 2, lane);
+    __syncthreads();  // every lane of the wave is done reading the feature tile
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = c_row(r, lane);
+        const float a1 = fmaxf(acc[c][r], 0.0f);
+        Aw[a_idx(rr, 32 * c + j, F)] = a1;
+        if (sv.a1 != nullptr && r0 + rr < S) sv.a1[(size_t)(r0 + rr) * F + 32 * c + j] = a1;
+      }
+    __syncthreads();
+    f32x16 acc2[NC2];
+#pragma unroll
+    for (int c = 0; c < NC2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[c][r] = b2s[32 * c + j];
+    mma_tile<NC2>(acc2, Aw, F, W2T, HP, F / 2, lane);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = c_row(r, lane), col = 32 * c + j;
+        const float a2 = col < H ? fmaxf(acc2[c][r], 0.0f) : 0.0f;
+        Aw[a_idx(rr, col, F)] = a2;
+        if (sv.a2 != nullptr && col < H && r0 + rr < S) sv.a2[(size_t)(r0 + rr) * H + col] = a2;
+      }
+    __syncthreads();
+    // last layer (F/2 -> 1): row j, each half-wave sums half of the columns
+    float sc = 0.0f;
+    for (int k = kh * (HP / 2); k < (kh + 1) * (HP / 2); ++k) sc = fmaf(Aw[a_idx(j, k, F)], w3s[k], sc);
+    sc += __shfl_xor(sc, 32, 64);
+    const float out = sc + b3;
+    const float inv_sigma = 1.0f / sigma;
+    const float score = out * inv_sigma;                                          // :205
+    const float target = (-1.0f / (sigma * sigma)) * __fsub_rn(pd, d);            // :199
+    const float diff = score - target;
+    const float pw = powf(sigma, anneal_power);
+    if (valid && kh == 0) {
+      loss_e[row] = (0.5f * (diff * diff)) * pw;  // :209
+      if (sv.pd != nullptr) {
+        sv.pd[row] = pd;
+        sv.emb[row] = emb;
+        sv.gscale[row] = diff * pw * inv_sigma;  // d loss_e / d out
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// fixed-order two-stage sum
+__global__ __launch_bounds__(256) void k_sum_partial(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = blockIdx.x * per, hi = min(n, lo + per);
+  float s = 0.0f;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) s += x[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void k_loss_final(const float* __restrict__ partial, int nblk, const int64_t* __restrict__ divisor,
+                             float out_scale, float* __restrict__ loss, int accumulate) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = 0.0f;
+  for (int b = 0; b < nblk; ++b) s += partial[b];
+  const float v = (s / (float)divisor[0]) * out_scale;  // loss.mean() over max(edge2graph)+1 graphs, NCSN.py:210-212
+  loss[0] = accumulate ? loss[0] + v : v;
+}
+#define GEOSSL_LOSS_BLOCKS 256
+
+// ---------------------------------------------------------------------------------------------- backward
+template <int NC>
+__global__ __launch_bounds__(256) void k_ncsn_bwd_rows(GeosslNcsnWeights w, GeosslNcsnSaved sv, int S,
+                                                       const int64_t* __restrict__ divisor, float out_scale,
+                                                       const float* __restrict__ gout, float* __restrict__ dz1,
+                                                       float* __restrict__ dfeat, float* __restrict__ demb,
+                                                       float* __restrict__ grow) {
+  constexpr int F = 32 * NC, H = F / 2, NC2 = (H + 31) / 32, HP = 32 * NC2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* W1s = smem;             // [n][k] = o1_w[n][k], k < F   (contraction over n)
+  float* At = W1s + F * F;       // 4 x [32][F]
+  float* wls = At + 4 * 32 * F;  // [F]
+  float* w3s = wls + F;          // [HP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
+  load_weight_N(w.o1_w, F, F, F + 1, W1s, F, F, F, tid, 256);
+  for (int i = tid; i < F; i += 256) wls[i] = w.o1_w[(size_t)i * (F + 1) + F];
+  for (int i = tid; i < HP; i += 256) w3s[i] = i < H ? w.o3_w[i] : 0.0f;
+  __syncthreads();
+  const float scale = out_scale * (gout != nullptr ? gout[0] : 1.0f) / (float)divisor[0];
+  float* Aw = At + wave * 32 * F;
+  const int ntiles = (S + 127) / 128;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int r0 = t * 128 + wave * 32;
+    const int row = r0 + j;
+    const float gr = row < S ? sv.gscale[row] * scale : 0.0f;  // d L / d out_row
+    if (row < S && kh == 0) grow[row] = gr;
+    // da2[row][m] = gr * w3[m] * [a2 > 0]
+    for (int rr = 0; rr < 32; ++rr) {
+      const float g = __shfl(gr, rr, 64);
+      const int rw = r0 + rr;
+      for (int m = lane; m < HP; m += 64) {
+        float v = 0.0f;
+        if (rw < S && m < H && sv.a2[(size_t)rw * H + m] > 0.0f) v = g * w3s[m];
+        Aw[a_idx(rr, m, F)] = v;
+      }
+    }
+    __syncthreads();
+    f32x16 acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+    // dz1 = (da2 @ o2_w) * [a1 > 0];  B[m][k] = o2_w[m][k] read straight from global (lanes = consecutive k)
+    mma_tile<NC>(acc, Aw, F, w.o2_w, F, H / 2, lane);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = c_row(r, lane), rw = r0 + rr, col = 32 * c + j;
+        float v = 0.0f;
+        if (rw < S) {
+          v = sv.a1[(size_t)rw * F + col] > 0.0f ? acc[c][r] : 0.0f;
+          dz1[(size_t)rw * F + col] = v;
+        }
+        Aw[a_idx(rr, col, F)] = v;
+      }
+    __syncthreads();
+    // demb[row] = sum_n dz1[row][n] * o1_w[n][F]
+    float de = 0.0f;
+    for (int k = kh * (F / 2); k < (kh + 1) * (F / 2); ++k) de = fmaf(Aw[a_idx(j, k, F)], wls[k], de);
+    de += __shfl_xor(de, 32, 64);
+    if (row < S && kh == 0) demb[row] = de;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+    mma_tile<NC>(acc, Aw, F, W1s, F, F / 2, lane);  // dfeat = dz1 @ o1_w[:, :F]
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rw = r0 + c_row(r, lane);
+        if (rw < S) dfeat[(size_t)rw * F + 32 * c + j] = acc[c][r];
+      }
+    __syncthreads();
+  }
+}
+
+struct NcsnW2Loader {  // A = da2 (rebuilt from grow, w3, a2 mask) [S][H], B = a1 [S][F]
+  const float* grow;
+  const float* w3;
+  const float* a2;
+  const float* a1;
+  int F, H;
+  template <int MP, int NP>
+  __device__ __forceinline__ void load(int z, int row0, int row_end, int M, int N, float* As, float* Bs, float* es,
+                                       int tid) const {
+    for (int i = tid; i < 64 * MP; i += 256) {
+      const int r = i / MP, m = i - r * MP, row = row0 + r;
+      float v = 0.0f;
+      if (row < row_end && m < M && a2[(size_t)row * H + m] > 0.0f) v = grow[row] * w3[m];
+      As[i] = v;
+    }
+    for (int i = tid; i < 64 * NP; i += 256) {
+      const int r = i / NP, n = i - r * NP, row = row0 + r;
+      Bs[i] = (row < row_end && n < N) ? a1[(size_t)row * F + n] : 0.0f;
+    }
+  }
+};
+
+struct NcsnW1Loader {  // A = dz1 [S][F], B = h[u]+h[v] (rebuilt), e = emb
+  const float* dz1;
+  const float* h;
+  const int64_t* sei0;
+  const int64_t* sei1;
+  const float* emb;
+  int F;
+  template <int MP, int NP>
+  __device__ __forceinline__ void load(int z, int row0, int row_end, int M, int N, float* As, float* Bs, float* es,
+                                       int tid) const {
+    for (int i = tid; i < 64 * MP; i += 256) {
+      const int r = i / MP, m = i - r * MP, row = row0 + r;
+      As[i] = (row < row_end && m < M) ? dz1[(size_t)row * F + m] : 0.0f;
+    }
+    for (int i = tid; i < 64 * NP; i += 256) {
+      const int r = i / NP, n = i - r * NP, row = row0 + r;
+      float v = 0.0f;
+      if (row < row_end && n < N) v = h[sei0[row] * F + n] + h[sei1[row] * F + n];
+      Bs[i] = v;
+    }
+    if (tid < 64) es[tid] = (row0 + tid < row_end) ? emb[row0 + tid] : 0.0f;
+  }
+};
+
+// The vector-shaped gradients of the head: layers.2.weight/bias of output_mlp and the whole input_distance_mlp.
+// Block b reduces its row chunk; thread k owns hidden unit k.  partial layout per block: [o3_w H][in_w2 F][in_w1 F]
+// [in_b1 F][o3_b 1][in_b2 1].
+__global__ __launch_bounds__(128) void k_ncsn_small_partial(GeosslNcsnWeights w, GeosslNcsnSaved sv,
+                                                            const float* __restrict__ grow,
+                                                            const float* __restrict__ demb, int S, int F, int chunk,
+                                                            float* __restrict__ partial) {
+  const int H = F / 2, len = H + 3 * F + 2;
+  const int lo = blockIdx.x * chunk, hi = min(S, lo + chunk);
+  float* P = partial + (size_t)blockIdx.x * len;
+  for (int k = threadIdx.x; k < F; k += blockDim.x) {
+    const float w1 = w.in_w1[k], b1 = w.in_b1[k], w2 = w.in_w2[k];
+    float s_o3 = 0.0f, s_w2 = 0.0f, s_w1 = 0.0f, s_b1 = 0.0f;
+    for (int s = lo; s < hi; ++s) {
+      const float de = demb[s], pd = sv.pd[s];
+      const float pre = fmaf(w1, pd, b1);
+      s_w2 = fmaf(de, fmaxf(pre, 0.0f), s_w2);
+      const float dp = pre > 0.0f ? de * w2 : 0.0f;
+      s_w1 = fmaf(dp, pd, s_w1);
+      s_b1 += dp;
+      if (k < H) s_o3 = fmaf(grow[s], sv.a2[(size_t)s * H + k], s_o3);
+    }
+    if (k < H) P[k] = s_o3;
+    P[H + k] = s_w2;
+    P[H + F + k] = s_w1;
+    P[H + 2 * F + k] = s_b1;
+  }
+  if (threadIdx.x == 0) {
+    float sg = 0.0f, sd = 0.0f;
+    for (int s = lo; s < hi; ++s) {
+      sg += grow[s];
+      sd += demb[s];
+    }
+    P[H + 3 * F] = sg;
+    P[H + 3 * F + 1] = sd;
+  }
+}
+__global__ void k_ncsn_small_reduce(const float* __restrict__ partial, int nblk, int F, GeosslNcsnGrads g,
+                                    int accumulate) {
+  const int H = F / 2, len = H + 3 * F + 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+    float* dst;
+    if (i < H) dst = g.o3_w + i;
+    else if (i < H + F) dst = g.in_w2 + (i - H);
+    else if (i < H + 2 * F) dst = g.in_w1 + (i - H - F);
+    else if (i < H + 3 * F) dst = g.in_b1 + (i - H - 2 * F);
+    else if (i == H + 3 * F) dst = g.o3_b;
+    else dst = g.in_b2;
+    float s = accumulate ? *dst : 0.0f;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * len + i];
+    *dst = s;
+  }
+}
+
+// dh[a] (+)= sum over incident super-edges (fixed order) of dfeat[s]; one wave per atom
+__global__ __launch_bounds__(256) void k_incidence_gather(const float* __restrict__ dfeat,
+                                                          const int64_t* __restrict__ inc_ptr,
+                                                          const int32_t* __restrict__ inc_idx, int N, int F,
+                                                          float* __restrict__ dh, int accumulate) {
+  const int a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (a >= N) return;
+  const int64_t p0 = inc_ptr[a], p1 = inc_ptr[a + 1];
+  for (int f = lane; f < F; f += 64) {
+    float s = accumulate ? dh[(size_t)a * F + f] : 0.0f;
+    for (int64_t p = p0; p < p1; ++p) s += dfeat[(size_t)inc_idx[p] * F + f];
+    dh[(size_t)a * F + f] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- Adam
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, int64_t n, float step_size, float beta1, float beta2, float eps,
+                       float wd, float bc2_sqrt, float grad_scale) {
+  // torch.optim.Adam single-tensor path: exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad,
+  // value=1-beta2); denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps); param.addcdiv_(exp_avg, denom,
+  // value=-lr/bias_correction1)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * grad_scale;
+    const float pi = p[i];
+    if (wd != 0.0f) gi = fmaf(wd, pi, gi);
+    const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
+    const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi + (-step_size * mi) / denom;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t geossl_ddm_loss_fwd_workspace_floats(int F) {
+  const int H = F / 2, HP = (H + 31) / 32 * 32;
+  return (int64_t)F * HP;
+}
+
+extern "C" int geossl_ddm_loss_fwd(const float* h, const int64_t* batch, const int64_t* sei0, const int64_t* sei1,
+                                   int64_t S, const float* distance, const int64_t* noise_level,
+                                   const float* distance_noise, const GeosslNcsnWeights* w, int F, float anneal_power,
+                                   float* loss_e, const GeosslNcsnSaved* saved, float* workspace, hipStream_t stream) {
+  if (S <= 0) return 0;
+  if (F != 32 && F != 64 && F != 128) return (int)hipErrorInvalidValue;
+  const int H = F / 2, HP = (H + 31) / 32 * 32;
+  hipLaunchKernelGGL(k_transpose_pad, dim3(grid1d(F * HP, 256)), dim3(256), 0, stream, w->o2_w, H, F, HP, workspace);
+  GEOSSL_CHECK_LAUNCH();
+  GeosslNcsnSaved sv = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (saved != nullptr) sv = *saved;
+  const int ntiles = (int)((S + 127) / 128);
+  const size_t lds = ((size_t)F * F + 4 * 32 * F + 5 * F + 2 * HP) * sizeof(float);
+  dim3 grid(ntiles < 256 ? ntiles : 256);
+#define LAUNCH(NCV)                                                                                              \
+  do {                                                                                                           \
+    allow_big_lds(&k_ncsn_fwd<NCV>);                                                                             \
+    hipLaunchKernelGGL((k_ncsn_fwd<NCV>), grid, dim3(256), lds, stream, h, batch, sei0, sei1, (int)S, distance,  \
+                       noise_level, distance_noise, *w, workspace, anneal_power, loss_e, sv);                    \
+  } while (0)
+  if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
+#undef LAUNCH
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int64_t geossl_loss_reduce_workspace_floats(int64_t S) { return GEOSSL_LOSS_BLOCKS; }
+
+extern "C" int geossl_loss_reduce(const float* loss_e, int64_t S, const int64_t* stats_divisor, float out_scale,
+                                  float* loss, float* workspace, int accumulate, hipStream_t stream) {
+  hipLaunchKernelGGL(k_sum_partial, dim3(GEOSSL_LOSS_BLOCKS), dim3(256), 0, stream, loss_e, S, workspace);
+  GEOSSL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, stream, workspace, GEOSSL_LOSS_BLOCKS, stats_divisor, out_scale,
+                     loss, accumulate);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_ddm_loss_bwd_rows(const GeosslNcsnWeights* w, const GeosslNcsnSaved* saved, int64_t S, int F,
+                                        const int64_t* stats_divisor, float out_scale, const float* gout, float* dz1,
+                                        float* dfeat, float* demb, float* grow, hipStream_t stream) {
+  if (S <= 0) return 0;
+  if (F != 32 && F != 64 && F != 128) return (int)hipErrorInvalidValue;
+  const int H = F / 2, HP = (H + 31) / 32 * 32;
+  const int ntiles = (int)((S + 127) / 128);
+  const size_t lds = ((size_t)F * F + 4 * 32 * F + F + HP) * sizeof(float);
+  dim3 grid(ntiles < 256 ? ntiles : 256);
+#define LAUNCH(NCV)                                                                                               \
+  do {                                                                                                            \
+    allow_big_lds(&k_ncsn_bwd_rows<NCV>);                                                                         \
+    hipLaunchKernelGGL((k_ncsn_bwd_rows<NCV>), grid, dim3(256), lds, stream, *w, *saved, (int)S, stats_divisor,   \
+                       out_scale, gout, dz1, dfeat, demb, grow);                                                  \
+  } while (0)
+  if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
+#undef LAUNCH
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+static inline void small_plan(int64_t S, int* chunk, int* nblk) {
+  int64_t c = (S + 511) / 512;
+  if (c < 64) c = 64;
+  *chunk = (int)c;
+  *nblk = (int)((S + c - 1) / c);
+  if (*nblk < 1) *nblk = 1;
+}
+
+extern "C" int64_t geossl_ddm_loss_bwd_workspace_floats(int64_t S, int F) {
+  int chunk, nblk;
+  small_plan(S, &chunk, &nblk);
+  const int64_t a = tn_workspace_floats(S, F, F, 1), b = (int64_t)nblk * (F / 2 + 3 * F + 2);
+  return a > b ? a : b;
+}
+
+extern "C" int geossl_ddm_loss_bwd_weights(const float* h, const int64_t* sei0, const int64_t* sei1, int64_t S, int F,
+                                           const GeosslNcsnWeights* w, const GeosslNcsnSaved* saved, const float* dz1,
+                                           const float* demb, const float* grow, const GeosslNcsnGrads* grads,
+                                           float* workspace, int accumulate, hipStream_t stream) {
+  if (S <= 0) return 0;
+  const int H = F / 2;
+  TnOut o;
+  for (int z = 0; z < GEOSSL_TN_MAX; ++z) o.dW[z] = o.db[z] = o.dd[z] = nullptr;
+  // output_mlp.layers.1: dW[m][k] = sum_s da2[s][m] a1[s][k]
+  o.dW[0] = grads->o2_w;
+  o.db[0] = grads->o2_b;
+  NcsnW2Loader l2{grow, w->o3_w, saved->a2, saved->a1, F, H};
+  int rc = launch_tn(l2, 1, S, H, F, o, F, 1, workspace, accumulate, stream);
+  if (rc) return rc;
+  // output_mlp.layers.0: dW[n][k<F] = sum_s dz1[s][n] (h[u]+h[v])[s][k];  dW[n][F] = sum_s dz1[s][n] emb[s]
+  o.dW[0] = grads->o1_w;
+  o.db[0] = grads->o1_b;
+  o.dd[0] = grads->o1_w + F;
+  NcsnW1Loader l1{dz1, h, sei0, sei1, saved->emb, F};
+  rc = launch_tn(l1, 1, S, F, F, o, F + 1, F + 1, workspace, accumulate, stream);
+  if (rc) return rc;
+  int chunk, nblk;
+  small_plan(S, &chunk, &nblk);
+  hipLaunchKernelGGL(k_ncsn_small_partial, dim3(nblk), dim3(128), 0, stream, *w, *saved, grow, demb, (int)S, F, chunk,
+                     workspace);
+  GEOSSL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_ncsn_small_reduce, dim3(2), dim3(256), 0, stream, workspace, nblk, F, *grads, accumulate);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_incidence_gather(const float* dfeat, const int64_t* inc_ptr, const int32_t* inc_idx, int64_t N,
+                                       int F, float* dh, int accumulate, hipStream_t stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(k_incidence_gather, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, dfeat, inc_ptr, inc_idx,
+                     (int)N, F, dh, accumulate);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                float beta1, float beta2, float eps, float weight_decay, int64_t step_count,
+                                float grad_scale, hipStream_t stream) {
+  if (n <= 0) return 0;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step_count);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step_count);
+  hipLaunchKernelGGL(k_adam, dim3(grid1d(n, 256)), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, n,
+                     (float)((double)lr / bc1), beta1, beta2, eps, weight_decay, (float)sqrt(bc2), grad_scale);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,158 @@
+// Dense atom-row kernels: Linear forward / backward-input (row GEMM against a weight tile held in LDS)
+// and Linear backward-weight (column GEMM: dW = dY^T X, reduced over rows, two-stage deterministic).
+//
+// Replaces the ATen Linear call sites of the hot path: schnet.py:99,101,166,189,191 and their autograd.
+#include "common.h"
+#include "geossl_hip.h"
+#include "tn.h"
+
+using namespace geossl;
+
+// ------------------------------------------------------------------------------------------------
+// Row GEMM.  Y[r][n] = epi( sum_k X[r][k] * B[k][n] ), r < R, n < 32*NC*gridDim.y.
+//   transB = 1: W is torch-layout [NO][K]  -> B[k][n] = W[n][k]   (Linear forward)
+//   transB = 0: W is [K][NO] row-major      -> B[k][n] = W[k][n]   (Linear backward-input: dX = dY W)
+// A fragments come straight from global memory: lane (row j, half kh) loads 16 B = X[r0+j][8q+4kh .. +3]
+// and feeds them to four consecutive MFMA k-steps, B rows taken in the same (permuted) k order, so the
+// sum runs over the same products in a fixed order and no LDS staging of X is needed.  Needs K % 8 == 0.
+template <int NC>
+__global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, const float* __restrict__ W,
+                                                const float* __restrict__ bias, const float* __restrict__ res,
+                                                const float* __restrict__ tprev, float* __restrict__ Y, int R, int K,
+                                                int NO, int ldx, int ldy, int transB, int flags) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NB = 32 * NC;  // columns handled by this block
+  float* Bs = smem;            // [K][NB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.y * NB;
+  // stage the weight slice
+  if (transB) {
+    for (int i = tid; i < K * NB; i += 256) {
+      const int n = i / K, k = i - n * K;
+      Bs[k * NB + n] = (n0 + n < NO) ? W[(size_t)(n0 + n) * K + k] : 0.0f;
+    }
+  } else {
+    for (int i = tid; i < K * NB; i += 256) {
+      const int k = i / NB, n = i - k * NB;
+      Bs[k * NB + n] = (n0 + n < NO) ? W[(size_t)k * NO + n0 + n] : 0.0f;
+    }
+  }
+  __syncthreads();
+  const int j = lane & 31, kh = lane >> 5;
+  const int ntiles = (R + 127) / 128;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int r0 = t * 128 + wave * 32;
+    if (r0 >= R) continue;
+    f32x16 acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float b = (flags & GEOSSL_EPI_BIAS) && (n0 + 32 * c + j < NO) ? bias[n0 + 32 * c + j] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = b;
+    }
+    const int arow = min(r0 + j, R - 1);  // clamp: rows past R are computed and discarded
+    const float4* xp = reinterpret_cast<const float4*>(X + (size_t)arow * ldx + 4 * kh);
+#pragma unroll 2
+    for (int q = 0; q < K / 8; ++q) {
+      const float4 a4 = xp[2 * q];
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float* bp = Bs + (8 * q + 4 * kh + s) * NB + j;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bp[32 * c], acc[c], 0, 0, 0);
+      }
+    }
+    // epilogue in C layout
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = n0 + 32 * c + j;
+      if (col >= NO) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = r0 + c_row(r, lane);
+        if (row >= R) continue;
+        float v = acc[c][r];
+        if (flags & GEOSSL_EPI_SSP) v = ssp(v);
+        if (flags & GEOSSL_EPI_MUL_DSSP) v *= dssp_from_out(tprev[(size_t)row * ldy + col]);
+        if (flags & GEOSSL_EPI_RESIDUAL) v += res[(size_t)row * ldy + col];
+        Y[(size_t)row * ldy + col] = v;
+      }
+    }
+  }
+}
+
+extern "C" int geossl_linear(const float* X, const float* W, const float* bias, const float* res, const float* tprev,
+                             float* Y, int64_t R, int K, int NO, int transB, int flags, hipStream_t stream) {
+  if (R <= 0) return 0;
+  if (K % 8 != 0 || K > 256 || NO > 256) return (int)hipErrorInvalidValue;
+  const int ntiles = (int)((R + 127) / 128);
+  const int NOp = (NO + 31) / 32 * 32;
+  // split the output columns over gridDim.y when there are too few row tiles to fill 256 CUs
+  int NC = NOp / 32;
+  if (NC == 4 && ntiles < 512) NC = 2;
+  if (NC == 3) NC = 1;
+  const int ny = NOp / (32 * NC);
+  dim3 grid(ntiles < 1024 ? ntiles : 1024, ny);
+  const size_t lds = (size_t)K * 32 * NC * sizeof(float);
+  const int ldx = K, ldy = NO;
+#define LAUNCH(NCV)                                                                                               \
+  hipLaunchKernelGGL((k_linear<NCV>), grid, dim3(256), lds, stream, X, W, bias, res, tprev, Y, (int)R, K, NO, ldx, \
+                     ldy, transB, flags)
+  switch (NC) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 4: LAUNCH(4); break;
+    default: return (int)hipErrorInvalidValue;
+  }
+#undef LAUNCH
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Column GEMM (weight gradient), plain operands — template in tn.h.
+namespace geossl {
+__global__ void k_reduce_partials(GeosslReduceBatch batch, const float* __restrict__ partial, int nblk, int len,
+                                  int ncols, int ld, int cstride, int accumulate) {
+  const int z = blockIdx.y;
+  float* out = batch.out[z];
+  if (out == nullptr) return;
+  const float* p = partial + (size_t)z * nblk * len;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+    const size_t o = (size_t)(i / ncols) * ld + (size_t)(i % ncols) * cstride;
+    float s = accumulate ? out[o] : 0.0f;
+    for (int b = 0; b < nblk; ++b) s += p[(size_t)b * len + i];
+    out[o] = s;
+  }
+}
+}  // namespace geossl
+
+extern "C" void geossl_tn_plan(int64_t R, int* chunk, int* nblk) {
+  // aim for <= 384 row chunks, each a multiple of 64 rows
+  int64_t c = (R + 383) / 384;
+  c = (c + 63) / 64 * 64;
+  if (c < 64) c = 64;
+  *chunk = (int)c;
+  *nblk = (int)((R + c - 1) / c);
+  if (*nblk < 1) *nblk = 1;
+}
+
+extern "C" int64_t geossl_tn_workspace_floats(int64_t R, int M, int N, int nprob) {
+  return tn_workspace_floats(R, M, N, nprob);
+}
+
+extern "C" int geossl_linear_wgrad(const GeosslTnBatch* batch, int nprob, int64_t R, int M, int N, float* workspace,
+                                   int accumulate, hipStream_t stream) {
+  PlainLoader ld;
+  ld.batch = *batch;
+  TnOut out;
+  for (int z = 0; z < GEOSSL_TN_MAX; ++z) {
+    out.dW[z] = batch->dW[z];
+    out.db[z] = batch->db[z];
+    out.dd[z] = nullptr;
+  }
+  return launch_tn(ld, nprob, R, M, N, out, N, 1, workspace, accumulate, stream);
+}
+
+extern "C" int geossl_abi_version(void) { return GEOSSL_ABI_VERSION; }

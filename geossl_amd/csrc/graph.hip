@@ -1,0 +1,328 @@
+// Batch layout, radius graph and super-edge bookkeeping (integer / index side of the path).
+//
+// One wave per molecule: positions of the molecule are staged in LDS, every target atom scans its sources in
+// ascending order 64 at a time (ballot + popcount gives the running hit count for the neighbour cap), and
+// the adjacency is kept as an n x ceil(n/64) bit matrix in LDS.  All outputs are written in the canonical
+// order (target-major, sources ascending) without atomics, so edge lists are bit-reproducible.
+#include "common.h"
+#include "geossl_hip.h"
+
+using namespace geossl;
+
+namespace {
+
+__device__ __forceinline__ float dist2_nofma(const float* pi, const float* pj) {
+  // fl32(fl32(fl32(dx*dx)+fl32(dy*dy))+fl32(dz*dz)), d = x_j - x_i; explicit _rn ops so nothing is contracted
+  const float dx = __fsub_rn(pj[0], pi[0]), dy = __fsub_rn(pj[1], pi[1]), dz = __fsub_rn(pj[2], pi[2]);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// ---------------------------------------------------------------------------------------------- layout
+__global__ __launch_bounds__(1024) void k_layout_build(const int64_t* __restrict__ batch, int N, int B,
+                                                       int32_t* __restrict__ mol_ptr, int32_t* __restrict__ pair_ptr,
+                                                       int64_t* __restrict__ stats) {
+  __shared__ int s_scan[1024];
+  __shared__ int s_carry, s_bad, s_maxn;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_carry = 0;
+    s_bad = 0;
+    s_maxn = 0;
+  }
+  __syncthreads();
+  int bad = 0;
+  for (int a = tid; a < N; a += 1024) {
+    const int64_t g = batch[a];
+    if (g < 0 || g >= B || (a > 0 && batch[a - 1] > g)) bad = 1;
+  }
+  if (bad) atomicOr(&s_bad, 1);
+  for (int g = tid; g <= B; g += 1024) {  // mol_ptr[g] = first atom with batch >= g
+    int lo = 0, hi = N;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (batch[mid] < g) lo = mid + 1; else hi = mid;
+    }
+    mol_ptr[g] = lo;
+  }
+  __syncthreads();
+  __threadfence_block();
+  int maxn = 0;
+  for (int base = 0; base < B; base += 1024) {
+    const int g = base + tid;
+    int n = 0;
+    if (g < B) n = mol_ptr[g + 1] - mol_ptr[g];
+    maxn = max(maxn, n);
+    const int v = n * (n - 1) / 2;
+    s_scan[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // inclusive Hillis-Steele scan
+      const int add = tid >= o ? s_scan[tid - o] : 0;
+      __syncthreads();
+      s_scan[tid] += add;
+      __syncthreads();
+    }
+    const int carry = s_carry;
+    if (g < B) pair_ptr[g] = carry + s_scan[tid] - v;
+    __syncthreads();
+    if (tid == 1023) s_carry = carry + s_scan[1023];
+    __syncthreads();
+  }
+  atomicMax(&s_maxn, maxn);
+  __syncthreads();
+  if (tid == 0) {
+    pair_ptr[B] = s_carry;
+    stats[0] = s_maxn;
+    stats[1] = s_carry;
+    stats[2] = s_bad;
+    stats[3] = 0;
+  }
+}
+
+__global__ void k_pair_index_fill(const int32_t* __restrict__ mol_ptr, const int32_t* __restrict__ pair_ptr, int B,
+                                  int32_t* __restrict__ pair_i, int32_t* __restrict__ pair_j) {
+  const int m = blockIdx.x;
+  if (m >= B) return;
+  const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m];
+  for (int a = 0; a + 1 < n; ++a) {
+    const int row = base + a * n - a * (a + 1) / 2 - a - 1;  // slot(a,b) = row + b
+    for (int b = a + 1 + threadIdx.x; b < n; b += blockDim.x) {
+      pair_i[row + b] = a0 + a;
+      pair_j[row + b] = a0 + b;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------- radius graph
+// MODE 0: in-degree; MODE 1: edge list fill; MODE 2: pair-slot geometry.  One 64-lane block per molecule.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_radius(const float* __restrict__ pos, const int32_t* __restrict__ mol_ptr,
+                                               const int32_t* __restrict__ pair_ptr, int B, int max_n, float r2, int cap,
+                                               int32_t* __restrict__ deg, const int64_t* __restrict__ edge_ptr,
+                                               int64_t* __restrict__ edge_src, int64_t* __restrict__ edge_dst,
+                                               float* __restrict__ edge_weight, float* __restrict__ pair_d,
+                                               uint8_t* __restrict__ pair_flag, float cutoff,
+                                               float* __restrict__ pair_c) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int m = blockIdx.x;
+  if (m >= B) return;
+  const int lane = threadIdx.x;
+  const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0;
+  const int words = (max_n + 63) / 64;
+  unsigned long long* adj = reinterpret_cast<unsigned long long*>(smem_raw);  // [max_n][words]
+  float* sp = reinterpret_cast<float*>(adj + (size_t)max_n * words);         // [max_n][3]
+  for (int i = lane; i < 3 * n; i += 64) sp[i] = pos[(size_t)a0 * 3 + i];
+  __syncthreads();
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int i = 0; i < n; ++i) {
+    int found = 0, d_in = 0;
+    int64_t ebase = 0;
+    if (MODE == 1) ebase = edge_ptr[a0 + i];
+    for (int c = 0; c * 64 < n; ++c) {
+      const int jn = c * 64 + lane;
+      float d2 = 0.0f;
+      bool hit = false;
+      if (jn < n) {
+        d2 = dist2_nofma(sp + 3 * i, sp + 3 * jn);
+        hit = d2 < r2;
+      }
+      const unsigned long long mask = __ballot(hit);
+      const int rank = found + __popcll(mask & lt);
+      bool keep = hit && rank < cap;
+      found += __popcll(mask);
+      if (jn == i) keep = false;  // self edge dropped after the cap was applied
+      const unsigned long long kept = __ballot(keep);
+      if (MODE == 2 && lane == 0) adj[(size_t)i * words + c] = kept;
+      if (MODE == 1 && keep) {
+        const int64_t e = ebase + d_in + __popcll(kept & lt);
+        edge_src[e] = a0 + jn;
+        edge_dst[e] = a0 + i;
+        edge_weight[e] = sqrtf(d2);
+      }
+      d_in += __popcll(kept);
+    }
+    if (MODE == 0 && lane == 0) deg[a0 + i] = d_in;
+  }
+  if (MODE == 2) {
+    __syncthreads();
+    const int base = pair_ptr[m];
+    for (int a = 0; a + 1 < n; ++a) {
+      const int row = base + a * n - a * (a + 1) / 2 - a - 1;
+      for (int b = a + 1 + lane; b < n; b += 64) {
+        const float d2 = dist2_nofma(sp + 3 * a, sp + 3 * b);
+        const unsigned f0 = (adj[(size_t)a * words + (b >> 6)] >> (b & 63)) & 1ull;  // edge b -> a (target a)
+        const unsigned f1 = (adj[(size_t)b * words + (a >> 6)] >> (a & 63)) & 1ull;  // edge a -> b (target b)
+        const float d = sqrtf(d2);
+        pair_d[row + b] = d;
+        // CFConv envelope, schnet.py:186: 0.5 * (cos(d * PI / cutoff) + 1.0), fp32 op by op
+        pair_c[row + b] = 0.5f * (cosf(__fdiv_rn(__fmul_rn(d, GEOSSL_PI_F), cutoff)) + 1.0f);
+        pair_flag[row + b] = (uint8_t)(f0 | (f1 << 1));
+      }
+    }
+  }
+}
+
+inline size_t radius_lds(int max_n) {
+  const size_t words = (max_n + 63) / 64;
+  return (size_t)max_n * words * 8 + (size_t)max_n * 12;
+}
+
+// ------------------------------------------------------------------------------- super-edge bookkeeping
+__global__ void k_super_edge_ptr(const int64_t* __restrict__ batch, const int64_t* __restrict__ sei0,
+                                 const int64_t* __restrict__ sei1, int S, int B, int32_t* __restrict__ se_ptr,
+                                 int64_t* __restrict__ stats) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  if (tid == 0) stats[0] = S > 0 ? batch[sei0[S - 1]] + 1 : 0;  // max(edge2graph)+1 under the ordering assumption
+  for (int s = tid; s < S; s += nth) {
+    const int64_t g = batch[sei0[s]];
+    if (batch[sei1[s]] != g || (s > 0 && batch[sei0[s - 1]] > g)) stats[1] = 1;
+  }
+  for (int g = tid; g <= B; g += nth) {
+    int lo = 0, hi = S;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (batch[sei0[mid]] < g) lo = mid + 1; else hi = mid;
+    }
+    se_ptr[g] = lo;
+  }
+}
+
+// one wave per atom: entries ordered by super-edge id, the u-side entry before the v-side entry
+template <int FILL>
+__global__ __launch_bounds__(256) void k_incidence(const int64_t* __restrict__ batch, const int64_t* __restrict__ sei0,
+                                                   const int64_t* __restrict__ sei1, const int32_t* __restrict__ se_ptr,
+                                                   int N, int32_t* __restrict__ inc_cnt,
+                                                   const int64_t* __restrict__ inc_ptr, int32_t* __restrict__ inc_idx) {
+  const int a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (a >= N) return;
+  const int g = (int)batch[a];
+  const int s0 = se_ptr[g], s1 = se_ptr[g + 1];
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int count = 0;
+  const int64_t base = FILL ? inc_ptr[a] : 0;
+  for (int s = s0 + lane; s - lane < s1; s += 64) {
+    bool mu = false, mv = false;
+    if (s < s1) {
+      mu = sei0[s] == a;
+      mv = sei1[s] == a;
+    }
+    const unsigned long long bu = __ballot(mu), bv = __ballot(mv);
+    if (FILL) {
+      const int before = count + __popcll(bu & lt) + __popcll(bv & lt);
+      if (mu) inc_idx[base + before] = s;
+      if (mv) inc_idx[base + before + (mu ? 1 : 0)] = s;
+    }
+    count += __popcll(bu) + __popcll(bv);
+  }
+  if (!FILL && lane == 0) inc_cnt[a] = count;
+}
+
+__global__ void k_pair_distance(const float* __restrict__ pos, const int64_t* __restrict__ sei0,
+                                const int64_t* __restrict__ sei1, int S, float* __restrict__ out) {
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += gridDim.x * blockDim.x) {
+    const int64_t u = sei0[s], v = sei1[s];
+    const float dx = __fsub_rn(pos[3 * u], pos[3 * v]), dy = __fsub_rn(pos[3 * u + 1], pos[3 * v + 1]),
+                dz = __fsub_rn(pos[3 * u + 2], pos[3 * v + 2]);
+    out[s] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+  }
+}
+
+__global__ void k_axpy(const float* __restrict__ a, const float* __restrict__ b, float alpha, int64_t n,
+                       float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = a[i] + alpha * b[i];
+}
+
+inline int grid1d(int64_t n, int block, int cap = 2048) {
+  int64_t g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int geossl_layout_build(const int64_t* batch, int64_t N, int64_t B, int32_t* mol_ptr, int32_t* pair_ptr,
+                                   int64_t* stats, hipStream_t stream) {
+  hipLaunchKernelGGL(k_layout_build, dim3(1), dim3(1024), 0, stream, batch, (int)N, (int)B, mol_ptr, pair_ptr, stats);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_pair_index_fill(const int32_t* mol_ptr, const int32_t* pair_ptr, int64_t B, int32_t* pair_i,
+                                      int32_t* pair_j, hipStream_t stream) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(k_pair_index_fill, dim3((unsigned)B), dim3(64), 0, stream, mol_ptr, pair_ptr, (int)B, pair_i,
+                     pair_j);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_radius_graph_count(const float* pos, const int32_t* mol_ptr, int64_t B, int max_n, float r2,
+                                         int cap, int32_t* deg, hipStream_t stream) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL((k_radius<0>), dim3((unsigned)B), dim3(64), radius_lds(max_n), stream, pos, mol_ptr, nullptr,
+                     (int)B, max_n, r2, cap, deg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, nullptr);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_radius_graph_fill(const float* pos, const int32_t* mol_ptr, int64_t B, int max_n, float r2,
+                                        int cap, const int64_t* edge_ptr, int64_t* edge_src, int64_t* edge_dst,
+                                        float* edge_weight, hipStream_t stream) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL((k_radius<1>), dim3((unsigned)B), dim3(64), radius_lds(max_n), stream, pos, mol_ptr, nullptr,
+                     (int)B, max_n, r2, cap, nullptr, edge_ptr, edge_src, edge_dst, edge_weight, nullptr, nullptr, 1.0f,
+                     nullptr);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_pair_geometry(const float* pos, const int32_t* mol_ptr, const int32_t* pair_ptr, int64_t B,
+                                    int max_n, float r2, int cap, float cutoff, float* pair_d, float* pair_c,
+                                    uint8_t* pair_flag, hipStream_t stream) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL((k_radius<2>), dim3((unsigned)B), dim3(64), radius_lds(max_n), stream, pos, mol_ptr, pair_ptr,
+                     (int)B, max_n, r2, cap, nullptr, nullptr, nullptr, nullptr, nullptr, pair_d, pair_flag, cutoff, pair_c);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_super_edge_ptr(const int64_t* batch, const int64_t* sei0, const int64_t* sei1, int64_t S,
+                                     int64_t B, int32_t* se_ptr, int64_t* stats, hipStream_t stream) {
+  hipLaunchKernelGGL(k_super_edge_ptr, dim3(grid1d(S > B ? S : B + 1, 256)), dim3(256), 0, stream, batch, sei0, sei1,
+                     (int)S, (int)B, se_ptr, stats);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_incidence_count(const int64_t* batch, const int64_t* sei0, const int64_t* sei1,
+                                      const int32_t* se_ptr, int64_t N, int32_t* inc_cnt, hipStream_t stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL((k_incidence<0>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, batch, sei0, sei1, se_ptr,
+                     (int)N, inc_cnt, nullptr, nullptr);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_incidence_fill(const int64_t* batch, const int64_t* sei0, const int64_t* sei1,
+                                     const int32_t* se_ptr, int64_t N, const int64_t* inc_ptr, int32_t* inc_idx,
+                                     hipStream_t stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL((k_incidence<1>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, batch, sei0, sei1, se_ptr,
+                     (int)N, nullptr, inc_ptr, inc_idx);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_pair_distance(const float* pos, const int64_t* sei0, const int64_t* sei1, int64_t S, float* out,
+                                    hipStream_t stream) {
+  if (S <= 0) return 0;
+  hipLaunchKernelGGL(k_pair_distance, dim3(grid1d(S, 256)), dim3(256), 0, stream, pos, sei0, sei1, (int)S, out);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_axpy(const float* a, const float* b, float alpha, int64_t n, float* out, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_axpy, dim3(grid1d(n, 256)), dim3(256), 0, stream, a, b, alpha, n, out);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,486 @@
+// SchNet pair-row and atom-row kernels: continuous-filter network (forward, backward), neighbour
+// aggregation, embedding, readout.  Replaces, for the hot path, GaussianSmearing + InteractionBlock.mlp +
+// CFConv.message/propagate (schnet.py:141-145,185-195,205-207), Embedding (:89) and scatter readout (:115).
+#include "common.h"
+#include "geossl_hip.h"
+#include "tn.h"
+
+using namespace geossl;
+
+namespace {
+
+inline int grid1d(int64_t n, int block, int cap = 2048) {
+  int64_t g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ------------------------------------------------------------------------------------------- K2 (export)
+__global__ void k_rbf(const float* __restrict__ d, int64_t E, const float* __restrict__ offset, int G, float coeff,
+                      float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E * G; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i / G;
+    const int g = (int)(i - e * G);
+    const float diff = d[e] - offset[g];
+    out[i] = expf(coeff * (diff * diff));
+  }
+}
+
+// ------------------------------------------------------------------------------------------- K3 forward
+// grid (blocks per layer, L).  A block keeps its layer's two weight matrices in LDS and walks 128-row tiles
+// (4 waves x 32 pair rows).  GEMM1's A operand (the Gaussian smearing of the row's distance) is computed in
+// registers in MFMA A-fragment layout; the hidden activation goes through a wave-private swizzled LDS tile
+// into GEMM2; the envelope C(d) multiplies the result on the way out.
+template <int NC>
+__global__ __launch_bounds__(256) void k_filter_fwd(const float* __restrict__ pair_d, const float* __restrict__ pair_c,
+                                                    int P, GeosslFilterWeights w, int G, int GP,
+                                                    const float* __restrict__ offset, float coeff,
+                                                    float* __restrict__ Tout, float* __restrict__ Wf) {
+  constexpr int F = 32 * NC;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* W1s = smem;                 // [GP][F]
+  float* W2s = W1s + GP * F;         // [F][F]   (k-major: W2s[k][n] = w2[n][k])
+  float* At = W2s + F * F;           // 4 x [32][F] swizzled
+  float* b1s = At + 4 * 32 * F;      // [F]
+  float* b2s = b1s + F;              // [F]
+  float* offs = b2s + F;             // [GP]
+  float* cw = offs + GP;             // [4][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
+  const int l = blockIdx.y;
+  load_weight_T(w.w1[l], F, G, G, W1s, F, GP, F, tid, 256);
+  load_weight_T(w.w2[l], F, F, F, W2s, F, F, F, tid, 256);
+  for (int i = tid; i < F; i += 256) {
+    b1s[i] = w.b1[l][i];
+    b2s[i] = w.b2[l][i];
+  }
+  for (int i = tid; i < GP; i += 256) offs[i] = i < G ? offset[i] : 0.0f;
+  __syncthreads();
+  float* Aw = At + wave * 32 * F;
+  const size_t lbase = (size_t)l * P;
+  const int ntiles = (P + 127) / 128;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int r0 = t * 128 + wave * 32;
+    const int row = r0 + j;
+    const float d = row < P ? pair_d[row] : 0.0f;
+    if (kh == 0) cw[wave * 32 + j] = row < P ? pair_c[row] : 0.0f;
+    f32x16 acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float b = b1s[32 * c + j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = b;
+    }
+#pragma unroll 2
+    for (int kk = 0; kk < GP / 2; ++kk) {
+      const int k = 2 * kk + kh;
+      const float diff = d - offs[k];
+      const float a = k < G ? expf(coeff * (diff * diff)) : 0.0f;  // schnet.py:206-207
+      const float* bp = W1s + k * F + j;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[32 * c], acc[c], 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = c_row(r, lane);
+        const float tv = ssp(acc[c][r]);
+        Aw[a_idx(rr, 32 * c + j, F)] = tv;
+        if (Tout != nullptr && r0 + rr < P) Tout[(lbase + r0 + rr) * F + 32 * c + j] = tv;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float b = b2s[32 * c + j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = b;
+    }
+    mma_tile<NC>(acc, Aw, F, W2s, F, F / 2, lane);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = c_row(r, lane);
+        if (r0 + rr < P) Wf[(lbase + r0 + rr) * F + 32 * c + j] = acc[c][r] * cw[wave * 32 + rr];  // schnet.py:187
+      }
+    __syncthreads();
+  }
+}
+
+// dO[p][n] = C(d_p) * (flag0 * dagg[i][n] * x[j][n] + flag1 * dagg[j][n] * x[i][n])  for pair slot p = (i<j):
+// the gradient reaching the filter-network output, rebuilt from atom tensors (never stored per pair).
+__device__ __forceinline__ float filter_out_grad(const float* __restrict__ x, const float* __restrict__ dagg, int i,
+                                                 int j, unsigned flag, float c, int n, int F) {
+  float v = 0.0f;
+  if (flag & 1u) v += dagg[(size_t)i * F + n] * x[(size_t)j * F + n];
+  if (flag & 2u) v += dagg[(size_t)j * F + n] * x[(size_t)i * F + n];
+  return v * c;
+}
+
+// ------------------------------------------------------------------------------------ K3 backward (hidden)
+template <int NC>
+__global__ __launch_bounds__(256) void k_filter_bwd_hidden(const float* __restrict__ pair_c,
+                                                           const uint8_t* __restrict__ pair_flag,
+                                                           const int32_t* __restrict__ pair_i,
+                                                           const int32_t* __restrict__ pair_j, int P,
+                                                           GeosslFilterWeights w, GeosslFilterGradIn g,
+                                                           const float* __restrict__ T, float* __restrict__ dU) {
+  constexpr int F = 32 * NC;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* W2s = smem;         // [n][k] = w2[n][k]  (contraction over n)
+  float* At = W2s + F * F;   // 4 x [32][F]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31;
+  const int l = blockIdx.y;
+  load_weight_N(w.w2[l], F, F, F, W2s, F, F, F, tid, 256);
+  __syncthreads();
+  float* Aw = At + wave * 32 * F;
+  const float* __restrict__ x = g.x[l];
+  const float* __restrict__ dagg = g.dagg[l];
+  const size_t lbase = (size_t)l * P;
+  const int ntiles = (P + 127) / 128;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int r0 = t * 128 + wave * 32;
+    for (int rr = 0; rr < 32; ++rr) {
+      const int row = r0 + rr;
+      if (row < P) {
+        const int ai = pair_i[row], aj = pair_j[row];
+        const unsigned fl = pair_flag[row];
+        const float c = pair_c[row];
+        for (int n = lane; n < F; n += 64) Aw[a_idx(rr, n, F)] = filter_out_grad(x, dagg, ai, aj, fl, c, n, F);
+      } else {
+        for (int n = lane; n < F; n += 64) Aw[a_idx(rr, n, F)] = 0.0f;
+      }
+    }
+    __syncthreads();
+    f32x16 acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+    mma_tile<NC>(acc, Aw, F, W2s, F, F / 2, lane);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = r0 + c_row(r, lane);
+        if (row < P) {
+          const size_t o = (lbase + row) * F + 32 * c + j;
+          dU[o] = acc[c][r] * dssp_from_out(T[o]);
+        }
+      }
+    __syncthreads();
+  }
+}
+
+// ----------------------------------------------------------------------------------- K3 backward (weights)
+struct FilterW2Loader {  // A = dO (rebuilt), B = T_l
+  const float* pair_c;
+  const uint8_t* pair_flag;
+  const int32_t* pair_i;
+  const int32_t* pair_j;
+  GeosslFilterGradIn g;
+  const float* T;
+  int P, F;
+  template <int MP, int NP>
+  __device__ __forceinline__ void load(int z, int row0, int row_end, int M, int N, float* As, float* Bs, float* es,
+                                       int tid) const {
+    const float* __restrict__ x = g.x[z];
+    const float* __restrict__ dagg = g.dagg[z];
+    for (int i = tid; i < 64 * MP; i += 256) {
+      const int r = i / MP, m = i - r * MP, row = row0 + r;
+      float v = 0.0f;
+      if (row < row_end && m < M) v = filter_out_grad(x, dagg, pair_i[row], pair_j[row], pair_flag[row], pair_c[row], m, F);
+      As[i] = v;
+    }
+    const float* __restrict__ Tl = T + (size_t)z * P * F;
+    for (int i = tid; i < 64 * NP; i += 256) {
+      const int r = i / NP, n = i - r * NP, row = row0 + r;
+      Bs[i] = (row < row_end && n < N) ? Tl[(size_t)row * F + n] : 0.0f;
+    }
+  }
+};
+
+struct FilterW1Loader {  // A = dU_l, B = Gaussian smearing of d (rebuilt)
+  const float* pair_d;
+  const float* dU;
+  const float* offset;
+  float coeff;
+  int P, F, G;
+  template <int MP, int NP>
+  __device__ __forceinline__ void load(int z, int row0, int row_end, int M, int N, float* As, float* Bs, float* es,
+                                       int tid) const {
+    const float* __restrict__ Ul = dU + (size_t)z * P * F;
+    for (int i = tid; i < 64 * MP; i += 256) {
+      const int r = i / MP, m = i - r * MP, row = row0 + r;
+      As[i] = (row < row_end && m < M) ? Ul[(size_t)row * F + m] : 0.0f;
+    }
+    for (int i = tid; i < 64 * NP; i += 256) {
+      const int r = i / NP, n = i - r * NP, row = row0 + r;
+      float v = 0.0f;
+      if (row < row_end && n < N) {
+        const float diff = pair_d[row] - offset[n];
+        v = expf(coeff * (diff * diff));
+      }
+      Bs[i] = v;
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------- K4
+// One wave per molecule.  Lane f owns feature columns f, f+64, ... of every atom row of the molecule, so the
+// LDS copy of x and the accumulators are thread-private (no barriers, no atomics); each filter row is read
+// once and applied in both directions.  Separate multiply and add (no FMA) in ascending source order: the
+// same rounding sequence as a sequential index_add over the canonical edge list.
+__global__ __launch_bounds__(64) void k_aggregate(const float* __restrict__ x, const float* __restrict__ Wf,
+                                                  const uint8_t* __restrict__ pair_flag,
+                                                  const int32_t* __restrict__ mol_ptr,
+                                                  const int32_t* __restrict__ pair_ptr, int B, int F, int swap,
+                                                  float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int m = blockIdx.x;
+  if (m >= B) return;
+  const int lane = threadIdx.x;
+  const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m];
+  float* xs = smem;           // [n][F]
+  float* acc = smem + n * F;  // [n][F]
+  for (int i = 0; i < n; ++i)
+    for (int f = lane; f < F; f += 64) {
+      xs[i * F + f] = x[(size_t)(a0 + i) * F + f];
+      acc[i * F + f] = 0.0f;
+    }
+  for (int a = 0; a + 1 < n; ++a) {
+    const int rowb = base + a * n - a * (a + 1) / 2 - a - 1;
+    for (int b = a + 1; b < n; ++b) {
+      unsigned fl = pair_flag[rowb + b];
+      if (swap) fl = ((fl & 1u) << 1) | ((fl >> 1) & 1u);
+      if (fl == 0) continue;
+      const float* __restrict__ wr = Wf + (size_t)(rowb + b) * F;
+      for (int f = lane; f < F; f += 64) {
+        const float wv = wr[f];
+        if (fl & 1u) acc[a * F + f] = __fadd_rn(acc[a * F + f], __fmul_rn(xs[b * F + f], wv));  // edge b -> a
+        if (fl & 2u) acc[b * F + f] = __fadd_rn(acc[b * F + f], __fmul_rn(xs[a * F + f], wv));  // edge a -> b
+      }
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int f = lane; f < F; f += 64) out[(size_t)(a0 + i) * F + f] = acc[i * F + f];
+}
+
+// --------------------------------------------------------------------------------------------- embedding
+__global__ void k_embedding_fwd(const int64_t* __restrict__ z, int64_t zs, const float* __restrict__ table, int C,
+                                int64_t N, int F, float* __restrict__ out, int32_t* __restrict__ status) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N * F; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = i / F;
+    const int f = (int)(i - a * F);
+    const int64_t c = z[a * zs];
+    if (c < 0 || c >= C) {
+      if (status != nullptr) *status = 1;
+      out[i] = 0.0f;
+    } else {
+      out[i] = table[c * F + f];
+    }
+  }
+}
+
+#define GEOSSL_EMB_CHUNKS 64
+// block (chunk, class): sums the rows of its chunk whose type is `class`, in row order
+__global__ void k_embedding_bwd_partial(const int64_t* __restrict__ z, int64_t zs, const float* __restrict__ dh,
+                                        int64_t N, int F, float* __restrict__ partial) {
+  const int chunk = blockIdx.x, c = blockIdx.y, C = gridDim.y;
+  const int64_t per = (N + GEOSSL_EMB_CHUNKS - 1) / GEOSSL_EMB_CHUNKS;
+  const int64_t lo = chunk * per, hi = min((int64_t)N, lo + per);
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float s = 0.0f;
+    for (int64_t a = lo; a < hi; ++a)
+      if (z[a * zs] == c) s += dh[a * F + f];
+    partial[((size_t)chunk * C + c) * F + f] = s;
+  }
+}
+__global__ void k_embedding_bwd_reduce(const float* __restrict__ partial, int len, float* __restrict__ dtable,
+                                       int accumulate) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+    float s = accumulate ? dtable[i] : 0.0f;
+    for (int b = 0; b < GEOSSL_EMB_CHUNKS; ++b) s += partial[(size_t)b * len + i];
+    dtable[i] = s;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- readout
+__global__ void k_segment_reduce_fwd(const float* __restrict__ h, const int32_t* __restrict__ mol_ptr, int B, int F,
+                                     int mean, float* __restrict__ out) {
+  const int m = blockIdx.x;
+  if (m >= B) return;
+  const int a0 = mol_ptr[m], a1 = mol_ptr[m + 1];
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float s = 0.0f;
+    for (int a = a0; a < a1; ++a) s += h[(size_t)a * F + f];
+    if (mean) s = s / fmaxf((float)(a1 - a0), 1.0f);
+    out[(size_t)m * F + f] = s;
+  }
+}
+__global__ void k_segment_reduce_bwd(const float* __restrict__ dout, const int32_t* __restrict__ mol_ptr, int B, int F,
+                                     int mean, float* __restrict__ dh, int accumulate) {
+  const int m = blockIdx.x;
+  if (m >= B) return;
+  const int a0 = mol_ptr[m], a1 = mol_ptr[m + 1];
+  const float cnt = fmaxf((float)(a1 - a0), 1.0f);
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float gv = dout[(size_t)m * F + f];
+    if (mean) gv = gv / cnt;
+    for (int a = a0; a < a1; ++a) {
+      const size_t o = (size_t)a * F + f;
+      dh[o] = accumulate ? dh[o] + gv : gv;
+    }
+  }
+}
+
+template <typename K>
+inline void allow_big_lds(K kernel) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+}
+
+inline int blocks_per_layer(int L, int ntiles) {
+  int b = 256 / (L > 0 ? L : 1);
+  if (b < 1) b = 1;
+  if (b > ntiles) b = ntiles;
+  return b;
+}
+
+}  // namespace
+
+extern "C" int geossl_rbf_fwd(const float* d, int64_t E, const float* offset, int G, float coeff, float* out,
+                              hipStream_t stream) {
+  if (E <= 0) return 0;
+  hipLaunchKernelGGL(k_rbf, dim3(grid1d(E * G, 256)), dim3(256), 0, stream, d, E, offset, G, coeff, out);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_cfconv_filter_fwd(const float* pair_d, const float* pair_c, int64_t P,
+                                        const GeosslFilterWeights* w, int L, int F, int G, const float* offset,
+                                        float coeff, float* T, float* Wf, hipStream_t stream) {
+  if (P <= 0 || L <= 0) return 0;
+  if (L > GEOSSL_MAX_L || (F != 32 && F != 64 && F != 128) || G > 128) return (int)hipErrorInvalidValue;
+  const int GP = (G + 1) / 2 * 2;
+  const int ntiles = (int)((P + 127) / 128);
+  dim3 grid(blocks_per_layer(L, ntiles), L);
+  const size_t lds = ((size_t)GP * F + (size_t)F * F + 4 * 32 * F + 2 * F + GP + 128) * sizeof(float);
+#define LAUNCH(NCV)                                                                                          \
+  do {                                                                                                       \
+    allow_big_lds(&k_filter_fwd<NCV>);                                                                       \
+    hipLaunchKernelGGL((k_filter_fwd<NCV>), grid, dim3(256), lds, stream, pair_d, pair_c, (int)P, *w, G, GP, \
+                       offset, coeff, T, Wf);                                                                \
+  } while (0)
+  if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
+#undef LAUNCH
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_cfconv_filter_bwd_hidden(const float* pair_c, const uint8_t* pair_flag, const int32_t* pair_i,
+                                               const int32_t* pair_j, int64_t P, const GeosslFilterWeights* w,
+                                               const GeosslFilterGradIn* g, int L, int F, const float* T, float* dU,
+                                               hipStream_t stream) {
+  if (P <= 0 || L <= 0) return 0;
+  if (L > GEOSSL_MAX_L || (F != 32 && F != 64 && F != 128)) return (int)hipErrorInvalidValue;
+  const int ntiles = (int)((P + 127) / 128);
+  dim3 grid(blocks_per_layer(L, ntiles), L);
+  const size_t lds = ((size_t)F * F + 4 * 32 * F) * sizeof(float);
+#define LAUNCH(NCV)                                                                                                \
+  do {                                                                                                             \
+    allow_big_lds(&k_filter_bwd_hidden<NCV>);                                                                      \
+    hipLaunchKernelGGL((k_filter_bwd_hidden<NCV>), grid, dim3(256), lds, stream, pair_c, pair_flag, pair_i, pair_j, \
+                       (int)P, *w, *g, T, dU);                                                                     \
+  } while (0)
+  if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
+#undef LAUNCH
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int64_t geossl_cfconv_filter_bwd_workspace_floats(int64_t P, int L, int F, int G) {
+  const int64_t a = tn_workspace_floats(P, F, F, L), b = tn_workspace_floats(P, F, G, L);
+  return a > b ? a : b;
+}
+
+extern "C" int geossl_cfconv_filter_bwd_weights(const float* pair_d, const float* pair_c, const uint8_t* pair_flag,
+                                                const int32_t* pair_i, const int32_t* pair_j, int64_t P,
+                                                const GeosslFilterGradIn* g, int L, int F, int G, const float* offset,
+                                                float coeff, const float* T, const float* dU,
+                                                const GeosslFilterGradOut* out, float* workspace, int accumulate,
+                                                hipStream_t stream) {
+  if (P <= 0 || L <= 0) return 0;
+  if (L > GEOSSL_MAX_L) return (int)hipErrorInvalidValue;
+  TnOut o;
+  for (int z = 0; z < GEOSSL_TN_MAX; ++z) {
+    o.dW[z] = z < L ? out->dw2[z] : nullptr;
+    o.db[z] = z < L ? out->db2[z] : nullptr;
+    o.dd[z] = nullptr;
+  }
+  FilterW2Loader l2{pair_c, pair_flag, pair_i, pair_j, *g, T, (int)P, F};
+  int rc = launch_tn(l2, L, P, F, F, o, F, 1, workspace, accumulate, stream);
+  if (rc) return rc;
+  for (int z = 0; z < L; ++z) {
+    o.dW[z] = out->dw1[z];
+    o.db[z] = out->db1[z];
+  }
+  FilterW1Loader l1{pair_d, dU, offset, coeff, (int)P, F, G};
+  return launch_tn(l1, L, P, F, G, o, G, 1, workspace, accumulate, stream);
+}
+
+extern "C" int geossl_cfconv_aggregate(const float* x, const float* Wf, const uint8_t* pair_flag,
+                                       const int32_t* mol_ptr, const int32_t* pair_ptr, int64_t B, int max_n, int F,
+                                       int swap, float* out, hipStream_t stream) {
+  if (B <= 0) return 0;
+  const size_t lds = (size_t)2 * max_n * F * sizeof(float);
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  allow_big_lds(&k_aggregate);
+  hipLaunchKernelGGL(k_aggregate, dim3((unsigned)B), dim3(64), lds, stream, x, Wf, pair_flag, mol_ptr, pair_ptr, (int)B,
+                     F, swap, out);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_embedding_fwd(const int64_t* z, int64_t z_stride, const float* table, int num_classes, int64_t N,
+                                    int F, float* out, int32_t* status, hipStream_t stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(k_embedding_fwd, dim3(grid1d(N * F, 256)), dim3(256), 0, stream, z, z_stride, table, num_classes, N,
+                     F, out, status);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int64_t geossl_embedding_bwd_workspace_floats(int num_classes, int F) {
+  return (int64_t)GEOSSL_EMB_CHUNKS * num_classes * F;
+}
+
+extern "C" int geossl_embedding_bwd(const int64_t* z, int64_t z_stride, const float* dh, int num_classes, int64_t N,
+                                    int F, float* dtable, float* workspace, int accumulate, hipStream_t stream) {
+  if (num_classes <= 0) return 0;
+  hipLaunchKernelGGL(k_embedding_bwd_partial, dim3(GEOSSL_EMB_CHUNKS, num_classes), dim3(F < 256 ? F : 256), 0, stream,
+                     z, z_stride, dh, N, F, workspace);
+  GEOSSL_CHECK_LAUNCH();
+  const int len = num_classes * F;
+  hipLaunchKernelGGL(k_embedding_bwd_reduce, dim3(grid1d(len, 256)), dim3(256), 0, stream, workspace, len, dtable,
+                     accumulate);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_segment_reduce_fwd(const float* h, const int32_t* mol_ptr, int64_t B, int F, int mean, float* out,
+                                         hipStream_t stream) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(k_segment_reduce_fwd, dim3((unsigned)B), dim3(F < 256 ? ((F + 63) / 64 * 64) : 256), 0, stream, h,
+                     mol_ptr, (int)B, F, mean, out);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_segment_reduce_bwd(const float* dout, const int32_t* mol_ptr, int64_t B, int F, int mean,
+                                         float* dh, int accumulate, hipStream_t stream) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(k_segment_reduce_bwd, dim3((unsigned)B), dim3(F < 256 ? ((F + 63) / 64 * 64) : 256), 0, stream,
+                     dout, mol_ptr, (int)B, F, mean, dh, accumulate);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,104 @@
+"""Position-independent index structures of a collated batch, built on the GPU once per batch.
+
+Host-side mirror of what the reference gets from ``BatchAtomTuple.from_data_list``
+(Geom3D/dataloaders/dataloaders_AtomTuple.py:46-78): ``batch`` is sorted, index tensors carry
+node offsets, ``num_graphs = batch[-1] + 1``.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+
+class MolLayout:
+    """mol_ptr / pair-slot enumeration of a sorted ``batch`` vector.
+
+    pair slots: per molecule the n(n-1)/2 pairs (i<j) in lexicographic order — the enumeration of
+    AtomTupleExtractor 'combination' (dataloaders_AtomTuple.py:22-23); slot p joins atoms
+    pair_i[p] < pair_j[p].
+    """
+
+    def __init__(self, batch, num_graphs=None):
+        _lib.require_cuda(batch)
+        if batch.dtype != torch.long or batch.dim() != 1:
+            raise ValueError("batch must be a 1-D int64 tensor")
+        batch = batch.contiguous()
+        self.N = int(batch.numel())
+        dev = batch.device
+        if self.N == 0:
+            self.B = int(num_graphs or 0)
+        else:
+            self.B = int(num_graphs) if num_graphs is not None else int(batch[-1].item()) + 1  # :75-78
+        B = self.B
+        self.mol_ptr = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+        self.pair_ptr = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+        stats = torch.zeros(4, dtype=torch.int64, device=dev)
+        if B > 0:
+            call("geossl_layout_build", ptr(batch), self.N, B, ptr(self.mol_ptr), ptr(self.pair_ptr), ptr(stats),
+                 stream())
+        max_n, P, bad, _ = stats.tolist()
+        if bad:
+            raise ValueError("batch vector must be sorted ascending with ids in [0, num_graphs) "
+                             "(collated batches are; dataloaders_AtomTuple.py:61,72)")
+        self.max_n, self.P = int(max_n), int(P)
+        self.pair_i = torch.empty(self.P, dtype=torch.int32, device=dev)
+        self.pair_j = torch.empty(self.P, dtype=torch.int32, device=dev)
+        if self.P > 0:
+            call("geossl_pair_index_fill", ptr(self.mol_ptr), ptr(self.pair_ptr), B, ptr(self.pair_i),
+                 ptr(self.pair_j), stream())
+        self.device = dev
+        self._batch_version = batch._version
+
+
+def get_layout(batch):
+    """Layout cached on the batch tensor object itself (the same object is passed for both views
+    and both heads of a DDM step)."""
+    lay = getattr(batch, "_geossl_layout", None)
+    if lay is None or lay._batch_version != batch._version or lay.N != batch.numel():
+        lay = MolLayout(batch)
+        batch._geossl_layout = lay
+    return lay
+
+
+class SuperEdgeLayout:
+    """Per-batch bookkeeping of ``super_edge_index`` for the DDM head: first super-edge of every
+    molecule, the divisor ``max(edge2graph)+1`` of NCSN.py:210-212 (kept on the device), and the
+    atom -> incident super-edge lists used to reduce d loss / d node_feature without atomics."""
+
+    def __init__(self, batch, super_edge_index, num_graphs, validate=True):
+        _lib.require_cuda(batch, super_edge_index)
+        sei = super_edge_index
+        if sei.dtype != torch.long or sei.dim() != 2 or sei.size(0) != 2:
+            raise ValueError("super_edge_index must be int64 [2, S]")
+        self.sei0 = sei[0].contiguous()
+        self.sei1 = sei[1].contiguous()
+        self.batch = batch.contiguous()
+        self.S = int(sei.size(1))
+        self.N = int(batch.numel())
+        self.B = int(num_graphs)
+        dev = batch.device
+        self.se_ptr = torch.zeros(self.B + 1, dtype=torch.int32, device=dev)
+        self.stats = torch.zeros(2, dtype=torch.int64, device=dev)
+        call("geossl_super_edge_ptr", ptr(self.batch), ptr(self.sei0), ptr(self.sei1), self.S, self.B,
+             ptr(self.se_ptr), ptr(self.stats), stream())
+        inc_cnt = torch.zeros(self.N, dtype=torch.int32, device=dev)
+        call("geossl_incidence_count", ptr(self.batch), ptr(self.sei0), ptr(self.sei1), ptr(self.se_ptr), self.N,
+             ptr(inc_cnt), stream())
+        self.inc_ptr = torch.zeros(self.N + 1, dtype=torch.int64, device=dev)
+        self.inc_ptr[1:] = torch.cumsum(inc_cnt, 0, dtype=torch.int64)
+        self.inc_idx = torch.empty(2 * self.S, dtype=torch.int32, device=dev)
+        call("geossl_incidence_fill", ptr(self.batch), ptr(self.sei0), ptr(self.sei1), ptr(self.se_ptr), self.N,
+             ptr(self.inc_ptr), ptr(self.inc_idx), stream())
+        if validate and int(self.stats[1].item()):
+            raise ValueError("super_edge_index must be grouped by molecule in batch order with both ends in "
+                             "the same molecule (collated AtomTupleExtractor output is)")
+        self._versions = (batch._version, sei._version)
+
+
+def get_super_edge_layout(batch, super_edge_index, num_graphs):
+    lay = getattr(super_edge_index, "_geossl_layout", None)
+    if (lay is None or lay._versions != (batch._version, super_edge_index._version)
+            or lay.S != super_edge_index.size(1) or lay.N != batch.numel()):
+        lay = SuperEdgeLayout(batch, super_edge_index, num_graphs)
+        super_edge_index._geossl_layout = lay
+    return lay

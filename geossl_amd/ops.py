@@ -1,0 +1,135 @@
+"""Thin functional wrappers over the C ABI (one call = one or a few kernel launches on the current
+stream).  Every function takes/returns CUDA tensors; nothing here computes on the host."""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+from .layout import MolLayout, get_layout
+
+PI_F32 = float(torch.tensor(math.pi, dtype=torch.float32))
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise TypeError("expected float32, got %s" % t.dtype)
+    return t.contiguous()
+
+
+def radius_cap(max_num_neighbors, loop=False):
+    # torch_cluster.radius_graph searches max_num_neighbors (+1 when loop=False: the self hit) candidates
+    return max_num_neighbors if loop else max_num_neighbors + 1
+
+
+def radius_graph(pos, r, batch=None, loop=False, max_num_neighbors=32, layout=None, return_weight=False):
+    """torch_geometric.nn.radius_graph(pos, r, batch) as called at schnet.py:91 and
+    datasets_3D_Radius.py:120 -> int64 [2, E] = [source j; target i], target-major, sources ascending."""
+    _lib.require_cuda(pos)
+    if loop:
+        raise NotImplementedError("loop=True is not on the GeoSSL path")
+    pos = _f32(pos)
+    N = pos.size(0)
+    if batch is None:
+        batch = torch.zeros(N, dtype=torch.long, device=pos.device)
+    lay = layout or get_layout(batch)
+    r2 = float(torch.tensor(float(r) * float(r), dtype=torch.float32))
+    cap = radius_cap(max_num_neighbors)
+    deg = torch.zeros(N, dtype=torch.int32, device=pos.device)
+    call("geossl_radius_graph_count", ptr(pos), ptr(lay.mol_ptr), lay.B, lay.max_n, r2, cap, ptr(deg), stream())
+    edge_ptr = torch.zeros(N + 1, dtype=torch.int64, device=pos.device)
+    edge_ptr[1:] = torch.cumsum(deg, 0, dtype=torch.int64)
+    E = int(edge_ptr[-1].item())
+    edge_index = torch.empty(2, E, dtype=torch.int64, device=pos.device)
+    weight = torch.empty(E, dtype=torch.float32, device=pos.device)
+    if E > 0:
+        call("geossl_radius_graph_fill", ptr(pos), ptr(lay.mol_ptr), lay.B, lay.max_n, r2, cap, ptr(edge_ptr),
+             ptr(edge_index[0]), ptr(edge_index[1]), ptr(weight), stream())
+    return (edge_index, weight) if return_weight else edge_index
+
+
+def pair_geometry(pos, layout, cutoff, max_num_neighbors=32):
+    """Radius graph in pair-slot form: (pair_d [P], pair_c [P], pair_flag [P] u8)."""
+    pos = _f32(pos)
+    dev = pos.device
+    P = layout.P
+    pair_d = torch.empty(P, dtype=torch.float32, device=dev)
+    pair_c = torch.empty(P, dtype=torch.float32, device=dev)
+    pair_flag = torch.empty(P, dtype=torch.uint8, device=dev)
+    r2 = float(torch.tensor(float(cutoff) * float(cutoff), dtype=torch.float32))
+    if P > 0:
+        call("geossl_pair_geometry", ptr(pos), ptr(layout.mol_ptr), ptr(layout.pair_ptr), layout.B, layout.max_n, r2,
+             radius_cap(max_num_neighbors), float(cutoff), ptr(pair_d), ptr(pair_c), ptr(pair_flag), stream())
+    return pair_d, pair_c, pair_flag
+
+
+def gaussian_smearing(dist, offset, coeff):
+    """GaussianSmearing.forward, schnet.py:205-207."""
+    _lib.require_cuda(dist)
+    d = _f32(dist).view(-1)
+    out = torch.empty(d.numel(), offset.numel(), dtype=torch.float32, device=d.device)
+    call("geossl_rbf_fwd", ptr(d), d.numel(), ptr(offset), offset.numel(), float(coeff), ptr(out), stream())
+    return out
+
+
+def linear(x, w, bias=None, res=None, tprev=None, transB=True, flags=0, out=None):
+    """Y = epi(X @ Bm); transB: w is torch layout [NO][K] (forward) else [K][NO] (dX = dY @ W)."""
+    R, K = x.shape
+    NO = w.size(0) if transB else w.size(1)
+    if out is None:
+        out = torch.empty(R, NO, dtype=torch.float32, device=x.device)
+    if bias is not None:
+        flags |= _lib.EPI_BIAS
+    if res is not None:
+        flags |= _lib.EPI_RESIDUAL
+    if tprev is not None:
+        flags |= _lib.EPI_MUL_DSSP
+    call("geossl_linear", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(tprev), ptr(out), R, K, NO, 1 if transB else 0,
+         flags, stream())
+    return out
+
+
+def linear_wgrad(problems, R, M, N, accumulate=False):
+    """Batched weight gradients.  problems: list of (A [R,M], B [R,N], dW [M,N], db [M] or None)."""
+    dev = problems[0][0].device
+    for lo in range(0, len(problems), _lib.TN_MAX):
+        chunk = problems[lo:lo + _lib.TN_MAX]
+        tb = _lib.TnBatch()
+        for i, (A, Bm, dW, db) in enumerate(chunk):
+            tb.A[i], tb.B[i], tb.dW[i], tb.db[i] = ptr(A), ptr(Bm), ptr(dW), ptr(db)
+        nfl = _lib.load().geossl_tn_workspace_floats(R, M, N, len(chunk))
+        ws = torch.empty(nfl, dtype=torch.float32, device=dev)
+        call("geossl_linear_wgrad", C.byref(tb), len(chunk), R, M, N, ptr(ws), 1 if accumulate else 0, stream())
+
+
+def aggregate(x, Wf_l, pair_flag, layout, swap=False):
+    N, F = x.shape
+    out = torch.empty_like(x)
+    call("geossl_cfconv_aggregate", ptr(x), ptr(Wf_l), ptr(pair_flag), ptr(layout.mol_ptr), ptr(layout.pair_ptr),
+         layout.B, layout.max_n, F, 1 if swap else 0, ptr(out), stream())
+    return out
+
+
+def segment_reduce(h, layout, reduce):
+    """torch_scatter.scatter(h, batch, dim=0, reduce) for a sorted batch (schnet.py:115)."""
+    out = torch.empty(layout.B, h.size(1), dtype=torch.float32, device=h.device)
+    call("geossl_segment_reduce_fwd", ptr(h), ptr(layout.mol_ptr), layout.B, h.size(1), 1 if reduce == "mean" else 0,
+         ptr(out), stream())
+    return out
+
+
+def pair_distance(pos, sei0, sei1):
+    """pretrain_GeoSSL.py:199-205 -> [S, 1]."""
+    pos = _f32(pos)
+    S = sei0.numel()
+    out = torch.empty(S, 1, dtype=torch.float32, device=pos.device)
+    call("geossl_pair_distance", ptr(pos), ptr(sei0), ptr(sei1), S, ptr(out), stream())
+    return out
+
+
+def add_scaled(a, b, alpha=1.0):
+    a, b = _f32(a), _f32(b)
+    out = torch.empty_like(a)
+    call("geossl_axpy", ptr(a), ptr(b), float(alpha), a.numel(), ptr(out), stream())
+    return out

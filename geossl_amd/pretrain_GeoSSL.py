@@ -1,0 +1,159 @@
+"""Step API of ``pretrain_GeoSSL.py --GeoSSL_option=DDM`` (examples/pretrain_GeoSSL.py:68-74,179-212,
+234-260) on the HIP path.
+
+``perturb`` and ``do_DDM`` keep the reference signatures.  The reference reads two module globals
+(``NCSN_model_01/02``, :207-208); here they are module attributes with the same names, or can be
+passed with ``NCSN_models=``.  ``DDMTrainer`` is the training-loop body (:234-260) with all
+parameters in one flat buffer: one fused Adam launch and one RCCL all-reduce per step.
+"""
+import torch
+
+from . import _lib, ops
+from ._lib import call, ptr, stream
+from .layout import MolLayout
+
+NCSN_model_01 = None
+NCSN_model_02 = None
+
+
+def perturb(x, positions, mu, sigma, noise=None, device_noise=False, generator=None):
+    """pretrain_GeoSSL.py:68-74.  Default: the N(mu, sigma) draw is made on the CPU and copied to
+    the device exactly like the reference (:72), so the same seed gives the same noise.
+    ``device_noise=True`` draws on the GPU instead (no host RNG / PCIe copy); ``noise=`` injects it."""
+    x_perturb = x
+    device = positions.device
+    if noise is None:
+        if device_noise:
+            noise = torch.empty_like(positions).normal_(mu, sigma, generator=generator)
+        else:
+            noise = torch.normal(mu, sigma, size=positions.size()).to(device)
+    positions_perturb = ops.add_scaled(positions, noise, 1.0)
+    return x_perturb, positions_perturb
+
+
+def _two_view_batch(batch_vec, num_graphs):
+    """batch ids of the concatenated (clean ‖ perturbed) 2B-molecule batch + its layout, cached on
+    the batch tensor object."""
+    cached = getattr(batch_vec, "_geossl_two_view", None)
+    if cached is None or cached[2] != batch_vec._version:
+        b2 = torch.cat([batch_vec, batch_vec + num_graphs])
+        cached = (b2, MolLayout(b2, 2 * num_graphs), batch_vec._version)
+        batch_vec._geossl_two_view = cached
+    return cached[0], cached[1]
+
+
+def do_DDM(args, batch, model, criterion=None, mu=0.0, sigma=0.3, num_neg=1, NCSN_models=None, noise=None,
+           fuse_views=True, device_noise=False):
+    """pretrain_GeoSSL.py:179-212 -> (loss, 0).
+
+    noise: optional dict with pos_noise [N,3], noise_level_1/2 [B] int64, dist_noise_1/2 [S,1] —
+    the five random draws of the step; anything missing is drawn like the reference does.
+    fuse_views: run the clean and the perturbed view through the backbone as one 2B-molecule batch
+    (molecules never interact, so every row sees the same arithmetic as in two separate calls).
+    """
+    noise = noise or {}
+    n1, n2 = NCSN_models if NCSN_models is not None else (NCSN_model_01, NCSN_model_02)
+    if n1 is None or n2 is None:
+        raise RuntimeError("set geossl_amd.pretrain_GeoSSL.NCSN_model_01/02 or pass NCSN_models=(m1, m2)")
+    positions = batch.positions
+    x_01 = batch.x[:, 0]
+    positions_01 = positions
+    x_02, positions_02 = perturb(x_01, positions, mu, sigma, noise=noise.get("pos_noise"), device_noise=device_noise)
+
+    if args.model_3d == "schnet":
+        if fuse_views:
+            num_graphs = batch.num_graphs
+            b2, lay2 = _two_view_batch(batch.batch, num_graphs)
+            N = positions.size(0)
+            _, h = model(torch.cat([x_01, x_02]), torch.cat([positions_01, positions_02]), b2, return_latent=True,
+                         layout=lay2)
+            molecule_3D_repr_01, molecule_3D_repr_02 = h[:N], h[N:]
+        else:
+            _, molecule_3D_repr_01 = model(x_01, positions_01, batch.batch, return_latent=True)
+            _, molecule_3D_repr_02 = model(x_02, positions_02, batch.batch, return_latent=True)
+    elif args.model_3d == "painn":
+        _, molecule_3D_repr_01 = model(x_01, positions_01, batch.radius_edge_index, batch.batch, return_latent=True)
+        _, molecule_3D_repr_02 = model(x_02, positions_02, batch.radius_edge_index, batch.batch, return_latent=True)
+    else:
+        raise Exception("3D model {} not included.".format(args.model_3d))
+
+    if getattr(args, "normalize", False):
+        raise NotImplementedError("--normalize (pretrain_GeoSSL.py:193-195) is unset in the DDM scripts and not built")
+
+    super_edge_index = batch.super_edge_index
+    distance_01 = ops.pair_distance(positions_01, super_edge_index[0], super_edge_index[1])  # :199-201
+    distance_02 = ops.pair_distance(positions_02, super_edge_index[0], super_edge_index[1])  # :203-205
+
+    # cross-view pairing (:207-208); each head returns 0.5 * its loss so the sum is (l1 + l2) / 2 (:210)
+    loss_01 = n1(batch, molecule_3D_repr_01, distance_02, noise_level=noise.get("noise_level_1"),
+                 distance_noise=noise.get("dist_noise_1"), out_scale=0.5)
+    loss_02 = n2(batch, molecule_3D_repr_02, distance_01, noise_level=noise.get("noise_level_2"),
+                 distance_noise=noise.get("dist_noise_2"), out_scale=0.5)
+    loss = loss_01 + loss_02
+    return loss, 0
+
+
+class Batch:
+    """Device-resident collated batch with the attributes do_DDM / NCSN_version_03 read
+    (BatchAtomTuple, dataloaders_AtomTuple.py:40-78)."""
+
+    def __init__(self, x, positions, batch, super_edge_index, radius_edge_index=None, num_graphs=None):
+        self.x, self.positions, self.batch, self.super_edge_index = x, positions, batch, super_edge_index
+        self.radius_edge_index = radius_edge_index
+        self._num_graphs = num_graphs
+
+    @property
+    def num_graphs(self):
+        if self._num_graphs is None:
+            self._num_graphs = self.batch[-1].item() + 1  # dataloaders_AtomTuple.py:75-78
+        return self._num_graphs
+
+    @classmethod
+    def from_numpy(cls, d, device):
+        import numpy as np
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        rei = t(d["radius_edge_index"]) if "radius_edge_index" in d else None
+        ng = int(len(d["sizes"])) if "sizes" in d else None
+        return cls(t(d["x"]), t(d["positions"]), t(d["batch"]), t(d["super_edge_index"]), rei, ng)
+
+    def to(self, device):
+        mv = lambda a: None if a is None else a.to(device)
+        return Batch(mv(self.x), mv(self.positions), mv(self.batch), mv(self.super_edge_index),
+                     mv(self.radius_edge_index), self._num_graphs)
+
+
+class Args:
+    """The three fields do_DDM reads from the reference's argparse namespace."""
+
+    def __init__(self, model_3d="schnet", normalize=False):
+        self.model_3d = model_3d
+        self.normalize = normalize
+
+
+class DDMTrainer:
+    """The body of ``train()`` (pretrain_GeoSSL.py:234-260) for the DDM option: forward of both
+    views + both heads, backward, gradient all-reduce, Adam — flat parameter buffer, no host sync
+    inside ``step`` (the reference's per-step ``loss.item()`` at :255 is logging, call
+    ``float(loss)`` outside the timed region if wanted)."""
+
+    def __init__(self, model, ncsn_01, ncsn_02, lr=5e-4, weight_decay=0.0, mu=0.0, sigma=0.3, model_3d="schnet",
+                 device_noise=True):
+        from .optim import FlatParams, FusedAdam
+        from .parallel import GradAllReduce
+        self.model, self.n1, self.n2 = model, ncsn_01, ncsn_02
+        self.args = Args(model_3d)
+        self.mu, self.sigma = mu, sigma
+        self.device_noise = device_noise
+        self.flat = FlatParams([model, ncsn_01, ncsn_02])
+        self.opt = FusedAdam(self.flat, lr=lr, weight_decay=weight_decay)
+        self.reduce = GradAllReduce(self.flat.grad)
+
+    def step(self, batch, noise=None):
+        self.flat.zero_grad()
+        loss, _ = do_DDM(self.args, batch, self.model, None, self.mu, self.sigma, NCSN_models=(self.n1, self.n2),
+                         noise=noise, device_noise=self.device_noise)
+        loss.backward()
+        self.flat.rebind_grads()
+        scale = self.reduce()
+        self.opt.step(grad_scale=scale)
+        return loss.detach()

@@ -1,0 +1,229 @@
+/* C ABI of libgeossl_hip.so — the MI355X (gfx950) hot path of GeoSSL's SchNet/PaiNN + DDM step.
+ *
+ * The reference (chao1224/GeoSSL) is pure Python: it has no FFI, the "interface" this library sits behind is
+ * the set of ATen / torch_geometric / torch_scatter / torch_cluster calls its hot path makes.  Every entry
+ * point below names the reference call site(s) it replaces (paths relative to the reference root).
+ *
+ * Conventions (all functions):
+ *   - raw DEVICE pointers, explicit sizes, scalars by value, trailing hipStream_t;
+ *   - return value is a hipError_t as int (0 = success); nothing throws, allocates or synchronises;
+ *   - the caller owns every buffer, pre-allocates outputs / workspaces and keeps inputs alive until the
+ *     stream reaches the call; re-entrant, no global state.
+ *   - fp32 everywhere; "i64" index tensors are the reference's int64 tensors, internal indices are int32.
+ */
+#ifndef GEOSSL_HIP_H
+#define GEOSSL_HIP_H
+#include <stdint.h>
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+#else
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEOSSL_ABI_VERSION 1
+#define GEOSSL_MAX_L 12 /* max interaction blocks handled by the batched-by-layer kernels */
+#define GEOSSL_TN_MAX 32 /* max problems in one batched weight-gradient launch */
+
+/* epilogue flags of geossl_linear */
+#define GEOSSL_EPI_BIAS 1      /* + bias[n] */
+#define GEOSSL_EPI_SSP 2       /* ShiftedSoftplus (schnet.py:210-216) */
+#define GEOSSL_EPI_RESIDUAL 4  /* + res[r][n]   (h = h + block(h), schnet.py:97) */
+#define GEOSSL_EPI_MUL_DSSP 8  /* * d ssp/dx recovered from the saved ssp OUTPUT tprev[r][n] (backward) */
+
+int geossl_abi_version(void);
+
+/* ---- batch layout (position independent; built once per collated batch) -------------------------------
+ * Replaces the index bookkeeping of BatchAtomTuple.from_data_list (Geom3D/dataloaders/dataloaders_AtomTuple.py:57-73)
+ * and the `batch[-1].item()+1` of num_graphs (:75-78).  `batch` must be sorted ascending (collated batches are).
+ *   mol_ptr[B+1]  : atom offsets; pair_ptr[B+1] : offsets of the n(n-1)/2 "pair slots" (i<j, lexicographic —
+ *                   the same enumeration as AtomTupleExtractor "combination", :22-23)
+ *   stats[4]      : {max atoms per molecule, total pair slots P, 1 if batch is not sorted / out of range, 0}
+ *   pair_i/pair_j : atom ids (global) of every pair slot                                                   */
+int geossl_layout_build(const int64_t* batch, int64_t N, int64_t B, int32_t* mol_ptr, int32_t* pair_ptr,
+                        int64_t* stats, hipStream_t stream);
+int geossl_pair_index_fill(const int32_t* mol_ptr, const int32_t* pair_ptr, int64_t B, int32_t* pair_i,
+                           int32_t* pair_j, hipStream_t stream);
+
+/* ---- radius graph (K1) — torch_cluster.radius_graph via torch_geometric (schnet.py:91;
+ * datasets_3D_Radius.py:120) + the edge length of schnet.py:93.
+ * Semantics: per molecule, per target i scan sources j ascending, hit when fl32(dx^2+dy^2+dz^2) < r2 (strict,
+ * no FMA), stop after `cap` hits (cap = max_num_neighbors + 1, the self hit counts), drop j == i.
+ *   _count : deg[N] = in-degree of every target
+ *   _fill  : edge_ptr[N+1] = exclusive scan of deg (caller); writes edge_index as two int64 rows
+ *            (src = source j, dst = target i; target-major, sources ascending) and edge_weight[E]
+ *   geossl_pair_geometry : the same graph in pair-slot form for the fused SchNet path:
+ *            pair_d[P] = |x_i - x_j|, pair_c[P] = 0.5*(cos(d*pi/cutoff)+1) (the CFConv envelope, schnet.py:186),
+ *            pair_flag[P] bit0 = edge (j -> i) present, bit1 = edge (i -> j) present, for slot (i<j).       */
+int geossl_radius_graph_count(const float* pos, const int32_t* mol_ptr, int64_t B, int max_n, float r2, int cap,
+                              int32_t* deg, hipStream_t stream);
+int geossl_radius_graph_fill(const float* pos, const int32_t* mol_ptr, int64_t B, int max_n, float r2, int cap,
+                             const int64_t* edge_ptr, int64_t* edge_src, int64_t* edge_dst, float* edge_weight,
+                             hipStream_t stream);
+int geossl_pair_geometry(const float* pos, const int32_t* mol_ptr, const int32_t* pair_ptr, int64_t B, int max_n,
+                         float r2, int cap, float cutoff, float* pair_d, float* pair_c, uint8_t* pair_flag,
+                         hipStream_t stream);
+
+/* ---- Gaussian smearing (K2) — GaussianSmearing.forward, schnet.py:205-207: out[e][g] = exp(coeff*(d-off_g)^2) */
+int geossl_rbf_fwd(const float* d, int64_t E, const float* offset, int G, float coeff, float* out,
+                   hipStream_t stream);
+
+/* ---- continuous-filter network for all interaction blocks (K3) — InteractionBlock.mlp applied in
+ * CFConv.forward, schnet.py:141-145,186-187:  Wf_l[p] = (ssp(rbf(d_p) A1_l^T + b1_l) A2_l^T + b2_l) * C(d_p),
+ * C(d) = 0.5*(cos(d*pi/cutoff)+1).  One launch covers every layer l < L and every pair slot p < P.
+ *   T (optional, training) : saved hidden activation ssp(.) [L][P][F];  Wf : [L][P][F]                      */
+typedef struct {
+  const float* w1[GEOSSL_MAX_L]; /* mlp.0.weight [F][G] */
+  const float* b1[GEOSSL_MAX_L]; /* mlp.0.bias   [F]    */
+  const float* w2[GEOSSL_MAX_L]; /* mlp.2.weight [F][F] */
+  const float* b2[GEOSSL_MAX_L]; /* mlp.2.bias   [F]    */
+} GeosslFilterWeights;
+int geossl_cfconv_filter_fwd(const float* pair_d, const float* pair_c, int64_t P, const GeosslFilterWeights* w, int L,
+                             int F, int G, const float* offset, float coeff, float* T, float* Wf, hipStream_t stream);
+
+/* Backward of K3 with respect to the filter-network weights (positions carry no gradient on the DDM path).
+ * dWf is never materialised: dWf[p] = flag0*dagg[i]*x[j] + flag1*dagg[j]*x[i] is rebuilt from the per-layer atom
+ * tensors x_l = conv.lin1(h) and dagg_l = dL/d(aggregate) (both [N][F]).
+ *   _bwd_hidden : dU_l[p] = ((dWf_l[p]*C(d_p)) A2_l) * ssp'(.)     -> dU [L][P][F]
+ *   _bwd_weights: dA2_l = sum_p dO^T T, db2_l = sum_p dO, dA1_l = sum_p dU^T rbf(d), db1_l = sum_p dU      */
+typedef struct {
+  const float* x[GEOSSL_MAX_L];    /* [N][F] */
+  const float* dagg[GEOSSL_MAX_L]; /* [N][F] */
+} GeosslFilterGradIn;
+typedef struct {
+  float* dw1[GEOSSL_MAX_L];
+  float* db1[GEOSSL_MAX_L];
+  float* dw2[GEOSSL_MAX_L];
+  float* db2[GEOSSL_MAX_L];
+} GeosslFilterGradOut;
+int geossl_cfconv_filter_bwd_hidden(const float* pair_c, const uint8_t* pair_flag, const int32_t* pair_i,
+                                    const int32_t* pair_j, int64_t P, const GeosslFilterWeights* w,
+                                    const GeosslFilterGradIn* g, int L, int F, const float* T, float* dU,
+                                    hipStream_t stream);
+int64_t geossl_cfconv_filter_bwd_workspace_floats(int64_t P, int L, int F, int G);
+int geossl_cfconv_filter_bwd_weights(const float* pair_d, const float* pair_c, const uint8_t* pair_flag,
+                                     const int32_t* pair_i, const int32_t* pair_j, int64_t P,
+                                     const GeosslFilterGradIn* g, int L, int F, int G, const float* offset, float coeff,
+                                     const float* T, const float* dU, const GeosslFilterGradOut* out, float* workspace,
+                                     int accumulate, hipStream_t stream);
+
+/* ---- neighbour aggregation (K4) — MessagePassing.propagate(aggr="add") with message x_j * W
+ * (schnet.py:190,194-195): out[i] = sum over edges (j -> i), j ascending, of x[j] * Wf[slot(i,j)].
+ * swap = 1 runs the transposed graph (backward w.r.t. x): out[j] = sum over edges (j -> i) of x[i]*Wf.       */
+int geossl_cfconv_aggregate(const float* x, const float* Wf, const uint8_t* pair_flag, const int32_t* mol_ptr,
+                            const int32_t* pair_ptr, int64_t B, int max_n, int F, int swap, float* out,
+                            hipStream_t stream);
+
+/* ---- atom-row Linear — ATen Linear at schnet.py:99,101,166,189,191 and its autograd.
+ * Y[r][n] = epi(sum_k X[r][k] * Bm[k][n]); transB=1: W is torch layout [NO][K] (forward);
+ * transB=0: W is [K][NO] (backward w.r.t. input: dX = dY W).  K % 8 == 0, K,NO <= 256.                      */
+int geossl_linear(const float* X, const float* W, const float* bias, const float* res, const float* tprev, float* Y,
+                  int64_t R, int K, int NO, int transB, int flags, hipStream_t stream);
+
+/* batched weight gradients: dW_z[m][n] (+)= sum_r A_z[r][m]*B_z[r][n], db_z[m] (+)= sum_r A_z[r][m]          */
+typedef struct {
+  const float* A[GEOSSL_TN_MAX];
+  const float* B[GEOSSL_TN_MAX];
+  float* dW[GEOSSL_TN_MAX];
+  float* db[GEOSSL_TN_MAX]; /* may be NULL */
+} GeosslTnBatch;
+typedef struct {
+  float* out[GEOSSL_TN_MAX];
+} GeosslReduceBatch;
+void geossl_tn_plan(int64_t R, int* chunk, int* nblk);
+int64_t geossl_tn_workspace_floats(int64_t R, int M, int N, int nprob);
+int geossl_linear_wgrad(const GeosslTnBatch* batch, int nprob, int64_t R, int M, int N, float* workspace,
+                        int accumulate, hipStream_t stream);
+
+/* ---- embedding — torch.nn.Embedding at schnet.py:89 (z is a strided int64 view x[:,0])                     */
+int geossl_embedding_fwd(const int64_t* z, int64_t z_stride, const float* table, int num_classes, int64_t N, int F,
+                         float* out, int32_t* status, hipStream_t stream);
+int64_t geossl_embedding_bwd_workspace_floats(int num_classes, int F);
+int geossl_embedding_bwd(const int64_t* z, int64_t z_stride, const float* dh, int num_classes, int64_t N, int F,
+                         float* dtable, float* workspace, int accumulate, hipStream_t stream);
+
+/* ---- readout — torch_scatter.scatter(h, batch, dim=0, reduce) at schnet.py:115 / painn.py:266
+ * mean = sum / max(count,1).  _bwd: dh[a] = dout[batch[a]] (/count).                                          */
+int geossl_segment_reduce_fwd(const float* h, const int32_t* mol_ptr, int64_t B, int F, int mean, float* out,
+                              hipStream_t stream);
+int geossl_segment_reduce_bwd(const float* dout, const int32_t* mol_ptr, int64_t B, int F, int mean, float* dh,
+                              int accumulate, hipStream_t stream);
+
+/* ---- DDM pieces — examples/pretrain_GeoSSL.py:68-74,199-205 and examples/NCSN.py:183-220 ----------------- */
+/* perturb (:72): out = pos + noise */
+int geossl_axpy(const float* a, const float* b, float alpha, int64_t n, float* out, hipStream_t stream);
+/* super-edge length (:199-205): out[s] = sqrt(sum((pos[u]-pos[v])^2)) */
+int geossl_pair_distance(const float* pos, const int64_t* sei0, const int64_t* sei1, int64_t S, float* out,
+                         hipStream_t stream);
+/* per-batch bookkeeping for the NCSN head: se_ptr[B+1] = first super-edge of every molecule (needs
+ * batch[sei0] non-decreasing and both ends in one molecule: true for collated batches),
+ * stats = {max(edge2graph)+1 (the divisor of NCSN.py:212), 1 if the ordering assumption fails}; and the
+ * atom -> incident super-edge lists (inc_ptr from an exclusive scan of inc_cnt by the caller).              */
+int geossl_super_edge_ptr(const int64_t* batch, const int64_t* sei0, const int64_t* sei1, int64_t S, int64_t B,
+                          int32_t* se_ptr, int64_t* stats, hipStream_t stream);
+int geossl_incidence_count(const int64_t* batch, const int64_t* sei0, const int64_t* sei1, const int32_t* se_ptr,
+                           int64_t N, int32_t* inc_cnt, hipStream_t stream);
+int geossl_incidence_fill(const int64_t* batch, const int64_t* sei0, const int64_t* sei1, const int32_t* se_ptr,
+                          int64_t N, const int64_t* inc_ptr, int32_t* inc_idx, hipStream_t stream);
+
+typedef struct {
+  const float* in_w1; /* input_distance_mlp.layers.0.weight [F][1] */
+  const float* in_b1; /* [F] */
+  const float* in_w2; /* input_distance_mlp.layers.1.weight [1][F] */
+  const float* in_b2; /* [1] */
+  const float* o1_w;  /* output_mlp.layers.0.weight [F][F+1] */
+  const float* o1_b;  /* [F] */
+  const float* o2_w;  /* output_mlp.layers.1.weight [F/2][F] */
+  const float* o2_b;  /* [F/2] */
+  const float* o3_w;  /* output_mlp.layers.2.weight [1][F/2] */
+  const float* o3_b;  /* [1] */
+  const float* sigmas; /* [K] */
+} GeosslNcsnWeights;
+typedef struct {
+  float* in_w1; float* in_b1; float* in_w2; float* in_b2;
+  float* o1_w; float* o1_b; float* o2_w; float* o2_b; float* o3_w; float* o3_b;
+} GeosslNcsnGrads;
+/* Saved per-row state of the head (training): a1 [S][F], a2 [S][F/2] (post-relu), pd[S] (perturbed distance),
+ * emb[S], gscale[S] = d loss_e / d(output_mlp out).                                                         */
+typedef struct {
+  float* a1; float* a2; float* pd; float* emb; float* gscale;
+} GeosslNcsnSaved;
+/* K5 forward: loss_e[S] (NCSN.py:209) from node features h [N][F], distances d[S], the two random draws
+ * noise_level[B] (i64, :190) and distance_noise[S] (:194) given as inputs.                                   */
+int64_t geossl_ddm_loss_fwd_workspace_floats(int F);
+int geossl_ddm_loss_fwd(const float* h, const int64_t* batch, const int64_t* sei0, const int64_t* sei1, int64_t S,
+                        const float* distance, const int64_t* noise_level, const float* distance_noise,
+                        const GeosslNcsnWeights* w, int F, float anneal_power, float* loss_e,
+                        const GeosslNcsnSaved* saved, float* workspace, hipStream_t stream);
+/* loss = sum_s loss_e[s] / divisor (NCSN.py:210-212), fixed-order two-stage sum; out_scale multiplies the result
+ * (0.5 for the (l1+l2)/2 of pretrain_GeoSSL.py:210) and accumulate adds to *loss.                            */
+int64_t geossl_loss_reduce_workspace_floats(int64_t S);
+int geossl_loss_reduce(const float* loss_e, int64_t S, const int64_t* stats_divisor, float out_scale, float* loss,
+                       float* workspace, int accumulate, hipStream_t stream);
+/* K5 backward.  gout = upstream gradient of the head's scalar loss (device scalar, may be NULL = 1),
+ * row pass: dz1 [S][F] (grad at output_mlp hidden 1 pre-activation), dfeat [S][F] (grad w.r.t. h_u + h_v),
+ * demb[S]; then weight gradients; then dh[a] (+)= sum of dfeat over incident super-edges (fixed order).      */
+int geossl_ddm_loss_bwd_rows(const GeosslNcsnWeights* w, const GeosslNcsnSaved* saved, int64_t S, int F,
+                             const int64_t* stats_divisor, float out_scale, const float* gout, float* dz1,
+                             float* dfeat, float* demb, float* grow, hipStream_t stream);
+int64_t geossl_ddm_loss_bwd_workspace_floats(int64_t S, int F);
+int geossl_ddm_loss_bwd_weights(const float* h, const int64_t* sei0, const int64_t* sei1, int64_t S, int F,
+                                const GeosslNcsnWeights* w, const GeosslNcsnSaved* saved, const float* dz1,
+                                const float* demb, const float* grow, const GeosslNcsnGrads* grads,
+                                float* workspace, int accumulate, hipStream_t stream);
+int geossl_incidence_gather(const float* dfeat, const int64_t* inc_ptr, const int32_t* inc_idx, int64_t N, int F,
+                            float* dh, int accumulate, hipStream_t stream);
+
+/* ---- Adam — torch.optim.Adam step at pretrain_GeoSSL.py:258-260,343 over one flat fp32 buffer
+ * (amsgrad off; weight_decay added to the gradient as torch does).  step_count is the 1-based step.        */
+int geossl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int64_t step_count, float grad_scale,
+                     hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEOSSL_HIP_H */

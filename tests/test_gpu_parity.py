@@ -1,0 +1,376 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+(1) the committed golden vectors produced by the unmodified reference and (2) the CPU oracle on the
+same seeded inputs.  Tolerances (BASELINE.json north_star): radius-graph edge indices bit-exact;
+fp32 outputs / loss <= 1e-5 relative; parameter gradients <= 1e-4 relative (fp32 reductions over up
+to ~3e5 rows in a different order)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, max_rel, rel_err
+from helpers import (cfg_of, grad_summary, ncsn_oracle_params, product_ncsn, product_schnet, schnet_oracle_params, t,
+                     unique_named_grads)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL_OUT = 1e-5
+TOL_GRAD = 1e-4
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded():
+    from geossl_amd import _lib
+    _lib.load()
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+
+
+# ------------------------------------------------------------------------------------------- graph (K1)
+@pytest.mark.parametrize("r", [5.0, 10.0, 1.5])
+def test_radius_graph_golden_bit_exact(r):
+    from geossl_amd import ops
+    g = load_golden("g3_radius_graph")
+    e, w = ops.radius_graph(t(g["positions"], DEV), r, t(g["batch"], DEV), return_weight=True)
+    assert e.dtype == torch.int64
+    assert torch.equal(e.cpu(), t(g["edge_index_%g" % r]))
+    assert max_rel(w.cpu(), g["edge_weight_%g" % r]) < 1e-6
+
+
+@pytest.mark.parametrize("mode,r", [("A", 5.0), ("B", 5.0), ("B", 10.0)])
+def test_radius_graph_full_batch_vs_oracle(mode, r):
+    from geossl_amd import ops
+    from geossl_amd.synthetic import make_batch
+    from oracle.graph import radius_graph_np
+    b = make_batch(1024, seed=7, mode=mode)
+    e = ops.radius_graph(t(b["positions"], DEV), r, t(b["batch"], DEV))
+    ref = radius_graph_np(b["positions"], r, b["batch"])
+    assert np.array_equal(e.cpu().numpy(), ref)
+
+
+def test_radius_graph_edge_cases():
+    from geossl_amd import ops
+    pos = torch.zeros(1, 3, device=DEV)
+    assert ops.radius_graph(pos, 5.0, torch.zeros(1, dtype=torch.long, device=DEV)).shape == (2, 0)
+    # exactly-at-cutoff pair is excluded (strict <), batch=None means one graph
+    pos = torch.tensor([[0.0, 0, 0], [5.0, 0, 0], [0, 4.999999, 0]], device=DEV)
+    e = ops.radius_graph(pos, 5.0)
+    assert e.cpu().tolist() == [[2, 0], [0, 2]]
+    with pytest.raises(ValueError):
+        ops.radius_graph(torch.zeros(3, 3, device=DEV), 5.0, torch.tensor([1, 0, 0], device=DEV))
+
+
+def test_pair_geometry_matches_edge_list():
+    """The pair-slot form used inside SchNet carries exactly the canonical edge set."""
+    from geossl_amd import ops
+    from geossl_amd.layout import MolLayout
+    g = load_golden("g3_radius_graph")
+    pos, bat = t(g["positions"], DEV), t(g["batch"], DEV)
+    lay = MolLayout(bat)
+    for r in (5.0, 10.0):
+        d, c, fl = ops.pair_geometry(pos, lay, r)
+        pi, pj, fl = lay.pair_i.cpu().long(), lay.pair_j.cpu().long(), fl.cpu()
+        src = torch.cat([pj[(fl & 1) > 0], pi[(fl & 2) > 0]])
+        dst = torch.cat([pi[(fl & 1) > 0], pj[(fl & 2) > 0]])
+        key = torch.argsort(dst * 100000 + src)
+        e = torch.stack([src[key], dst[key]])
+        assert torch.equal(e, t(g["edge_index_%g" % r]))
+        dd = (pos[lay.pair_i.long()] - pos[lay.pair_j.long()]).norm(dim=-1)
+        assert max_rel(d, dd) < 1e-6
+        cc = 0.5 * (torch.cos(dd * np.pi / r) + 1.0)
+        assert float((c - cc).abs().max()) < 2e-6
+
+
+# ------------------------------------------------------------------------------------ element kernels
+def test_gaussian_smearing_golden():
+    from geossl_amd import ops
+    g = load_golden("g1_g2_smearing_ssp")
+    for r, G in [(10.0, 51), (5.0, 51), (10.0, 50)]:
+        key = "%g_%d" % (r, G)
+        y = ops.gaussian_smearing(t(g["d_" + key], DEV), t(g["offset_" + key], DEV), float(g["coeff_" + key]))
+        assert float((y.cpu() - t(g["y_" + key])).abs().max()) < 2e-6
+
+
+def test_linear_and_ssp_epilogues_vs_torch():
+    from geossl_amd import _lib, ops
+    torch.manual_seed(0)
+    for R, K, NO in [(1000, 128, 128), (77, 32, 32), (300, 64, 64), (5, 128, 128)]:
+        x = torch.randn(R, K, device=DEV)
+        w = torch.randn(NO, K, device=DEV) / K ** 0.5
+        b = torch.randn(NO, device=DEV)
+        res = torch.randn(R, NO, device=DEV)
+        ref = x.double() @ w.double().t() + b.double()
+        assert rel_err(ops.linear(x, w, bias=b).cpu(), ref.cpu()) < 1e-6
+        sp = torch.nn.functional.softplus(ref) - float(torch.log(torch.tensor(2.0)))
+        assert rel_err(ops.linear(x, w, bias=b, flags=_lib.EPI_SSP).cpu(), sp.cpu()) < 1e-6
+        assert rel_err(ops.linear(x, w, bias=b, res=res).cpu(), (ref + res.double()).cpu()) < 1e-6
+        # backward-input form: dX = dY @ W, optionally times ssp'(pre) recovered from the ssp output
+        dy = torch.randn(R, NO, device=DEV)
+        dx_ref = dy.double() @ w.double()
+        assert rel_err(ops.linear(dy, w, transB=False).cpu(), dx_ref.cpu()) < 1e-6
+        pre = torch.randn(R, K, device=DEV) * 3
+        tout = (torch.nn.functional.softplus(pre) - float(torch.log(torch.tensor(2.0))))
+        got = ops.linear(dy, w, transB=False, tprev=tout)
+        assert rel_err(got.cpu(), (dx_ref * torch.sigmoid(pre.double())).cpu()) < 2e-6
+        # weight gradient
+        dW = torch.empty(NO, K, device=DEV)
+        db = torch.empty(NO, device=DEV)
+        ops.linear_wgrad([(dy, x, dW, db)], R, NO, K)
+        assert rel_err(dW.cpu(), (dy.double().t() @ x.double()).cpu()) < 1e-6
+        assert rel_err(db.cpu(), dy.double().sum(0).cpu()) < 1e-6
+
+
+def test_mfma_tile_layout_asymmetric():
+    """A = I against an asymmetric B catches a transposed C-write (cdna guide: always test this)."""
+    from geossl_amd import ops
+    x = torch.eye(128, device=DEV)
+    w = torch.arange(128 * 128, dtype=torch.float32, device=DEV).view(128, 128) * 1e-3
+    assert torch.equal(ops.linear(x, w).cpu(), w.t().cpu())
+    assert torch.equal(ops.linear(x, w, transB=False).cpu(), w.cpu())
+
+
+# ------------------------------------------------------------------------------------------- SchNet (K2-K4)
+def _schnet_golden_case(tag):
+    g = load_golden("g4_schnet_" + tag)
+    cfg = cfg_of(g)
+    model = product_schnet(cfg, DEV)
+    x = t(g["x"], DEV)
+    out, h = model(x[:, 0], t(g["positions"], DEV), t(g["batch"], DEV), return_latent=True)
+    return g, cfg, model, out, h
+
+
+@pytest.mark.parametrize("tag", ["reduced", "full_r5", "full_r10"])
+def test_schnet_forward_golden(tag):
+    g, cfg, model, out, h = _schnet_golden_case(tag)
+    assert max_rel(out.cpu(), g["out"]) < TOL_OUT
+    assert max_rel(h.cpu(), g["h"]) < TOL_OUT
+
+
+@pytest.mark.parametrize("tag", ["reduced", "full_r5", "full_r10"])
+def test_schnet_param_grads_golden(tag):
+    g, cfg, model, out, h = _schnet_golden_case(tag)
+    loss = (out ** 2).sum() + (h ** 2).sum() * 0.5
+    assert rel_err(loss.detach().cpu(), g["loss"]) < TOL_OUT
+    loss.backward()
+    grads = unique_named_grads(model)
+    for k in g:
+        if k.startswith("gsum/"):
+            assert rel_err(grad_summary(grads[k[5:]].cpu()), g[k]) < TOL_GRAD, k
+        if k.startswith("grad/"):
+            assert rel_err(grads[k[5:]].cpu(), g[k]) < TOL_GRAD, k
+
+
+def test_schnet_no_grad_and_state_dict_roundtrip(tmp_path):
+    g = load_golden("g4_schnet_reduced")
+    cfg = cfg_of(g)
+    model = product_schnet(cfg, DEV)
+    x = t(g["x"], DEV)
+    with torch.no_grad():
+        out = model(x[:, 0], t(g["positions"], DEV), t(g["batch"], DEV))
+    assert max_rel(out.cpu(), g["out"]) < TOL_OUT
+    # the reference's checkpoint format: {"model": state_dict} (pretrain_GeoSSL.py:54-64)
+    path = tmp_path / "model.pth"
+    torch.save({"model": model.state_dict()}, path)
+    from geossl_amd.Geom3D.models import SchNet
+    m2 = SchNet(**cfg).to(DEV)
+    m2.load_state_dict(torch.load(path)["model"])
+    with torch.no_grad():
+        out2 = m2(x[:, 0], t(g["positions"], DEV), t(g["batch"], DEV))
+    assert torch.equal(out, out2)
+
+
+def test_schnet_se3_invariance_full_batch():
+    """Domain property at BASELINE size: rotating + translating every molecule leaves h unchanged."""
+    from geossl_amd.synthetic import make_batch
+    b = make_batch(1024, seed=3, mode="B")
+    cfg = dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=5.0, node_class=9,
+               readout="mean")
+    model = product_schnet(cfg, DEV)
+    x, pos, bat = t(b["x"], DEV), t(b["positions"], DEV), t(b["batch"], DEV)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64))
+    pos2 = (pos.double().cpu() @ q + torch.tensor([0.3, -1.2, 2.0], dtype=torch.float64)).float().to(DEV)
+    with torch.no_grad():
+        out1, h1 = model(x[:, 0], pos, bat, return_latent=True)
+        out2, h2 = model(x[:, 0], pos2, bat, return_latent=True)
+    assert torch.isfinite(h1).all()
+    assert rel_err(h2.cpu(), h1.cpu()) < 5e-5  # distances move by ~1 ulp under an fp32 rotation
+    assert out1.shape == (1024, 128)
+
+
+def test_schnet_vs_oracle_synthetic_128():
+    from geossl_amd.synthetic import make_batch
+    from oracle import nets
+    b = make_batch(128, seed=11, mode="B")
+    cfg = dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=5.0, node_class=9,
+               readout="mean")
+    model = product_schnet(cfg, DEV)
+    P = schnet_oracle_params(cfg)
+    x, pos, bat = t(b["x"]), t(b["positions"]), t(b["batch"])
+    out_o, h_o = nets.schnet_forward(P, x[:, 0], pos, bat, 5.0, 6, "mean", return_latent=True)
+    (h_o ** 2).sum().backward()
+    out, h = model(x.to(DEV)[:, 0], pos.to(DEV), bat.to(DEV), return_latent=True)
+    (h ** 2).sum().backward()
+    assert max_rel(h.detach().cpu(), h_o.detach()) < TOL_OUT
+    assert max_rel(out.detach().cpu(), out_o.detach()) < TOL_OUT
+    grads = unique_named_grads(model)
+    for k, gval in grads.items():
+        assert rel_err(gval.cpu(), P[k].grad) < TOL_GRAD, k
+
+
+def test_schnet_errors():
+    from geossl_amd import _lib
+    from geossl_amd.Geom3D.models import SchNet
+    m = SchNet(32, 32, 2, 8, 5.0, node_class=9).to(DEV)
+    with pytest.raises(AssertionError):  # schnet.py:86
+        m(torch.zeros(3, 1, dtype=torch.long, device=DEV), torch.zeros(3, 3, device=DEV))
+    with pytest.raises(_lib.GeosslHipError):  # no CPU fallback
+        SchNet(32, 32, 2, 8, 5.0, node_class=9)(torch.zeros(3, dtype=torch.long), torch.zeros(3, 3))
+
+
+# --------------------------------------------------------------------------------------------- NCSN (K5)
+class _Data:
+    def __init__(self, g, dev):
+        self.batch = t(g["batch"], dev)
+        self.super_edge_index = t(g["super_edge_index"], dev)
+        self.x = t(g["x"], dev)
+        self.positions = t(g["positions"], dev)
+
+    @property
+    def num_graphs(self):
+        return self.batch[-1].item() + 1
+
+
+@pytest.mark.parametrize("tag", ["comb_K50_p2", "comb_K30_p0.05", "comb_K50_p5_last1", "perm_K30_p10"])
+def test_ncsn_golden(tag):
+    g = load_golden("g5_ncsn_" + tag)
+    head = product_ncsn(128, int(g["K"]), float(g["anneal_power"]), DEV)
+    assert torch.equal(head.sigmas.cpu(), t(g["sigmas"]))
+    data = _Data(g, DEV)
+    h = t(g["h"], DEV).clone().requires_grad_()
+    loss = head(data, h, t(g["distance"], DEV), noise_level=t(g["noise_level"], DEV),
+                distance_noise=t(g["distance_noise"], DEV))
+    assert loss.dim() == 0
+    assert rel_err(loss.detach().cpu(), g["loss"]) < TOL_OUT
+    loss.backward()
+    assert rel_err(h.grad.cpu(), g["grad_h"]) < TOL_GRAD
+    grads = unique_named_grads(head)
+    for k in g:
+        if k.startswith("grad/"):
+            assert rel_err(grads[k[5:]].cpu(), g[k]) < TOL_GRAD, k
+
+
+def test_ncsn_draws_its_own_noise_like_the_reference():
+    g = load_golden("g5_ncsn_comb_K50_p2")
+    head = product_ncsn(128, 50, 2, DEV)
+    data = _Data(g, DEV)
+    torch.manual_seed(3)
+    l1 = head(data, t(g["h"], DEV), t(g["distance"], DEV))
+    torch.manual_seed(3)
+    nl = torch.randint(0, 50, (data.num_graphs,), device=DEV)
+    dn = torch.randn_like(t(g["distance"], DEV))
+    l2 = head(data, t(g["h"], DEV), t(g["distance"], DEV), noise_level=nl, distance_noise=dn)
+    assert torch.equal(l1, l2)
+
+
+# ---------------------------------------------------------------------------------------------- do_DDM
+def _ddm_case(tag, fuse):
+    from geossl_amd import pretrain_GeoSSL as pg
+    g = load_golden("g6_ddm_" + tag)
+    cfg = cfg_of(g)
+    F = cfg["hidden_channels"]
+    model = product_schnet(cfg, DEV)
+    n1, n2 = product_ncsn(F, 50, 2, DEV), product_ncsn(F, 50, 2, DEV, scale=0.9)
+    batch = pg.Batch(t(g["x"], DEV), t(g["positions"], DEV), t(g["batch"], DEV), t(g["super_edge_index"], DEV))
+    noise = {k: t(g[k], DEV) for k in ("pos_noise", "noise_level_1", "dist_noise_1", "noise_level_2", "dist_noise_2")}
+    loss, acc = pg.do_DDM(pg.Args("schnet"), batch, model, None, 0.0, 0.3, NCSN_models=(n1, n2), noise=noise,
+                          fuse_views=fuse)
+    assert acc == 0
+    return g, model, n1, n2, loss
+
+
+@pytest.mark.parametrize("tag", ["reduced", "full"])
+@pytest.mark.parametrize("fuse", [True, False])
+def test_do_ddm_golden(tag, fuse):
+    g, model, n1, n2, loss = _ddm_case(tag, fuse)
+    assert rel_err(loss.detach().cpu(), g["loss"]) < TOL_OUT
+    loss.backward()
+    mods = {"model": unique_named_grads(model), "ncsn1": unique_named_grads(n1), "ncsn2": unique_named_grads(n2)}
+    for k in g:
+        if k.startswith("gsum/") or k.startswith("grad/"):
+            _, m, name = k.split("/", 2)
+            got = mods[m][name].cpu()
+            got = grad_summary(got) if k.startswith("gsum/") else got
+            assert rel_err(got, g[k]) < TOL_GRAD, k
+
+
+def test_ddm_full_size_vs_oracle_sample_and_determinism():
+    """BASELINE config (1024 molecules, n=18, r=5 A): the loss is reproducible bit for bit across two
+    runs (no atomics anywhere), and equals the oracle on a 64-molecule slice of the same batch."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    from oracle import nets
+    cfg = dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=5.0, node_class=9,
+               readout="mean")
+    model = product_schnet(cfg, DEV)
+    n1, n2 = product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9)
+
+    def run(nmol):
+        b = make_batch(nmol, seed=0, mode="A")
+        nz = draw_noise(b, seed=1)
+        batch = pg.Batch.from_numpy(b, DEV)
+        noise = {k: t(v, DEV) for k, v in nz.items()}
+        for m in (model, n1, n2):
+            m.zero_grad()
+        loss, _ = pg.do_DDM(pg.Args("schnet"), batch, model, None, 0.0, 0.3, NCSN_models=(n1, n2), noise=noise)
+        loss.backward()
+        return b, nz, loss.detach().clone(), model.lin2.weight.grad.clone()
+
+    _, _, l_a, g_a = run(1024)
+    _, _, l_b, g_b = run(1024)
+    assert torch.isfinite(l_a) and torch.equal(l_a, l_b) and torch.equal(g_a, g_b)
+    b, nz, l_small, _ = run(64)
+    Pm, P1, P2 = schnet_oracle_params(cfg, False), ncsn_oracle_params(128, 50), ncsn_oracle_params(128, 50, 0.9)
+    ref = nets.do_ddm_schnet(Pm, P1, P2, t(b["x"]), t(b["positions"]), t(b["batch"]), t(b["super_edge_index"]),
+                             t(nz["pos_noise"]), t(nz["noise_level_1"]), t(nz["dist_noise_1"]), t(nz["noise_level_2"]),
+                             t(nz["dist_noise_2"]), 5.0, 6, 2, "mean")
+    assert rel_err(l_small.cpu(), ref.detach()) < TOL_OUT
+
+
+# ---------------------------------------------------------------------------------------------- optimizer
+def test_fused_adam_matches_torch_adam():
+    from geossl_amd.optim import FlatParams, FusedAdam
+    torch.manual_seed(0)
+    lin_a = torch.nn.Linear(64, 48).to(DEV)
+    lin_b = torch.nn.Linear(64, 48).to(DEV)
+    lin_b.load_state_dict(lin_a.state_dict())
+    ref = torch.optim.Adam(lin_a.parameters(), lr=5e-4)
+    flat = FlatParams([lin_b])
+    opt = FusedAdam(flat, lr=5e-4)
+    for step in range(5):
+        x = torch.randn(32, 64, device=DEV)
+        for lin, o in ((lin_a, ref), (lin_b, opt)):
+            o.zero_grad()
+            lin(x).pow(2).sum().backward()
+        flat.rebind_grads()
+        ref.step()
+        opt.step()
+    assert rel_err(lin_b.weight.detach().cpu(), lin_a.weight.detach().cpu()) < 1e-6
+
+
+def test_trainer_step_reduces_loss():
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    cfg = dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=5.0, node_class=9,
+               readout="mean")
+    torch.manual_seed(0)
+    from geossl_amd.Geom3D.models import SchNet
+    from geossl_amd.NCSN import NCSN_version_03
+    model = SchNet(**cfg).to(DEV)
+    n1 = NCSN_version_03(128, 10.0, 0.01, 50, "symmetry", 2).to(DEV)
+    n2 = NCSN_version_03(128, 10.0, 0.01, 50, "symmetry", 2).to(DEV)
+    tr = pg.DDMTrainer(model, n1, n2, lr=5e-4)
+    b = make_batch(256, seed=0)
+    batch = pg.Batch.from_numpy(b, DEV)
+    noise = {k: t(v, DEV) for k, v in draw_noise(b, seed=1).items()}
+    losses = [float(tr.step(batch, noise)) for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]

@@ -1,0 +1,207 @@
+"""CPU-only tests of the host side: C-ABI surface, module/parameter mirror of the reference interface,
+error behaviour, synthetic generator, multi-process gradient all-reduce (gloo, world_size 2)."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, REPO, load_golden
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from geossl_amd import _lib, build
+    build.build(verbose=False)
+    h = open(os.path.join(REPO, "include", "geossl_hip.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    declared = set(re.findall(r"\b(?:int|int64_t|void)\s+(geossl_\w+)\s*\(", h))
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (geossl_\w+)", out))
+    assert declared <= exported, declared - exported
+    lib = _lib.load()  # binds argtypes for every prototype; no compute call without a GPU
+    assert lib.geossl_abi_version() == 1
+    # host-only planning helpers are callable on CPU
+    import ctypes as C
+    chunk, nblk = C.c_int(), C.c_int()
+    lib.geossl_tn_plan(36864, C.byref(chunk), C.byref(nblk))
+    assert chunk.value % 64 == 0 and chunk.value * nblk.value >= 36864
+    assert lib.geossl_tn_workspace_floats(36864, 128, 128, 20) == 20 * nblk.value * (128 * 128 + 256)
+
+
+def test_header_argument_counts_match_ctypes():
+    from geossl_amd import _lib
+    h = open(os.path.join(REPO, "include", "geossl_hip.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    for ret, name, args in re.findall(r"\b(int|int64_t|void)\s+(geossl_\w+)\s*\(([^;{]*?)\)\s*;", h, flags=re.S):
+        a = [x.strip() for x in args.split(",") if x.strip() and x.strip() != "void"]
+        assert len(a) == len(_lib.PROTOTYPES[name][1]), name
+
+
+def test_state_dict_mirrors_reference():
+    from geossl_amd.Geom3D.models import PaiNN, SchNet
+    from geossl_amd.NCSN import NCSN_version_03
+    spec = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+    mods = {
+        "SchNet": SchNet(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=10.0,
+                         node_class=9, readout="mean"),
+        "PaiNN": PaiNN(n_atom_basis=128, n_interactions=3, n_rbf=20, cutoff=5.0, max_z=9, n_out=1, readout="add"),
+        "NCSN_version_03": NCSN_version_03(128, 10.0, 0.01, 50, "symmetry", 2),
+    }
+    for name, m in mods.items():
+        got = [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()]
+        assert got == spec[name]["state_dict"], name
+        gotp = [[k, list(p.shape), bool(p.requires_grad)] for k, p in m.named_parameters()]
+        assert gotp == spec[name]["named_parameters"], name
+        assert sum(p.numel() for p in m.parameters()) == spec[name]["num_params"]
+
+
+def test_schnet_init_quirks():
+    from geossl_amd.Geom3D.models import SchNet
+    torch.manual_seed(0)
+    s = SchNet(node_class=9)
+    spec = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))["SchNet_init"]
+    blk = s.interactions[0]
+    assert blk.mlp is blk.conv.nn  # one module under two names (schnet.py:141-148)
+    assert float(blk.mlp[0].bias.abs().max()) == 0.0
+    # same seed, same construction order -> bit-identical init, incl. the never-zeroed mlp[2].bias
+    assert abs(float(blk.mlp[2].bias.abs().max()) - spec["mlp2_bias_absmax"]) < 1e-12
+    assert s.atomic_mass.dtype == torch.float64 and s.atomic_mass.shape == (119,)
+    with pytest.raises(AssertionError):
+        SchNet(node_class=9, readout="max")
+
+
+def test_ncsn_sigma_ladder_and_frozen_parameter():
+    from geossl_amd.NCSN import NCSN_version_03
+    g = load_golden("g5_ncsn_comb_K50_p2")
+    m = NCSN_version_03(128, 10.0, 0.01, 50, "symmetry", 2)
+    assert torch.equal(m.sigmas.data, torch.from_numpy(g["sigmas"])) and not m.sigmas.requires_grad
+
+
+def test_no_cpu_fallback_and_no_oracle_in_product():
+    from geossl_amd import _lib, ops
+    with pytest.raises(_lib.GeosslHipError):
+        ops.radius_graph(torch.zeros(4, 3), 5.0)
+    pkg = os.path.join(REPO, "geossl_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+                assert "/root/reference" not in src, f
+
+
+def test_painn_forward_fails_loudly():
+    from geossl_amd.Geom3D.models import PaiNN
+    p = PaiNN(128, 3, 20, 5.0, 1, "add", max_z=9)
+    with pytest.raises(NotImplementedError):
+        p(torch.zeros(2, dtype=torch.long), torch.zeros(2, 3), torch.zeros(2, 0, dtype=torch.long),
+          torch.zeros(2, dtype=torch.long))
+    assert isinstance(p.create_output_layers(), torch.nn.Sequential)
+
+
+def test_install_as_reference_aliases():
+    import geossl_amd
+    geossl_amd.install_as_reference()
+    from Geom3D.models import PaiNN, SchNet  # noqa: F401
+    from NCSN import NCSN_version_03  # noqa: F401
+
+
+def test_synthetic_batch_statistics():
+    from geossl_amd.synthetic import draw_noise, make_batch
+    from oracle.graph import radius_graph_np
+    b = make_batch(256, seed=0)
+    assert b["positions"].dtype == np.float32 and b["x"].shape == (256 * 18, 2)
+    assert b["super_edge_index"].shape == (2, 256 * 153)
+    e = radius_graph_np(b["positions"], 5.0, b["batch"])
+    assert 270 < e.shape[1] / 256 < 300  # ~284 directed edges / molecule at 5 A
+    p = b["positions"].reshape(256, 18, 3)
+    d = np.linalg.norm(p[:, :, None] - p[:, None], axis=-1) + np.eye(18)[None] * 10
+    assert d.min() >= 1.0 - 1e-5
+    bb = make_batch(512, seed=1, mode="B")
+    assert bb["sizes"].min() >= 2 and bb["sizes"].max() <= 33
+    nz = draw_noise(b, 3)
+    assert nz["pos_noise"].shape == b["positions"].shape and nz["noise_level_1"].max() < 50
+
+
+def test_cosine_lr_closed_form():
+    from geossl_amd.optim import cosine_annealing_lr
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=5e-4)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 100)
+    for epoch in range(1, 6):
+        opt.step()
+        sch.step()
+        assert abs(opt.param_groups[0]["lr"] - cosine_annealing_lr(5e-4, epoch, 100)) < 1e-12
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {repo!r}); sys.path.insert(0, {golden!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from geossl_amd.parallel import init_distributed, shard_batch_numpy, GradAllReduce
+from geossl_amd.synthetic import make_batch, draw_noise
+from helpers import schnet_oracle_params, ncsn_oracle_params, t
+from oracle import nets
+torch.set_num_threads(2)
+rank, _, world = init_distributed("gloo")
+cfg = dict(hidden_channels=32, num_filters=32, num_interactions=2, num_gaussians=8, cutoff=5.0, node_class=9, readout="mean")
+full = make_batch(8, seed=5, mode="B")
+def grads_of(b, seed):
+    nz = draw_noise(b, seed)
+    Pm, P1, P2 = schnet_oracle_params(cfg), ncsn_oracle_params(32, 50), ncsn_oracle_params(32, 50, 0.9)
+    loss = nets.do_ddm_schnet(Pm, P1, P2, t(b["x"]), t(b["positions"]), t(b["batch"]), t(b["super_edge_index"]),
+        t(nz["pos_noise"]), t(nz["noise_level_1"]), t(nz["dist_noise_1"]), t(nz["noise_level_2"]), t(nz["dist_noise_2"]),
+        5.0, 2, 2)
+    loss.backward()
+    flat = torch.cat([p.grad.reshape(-1) for P in (Pm, P1, P2) for k, p in sorted(P.items()) if p.requires_grad])
+    return loss.detach(), flat, nz
+mine = shard_batch_numpy(full, rank, world)
+assert mine["batch"].min() == 0 and len(mine["sizes"]) == 4
+assert mine["super_edge_index"].min() == 0 and mine["super_edge_index"].max() == mine["x"].shape[0] - 1
+loss, flat, nz = grads_of(mine, 100 + rank)
+red = GradAllReduce(flat)
+scale = red()
+flat = flat * scale
+# every rank now holds the mean of the two per-rank gradients
+torch.save(dict(loss=loss, flat=flat, nz=nz, shard=mine), os.path.join({out!r}, "rank%d.pt" % rank))
+dist.barrier()
+"""
+
+
+def test_gradient_allreduce_world2_gloo(tmp_path):
+    """N>1 path on CPU: two gloo ranks shard a batch by whole molecules, run the (oracle) DDM step on
+    their shard, all-reduce the flat gradient; the result equals the mean of the per-shard gradients
+    computed in one process."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(repo=REPO, golden=GOLDEN, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=False)
+    assert torch.equal(r0["flat"], r1["flat"])  # both ranks hold the same reduced buffer
+    # recompute per-shard grads in this process and average
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from helpers import ncsn_oracle_params, schnet_oracle_params, t
+    from oracle import nets
+    cfg = dict(hidden_channels=32, num_filters=32, num_interactions=2, num_gaussians=8, cutoff=5.0, node_class=9,
+               readout="mean")
+    flats = []
+    for r in (r0, r1):
+        b, nz = r["shard"], r["nz"]
+        Pm, P1, P2 = schnet_oracle_params(cfg), ncsn_oracle_params(32, 50), ncsn_oracle_params(32, 50, 0.9)
+        loss = nets.do_ddm_schnet(Pm, P1, P2, t(b["x"]), t(b["positions"]), t(b["batch"]), t(b["super_edge_index"]),
+                                  t(nz["pos_noise"]), t(nz["noise_level_1"]), t(nz["dist_noise_1"]),
+                                  t(nz["noise_level_2"]), t(nz["dist_noise_2"]), 5.0, 2, 2)
+        loss.backward()
+        flats.append(torch.cat([p.grad.reshape(-1) for P in (Pm, P1, P2) for k, p in sorted(P.items())
+                                if p.requires_grad]))
+    want = (flats[0] + flats[1]) / 2
+    assert float((r0["flat"] - want).abs().max() / want.abs().max()) < 1e-6
