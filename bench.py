@@ -56,7 +56,7 @@ def alg_model(n_atoms, n_edges, n_super):
     return step_bytes, step_flops, per_kernel
 
 
-def cpu_baseline(seed, n_mols=256, timed=2):
+def cpu_baseline(seed, n_mols=128, timed=2, max_threads=16):
     """The CPU oracle (pure-torch restatement pinned to the reference by golden vectors) on a bounded
     sample of the same workload: DDM step fwd+bwd + Adam on `n_mols` molecules."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -64,7 +64,8 @@ def cpu_baseline(seed, n_mols=256, timed=2):
     from geossl_amd.synthetic import draw_noise, make_batch
     from helpers import ncsn_oracle_params, schnet_oracle_params, t
     from oracle import nets
-    cores = os.cpu_count() or 1
+    # the step is ~150 small ATen ops: beyond ~16 threads torch's CPU backend only adds fork/join overhead
+    cores = min(os.cpu_count() or 1, max_threads)
     torch.set_num_threads(cores)
     cfg = dict(hidden_channels=F, num_filters=F, num_interactions=L, num_gaussians=G, cutoff=CUTOFF, node_class=9,
                readout="mean")

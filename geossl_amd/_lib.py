@@ -68,7 +68,7 @@ PROTOTYPES = {
                                                P(FilterGradOut), vp, i32, vp]),
     "geossl_cfconv_aggregate": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]),
     "geossl_linear": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
-    "geossl_tn_plan": (None, [i64, P(i32), P(i32)]),
+    "geossl_tn_plan": (None, [i64, i32, P(i32), P(i32)]),
     "geossl_tn_workspace_floats": (i64, [i64, i32, i32, i32]),
     "geossl_linear_wgrad": (i32, [P(TnBatch), i32, i64, i32, i32, vp, i32, vp]),
     "geossl_embedding_fwd": (i32, [vp, i64, vp, i32, i64, i32, vp, vp, vp]),

@@ -35,15 +35,20 @@ __device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 *
 // swizzled index into a wave-private [32][AS] A tile (AS multiple of 32)
 __device__ __forceinline__ int a_idx(int row, int k, int AS) { return row * AS + (k ^ (row & 31)); }
 
-// ShiftedSoftplus (schnet.py:210-216): F.softplus(x) (beta 1, threshold 20) - fp32(log 2)
+// ShiftedSoftplus (schnet.py:210-216): F.softplus(x) (beta 1, threshold 20) - fp32(log 2).
+// softplus(x) = max(x,0) + log1p(exp(-|x|)); above torch's threshold 20 the log1p term (< 2.1e-9) is below the
+// fp32 resolution of x, so the identity branch is reproduced without a compare.  exp/log run on the hardware
+// v_exp_f32 / v_log_f32 (argument magnitude <= ~17 where it matters: absolute error < 1e-7), with a short
+// series for small exp(-|x|) where 1+z would lose the low bits.
 #define GEOSSL_SSP_SHIFT 0.693147182464599609375f  // float(torch.log(torch.tensor(2.0)))
 __device__ __forceinline__ float ssp(float x) {
-  float sp = (x > 20.0f) ? x : log1pf(expf(x));
-  return sp - GEOSSL_SSP_SHIFT;
+  const float z = __expf(-fabsf(x));
+  const float l = z < 0.0078125f ? z * (1.0f - z * (0.5f - z * 0.33333334f)) : __logf(1.0f + z);
+  return (fmaxf(x, 0.0f) + l) - GEOSSL_SSP_SHIFT;
 }
 // d ssp / dx = sigmoid(x), recovered from the saved output t = ssp(x):
 // exp(-softplus(x)) = 1 - sigmoid(x)  =>  sigmoid(x) = 1 - 0.5*exp(-t)   (0.5 = exp(-log 2))
-__device__ __forceinline__ float dssp_from_out(float t) { return 1.0f - 0.5f * expf(-t); }
+__device__ __forceinline__ float dssp_from_out(float t) { return 1.0f - 0.5f * __expf(-t); }
 
 // acc[c] += A(32 x K) * B(K x 32*NC); A from a swizzled wave-private LDS tile, B from LDS/global Bs[k][col].
 template <int NC, typename BPtr>

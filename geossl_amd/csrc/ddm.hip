@@ -33,6 +33,37 @@ __global__ void k_transpose_pad(const float* __restrict__ W, int rows, int cols,
   }
 }
 
+// A wave gathers h[u] + h[v] for NROWS rows (endpoints held by lanes 0..NROWS-1), four rows at a time with all
+// eight row loads of a group in flight together.
+template <int F, int NROWS, class Store>
+__device__ __forceinline__ void gather_endpoint_sum_rows(const float* __restrict__ h, int64_t my_u, int64_t my_v,
+                                                         int lane, Store store) {
+  constexpr int NV = (F + 63) / 64;
+#pragma unroll 1
+  for (int r4 = 0; r4 < NROWS; r4 += 4) {
+    float hu[4][NV], hv[4][NV];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t uu = __shfl(my_u, r4 + q, 64), vv = __shfl(my_v, r4 + q, 64);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int n = lane + 64 * v;
+        if (n < F) {
+          hu[q][v] = h[uu * F + n];
+          hv[q][v] = h[vv * F + n];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int n = lane + 64 * v;
+        if (n < F) store(r4 + q, n, hu[q][v] + hv[q][v]);
+      }
+  }
+}
+
 template <int NC>
 __global__ __launch_bounds__(256) void k_ncsn_fwd(const float* __restrict__ h, const int64_t* __restrict__ batch,
                                                   const int64_t* __restrict__ sei0, const int64_t* __restrict__ sei1,
@@ -87,10 +118,7 @@ __global__ __launch_bounds__(256) void k_ncsn_fwd(const float* __restrict__ h, c
     e += __shfl_xor(e, 32, 64);
     const float emb = e + ib2;
     // gather h[u] + h[v] (:201-203) into the A tile
-    for (int rr = 0; rr < 32; ++rr) {
-      const int64_t uu = __shfl(u, rr, 64), vv = __shfl(v, rr, 64);
-      for (int n = lane; n < F; n += 64) Aw[a_idx(rr, n, F)] = h[uu * F + n] + h[vv * F + n];
-    }
+    gather_endpoint_sum_rows<F, 32>(h, u, v, lane, [&](int rr, int n, float val) { Aw[a_idx(rr, n, F)] = val; });
     __syncthreads();
     f32x16 acc[NC];
 #pragma unroll
@@ -269,10 +297,7 @@ struct NcsnW2Loader {  // A = da2 (rebuilt from grow, w3, a2 mask) [S][H], B = a
       if (row < row_end && m < M && a2[(size_t)row * H + m] > 0.0f) v = grow[row] * w3[m];
       As[i] = v;
     }
-    for (int i = tid; i < 64 * NP; i += 256) {
-      const int r = i / NP, n = i - r * NP, row = row0 + r;
-      Bs[i] = (row < row_end && n < N) ? a1[(size_t)row * F + n] : 0.0f;
-    }
+    load_rows_f4<NP>(a1, F, N, row0, row_end, Bs, tid);
   }
 };
 
@@ -286,16 +311,16 @@ struct NcsnW1Loader {  // A = dz1 [S][F], B = h[u]+h[v] (rebuilt), e = emb
   template <int MP, int NP>
   __device__ __forceinline__ void load(int z, int row0, int row_end, int M, int N, float* As, float* Bs, float* es,
                                        int tid) const {
-    for (int i = tid; i < 64 * MP; i += 256) {
-      const int r = i / MP, m = i - r * MP, row = row0 + r;
-      As[i] = (row < row_end && m < M) ? dz1[(size_t)row * F + m] : 0.0f;
-    }
-    for (int i = tid; i < 64 * NP; i += 256) {
-      const int r = i / NP, n = i - r * NP, row = row0 + r;
-      float v = 0.0f;
-      if (row < row_end && n < N) v = h[sei0[row] * F + n] + h[sei1[row] * F + n];
-      Bs[i] = v;
-    }
+    load_rows_f4<MP>(dz1, F, M, row0, row_end, As, tid);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int myrow = row0 + 16 * wave + (lane & 15);
+    const bool ok = myrow < row_end;
+    const int64_t u = ok ? sei0[myrow] : 0, v = ok ? sei1[myrow] : 0;
+    const float keep = ok ? 1.0f : 0.0f;
+    float* Bw = Bs + 16 * wave * NP;  // NP == F here
+    gather_endpoint_sum_rows<NP, 16>(h, u, v, lane, [&](int rr, int n, float val) {
+      Bw[rr * NP + n] = val * __shfl(keep, rr, 64);
+    });
     if (tid < 64) es[tid] = (row0 + tid < row_end) ? emb[row0 + tid] : 0.0f;
   }
 };

@@ -22,19 +22,20 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, con
                                                 int NO, int ldx, int ldy, int transB, int flags) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NB = 32 * NC;  // columns handled by this block
-  float* Bs = smem;            // [K][NB]
+  constexpr int BS = NB + 1;   // odd row stride: the transposing store (lanes = consecutive k) is conflict-free
+  float* Bs = smem;            // [K][BS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.y * NB;
   // stage the weight slice
   if (transB) {
     for (int i = tid; i < K * NB; i += 256) {
       const int n = i / K, k = i - n * K;
-      Bs[k * NB + n] = (n0 + n < NO) ? W[(size_t)(n0 + n) * K + k] : 0.0f;
+      Bs[k * BS + n] = (n0 + n < NO) ? W[(size_t)(n0 + n) * K + k] : 0.0f;
     }
   } else {
     for (int i = tid; i < K * NB; i += 256) {
       const int k = i / NB, n = i - k * NB;
-      Bs[k * NB + n] = (n0 + n < NO) ? W[(size_t)k * NO + n0 + n] : 0.0f;
+      Bs[k * BS + n] = (n0 + n < NO) ? W[(size_t)k * NO + n0 + n] : 0.0f;
     }
   }
   __syncthreads();
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, con
       const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float* bp = Bs + (8 * q + 4 * kh + s) * NB + j;
+        const float* bp = Bs + (8 * q + 4 * kh + s) * BS + j;
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bp[32 * c], acc[c], 0, 0, 0);
       }
@@ -94,7 +95,7 @@ extern "C" int geossl_linear(const float* X, const float* W, const float* bias, 
   if (NC == 3) NC = 1;
   const int ny = NOp / (32 * NC);
   dim3 grid(ntiles < 1024 ? ntiles : 1024, ny);
-  const size_t lds = (size_t)K * 32 * NC * sizeof(float);
+  const size_t lds = (size_t)K * (32 * NC + 1) * sizeof(float);
   const int ldx = K, ldy = NO;
 #define LAUNCH(NCV)                                                                                               \
   hipLaunchKernelGGL((k_linear<NCV>), grid, dim3(256), lds, stream, X, W, bias, res, tprev, Y, (int)R, K, NO, ldx, \
@@ -113,24 +114,43 @@ extern "C" int geossl_linear(const float* X, const float* W, const float* bias, 
 // ------------------------------------------------------------------------------------------------
 // Column GEMM (weight gradient), plain operands — template in tn.h.
 namespace geossl {
-__global__ void k_reduce_partials(GeosslReduceBatch batch, const float* __restrict__ partial, int nblk, int len,
-                                  int ncols, int ld, int cstride, int accumulate) {
+// block = 64 outputs x 4 slices of the partial list; the four slice sums are combined in slice order.
+__global__ __launch_bounds__(256) void k_reduce_partials(GeosslReduceBatch batch, const float* __restrict__ partial,
+                                                         int nblk, int len, int ncols, int ld, int cstride,
+                                                         int accumulate) {
+  __shared__ float red[4][64];
   const int z = blockIdx.y;
   float* out = batch.out[z];
   if (out == nullptr) return;
   const float* p = partial + (size_t)z * nblk * len;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const int per = (nblk + 3) / 4, b0 = slice * per, b1 = min(nblk, b0 + per);
+  float s = 0.0f;
+  if (i < len) {
+#pragma unroll 8
+    for (int b = b0; b < b1; ++b) s += p[(size_t)b * len + i];
+  }
+  red[slice][lane] = s;
+  __syncthreads();
+  if (slice == 0 && i < len) {
     const size_t o = (size_t)(i / ncols) * ld + (size_t)(i % ncols) * cstride;
-    float s = accumulate ? out[o] : 0.0f;
-    for (int b = 0; b < nblk; ++b) s += p[(size_t)b * len + i];
-    out[o] = s;
+    float v = accumulate ? out[o] : 0.0f;
+    v += red[0][lane];
+    v += red[1][lane];
+    v += red[2][lane];
+    v += red[3][lane];
+    out[o] = v;
   }
 }
 }  // namespace geossl
 
-extern "C" void geossl_tn_plan(int64_t R, int* chunk, int* nblk) {
-  // aim for <= 384 row chunks, each a multiple of 64 rows
-  int64_t c = (R + 383) / 384;
+extern "C" void geossl_tn_plan(int64_t R, int nprob, int* chunk, int* nblk) {
+  // about 1024 row chunks over all problems of the launch (4 per CU), each a multiple of 64 rows
+  int target = 1024 / (nprob > 0 ? nprob : 1);
+  if (target < 32) target = 32;
+  if (target > 512) target = 512;
+  int64_t c = (R + target - 1) / target;
   c = (c + 63) / 64 * 64;
   if (c < 64) c = 64;
   *chunk = (int)c;

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_filter_fwd(const float* __restrict__ pa
     for (int kk = 0; kk < GP / 2; ++kk) {
       const int k = 2 * kk + kh;
       const float diff = d - offs[k];
-      const float a = k < G ? expf(coeff * (diff * diff)) : 0.0f;  // schnet.py:206-207
+      const float a = k < G ? __expf(coeff * (diff * diff)) : 0.0f;  // schnet.py:206-207
       const float* bp = W1s + k * F + j;
 #pragma unroll
       for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[32 * c], acc[c], 0, 0, 0);
@@ -108,12 +108,59 @@ __global__ __launch_bounds__(256) void k_filter_fwd(const float* __restrict__ pa
 
 // dO[p][n] = C(d_p) * (flag0 * dagg[i][n] * x[j][n] + flag1 * dagg[j][n] * x[i][n])  for pair slot p = (i<j):
 // the gradient reaching the filter-network output, rebuilt from atom tensors (never stored per pair).
-__device__ __forceinline__ float filter_out_grad(const float* __restrict__ x, const float* __restrict__ dagg, int i,
-                                                 int j, unsigned flag, float c, int n, int F) {
-  float v = 0.0f;
-  if (flag & 1u) v += dagg[(size_t)i * F + n] * x[(size_t)j * F + n];
-  if (flag & 2u) v += dagg[(size_t)j * F + n] * x[(size_t)i * F + n];
-  return v * c;
+// Row descriptor of one pair slot, held by the lane that "owns" the row and broadcast by shuffle.
+struct PairRowDesc {
+  int i, j;
+  float m0, m1;  // C(d) * flag bit 0 / bit 1 (0 for rows past the end)
+};
+__device__ __forceinline__ PairRowDesc load_pair_desc(const int32_t* __restrict__ pair_i,
+                                                      const int32_t* __restrict__ pair_j,
+                                                      const uint8_t* __restrict__ pair_flag,
+                                                      const float* __restrict__ pair_c, int row, int row_end) {
+  PairRowDesc d;
+  const bool ok = row < row_end;
+  const int r = ok ? row : 0;
+  d.i = pair_i[r];
+  d.j = pair_j[r];
+  const unsigned fl = ok ? pair_flag[r] : 0u;
+  const float c = pair_c[r];
+  d.m0 = (fl & 1u) ? c : 0.0f;
+  d.m1 = (fl & 2u) ? c : 0.0f;
+  return d;
+}
+// A wave rebuilds NROWS rows (descriptors in lanes 0..NROWS-1) four rows at a time: the 16*F/64 gathers of a
+// group are issued back to back before any is consumed, so their L2 latencies overlap instead of chaining.
+template <int F, int NROWS, class Store>
+__device__ __forceinline__ void build_filter_out_grad_rows(const float* __restrict__ x, const float* __restrict__ dagg,
+                                                           const PairRowDesc& mine, int lane, Store store) {
+  constexpr int NV = (F + 63) / 64;
+#pragma unroll 1
+  for (int r4 = 0; r4 < NROWS; r4 += 4) {
+    float da_i[4][NV], x_j[4][NV], da_j[4][NV], x_i[4][NV], m0[4], m1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ii = __shfl(mine.i, r4 + q, 64), jj = __shfl(mine.j, r4 + q, 64);
+      m0[q] = __shfl(mine.m0, r4 + q, 64);
+      m1[q] = __shfl(mine.m1, r4 + q, 64);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int n = lane + 64 * v;
+        if (n < F) {
+          da_i[q][v] = dagg[(size_t)ii * F + n];
+          x_j[q][v] = x[(size_t)jj * F + n];
+          da_j[q][v] = dagg[(size_t)jj * F + n];
+          x_i[q][v] = x[(size_t)ii * F + n];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int n = lane + 64 * v;
+        if (n < F) store(r4 + q, n, m0[q] * (da_i[q][v] * x_j[q][v]) + m1[q] * (da_j[q][v] * x_i[q][v]));
+      }
+  }
 }
 
 // ------------------------------------------------------------------------------------ K3 backward (hidden)
@@ -139,17 +186,9 @@ __global__ __launch_bounds__(256) void k_filter_bwd_hidden(const float* __restri
   const int ntiles = (P + 127) / 128;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int r0 = t * 128 + wave * 32;
-    for (int rr = 0; rr < 32; ++rr) {
-      const int row = r0 + rr;
-      if (row < P) {
-        const int ai = pair_i[row], aj = pair_j[row];
-        const unsigned fl = pair_flag[row];
-        const float c = pair_c[row];
-        for (int n = lane; n < F; n += 64) Aw[a_idx(rr, n, F)] = filter_out_grad(x, dagg, ai, aj, fl, c, n, F);
-      } else {
-        for (int n = lane; n < F; n += 64) Aw[a_idx(rr, n, F)] = 0.0f;
-      }
-    }
+    const PairRowDesc mine = load_pair_desc(pair_i, pair_j, pair_flag, pair_c, r0 + j, P);
+    build_filter_out_grad_rows<F, 32>(x, dagg, mine, lane,
+                                      [&](int rr, int n, float v) { Aw[a_idx(rr, n, F)] = v; });
     __syncthreads();
     f32x16 acc[NC];
 #pragma unroll
@@ -185,17 +224,13 @@ struct FilterW2Loader {  // A = dO (rebuilt), B = T_l
                                        int tid) const {
     const float* __restrict__ x = g.x[z];
     const float* __restrict__ dagg = g.dagg[z];
-    for (int i = tid; i < 64 * MP; i += 256) {
-      const int r = i / MP, m = i - r * MP, row = row0 + r;
-      float v = 0.0f;
-      if (row < row_end && m < M) v = filter_out_grad(x, dagg, pair_i[row], pair_j[row], pair_flag[row], pair_c[row], m, F);
-      As[i] = v;
-    }
+    const int lane = tid & 63, wave = tid >> 6;
+    // wave w rebuilds rows 16w .. 16w+15 of the slice (MP == F here)
+    const PairRowDesc mine = load_pair_desc(pair_i, pair_j, pair_flag, pair_c, row0 + 16 * wave + (lane & 15), row_end);
+    float* Aw = As + 16 * wave * MP;
+    build_filter_out_grad_rows<MP, 16>(x, dagg, mine, lane, [&](int rr, int n, float v) { Aw[rr * MP + n] = v; });
     const float* __restrict__ Tl = T + (size_t)z * P * F;
-    for (int i = tid; i < 64 * NP; i += 256) {
-      const int r = i / NP, n = i - r * NP, row = row0 + r;
-      Bs[i] = (row < row_end && n < N) ? Tl[(size_t)row * F + n] : 0.0f;
-    }
+    load_rows_f4<NP>(Tl, F, N, row0, row_end, Bs, tid);
   }
 };
 
@@ -209,16 +244,13 @@ struct FilterW1Loader {  // A = dU_l, B = Gaussian smearing of d (rebuilt)
   __device__ __forceinline__ void load(int z, int row0, int row_end, int M, int N, float* As, float* Bs, float* es,
                                        int tid) const {
     const float* __restrict__ Ul = dU + (size_t)z * P * F;
-    for (int i = tid; i < 64 * MP; i += 256) {
-      const int r = i / MP, m = i - r * MP, row = row0 + r;
-      As[i] = (row < row_end && m < M) ? Ul[(size_t)row * F + m] : 0.0f;
-    }
+    load_rows_f4<MP>(Ul, F, M, row0, row_end, As, tid);
     for (int i = tid; i < 64 * NP; i += 256) {
       const int r = i / NP, n = i - r * NP, row = row0 + r;
       float v = 0.0f;
       if (row < row_end && n < N) {
         const float diff = pair_d[row] - offset[n];
-        v = expf(coeff * (diff * diff));
+        v = __expf(coeff * (diff * diff));
       }
       Bs[i] = v;
     }
@@ -230,39 +262,56 @@ struct FilterW1Loader {  // A = dU_l, B = Gaussian smearing of d (rebuilt)
 // LDS copy of x and the accumulators are thread-private (no barriers, no atomics); each filter row is read
 // once and applied in both directions.  Separate multiply and add (no FMA) in ascending source order: the
 // same rounding sequence as a sequential index_add over the canonical edge list.
-__global__ __launch_bounds__(64) void k_aggregate(const float* __restrict__ x, const float* __restrict__ Wf,
-                                                  const uint8_t* __restrict__ pair_flag,
-                                                  const int32_t* __restrict__ mol_ptr,
-                                                  const int32_t* __restrict__ pair_ptr, int B, int F, int swap,
-                                                  float* __restrict__ out) {
+__global__ __launch_bounds__(128) void k_aggregate(const float* __restrict__ x, const float* __restrict__ Wf,
+                                                   const uint8_t* __restrict__ pair_flag,
+                                                   const int32_t* __restrict__ mol_ptr,
+                                                   const int32_t* __restrict__ pair_ptr, int B, int F, int max_n,
+                                                   int swap, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int m = blockIdx.x;
   if (m >= B) return;
-  const int lane = threadIdx.x;
-  const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m];
-  float* xs = smem;           // [n][F]
-  float* acc = smem + n * F;  // [n][F]
-  for (int i = 0; i < n; ++i)
-    for (int f = lane; f < F; f += 64) {
+  const int f = threadIdx.x;  // one feature column per thread
+  const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m], np = n * (n - 1) / 2;
+  float* xs = smem;                // [max_n][F]
+  float* acc = smem + max_n * F;   // [max_n][F]
+  uint8_t* sfl = reinterpret_cast<uint8_t*>(smem + 2 * max_n * F);  // [np] flag, then endpoints a, b
+  uint8_t* sa = sfl + max_n * (max_n - 1) / 2;
+  uint8_t* sb = sa + max_n * (max_n - 1) / 2;
+  for (int a = 0; a + 1 < n; ++a) {
+    const int row = a * n - a * (a + 1) / 2 - a - 1;
+    for (int b = a + 1 + threadIdx.x; b < n; b += blockDim.x) {
+      unsigned fl = pair_flag[base + row + b];
+      if (swap) fl = ((fl & 1u) << 1) | ((fl >> 1) & 1u);
+      sfl[row + b] = (uint8_t)fl;
+      sa[row + b] = (uint8_t)a;
+      sb[row + b] = (uint8_t)b;
+    }
+  }
+  if (f < F)
+    for (int i = 0; i < n; ++i) {
       xs[i * F + f] = x[(size_t)(a0 + i) * F + f];
       acc[i * F + f] = 0.0f;
     }
-  for (int a = 0; a + 1 < n; ++a) {
-    const int rowb = base + a * n - a * (a + 1) / 2 - a - 1;
-    for (int b = a + 1; b < n; ++b) {
-      unsigned fl = pair_flag[rowb + b];
-      if (swap) fl = ((fl & 1u) << 1) | ((fl >> 1) & 1u);
-      if (fl == 0) continue;
-      const float* __restrict__ wr = Wf + (size_t)(rowb + b) * F;
-      for (int f = lane; f < F; f += 64) {
-        const float wv = wr[f];
-        if (fl & 1u) acc[a * F + f] = __fadd_rn(acc[a * F + f], __fmul_rn(xs[b * F + f], wv));  // edge b -> a
-        if (fl & 2u) acc[b * F + f] = __fadd_rn(acc[b * F + f], __fmul_rn(xs[a * F + f], wv));  // edge a -> b
+  __syncthreads();
+  if (f < F) {
+    const float* __restrict__ wcol = Wf + (size_t)base * F + f;
+    for (int p0 = 0; p0 < np; p0 += 8) {
+      float w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = wcol[(size_t)min(p0 + u, np - 1) * F];  // 8 filter rows in flight
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + u;
+        if (p < np) {
+          const unsigned fl = sfl[p];
+          const int a = sa[p], b = sb[p];
+          if (fl & 1u) acc[a * F + f] = __fadd_rn(acc[a * F + f], __fmul_rn(xs[b * F + f], w[u]));  // edge b -> a
+          if (fl & 2u) acc[b * F + f] = __fadd_rn(acc[b * F + f], __fmul_rn(xs[a * F + f], w[u]));  // edge a -> b
+        }
       }
     }
+    for (int i = 0; i < n; ++i) out[(size_t)(a0 + i) * F + f] = acc[i * F + f];
   }
-  for (int i = 0; i < n; ++i)
-    for (int f = lane; f < F; f += 64) out[(size_t)(a0 + i) * F + f] = acc[i * F + f];
 }
 
 // --------------------------------------------------------------------------------------------- embedding
@@ -432,11 +481,12 @@ extern "C" int geossl_cfconv_aggregate(const float* x, const float* Wf, const ui
                                        const int32_t* mol_ptr, const int32_t* pair_ptr, int64_t B, int max_n, int F,
                                        int swap, float* out, hipStream_t stream) {
   if (B <= 0) return 0;
-  const size_t lds = (size_t)2 * max_n * F * sizeof(float);
+  if (max_n > 255 || F > 128) return (int)hipErrorInvalidValue;
+  const size_t lds = (size_t)2 * max_n * F * sizeof(float) + (size_t)3 * (max_n * (max_n - 1) / 2) + 16;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   allow_big_lds(&k_aggregate);
-  hipLaunchKernelGGL(k_aggregate, dim3((unsigned)B), dim3(64), lds, stream, x, Wf, pair_flag, mol_ptr, pair_ptr, (int)B,
-                     F, swap, out);
+  hipLaunchKernelGGL(k_aggregate, dim3((unsigned)B), dim3(F > 64 ? 128 : 64), lds, stream, x, Wf, pair_flag, mol_ptr,
+                     pair_ptr, (int)B, F, max_n, swap, out);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

@@ -84,7 +84,7 @@ __global__ void k_reduce_partials(GeosslReduceBatch batch, const float* __restri
 
 inline int64_t tn_workspace_floats(int64_t R, int M, int N, int nprob) {
   int chunk, nblk;
-  geossl_tn_plan(R, &chunk, &nblk);
+  geossl_tn_plan(R, nprob, &chunk, &nblk);
   return (int64_t)nprob * nblk * ((int64_t)M * N + 2 * M);
 }
 
@@ -96,7 +96,7 @@ int launch_tn(const Loader& ld, int nprob, int64_t R, int M, int N, const TnOut&
   if (nprob <= 0 || R <= 0) return 0;
   if (nprob > GEOSSL_TN_MAX) return (int)hipErrorInvalidValue;
   int chunk, nblk;
-  geossl_tn_plan(R, &chunk, &nblk);
+  geossl_tn_plan(R, nprob, &chunk, &nblk);
   float* partial = workspace;
   float* pbias = partial + (size_t)nprob * nblk * M * N;
   float* pdot = pbias + (size_t)nprob * nblk * M;
@@ -134,40 +134,47 @@ int launch_tn(const Loader& ld, int nprob, int64_t R, int M, int N, const TnOut&
   GeosslReduceBatch rb;
   for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = z < nprob ? out.dW[z] : nullptr;
   const int len = M * N;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((len + 255) / 256, nprob), dim3(256), 0, stream, rb, partial, nblk, len, N,
+  hipLaunchKernelGGL(k_reduce_partials, dim3((len + 63) / 64, nprob), dim3(256), 0, stream, rb, partial, nblk, len, N,
                      dW_ld, 1, accumulate);
   GEOSSL_CHECK_LAUNCH();
   if (any_b) {
     for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = z < nprob ? out.db[z] : nullptr;
-    hipLaunchKernelGGL(k_reduce_partials, dim3((M + 255) / 256, nprob), dim3(256), 0, stream, rb, pbias, nblk, M, M, M,
+    hipLaunchKernelGGL(k_reduce_partials, dim3((M + 63) / 64, nprob), dim3(256), 0, stream, rb, pbias, nblk, M, M, M,
                        1, accumulate);
     GEOSSL_CHECK_LAUNCH();
   }
   if (any_d) {
     for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = z < nprob ? out.dd[z] : nullptr;
-    hipLaunchKernelGGL(k_reduce_partials, dim3((M + 255) / 256, nprob), dim3(256), 0, stream, rb, pdot, nblk, M, M,
+    hipLaunchKernelGGL(k_reduce_partials, dim3((M + 63) / 64, nprob), dim3(256), 0, stream, rb, pdot, nblk, M, M,
                        M, dd_stride, accumulate);
     GEOSSL_CHECK_LAUNCH();
   }
   return 0;
 }
 
-// Plain loader: A_z [R][M], B_z [R][N] row-major in global memory.
+// 64-row slice of a row-major [R][ld] matrix (first ncols columns, ncols % 4 == 0, ld % 4 == 0) -> dst[64][NPAD],
+// 16-byte loads and stores, zero fill past row_end / ncols.
+template <int NPAD>
+__device__ __forceinline__ void load_rows_f4(const float* __restrict__ src, int ld, int ncols, int row0, int row_end,
+                                             float* dst, int tid) {
+  constexpr int Q = NPAD / 4;
+#pragma unroll 4
+  for (int i = tid; i < 64 * Q; i += 256) {
+    const int r = i / Q, c4 = i - r * Q, row = row0 + r;
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (row < row_end && 4 * c4 < ncols) v = *reinterpret_cast<const float4*>(src + (size_t)row * ld + 4 * c4);
+    *reinterpret_cast<float4*>(dst + r * NPAD + 4 * c4) = v;
+  }
+}
+
+// Plain loader: A_z [R][M], B_z [R][N] row-major in global memory (M, N multiples of 4).
 struct PlainLoader {
   GeosslTnBatch batch;
   template <int MP, int NP>
   __device__ __forceinline__ void load(int z, int row0, int row_end, int M, int N, float* As, float* Bs, float* es,
                                        int tid) const {
-    const float* __restrict__ A = batch.A[z];
-    const float* __restrict__ B = batch.B[z];
-    for (int i = tid; i < 64 * MP; i += 256) {
-      const int r = i / MP, m = i - r * MP;
-      As[i] = (row0 + r < row_end && m < M) ? A[(size_t)(row0 + r) * M + m] : 0.0f;
-    }
-    for (int i = tid; i < 64 * NP; i += 256) {
-      const int r = i / NP, n = i - r * NP;
-      Bs[i] = (row0 + r < row_end && n < N) ? B[(size_t)(row0 + r) * N + n] : 0.0f;
-    }
+    load_rows_f4<MP>(batch.A[z], M, M, row0, row_end, As, tid);
+    load_rows_f4<NP>(batch.B[z], N, N, row0, row_end, Bs, tid);
   }
 };
 

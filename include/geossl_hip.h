@@ -133,7 +133,7 @@ typedef struct {
 typedef struct {
   float* out[GEOSSL_TN_MAX];
 } GeosslReduceBatch;
-void geossl_tn_plan(int64_t R, int* chunk, int* nblk);
+void geossl_tn_plan(int64_t R, int nprob, int* chunk, int* nblk);
 int64_t geossl_tn_workspace_floats(int64_t R, int M, int N, int nprob);
 int geossl_linear_wgrad(const GeosslTnBatch* batch, int nprob, int64_t R, int M, int N, float* workspace,
                         int accumulate, hipStream_t stream);

@@ -41,3 +41,16 @@ def max_rel(a, b, floor=1e-6):
     a = torch.as_tensor(a).detach().double().reshape(-1)
     b = torch.as_tensor(b).detach().double().reshape(-1)
     return float(((a - b).abs() / (b.abs() + floor * b.abs().max().clamp_min(1e-30))).max())
+
+
+def max_abs_rel(a, b):
+    """max |a-b| / max |b| — error relative to the tensor's scale (near-zero elements of an fp32
+    result carry absolute, not relative, rounding error)."""
+    a = torch.as_tensor(a).detach().double().reshape(-1)
+    b = torch.as_tensor(b).detach().double().reshape(-1)
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def assert_close(a, b, tol, what=""):
+    r, m = rel_err(a, b), max_abs_rel(a, b)
+    assert r < tol and m < tol, "%s: l2-rel %.3e, max-abs/max %.3e (tol %.1e)" % (what, r, m, tol)

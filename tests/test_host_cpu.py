@@ -28,7 +28,7 @@ def test_c_abi_exports_every_declared_symbol():
     # host-only planning helpers are callable on CPU
     import ctypes as C
     chunk, nblk = C.c_int(), C.c_int()
-    lib.geossl_tn_plan(36864, C.byref(chunk), C.byref(nblk))
+    lib.geossl_tn_plan(36864, 20, C.byref(chunk), C.byref(nblk))
     assert chunk.value % 64 == 0 and chunk.value * nblk.value >= 36864
     assert lib.geossl_tn_workspace_floats(36864, 128, 128, 20) == 20 * nblk.value * (128 * 128 + 256)
 
