@@ -26,7 +26,7 @@ F, L, G, CUTOFF, K_LEVELS = 128, 6, 51, 5.0, 50
 HBM_PEAK = 8.0e12       # B/s, spec (MI355X_MICROARCH.md)
 FP32_PEAK = 157.3e12    # FLOP/s, vector == f32-MFMA rate
 # entry points whose launches are bracketed with HIP events inside the timed region
-TIMED = ("geossl_cfconv_filter_fwd", "geossl_cfconv_filter_bwd_hidden", "geossl_cfconv_filter_bwd_weights",
+TIMED = ("geossl_cfconv_filter_fwd", "geossl_cfconv_filter_bwd",
          "geossl_ddm_loss_fwd", "geossl_ddm_loss_bwd_rows", "geossl_ddm_loss_bwd_weights", "geossl_linear_wgrad")
 
 
@@ -46,8 +46,7 @@ def alg_model(n_atoms, n_edges, n_super):
     per_kernel = {
         # (algorithmic flops, algorithmic bytes) of ONE launch, both views together
         "geossl_cfconv_filter_fwd": (2 * E * L * edge_fwd, 2 * E * L * (4 * G + 4 + 4 * F)),
-        "geossl_cfconv_filter_bwd_hidden": (2 * E * L * 2 * F * F, 2 * E * L * (3 * 4 * F)),
-        "geossl_cfconv_filter_bwd_weights": (2 * E * L * (2 * F * F + 2 * G * F), 2 * E * L * (3 * 4 * F + 4 * G)),
+        "geossl_cfconv_filter_bwd": (2 * E * L * edge_bwd, 2 * E * L * (2 * 4 * F + 4 * G + 4)),
         "geossl_ddm_loss_fwd": (S * ncsn_fwd, S * (16 + 8 * F + 12)),
         "geossl_ddm_loss_bwd_rows": (S * (2 * F * F + 2 * F * (F // 2)), S * (4 * F * 3)),
         "geossl_ddm_loss_bwd_weights": (S * (2 * F * F + 2 * F * (F // 2)), S * (4 * F * 4)),

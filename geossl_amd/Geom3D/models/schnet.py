@@ -97,6 +97,11 @@ def _core_params(model):
     return ps
 
 
+def _direct_grads(params):
+    return all(p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 and p.grad.is_cuda
+               for p in params)
+
+
 class _SchNetCore(torch.autograd.Function):
     """(z, pos) -> atom features after the head (schnet.py:89-101) as ONE autograd node."""
 
@@ -144,6 +149,7 @@ class _SchNetCore(torch.autograd.Function):
             ctx.lay, ctx.cfg = lay, cfg
             ctx.z = z
             ctx.ps = ps
+            ctx.params = params
             ctx.saved = dict(pair_d=pair_d, pair_c=pair_c, pair_flag=pair_flag, Wf=Wf, T=T, hs=hs, xs=xs, aggs=aggs,
                              ts=ts, h_last=h, u=u)
         return hout
@@ -160,7 +166,11 @@ class _SchNetCore(torch.autograd.Function):
         st = stream()
         emb_w, head = ps[0], ps[1 + 9 * L:]
         layers = [ps[1 + 9 * l: 1 + 9 * (l + 1)] for l in range(L)]
-        grads = [torch.empty_like(p) for p in ps]
+        # When every parameter already owns a dense .grad (DDMTrainer's flat gradient buffer) the kernels accumulate
+        # straight into it and the node returns no parameter gradients: no temporaries, no AccumulateGrad adds.
+        direct = _direct_grads(ctx.params)
+        grads = [p.grad for p in ctx.params] if direct else [torch.empty_like(p) for p in ps]
+        accum = 1 if direct else 0
         g_emb, g_head = grads[0], grads[1 + 9 * L:]
         g_layers = [grads[1 + 9 * l: 1 + 9 * (l + 1)] for l in range(L)]
         dh_out = dhout.contiguous()
@@ -185,13 +195,13 @@ class _SchNetCore(torch.autograd.Function):
             keep += [dh, dy, dx]
             dh = dh_new
         # every atom-row weight gradient in one batched launch
-        ops.linear_wgrad(probs, N, F, F)
+        ops.linear_wgrad(probs, N, F, F, accumulate=bool(accum))
         # embedding table
         nfl = _lib.load().geossl_embedding_bwd_workspace_floats(emb_w.size(0), F)
         ws = torch.empty(nfl, dtype=torch.float32, device=dev)
         z = ctx.z
         call("geossl_embedding_bwd", ptr(z), z.stride(0) if z.numel() else 1, ptr(dh), emb_w.size(0), N, F,
-             ptr(g_emb), ptr(ws), 0, st)
+             ptr(g_emb), ptr(ws), accum, st)
         # continuous-filter network weights, all blocks at once
         P = lay.P
         if P > 0:
@@ -203,19 +213,18 @@ class _SchNetCore(torch.autograd.Function):
                 gin.x[l], gin.dagg[l] = ptr(sv["xs"][l]), ptr(daggs[l])
                 gl = g_layers[l]
                 gout.dw1[l], gout.db1[l], gout.dw2[l], gout.db2[l] = ptr(gl[0]), ptr(gl[1]), ptr(gl[2]), ptr(gl[3])
-            dU = torch.empty(L, P, F, dtype=torch.float32, device=dev)
-            call("geossl_cfconv_filter_bwd_hidden", ptr(sv["pair_c"]), ptr(sv["pair_flag"]), ptr(lay.pair_i),
-                 ptr(lay.pair_j), P, C.byref(fw), C.byref(gin), L, F, ptr(sv["T"]), ptr(dU), st)
             nfl = _lib.load().geossl_cfconv_filter_bwd_workspace_floats(P, L, F, G)
             ws2 = torch.empty(nfl, dtype=torch.float32, device=dev)
-            call("geossl_cfconv_filter_bwd_weights", ptr(sv["pair_d"]), ptr(sv["pair_c"]), ptr(sv["pair_flag"]),
-                 ptr(lay.pair_i), ptr(lay.pair_j), P, C.byref(gin), L, F, G, ptr(cfg["offset"]), cfg["coeff"],
-                 ptr(sv["T"]), ptr(dU), C.byref(gout), ptr(ws2), 0, st)
-        else:
+            call("geossl_cfconv_filter_bwd", ptr(sv["pair_d"]), ptr(sv["pair_c"]), ptr(sv["pair_flag"]),
+                 ptr(lay.pair_i), ptr(lay.pair_j), P, C.byref(fw), C.byref(gin), L, F, G, ptr(cfg["offset"]),
+                 cfg["coeff"], ptr(sv["T"]), C.byref(gout), ptr(ws2), accum, st)
+        elif not direct:
             for gl in g_layers:
                 for k in range(4):
                     gl[k].zero_()
         ctx.saved = None
+        if direct:
+            return (None, None, None, None) + (None,) * len(grads)
         return (None, None, None, None) + tuple(grads)
 
 
@@ -285,8 +294,8 @@ class SchNet(torch.nn.Module):
         if self.num_filters != F or F not in SUPPORTED_F:
             raise NotImplementedError("HIP path supports hidden_channels == num_filters in %s (got %d/%d)"
                                       % (SUPPORTED_F, self.hidden_channels, self.num_filters))
-        if self.num_interactions > _lib.MAX_L or self.num_gaussians > 128:
-            raise NotImplementedError("HIP path supports <= %d interactions and <= 128 gaussians" % _lib.MAX_L)
+        if self.num_interactions > _lib.MAX_L or self.num_gaussians > 64:
+            raise NotImplementedError("HIP path supports <= %d interactions and <= 64 gaussians" % _lib.MAX_L)
         if self.dipole:
             raise NotImplementedError("dipole readout (schnet.py:103-107,117-118) is off the GeoSSL path")
 

@@ -83,6 +83,7 @@ class _NcsnLoss(torch.autograd.Function):
         call("geossl_loss_reduce", ptr(loss_e), S, ptr(sel.stats), float(out_scale), ptr(loss), ptr(ws2), 0, st)
         if training:
             ctx.sel, ctx.ps, ctx.w, ctx.saved, ctx.h = sel, ps, w, saved, h
+            ctx.params = params
             ctx.sigmas = sigmas
             ctx.out_scale = float(out_scale)
         return loss
@@ -101,17 +102,20 @@ class _NcsnLoss(torch.autograd.Function):
         gout = gout.contiguous().to(torch.float32)
         call("geossl_ddm_loss_bwd_rows", C.byref(w), C.byref(sv), S, Fd, ptr(sel.stats), ctx.out_scale, ptr(gout),
              ptr(dz1), ptr(dfeat), ptr(demb), ptr(grow), st)
-        grads = [torch.empty_like(p) for p in ps]
+        direct = all(p.grad is not None and p.grad.is_contiguous() and p.grad.is_cuda for p in ctx.params)
+        grads = [p.grad for p in ctx.params] if direct else [torch.empty_like(p) for p in ps]
         g = _lib.NcsnGrads(*[ptr(t) for t in grads])
         nfl = _lib.load().geossl_ddm_loss_bwd_workspace_floats(S, Fd)
         ws = torch.empty(nfl, dtype=torch.float32, device=dev)
         call("geossl_ddm_loss_bwd_weights", ptr(h), ptr(sel.sei0), ptr(sel.sei1), S, Fd, C.byref(w), C.byref(sv),
-             ptr(dz1), ptr(demb), ptr(grow), C.byref(g), ptr(ws), 0, st)
+             ptr(dz1), ptr(demb), ptr(grow), C.byref(g), ptr(ws), 1 if direct else 0, st)
         dh = None
         if ctx.needs_input_grad[0]:
             dh = torch.empty(N, Fd, dtype=torch.float32, device=dev)
             call("geossl_incidence_gather", ptr(dfeat), ptr(sel.inc_ptr), ptr(sel.inc_idx), N, Fd, ptr(dh), 0, st)
         ctx.saved = None
+        if direct:
+            return (dh, None, None, None, None, None, None, None) + (None,) * len(grads)
         return (dh, None, None, None, None, None, None, None) + tuple(grads)
 
 

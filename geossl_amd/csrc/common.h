@@ -51,18 +51,63 @@ __device__ __forceinline__ float ssp(float x) {
 __device__ __forceinline__ float dssp_from_out(float t) { return 1.0f - 0.5f * __expf(-t); }
 
 // acc[c] += A(32 x K) * B(K x 32*NC); A from a swizzled wave-private LDS tile, B from LDS/global Bs[k][col].
+// Software pipelined by hand: the fragments of k-step kk+1 are requested before the MFMAs of k-step kk issue
+// (hipcc places the ds_read right in front of its first use otherwise and the wave stalls on LDS latency).
+// Plain (compiler-scheduled) variant for B operands read from global memory, where several k-steps of loads in
+// flight matter more than the exact issue order.
 template <int NC, typename BPtr>
-__device__ __forceinline__ void mma_tile(f32x16 (&acc)[NC], const float* At, int AS, BPtr Bs, int BS, int K2,
-                                         int lane) {
+__device__ __forceinline__ void mma_tile_gb(f32x16 (&acc)[NC], const float* At, int AS, BPtr Bs, int BS, int K2,
+                                            int lane) {
   const int j = lane & 31, kh = lane >> 5;
   const float* arow = At + j * AS;
-#pragma unroll 4
+#pragma unroll 8
   for (int kk = 0; kk < K2; ++kk) {
     const int k = 2 * kk + kh;
     const float a = arow[k ^ j];
     const float* bp = Bs + (size_t)k * BS + j;
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[32 * c], acc[c], 0, 0, 0);
+  }
+}
+
+template <int NC, typename BPtr>
+__device__ __forceinline__ void mma_tile(f32x16 (&acc)[NC], const float* At, int AS, BPtr Bs, int BS, int K2,
+                                         int lane) {
+  const int j = lane & 31, kh = lane >> 5;
+  const float* arow = At + j * AS;
+  float a0, a1, b0[NC], b1[NC];
+  {
+    a0 = arow[kh ^ j];
+    const float* bp = Bs + (size_t)kh * BS + j;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) b0[c] = bp[32 * c];
+  }
+  int kk = 0;
+  for (; kk + 1 < K2; kk += 2) {
+    {
+      const int k = 2 * (kk + 1) + kh;
+      a1 = arow[k ^ j];
+      const float* bp = Bs + (size_t)k * BS + j;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) b1[c] = bp[32 * c];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the requests above the MFMAs that hide their latency
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[c], acc[c], 0, 0, 0);
+    if (kk + 2 < K2) {
+      const int k = 2 * (kk + 2) + kh;
+      a0 = arow[k ^ j];
+      const float* bp = Bs + (size_t)k * BS + j;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) b0[c] = bp[32 * c];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[c], acc[c], 0, 0, 0);
+  }
+  if (kk < K2) {  // odd K2 tail
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[c], acc[c], 0, 0, 0);
   }
 }
 

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_ncsn_fwd(const float* __restrict__ h, c
     for (int c = 0; c < NC2; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[c][r] = b2s[32 * c + j];
-    mma_tile<NC2>(acc2, Aw, F, W2T, HP, F / 2, lane);
+    mma_tile_gb<NC2>(acc2, Aw, F, W2T, HP, F / 2, lane);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < NC2; ++c)
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void k_ncsn_bwd_rows(GeosslNcsnWeights w, Geos
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
     // dz1 = (da2 @ o2_w) * [a1 > 0];  B[m][k] = o2_w[m][k] read straight from global (lanes = consecutive k)
-    mma_tile<NC>(acc, Aw, F, w.o2_w, F, H / 2, lane);
+    mma_tile_gb<NC>(acc, Aw, F, w.o2_w, F, H / 2, lane);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -362,10 +362,16 @@ __global__ __launch_bounds__(128) void k_ncsn_small_partial(GeosslNcsnWeights w,
     P[H + 3 * F + 1] = sd;
   }
 }
-__global__ void k_ncsn_small_reduce(const float* __restrict__ partial, int nblk, int F, GeosslNcsnGrads g,
-                                    int accumulate) {
+// one 64-lane block per output scalar: lanes stride over the row chunks, fixed-order butterfly at the end
+__global__ __launch_bounds__(64) void k_ncsn_small_reduce(const float* __restrict__ partial, int nblk, int F,
+                                                          GeosslNcsnGrads g, int accumulate) {
   const int H = F / 2, len = H + 3 * F + 2;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+  const int i = blockIdx.x;
+  if (i >= len) return;
+  float s = 0.0f;
+  for (int b = threadIdx.x; b < nblk; b += 64) s += partial[(size_t)b * len + i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) {
     float* dst;
     if (i < H) dst = g.o3_w + i;
     else if (i < H + F) dst = g.in_w2 + (i - H);
@@ -373,9 +379,7 @@ __global__ void k_ncsn_small_reduce(const float* __restrict__ partial, int nblk,
     else if (i < H + 3 * F) dst = g.in_b1 + (i - H - 2 * F);
     else if (i == H + 3 * F) dst = g.o3_b;
     else dst = g.in_b2;
-    float s = accumulate ? *dst : 0.0f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * len + i];
-    *dst = s;
+    *dst = accumulate ? *dst + s : s;
   }
 }
 
@@ -521,7 +525,8 @@ extern "C" int geossl_ddm_loss_bwd_weights(const float* h, const int64_t* sei0, 
   hipLaunchKernelGGL(k_ncsn_small_partial, dim3(nblk), dim3(128), 0, stream, *w, *saved, grow, demb, (int)S, F, chunk,
                      workspace);
   GEOSSL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_ncsn_small_reduce, dim3(2), dim3(256), 0, stream, workspace, nblk, F, *grads, accumulate);
+  hipLaunchKernelGGL(k_ncsn_small_reduce, dim3(F / 2 + 3 * F + 2), dim3(64), 0, stream, workspace, nblk, F, *grads,
+                     accumulate);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

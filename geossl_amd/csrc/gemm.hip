@@ -26,16 +26,26 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, con
   float* Bs = smem;            // [K][BS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.y * NB;
-  // stage the weight slice
+  // stage the weight slice: 16-byte global loads, several in flight per thread
   if (transB) {
-    for (int i = tid; i < K * NB; i += 256) {
-      const int n = i / K, k = i - n * K;
-      Bs[k * BS + n] = (n0 + n < NO) ? W[(size_t)(n0 + n) * K + k] : 0.0f;
+    const int KQ = K / 4;
+#pragma unroll 4
+    for (int i = tid; i < NB * KQ; i += 256) {
+      const int n = i / KQ, k4 = i - n * KQ;
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (n0 + n < NO) v = *reinterpret_cast<const float4*>(W + (size_t)(n0 + n) * K + 4 * k4);
+      float* d = Bs + (4 * k4) * BS + n;
+      d[0] = v.x; d[BS] = v.y; d[2 * BS] = v.z; d[3 * BS] = v.w;
     }
   } else {
-    for (int i = tid; i < K * NB; i += 256) {
-      const int k = i / NB, n = i - k * NB;
-      Bs[k * BS + n] = (n0 + n < NO) ? W[(size_t)k * NO + n0 + n] : 0.0f;
+    constexpr int NQ = NB / 4;
+#pragma unroll 4
+    for (int i = tid; i < K * NQ; i += 256) {
+      const int k = i / NQ, n4 = i - k * NQ;
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (n0 + 4 * n4 < NO) v = *reinterpret_cast<const float4*>(W + (size_t)k * NO + n0 + 4 * n4);
+      float* d = Bs + k * BS + 4 * n4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
   }
   __syncthreads();

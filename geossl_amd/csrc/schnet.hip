@@ -69,14 +69,34 @@ __global__ __launch_bounds__(256) void k_filter_fwd(const float* __restrict__ pa
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][r] = b;
     }
-#pragma unroll 2
-    for (int kk = 0; kk < GP / 2; ++kk) {
-      const int k = 2 * kk + kh;
-      const float diff = d - offs[k];
-      const float a = k < G ? __expf(coeff * (diff * diff)) : 0.0f;  // schnet.py:206-207
-      const float* bp = W1s + k * F + j;
+    {
+      // Gaussian smearing of the row's distance, computed directly in MFMA A-fragment layout (schnet.py:206-207);
+      // operands of k-step kk+1 are prepared before the MFMAs of k-step kk issue.
+      auto rbf_a = [&](int kk) {
+        const int k = 2 * kk + kh;
+        const float diff = d - offs[k];
+        return k < G ? __expf(coeff * (diff * diff)) : 0.0f;
+      };
+      float a_cur = rbf_a(0), b_cur[NC], b_nxt[NC];
+      {
+        const float* bp = W1s + kh * F + j;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[32 * c], acc[c], 0, 0, 0);
+        for (int c = 0; c < NC; ++c) b_cur[c] = bp[32 * c];
+      }
+      const int K2 = GP / 2;
+      for (int kk = 0; kk < K2; ++kk) {
+        const int kn = min(kk + 1, K2 - 1);
+        const float a_nxt = rbf_a(kn);
+        const float* bp = W1s + (2 * kn + kh) * F + j;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) b_nxt[c] = bp[32 * c];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[c], acc[c], 0, 0, 0);
+        a_cur = a_nxt;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) b_cur[c] = b_nxt[c];
+      }
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -105,157 +125,6 @@ __global__ __launch_bounds__(256) void k_filter_fwd(const float* __restrict__ pa
     __syncthreads();
   }
 }
-
-// dO[p][n] = C(d_p) * (flag0 * dagg[i][n] * x[j][n] + flag1 * dagg[j][n] * x[i][n])  for pair slot p = (i<j):
-// the gradient reaching the filter-network output, rebuilt from atom tensors (never stored per pair).
-// Row descriptor of one pair slot, held by the lane that "owns" the row and broadcast by shuffle.
-struct PairRowDesc {
-  int i, j;
-  float m0, m1;  // C(d) * flag bit 0 / bit 1 (0 for rows past the end)
-};
-__device__ __forceinline__ PairRowDesc load_pair_desc(const int32_t* __restrict__ pair_i,
-                                                      const int32_t* __restrict__ pair_j,
-                                                      const uint8_t* __restrict__ pair_flag,
-                                                      const float* __restrict__ pair_c, int row, int row_end) {
-  PairRowDesc d;
-  const bool ok = row < row_end;
-  const int r = ok ? row : 0;
-  d.i = pair_i[r];
-  d.j = pair_j[r];
-  const unsigned fl = ok ? pair_flag[r] : 0u;
-  const float c = pair_c[r];
-  d.m0 = (fl & 1u) ? c : 0.0f;
-  d.m1 = (fl & 2u) ? c : 0.0f;
-  return d;
-}
-// A wave rebuilds NROWS rows (descriptors in lanes 0..NROWS-1) four rows at a time: the 16*F/64 gathers of a
-// group are issued back to back before any is consumed, so their L2 latencies overlap instead of chaining.
-template <int F, int NROWS, class Store>
-__device__ __forceinline__ void build_filter_out_grad_rows(const float* __restrict__ x, const float* __restrict__ dagg,
-                                                           const PairRowDesc& mine, int lane, Store store) {
-  constexpr int NV = (F + 63) / 64;
-#pragma unroll 1
-  for (int r4 = 0; r4 < NROWS; r4 += 4) {
-    float da_i[4][NV], x_j[4][NV], da_j[4][NV], x_i[4][NV], m0[4], m1[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int ii = __shfl(mine.i, r4 + q, 64), jj = __shfl(mine.j, r4 + q, 64);
-      m0[q] = __shfl(mine.m0, r4 + q, 64);
-      m1[q] = __shfl(mine.m1, r4 + q, 64);
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const int n = lane + 64 * v;
-        if (n < F) {
-          da_i[q][v] = dagg[(size_t)ii * F + n];
-          x_j[q][v] = x[(size_t)jj * F + n];
-          da_j[q][v] = dagg[(size_t)jj * F + n];
-          x_i[q][v] = x[(size_t)ii * F + n];
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const int n = lane + 64 * v;
-        if (n < F) store(r4 + q, n, m0[q] * (da_i[q][v] * x_j[q][v]) + m1[q] * (da_j[q][v] * x_i[q][v]));
-      }
-  }
-}
-
-// ------------------------------------------------------------------------------------ K3 backward (hidden)
-template <int NC>
-__global__ __launch_bounds__(256) void k_filter_bwd_hidden(const float* __restrict__ pair_c,
-                                                           const uint8_t* __restrict__ pair_flag,
-                                                           const int32_t* __restrict__ pair_i,
-                                                           const int32_t* __restrict__ pair_j, int P,
-                                                           GeosslFilterWeights w, GeosslFilterGradIn g,
-                                                           const float* __restrict__ T, float* __restrict__ dU) {
-  constexpr int F = 32 * NC;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* W2s = smem;         // [n][k] = w2[n][k]  (contraction over n)
-  float* At = W2s + F * F;   // 4 x [32][F]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31;
-  const int l = blockIdx.y;
-  load_weight_N(w.w2[l], F, F, F, W2s, F, F, F, tid, 256);
-  __syncthreads();
-  float* Aw = At + wave * 32 * F;
-  const float* __restrict__ x = g.x[l];
-  const float* __restrict__ dagg = g.dagg[l];
-  const size_t lbase = (size_t)l * P;
-  const int ntiles = (P + 127) / 128;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int r0 = t * 128 + wave * 32;
-    const PairRowDesc mine = load_pair_desc(pair_i, pair_j, pair_flag, pair_c, r0 + j, P);
-    build_filter_out_grad_rows<F, 32>(x, dagg, mine, lane,
-                                      [&](int rr, int n, float v) { Aw[a_idx(rr, n, F)] = v; });
-    __syncthreads();
-    f32x16 acc[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
-    mma_tile<NC>(acc, Aw, F, W2s, F, F / 2, lane);
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = r0 + c_row(r, lane);
-        if (row < P) {
-          const size_t o = (lbase + row) * F + 32 * c + j;
-          dU[o] = acc[c][r] * dssp_from_out(T[o]);
-        }
-      }
-    __syncthreads();
-  }
-}
-
-// ----------------------------------------------------------------------------------- K3 backward (weights)
-struct FilterW2Loader {  // A = dO (rebuilt), B = T_l
-  const float* pair_c;
-  const uint8_t* pair_flag;
-  const int32_t* pair_i;
-  const int32_t* pair_j;
-  GeosslFilterGradIn g;
-  const float* T;
-  int P, F;
-  template <int MP, int NP>
-  __device__ __forceinline__ void load(int z, int row0, int row_end, int M, int N, float* As, float* Bs, float* es,
-                                       int tid) const {
-    const float* __restrict__ x = g.x[z];
-    const float* __restrict__ dagg = g.dagg[z];
-    const int lane = tid & 63, wave = tid >> 6;
-    // wave w rebuilds rows 16w .. 16w+15 of the slice (MP == F here)
-    const PairRowDesc mine = load_pair_desc(pair_i, pair_j, pair_flag, pair_c, row0 + 16 * wave + (lane & 15), row_end);
-    float* Aw = As + 16 * wave * MP;
-    build_filter_out_grad_rows<MP, 16>(x, dagg, mine, lane, [&](int rr, int n, float v) { Aw[rr * MP + n] = v; });
-    const float* __restrict__ Tl = T + (size_t)z * P * F;
-    load_rows_f4<NP>(Tl, F, N, row0, row_end, Bs, tid);
-  }
-};
-
-struct FilterW1Loader {  // A = dU_l, B = Gaussian smearing of d (rebuilt)
-  const float* pair_d;
-  const float* dU;
-  const float* offset;
-  float coeff;
-  int P, F, G;
-  template <int MP, int NP>
-  __device__ __forceinline__ void load(int z, int row0, int row_end, int M, int N, float* As, float* Bs, float* es,
-                                       int tid) const {
-    const float* __restrict__ Ul = dU + (size_t)z * P * F;
-    load_rows_f4<MP>(Ul, F, M, row0, row_end, As, tid);
-    for (int i = tid; i < 64 * NP; i += 256) {
-      const int r = i / NP, n = i - r * NP, row = row0 + r;
-      float v = 0.0f;
-      if (row < row_end && n < N) {
-        const float diff = pair_d[row] - offset[n];
-        v = __expf(coeff * (diff * diff));
-      }
-      Bs[i] = v;
-    }
-  }
-};
 
 // ---------------------------------------------------------------------------------------------------- K4
 // One wave per molecule.  Lane f owns feature columns f, f+64, ... of every atom row of the molecule, so the
@@ -424,57 +293,6 @@ extern "C" int geossl_cfconv_filter_fwd(const float* pair_d, const float* pair_c
 #undef LAUNCH
   GEOSSL_CHECK_LAUNCH();
   return 0;
-}
-
-extern "C" int geossl_cfconv_filter_bwd_hidden(const float* pair_c, const uint8_t* pair_flag, const int32_t* pair_i,
-                                               const int32_t* pair_j, int64_t P, const GeosslFilterWeights* w,
-                                               const GeosslFilterGradIn* g, int L, int F, const float* T, float* dU,
-                                               hipStream_t stream) {
-  if (P <= 0 || L <= 0) return 0;
-  if (L > GEOSSL_MAX_L || (F != 32 && F != 64 && F != 128)) return (int)hipErrorInvalidValue;
-  const int ntiles = (int)((P + 127) / 128);
-  dim3 grid(blocks_per_layer(L, ntiles), L);
-  const size_t lds = ((size_t)F * F + 4 * 32 * F) * sizeof(float);
-#define LAUNCH(NCV)                                                                                                \
-  do {                                                                                                             \
-    allow_big_lds(&k_filter_bwd_hidden<NCV>);                                                                      \
-    hipLaunchKernelGGL((k_filter_bwd_hidden<NCV>), grid, dim3(256), lds, stream, pair_c, pair_flag, pair_i, pair_j, \
-                       (int)P, *w, *g, T, dU);                                                                     \
-  } while (0)
-  if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
-#undef LAUNCH
-  GEOSSL_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int64_t geossl_cfconv_filter_bwd_workspace_floats(int64_t P, int L, int F, int G) {
-  const int64_t a = tn_workspace_floats(P, F, F, L), b = tn_workspace_floats(P, F, G, L);
-  return a > b ? a : b;
-}
-
-extern "C" int geossl_cfconv_filter_bwd_weights(const float* pair_d, const float* pair_c, const uint8_t* pair_flag,
-                                                const int32_t* pair_i, const int32_t* pair_j, int64_t P,
-                                                const GeosslFilterGradIn* g, int L, int F, int G, const float* offset,
-                                                float coeff, const float* T, const float* dU,
-                                                const GeosslFilterGradOut* out, float* workspace, int accumulate,
-                                                hipStream_t stream) {
-  if (P <= 0 || L <= 0) return 0;
-  if (L > GEOSSL_MAX_L) return (int)hipErrorInvalidValue;
-  TnOut o;
-  for (int z = 0; z < GEOSSL_TN_MAX; ++z) {
-    o.dW[z] = z < L ? out->dw2[z] : nullptr;
-    o.db[z] = z < L ? out->db2[z] : nullptr;
-    o.dd[z] = nullptr;
-  }
-  FilterW2Loader l2{pair_c, pair_flag, pair_i, pair_j, *g, T, (int)P, F};
-  int rc = launch_tn(l2, L, P, F, F, o, F, 1, workspace, accumulate, stream);
-  if (rc) return rc;
-  for (int z = 0; z < L; ++z) {
-    o.dW[z] = out->dw1[z];
-    o.db[z] = out->db1[z];
-  }
-  FilterW1Loader l1{pair_d, dU, offset, coeff, (int)P, F, G};
-  return launch_tn(l1, L, P, F, G, o, G, 1, workspace, accumulate, stream);
 }
 
 extern "C" int geossl_cfconv_aggregate(const float* x, const float* Wf, const uint8_t* pair_flag,

@@ -39,15 +39,31 @@ __global__ __launch_bounds__(256) void k_tn(Loader ld, int R, int chunk, int M, 
   for (int row0 = row_begin; row0 < row_end; row0 += 64) {
     ld.template load<MP, NP>(z, row0, row_end, M, N, As, Bs, es, tid);
     __syncthreads();
-#pragma unroll 2
-    for (int kk = 0; kk < 32; ++kk) {
-      const float* ap = As + (2 * kk + kh) * MP + j;
-      const float* bp = Bs + (2 * kk + kh) * NP + j;
+    {
+      // operands of the wave's tiles for one k-step: NA distinct A fragments (M blocks), NB distinct B fragments
+      constexpr int NB_ = (T >= 4 ? (NCN >= 4 ? 1 : (4 / NCN > TPW ? TPW : 4 / NCN)) : 1);
+      (void)NB_;
+      float af[2][TPW], bf[2][TPW];
+      auto fetch = [&](int kk, float (&a)[TPW], float (&b)[TPW]) {
+        const float* ap = As + (2 * kk + kh) * MP + j;
+        const float* bp = Bs + (2 * kk + kh) * NP + j;
 #pragma unroll
-      for (int i = 0; i < TPW; ++i) {
-        const int t = wave + 4 * i;
-        if (t < T)
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[32 * (t / NCN)], bp[32 * (t % NCN)], acc[i], 0, 0, 0);
+        for (int i = 0; i < TPW; ++i) {
+          const int t = wave + 4 * i;
+          a[i] = t < T ? ap[32 * (t / NCN)] : 0.0f;
+          b[i] = t < T ? bp[32 * (t % NCN)] : 0.0f;
+        }
+      };
+      fetch(0, af[0], bf[0]);
+#pragma unroll
+      for (int kk = 0; kk < 32; ++kk) {
+        if (kk + 1 < 32) fetch(kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+          const int t = wave + 4 * i;
+          if (t < T) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][i], acc[i], 0, 0, 0);
+        }
       }
     }
     if (partial_bias != nullptr && tid < MP) {

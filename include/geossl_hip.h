@@ -84,11 +84,11 @@ typedef struct {
 int geossl_cfconv_filter_fwd(const float* pair_d, const float* pair_c, int64_t P, const GeosslFilterWeights* w, int L,
                              int F, int G, const float* offset, float coeff, float* T, float* Wf, hipStream_t stream);
 
-/* Backward of K3 with respect to the filter-network weights (positions carry no gradient on the DDM path).
- * dWf is never materialised: dWf[p] = flag0*dagg[i]*x[j] + flag1*dagg[j]*x[i] is rebuilt from the per-layer atom
- * tensors x_l = conv.lin1(h) and dagg_l = dL/d(aggregate) (both [N][F]).
- *   _bwd_hidden : dU_l[p] = ((dWf_l[p]*C(d_p)) A2_l) * ssp'(.)     -> dU [L][P][F]
- *   _bwd_weights: dA2_l = sum_p dO^T T, db2_l = sum_p dO, dA1_l = sum_p dU^T rbf(d), db1_l = sum_p dU      */
+/* Backward of K3 with respect to the filter-network weights, all blocks at once (positions carry no gradient on
+ * the DDM path).  The upstream gradient dWf[p] = flag0*dagg[i]*x[j] + flag1*dagg[j]*x[i] is never materialised: it is
+ * rebuilt from the per-layer atom tensors x_l = conv.lin1(h) and dagg_l = dL/d(aggregate) (both [N][F]) staged in LDS.
+ *   dA2_l = sum_p dO^T T,  db2_l = sum_p dO,  dU = ((dO) A2_l) * ssp'(.),  dA1_l = sum_p dU^T rbf(d),  db1_l = sum_p dU
+ * with dO = dWf * C(d).  Deterministic (per-wave / per-block partials + fixed-order reduction).                 */
 typedef struct {
   const float* x[GEOSSL_MAX_L];    /* [N][F] */
   const float* dagg[GEOSSL_MAX_L]; /* [N][F] */
@@ -99,16 +99,12 @@ typedef struct {
   float* dw2[GEOSSL_MAX_L];
   float* db2[GEOSSL_MAX_L];
 } GeosslFilterGradOut;
-int geossl_cfconv_filter_bwd_hidden(const float* pair_c, const uint8_t* pair_flag, const int32_t* pair_i,
-                                    const int32_t* pair_j, int64_t P, const GeosslFilterWeights* w,
-                                    const GeosslFilterGradIn* g, int L, int F, const float* T, float* dU,
-                                    hipStream_t stream);
 int64_t geossl_cfconv_filter_bwd_workspace_floats(int64_t P, int L, int F, int G);
-int geossl_cfconv_filter_bwd_weights(const float* pair_d, const float* pair_c, const uint8_t* pair_flag,
-                                     const int32_t* pair_i, const int32_t* pair_j, int64_t P,
-                                     const GeosslFilterGradIn* g, int L, int F, int G, const float* offset, float coeff,
-                                     const float* T, const float* dU, const GeosslFilterGradOut* out, float* workspace,
-                                     int accumulate, hipStream_t stream);
+int geossl_cfconv_filter_bwd(const float* pair_d, const float* pair_c, const uint8_t* pair_flag, const int32_t* pair_i,
+                             const int32_t* pair_j, int64_t P, const GeosslFilterWeights* w,
+                             const GeosslFilterGradIn* g, int L, int F, int G, const float* offset, float coeff,
+                             const float* T, const GeosslFilterGradOut* out, float* workspace, int accumulate,
+                             hipStream_t stream);
 
 /* ---- neighbour aggregation (K4) — MessagePassing.propagate(aggr="add") with message x_j * W
  * (schnet.py:190,194-195): out[i] = sum over edges (j -> i), j ascending, of x[j] * Wf[slot(i,j)].
