@@ -30,6 +30,12 @@ TIMED = ("geossl_cfconv_filter_fwd", "geossl_cfconv_filter_bwd",
          "geossl_ddm_loss_fwd", "geossl_ddm_loss_bwd_rows", "geossl_ddm_loss_bwd_weights", "geossl_linear_wgrad")
 
 
+# entry point -> prefix of the device kernels it launches (for the PMC traffic lookup)
+ENTRY_KERNELS = {"geossl_cfconv_filter_fwd": "k_filter_fwd", "geossl_cfconv_filter_bwd": "k_filter_bwd",
+                 "geossl_ddm_loss_fwd": "k_ncsn_fwd", "geossl_ddm_loss_bwd_rows": "k_ncsn_bwd_rows",
+                 "geossl_linear_wgrad": "geossl::k_tn<4, 4, geossl::PlainLoader"}
+
+
 def alg_model(n_atoms, n_edges, n_super):
     """SURVEY.md §8(d) algorithmic bytes and flops per batch (reference formulation: directed edges E,
     atoms N, super-edges S per view)."""
@@ -55,7 +61,7 @@ def alg_model(n_atoms, n_edges, n_super):
     return step_bytes, step_flops, per_kernel
 
 
-def cpu_baseline(seed, n_mols=128, timed=2, max_threads=16):
+def cpu_baseline(seed, n_mols=1024, timed=2, max_threads=16):
     """The CPU oracle (pure-torch restatement pinned to the reference by golden vectors) on a bounded
     sample of the same workload: DDM step fwd+bwd + Adam on `n_mols` molecules."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -187,13 +193,21 @@ def main():
         roof = None
         if dom is not None:
             fl, by = per_kernel[dom]
-            if dom.startswith("geossl_ddm") or dom == "geossl_linear_wgrad":
-                pass
             dur = kern[dom][0] * 1e-3
             ach_f, ach_b = fl / dur, by / dur
+            # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_hbm_traffic_pmc.json),
+            # summed over the kernels the entry point launches
+            traffic = None
+            try:
+                pm = json.load(open(os.path.join(REPO, "profiles", "r01_hbm_traffic_pmc.json")))["kernels"]
+                ks = [v for k, v in pm.items() if k.startswith(ENTRY_KERNELS.get(dom, "\0"))]
+                if ks:
+                    traffic = sum(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for v in ks)
+            except (OSError, KeyError, ValueError):
+                pass
             # the dense pair-row / super-edge-row kernels run on the f32 MFMA pipe: price them against it
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach_f / 1e12, "peak": FP32_PEAK / 1e12,
-                    "unit": "TFLOP/s", "frac": ach_f / FP32_PEAK, "traffic": None,
+                    "unit": "TFLOP/s", "frac": ach_f / FP32_PEAK, "traffic": traffic,
                     "avg_launch_ms": kern[dom][0], "launches_per_step": kern[dom][1],
                     "algorithmic_GBps": ach_b / 1e9, "hbm_frac": ach_b / HBM_PEAK}
         per_gpu = value / world

@@ -338,14 +338,27 @@ __global__ __launch_bounds__(128) void k_ncsn_small_partial(GeosslNcsnWeights w,
   for (int k = threadIdx.x; k < F; k += blockDim.x) {
     const float w1 = w.in_w1[k], b1 = w.in_b1[k], w2 = w.in_w2[k];
     float s_o3 = 0.0f, s_w2 = 0.0f, s_w1 = 0.0f, s_b1 = 0.0f;
-    for (int s = lo; s < hi; ++s) {
-      const float de = demb[s], pd = sv.pd[s];
-      const float pre = fmaf(w1, pd, b1);
-      s_w2 = fmaf(de, fmaxf(pre, 0.0f), s_w2);
-      const float dp = pre > 0.0f ? de * w2 : 0.0f;
-      s_w1 = fmaf(dp, pd, s_w1);
-      s_b1 += dp;
-      if (k < H) s_o3 = fmaf(grow[s], sv.a2[(size_t)s * H + k], s_o3);
+    for (int s0 = lo; s0 < hi; s0 += 8) {
+      float de[8], pd[8], gr[8], a2v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {  // eight rows of loads in flight
+        const int s = min(s0 + u, hi - 1);
+        de[u] = demb[s];
+        pd[u] = sv.pd[s];
+        gr[u] = grow[s];
+        a2v[u] = k < H ? sv.a2[(size_t)s * H + k] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (s0 + u < hi) {
+          const float pre = fmaf(w1, pd[u], b1);
+          s_w2 = fmaf(de[u], fmaxf(pre, 0.0f), s_w2);
+          const float dp = pre > 0.0f ? de[u] * w2 : 0.0f;
+          s_w1 = fmaf(dp, pd[u], s_w1);
+          s_b1 += dp;
+          s_o3 = fmaf(gr[u], a2v[u], s_o3);
+        }
+      }
     }
     if (k < H) P[k] = s_o3;
     P[H + k] = s_w2;
@@ -391,11 +404,36 @@ __global__ __launch_bounds__(256) void k_incidence_gather(const float* __restric
   const int a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (a >= N) return;
   const int64_t p0 = inc_ptr[a], p1 = inc_ptr[a + 1];
-  for (int f = lane; f < F; f += 64) {
-    float s = accumulate ? dh[(size_t)a * F + f] : 0.0f;
-    for (int64_t p = p0; p < p1; ++p) s += dfeat[(size_t)inc_idx[p] * F + f];
-    dh[(size_t)a * F + f] = s;
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // F <= 256
+  if (accumulate) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (lane + 64 * v < F) acc[v] = dh[(size_t)a * F + lane + 64 * v];
   }
+  for (int64_t pb = p0; pb < p1; pb += 64) {
+    const int cnt = (int)min((int64_t)64, p1 - pb);
+    const int mine = lane < cnt ? inc_idx[pb + lane] : 0;  // this chunk's super-edge ids, one per lane
+    for (int q0 = 0; q0 < cnt; q0 += 8) {
+      float val[8][4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int s = __shfl(mine, min(q0 + u, cnt - 1), 64);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (lane + 64 * v < F) val[u][v] = dfeat[(size_t)s * F + lane + 64 * v];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (q0 + u < cnt) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            if (lane + 64 * v < F) acc[v] += val[u][v];
+        }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+    if (lane + 64 * v < F) dh[(size_t)a * F + lane + 64 * v] = acc[v];
 }
 
 // ------------------------------------------------------------------------------------------------- Adam
