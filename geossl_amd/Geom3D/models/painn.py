@@ -1,16 +1,23 @@
 """PaiNN behind the reference's interface (Geom3D/models/painn.py:117-269) — BASELINE config 5.
 
-Round-1 status: the constructor, parameter registration order and state_dict keys mirror the
-reference so checkpoints interchange; the HIP message/mixing kernels are not
-built yet, and because the product has no CPU/PyTorch fallback ``forward`` raises instead of
-silently computing in ATen.
+Same constructor, ``forward(x, positions, radius_edge_index, batch, return_latent=False)`` signature,
+parameter registration order and state_dict keys as the reference.  The arithmetic runs on the HIP path:
+edge geometry / radial basis / cutoff, the filter-weighted message sum per target atom (filters recomputed per
+edge from the 20 radial values, never stored), the element-wise parts of the mixing block, and the Dense layers
+on the MFMA row/column GEMMs — forward and backward, as one autograd node.  CUDA tensors only.
 """
+import ctypes as C
+import os
 from typing import Callable, Optional
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.init import xavier_uniform_, zeros_
+
+from ... import _lib, ops
+from ..._lib import call, ptr, stream
+from ...layout import get_edge_layout, get_layout
 
 
 class Dense(nn.Linear):
@@ -118,7 +125,185 @@ class PaiNN(nn.Module):
         layers.append(Dense(neurons[-2], neurons[-1], activation=None))
         return nn.Sequential(*layers)
 
+    def _params(self):
+        ps = [self.embedding.weight, self.filter_net.weight, self.filter_net.bias]
+        for blk in self.interactions:
+            n = blk.interatomic_context_net
+            ps += [n[0].weight, n[0].bias, n[1].weight, n[1].bias]
+        for blk in self.mixing:
+            n = blk.intraatomic_context_net
+            ps += [n[0].weight, n[0].bias, n[1].weight, n[1].bias, blk.mu_channel_mix.weight]
+        return ps
+
     def forward(self, x, positions, radius_edge_index, batch, return_latent=False):
-        raise NotImplementedError(
-            "PaiNN's HIP interaction/mixing kernels are not built yet (BASELINE config 5, SURVEY.md §8a P2-P4); "
-            "geossl_amd has no PyTorch fallback by design")
+        _lib.require_cuda(x, positions, radius_edge_index, batch)
+        if self.share_filters or (self.n_interactions > 1 and self.interactions[0] is self.interactions[1]):
+            raise NotImplementedError("shared_filters / shared_interactions are off the GeoSSL path")
+        if self.n_atom_basis not in (32, 64, 128) or self.radial_basis.n_rbf not in (8, 16, 20, 32):
+            raise NotImplementedError("HIP path supports n_atom_basis in (32, 64, 128) and n_rbf in (8, 16, 20, 32)")
+        if self.activation is not F.silu:
+            raise NotImplementedError("HIP path implements the reference default activation F.silu")
+        if positions.requires_grad:
+            raise NotImplementedError("gradient w.r.t. positions is not built (SURVEY.md §8(f) N3)")
+        atomic_numbers = x[:, 0] if x.dim() == 2 else x  # painn.py:226-229
+        lay = get_layout(batch)
+        el = get_edge_layout(batch, radius_edge_index, lay.B)
+        cfg = dict(F=self.n_atom_basis, L=self.n_interactions, R=self.radial_basis.n_rbf, cutoff=float(self.cutoff),
+                   offsets=self.radial_basis.offsets, widths=self.radial_basis.widths,
+                   eps=float(self.mixing[0].epsilon))
+        q = _PaiNNCore.apply(atomic_numbers, positions.contiguous(), el, cfg, *self._params())
+        from .schnet import _SegmentReduce
+        h = _SegmentReduce.apply(q, lay, self.readout)  # painn.py:266
+        if return_latent:
+            return h, q
+        return h
+
+
+def _split3(t, F_):
+    return [t[:, c * F_:(c + 1) * F_] for c in range(3)]
+
+
+class _PaiNNCore(torch.autograd.Function):
+    """(atomic numbers, positions, radius_edge_index) -> scalar atom features q (painn.py:230-255)."""
+
+    @staticmethod
+    def forward(ctx, z, pos, el, cfg, *params):
+        F_, L, R = cfg["F"], cfg["L"], cfg["R"]
+        dev, N, E = pos.device, pos.size(0), el.E
+        st = stream()
+        training = any(ctx.needs_input_grad[4:])
+        ps = [p.detach().contiguous() for p in params]
+        emb_w, fw, fb = ps[0], ps[1], ps[2]
+        inter = [ps[3 + 4 * l: 7 + 4 * l] for l in range(L)]
+        mix = [ps[3 + 4 * L + 5 * l: 8 + 4 * L + 5 * l] for l in range(L)]
+        f32 = dict(dtype=torch.float32, device=dev)
+        dirv, fcut, phi = torch.empty(max(E, 1), 3, **f32), torch.empty(max(E, 1), **f32), torch.empty(max(E, 1), R, **f32)
+        call("geossl_painn_edge_geom", ptr(pos), ptr(el.idx_i), ptr(el.idx_j), E, cfg["cutoff"], ptr(cfg["offsets"]),
+             ptr(cfg["widths"]), R, ptr(dirv), ptr(fcut), ptr(phi), st)
+        q = torch.empty(N, F_, **f32)
+        call("geossl_embedding_fwd", ptr(z), z.stride(0) if z.numel() else 1, ptr(emb_w), emb_w.size(0), N, F_, ptr(q),
+             None, st)                                                      # painn.py:247 (row 0 is the zero padding row)
+        mu = torch.zeros(N, 3, F_, **f32)                                    # :249
+        inc_ptr, inc_idx = el.inc["i"]
+        saved = []
+        for l in range(L):
+            c0w, c0b, c1w, c1b = inter[l]
+            u = ops.linear(q, c0w, bias=c0b)                                 # Dense(F, F, silu)      :27-30,53
+            s = torch.empty_like(u)
+            call("geossl_silu_fwd", ptr(u), u.numel(), ptr(s), st)
+            xc = torch.empty(N, 3 * F_, **f32)
+            for c, oc in enumerate(_split3(xc, F_)):                         # Dense(F, 3F)
+                ops.linear(s, c1w[c * F_:(c + 1) * F_], bias=c1b[c * F_:(c + 1) * F_], out=oc)
+            q2, mu2 = torch.empty_like(q), torch.empty_like(mu)
+            call("geossl_painn_interaction_fwd", ptr(q), ptr(mu), ptr(xc), ptr(el.idx_j), ptr(inc_ptr), ptr(inc_idx),
+                 ptr(phi), ptr(fcut), ptr(dirv), ptr(fw[l * 3 * F_:(l + 1) * 3 * F_]), ptr(fb[l * 3 * F_:(l + 1) * 3 * F_]),
+                 N, F_, R, ptr(q2), ptr(mu2), st)                            # :54-64
+            i0w, i0b, i1w, i1b, mw = mix[l]
+            mm = ops.linear(mu2.view(3 * N, F_), mw)                         # mu_channel_mix        :100
+            cx, dot = torch.empty(N, 2 * F_, **f32), torch.empty(N, F_, **f32)
+            call("geossl_painn_mix_pre_fwd", ptr(q2), ptr(mm), N, F_, cfg["eps"], ptr(cx), ptr(dot), st)  # :101-104
+            u1 = ops.linear(cx, i0w, bias=i0b)                               # Dense(2F, F, silu)    :105
+            s1 = torch.empty_like(u1)
+            call("geossl_silu_fwd", ptr(u1), u1.numel(), ptr(s1), st)
+            xx = torch.empty(N, 3 * F_, **f32)
+            for c, oc in enumerate(_split3(xx, F_)):                         # Dense(F, 3F)
+                ops.linear(s1, i1w[c * F_:(c + 1) * F_], bias=i1b[c * F_:(c + 1) * F_], out=oc)
+            q3, mu3 = torch.empty_like(q), torch.empty_like(mu)
+            call("geossl_painn_mix_post_fwd", ptr(q2), ptr(mu2), ptr(mm), ptr(xx), ptr(dot), N, F_, ptr(q3), ptr(mu3), st)
+            if training:
+                saved.append(dict(q=q, mu=mu, u=u, s=s, xc=xc, q2=q2, mu2=mu2, mm=mm, cx=cx, dot=dot, u1=u1, s1=s1, xx=xx))
+            q, mu = q3, mu3
+        if training:
+            ctx.el, ctx.cfg, ctx.z, ctx.ps, ctx.params = el, cfg, z, ps, params
+            ctx.geom = (dirv, fcut, phi)
+            ctx.saved = saved
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        el, cfg, ps = ctx.el, ctx.cfg, ctx.ps
+        F_, L, R = cfg["F"], cfg["L"], cfg["R"]
+        dirv, fcut, phi = ctx.geom
+        dev, N = dq.device, dq.size(0)
+        st = stream()
+        f32 = dict(dtype=torch.float32, device=dev)
+        direct = all(p.grad is not None and p.grad.is_contiguous() and p.grad.is_cuda for p in ctx.params)
+        grads = [p.grad for p in ctx.params] if direct else [torch.zeros_like(p) for p in ps]
+        acc = 1 if direct else 0
+        g_emb, g_fw, g_fb = grads[0], grads[1], grads[2]
+        inter = [ps[3 + 4 * l: 7 + 4 * l] for l in range(L)]
+        mix = [ps[3 + 4 * L + 5 * l: 8 + 4 * L + 5 * l] for l in range(L)]
+        g_inter = [grads[3 + 4 * l: 7 + 4 * l] for l in range(L)]
+        g_mix = [grads[3 + 4 * L + 5 * l: 8 + 4 * L + 5 * l] for l in range(L)]
+        inc_ptr, inc_idx = el.inc["j"]
+        dq_cur = dq.contiguous()
+        dmu_cur = torch.zeros(N, 3, F_, **f32)
+        groups = {}  # (rows, lda, ldb, ldw) -> list of problems, all with M = N = F
+
+        def add(rows, lda, ldb, ldw, A, Bm, dW, db):
+            groups.setdefault((rows, lda, ldb, ldw), []).append((A, Bm, dW, db))
+
+        nfl = _lib.load().geossl_painn_interaction_bwd_workspace_floats(N, F_, R)
+        ws = torch.empty(max(int(nfl), 1), **f32)
+        keep = []
+        for l in reversed(range(L)):
+            sv = ctx.saved[l]
+            c0w, c0b, c1w, c1b = inter[l]
+            i0w, i0b, i1w, i1b, mw = mix[l]
+            gc0w, gc0b, gc1w, gc1b = g_inter[l]
+            gi0w, gi0b, gi1w, gi1b, gmw = g_mix[l]
+            # ---- mixing block
+            dxx, dmm = torch.empty(N, 3 * F_, **f32), torch.empty(3 * N, 2 * F_, **f32)
+            call("geossl_painn_mix_post_bwd", ptr(dq_cur), ptr(dmu_cur), ptr(sv["mm"]), ptr(sv["xx"]), ptr(sv["dot"]), N,
+                 F_, ptr(dxx), ptr(dmm), st)
+            ds1 = None
+            for c, xs_ in enumerate(_split3(dxx, F_)):
+                ds1 = ops.linear(xs_, i1w[c * F_:(c + 1) * F_], transB=False, res=ds1)
+                add(N, 3 * F_, F_, F_, xs_, sv["s1"], gi1w[c * F_:(c + 1) * F_], gi1b[c * F_:(c + 1) * F_])
+            du1 = torch.empty_like(ds1)
+            call("geossl_silu_bwd", ptr(sv["u1"]), ptr(ds1), ds1.numel(), ptr(du1), st)
+            dctx = ops.linear(du1, i0w, transB=False)                      # [N][2F]
+            for c in range(2):
+                add(N, F_, 2 * F_, 2 * F_, du1, sv["cx"][:, c * F_:(c + 1) * F_], gi0w[:, c * F_:(c + 1) * F_],
+                    gi0b if c == 0 else None)
+            dq2 = torch.empty(N, F_, **f32)
+            call("geossl_painn_mix_pre_bwd", ptr(dq_cur), ptr(dctx), ptr(sv["cx"]), ptr(sv["mm"]), N, F_, ptr(dq2),
+                 ptr(dmm), st)
+            dmu2 = ops.linear(dmm, mw, transB=False, res=dmu_cur.view(3 * N, F_))   # d mu (after interaction)
+            for c in range(2):
+                add(3 * N, 2 * F_, F_, F_, dmm[:, c * F_:(c + 1) * F_], sv["mu2"].view(3 * N, F_),
+                    gmw[c * F_:(c + 1) * F_], None)
+            # ---- interaction block
+            dxc, dmu_in = torch.empty(N, 3 * F_, **f32), torch.empty(N, 3, F_, **f32)
+            call("geossl_painn_interaction_bwd", ptr(dq2), ptr(dmu2), ptr(sv["mu"]), ptr(sv["xc"]), ptr(el.idx_i),
+                 ptr(inc_ptr), ptr(inc_idx), ptr(phi), ptr(fcut), ptr(dirv), ptr(ps[1][l * 3 * F_:(l + 1) * 3 * F_]),
+                 ptr(ps[2][l * 3 * F_:(l + 1) * 3 * F_]), N, F_, R, ptr(dxc), ptr(dmu_in),
+                 ptr(g_fw[l * 3 * F_:(l + 1) * 3 * F_]), ptr(g_fb[l * 3 * F_:(l + 1) * 3 * F_]), ptr(ws), acc, st)
+            ds = None
+            for c, xs_ in enumerate(_split3(dxc, F_)):
+                ds = ops.linear(xs_, c1w[c * F_:(c + 1) * F_], transB=False, res=ds)
+                add(N, 3 * F_, F_, F_, xs_, sv["s"], gc1w[c * F_:(c + 1) * F_], gc1b[c * F_:(c + 1) * F_])
+            du = torch.empty_like(ds)
+            call("geossl_silu_bwd", ptr(sv["u"]), ptr(ds), ds.numel(), ptr(du), st)
+            dq_in = ops.linear(du, c0w, transB=False, res=dq2)               # residual q2 = q + dq
+            add(N, F_, F_, F_, du, sv["q"], gc0w, gc0b)
+            keep += [dxx, dmm, du1, dxc, du, dq2, dmu2]
+            dq_cur, dmu_cur = dq_in, dmu_in
+        for (rows, lda, ldb, ldw), probs in groups.items():
+            ops.linear_wgrad(probs, rows, F_, F_, accumulate=bool(acc), lda=lda, ldb=ldb, ldw=ldw)
+        # embedding table; padding_idx = 0 keeps row 0 without gradient (painn.py:174)
+        z = ctx.z
+        emb_w = ps[0]
+        tmp = torch.empty_like(emb_w)
+        wsf = torch.empty(int(_lib.load().geossl_embedding_bwd_workspace_floats(emb_w.size(0), F_)), **f32)
+        call("geossl_embedding_bwd", ptr(z), z.stride(0) if z.numel() else 1, ptr(dq_cur), emb_w.size(0), N, F_, ptr(tmp),
+             ptr(wsf), 0, st)
+        tmp[0].zero_()
+        if direct:
+            g_emb.add_(tmp)
+        else:
+            g_emb.copy_(tmp)
+        ctx.saved = None
+        if direct:
+            return (None, None, None, None) + (None,) * len(grads)
+        return (None, None, None, None) + tuple(grads)

@@ -65,10 +65,10 @@ PROTOTYPES = {
     "geossl_cfconv_filter_bwd": (i32, [vp, vp, vp, vp, vp, i64, P(FilterWeights), P(FilterGradIn), i32, i32, i32, vp,
                                        f32, vp, P(FilterGradOut), vp, i32, vp]),
     "geossl_cfconv_aggregate": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]),
-    "geossl_linear": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "geossl_linear": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]),
     "geossl_tn_plan": (None, [i64, i32, P(i32), P(i32)]),
     "geossl_tn_workspace_floats": (i64, [i64, i32, i32, i32]),
-    "geossl_linear_wgrad": (i32, [P(TnBatch), i32, i64, i32, i32, vp, i32, vp]),
+    "geossl_linear_wgrad": (i32, [P(TnBatch), i32, i64, i32, i32, i32, i32, i32, vp, i32, vp]),
     "geossl_embedding_fwd": (i32, [vp, i64, vp, i32, i64, i32, vp, vp, vp]),
     "geossl_embedding_bwd_workspace_floats": (i64, [i32, i32]),
     "geossl_embedding_bwd": (i32, [vp, i64, vp, i32, i64, i32, vp, vp, i32, vp]),
@@ -77,8 +77,8 @@ PROTOTYPES = {
     "geossl_axpy": (i32, [vp, vp, f32, i64, vp, vp]),
     "geossl_pair_distance": (i32, [vp, vp, vp, i64, vp, vp]),
     "geossl_super_edge_ptr": (i32, [vp, vp, vp, i64, i64, vp, vp, vp]),
-    "geossl_incidence_count": (i32, [vp, vp, vp, vp, i64, vp, vp]),
-    "geossl_incidence_fill": (i32, [vp, vp, vp, vp, i64, vp, vp, vp]),
+    "geossl_incidence_count": (i32, [vp, vp, vp, vp, i64, i32, vp, vp]),
+    "geossl_incidence_fill": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp]),
     "geossl_ddm_loss_fwd_workspace_floats": (i64, [i32]),
     "geossl_ddm_loss_fwd": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, P(NcsnWeights), i32, f32, vp, P(NcsnSaved), vp, vp]),
     "geossl_loss_reduce_workspace_floats": (i64, [i64]),
@@ -88,6 +88,18 @@ PROTOTYPES = {
     "geossl_ddm_loss_bwd_weights": (i32, [vp, vp, vp, i64, i32, P(NcsnWeights), P(NcsnSaved), vp, vp, vp, P(NcsnGrads),
                                           vp, i32, vp]),
     "geossl_incidence_gather": (i32, [vp, vp, vp, i64, i32, vp, i32, vp]),
+    "geossl_painn_edge_geom": (i32, [vp, vp, vp, i64, f32, vp, vp, i32, vp, vp, vp, vp]),
+    "geossl_silu_fwd": (i32, [vp, i64, vp, vp]),
+    "geossl_silu_bwd": (i32, [vp, vp, i64, vp, vp]),
+    "geossl_painn_interaction_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp]),
+    "geossl_painn_interaction_bwd_workspace_floats": (i64, [i64, i32, i32]),
+    "geossl_painn_interaction_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp,
+                                           vp, i32, vp]),
+    "geossl_painn_mix_pre_fwd": (i32, [vp, vp, i64, i32, f32, vp, vp, vp]),
+    "geossl_painn_mix_post_fwd": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp]),
+    "geossl_painn_mix_post_bwd": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp]),
+    "geossl_painn_mix_pre_bwd": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp]),
+    "geossl_add": (i32, [vp, vp, i64, vp, vp]),
     "geossl_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, vp]),
 }
 

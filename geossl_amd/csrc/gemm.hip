@@ -93,23 +93,28 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, con
   }
 }
 
-extern "C" int geossl_linear(const float* X, const float* W, const float* bias, const float* res, const float* tprev,
-                             float* Y, int64_t R, int K, int NO, int transB, int flags, hipStream_t stream) {
+extern "C" int geossl_linear(const float* X, int ldx, const float* W, const float* bias, const float* res,
+                             const float* tprev, float* Y, int ldy, int64_t R, int K, int NO, int transB, int flags,
+                             hipStream_t stream) {
   if (R <= 0) return 0;
   if (K % 8 != 0 || K > 256 || NO > 256) return (int)hipErrorInvalidValue;
   const int ntiles = (int)((R + 127) / 128);
   const int NOp = (NO + 31) / 32 * 32;
   // split the output columns over gridDim.y when there are too few row tiles to fill 256 CUs
-  int NC = NOp / 32;
+  int NC = (NOp % 128 == 0) ? 4 : ((NOp % 64 == 0) ? 2 : 1);
   if (NC == 4 && ntiles < 512) NC = 2;
-  if (NC == 3) NC = 1;
   const int ny = NOp / (32 * NC);
   dim3 grid(ntiles < 1024 ? ntiles : 1024, ny);
   const size_t lds = (size_t)K * (32 * NC + 1) * sizeof(float);
-  const int ldx = K, ldy = NO;
+  if (ldx < K || ldy < NO || (ldx & 3)) return (int)hipErrorInvalidValue;
 #define LAUNCH(NCV)                                                                                               \
-  hipLaunchKernelGGL((k_linear<NCV>), grid, dim3(256), lds, stream, X, W, bias, res, tprev, Y, (int)R, K, NO, ldx, \
-                     ldy, transB, flags)
+  do {                                                                                                            \
+    if (lds > 64 * 1024)                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear<NCV>),                                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                          \
+    hipLaunchKernelGGL((k_linear<NCV>), grid, dim3(256), lds, stream, X, W, bias, res, tprev, Y, (int)R, K, NO,   \
+                       ldx, ldy, transB, flags);                                                                  \
+  } while (0)
   switch (NC) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;
@@ -172,17 +177,20 @@ extern "C" int64_t geossl_tn_workspace_floats(int64_t R, int M, int N, int nprob
   return tn_workspace_floats(R, M, N, nprob);
 }
 
-extern "C" int geossl_linear_wgrad(const GeosslTnBatch* batch, int nprob, int64_t R, int M, int N, float* workspace,
-                                   int accumulate, hipStream_t stream) {
+extern "C" int geossl_linear_wgrad(const GeosslTnBatch* batch, int nprob, int64_t R, int M, int N, int lda, int ldb,
+                                   int ldw, float* workspace, int accumulate, hipStream_t stream) {
+  if (lda < M || ldb < N || ldw < N || (lda & 3) || (ldb & 3) || (M & 3) || (N & 3)) return (int)hipErrorInvalidValue;
   PlainLoader ld;
   ld.batch = *batch;
+  ld.lda = lda;
+  ld.ldb = ldb;
   TnOut out;
   for (int z = 0; z < GEOSSL_TN_MAX; ++z) {
     out.dW[z] = batch->dW[z];
     out.db[z] = batch->db[z];
     out.dd[z] = nullptr;
   }
-  return launch_tn(ld, nprob, R, M, N, out, N, 1, workspace, accumulate, stream);
+  return launch_tn(ld, nprob, R, M, N, out, ldw, 1, workspace, accumulate, stream);
 }
 
 extern "C" int geossl_abi_version(void) { return GEOSSL_ABI_VERSION; }

@@ -190,7 +190,7 @@ __global__ void k_super_edge_ptr(const int64_t* __restrict__ batch, const int64_
 template <int FILL>
 __global__ __launch_bounds__(256) void k_incidence(const int64_t* __restrict__ batch, const int64_t* __restrict__ sei0,
                                                    const int64_t* __restrict__ sei1, const int32_t* __restrict__ se_ptr,
-                                                   int N, int32_t* __restrict__ inc_cnt,
+                                                   int N, int sides, int32_t* __restrict__ inc_cnt,
                                                    const int64_t* __restrict__ inc_ptr, int32_t* __restrict__ inc_idx) {
   const int a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (a >= N) return;
@@ -202,8 +202,8 @@ __global__ __launch_bounds__(256) void k_incidence(const int64_t* __restrict__ b
   for (int s = s0 + lane; s - lane < s1; s += 64) {
     bool mu = false, mv = false;
     if (s < s1) {
-      mu = sei0[s] == a;
-      mv = sei1[s] == a;
+      mu = (sides & 1) && sei0[s] == a;
+      mv = (sides & 2) && sei1[s] == a;
     }
     const unsigned long long bu = __ballot(mu), bv = __ballot(mv);
     if (FILL) {
@@ -294,20 +294,21 @@ extern "C" int geossl_super_edge_ptr(const int64_t* batch, const int64_t* sei0, 
 }
 
 extern "C" int geossl_incidence_count(const int64_t* batch, const int64_t* sei0, const int64_t* sei1,
-                                      const int32_t* se_ptr, int64_t N, int32_t* inc_cnt, hipStream_t stream) {
+                                      const int32_t* se_ptr, int64_t N, int sides, int32_t* inc_cnt,
+                                      hipStream_t stream) {
   if (N <= 0) return 0;
   hipLaunchKernelGGL((k_incidence<0>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, batch, sei0, sei1, se_ptr,
-                     (int)N, inc_cnt, nullptr, nullptr);
+                     (int)N, sides, inc_cnt, nullptr, nullptr);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int geossl_incidence_fill(const int64_t* batch, const int64_t* sei0, const int64_t* sei1,
-                                     const int32_t* se_ptr, int64_t N, const int64_t* inc_ptr, int32_t* inc_idx,
-                                     hipStream_t stream) {
+                                     const int32_t* se_ptr, int64_t N, int sides, const int64_t* inc_ptr,
+                                     int32_t* inc_idx, hipStream_t stream) {
   if (N <= 0) return 0;
   hipLaunchKernelGGL((k_incidence<1>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, batch, sei0, sei1, se_ptr,
-                     (int)N, nullptr, inc_ptr, inc_idx);
+                     (int)N, sides, nullptr, inc_ptr, inc_idx);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

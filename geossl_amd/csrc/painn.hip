@@ -1,0 +1,395 @@
+// PaiNN edge and atom kernels (BASELINE config 5): replaces, for the hot path, the per-edge arithmetic of
+// PaiNN.forward / PaiNNInteraction / PaiNNMixing (Geom3D/models/painn.py:32-66,91-114,230-253) and their autograd.
+// The Dense layers around them run on geossl_linear / geossl_linear_wgrad.
+//
+// Edge work is organised per atom through two incidence lists built once per batch from radius_edge_index
+// (idx_i = row 0, idx_j = row 1): edges by idx_i (forward scatter, painn.py:59,61) and edges by idx_j (backward).
+// One block per atom, one thread per feature: the filter value W_ij = (phi(d) W^T + b) * fcut of the thread's three
+// channels is recomputed from the 20 radial basis values on the fly (never stored per edge), messages are summed in
+// edge order in registers — no atomics, bit-reproducible.
+#include "common.h"
+#include "geossl_hip.h"
+
+using namespace geossl;
+
+namespace {
+
+constexpr int RMAX = 32;  // max radial basis functions
+
+inline int grid1d(int64_t n, int block, int cap = 4096) {
+  int64_t g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// painn.py:232-239 + painn_utils.py:99-103,152-154
+__global__ void k_painn_edge_geom(const float* __restrict__ pos, const int64_t* __restrict__ idx_i,
+                                  const int64_t* __restrict__ idx_j, int64_t E, float cutoff,
+                                  const float* __restrict__ offsets, const float* __restrict__ widths, int R,
+                                  float* __restrict__ dir, float* __restrict__ fcut, float* __restrict__ phi) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx_i[e], j = idx_j[e];
+    const float rx = pos[3 * i] - pos[3 * j], ry = pos[3 * i + 1] - pos[3 * j + 1], rz = pos[3 * i + 2] - pos[3 * j + 2];
+    const float d = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz)));
+    dir[3 * e] = rx / d;
+    dir[3 * e + 1] = ry / d;
+    dir[3 * e + 2] = rz / d;
+    const float c = 0.5f * (cosf(__fdiv_rn(__fmul_rn(d, GEOSSL_PI_F), cutoff)) + 1.0f);
+    fcut[e] = d < cutoff ? c : 0.0f;
+    for (int r = 0; r < R; ++r) {
+      const float w = widths[r];
+      const float coeff = -0.5f / (w * w);
+      const float diff = d - offsets[r];
+      phi[e * R + r] = expf(coeff * (diff * diff));
+    }
+  }
+}
+
+// silu (F.silu) and its derivative
+__global__ void k_silu_fwd(const float* __restrict__ u, int64_t n, float* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = u[i];
+    y[i] = x / (1.0f + expf(-x));
+  }
+}
+__global__ void k_silu_bwd(const float* __restrict__ u, const float* __restrict__ dy, int64_t n,
+                           float* __restrict__ du) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = u[i], s = 1.0f / (1.0f + expf(-x));
+    du[i] = dy[i] * (s * (1.0f + x * (1.0f - s)));
+  }
+}
+
+// ------------------------------------------------------------------------------------ interaction, forward
+// q_out[i] = q[i] + sum_e dq_e, mu_out[i] = mu[i] + sum_e (dmuR_e * dir_e + dmumu_e * mu[j_e]),  e over edges with
+// idx_i[e] == i in ascending e;  [dq, dmuR, dmumu]_e = W_e * x[j_e]  (painn.py:54-64)
+template <int R>
+__global__ __launch_bounds__(128) void k_painn_interaction_fwd(
+    const float* __restrict__ q, const float* __restrict__ mu, const float* __restrict__ xc,
+    const int64_t* __restrict__ idx_j, const int64_t* __restrict__ inc_ptr, const int32_t* __restrict__ inc_idx,
+    const float* __restrict__ phi, const float* __restrict__ fcut, const float* __restrict__ dir,
+    const float* __restrict__ Wf, const float* __restrict__ bf, int N, int F, float* __restrict__ q_out,
+    float* __restrict__ mu_out) {
+  const int i = blockIdx.x, f = threadIdx.x;
+  if (i >= N || f >= F) return;
+  float w0[R], w1[R], w2[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    w0[r] = Wf[(size_t)f * R + r];
+    w1[r] = Wf[(size_t)(F + f) * R + r];
+    w2[r] = Wf[(size_t)(2 * F + f) * R + r];
+  }
+  const float b0 = bf[f], b1 = bf[F + f], b2 = bf[2 * F + f];
+  float dq = 0.0f, dm0 = 0.0f, dm1 = 0.0f, dm2 = 0.0f;
+  const int64_t p0 = inc_ptr[i], p1 = inc_ptr[i + 1];
+  for (int64_t p = p0; p < p1; ++p) {
+    const int e = __builtin_amdgcn_readfirstlane(inc_idx[p]);  // uniform: edge data comes through scalar loads
+    const int64_t j = idx_j[e];
+    const float* __restrict__ ph = phi + (size_t)e * R;
+    float W0 = b0, W1 = b1, W2 = b2;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float pr = ph[r];
+      W0 = fmaf(pr, w0[r], W0);
+      W1 = fmaf(pr, w1[r], W1);
+      W2 = fmaf(pr, w2[r], W2);
+    }
+    const float fc = fcut[e];
+    W0 *= fc; W1 *= fc; W2 *= fc;                                  // painn.py:241
+    const float* __restrict__ xj = xc + (size_t)j * 3 * F;
+    const float x0 = W0 * xj[f], x1 = W1 * xj[F + f], x2 = W2 * xj[2 * F + f];  // :56
+    const float* __restrict__ mj = mu + (size_t)j * 3 * F;
+    dq += x0;                                                      // :59
+    dm0 += x1 * dir[3 * e] + x2 * mj[f];                           // :60-61
+    dm1 += x1 * dir[3 * e + 1] + x2 * mj[F + f];
+    dm2 += x1 * dir[3 * e + 2] + x2 * mj[2 * F + f];
+  }
+  q_out[(size_t)i * F + f] = q[(size_t)i * F + f] + dq;            // :63
+  float* mo = mu_out + (size_t)i * 3 * F;
+  const float* mi = mu + (size_t)i * 3 * F;
+  mo[f] = mi[f] + dm0;                                             // :64
+  mo[F + f] = mi[F + f] + dm1;
+  mo[2 * F + f] = mi[2 * F + f] + dm2;
+}
+
+// ----------------------------------------------------------------------------------- interaction, backward
+// Persistent blocks over source atoms j (edges with idx_j[e] == j, ascending e).  Per atom: gradient of the context
+// features x[j] and of mu[j]; across all atoms of the block: the filter-network weight/bias gradient partials.
+template <int R>
+__global__ __launch_bounds__(128) void k_painn_interaction_bwd(
+    const float* __restrict__ dq_out, const float* __restrict__ dmu_out, const float* __restrict__ mu,
+    const float* __restrict__ xc, const int64_t* __restrict__ idx_i, const int64_t* __restrict__ inc_ptr,
+    const int32_t* __restrict__ inc_idx, const float* __restrict__ phi, const float* __restrict__ fcut,
+    const float* __restrict__ dir, const float* __restrict__ Wf, const float* __restrict__ bf, int N, int F,
+    float* __restrict__ dxc, float* __restrict__ dmu_in, float* __restrict__ partial_w, float* __restrict__ partial_b) {
+  const int f = threadIdx.x;
+  if (f >= F) return;
+  float w0[R], w1[R], w2[R], g0[R], g1[R], g2[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    w0[r] = Wf[(size_t)f * R + r];
+    w1[r] = Wf[(size_t)(F + f) * R + r];
+    w2[r] = Wf[(size_t)(2 * F + f) * R + r];
+    g0[r] = g1[r] = g2[r] = 0.0f;
+  }
+  const float b0 = bf[f], b1 = bf[F + f], b2 = bf[2 * F + f];
+  float gb0 = 0.0f, gb1 = 0.0f, gb2 = 0.0f;
+  for (int j = blockIdx.x; j < N; j += gridDim.x) {
+    const float* __restrict__ xj = xc + (size_t)j * 3 * F;
+    const float* __restrict__ mj = mu + (size_t)j * 3 * F;
+    const float xj0 = xj[f], xj1 = xj[F + f], xj2 = xj[2 * F + f];
+    const float m0 = mj[f], m1 = mj[F + f], m2 = mj[2 * F + f];
+    float dx0 = 0.0f, dx1 = 0.0f, dx2 = 0.0f, dmj0 = 0.0f, dmj1 = 0.0f, dmj2 = 0.0f;
+    const int64_t p0 = inc_ptr[j], p1 = inc_ptr[j + 1];
+    for (int64_t p = p0; p < p1; ++p) {
+      const int e = __builtin_amdgcn_readfirstlane(inc_idx[p]);
+      const int64_t i = idx_i[e];
+      const float* __restrict__ ph = phi + (size_t)e * R;
+      float pr[R];
+      float W0 = b0, W1 = b1, W2 = b2;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        pr[r] = ph[r];
+        W0 = fmaf(pr[r], w0[r], W0);
+        W1 = fmaf(pr[r], w1[r], W1);
+        W2 = fmaf(pr[r], w2[r], W2);
+      }
+      const float fc = fcut[e];
+      W0 *= fc; W1 *= fc; W2 *= fc;
+      const float gq = dq_out[(size_t)i * F + f];
+      const float* __restrict__ gm = dmu_out + (size_t)i * 3 * F;
+      const float gm0 = gm[f], gm1 = gm[F + f], gm2 = gm[2 * F + f];
+      const float s1 = gm0 * dir[3 * e] + gm1 * dir[3 * e + 1] + gm2 * dir[3 * e + 2];
+      const float s2 = gm0 * m0 + gm1 * m1 + gm2 * m2;
+      dx0 = fmaf(gq, W0, dx0);
+      dx1 = fmaf(s1, W1, dx1);
+      dx2 = fmaf(s2, W2, dx2);
+      const float x2 = W2 * xj2;
+      dmj0 = fmaf(gm0, x2, dmj0);
+      dmj1 = fmaf(gm1, x2, dmj1);
+      dmj2 = fmaf(gm2, x2, dmj2);
+      // W_c = (b_c + sum_r phi_r w_c[r]) * fcut
+      const float t0 = gq * xj0 * fc, t1 = s1 * xj1 * fc, t2 = s2 * xj2 * fc;
+      gb0 += t0; gb1 += t1; gb2 += t2;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        g0[r] = fmaf(t0, pr[r], g0[r]);
+        g1[r] = fmaf(t1, pr[r], g1[r]);
+        g2[r] = fmaf(t2, pr[r], g2[r]);
+      }
+    }
+    float* dxo = dxc + (size_t)j * 3 * F;
+    dxo[f] = dx0; dxo[F + f] = dx1; dxo[2 * F + f] = dx2;
+    float* dmo = dmu_in + (size_t)j * 3 * F;
+    const float* __restrict__ gmj = dmu_out + (size_t)j * 3 * F;
+    dmo[f] = gmj[f] + dmj0;           // residual mu_out = mu + dmu  plus the edges that read mu[j]
+    dmo[F + f] = gmj[F + f] + dmj1;
+    dmo[2 * F + f] = gmj[2 * F + f] + dmj2;
+  }
+  float* pw = partial_w + (size_t)blockIdx.x * 3 * F * R;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    pw[(size_t)f * R + r] = g0[r];
+    pw[(size_t)(F + f) * R + r] = g1[r];
+    pw[(size_t)(2 * F + f) * R + r] = g2[r];
+  }
+  float* pb = partial_b + (size_t)blockIdx.x * 3 * F;
+  pb[f] = gb0; pb[F + f] = gb1; pb[2 * F + f] = gb2;
+}
+
+__global__ void k_partial_sum(const float* __restrict__ partial, int nblk, int len, float* __restrict__ out,
+                              int accumulate) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+    float s = accumulate ? out[i] : 0.0f;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * len + i];
+    out[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ mixing
+// mm = mu_channel_mix(mu) [N][3][2F] -> ctx = [q, |mu_V|] [N][2F], dot = sum_xyz mu_V*mu_W  (painn.py:100-104,110)
+__global__ void k_painn_mix_pre_fwd(const float* __restrict__ q, const float* __restrict__ mm, int64_t N, int F,
+                                    float eps, float* __restrict__ ctx, float* __restrict__ dot) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * F; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = t / F;
+    const int f = (int)(t - a * F);
+    const float* m = mm + a * 6 * F;
+    const float v0 = m[f], v1 = m[2 * F + f], v2 = m[4 * F + f];
+    const float w0 = m[F + f], w1 = m[3 * F + f], w2 = m[5 * F + f];
+    ctx[a * 2 * F + f] = q[t];
+    ctx[a * 2 * F + F + f] = sqrtf(v0 * v0 + v1 * v1 + v2 * v2 + eps);
+    dot[t] = v0 * w0 + v1 * w1 + v2 * w2;
+  }
+}
+// q' = q + dq_intra + dqmu_intra*dot ; mu' = mu + dmu_intra*mu_W   (painn.py:107-113)
+__global__ void k_painn_mix_post_fwd(const float* __restrict__ q, const float* __restrict__ mu,
+                                     const float* __restrict__ mm, const float* __restrict__ xx,
+                                     const float* __restrict__ dot, int64_t N, int F, float* __restrict__ q_out,
+                                     float* __restrict__ mu_out) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * F; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = t / F;
+    const int f = (int)(t - a * F);
+    const float* x = xx + a * 3 * F;
+    const float* m = mm + a * 6 * F;
+    q_out[t] = q[t] + x[f] + x[2 * F + f] * dot[t];
+    const float dmi = x[F + f];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mu_out[a * 3 * F + k * F + f] = mu[a * 3 * F + k * F + f] + dmi * m[2 * k * F + F + f];
+  }
+}
+// backward of mix_post: dxx [N][3F], dmm [N][3][2F] (without the |mu_V| term, added by mix_pre_bwd)
+__global__ void k_painn_mix_post_bwd(const float* __restrict__ dq_new, const float* __restrict__ dmu_new,
+                                     const float* __restrict__ mm, const float* __restrict__ xx,
+                                     const float* __restrict__ dot, int64_t N, int F, float* __restrict__ dxx,
+                                     float* __restrict__ dmm) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * F; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = t / F;
+    const int f = (int)(t - a * F);
+    const float* x = xx + a * 3 * F;
+    const float* m = mm + a * 6 * F;
+    const float gq = dq_new[t];
+    const float ddot = gq * x[2 * F + f];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float gm = dmu_new[a * 3 * F + k * F + f];
+      const float v = m[2 * k * F + f], w = m[2 * k * F + F + f];
+      s += gm * w;
+      dmm[a * 6 * F + 2 * k * F + f] = ddot * w;                    // d mu_V (dot term)
+      dmm[a * 6 * F + 2 * k * F + F + f] = gm * x[F + f] + ddot * v;  // d mu_W
+    }
+    dxx[a * 3 * F + f] = gq;
+    dxx[a * 3 * F + F + f] = s;
+    dxx[a * 3 * F + 2 * F + f] = gq * dot[t];
+  }
+}
+// backward of mix_pre: dq_in = dq_new + dctx[:, :F]; dmm_V += dctx[:, F:] * mu_V / |mu_V|
+__global__ void k_painn_mix_pre_bwd(const float* __restrict__ dq_new, const float* __restrict__ dctx,
+                                    const float* __restrict__ ctx, const float* __restrict__ mm, int64_t N, int F,
+                                    float* __restrict__ dq_in, float* __restrict__ dmm) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * F; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = t / F;
+    const int f = (int)(t - a * F);
+    dq_in[t] = dq_new[t] + dctx[a * 2 * F + f];
+    const float gvn = dctx[a * 2 * F + F + f] / ctx[a * 2 * F + F + f];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dmm[a * 6 * F + 2 * k * F + f] += gvn * mm[a * 6 * F + 2 * k * F + f];
+  }
+}
+
+__global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = a[i] + b[i];
+}
+
+}  // namespace
+
+extern "C" int geossl_painn_edge_geom(const float* pos, const int64_t* idx_i, const int64_t* idx_j, int64_t E,
+                                      float cutoff, const float* offsets, const float* widths, int R, float* dir,
+                                      float* fcut, float* phi, hipStream_t stream) {
+  if (E <= 0) return 0;
+  if (R > RMAX) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_painn_edge_geom, dim3(grid1d(E, 256)), dim3(256), 0, stream, pos, idx_i, idx_j, E, cutoff, offsets,
+                     widths, R, dir, fcut, phi);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_silu_fwd(const float* u, int64_t n, float* y, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_silu_fwd, dim3(grid1d(n, 256)), dim3(256), 0, stream, u, n, y);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int geossl_silu_bwd(const float* u, const float* dy, int64_t n, float* du, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_silu_bwd, dim3(grid1d(n, 256)), dim3(256), 0, stream, u, dy, n, du);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+#define GEOSSL_PAINN_DISPATCH_R(KERNEL, ...)                                   \
+  do {                                                                         \
+    if (R == 20) hipLaunchKernelGGL((KERNEL<20>), __VA_ARGS__);                \
+    else if (R == 16) hipLaunchKernelGGL((KERNEL<16>), __VA_ARGS__);           \
+    else if (R == 8) hipLaunchKernelGGL((KERNEL<8>), __VA_ARGS__);             \
+    else if (R == 32) hipLaunchKernelGGL((KERNEL<32>), __VA_ARGS__);           \
+    else return (int)hipErrorInvalidValue;                                     \
+  } while (0)
+
+extern "C" int geossl_painn_interaction_fwd(const float* q, const float* mu, const float* xc, const int64_t* idx_j,
+                                            const int64_t* inc_ptr, const int32_t* inc_idx, const float* phi,
+                                            const float* fcut, const float* dir, const float* Wf, const float* bf,
+                                            int64_t N, int F, int R, float* q_out, float* mu_out, hipStream_t stream) {
+  if (N <= 0) return 0;
+  if (F > 128) return (int)hipErrorInvalidValue;
+  GEOSSL_PAINN_DISPATCH_R(k_painn_interaction_fwd, dim3((unsigned)N), dim3(F > 64 ? 128 : 64), 0, stream, q, mu, xc,
+                          idx_j, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, (int)N, F, q_out, mu_out);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+#define GEOSSL_PAINN_BWD_BLOCKS 2048
+extern "C" int64_t geossl_painn_interaction_bwd_workspace_floats(int64_t N, int F, int R) {
+  const int64_t nb = N < GEOSSL_PAINN_BWD_BLOCKS ? N : GEOSSL_PAINN_BWD_BLOCKS;
+  return nb * (3 * (int64_t)F * R + 3 * F);
+}
+
+extern "C" int geossl_painn_interaction_bwd(const float* dq_out, const float* dmu_out, const float* mu, const float* xc,
+                                            const int64_t* idx_i, const int64_t* inc_ptr, const int32_t* inc_idx,
+                                            const float* phi, const float* fcut, const float* dir, const float* Wf,
+                                            const float* bf, int64_t N, int F, int R, float* dxc, float* dmu_in,
+                                            float* dWf, float* dbf, float* workspace, int accumulate,
+                                            hipStream_t stream) {
+  if (N <= 0) return 0;
+  if (F > 128) return (int)hipErrorInvalidValue;
+  const int nb = (int)(N < GEOSSL_PAINN_BWD_BLOCKS ? N : GEOSSL_PAINN_BWD_BLOCKS);
+  float* pw = workspace;
+  float* pb = workspace + (size_t)nb * 3 * F * R;
+  GEOSSL_PAINN_DISPATCH_R(k_painn_interaction_bwd, dim3(nb), dim3(F > 64 ? 128 : 64), 0, stream, dq_out, dmu_out, mu, xc,
+                          idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, (int)N, F, dxc, dmu_in, pw, pb);
+  GEOSSL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_partial_sum, dim3(grid1d(3 * F * R, 128)), dim3(128), 0, stream, pw, nb, 3 * F * R, dWf, accumulate);
+  hipLaunchKernelGGL(k_partial_sum, dim3(grid1d(3 * F, 128)), dim3(128), 0, stream, pb, nb, 3 * F, dbf, accumulate);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_painn_mix_pre_fwd(const float* q, const float* mm, int64_t N, int F, float eps, float* ctx,
+                                        float* dot, hipStream_t stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(k_painn_mix_pre_fwd, dim3(grid1d(N * F, 256)), dim3(256), 0, stream, q, mm, N, F, eps, ctx, dot);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int geossl_painn_mix_post_fwd(const float* q, const float* mu, const float* mm, const float* xx,
+                                         const float* dot, int64_t N, int F, float* q_out, float* mu_out,
+                                         hipStream_t stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(k_painn_mix_post_fwd, dim3(grid1d(N * F, 256)), dim3(256), 0, stream, q, mu, mm, xx, dot, N, F, q_out,
+                     mu_out);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int geossl_painn_mix_post_bwd(const float* dq_new, const float* dmu_new, const float* mm, const float* xx,
+                                         const float* dot, int64_t N, int F, float* dxx, float* dmm,
+                                         hipStream_t stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(k_painn_mix_post_bwd, dim3(grid1d(N * F, 256)), dim3(256), 0, stream, dq_new, dmu_new, mm, xx, dot, N,
+                     F, dxx, dmm);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int geossl_painn_mix_pre_bwd(const float* dq_new, const float* dctx, const float* ctx, const float* mm,
+                                        int64_t N, int F, float* dq_in, float* dmm, hipStream_t stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(k_painn_mix_pre_bwd, dim3(grid1d(N * F, 256)), dim3(256), 0, stream, dq_new, dctx, ctx, mm, N, F,
+                     dq_in, dmm);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int geossl_add(const float* a, const float* b, int64_t n, float* out, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_add, dim3(grid1d(n, 256)), dim3(256), 0, stream, a, b, n, out);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}

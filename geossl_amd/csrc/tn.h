@@ -186,11 +186,12 @@ __device__ __forceinline__ void load_rows_f4(const float* __restrict__ src, int 
 // Plain loader: A_z [R][M], B_z [R][N] row-major in global memory (M, N multiples of 4).
 struct PlainLoader {
   GeosslTnBatch batch;
+  int lda, ldb;  // row strides of A_z / B_z (>= M / N)
   template <int MP, int NP>
   __device__ __forceinline__ void load(int z, int row0, int row_end, int M, int N, float* As, float* Bs, float* es,
                                        int tid) const {
-    load_rows_f4<MP>(batch.A[z], M, M, row0, row_end, As, tid);
-    load_rows_f4<NP>(batch.B[z], N, N, row0, row_end, Bs, tid);
+    load_rows_f4<MP>(batch.A[z], lda, M, row0, row_end, As, tid);
+    load_rows_f4<NP>(batch.B[z], ldb, N, row0, row_end, Bs, tid);
   }
 };
 

@@ -82,12 +82,12 @@ class SuperEdgeLayout:
         call("geossl_super_edge_ptr", ptr(self.batch), ptr(self.sei0), ptr(self.sei1), self.S, self.B,
              ptr(self.se_ptr), ptr(self.stats), stream())
         inc_cnt = torch.zeros(self.N, dtype=torch.int32, device=dev)
-        call("geossl_incidence_count", ptr(self.batch), ptr(self.sei0), ptr(self.sei1), ptr(self.se_ptr), self.N,
+        call("geossl_incidence_count", ptr(self.batch), ptr(self.sei0), ptr(self.sei1), ptr(self.se_ptr), self.N, 3,
              ptr(inc_cnt), stream())
         self.inc_ptr = torch.zeros(self.N + 1, dtype=torch.int64, device=dev)
         self.inc_ptr[1:] = torch.cumsum(inc_cnt, 0, dtype=torch.int64)
         self.inc_idx = torch.empty(2 * self.S, dtype=torch.int32, device=dev)
-        call("geossl_incidence_fill", ptr(self.batch), ptr(self.sei0), ptr(self.sei1), ptr(self.se_ptr), self.N,
+        call("geossl_incidence_fill", ptr(self.batch), ptr(self.sei0), ptr(self.sei1), ptr(self.se_ptr), self.N, 3,
              ptr(self.inc_ptr), ptr(self.inc_idx), stream())
         if validate and int(self.stats[1].item()):
             raise ValueError("super_edge_index must be grouped by molecule in batch order with both ends in "
@@ -101,4 +101,49 @@ def get_super_edge_layout(batch, super_edge_index, num_graphs):
             or lay.S != super_edge_index.size(1) or lay.N != batch.numel()):
         lay = SuperEdgeLayout(batch, super_edge_index, num_graphs)
         super_edge_index._geossl_layout = lay
+    return lay
+
+
+class EdgeLayout:
+    """Per-batch bookkeeping of PaiNN's precomputed ``radius_edge_index`` (datasets_3D_Radius.py:120, collated with
+    node offsets by dataloaders_AtomTuple.py:64-65): the edges grouped by idx_i = row 0 (forward scatter,
+    painn.py:59,61) and by idx_j = row 1 (backward), each in ascending edge order."""
+
+    def __init__(self, batch, edge_index, num_graphs, validate=True):
+        _lib.require_cuda(batch, edge_index)
+        if edge_index.dtype != torch.long or edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError("radius_edge_index must be int64 [2, E]")
+        self.idx_i = edge_index[0].contiguous()
+        self.idx_j = edge_index[1].contiguous()
+        batch = batch.contiguous()
+        self.E, self.N, self.B = int(edge_index.size(1)), int(batch.numel()), int(num_graphs)
+        dev = batch.device
+        e_ptr = torch.zeros(self.B + 1, dtype=torch.int32, device=dev)
+        stats = torch.zeros(2, dtype=torch.int64, device=dev)
+        st = stream()
+        call("geossl_super_edge_ptr", ptr(batch), ptr(self.idx_i), ptr(self.idx_j), self.E, self.B, ptr(e_ptr),
+             ptr(stats), st)
+        self.inc = {}
+        for name, sides in (("i", 1), ("j", 2)):
+            cnt = torch.zeros(self.N, dtype=torch.int32, device=dev)
+            call("geossl_incidence_count", ptr(batch), ptr(self.idx_i), ptr(self.idx_j), ptr(e_ptr), self.N, sides,
+                 ptr(cnt), st)
+            iptr = torch.zeros(self.N + 1, dtype=torch.int64, device=dev)
+            iptr[1:] = torch.cumsum(cnt, 0, dtype=torch.int64)
+            idx = torch.empty(max(self.E, 1), dtype=torch.int32, device=dev)
+            call("geossl_incidence_fill", ptr(batch), ptr(self.idx_i), ptr(self.idx_j), ptr(e_ptr), self.N, sides,
+                 ptr(iptr), ptr(idx), st)
+            self.inc[name] = (iptr, idx)
+        if validate and self.E > 0 and int(stats[1].item()):
+            raise ValueError("radius_edge_index must be grouped by molecule in batch order with both ends in the "
+                             "same molecule (collated MoleculeDataset3DRadius output is)")
+        self._versions = (batch._version, edge_index._version)
+
+
+def get_edge_layout(batch, edge_index, num_graphs):
+    lay = getattr(edge_index, "_geossl_layout", None)
+    if (lay is None or lay._versions != (batch._version, edge_index._version) or lay.E != edge_index.size(1)
+            or lay.N != batch.numel()):
+        lay = EdgeLayout(batch, edge_index, num_graphs)
+        edge_index._geossl_layout = lay
     return lay

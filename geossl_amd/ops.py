@@ -73,10 +73,13 @@ def gaussian_smearing(dist, offset, coeff):
     return out
 
 
-def linear(x, w, bias=None, res=None, tprev=None, transB=True, flags=0, out=None):
-    """Y = epi(X @ Bm); transB: w is torch layout [NO][K] (forward) else [K][NO] (dX = dY @ W)."""
-    R, K = x.shape
-    NO = w.size(0) if transB else w.size(1)
+def linear(x, w, bias=None, res=None, tprev=None, transB=True, flags=0, out=None, K=None, NO=None):
+    """Y = epi(X @ Bm); transB: w is torch layout [NO][K] (forward) else [K][NO] (dX = dY @ W).
+    x / out may be column slices of wider row-major tensors (row stride = x.stride(0) / out.stride(0));
+    K / NO default to the slice widths."""
+    R = x.size(0)
+    K = x.size(1) if K is None else K
+    NO = (w.size(0) if transB else w.size(1)) if NO is None else NO
     if out is None:
         out = torch.empty(R, NO, dtype=torch.float32, device=x.device)
     if bias is not None:
@@ -85,14 +88,19 @@ def linear(x, w, bias=None, res=None, tprev=None, transB=True, flags=0, out=None
         flags |= _lib.EPI_RESIDUAL
     if tprev is not None:
         flags |= _lib.EPI_MUL_DSSP
-    call("geossl_linear", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(tprev), ptr(out), R, K, NO, 1 if transB else 0,
-         flags, stream())
+    assert x.stride(1) == 1 and out.stride(1) == 1
+    for aux in (res, tprev):
+        assert aux is None or (aux.stride(0) == out.stride(0) and aux.stride(1) == 1)
+    call("geossl_linear", ptr(x), x.stride(0), ptr(w), ptr(bias), ptr(res), ptr(tprev), ptr(out), out.stride(0), R, K, NO,
+         1 if transB else 0, flags, stream())
     return out
 
 
-def linear_wgrad(problems, R, M, N, accumulate=False):
-    """Batched weight gradients.  problems: list of (A [R,M], B [R,N], dW [M,N], db [M] or None)."""
+def linear_wgrad(problems, R, M, N, accumulate=False, lda=None, ldb=None, ldw=None):
+    """Batched weight gradients.  problems: list of (A [R,M], B [R,N], dW [M,N], db [M] or None); lda/ldb/ldw are
+    the row strides when A / B / dW are column slices of wider tensors."""
     dev = problems[0][0].device
+    lda, ldb, ldw = lda or M, ldb or N, ldw or N
     for lo in range(0, len(problems), _lib.TN_MAX):
         chunk = problems[lo:lo + _lib.TN_MAX]
         tb = _lib.TnBatch()
@@ -100,7 +108,8 @@ def linear_wgrad(problems, R, M, N, accumulate=False):
             tb.A[i], tb.B[i], tb.dW[i], tb.db[i] = ptr(A), ptr(Bm), ptr(dW), ptr(db)
         nfl = _lib.load().geossl_tn_workspace_floats(R, M, N, len(chunk))
         ws = torch.empty(nfl, dtype=torch.float32, device=dev)
-        call("geossl_linear_wgrad", C.byref(tb), len(chunk), R, M, N, ptr(ws), 1 if accumulate else 0, stream())
+        call("geossl_linear_wgrad", C.byref(tb), len(chunk), R, M, N, lda, ldb, ldw, ptr(ws), 1 if accumulate else 0,
+             stream())
 
 
 def aggregate(x, Wf_l, pair_flag, layout, swap=False):

@@ -115,11 +115,13 @@ int geossl_cfconv_aggregate(const float* x, const float* Wf, const uint8_t* pair
 
 /* ---- atom-row Linear — ATen Linear at schnet.py:99,101,166,189,191 and its autograd.
  * Y[r][n] = epi(sum_k X[r][k] * Bm[k][n]); transB=1: W is torch layout [NO][K] (forward);
- * transB=0: W is [K][NO] (backward w.r.t. input: dX = dY W).  K % 8 == 0, K,NO <= 256.                      */
-int geossl_linear(const float* X, const float* W, const float* bias, const float* res, const float* tprev, float* Y,
-                  int64_t R, int K, int NO, int transB, int flags, hipStream_t stream);
+ * transB=0: W is [K][NO] (backward w.r.t. input: dX = dY W).  K % 8 == 0, K,NO <= 256.  ldx / ldy: row strides of
+ * X and of Y (res and tprev share ldy), so column slices of wider tensors can be read / written in place.   */
+int geossl_linear(const float* X, int ldx, const float* W, const float* bias, const float* res, const float* tprev,
+                  float* Y, int ldy, int64_t R, int K, int NO, int transB, int flags, hipStream_t stream);
 
-/* batched weight gradients: dW_z[m][n] (+)= sum_r A_z[r][m]*B_z[r][n], db_z[m] (+)= sum_r A_z[r][m]          */
+/* batched weight gradients: dW_z[m][n] (+)= sum_r A_z[r][m]*B_z[r][n], db_z[m] (+)= sum_r A_z[r][m];
+ * lda / ldb / ldw: row strides of A_z, B_z, dW_z (M, N <= 128 per problem: wider layers are tiled by the caller)  */
 typedef struct {
   const float* A[GEOSSL_TN_MAX];
   const float* B[GEOSSL_TN_MAX];
@@ -131,8 +133,8 @@ typedef struct {
 } GeosslReduceBatch;
 void geossl_tn_plan(int64_t R, int nprob, int* chunk, int* nblk);
 int64_t geossl_tn_workspace_floats(int64_t R, int M, int N, int nprob);
-int geossl_linear_wgrad(const GeosslTnBatch* batch, int nprob, int64_t R, int M, int N, float* workspace,
-                        int accumulate, hipStream_t stream);
+int geossl_linear_wgrad(const GeosslTnBatch* batch, int nprob, int64_t R, int M, int N, int lda, int ldb, int ldw,
+                        float* workspace, int accumulate, hipStream_t stream);
 
 /* ---- embedding — torch.nn.Embedding at schnet.py:89 (z is a strided int64 view x[:,0])                     */
 int geossl_embedding_fwd(const int64_t* z, int64_t z_stride, const float* table, int num_classes, int64_t N, int F,
@@ -157,13 +159,15 @@ int geossl_pair_distance(const float* pos, const int64_t* sei0, const int64_t* s
 /* per-batch bookkeeping for the NCSN head: se_ptr[B+1] = first super-edge of every molecule (needs
  * batch[sei0] non-decreasing and both ends in one molecule: true for collated batches),
  * stats = {max(edge2graph)+1 (the divisor of NCSN.py:212), 1 if the ordering assumption fails}; and the
- * atom -> incident super-edge lists (inc_ptr from an exclusive scan of inc_cnt by the caller).              */
+ * atom -> incident (super-)edge lists (inc_ptr from an exclusive scan of inc_cnt by the caller); sides bit0 /
+ * bit1 select matches on row 0 / row 1 of the index (3 = both, the NCSN case; 1 or 2 = PaiNN's per-target /
+ * per-source edge lists).                                                                                     */
 int geossl_super_edge_ptr(const int64_t* batch, const int64_t* sei0, const int64_t* sei1, int64_t S, int64_t B,
                           int32_t* se_ptr, int64_t* stats, hipStream_t stream);
 int geossl_incidence_count(const int64_t* batch, const int64_t* sei0, const int64_t* sei1, const int32_t* se_ptr,
-                           int64_t N, int32_t* inc_cnt, hipStream_t stream);
+                           int64_t N, int sides, int32_t* inc_cnt, hipStream_t stream);
 int geossl_incidence_fill(const int64_t* batch, const int64_t* sei0, const int64_t* sei1, const int32_t* se_ptr,
-                          int64_t N, const int64_t* inc_ptr, int32_t* inc_idx, hipStream_t stream);
+                          int64_t N, int sides, const int64_t* inc_ptr, int32_t* inc_idx, hipStream_t stream);
 
 typedef struct {
   const float* in_w1; /* input_distance_mlp.layers.0.weight [F][1] */
@@ -212,6 +216,39 @@ int geossl_ddm_loss_bwd_weights(const float* h, const int64_t* sei0, const int64
                                 float* workspace, int accumulate, hipStream_t stream);
 int geossl_incidence_gather(const float* dfeat, const int64_t* inc_ptr, const int32_t* inc_idx, int64_t N, int F,
                             float* dh, int accumulate, hipStream_t stream);
+
+/* ---- PaiNN (BASELINE config 5) — Geom3D/models/painn.py:32-66,91-114,216-269 -------------------------------
+ * idx_i / idx_j are rows 0 / 1 of radius_edge_index (int64).  Edge geometry (painn.py:232-239): dir[E][3] = r_ij/d,
+ * fcut[E] = cosine cutoff * [d < cutoff] (painn_utils.py:152-154), phi[E][R] = Gaussian RBF (painn_utils.py:99-103).
+ * interaction_fwd (painn.py:54-64): inc_ptr/inc_idx = edges grouped by idx_i (geossl_incidence_*, sides = 1);
+ * xc = interatomic_context_net(q) [N][3F]; Wf/bf = the layer's 3F rows of filter_net; q [N][F], mu [N][3][F].
+ * interaction_bwd: edges grouped by idx_j (sides = 2); returns d xc, d mu (incl. the residual) and the
+ * filter_net gradient rows of the layer.  mix_* are the element-wise parts of PaiNNMixing (painn.py:100-113):
+ * mm = mu_channel_mix(mu) [N][3][2F], ctx = [q, |mu_V|] [N][2F], dot = sum_xyz mu_V*mu_W, xx = context net out.  */
+int geossl_painn_edge_geom(const float* pos, const int64_t* idx_i, const int64_t* idx_j, int64_t E, float cutoff,
+                           const float* offsets, const float* widths, int R, float* dir, float* fcut, float* phi,
+                           hipStream_t stream);
+int geossl_silu_fwd(const float* u, int64_t n, float* y, hipStream_t stream);
+int geossl_silu_bwd(const float* u, const float* dy, int64_t n, float* du, hipStream_t stream);
+int geossl_painn_interaction_fwd(const float* q, const float* mu, const float* xc, const int64_t* idx_j,
+                                 const int64_t* inc_ptr, const int32_t* inc_idx, const float* phi, const float* fcut,
+                                 const float* dir, const float* Wf, const float* bf, int64_t N, int F, int R,
+                                 float* q_out, float* mu_out, hipStream_t stream);
+int64_t geossl_painn_interaction_bwd_workspace_floats(int64_t N, int F, int R);
+int geossl_painn_interaction_bwd(const float* dq_out, const float* dmu_out, const float* mu, const float* xc,
+                                 const int64_t* idx_i, const int64_t* inc_ptr, const int32_t* inc_idx, const float* phi,
+                                 const float* fcut, const float* dir, const float* Wf, const float* bf, int64_t N, int F,
+                                 int R, float* dxc, float* dmu_in, float* dWf, float* dbf, float* workspace,
+                                 int accumulate, hipStream_t stream);
+int geossl_painn_mix_pre_fwd(const float* q, const float* mm, int64_t N, int F, float eps, float* ctx, float* dot,
+                             hipStream_t stream);
+int geossl_painn_mix_post_fwd(const float* q, const float* mu, const float* mm, const float* xx, const float* dot,
+                              int64_t N, int F, float* q_out, float* mu_out, hipStream_t stream);
+int geossl_painn_mix_post_bwd(const float* dq_new, const float* dmu_new, const float* mm, const float* xx,
+                              const float* dot, int64_t N, int F, float* dxx, float* dmm, hipStream_t stream);
+int geossl_painn_mix_pre_bwd(const float* dq_new, const float* dctx, const float* ctx, const float* mm, int64_t N, int F,
+                             float* dq_in, float* dmm, hipStream_t stream);
+int geossl_add(const float* a, const float* b, int64_t n, float* out, hipStream_t stream);
 
 /* ---- Adam — torch.optim.Adam step at pretrain_GeoSSL.py:258-260,343 over one flat fp32 buffer
  * (amsgrad off; weight_decay added to the gradient as torch does).  step_count is the 1-based step.        */

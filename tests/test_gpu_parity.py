@@ -352,6 +352,61 @@ def test_ddm_full_size_vs_oracle_sample_and_determinism():
     assert rel_err(l_small.cpu(), ref.detach()) < TOL_OUT
 
 
+# ---------------------------------------------------------------------------------------------- PaiNN (config 5)
+def _painn_model(cfg):
+    from filler import fill_module_
+    from geossl_amd.Geom3D.models import PaiNN
+    return fill_module_(PaiNN(**cfg)).to(DEV)
+
+
+def test_painn_forward_and_grads_golden():
+    """G7: hydrogen-containing batch (padding_idx row), perturbed geometry so that some precomputed edges lie
+    beyond the cutoff (mask path)."""
+    g = load_golden("g7_painn")
+    cfg = cfg_of(g)
+    assert int(g["n_beyond"]) > 0
+    model = _painn_model(cfg)
+    out, q = model(t(g["x"], DEV), t(g["positions_perturbed"], DEV), t(g["radius_edge_index"], DEV), t(g["batch"], DEV),
+                   return_latent=True)
+    assert_close(out.cpu(), g["out"], TOL_OUT, "out")
+    assert_close(q.cpu(), g["q"], TOL_OUT, "q")
+    loss = (out ** 2).sum() + 0.5 * (q ** 2).sum()
+    assert rel_err(loss.detach().cpu(), g["loss"]) < TOL_OUT
+    loss.backward()
+    grads = unique_named_grads(model)
+    assert float(grads["embedding.weight"][0].abs().max()) == 0.0  # padding_idx = 0 (painn.py:174)
+    for k in g:
+        if k.startswith("gsum/"):
+            assert rel_err(grad_summary(grads[k[5:]].cpu()), g[k]) < TOL_GRAD, k
+
+
+def test_painn_radius_edge_index_matches_per_molecule_radius_graph():
+    """P0 / N4: radius_edge_index = per-molecule radius_graph on the clean geometry (datasets_3D_Radius.py:120)."""
+    from geossl_amd import ops
+    g = load_golden("g7_painn")
+    e = ops.radius_graph(t(g["positions"], DEV), 5.0, t(g["batch"], DEV))
+    assert torch.equal(e.cpu(), t(g["radius_edge_index"]))
+
+
+def test_painn_do_ddm_golden():
+    from geossl_amd import pretrain_GeoSSL as pg
+    g, d = load_golden("g7_painn"), load_golden("g7_painn_ddm")
+    cfg = cfg_of(g)
+    model = _painn_model(cfg)
+    n1, n2 = product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV)
+    batch = pg.Batch(t(g["x"], DEV), t(g["positions"], DEV), t(g["batch"], DEV), t(g["super_edge_index"], DEV),
+                     radius_edge_index=t(g["radius_edge_index"], DEV))
+    noise = {k: t(d[k], DEV) for k in ("pos_noise", "noise_level_1", "dist_noise_1", "noise_level_2", "dist_noise_2")}
+    loss, _ = pg.do_DDM(pg.Args("painn"), batch, model, None, 0.0, 0.3, NCSN_models=(n1, n2), noise=noise)
+    assert rel_err(loss.detach().cpu(), d["loss"]) < TOL_OUT
+    loss.backward()
+    mods = {"model": unique_named_grads(model), "ncsn1": unique_named_grads(n1), "ncsn2": unique_named_grads(n2)}
+    for k in d:
+        if k.startswith("gsum/"):
+            _, m, name = k.split("/", 2)
+            assert rel_err(grad_summary(mods[m][name].cpu()), d[k]) < TOL_GRAD, k
+
+
 # ---------------------------------------------------------------------------------------------- optimizer
 def test_fused_adam_matches_torch_adam():
     from geossl_amd.optim import FlatParams, FusedAdam

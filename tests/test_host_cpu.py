@@ -97,8 +97,9 @@ def test_no_cpu_fallback_and_no_oracle_in_product():
 
 def test_painn_forward_fails_loudly():
     from geossl_amd.Geom3D.models import PaiNN
+    from geossl_amd import _lib
     p = PaiNN(128, 3, 20, 5.0, 1, "add", max_z=9)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(_lib.GeosslHipError):  # CPU tensors: no fallback
         p(torch.zeros(2, dtype=torch.long), torch.zeros(2, 3), torch.zeros(2, 0, dtype=torch.long),
           torch.zeros(2, dtype=torch.long))
     assert isinstance(p.create_output_layers(), torch.nn.Sequential)
