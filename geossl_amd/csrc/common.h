@@ -142,6 +142,61 @@ __device__ __forceinline__ void load_weight_N(const float* __restrict__ W, int n
   }
 }
 
+// Store a wave's C-layout 32x32 block (16 accumulator registers: lane = column, register = row) to a row-major
+// global tile with 16-byte stores.  Narrow stores are issue-bound on this chip (one 4-byte-per-lane store costs
+// about as much issue time as a 16-byte one), so the block is transposed through a wave-private 16x32 LDS stage
+// (2 KB) in two halves: 8 ds_write_b32 + 2 ds_read_b128 + 2 global_store_dwordx4 per half instead of 16 dword
+// stores per block.  dst points at (row 0, column 0) of the 32x32 block; ld = row stride in floats (multiple of 4);
+// rows >= nrows_valid are skipped.  val(r) returns the value of accumulator register r.
+template <class ValFn>
+__device__ __forceinline__ void store_c_block_x4(float* __restrict__ dst, size_t ld, int nrows_valid, float* stage,
+                                                 int lane, ValFn val) {
+  const int j = lane & 31, kh = lane >> 5;
+  const int rr = lane >> 3, c4 = lane & 7;  // read side: row within an 8-row group, 16-byte chunk within the row
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = 8 * half + q;                        // accumulator register
+      const int row16 = (r & 3) + 8 * ((r >> 2) & 1) + 4 * kh;  // row within this half's 16 rows
+      stage[row16 * 32 + j] = val(r);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS ops complete in order
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row16 = 8 * u + rr;
+      const float4 v = *reinterpret_cast<const float4*>(stage + row16 * 32 + 4 * c4);
+      const int row = 16 * half + row16;
+      if (row < nrows_valid) *reinterpret_cast<float4*>(dst + (size_t)row * ld + 4 * c4) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the stage is overwritten
+  }
+}
+
+// Same transposition, handing each lane 16-byte row pieces: consume(row in [0,32), col4 in {0,4,..,28}, float4).
+template <class ValFn, class ConsumeFn>
+__device__ __forceinline__ void transpose_c_block(float* stage, int lane, ValFn val, ConsumeFn consume) {
+  const int j = lane & 31, kh = lane >> 5;
+  const int rr = lane >> 3, c4 = lane & 7;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = 8 * half + q;
+      const int row16 = (r & 3) + 8 * ((r >> 2) & 1) + 4 * kh;
+      stage[row16 * 32 + j] = val(r);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row16 = 8 * u + rr;
+      const float4 v = *reinterpret_cast<const float4*>(stage + row16 * 32 + 4 * c4);
+      consume(16 * half + row16, 4 * c4, v);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

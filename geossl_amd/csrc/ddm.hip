@@ -33,17 +33,17 @@ __global__ void k_transpose_pad(const float* __restrict__ W, int rows, int cols,
   }
 }
 
-// A wave gathers h[u] + h[v] for NROWS rows (endpoints held by lanes 0..NROWS-1), four rows at a time with all
-// eight row loads of a group in flight together.
+// A wave gathers h[u] + h[v] for NROWS rows (endpoints held by lanes 0..NROWS-1), eight rows at a time with all
+// sixteen row loads of a group in flight together.
 template <int F, int NROWS, class Store>
 __device__ __forceinline__ void gather_endpoint_sum_rows(const float* __restrict__ h, int64_t my_u, int64_t my_v,
                                                          int lane, Store store) {
   constexpr int NV = (F + 63) / 64;
 #pragma unroll 1
-  for (int r4 = 0; r4 < NROWS; r4 += 4) {
-    float hu[4][NV], hv[4][NV];
+  for (int r4 = 0; r4 < NROWS; r4 += 8) {
+    float hu[8][NV], hv[8][NV];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 8; ++q) {
       const int64_t uu = __shfl(my_u, r4 + q, 64), vv = __shfl(my_v, r4 + q, 64);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
@@ -55,7 +55,7 @@ __device__ __forceinline__ void gather_endpoint_sum_rows(const float* __restrict
       }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 8; ++q)
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int n = lane + 64 * v;
@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void k_ncsn_fwd(const float* __restrict__ h, c
   float* iw1 = w3s + HP;         // [F]
   float* ib1 = iw1 + F;          // [F]
   float* iw2 = ib1 + F;          // [F]
+  float* stage = iw2 + F + (threadIdx.x >> 6) * 512;  // wave-private 16x32 transposition stage for wide stores
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
   load_weight_T(w.o1_w, F, F, F + 1, W1s, F, F, F, tid, 256);
   for (int i = tid; i < F; i += 256) {
@@ -130,14 +131,16 @@ __global__ __launch_bounds__(256) void k_ncsn_fwd(const float* __restrict__ h, c
     mma_tile<NC>(acc, Aw, F, W1s, F, F / 2, lane);
     __syncthreads();  // every lane of the wave is done reading the feature tile
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
+    for (int c = 0; c < NC; ++c) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int rr = c_row(r, lane);
         const float a1 = fmaxf(acc[c][r], 0.0f);
-        Aw[a_idx(rr, 32 * c + j, F)] = a1;
-        if (sv.a1 != nullptr && r0 + rr < S) sv.a1[(size_t)(r0 + rr) * F + 32 * c + j] = a1;
+        acc[c][r] = a1;
+        Aw[a_idx(c_row(r, lane), 32 * c + j, F)] = a1;
       }
+      if (sv.a1 != nullptr)
+        store_c_block_x4(sv.a1 + (size_t)r0 * F + 32 * c, F, S - r0, stage, lane, [&](int r) { return acc[c][r]; });
+    }
     __syncthreads();
     f32x16 acc2[NC2];
 #pragma unroll
@@ -147,14 +150,26 @@ __global__ __launch_bounds__(256) void k_ncsn_fwd(const float* __restrict__ h, c
     mma_tile_gb<NC2>(acc2, Aw, F, W2T, HP, F / 2, lane);
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < NC2; ++c)
+    for (int c = 0; c < NC2; ++c) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int rr = c_row(r, lane), col = 32 * c + j;
+        const int col = 32 * c + j;
         const float a2 = col < H ? fmaxf(acc2[c][r], 0.0f) : 0.0f;
-        Aw[a_idx(rr, col, F)] = a2;
-        if (sv.a2 != nullptr && col < H && r0 + rr < S) sv.a2[(size_t)(r0 + rr) * H + col] = a2;
+        acc2[c][r] = a2;
+        Aw[a_idx(c_row(r, lane), col, F)] = a2;
       }
+      if (sv.a2 != nullptr) {
+        if (H % 32 == 0) {
+          store_c_block_x4(sv.a2 + (size_t)r0 * H + 32 * c, H, S - r0, stage, lane, [&](int r) { return acc2[c][r]; });
+        } else {  // H = 16 (F = 32): narrow path
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rr = c_row(r, lane), col = 32 * c + j;
+            if (col < H && r0 + rr < S) sv.a2[(size_t)(r0 + rr) * H + col] = acc2[c][r];
+          }
+        }
+      }
+    }
     __syncthreads();
     // last layer (F/2 -> 1): row j, each half-wave sums half of the columns
     float sc = 0.0f;
@@ -212,12 +227,12 @@ __global__ __launch_bounds__(256) void k_ncsn_bwd_rows(GeosslNcsnWeights w, Geos
                                                        float* __restrict__ grow) {
   constexpr int F = 32 * NC, H = F / 2, NC2 = (H + 31) / 32, HP = 32 * NC2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* W1s = smem;             // [n][k] = o1_w[n][k], k < F   (contraction over n)
-  float* At = W1s + F * F;       // 4 x [32][F]
+  float* At = smem;              // 4 x [32][F]; both weight matrices are read from global memory (L2 resident),
+                                 // which keeps the block at 66 KB of LDS: two blocks per CU
   float* wls = At + 4 * 32 * F;  // [F]
   float* w3s = wls + F;          // [HP]
+  float* stage = w3s + HP + (threadIdx.x >> 6) * 512;  // wave-private 16x32 transposition stage for wide stores
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
-  load_weight_N(w.o1_w, F, F, F + 1, W1s, F, F, F, tid, 256);
   for (int i = tid; i < F; i += 256) wls[i] = w.o1_w[(size_t)i * (F + 1) + F];
   for (int i = tid; i < HP; i += 256) w3s[i] = i < H ? w.o3_w[i] : 0.0f;
   __syncthreads();
@@ -229,14 +244,19 @@ __global__ __launch_bounds__(256) void k_ncsn_bwd_rows(GeosslNcsnWeights w, Geos
     const int row = r0 + j;
     const float gr = row < S ? sv.gscale[row] * scale : 0.0f;  // d L / d out_row
     if (row < S && kh == 0) grow[row] = gr;
-    // da2[row][m] = gr * w3[m] * [a2 > 0]
-    for (int rr = 0; rr < 32; ++rr) {
-      const float g = __shfl(gr, rr, 64);
-      const int rw = r0 + rr;
-      for (int m = lane; m < HP; m += 64) {
-        float v = 0.0f;
-        if (rw < S && m < H && sv.a2[(size_t)rw * H + m] > 0.0f) v = g * w3s[m];
-        Aw[a_idx(rr, m, F)] = v;
+    // da2[row][m] = gr * w3[m] * [a2 > 0]; lane = column m, the 32 row loads are issued together
+    for (int m = lane; m < HP; m += 64) {
+      float a2v[32];
+#pragma unroll
+      for (int rr = 0; rr < 32; ++rr) {
+        const int rw = min(r0 + rr, S - 1);
+        a2v[rr] = m < H ? sv.a2[(size_t)rw * H + m] : 0.0f;
+      }
+      const float w3m = w3s[m];
+#pragma unroll
+      for (int rr = 0; rr < 32; ++rr) {
+        const float g = __shfl(gr, rr, 64);
+        Aw[a_idx(rr, m, F)] = (r0 + rr < S && a2v[rr] > 0.0f) ? g * w3m : 0.0f;
       }
     }
     __syncthreads();
@@ -249,17 +269,17 @@ __global__ __launch_bounds__(256) void k_ncsn_bwd_rows(GeosslNcsnWeights w, Geos
     mma_tile_gb<NC>(acc, Aw, F, w.o2_w, F, H / 2, lane);
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
+    for (int c = 0; c < NC; ++c) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rr = c_row(r, lane), rw = r0 + rr, col = 32 * c + j;
         float v = 0.0f;
-        if (rw < S) {
-          v = sv.a1[(size_t)rw * F + col] > 0.0f ? acc[c][r] : 0.0f;
-          dz1[(size_t)rw * F + col] = v;
-        }
+        if (rw < S) v = sv.a1[(size_t)rw * F + col] > 0.0f ? acc[c][r] : 0.0f;
+        acc[c][r] = v;
         Aw[a_idx(rr, col, F)] = v;
       }
+      store_c_block_x4(dz1 + (size_t)r0 * F + 32 * c, F, S - r0, stage, lane, [&](int r) { return acc[c][r]; });
+    }
     __syncthreads();
     // demb[row] = sum_n dz1[row][n] * o1_w[n][F]
     float de = 0.0f;
@@ -270,14 +290,10 @@ __global__ __launch_bounds__(256) void k_ncsn_bwd_rows(GeosslNcsnWeights w, Geos
     for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
-    mma_tile<NC>(acc, Aw, F, W1s, F, F / 2, lane);  // dfeat = dz1 @ o1_w[:, :F]
+    mma_tile_gb<NC>(acc, Aw, F, w.o1_w, F + 1, F / 2, lane);  // dfeat = dz1 @ o1_w[:, :F]
 #pragma unroll
     for (int c = 0; c < NC; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rw = r0 + c_row(r, lane);
-        if (rw < S) dfeat[(size_t)rw * F + 32 * c + j] = acc[c][r];
-      }
+      store_c_block_x4(dfeat + (size_t)r0 * F + 32 * c, F, S - r0, stage, lane, [&](int r) { return acc[c][r]; });
     __syncthreads();
   }
 }
@@ -475,7 +491,7 @@ extern "C" int geossl_ddm_loss_fwd(const float* h, const int64_t* batch, const i
   GeosslNcsnSaved sv = {nullptr, nullptr, nullptr, nullptr, nullptr};
   if (saved != nullptr) sv = *saved;
   const int ntiles = (int)((S + 127) / 128);
-  const size_t lds = ((size_t)F * F + 4 * 32 * F + 5 * F + 2 * HP) * sizeof(float);
+  const size_t lds = ((size_t)F * F + 4 * 32 * F + 5 * F + 2 * HP + 4 * 512) * sizeof(float);
   dim3 grid(ntiles < 256 ? ntiles : 256);
 #define LAUNCH(NCV)                                                                                              \
   do {                                                                                                           \
@@ -508,7 +524,7 @@ extern "C" int geossl_ddm_loss_bwd_rows(const GeosslNcsnWeights* w, const Geossl
   if (F != 32 && F != 64 && F != 128) return (int)hipErrorInvalidValue;
   const int H = F / 2, HP = (H + 31) / 32 * 32;
   const int ntiles = (int)((S + 127) / 128);
-  const size_t lds = ((size_t)F * F + 4 * 32 * F + F + HP) * sizeof(float);
+  const size_t lds = ((size_t)4 * 32 * F + F + HP + 4 * 512) * sizeof(float);
   dim3 grid(ntiles < 256 ? ntiles : 256);
 #define LAUNCH(NCV)                                                                                               \
   do {                                                                                                            \

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "geossl_hip.h"
 #include "tn.h"
+#include <stdlib.h>
 
 using namespace geossl;
 
@@ -77,7 +78,33 @@ __device__ __forceinline__ void stage_atoms(const float* __restrict__ src, int a
 }
 
 // ------------------------------------------------------------------------------------------------ kernel A
-template <int NC>
+// Software pipelined across tiles (one wave per SIMD cannot rely on other waves to hide memory latency): the row
+// descriptors of tile t+1 are requested before the dt GEMM of tile t, and its atom window is requested (global ->
+// registers) before the dW1 phase of tile t and written to LDS after it, so both global round trips run under MFMA
+// work.  The atom window of tile t is only read by the dt GEMM, which is why the single LDS stage can be refilled
+// while the dW1 phase of the same tile still runs.
+struct RowDesc {
+  int ai, aj;
+  float m0, m1, d;
+};
+__device__ __forceinline__ RowDesc fetch_row_desc(const float* __restrict__ pair_d, const float* __restrict__ pair_c,
+                                                  const uint8_t* __restrict__ pair_flag,
+                                                  const int32_t* __restrict__ pair_i,
+                                                  const int32_t* __restrict__ pair_j, int P, int row) {
+  RowDesc r;
+  const bool ok = row < P;
+  const int q = ok ? row : P - 1;
+  r.ai = pair_i[q];
+  r.aj = pair_j[q];
+  const unsigned fl = ok ? pair_flag[q] : 0u;
+  const float c = pair_c[q];
+  r.m0 = (fl & 1u) ? c : 0.0f;
+  r.m1 = (fl & 2u) ? c : 0.0f;
+  r.d = pair_d[q];
+  return r;
+}
+
+template <int NC, int ABL = 0>
 __global__ __launch_bounds__(256) void k_filter_bwd_a(const float* __restrict__ pair_d, const float* __restrict__ pair_c,
                                                       const uint8_t* __restrict__ pair_flag,
                                                       const int32_t* __restrict__ pair_i,
@@ -85,20 +112,22 @@ __global__ __launch_bounds__(256) void k_filter_bwd_a(const float* __restrict__ 
                                                       GeosslFilterGradIn g, int G, const float* __restrict__ offset,
                                                       float coeff, const float* __restrict__ T,
                                                       float* __restrict__ partial_w1, float* __restrict__ partial_b1) {
-  constexpr int F = 32 * NC, AS = F + 1;
+  constexpr int F = 32 * NC, AS = F + 1, Q = F / 4;
+  constexpr int NPRE = (2 * ATOM_CAP * Q + 255) / 256;  // float4 per thread to move one atom window (x and dagg)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W2s = smem;                      // [n][k] = w2[n][k]: B operand of dt = dO W2 (contraction over n)
   float* xs = W2s + F * F;                // [ATOM_CAP][F+1]
   float* ds = xs + ATOM_CAP * AS;         // [ATOM_CAP][F+1]
   float* offs = ds + ATOM_CAP * AS;       // [64]
   float* tabf = offs + 64;                // tm0, tm1, td: 3 x [128]
-  int* tabi = reinterpret_cast<int*>(tabf + 3 * 128);  // ti, tj: 2 x [128], then s_amax
+  int* tabi = reinterpret_cast<int*>(tabf + 3 * 128);  // ti, tj: 2 x [128], then s_amax[2]
   TileDesc td{tabi, tabi + 128, tabf, tabf + 128, tabf + 256};
   int* s_amax = tabi + 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
   const int l = blockIdx.y;
   load_weight_N(w.w2[l], F, F, F, W2s, F, F, F, tid, 256);
   if (tid < 64) offs[tid] = tid < G ? offset[tid] : 0.0f;
+  if (tid < 2) s_amax[tid] = 0;
   const float* __restrict__ x = g.x[l];
   const float* __restrict__ dagg = g.dagg[l];
   const size_t lbase = (size_t)l * P;
@@ -115,25 +144,42 @@ __global__ __launch_bounds__(256) void k_filter_bwd_a(const float* __restrict__ 
   const int ntiles = (P + 127) / 128;
   const int per = (ntiles + gridDim.x - 1) / gridDim.x;  // contiguous tile range per block (atom reuse in L2)
   const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
-  for (int t = t_begin; t < t_end; ++t) {
-    const int r0b = t * 128;
-    __syncthreads();  // previous tile done with the tables / atom tiles
-    if (tid == 0) *s_amax = 0;
+  if (t_begin >= t_end) {
+    // nothing to do for this block: still publish zero partials below
+  }
+  // ---- prologue: descriptors and atom window of the first tile, synchronously
+  RowDesc pd{0, 0, 0.0f, 0.0f, 0.0f};
+  if (t_begin < t_end && tid < 128) pd = fetch_row_desc(pair_d, pair_c, pair_flag, pair_i, pair_j, P, t_begin * 128 + tid);
+  __syncthreads();
+  int a_lo = 0, na = 0;
+  bool staged = false;
+  if (t_begin < t_end) {
+    if (tid < 128) {
+      td.ti[tid] = pd.ai; td.tj[tid] = pd.aj; td.tm0[tid] = pd.m0; td.tm1[tid] = pd.m1; td.td[tid] = pd.d;
+      atomicMax(&s_amax[t_begin & 1], pd.aj + 1);
+    }
     __syncthreads();
-    load_tile_desc(pair_d, pair_c, pair_flag, pair_i, pair_j, P, r0b, td, s_amax, tid);
-    __syncthreads();
-    const int a_lo = td.ti[0];  // pair slots are lexicographic inside a molecule: the first row has the smallest atom
-    const int na = *s_amax - a_lo;
-    const bool staged = na <= ATOM_CAP;
+    a_lo = td.ti[0];
+    na = s_amax[t_begin & 1] - a_lo;
+    staged = na <= ATOM_CAP;
     if (staged) {
       stage_atoms<F>(x, a_lo, na, xs, tid);
       stage_atoms<F>(dagg, a_lo, na, ds, tid);
     }
-    __syncthreads();
+    if (t_begin + 1 < t_end && tid < 128)
+      pd = fetch_row_desc(pair_d, pair_c, pair_flag, pair_i, pair_j, P, (t_begin + 1) * 128 + tid);
+  }
+  for (int t = t_begin; t < t_end; ++t) {
+    const int r0b = t * 128;
+    __syncthreads();  // tables(t) and atoms(t) are in LDS
+    if (tid == 0) s_amax[(t + 1) & 1] = 0;  // slot of the next tile (last read two tiles ago)
     const int myr = wave * 32 + j;
     const int r0 = r0b + wave * 32;
     const int gi = td.ti[myr], gj = td.tj[myr];
     const float m0 = td.tm0[myr], m1 = td.tm1[myr];
+    float dd16[16];  // distances of the rows this lane contracts over in the dW1 phase
+#pragma unroll
+    for (int s = 0; s < 16; ++s) dd16[s] = td.td[wave * 32 + c_row(s, lane)];
     // saved hidden activation of this wave's 32 rows in C layout (requested now, used after the GEMM)
     float tc[NC][16];
 #pragma unroll
@@ -141,14 +187,15 @@ __global__ __launch_bounds__(256) void k_filter_bwd_a(const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = min(r0 + c_row(r, lane), P - 1);
-        tc[c][r] = T[(lbase + row) * F + 32 * c + j];
+        tc[c][r] = ABL == 3 ? 0.5f : T[(lbase + row) * F + 32 * c + j];
       }
     f32x16 acc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
-    if (staged) {
+      for (int r = 0; r < 16; ++r) acc[c][r] = ABL == 1 ? 0.001f * r : 0.0f;
+    if (ABL == 1) {
+    } else if (staged) {
       const float* di = ds + (gi - a_lo) * AS;
       const float* dj = ds + (gj - a_lo) * AS;
       const float* xi = xs + (gi - a_lo) * AS;
@@ -189,7 +236,35 @@ __global__ __launch_bounds__(256) void k_filter_bwd_a(const float* __restrict__ 
         for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[32 * c], acc[c], 0, 0, 0);
       }
     }
-    // dU = dt * ssp'(pre) in place (C layout: lane = hidden unit 32c+j, register = pair row)
+    __syncthreads();  // every wave is done with tables(t) and atoms(t)
+    // ---- publish the descriptors of tile t+1 and request its atom window (global -> registers)
+    const bool more = t + 1 < t_end;
+    float4 pre[NPRE];
+    int a_lo_n = 0, na_n = 0;
+    bool staged_n = false;
+    if (more) {
+      if (tid < 128) {
+        td.ti[tid] = pd.ai; td.tj[tid] = pd.aj; td.tm0[tid] = pd.m0; td.tm1[tid] = pd.m1; td.td[tid] = pd.d;
+        atomicMax(&s_amax[(t + 1) & 1], pd.aj + 1);
+      }
+      __syncthreads();
+      a_lo_n = td.ti[0];
+      na_n = s_amax[(t + 1) & 1] - a_lo_n;
+      staged_n = na_n <= ATOM_CAP;
+      if (staged_n && ABL != 4) {
+        const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)a_lo_n * F);
+        const float4* d4 = reinterpret_cast<const float4*>(dagg + (size_t)a_lo_n * F);
+        const int nq = na_n * Q;
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+          const int i = tid + 256 * u;
+          pre[u] = i < nq ? x4[i] : (i < 2 * nq ? d4[i - nq] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        }
+      }
+      if (t + 2 < t_end && tid < 128)
+        pd = fetch_row_desc(pair_d, pair_c, pair_flag, pair_i, pair_j, P, (t + 2) * 128 + tid);
+    }
+    // ---- dU = dt * ssp'(pre) in place (C layout: lane = hidden unit 32c+j, register = pair row)
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -199,14 +274,14 @@ __global__ __launch_bounds__(256) void k_filter_bwd_a(const float* __restrict__ 
       }
     // dW1[k][g] += sum_rows dU[row][k] * rbf(d_row)[g]: k-step s contracts over the two rows held in register s
     // (row c_row(s, lane) for each half-wave); A fragment = acc[c][s] as is.
+    if (ABL != 2)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const float dd = td.td[wave * 32 + c_row(s, lane)];
       float bv[2];
 #pragma unroll
       for (int g2 = 0; g2 < 2; ++g2) {
         const int gg = 32 * g2 + j;
-        const float diff = dd - offs[gg];
+        const float diff = dd16[s] - offs[gg];
         bv[g2] = gg < G ? __expf(coeff * (diff * diff)) : 0.0f;
       }
 #pragma unroll
@@ -215,6 +290,23 @@ __global__ __launch_bounds__(256) void k_filter_bwd_a(const float* __restrict__ 
         for (int g2 = 0; g2 < 2; ++g2)
           accw[c][g2] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[c][s], bv[g2], accw[c][g2], 0, 0, 0);
     }
+    // ---- the atom window of tile t+1 lands in LDS (its previous content was last read before the barrier above)
+    if (more && staged_n && ABL != 4) {
+      const int nq = na_n * Q;
+#pragma unroll
+      for (int u = 0; u < NPRE; ++u) {
+        const int i = tid + 256 * u;
+        if (i < 2 * nq) {
+          const int ii = i < nq ? i : i - nq;
+          const int a = ii / Q, q4 = ii - a * Q;
+          float* d = (i < nq ? xs : ds) + a * AS + 4 * q4;
+          d[0] = pre[u].x; d[1] = pre[u].y; d[2] = pre[u].z; d[3] = pre[u].w;
+        }
+      }
+    }
+    a_lo = a_lo_n;
+    na = na_n;
+    staged = staged_n;
   }
   // one partial per wave: [F][G] and [F]
   const size_t pw = ((size_t)l * gridDim.x + blockIdx.x) * 4 + wave;
@@ -234,6 +326,7 @@ __global__ __launch_bounds__(256) void k_filter_bwd_a(const float* __restrict__ 
     const float s = bsum[c] + __shfl_xor(bsum[c], 32, 64);
     if (kh == 0) partial_b1[pw * F + 32 * c + j] = s;
   }
+  (void)na;
 }
 
 // ------------------------------------------------------------------------------------------------ kernel B
@@ -382,6 +475,7 @@ extern "C" int geossl_cfconv_filter_bwd(const float* pair_d, const float* pair_c
   const int ntiles = (int)((P + 127) / 128);
   const int nb = blocks_per_layer(L, ntiles);
   dim3 grid(nb, L);
+  static const int abl = getenv("GEOSSL_ABLATE") ? atoi(getenv("GEOSSL_ABLATE")) : 0;
   float* pw1 = workspace;                                   // [L][nb*4][F][G]
   float* pb1 = pw1 + (size_t)L * nb * 4 * F * G;            // [L][nb*4][F]
   const int nbb = 2 * nb;                                   // kernel B runs two (smaller) blocks per CU
@@ -396,7 +490,12 @@ extern "C" int geossl_cfconv_filter_bwd(const float* pair_d, const float* pair_c
   do {                                                                                                                \
     allow_big_lds(&k_filter_bwd_a<NCV>);                                                                              \
     allow_big_lds(&k_filter_bwd_b<NCV>);                                                                              \
-    hipLaunchKernelGGL((k_filter_bwd_a<NCV>), grid, dim3(256), lds_a, stream, pair_d, pair_c, pair_flag, pair_i,      \
+    if (abl == 1) { allow_big_lds(&k_filter_bwd_a<NCV, 1>); hipLaunchKernelGGL((k_filter_bwd_a<NCV, 1>), grid, dim3(256), lds_a, stream, pair_d, pair_c, pair_flag, pair_i, pair_j, (int)P, *w, *g, G, offset, coeff, T, pw1, pb1); } \
+    else if (abl == 2) { allow_big_lds(&k_filter_bwd_a<NCV, 2>); hipLaunchKernelGGL((k_filter_bwd_a<NCV, 2>), grid, dim3(256), lds_a, stream, pair_d, pair_c, pair_flag, pair_i, pair_j, (int)P, *w, *g, G, offset, coeff, T, pw1, pb1); } \
+    else if (abl == 3) { allow_big_lds(&k_filter_bwd_a<NCV, 3>); hipLaunchKernelGGL((k_filter_bwd_a<NCV, 3>), grid, dim3(256), lds_a, stream, pair_d, pair_c, pair_flag, pair_i, pair_j, (int)P, *w, *g, G, offset, coeff, T, pw1, pb1); } \
+    else if (abl == 4) { allow_big_lds(&k_filter_bwd_a<NCV, 4>); hipLaunchKernelGGL((k_filter_bwd_a<NCV, 4>), grid, dim3(256), lds_a, stream, pair_d, pair_c, pair_flag, pair_i, pair_j, (int)P, *w, *g, G, offset, coeff, T, pw1, pb1); } \
+    else if (abl == 9) { } \
+    else hipLaunchKernelGGL((k_filter_bwd_a<NCV>), grid, dim3(256), lds_a, stream, pair_d, pair_c, pair_flag, pair_i,      \
                        pair_j, (int)P, *w, *g, G, offset, coeff, T, pw1, pb1);                                        \
     hipLaunchKernelGGL((k_filter_bwd_b<NCV>), dim3(nbb, L), dim3(256), lds_b, stream, pair_d, pair_c, pair_flag,     \
                        pair_i, pair_j, (int)P, *g, T, pw2, pb2);                                                              \

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, con
   constexpr int NB = 32 * NC;  // columns handled by this block
   constexpr int BS = NB + 1;   // odd row stride: the transposing store (lanes = consecutive k) is conflict-free
   float* Bs = smem;            // [K][BS]
+  float* stage = smem + ((K * BS + 3) & ~3) + (threadIdx.x >> 6) * 512;  // wave-private 16x32 transposition stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.y * NB;
   // stage the weight slice: 16-byte global loads, several in flight per thread
@@ -74,21 +75,26 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, con
         for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bp[32 * c], acc[c], 0, 0, 0);
       }
     }
-    // epilogue in C layout
+    // epilogue on 16-byte row pieces (accumulator blocks transposed through the wave's LDS stage): bias, ssp,
+    // ssp' and residual are applied with wide loads, the result leaves with wide stores
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const int col = n0 + 32 * c + j;
-      if (col >= NO) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = r0 + c_row(r, lane);
-        if (row >= R) continue;
-        float v = acc[c][r];
-        if (flags & GEOSSL_EPI_SSP) v = ssp(v);
-        if (flags & GEOSSL_EPI_MUL_DSSP) v *= dssp_from_out(tprev[(size_t)row * ldy + col]);
-        if (flags & GEOSSL_EPI_RESIDUAL) v += res[(size_t)row * ldy + col];
-        Y[(size_t)row * ldy + col] = v;
-      }
+      const int cb = n0 + 32 * c;
+      transpose_c_block(stage, lane, [&](int r) { return acc[c][r]; }, [&](int rl, int c4, float4 v) {
+        const int row = r0 + rl, col = cb + c4;
+        if (row >= R || col >= NO) return;
+        const size_t o = (size_t)row * ldy + col;
+        if (flags & GEOSSL_EPI_SSP) { v.x = ssp(v.x); v.y = ssp(v.y); v.z = ssp(v.z); v.w = ssp(v.w); }
+        if (flags & GEOSSL_EPI_MUL_DSSP) {
+          const float4 tp = *reinterpret_cast<const float4*>(tprev + o);
+          v.x *= dssp_from_out(tp.x); v.y *= dssp_from_out(tp.y); v.z *= dssp_from_out(tp.z); v.w *= dssp_from_out(tp.w);
+        }
+        if (flags & GEOSSL_EPI_RESIDUAL) {
+          const float4 rs = *reinterpret_cast<const float4*>(res + o);
+          v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+        }
+        *reinterpret_cast<float4*>(Y + o) = v;
+      });
     }
   }
 }
@@ -105,8 +111,8 @@ extern "C" int geossl_linear(const float* X, int ldx, const float* W, const floa
   if (NC == 4 && ntiles < 512) NC = 2;
   const int ny = NOp / (32 * NC);
   dim3 grid(ntiles < 1024 ? ntiles : 1024, ny);
-  const size_t lds = (size_t)K * (32 * NC + 1) * sizeof(float);
-  if (ldx < K || ldy < NO || (ldx & 3)) return (int)hipErrorInvalidValue;
+  const size_t lds = ((size_t)((K * (32 * NC + 1) + 3) & ~3) + 4 * 512) * sizeof(float);
+  if (ldx < K || ldy < NO || (ldx & 3) || (ldy & 3) || (NO & 3)) return (int)hipErrorInvalidValue;
 #define LAUNCH(NCV)                                                                                               \
   do {                                                                                                            \
     if (lds > 64 * 1024)                                                                                          \

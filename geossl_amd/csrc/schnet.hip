@@ -25,107 +25,6 @@ __global__ void k_rbf(const float* __restrict__ d, int64_t E, const float* __res
   }
 }
 
-// ------------------------------------------------------------------------------------------- K3 forward
-// grid (blocks per layer, L).  A block keeps its layer's two weight matrices in LDS and walks 128-row tiles
-// (4 waves x 32 pair rows).  GEMM1's A operand (the Gaussian smearing of the row's distance) is computed in
-// registers in MFMA A-fragment layout; the hidden activation goes through a wave-private swizzled LDS tile
-// into GEMM2; the envelope C(d) multiplies the result on the way out.
-template <int NC>
-__global__ __launch_bounds__(256) void k_filter_fwd(const float* __restrict__ pair_d, const float* __restrict__ pair_c,
-                                                    int P, GeosslFilterWeights w, int G, int GP,
-                                                    const float* __restrict__ offset, float coeff,
-                                                    float* __restrict__ Tout, float* __restrict__ Wf) {
-  constexpr int F = 32 * NC;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* W1s = smem;                 // [GP][F]
-  float* W2s = W1s + GP * F;         // [F][F]   (k-major: W2s[k][n] = w2[n][k])
-  float* At = W2s + F * F;           // 4 x [32][F] swizzled
-  float* b1s = At + 4 * 32 * F;      // [F]
-  float* b2s = b1s + F;              // [F]
-  float* offs = b2s + F;             // [GP]
-  float* cw = offs + GP;             // [4][32]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
-  const int l = blockIdx.y;
-  load_weight_T(w.w1[l], F, G, G, W1s, F, GP, F, tid, 256);
-  load_weight_T(w.w2[l], F, F, F, W2s, F, F, F, tid, 256);
-  for (int i = tid; i < F; i += 256) {
-    b1s[i] = w.b1[l][i];
-    b2s[i] = w.b2[l][i];
-  }
-  for (int i = tid; i < GP; i += 256) offs[i] = i < G ? offset[i] : 0.0f;
-  __syncthreads();
-  float* Aw = At + wave * 32 * F;
-  const size_t lbase = (size_t)l * P;
-  const int ntiles = (P + 127) / 128;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int r0 = t * 128 + wave * 32;
-    const int row = r0 + j;
-    const float d = row < P ? pair_d[row] : 0.0f;
-    if (kh == 0) cw[wave * 32 + j] = row < P ? pair_c[row] : 0.0f;
-    f32x16 acc[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const float b = b1s[32 * c + j];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][r] = b;
-    }
-    {
-      // Gaussian smearing of the row's distance, computed directly in MFMA A-fragment layout (schnet.py:206-207);
-      // operands of k-step kk+1 are prepared before the MFMAs of k-step kk issue.
-      auto rbf_a = [&](int kk) {
-        const int k = 2 * kk + kh;
-        const float diff = d - offs[k];
-        return k < G ? __expf(coeff * (diff * diff)) : 0.0f;
-      };
-      float a_cur = rbf_a(0), b_cur[NC], b_nxt[NC];
-      {
-        const float* bp = W1s + kh * F + j;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) b_cur[c] = bp[32 * c];
-      }
-      const int K2 = GP / 2;
-      for (int kk = 0; kk < K2; ++kk) {
-        const int kn = min(kk + 1, K2 - 1);
-        const float a_nxt = rbf_a(kn);
-        const float* bp = W1s + (2 * kn + kh) * F + j;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) b_nxt[c] = bp[32 * c];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[c], acc[c], 0, 0, 0);
-        a_cur = a_nxt;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) b_cur[c] = b_nxt[c];
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = c_row(r, lane);
-        const float tv = ssp(acc[c][r]);
-        Aw[a_idx(rr, 32 * c + j, F)] = tv;
-        if (Tout != nullptr && r0 + rr < P) Tout[(lbase + r0 + rr) * F + 32 * c + j] = tv;
-      }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const float b = b2s[32 * c + j];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][r] = b;
-    }
-    mma_tile<NC>(acc, Aw, F, W2s, F, F / 2, lane);
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = c_row(r, lane);
-        if (r0 + rr < P) Wf[(lbase + r0 + rr) * F + 32 * c + j] = acc[c][r] * cw[wave * 32 + rr];  // schnet.py:187
-      }
-    __syncthreads();
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------- K4
 // One wave per molecule.  Lane f owns feature columns f, f+64, ... of every atom row of the molecule, so the
 // LDS copy of x and the accumulators are thread-private (no barriers, no atomics); each filter row is read
@@ -270,27 +169,6 @@ extern "C" int geossl_rbf_fwd(const float* d, int64_t E, const float* offset, in
                               hipStream_t stream) {
   if (E <= 0) return 0;
   hipLaunchKernelGGL(k_rbf, dim3(grid1d(E * G, 256)), dim3(256), 0, stream, d, E, offset, G, coeff, out);
-  GEOSSL_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int geossl_cfconv_filter_fwd(const float* pair_d, const float* pair_c, int64_t P,
-                                        const GeosslFilterWeights* w, int L, int F, int G, const float* offset,
-                                        float coeff, float* T, float* Wf, hipStream_t stream) {
-  if (P <= 0 || L <= 0) return 0;
-  if (L > GEOSSL_MAX_L || (F != 32 && F != 64 && F != 128) || G > 128) return (int)hipErrorInvalidValue;
-  const int GP = (G + 1) / 2 * 2;
-  const int ntiles = (int)((P + 127) / 128);
-  dim3 grid(blocks_per_layer(L, ntiles), L);
-  const size_t lds = ((size_t)GP * F + (size_t)F * F + 4 * 32 * F + 2 * F + GP + 128) * sizeof(float);
-#define LAUNCH(NCV)                                                                                          \
-  do {                                                                                                       \
-    allow_big_lds(&k_filter_fwd<NCV>);                                                                       \
-    hipLaunchKernelGGL((k_filter_fwd<NCV>), grid, dim3(256), lds, stream, pair_d, pair_c, (int)P, *w, G, GP, \
-                       offset, coeff, T, Wf);                                                                \
-  } while (0)
-  if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
-#undef LAUNCH
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
