@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--mols", type=int, default=1024, help="molecules per GPU per step")
     ap.add_argument("--dataset-mols", type=int, default=100000, help="synthetic dataset size (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="schnet", choices=["schnet", "painn"],
+                    help="backbone: schnet = the headline configuration; painn = BASELINE config 5 (secondary line)")
     args = ap.parse_args()
 
     from geossl_amd import _lib
@@ -121,11 +123,15 @@ def main():
     _lib.load()
 
     torch.manual_seed(1234)  # identical initial weights on every rank
-    model = SchNet(hidden_channels=F, num_filters=F, num_interactions=L, num_gaussians=G, cutoff=CUTOFF,
-                   node_class=9, readout="mean").to(dev)
+    if args.model == "schnet":
+        model = SchNet(hidden_channels=F, num_filters=F, num_interactions=L, num_gaussians=G, cutoff=CUTOFF,
+                       node_class=9, readout="mean").to(dev)
+    else:  # pretrain_GeoSSL.py:33-42 with config.py:118-121 defaults
+        from geossl_amd.Geom3D.models import PaiNN
+        model = PaiNN(n_atom_basis=F, n_interactions=3, n_rbf=20, cutoff=5.0, max_z=9, n_out=1, readout="add").to(dev)
     n1 = NCSN_version_03(F, 10.0, 0.01, K_LEVELS, "symmetry", 2).to(dev)
     n2 = NCSN_version_03(F, 10.0, 0.01, K_LEVELS, "symmetry", 2).to(dev)
-    trainer = pg.DDMTrainer(model, n1, n2, lr=5e-4, mu=0.0, sigma=0.3, device_noise=True)
+    trainer = pg.DDMTrainer(model, n1, n2, lr=5e-4, mu=0.0, sigma=0.3, device_noise=True, model_3d=args.model)
 
     # pre-collated, device-resident batches: each rank owns its own molecules (weak scaling)
     total_steps = args.warmup + args.steps
@@ -135,6 +141,9 @@ def main():
         b = make_batch(args.mols, seed=1000 * (rank + 1) + i, mode="A")
         bt = pg.Batch.from_numpy(b, dev)
         bt.num_graphs  # cached python int
+        if args.model == "painn":  # precomputed on the clean geometry, like MoleculeDataset3DRadius (datasets_3D_Radius.py:120)
+            from geossl_amd import ops as _ops
+            bt.radius_edge_index = _ops.radius_graph(bt.positions, 5.0, bt.batch)
         batches.append(bt)
     # build the per-batch index structures once (part of collation, not of the step)
     gen = torch.Generator(device=dev)
@@ -216,9 +225,10 @@ def main():
             "value": value, "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "pretrain_GeoSSL.py --GeoSSL_option=DDM step, SchNet F=128 L=6 G=51 cutoff=5A, "
-                                   "bs=%d molecules/GPU x n=18 atoms, %d pre-collated device-resident batches/GPU"
-                                   % (args.mols, n_batches),
+            "config": {"workload": ("pretrain_GeoSSL.py --GeoSSL_option=DDM step, %s, "
+                                    "bs=%d molecules/GPU x n=18 atoms, %d pre-collated device-resident batches/GPU"
+                                    % ("SchNet F=128 L=6 G=51 cutoff=5A" if args.model == "schnet"
+                                       else "PaiNN F=128 L=3 rbf=20 cutoff=5A (BASELINE config 5)", args.mols, n_batches)),
                        "molecules_per_gpu_per_step": args.mols, "atoms": N, "directed_edges": E, "super_edges": S,
                        "parallelism": "dp%d" % world},
             "roofline": roof,
@@ -229,7 +239,10 @@ def main():
             "kernel_ms": {k: {"avg_ms": v[0], "per_step": v[1]} for k, v in kern.items()},
             "final_loss": final_loss,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.model != "schnet":
+            out["roofline"] = None  # the byte/flop model of SURVEY 8(d) is SchNet's; the PaiNN line reports throughput only
+            out["step_roofline"] = None
+        if world == 1 and not args.no_cpu_baseline and args.model == "schnet":
             out["cpu_baseline"] = cpu_baseline(seed=1000)
         print(json.dumps(out))
     if world > 1:

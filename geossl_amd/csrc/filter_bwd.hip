@@ -353,6 +353,9 @@ __global__ __launch_bounds__(256, 2) void k_filter_bwd_b(const float* __restrict
   int* tabi = reinterpret_cast<int*>(tabf + 3 * TRB);
   TileDesc td{tabi, tabi + TRB, tabf, tabf + TRB, tabf + 2 * TRB};
   int* s_amax = tabi + 2 * TRB;
+  // packed per-row descriptor {LDS offset of atom i, of atom j, C*flag0, C*flag1}: one 16-byte broadcast read per
+  // k-step instead of four 4-byte ones (the MFMA loop of this kernel is LDS-issue bound)
+  int4* desc4 = reinterpret_cast<int4*>(smem + ((TRB * F + 2 * ATOM_CAP_B * AS + 5 * TRB + 4 + 3) & ~3));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
   const int l = blockIdx.y;
   const float* __restrict__ x = g.x[l];
@@ -392,14 +395,18 @@ __global__ __launch_bounds__(256, 2) void k_filter_bwd_b(const float* __restrict
     if (staged) {
       stage_atoms<F>(x, a_lo, na, xs, tid);
       stage_atoms<F>(dagg, a_lo, na, ds, tid);
+      if (tid < TRB)
+        desc4[tid] = make_int4((td.ti[tid] - a_lo) * AS, (td.tj[tid] - a_lo) * AS, __float_as_int(td.tm0[tid]),
+                               __float_as_int(td.tm1[tid]));
     }
     __syncthreads();
     if (ncol < F) {
       if (staged) {
         // A fragment of k-step kk: dO[row = 2kk+kh][ncol]; the row's descriptor is uniform over the half-wave
         auto afrag = [&](int row) {
-          const int oi = (td.ti[row] - a_lo) * AS + ncol, oj = (td.tj[row] - a_lo) * AS + ncol;
-          return td.tm0[row] * (ds[oi] * xs[oj]) + td.tm1[row] * (ds[oj] * xs[oi]);
+          const int4 q = desc4[row];
+          const int oi = q.x + ncol, oj = q.y + ncol;
+          return __int_as_float(q.z) * (ds[oi] * xs[oj]) + __int_as_float(q.w) * (ds[oj] * xs[oi]);
         };
         float a_cur = afrag(kh), b_cur[NC], b_nxt[NC];
         {
@@ -485,7 +492,7 @@ extern "C" int geossl_cfconv_filter_bwd(const float* pair_d, const float* pair_c
   const size_t atoms = (size_t)2 * ATOM_CAP * (F + 1) * sizeof(float);
   const size_t lds_a = (size_t)F * F * sizeof(float) + atoms + 64 * sizeof(float) + tab;
   const size_t lds_b = (size_t)TRB * F * sizeof(float) + (size_t)2 * ATOM_CAP_B * (F + 1) * sizeof(float) +
-                       (5 * TRB + 4) * sizeof(float);
+                       (5 * TRB + 8) * sizeof(float) + (size_t)TRB * 16;
 #define LAUNCH(NCV)                                                                                                   \
   do {                                                                                                                \
     allow_big_lds(&k_filter_bwd_a<NCV>);                                                                              \

@@ -42,17 +42,13 @@ __global__ __launch_bounds__(128) void k_aggregate(const float* __restrict__ x, 
   const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m], np = n * (n - 1) / 2;
   float* xs = smem;                // [max_n][F]
   float* acc = smem + max_n * F;   // [max_n][F]
-  uint8_t* sfl = reinterpret_cast<uint8_t*>(smem + 2 * max_n * F);  // [np] flag, then endpoints a, b
-  uint8_t* sa = sfl + max_n * (max_n - 1) / 2;
-  uint8_t* sb = sa + max_n * (max_n - 1) / 2;
+  uint8_t* sfl = reinterpret_cast<uint8_t*>(smem + 2 * max_n * F);  // [np] edge flags of the pair slots
   for (int a = 0; a + 1 < n; ++a) {
     const int row = a * n - a * (a + 1) / 2 - a - 1;
     for (int b = a + 1 + threadIdx.x; b < n; b += blockDim.x) {
       unsigned fl = pair_flag[base + row + b];
       if (swap) fl = ((fl & 1u) << 1) | ((fl >> 1) & 1u);
       sfl[row + b] = (uint8_t)fl;
-      sa[row + b] = (uint8_t)a;
-      sb[row + b] = (uint8_t)b;
     }
   }
   if (f < F)
@@ -63,18 +59,30 @@ __global__ __launch_bounds__(128) void k_aggregate(const float* __restrict__ x, 
   __syncthreads();
   if (f < F) {
     const float* __restrict__ wcol = Wf + (size_t)base * F + f;
+    // flat walk over the pair slots (a < b, lexicographic) with eight filter rows in flight; the accumulator of the
+    // current row atom a lives in a register (it starts from the LDS value, which already holds every earlier source
+    // a' < a, so the summation order per target stays ascending in the source index)
+    int a = 0, b = 1;
+    float xa = n > 0 ? xs[f] : 0.0f, acc_a = 0.0f;
     for (int p0 = 0; p0 < np; p0 += 8) {
       float w[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) w[u] = wcol[(size_t)min(p0 + u, np - 1) * F];  // 8 filter rows in flight
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int p = p0 + u;
-        if (p < np) {
-          const unsigned fl = sfl[p];
-          const int a = sa[p], b = sb[p];
-          if (fl & 1u) acc[a * F + f] = __fadd_rn(acc[a * F + f], __fmul_rn(xs[b * F + f], w[u]));  // edge b -> a
-          if (fl & 2u) acc[b * F + f] = __fadd_rn(acc[b * F + f], __fmul_rn(xs[a * F + f], w[u]));  // edge a -> b
+        if (p0 + u < np) {
+          const unsigned fl = sfl[p0 + u];
+          if (fl & 1u) acc_a = __fadd_rn(acc_a, __fmul_rn(xs[b * F + f], w[u]));                  // edge b -> a
+          if (fl & 2u) acc[b * F + f] = __fadd_rn(acc[b * F + f], __fmul_rn(xa, w[u]));           // edge a -> b
+          if (++b == n) {  // row a finished: publish its sum, move to the next row atom
+            acc[a * F + f] = acc_a;
+            ++a;
+            b = a + 1;
+            if (a < n) {
+              xa = xs[a * F + f];
+              acc_a = acc[a * F + f];
+            }
+          }
         }
       }
     }
@@ -178,7 +186,7 @@ extern "C" int geossl_cfconv_aggregate(const float* x, const float* Wf, const ui
                                        int swap, float* out, hipStream_t stream) {
   if (B <= 0) return 0;
   if (max_n > 255 || F > 128) return (int)hipErrorInvalidValue;
-  const size_t lds = (size_t)2 * max_n * F * sizeof(float) + (size_t)3 * (max_n * (max_n - 1) / 2) + 16;
+  const size_t lds = (size_t)2 * max_n * F * sizeof(float) + (size_t)(max_n * (max_n - 1) / 2) + 16;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   allow_big_lds(&k_aggregate);
   hipLaunchKernelGGL(k_aggregate, dim3((unsigned)B), dim3(F > 64 ? 128 : 64), lds, stream, x, Wf, pair_flag, mol_ptr,
