@@ -217,6 +217,49 @@ def test_schnet_vs_oracle_synthetic_128():
         assert rel_err(gval.cpu(), P[k].grad) < TOL_GRAD, k
 
 
+@pytest.mark.parametrize("cutoff", [5.0, 10.0])
+def test_schnet_big_and_tiny_molecules_vs_oracle(cutoff):
+    """Paths the Molecule3D-sized fixtures never take: molecules above the 32-neighbour cap (asymmetric graph, flag
+    bits differ), pair tiles whose atom window exceeds the LDS stage (60-atom molecules; runs of 2-atom molecules
+    packing 128 molecules into one tile -> global-operand fallback of the backward kernels), single atoms."""
+    from geossl_amd.synthetic import make_batch
+    from oracle import nets
+    sizes = [60, 3] + [2] * 150 + [50, 1, 1, 18] + [2] * 40 + [33]
+    b = make_batch(0, seed=5, sizes=sizes)
+    cfg = dict(hidden_channels=128, num_filters=128, num_interactions=3, num_gaussians=51, cutoff=cutoff, node_class=9,
+               readout="add")
+    model = product_schnet(cfg, DEV)
+    P = schnet_oracle_params(cfg)
+    x, pos, bat = t(b["x"]), t(b["positions"]), t(b["batch"])
+    out_o, h_o = nets.schnet_forward(P, x[:, 0], pos, bat, cutoff, 3, "add", return_latent=True)
+    ((h_o ** 2).sum() + out_o.sum()).backward()
+    out, h = model(x.to(DEV)[:, 0], pos.to(DEV), bat.to(DEV), return_latent=True)
+    ((h ** 2).sum() + out.sum()).backward()
+    assert_close(h.detach().cpu(), h_o.detach(), TOL_OUT, "h")
+    assert_close(out.detach().cpu(), out_o.detach(), TOL_OUT, "out")
+    for k, gval in unique_named_grads(model).items():
+        assert rel_err(gval.cpu(), P[k].grad) < TOL_GRAD, k
+
+
+@pytest.mark.parametrize("F", [32, 64])
+def test_schnet_other_widths_vs_oracle(F):
+    from geossl_amd.synthetic import make_batch
+    from oracle import nets
+    b = make_batch(24, seed=8, mode="B")
+    cfg = dict(hidden_channels=F, num_filters=F, num_interactions=2, num_gaussians=50, cutoff=10.0, node_class=9,
+               readout="mean")
+    model = product_schnet(cfg, DEV)
+    P = schnet_oracle_params(cfg)
+    x, pos, bat = t(b["x"]), t(b["positions"]), t(b["batch"])
+    _, h_o = nets.schnet_forward(P, x[:, 0], pos, bat, 10.0, 2, "mean", return_latent=True)
+    (h_o ** 2).sum().backward()
+    _, h = model(x.to(DEV)[:, 0], pos.to(DEV), bat.to(DEV), return_latent=True)
+    (h ** 2).sum().backward()
+    assert_close(h.detach().cpu(), h_o.detach(), TOL_OUT, "h")
+    for k, gval in unique_named_grads(model).items():
+        assert rel_err(gval.cpu(), P[k].grad) < TOL_GRAD, k
+
+
 def test_schnet_errors():
     from geossl_amd import _lib
     from geossl_amd.Geom3D.models import SchNet
