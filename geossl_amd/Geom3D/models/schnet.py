@@ -216,7 +216,7 @@ class _SchNetCore(torch.autograd.Function):
             nfl = _lib.load().geossl_cfconv_filter_bwd_workspace_floats(P, L, F, G)
             ws2 = torch.empty(nfl, dtype=torch.float32, device=dev)
             call("geossl_cfconv_filter_bwd", ptr(sv["pair_d"]), ptr(sv["pair_c"]), ptr(sv["pair_flag"]),
-                 ptr(lay.pair_i), ptr(lay.pair_j), P, C.byref(fw), C.byref(gin), L, F, G, ptr(cfg["offset"]),
+                 ptr(lay.pair_i), ptr(lay.pair_j), P, N, C.byref(fw), C.byref(gin), L, F, G, ptr(cfg["offset"]),
                  cfg["coeff"], ptr(sv["T"]), C.byref(gout), ptr(ws2), accum, st)
         elif not direct:
             for gl in g_layers:

@@ -73,17 +73,32 @@ __device__ __forceinline__ void stage_atoms(const float* __restrict__ src, int a
 
 // Builds the dO tile of rows [r0, r0+64) of layer l in LDS (NW waves).  Starts with a barrier (the previous tile must
 // be fully consumed) and ends with one; the tile and tdd are valid afterwards.
+// `alo` = first atom of the tile's window (= pair_i[r0]: pair slots are lexicographic inside a molecule, so the first
+// row holds the smallest atom); it is fetched one tile ahead by the caller, which lets the row descriptors and a
+// fixed ATOM_CAP-row window of x / dagg be requested together — one global round trip per tile instead of two.
 template <int F, int NW>
 __device__ __forceinline__ void build_dO_tile(const TileLds<F>& L, const float* __restrict__ pair_d,
                                               const float* __restrict__ pair_c, const uint8_t* __restrict__ pair_flag,
                                               const int32_t* __restrict__ pair_i, const int32_t* __restrict__ pair_j,
-                                              int P, int r0, const float* __restrict__ x,
+                                              int P, int N, int r0, int alo, const float* __restrict__ x,
                                               const float* __restrict__ dagg, int tid) {
-  constexpr int AS = F + 1, NT = 64 * NW;
+  constexpr int AS = F + 1, NT = 64 * NW, Q = F / 4;
+  constexpr int NPRE = (ATOM_CAP * Q + NT - 1) / NT;  // float4 per thread and array for the atom window
   const int lane = tid & 63, wave = tid >> 6;
-  __syncthreads();
+  // ---- requests: atom window (speculative, fixed size) and row descriptors
+  const int nwin = min(ATOM_CAP, N - alo);
+  const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)alo * F);
+  const float4* d4 = reinterpret_cast<const float4*>(dagg + (size_t)alo * F);
+  float4 px[NPRE], pdg[NPRE];
+#pragma unroll
+  for (int u = 0; u < NPRE; ++u) {
+    const int i = tid + NT * u;
+    const bool ok = i < nwin * Q;
+    px[u] = ok ? x4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    pdg[u] = ok ? d4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
   int ai = 0, aj = 0;
-  float m0 = 0.0f, m1 = 0.0f;
+  float m0 = 0.0f, m1 = 0.0f, dd = 0.0f;
   if (wave == 0) {  // one pair row per lane
     const int row = r0 + lane;
     const bool ok = row < P;
@@ -94,24 +109,32 @@ __device__ __forceinline__ void build_dO_tile(const TileLds<F>& L, const float* 
     const float c = pair_c[q];
     m0 = (fl & 1u) ? c : 0.0f;
     m1 = (fl & 2u) ? c : 0.0f;
-    L.tdd[lane] = pair_d[q];
-    int amax = aj + 1;
+    dd = pair_d[q];
+  }
+  __syncthreads();  // previous tile fully consumed: LDS may be overwritten
+  int amax = aj + 1;
+  if (wave == 0) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o, 64));
+    const bool staged0 = amax - alo <= ATOM_CAP;
+    L.tdd[lane] = dd;
+    L.desc[lane] = staged0 ? make_int4((ai - alo) * AS, (aj - alo) * AS, __float_as_int(m0), __float_as_int(m1))
+                           : make_int4(ai, aj, __float_as_int(m0), __float_as_int(m1));
     if (lane == 0) *L.s_amax = amax;
   }
-  const int alo = pair_i[r0];  // pair slots are lexicographic inside a molecule: the first row has the smallest atom
-  __syncthreads();
-  const int na = *L.s_amax - alo;
-  const bool staged = na <= ATOM_CAP;
-  if (wave == 0)
-    L.desc[lane] = staged ? make_int4((ai - alo) * AS, (aj - alo) * AS, __float_as_int(m0), __float_as_int(m1))
-                          : make_int4(ai, aj, __float_as_int(m0), __float_as_int(m1));
-  if (staged) {
-    stage_atoms<F, NT>(x, alo, na, L.xs, tid);
-    stage_atoms<F, NT>(dagg, alo, na, L.ds, tid);
+#pragma unroll
+  for (int u = 0; u < NPRE; ++u) {
+    const int i = tid + NT * u;
+    if (i < nwin * Q) {
+      const int a = i / Q, q4 = i - a * Q;
+      float* dx = L.xs + a * AS + 4 * q4;
+      float* dg = L.ds + a * AS + 4 * q4;
+      dx[0] = px[u].x; dx[1] = px[u].y; dx[2] = px[u].z; dx[3] = px[u].w;
+      dg[0] = pdg[u].x; dg[1] = pdg[u].y; dg[2] = pdg[u].z; dg[3] = pdg[u].w;
+    }
   }
   __syncthreads();
+  const bool staged = *L.s_amax - alo <= ATOM_CAP;
   // lane = pair row, wave w takes n = w, w+NW, ...
   const int4 q = L.desc[lane];
   const float qm0 = __int_as_float(q.z), qm1 = __int_as_float(q.w);
@@ -139,7 +162,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_filter_bwd_a(const float* __rest
                                                              const float* __restrict__ pair_c,
                                                              const uint8_t* __restrict__ pair_flag,
                                                              const int32_t* __restrict__ pair_i,
-                                                             const int32_t* __restrict__ pair_j, int P,
+                                                             const int32_t* __restrict__ pair_j, int P, int N,
                                                              GeosslFilterWeights w, GeosslFilterGradIn g, int G,
                                                              const float* __restrict__ offset, float coeff,
                                                              const float* __restrict__ T,
@@ -173,8 +196,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_filter_bwd_a(const float* __rest
   const int ntiles = (P + TR - 1) / TR;
   const int per = (ntiles + gridDim.x - 1) / gridDim.x;  // contiguous tile range per block (atom reuse in L2)
   const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
+  int alo_next = t_begin < t_end ? pair_i[t_begin * TR] : 0;
   for (int t = t_begin; t < t_end; ++t) {
     const int r0 = t * TR;
+    const int alo = alo_next;
+    if (t + 1 < t_end) alo_next = pair_i[r0 + TR];  // one tile ahead: the next build needs it before anything else
     // saved hidden activation of the tile's rows for this lane's hidden unit, C layout (requested before the build)
     float tc[2][16];
 #pragma unroll
@@ -184,7 +210,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_filter_bwd_a(const float* __rest
         const int row = min(r0 + 32 * rb + c_row(r, lane), P - 1);
         tc[rb][r] = T[(lbase + row) * F + col];
       }
-    build_dO_tile<F, NW>(L, pair_d, pair_c, pair_flag, pair_i, pair_j, P, r0, x, dagg, tid);
+    build_dO_tile<F, NW>(L, pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, r0, alo, x, dagg, tid);
     f32x16 acc[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -252,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_filter_bwd_b(const float* __rest
                                                              const float* __restrict__ pair_c,
                                                              const uint8_t* __restrict__ pair_flag,
                                                              const int32_t* __restrict__ pair_i,
-                                                             const int32_t* __restrict__ pair_j, int P,
+                                                             const int32_t* __restrict__ pair_j, int P, int N,
                                                              GeosslFilterGradIn g, const float* __restrict__ T,
                                                              float* __restrict__ partial_w2,
                                                              float* __restrict__ partial_b2) {
@@ -274,28 +300,41 @@ __global__ __launch_bounds__(64 * NW, 2) void k_filter_bwd_b(const float* __rest
   const int ntiles = (P + TR - 1) / TR;
   const int per = (ntiles + gridDim.x - 1) / gridDim.x;
   const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
+  int alo_next = t_begin < t_end ? pair_i[t_begin * TR] : 0;
   for (int t = t_begin; t < t_end; ++t) {
     const int r0 = t * TR;
-    build_dO_tile<F, NW>(L, pair_d, pair_c, pair_flag, pair_i, pair_j, P, r0, x, dagg, tid);
-    const float* abase = L.dO + nrow * TS + kh;  // A[i = n][kslot kh] of k-step kk = dO[row 2kk+kh][n] = abase[2kk]
-    const float* tbase = T + lbase * F + NCB * j;  // this lane's NCB consecutive columns of a T row
-#pragma unroll 8
-    for (int kk = 0; kk < TR / 2; ++kk) {
-      const int row = min(r0 + 2 * kk + kh, P - 1);  // rows past P have dO = 0
-      const float a = abase[2 * kk];
-      float bv[NCB];
-      if constexpr (NCB == 4) {
-        const float4 v = *reinterpret_cast<const float4*>(tbase + (size_t)row * F);
-        bv[0] = v.x; bv[1] = v.y; bv[2] = v.z; bv[3] = v.w;
-      } else if constexpr (NCB == 2) {
-        const float2 v = *reinterpret_cast<const float2*>(tbase + (size_t)row * F);
-        bv[0] = v.x; bv[1] = v.y;
-      } else {
-        bv[0] = tbase[(size_t)row * F];
-      }
+    const int alo = alo_next;
+    if (t + 1 < t_end) alo_next = pair_i[r0 + TR];
+    // B fragments of the whole tile first: row 2kk+kh of T, this lane's NCB consecutive columns.  They do not depend on
+    // the dO tile, so the 32 loads fly while the tile is being built; the MFMA loop below then touches LDS only.
+    float bv[TR / 2][NCB];
+    {
+      const float* tbase = T + lbase * F + NCB * j;
 #pragma unroll
-      for (int c = 0; c < NCB; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[c], acc[c], 0, 0, 0);
-      bsum += a;
+      for (int kk = 0; kk < TR / 2; ++kk) {
+        const int row = min(r0 + 2 * kk + kh, P - 1);  // rows past P have dO = 0
+        if constexpr (NCB == 4) {
+          const float4 v = *reinterpret_cast<const float4*>(tbase + (size_t)row * F);
+          bv[kk][0] = v.x; bv[kk][1] = v.y; bv[kk][2] = v.z; bv[kk][3] = v.w;
+        } else if constexpr (NCB == 2) {
+          const float2 v = *reinterpret_cast<const float2*>(tbase + (size_t)row * F);
+          bv[kk][0] = v.x; bv[kk][1] = v.y;
+        } else {
+          bv[kk][0] = tbase[(size_t)row * F];
+        }
+      }
+    }
+    build_dO_tile<F, NW>(L, pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, r0, alo, x, dagg, tid);
+    const float* abase = L.dO + nrow * TS + kh;  // A[i = n][kslot kh] of k-step kk = dO[row 2kk+kh][n] = abase[2kk]
+    float a_cur = abase[0];
+#pragma unroll
+    for (int kk = 0; kk < TR / 2; ++kk) {
+      const float a_nxt = abase[2 * (kk + 1 < TR / 2 ? kk + 1 : kk)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, bv[kk][c], acc[c], 0, 0, 0);
+      bsum += a_cur;
+      a_cur = a_nxt;
     }
   }
   const size_t pb = (size_t)l * gridDim.x + blockIdx.x;
@@ -326,7 +365,7 @@ extern "C" int64_t geossl_cfconv_filter_bwd_workspace_floats(int64_t P, int L, i
 }
 
 extern "C" int geossl_cfconv_filter_bwd(const float* pair_d, const float* pair_c, const uint8_t* pair_flag,
-                                        const int32_t* pair_i, const int32_t* pair_j, int64_t P,
+                                        const int32_t* pair_i, const int32_t* pair_j, int64_t P, int64_t N,
                                         const GeosslFilterWeights* w, const GeosslFilterGradIn* g, int L, int F, int G,
                                         const float* offset, float coeff, const float* T,
                                         const GeosslFilterGradOut* out, float* workspace, int accumulate,
@@ -346,9 +385,9 @@ extern "C" int geossl_cfconv_filter_bwd(const float* pair_d, const float* pair_c
     allow_big_lds(&k_filter_bwd_a<NW>);                                                                             \
     allow_big_lds(&k_filter_bwd_b<NW>);                                                                             \
     hipLaunchKernelGGL((k_filter_bwd_a<NW>), grid, dim3(64 * NW), lds, stream, pair_d, pair_c, pair_flag, pair_i,   \
-                       pair_j, (int)P, *w, *g, G, offset, coeff, T, pw1, pb1);                                      \
+                       pair_j, (int)P, (int)N, *w, *g, G, offset, coeff, T, pw1, pb1);                                      \
     hipLaunchKernelGGL((k_filter_bwd_b<NW>), grid, dim3(64 * NW), lds, stream, pair_d, pair_c, pair_flag, pair_i,   \
-                       pair_j, (int)P, *g, T, pw2, pb2);                                                            \
+                       pair_j, (int)P, (int)N, *g, T, pw2, pb2);                                                            \
   } while (0)
   if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
 #undef LAUNCH

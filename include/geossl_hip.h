@@ -101,7 +101,7 @@ typedef struct {
 } GeosslFilterGradOut;
 int64_t geossl_cfconv_filter_bwd_workspace_floats(int64_t P, int L, int F, int G);
 int geossl_cfconv_filter_bwd(const float* pair_d, const float* pair_c, const uint8_t* pair_flag, const int32_t* pair_i,
-                             const int32_t* pair_j, int64_t P, const GeosslFilterWeights* w,
+                             const int32_t* pair_j, int64_t P, int64_t N, const GeosslFilterWeights* w,
                              const GeosslFilterGradIn* g, int L, int F, int G, const float* offset, float coeff,
                              const float* T, const GeosslFilterGradOut* out, float* workspace, int accumulate,
                              hipStream_t stream);
