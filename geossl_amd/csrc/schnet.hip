@@ -64,12 +64,13 @@ __global__ __launch_bounds__(128) void k_aggregate(const float* __restrict__ x, 
     // a' < a, so the summation order per target stays ascending in the source index)
     int a = 0, b = 1;
     float xa = n > 0 ? xs[f] : 0.0f, acc_a = 0.0f;
-    for (int p0 = 0; p0 < np; p0 += 8) {
-      float w[8];
+    constexpr int U = 16;  // filter rows in flight per thread
+    for (int p0 = 0; p0 < np; p0 += U) {
+      float w[U];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) w[u] = wcol[(size_t)min(p0 + u, np - 1) * F];  // 8 filter rows in flight
+      for (int u = 0; u < U; ++u) w[u] = wcol[(size_t)min(p0 + u, np - 1) * F];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < U; ++u) {
         if (p0 + u < np) {
           const unsigned fl = sfl[p0 + u];
           if (fl & 1u) acc_a = __fadd_rn(acc_a, __fmul_rn(xs[b * F + f], w[u]));                  // edge b -> a
@@ -106,19 +107,31 @@ __global__ void k_embedding_fwd(const int64_t* __restrict__ z, int64_t zs, const
   }
 }
 
-#define GEOSSL_EMB_CHUNKS 64
-// block (chunk, class): sums the rows of its chunk whose type is `class`, in row order
+#define GEOSSL_EMB_CHUNKS 256
+// block = one chunk of rows, thread f owns feature column f of a [classes][F] accumulator table in LDS (thread-private
+// columns: no barriers, rows added in row order); every row of dh is read once, eight rows in flight
 __global__ void k_embedding_bwd_partial(const int64_t* __restrict__ z, int64_t zs, const float* __restrict__ dh,
-                                        int64_t N, int F, float* __restrict__ partial) {
-  const int chunk = blockIdx.x, c = blockIdx.y, C = gridDim.y;
+                                        int64_t N, int F, int C, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int chunk = blockIdx.x, f = threadIdx.x;
   const int64_t per = (N + GEOSSL_EMB_CHUNKS - 1) / GEOSSL_EMB_CHUNKS;
   const int64_t lo = chunk * per, hi = min((int64_t)N, lo + per);
-  for (int f = threadIdx.x; f < F; f += blockDim.x) {
-    float s = 0.0f;
-    for (int64_t a = lo; a < hi; ++a)
-      if (z[a * zs] == c) s += dh[a * F + f];
-    partial[((size_t)chunk * C + c) * F + f] = s;
+  if (f >= F) return;
+  for (int c = 0; c < C; ++c) smem[c * F + f] = 0.0f;
+  for (int64_t a0 = lo; a0 < hi; a0 += 8) {
+    float v[8];
+    int cls[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t a = min(a0 + u, hi - 1);
+      v[u] = dh[a * F + f];
+      cls[u] = (int)z[a * zs];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (a0 + u < hi && cls[u] >= 0 && cls[u] < C) smem[cls[u] * F + f] += v[u];
   }
+  for (int c = 0; c < C; ++c) partial[((size_t)chunk * C + c) * F + f] = smem[c * F + f];
 }
 __global__ void k_embedding_bwd_reduce(const float* __restrict__ partial, int len, float* __restrict__ dtable,
                                        int accumulate) {
@@ -211,8 +224,10 @@ extern "C" int64_t geossl_embedding_bwd_workspace_floats(int num_classes, int F)
 extern "C" int geossl_embedding_bwd(const int64_t* z, int64_t z_stride, const float* dh, int num_classes, int64_t N,
                                     int F, float* dtable, float* workspace, int accumulate, hipStream_t stream) {
   if (num_classes <= 0) return 0;
-  hipLaunchKernelGGL(k_embedding_bwd_partial, dim3(GEOSSL_EMB_CHUNKS, num_classes), dim3(F < 256 ? F : 256), 0, stream,
-                     z, z_stride, dh, N, F, workspace);
+  if (F > 256 || (size_t)num_classes * F * sizeof(float) > 160 * 1024) return (int)hipErrorInvalidValue;
+  allow_big_lds(&k_embedding_bwd_partial);
+  hipLaunchKernelGGL(k_embedding_bwd_partial, dim3(GEOSSL_EMB_CHUNKS), dim3((F + 63) / 64 * 64),
+                     (size_t)num_classes * F * sizeof(float), stream, z, z_stride, dh, N, F, num_classes, workspace);
   GEOSSL_CHECK_LAUNCH();
   const int len = num_classes * F;
   hipLaunchKernelGGL(k_embedding_bwd_reduce, dim3(grid1d(len, 256)), dim3(256), 0, stream, workspace, len, dtable,
