@@ -2,139 +2,221 @@
 // CFConv.forward, schnet.py:141-145,186-187 (with GaussianSmearing, :205-207, folded in):
 //     Wf_l[p] = ( ssp( rbf(d_p) A1_l^T + b1_l ) A2_l^T + b2_l ) * C(d_p)          for every pair slot p, layer l.
 //
-// Column-split waves with register-resident weights: wave w of a block owns output columns [32w, 32w+32) of BOTH
-// GEMMs and keeps its slices of A1_l (G x 32) and A2_l (F x 32) as MFMA B fragments in registers for the whole
-// launch (a block serves one layer).  The only LDS tile is the hidden activation t of the block's 128 pair rows
-// (64 KB at F = 128), so two blocks fit per CU and one block's ssp / store phase overlaps the other's MFMA phase:
-//   GEMM1  every wave evaluates the Gaussian smearing of all 128 rows directly in A-fragment layout (one exp per
-//          row block and k-step) and multiplies by its own 32 hidden columns;
-//   ssp    in C layout; t goes to LDS (swizzled, conflict-free) and, when training, to HBM;
-//   GEMM2  one register B fragment feeds four independent MFMAs (the four 32-row A fragments come from LDS);
-//   out    times the envelope C(d), 128-byte row segments to HBM.
+// fp32 results on the bf16 matrix pipe (see split.h).  Both GEMMs are evaluated TRANSPOSED with the pair rows on
+// the MFMA N axis (lanes) and the weights as the A operand:   t^T = A1 rbf^T,   Wf^T = A2 t^T.   A wave owns 32
+// pair rows end to end (no block-level sync in the main loop):
+//   * rbf^T B fragments: lane (row j, half kh) evaluates the 8 Gaussians of its k-step for its own row - every
+//     exp is computed exactly once;
+//   * the C layout of t^T (lane = pair row, registers = 4 consecutive hidden features per group) IS the B
+//     fragment layout of the second GEMM under a fixed permutation of the contraction index that the weight
+//     fragments share, so ssp + splitting happen in registers with no transposition through LDS;
+//   * the same layout gives 16-byte row-major global stores of t (saved for the backward) and Wf;
+//   * the weights live in LDS pre-split and pre-permuted as ready-made A fragments (1 KB per fragment, lane i at
+//     byte 16 i: conflict-free ds_read_b128), 144 KB for F = 128, G <= 64; one block of 8 waves per CU.
 #include "common.h"
 #include "geossl_hip.h"
+#include "split.h"
 
 using namespace geossl;
 
 namespace {
 
-template <typename K>
-inline void allow_big_lds(K kernel) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-}
-
-// NW = F/32 waves per block; K1 = k-steps of GEMM1 (>= ceil(G/2))
-template <int NW, int K1>
-__global__ __launch_bounds__(64 * NW, 2) void k_filter_fwd(const float* __restrict__ pair_d,
-                                                           const float* __restrict__ pair_c, int P,
-                                                           GeosslFilterWeights w, int G,
-                                                           const float* __restrict__ offset, float coeff,
-                                                           float* __restrict__ Tout, float* __restrict__ Wf) {
-  constexpr int F = 32 * NW, K2 = F / 2, NT = 64 * NW;
-  constexpr int TS = 129;  // row stride of the k-major hidden-activation tile: C-layout writes (lanes = k) and
-                           // A-fragment reads (lanes = rows) are both conflict-free, and every A read of GEMM2 is
-                           // base + compile-time offset (no per-step address arithmetic)
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* At = smem;            // [F (k)][TS] hidden activations of the tile's 128 rows, k-major
-  float* cw = At + F * TS;     // [128] envelope of the tile's rows
-  float* stage = cw + 128 + (threadIdx.x >> 6) * 512;  // wave-private 16x32 transposition stage for wide stores
+// NMB = F/32 row blocks of the weight matrices; K1S = 16-wide k-steps of the first GEMM (>= ceil(G/16))
+template <int NMB, int K1S>
+__global__ __launch_bounds__(512) void k_filter_fwd(const float* __restrict__ pair_d,
+                                                    const float* __restrict__ pair_c, int P,
+                                                    GeosslFilterWeights w, int G,
+                                                    const float* __restrict__ offset, float coeff,
+                                                    float* __restrict__ Tout, float* __restrict__ Wf) {
+  constexpr int F = 32 * NMB, K2S = F / 16;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  u32x4* W2f = reinterpret_cast<u32x4*>(smem_raw);          // [NMB][K2S][3][64] A fragments of A2
+  u32x4* W1f = W2f + NMB * K2S * 3 * 64;                    // [NMB][K1S][3][64] A fragments of A1
+  float* b1s = reinterpret_cast<float*>(W1f + NMB * K1S * 3 * 64);  // [F]
+  float* b2s = b1s + F;                                     // [F]
+  float* offs = b2s + F;                                    // [16*K1S] Gaussian centres, zero padded
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
   const int l = blockIdx.y;
-  const int col = 32 * wave + j;
-  // ---- second-layer weight slice of this wave as B fragments: bw2[kk] = A2[col][2kk+kh]
-  float bw2[K2];
+  // ---- one-time weight formatting: split + permute into ready-made A fragments
   {
-    const float4* w2 = reinterpret_cast<const float4*>(w.w2[l] + (size_t)col * F);
-#pragma unroll
-    for (int q = 0; q < K2 / 2; ++q) {
-      const float4 v = w2[q];
-      bw2[2 * q] = kh ? v.y : v.x;
-      bw2[2 * q + 1] = kh ? v.w : v.z;
+    const float* __restrict__ w2 = w.w2[l];
+    for (int i = tid; i < NMB * K2S * 64; i += 512) {
+      const int ln = i & 63, ks = (i >> 6) % K2S, mb = i / (64 * K2S);
+      // contraction-index permutation kperm (split.h): elements 0..3 <- features 4kh.., 4..7 <- features 8+4kh..
+      const float* row = w2 + (size_t)(32 * mb + (ln & 31)) * F + 16 * ks + 4 * (ln >> 5);
+      const float4 lo = *reinterpret_cast<const float4*>(row), hi = *reinterpret_cast<const float4*>(row + 8);
+      const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      const Frag3 f = split8(v);
+      u32x4* dst = W2f + ((size_t)(mb * K2S + ks) * 3) * 64 + ln;
+      dst[0] = f.h;
+      dst[64] = f.m;
+      dst[128] = f.l;
     }
+    const float* __restrict__ w1 = w.w1[l];
+    for (int i = tid; i < NMB * K1S * 64; i += 512) {
+      const int ln = i & 63, ks = (i >> 6) % K1S, mb = i / (64 * K1S);
+      const float* row = w1 + (size_t)(32 * mb + (ln & 31)) * G;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int g = 16 * ks + 8 * (ln >> 5) + e;
+        v[e] = g < G ? row[g] : 0.0f;
+      }
+      const Frag3 f = split8(v);
+      u32x4* dst = W1f + ((size_t)(mb * K1S + ks) * 3) * 64 + ln;
+      dst[0] = f.h;
+      dst[64] = f.m;
+      dst[128] = f.l;
+    }
+    for (int i = tid; i < F; i += 512) {
+      b1s[i] = w.b1[l][i];
+      b2s[i] = w.b2[l][i];
+    }
+    for (int i = tid; i < 16 * K1S; i += 512) offs[i] = i < G ? offset[i] : 0.0f;
   }
-  const float* __restrict__ w1p = w.w1[l] + (size_t)col * G;  // first-layer row of this lane's column (L1 resident)
-  const float b1c = w.b1[l][col], b2c = w.b2[l][col];
+  __syncthreads();
   const size_t lbase = (size_t)l * P;
-  const int ntiles = (P + 127) / 128;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int r0 = t * 128;
-    float d[4];
+  const int nrb = (P + 31) / 32;
+  // ---- main loop: a wave takes 32 pair rows through both GEMMs; no block-level synchronisation
+  for (int rb = blockIdx.x * 8 + wave; rb < nrb; rb += gridDim.x * 8) {
+    const int row = 32 * rb + j;
+    const bool live = row < P;
+    const float d = live ? pair_d[row] : 0.0f;
+    const float cw = live ? pair_c[row] : 0.0f;
+    // first GEMM, transposed: acc1[mb] = (A1 rbf^T)[32mb.., rows]; bias along the register (feature) axis
+    f32x16 acc1[NMB];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-      const int row = r0 + 32 * rb + j;
-      d[rb] = row < P ? pair_d[row] : 0.0f;
-    }
-    for (int i = tid; i < 128; i += NT) cw[i] = r0 + i < P ? pair_c[r0 + i] : 0.0f;
-    f32x16 acc[4];
+    for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rb][r] = b1c;
-    // GEMM1: Gaussian smearing (schnet.py:206-207) in A-fragment layout x this wave's columns of A1^T
-#pragma unroll 2
-    for (int kk = 0; kk < K1; ++kk) {
-      const int k = 2 * kk + kh;
-      const bool ok = k < G;
-      const float off = ok ? offset[k] : 0.0f, b = ok ? w1p[k] : 0.0f;
-      float a[4];
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        const float diff = d[rb] - off;
-        a[rb] = ok ? __expf(coeff * (diff * diff)) : 0.0f;
+      for (int q = 0; q < 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4*>(b1s + 32 * mb + 8 * q + 4 * kh);
+        acc1[mb][4 * q] = b.x;
+        acc1[mb][4 * q + 1] = b.y;
+        acc1[mb][4 * q + 2] = b.z;
+        acc1[mb][4 * q + 3] = b.w;
       }
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb], b, acc[rb], 0, 0, 0);
-    }
-    // ssp; hidden activation to LDS (k-major) and, when training, to HBM (16-byte stores via the LDS stage)
-    {
-      float* tcol = At + col * TS + 4 * kh;
+    for (int ks = 0; ks < K1S; ++ks) {
+      float v[8];
+      {
+        const float4 o0 = *reinterpret_cast<const float4*>(offs + 16 * ks + 8 * kh);
+        const float4 o1 = *reinterpret_cast<const float4*>(offs + 16 * ks + 8 * kh + 4);
+        const float o[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float tv = ssp(acc[rb][r]);
-          acc[rb][r] = tv;
-          tcol[32 * rb + (r & 3) + 8 * (r >> 2)] = tv;
+        for (int e = 0; e < 8; ++e) {
+          const float diff = d - o[e];
+          v[e] = __expf(coeff * (diff * diff));  // schnet.py:206-207 (padded centres meet zero weights)
         }
-        if (Tout != nullptr)
-          store_c_block_x4(Tout + (lbase + r0 + 32 * rb) * F + 32 * wave, F, P - (r0 + 32 * rb), stage, lane,
-                           [&](int r) { return acc[rb][r]; });
-        __builtin_amdgcn_sched_barrier(0);  // one row block at a time keeps the live set small
       }
-    }
-    __syncthreads();
+      const Frag3 bf = split8(v);
+      Frag3 af[NMB];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rb][r] = b2c;
-    // GEMM2: four 32-row A fragments from LDS per k-step against one register B fragment
-    {
-      const float* abase = At + kh * TS + j;  // A[row = 32rb+j][k = 2kk+kh] = abase[kk*2*TS + 32*rb]
-      float a_cur[4], a_nxt[4];
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) a_cur[rb] = abase[32 * rb];
-#pragma unroll
-      for (int kk = 0; kk < K2; ++kk) {
-        constexpr int last = K2 - 1;
-        const int kn = kk < last ? kk + 1 : kk;
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) a_nxt[rb] = abase[kn * 2 * TS + 32 * rb];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[rb], bw2[kk], acc[rb], 0, 0, 0);
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) a_cur[rb] = a_nxt[rb];
+      for (int mb = 0; mb < NMB; ++mb) {
+        const u32x4* src = W1f + ((size_t)(mb * K1S + ks) * 3) * 64 + lane;
+        af[mb].h = src[0];
+        af[mb].m = src[64];
+        af[mb].l = src[128];
       }
-    }
+      // product-major, block-minor: consecutive MFMAs hit different accumulators
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-      store_c_block_x4(Wf + (lbase + r0 + 32 * rb) * F + 32 * wave, F, P - (r0 + 32 * rb), stage, lane, [&](int r) {
-        return acc[rb][r] * cw[32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kh];  // schnet.py:187
-      });
+      for (int mb = 0; mb < NMB; ++mb) acc1[mb] = mfma_bf16(af[mb].l, bf.h, acc1[mb]);
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) acc1[mb] = mfma_bf16(af[mb].h, bf.l, acc1[mb]);
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) acc1[mb] = mfma_bf16(af[mb].m, bf.m, acc1[mb]);
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) acc1[mb] = mfma_bf16(af[mb].m, bf.h, acc1[mb]);
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) acc1[mb] = mfma_bf16(af[mb].h, bf.m, acc1[mb]);
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) acc1[mb] = mfma_bf16(af[mb].h, bf.h, acc1[mb]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+    // ssp; t to HBM (row-major, 16 bytes per store) when training; split into the B fragments of the second GEMM:
+    // registers 0..7 of block mb are k-step 2mb, registers 8..15 k-step 2mb+1, element e = register & 7
+    Frag3 tb[K2S];
+    {
+      float* trow = Tout != nullptr ? Tout + (lbase + row) * F + 4 * kh : nullptr;
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = ssp(acc1[mb][8 * half + e]);
+          if (trow != nullptr && live) {
+            *reinterpret_cast<float4*>(trow + 32 * mb + 16 * half) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(trow + 32 * mb + 16 * half + 8) = make_float4(v[4], v[5], v[6], v[7]);
+          }
+          tb[2 * mb + half] = split8(v);
+          __builtin_amdgcn_sched_barrier(0);  // one 8-register group at a time keeps the live set small
+        }
+      }
+    }
+    // second GEMM, transposed, two 32-feature output blocks at a time
+    constexpr int MP = NMB >= 2 ? 2 : 1;
+    float* orow = Wf + (lbase + row) * F + 4 * kh;
+#pragma unroll
+    for (int mb0 = 0; mb0 < NMB; mb0 += MP) {
+      f32x16 acc2[MP];
+#pragma unroll
+      for (int u = 0; u < MP; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 b = *reinterpret_cast<const float4*>(b2s + 32 * (mb0 + u) + 8 * q + 4 * kh);
+          acc2[u][4 * q] = b.x;
+          acc2[u][4 * q + 1] = b.y;
+          acc2[u][4 * q + 2] = b.z;
+          acc2[u][4 * q + 3] = b.w;
+        }
+      Frag3 af[MP], an[MP];
+#pragma unroll
+      for (int u = 0; u < MP; ++u) {
+        const u32x4* src = W2f + ((size_t)((mb0 + u) * K2S) * 3) * 64 + lane;
+        af[u].h = src[0];
+        af[u].m = src[64];
+        af[u].l = src[128];
+      }
+#pragma unroll
+      for (int ks = 0; ks < K2S; ++ks) {
+        if (ks + 1 < K2S) {  // fragments of the next k-step are requested before this step's MFMAs issue
+#pragma unroll
+          for (int u = 0; u < MP; ++u) {
+            const u32x4* src = W2f + ((size_t)((mb0 + u) * K2S + ks + 1) * 3) * 64 + lane;
+            an[u].h = src[0];
+            an[u].m = src[64];
+            an[u].l = src[128];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < MP; ++u) acc2[u] = mfma_bf16(af[u].l, tb[ks].h, acc2[u]);
+#pragma unroll
+        for (int u = 0; u < MP; ++u) acc2[u] = mfma_bf16(af[u].h, tb[ks].l, acc2[u]);
+#pragma unroll
+        for (int u = 0; u < MP; ++u) acc2[u] = mfma_bf16(af[u].m, tb[ks].m, acc2[u]);
+#pragma unroll
+        for (int u = 0; u < MP; ++u) acc2[u] = mfma_bf16(af[u].m, tb[ks].h, acc2[u]);
+#pragma unroll
+        for (int u = 0; u < MP; ++u) acc2[u] = mfma_bf16(af[u].h, tb[ks].m, acc2[u]);
+#pragma unroll
+        for (int u = 0; u < MP; ++u) acc2[u] = mfma_bf16(af[u].h, tb[ks].h, acc2[u]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 1 < K2S) {
+#pragma unroll
+          for (int u = 0; u < MP; ++u) af[u] = an[u];
+        }
+      }
+      if (live) {
+#pragma unroll
+        for (int u = 0; u < MP; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)  // schnet.py:187: filter times the cosine envelope
+            *reinterpret_cast<float4*>(orow + 32 * (mb0 + u) + 8 * q) =
+                make_float4(acc2[u][4 * q] * cw, acc2[u][4 * q + 1] * cw, acc2[u][4 * q + 2] * cw,
+                            acc2[u][4 * q + 3] * cw);
+      }
+    }
   }
 }
 
@@ -144,24 +226,25 @@ extern "C" int geossl_cfconv_filter_fwd(const float* pair_d, const float* pair_c
                                         const GeosslFilterWeights* w, int L, int F, int G, const float* offset,
                                         float coeff, float* T, float* Wf, hipStream_t stream) {
   if (P <= 0 || L <= 0) return 0;
-  if (L > GEOSSL_MAX_L || (F != 32 && F != 64 && F != 128) || G > 64) return (int)hipErrorInvalidValue;
-  const int ntiles = (int)((P + 127) / 128);
-  int per_layer = 512 / L;  // two blocks per CU
+  if (L > GEOSSL_MAX_L || (F != 32 && F != 64 && F != 128) || G > 64 || G < 1) return (int)hipErrorInvalidValue;
+  const int nrb = (int)((P + 31) / 32);
+  int per_layer = 256 / L;  // one 8-wave block per CU, a layer per block (its weights stay in LDS)
   if (per_layer < 1) per_layer = 1;
-  if (per_layer > ntiles) per_layer = ntiles;
+  if (per_layer > (nrb + 7) / 8) per_layer = (nrb + 7) / 8;
   dim3 grid(per_layer, L);
-  const size_t lds = ((size_t)F * 129 + 128 + 4 * 512) * sizeof(float);
-#define LAUNCH(NW, K1)                                                                                          \
+#define LAUNCH(NMB, K1S)                                                                                        \
   do {                                                                                                          \
-    allow_big_lds(&k_filter_fwd<NW, K1>);                                                                       \
-    hipLaunchKernelGGL((k_filter_fwd<NW, K1>), grid, dim3(64 * NW), lds, stream, pair_d, pair_c, (int)P, *w, G, \
+    const size_t lds = (size_t)(NMB * (2 * NMB) + NMB * K1S) * 3 * 1024 + (2 * 32 * NMB + 16 * K1S) * 4;        \
+    allow_big_lds(&k_filter_fwd<NMB, K1S>);                                                                     \
+    hipLaunchKernelGGL((k_filter_fwd<NMB, K1S>), grid, dim3(512), lds, stream, pair_d, pair_c, (int)P, *w, G,   \
                        offset, coeff, T, Wf);                                                                   \
   } while (0)
-#define LAUNCH_F(NW)                    \
+#define LAUNCH_F(NMB)                   \
   do {                                  \
-    if (G <= 8) LAUNCH(NW, 4);          \
-    else if (G <= 52) LAUNCH(NW, 26);   \
-    else LAUNCH(NW, 32);                \
+    if (G <= 16) LAUNCH(NMB, 1);        \
+    else if (G <= 32) LAUNCH(NMB, 2);   \
+    else if (G <= 48) LAUNCH(NMB, 3);   \
+    else LAUNCH(NMB, 4);                \
   } while (0)
   if (F == 128) LAUNCH_F(4); else if (F == 64) LAUNCH_F(2); else LAUNCH_F(1);
 #undef LAUNCH_F

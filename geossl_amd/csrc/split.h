@@ -1,0 +1,93 @@
+// fp32 GEMMs on the bf16 matrix pipe of gfx950 ("3 x bf16 split").
+//
+// Measured on MI355X (scratch microbenchmarks): v_mfma_f32_32x32x2_f32 runs on the same FP32 lanes as
+// the vector ALU - an f32 MFMA and the exp / softplus / address arithmetic of ANY wave on the SIMD serialise (the
+// time of a kernel is MFMA time + VALU time), and 157 TFLOP/s is the ceiling of both together.  The bf16 MFMA has
+// its own pipe (2.4 PFLOP/s measured) and does overlap with vector work issued by the same wave.
+//
+// Every fp32 operand is therefore split EXACTLY into three bf16 pieces, x = h + m + l (3 x 8 significant bits;
+// bf16 has the exponent range of fp32, so no scaling is involved), and a product sum_k a_k b_k is accumulated in
+// fp32 by six MFMAs over the piece products of weight 2^0 .. 2^-16:
+//        l*h, h*l, m*m, m*h, h*m, h*h          (smallest first)
+// The three dropped products (m*l, l*m, l*l) are <= 2^-24 relative to |a_k||b_k| - the size of the one rounding an
+// fp32 FMA commits per product - so the result carries fp32-GEMM accuracy (tests: 1e-6 relative against an fp64
+// evaluation, like the f32-MFMA path it replaces).  Six 32x32x16 bf16 MFMAs cost 192 matrix-pipe cycles per 16 k;
+// eight 32x32x2 f32 MFMAs cost 512 cycles of the shared FP32 lanes.
+//
+// Operand maps of v_mfma_f32_32x32x16_bf16 (A and B are symmetric):
+//     A: lane l holds A[row = l&31][k = 8 consecutive indices of half (l>>5)]      (one 16-byte register quad)
+//     B: lane l holds B[k = same 8 indices][col = l&31]
+//     C/D: as for the f32 MFMA: acc[reg], row = (reg&3) + 8*(reg>>2) + 4*(l>>5), col = l&31
+// Which 8 contraction indices a (half, element) pair stands for is free as long as A and B agree.  `kperm` is the
+// choice that makes the C layout of one product (register = 4 consecutive rows per group of 8) directly the operand
+// layout of the next, so chained products need no transposition.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+
+namespace geossl {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename K>
+inline void allow_big_lds(K kernel) {
+  static bool done = false;  // one attribute call per kernel instantiation (keeps it out of graph capture too)
+  if (!done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    done = true;
+  }
+}
+
+// element e (0..7) of half kh of a 16-wide k-step <-> index (e&3) + 8*(e>>2) + 4*kh of the step: registers
+// 0..7 / 8..15 of a C-layout accumulator are then elements 0..7 of two consecutive k-steps
+__device__ __forceinline__ int kperm(int e, int kh) { return (e & 3) + 8 * (e >> 2) + 4 * kh; }
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {  // round-to-nearest-even pack: low half = a
+  bf16x2 p = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, p);
+}
+// exact 3-way split of two fp32 values into packed bf16 pairs: v = h + m + l
+__device__ __forceinline__ void split2(float v0, float v1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = pk_bf16(v0, v1);
+  float r0 = v0 - __uint_as_float(h << 16), r1 = v1 - __uint_as_float(h & 0xffff0000u);
+  m = pk_bf16(r0, r1);
+  r0 -= __uint_as_float(m << 16);
+  r1 -= __uint_as_float(m & 0xffff0000u);
+  l = pk_bf16(r0, r1);
+}
+struct Frag3 {
+  u32x4 h, m, l;
+};
+// 8 fp32 values (one lane's share of a 16-wide k-step) -> three bf16x8 fragments
+__device__ __forceinline__ Frag3 split8(const float (&v)[8]) {
+  Frag3 f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t h, m, l;
+    split2(v[2 * q], v[2 * q + 1], h, m, l);
+    f.h[q] = h;
+    f.m[q] = m;
+    f.l[q] = l;
+  }
+  return f;
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                 0, 0);
+}
+// acc += A * B from piece fragments, smallest products first
+__device__ __forceinline__ void mma6(f32x16& acc, const Frag3& a, const Frag3& b) {
+  acc = mfma_bf16(a.l, b.h, acc);
+  acc = mfma_bf16(a.h, b.l, acc);
+  acc = mfma_bf16(a.m, b.m, acc);
+  acc = mfma_bf16(a.m, b.h, acc);
+  acc = mfma_bf16(a.h, b.m, acc);
+  acc = mfma_bf16(a.h, b.h, acc);
+}
+
+}  // namespace geossl
