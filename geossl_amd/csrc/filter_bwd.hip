@@ -1,198 +1,116 @@
 // Backward of the continuous-filter network (InteractionBlock.mlp inside CFConv, schnet.py:141-145,186-187) with
-// respect to its weights, for all interaction blocks in two launches.
+// respect to its weights, for all interaction blocks in ONE launch, on the bf16 matrix pipe (split.h).
 //
 // Upstream gradient per pair slot p = (i<j) of layer l (never stored per pair in HBM):
-//     dO[p][n] = C(d_p) * ( flag0 * dagg_l[i][n] * x_l[j][n]  +  flag1 * dagg_l[j][n] * x_l[i][n] )
-// Both kernels work on 64-row tiles of pair slots.  A tile touches the atoms of at most a few molecules, so the rows
-// a_lo..a_hi of x_l and dagg_l are staged in LDS with coalesced 16-byte loads, and the tile of dO is built ONCE per
-// block in LDS, n-major ([n][64 rows], row stride 65): it is the A operand of both products below with nothing but
-// base + immediate-offset ds_reads in the MFMA loops.  ~75 KB of LDS -> two blocks per CU.
+//     dO[p][c] = C(d_p) * ( flag0 * dagg_l[i][c] * x_l[j][c]  +  flag1 * dagg_l[j][c] * x_l[i][c] )
+// and, with t the saved hidden activation and rbf the Gaussian smearing of d_p,
+//     dt = dO W2 ;  dU = dt * ssp'(.) ;  dW1 += dU^T rbf ;  db1 += sum dU ;  dW2 += dO^T t ;  db2 += sum dO.
 //
-//   k_filter_bwd_a :  dt = dO W2 ; dU = dt * ssp'(.) ; dW1 += dU^T rbf(d) ; db1 += sum dU
-//       column-split waves: wave w owns hidden units [32w, 32w+32) and keeps that slice of W2 as B fragments in
-//       registers.  dt's accumulators (C layout: lane = hidden unit, register = pair row) ARE the A operand of the
-//       dW1 product when the contraction slot of k-step s is the row held in register s — dU never leaves registers.
-//   k_filter_bwd_b :  dW2 += dO^T T ; db2 += sum dO
-//       wave w owns rows n in [32w, 32w+32) of dW2; A fragments are single ds_reads of the dO tile, B fragments are
-//       16-byte global loads of the saved hidden activation T (each half-wave reads one full 512-byte row), with the
-//       output columns of an accumulator block taken as {4j + c} so that no transposition is needed.
-// Weight-gradient accumulators stay in registers across all tiles of a block; one partial per block, fixed-order
-// reduction afterwards (no atomics).
+// A block works on 32-row tiles of pair slots.  A tile touches the atoms of at most a few molecules, so rows
+// a_lo.. of x_l and dagg_l are staged in LDS with coalesced 16-byte loads; from them all threads build, pre-split
+// into bf16 pieces and laid out as ready-made MFMA fragments (lane i at byte 16 i: conflict-free ds_read_b128),
+//     dOr : dO as A operand with the pair row on M and the channel c on K      (for dt = dO W2)
+//     dOf : dO as A operand with the channel c on M and the pair row on K      (for dW2 = dO^T t)
+//     rbf : Gaussian smearing as B operand with the pair row on K              (for dW1 = dU^T rbf)
+// The waves of a block are split by the hidden unit h they own (32 each) and by role:
+//   role A (waves 0..NW-1):  dt for its h slice (W2 slice as B fragments in registers), dU in place; the C layout of
+//       dt (lane = h, register = pair row in `kperm` order) IS the A-fragment layout of dW1's contraction over pair
+//       rows, so dU is split in registers and multiplied with the rbf fragments: dU never leaves the wave;
+//   role B (waves NW..2NW-1): loads the t slice of its h directly in B-fragment layout (lane = h, 8 pair rows),
+//       splits it in registers and accumulates dW2[:, h slice] against the dOf fragments.
+// T is read from HBM once (the second read of a slice hits L2), the dO tile is built once.  Weight-gradient
+// accumulators stay in registers across all tiles of a block; one partial per block, fixed-order reduction
+// afterwards (no atomics).
 #include "common.h"
 #include "geossl_hip.h"
+#include "split.h"
 #include "tn.h"
 
 using namespace geossl;
 
 namespace {
 
-constexpr int TR = 64;         // pair rows per tile
-constexpr int TS = TR + 1;     // row stride of the n-major dO tile
+constexpr int TR = 32;         // pair rows per tile
 constexpr int ATOM_CAP = 40;   // atoms staged per tile (two 18..20-atom molecules, or more smaller ones)
 
-template <typename K>
-inline void allow_big_lds(K kernel) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-}
-
-// LDS carve shared by both kernels
 template <int F>
-struct TileLds {
-  static constexpr int AS = F + 1;
-  float* dO;     // [F][TS]
+struct BwdLds {
+  static constexpr int AS = F + 4;  // staged atom row stride (16-byte aligned rows)
+  static constexpr int KC = F / 16, CB = F / 32;
+  u32x4* dOr;    // [KC][3][64]
+  u32x4* dOf;    // [CB][2][3][64]
+  u32x4* rbf;    // [2][2][3][64]
   float* xs;     // [ATOM_CAP][AS]
   float* ds;     // [ATOM_CAP][AS]
   float* tdd;    // [TR] distances of the tile's rows
-  int4* desc;    // [TR] {LDS offset of atom i, of atom j, C*flag0, C*flag1} (staged) or {i*F, j*F, ..} (global)
-  int* s_amax;   // [1]
-  __device__ explicit TileLds(float* smem) {
-    dO = smem;
-    xs = dO + F * TS;
+  int4* desc;    // [TR] {offset of atom i, of atom j (LDS floats if staged, else atom index), C*flag0, C*flag1}
+  int* s_amax;   // [4]
+  __device__ explicit BwdLds(uint8_t* smem) {
+    dOr = reinterpret_cast<u32x4*>(smem);
+    dOf = dOr + KC * 3 * 64;
+    rbf = dOf + CB * 2 * 3 * 64;
+    xs = reinterpret_cast<float*>(rbf + 2 * 2 * 3 * 64);
     ds = xs + ATOM_CAP * AS;
     tdd = ds + ATOM_CAP * AS;
-    desc = reinterpret_cast<int4*>(smem + ((F * TS + 2 * ATOM_CAP * AS + TR + 3) & ~3));
+    desc = reinterpret_cast<int4*>(tdd + TR);
     s_amax = reinterpret_cast<int*>(desc + TR);
   }
-  static size_t bytes() { return ((size_t)((F * TS + 2 * ATOM_CAP * AS + TR + 3) & ~3) + 4 * TR + 4) * sizeof(float); }
+  static size_t bytes() {
+    return (size_t)(KC * 3 + CB * 6 + 12) * 1024 + (size_t)(2 * ATOM_CAP * AS + TR) * 4 + TR * 16 + 16;
+  }
 };
 
-// rows [a_lo, a_lo+na) of src[N][F] -> dst[na][F+1], 16-byte global loads
-template <int F, int NT>
-__device__ __forceinline__ void stage_atoms(const float* __restrict__ src, int a_lo, int na, float* dst, int tid) {
-  constexpr int Q = F / 4;
-  const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)a_lo * F);
-#pragma unroll 4
-  for (int i = tid; i < na * Q; i += NT) {
-    const int a = i / Q, q = i - a * Q;
-    const float4 v = s4[i];
-    float* d = dst + a * (F + 1) + 4 * q;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-  }
-}
-
-// Builds the dO tile of rows [r0, r0+64) of layer l in LDS (NW waves).  Starts with a barrier (the previous tile must
-// be fully consumed) and ends with one; the tile and tdd are valid afterwards.
-// `alo` = first atom of the tile's window (= pair_i[r0]: pair slots are lexicographic inside a molecule, so the first
-// row holds the smallest atom); it is fetched one tile ahead by the caller, which lets the row descriptors and a
-// fixed ATOM_CAP-row window of x / dagg be requested together — one global round trip per tile instead of two.
-template <int F, int NW>
-__device__ __forceinline__ void build_dO_tile(const TileLds<F>& L, const float* __restrict__ pair_d,
-                                              const float* __restrict__ pair_c, const uint8_t* __restrict__ pair_flag,
-                                              const int32_t* __restrict__ pair_i, const int32_t* __restrict__ pair_j,
-                                              int P, int N, int r0, int alo, const float* __restrict__ x,
-                                              const float* __restrict__ dagg, int tid) {
-  constexpr int AS = F + 1, NT = 64 * NW, Q = F / 4;
+template <int NW, bool ROLE_A>
+__device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d, const float* __restrict__ pair_c,
+                                                const uint8_t* __restrict__ pair_flag,
+                                                const int32_t* __restrict__ pair_i,
+                                                const int32_t* __restrict__ pair_j, int P, int N,
+                                                const GeosslFilterWeights& w, const GeosslFilterGradIn& g, int G,
+                                                const float* __restrict__ offset, float coeff,
+                                                const float* __restrict__ T, float* __restrict__ partial_w1,
+                                                float* __restrict__ partial_b1, float* __restrict__ partial_w2,
+                                                float* __restrict__ partial_b2) {
+  constexpr int F = 32 * NW, NT = 128 * NW, KC = F / 16, CB = F / 32, AS = BwdLds<F>::AS, Q = F / 4;
   constexpr int NPRE = (ATOM_CAP * Q + NT - 1) / NT;  // float4 per thread and array for the atom window
-  const int lane = tid & 63, wave = tid >> 6;
-  // ---- requests: atom window (speculative, fixed size) and row descriptors
-  const int nwin = min(ATOM_CAP, N - alo);
-  const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)alo * F);
-  const float4* d4 = reinterpret_cast<const float4*>(dagg + (size_t)alo * F);
-  float4 px[NPRE], pdg[NPRE];
-#pragma unroll
-  for (int u = 0; u < NPRE; ++u) {
-    const int i = tid + NT * u;
-    const bool ok = i < nwin * Q;
-    px[u] = ok ? x4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    pdg[u] = ok ? d4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  }
-  int ai = 0, aj = 0;
-  float m0 = 0.0f, m1 = 0.0f, dd = 0.0f;
-  if (wave == 0) {  // one pair row per lane
-    const int row = r0 + lane;
-    const bool ok = row < P;
-    const int q = ok ? row : P - 1;
-    ai = pair_i[q];
-    aj = pair_j[q];
-    const unsigned fl = ok ? pair_flag[q] : 0u;
-    const float c = pair_c[q];
-    m0 = (fl & 1u) ? c : 0.0f;
-    m1 = (fl & 2u) ? c : 0.0f;
-    dd = pair_d[q];
-  }
-  __syncthreads();  // previous tile fully consumed: LDS may be overwritten
-  int amax = aj + 1;
-  if (wave == 0) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o, 64));
-    const bool staged0 = amax - alo <= ATOM_CAP;
-    L.tdd[lane] = dd;
-    L.desc[lane] = staged0 ? make_int4((ai - alo) * AS, (aj - alo) * AS, __float_as_int(m0), __float_as_int(m1))
-                           : make_int4(ai, aj, __float_as_int(m0), __float_as_int(m1));
-    if (lane == 0) *L.s_amax = amax;
-  }
-#pragma unroll
-  for (int u = 0; u < NPRE; ++u) {
-    const int i = tid + NT * u;
-    if (i < nwin * Q) {
-      const int a = i / Q, q4 = i - a * Q;
-      float* dx = L.xs + a * AS + 4 * q4;
-      float* dg = L.ds + a * AS + 4 * q4;
-      dx[0] = px[u].x; dx[1] = px[u].y; dx[2] = px[u].z; dx[3] = px[u].w;
-      dg[0] = pdg[u].x; dg[1] = pdg[u].y; dg[2] = pdg[u].z; dg[3] = pdg[u].w;
-    }
-  }
-  __syncthreads();
-  const bool staged = *L.s_amax - alo <= ATOM_CAP;
-  // lane = pair row, wave w takes n = w, w+NW, ...
-  const int4 q = L.desc[lane];
-  const float qm0 = __int_as_float(q.z), qm1 = __int_as_float(q.w);
-  if (staged) {
-    const float* di = L.ds + q.x;
-    const float* dj = L.ds + q.y;
-    const float* xi = L.xs + q.x;
-    const float* xj = L.xs + q.y;
-#pragma unroll 4
-    for (int n = wave; n < F; n += NW) L.dO[n * TS + lane] = qm0 * (di[n] * xj[n]) + qm1 * (dj[n] * xi[n]);
-  } else {
-    // atom window larger than the LDS stage (a run of tiny molecules): operands straight from global memory
-    const float* di = dagg + (size_t)q.x * F;
-    const float* dj = dagg + (size_t)q.y * F;
-    const float* xi = x + (size_t)q.x * F;
-    const float* xj = x + (size_t)q.y * F;
-    for (int n = wave; n < F; n += NW) L.dO[n * TS + lane] = qm0 * (di[n] * xj[n]) + qm1 * (dj[n] * xi[n]);
-  }
-  __syncthreads();
-}
-
-// ------------------------------------------------------------------------------------------------ kernel A
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void k_filter_bwd_a(const float* __restrict__ pair_d,
-                                                             const float* __restrict__ pair_c,
-                                                             const uint8_t* __restrict__ pair_flag,
-                                                             const int32_t* __restrict__ pair_i,
-                                                             const int32_t* __restrict__ pair_j, int P, int N,
-                                                             GeosslFilterWeights w, GeosslFilterGradIn g, int G,
-                                                             const float* __restrict__ offset, float coeff,
-                                                             const float* __restrict__ T,
-                                                             float* __restrict__ partial_w1,
-                                                             float* __restrict__ partial_b1) {
-  constexpr int F = 32 * NW, K2 = F / 2;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const TileLds<F> L(smem);
+  static_assert(TR * (F / 8) == NT && CB * 2 * 64 == NT, "one dOr and one dOf fragment lane per thread");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  const BwdLds<F> L(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
+  constexpr bool roleA = ROLE_A;
+  const int hs = roleA ? wave : wave - NW;  // hidden-unit slice [32 hs, 32 hs + 32)
   const int l = blockIdx.y;
-  const int col = 32 * wave + j;  // hidden unit owned by this lane
-  // B fragments of dt = dO W2 for this wave's columns: bw2[kk] = W2[n = 2kk+kh][col]
-  float bw2[K2];
-  {
-    const float* w2 = w.w2[l] + col;
-#pragma unroll
-    for (int kk = 0; kk < K2; ++kk) bw2[kk] = w2[(size_t)(2 * kk + kh) * F];
-  }
   const float* __restrict__ x = g.x[l];
   const float* __restrict__ dagg = g.dagg[l];
   const size_t lbase = (size_t)l * P;
-  f32x16 accw[2];  // dW1 rows [32w, 32w+32) x gaussians [0, 64)
-  float bsum = 0.0f;
+  const float* __restrict__ Tcol = T + lbase * F + 32 * hs + j;  // this lane's hidden unit
+
+  // ---- role A: W2 slice as B fragments of dt = dO W2:  B[k = c = 16ks + 8kh + e][n = h] = W2[c][h]
+  Frag3 bw2[roleA ? KC : 1];
+  f32x16 accw1[2];             // role A: dW1 rows [32hs, +32) x gaussians [0, 64): lane = g, register = h
+  f32x16 accw2[roleA ? 1 : CB];  // role B: dW2 rows c (register) x this slice's h (lane)
+  float bsum1 = 0.0f, bsum2 = 0.0f;
+  if constexpr (roleA) {
+    const float* w2 = w.w2[l] + 32 * hs + j;
 #pragma unroll
-  for (int g2 = 0; g2 < 2; ++g2)
+    for (int ks = 0; ks < KC; ++ks) {
+      float v[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accw[g2][r] = 0.0f;
-  float offr[2];
+      for (int e = 0; e < 8; ++e) v[e] = w2[(size_t)(16 * ks + 8 * kh + e) * F];
+      bw2[ks] = split8(v);
+    }
 #pragma unroll
-  for (int g2 = 0; g2 < 2; ++g2) offr[g2] = (32 * g2 + j) < G ? offset[32 * g2 + j] : 0.0f;
+    for (int gb = 0; gb < 2; ++gb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accw1[gb][r] = 0.0f;
+  } else {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accw2[cb][r] = 0.0f;
+  }
+  // fragment-lane roles of this thread in the tile build
+  const int r_row = tid & 31, r_kh = (tid >> 5) & 1, r_ks = tid >> 6;         // dOr: row, k half, k-step (c)
+  const int f_c = 32 * (tid / 128) + (tid & 31), f_kh = (tid >> 5) & 1, f_ks = (tid >> 6) & 1;  // dOf
   const int ntiles = (P + TR - 1) / TR;
   const int per = (ntiles + gridDim.x - 1) / gridDim.x;  // contiguous tile range per block (atom reuse in L2)
   const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
@@ -201,156 +119,278 @@ __global__ __launch_bounds__(64 * NW, 2) void k_filter_bwd_a(const float* __rest
     const int r0 = t * TR;
     const int alo = alo_next;
     if (t + 1 < t_end) alo_next = pair_i[r0 + TR];  // one tile ahead: the next build needs it before anything else
-    // saved hidden activation of the tile's rows for this lane's hidden unit, C layout (requested before the build)
-    float tc[2][16];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = min(r0 + 32 * rb + c_row(r, lane), P - 1);
-        tc[rb][r] = T[(lbase + row) * F + col];
-      }
-    build_dO_tile<F, NW>(L, pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, r0, alo, x, dagg, tid);
-    f32x16 acc[2];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+    // ---- requests of this tile: atom window (speculative, fixed size), row descriptors, saved activations
+    const int nwin = min(ATOM_CAP, N - alo);
+    float4 px[NPRE], pdg[NPRE];
     {
-      const float* abase = L.dO + kh * TS + j;  // A[row = 32rb+j][n = 2kk+kh] = abase[kk*2*TS + 32*rb]
-      float a_cur[2], a_nxt[2];
+      const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)alo * F);
+      const float4* d4 = reinterpret_cast<const float4*>(dagg + (size_t)alo * F);
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) a_cur[rb] = abase[32 * rb];
-#pragma unroll
-      for (int kk = 0; kk < K2; ++kk) {
-        const int kn = kk + 1 < K2 ? kk + 1 : kk;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) a_nxt[rb] = abase[kn * 2 * TS + 32 * rb];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[rb], bw2[kk], acc[rb], 0, 0, 0);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) a_cur[rb] = a_nxt[rb];
+      for (int u = 0; u < NPRE; ++u) {
+        const int i = tid + NT * u;
+        const bool ok = i < nwin * Q;
+        px[u] = ok ? x4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        pdg[u] = ok ? d4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       }
     }
-    // dU = dt * ssp'(pre) in place (C layout: lane = hidden unit, register = pair row); then
-    // dW1[k][g] += sum_rows dU[row][k] * rbf(d_row)[g]: k-step (rb, s) contracts over the two rows held in register s
+    int ai = 0, aj = 0;
+    float m0 = 0.0f, m1 = 0.0f, dd = 0.0f;
+    if (wave == 0 && lane < TR) {  // one pair row per lane
+      const int row = r0 + lane;
+      const bool ok = row < P;
+      const int q = ok ? row : P - 1;
+      ai = pair_i[q];
+      aj = pair_j[q];
+      const unsigned fl = ok ? pair_flag[q] : 0u;
+      const float c = pair_c[q];
+      m0 = (fl & 1u) ? c : 0.0f;
+      m1 = (fl & 2u) ? c : 0.0f;
+      dd = pair_d[q];
+    }
+    // saved hidden activation of this lane's hidden unit: role A in C layout (register r <-> row c_row(r)), role B
+    // in B-fragment layout (k-step s, element e <-> row 16s + 8kh + e); rows past P are clamped (their dO is 0)
+    float tc[16];
+    if constexpr (roleA) {
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
+      for (int r = 0; r < 16; ++r) tc[r] = Tcol[(size_t)min(r0 + c_row(r, lane), P - 1) * F];
+    } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc[rb][r] *= dssp_from_out(tc[rb][r]);
-        bsum += acc[rb][r];
+      for (int r = 0; r < 16; ++r) tc[r] = Tcol[(size_t)min(r0 + 16 * (r >> 3) + 8 * kh + (r & 7), P - 1) * F];
+    }
+    __syncthreads();  // previous tile fully consumed: LDS may be overwritten
+    if (wave == 0) {
+      int amax = lane < TR ? aj + 1 : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o, 64));
+      const bool staged0 = amax - alo <= ATOM_CAP;
+      if (lane < TR) {
+        L.tdd[lane] = dd;
+        L.desc[lane] = staged0 ? make_int4((ai - alo) * AS, (aj - alo) * AS, __float_as_int(m0), __float_as_int(m1))
+                               : make_int4(ai, aj, __float_as_int(m0), __float_as_int(m1));
       }
+      if (lane == 0) *L.s_amax = amax;
+    }
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const float dd = L.tdd[32 * rb + c_row(s, lane)];
-        float bv[2];
+    for (int u = 0; u < NPRE; ++u) {
+      const int i = tid + NT * u;
+      if (i < nwin * Q) {
+        const int a = i / Q, q4 = i - a * Q;
+        *reinterpret_cast<float4*>(L.xs + a * AS + 4 * q4) = px[u];
+        *reinterpret_cast<float4*>(L.ds + a * AS + 4 * q4) = pdg[u];
+      }
+    }
+    __syncthreads();
+    const bool staged = *L.s_amax - alo <= ATOM_CAP;
+    // ---- tile build: every thread one dOr fragment lane, one dOf fragment lane, (half the threads) one rbf lane
+    auto build = [&](const float* xb, const float* db, int stride) {
+      {  // dOr: A[m = row][k = c = 16 r_ks + 8 r_kh + e]
+        const int4 q = L.desc[r_row];
+        const float qm0 = __int_as_float(q.z), qm1 = __int_as_float(q.w);
+        const int c0 = 16 * r_ks + 8 * r_kh;
+        const float* di = db + (size_t)q.x * stride + c0;
+        const float* dj = db + (size_t)q.y * stride + c0;
+        const float* xi = xb + (size_t)q.x * stride + c0;
+        const float* xj = xb + (size_t)q.y * stride + c0;
+        float v[8];
 #pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {
-          const float diff = dd - offr[g2];
-          bv[g2] = (32 * g2 + j) < G ? __expf(coeff * (diff * diff)) : 0.0f;
+        for (int h4 = 0; h4 < 2; ++h4) {
+          const float4 a = *reinterpret_cast<const float4*>(di + 4 * h4), b = *reinterpret_cast<const float4*>(xj + 4 * h4);
+          const float4 c = *reinterpret_cast<const float4*>(dj + 4 * h4), d = *reinterpret_cast<const float4*>(xi + 4 * h4);
+          v[4 * h4 + 0] = qm0 * (a.x * b.x) + qm1 * (c.x * d.x);
+          v[4 * h4 + 1] = qm0 * (a.y * b.y) + qm1 * (c.y * d.y);
+          v[4 * h4 + 2] = qm0 * (a.z * b.z) + qm1 * (c.z * d.z);
+          v[4 * h4 + 3] = qm0 * (a.w * b.w) + qm1 * (c.w * d.w);
         }
+        const Frag3 f = split8(v);
+        u32x4* dst = L.dOr + (size_t)(r_ks * 3) * 64 + (r_row + 32 * r_kh);
+        dst[0] = f.h;
+        dst[64] = f.m;
+        dst[128] = f.l;
+      }
+      {  // dOf: A[m = c][k = row = 16 f_ks + 8 f_kh + e]
+        float v[8];
 #pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2)
-          accw[g2] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[rb][s], bv[g2], accw[g2], 0, 0, 0);
+        for (int e = 0; e < 8; ++e) {
+          const int4 q = L.desc[16 * f_ks + 8 * f_kh + e];
+          const float qm0 = __int_as_float(q.z), qm1 = __int_as_float(q.w);
+          v[e] = qm0 * (db[(size_t)q.x * stride + f_c] * xb[(size_t)q.y * stride + f_c]) +
+                 qm1 * (db[(size_t)q.y * stride + f_c] * xb[(size_t)q.x * stride + f_c]);
+          bsum2 += v[e];
+        }
+        const Frag3 f = split8(v);
+        u32x4* dst = L.dOf + (size_t)(((f_c >> 5) * 2 + f_ks) * 3) * 64 + ((f_c & 31) + 32 * f_kh);
+        dst[0] = f.h;
+        dst[64] = f.m;
+        dst[128] = f.l;
+      }
+    };
+    if (staged) build(L.xs, L.ds, 1);  // descriptors hold LDS float offsets
+    else build(x, dagg, F);            // a run of tiny molecules: operands straight from global memory
+    for (int it = tid; it < 2 * 2 * 64; it += NT) {  // rbf: B[k = row = 16ks + kperm(e, kh)][n = g]
+      const int ln = it & 63, ks = (it >> 6) & 1, gb = it >> 7;
+      const int gg = 32 * gb + (ln & 31);
+      const float off = gg < G ? offset[gg] : 0.0f;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float diff = L.tdd[16 * ks + kperm(e, ln >> 5)] - off;
+        v[e] = gg < G ? __expf(coeff * (diff * diff)) : 0.0f;
+      }
+      const Frag3 f = split8(v);
+      u32x4* dst = L.rbf + (size_t)((gb * 2 + ks) * 3) * 64 + ln;
+      dst[0] = f.h;
+      dst[64] = f.m;
+      dst[128] = f.l;
+    }
+    __syncthreads();
+    if constexpr (roleA) {
+      // dt = dO W2 for this wave's hidden units; two accumulators (even / odd k-steps) keep dependent MFMAs apart
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < KC; ks += 2) {
+        Frag3 a0, a1;
+        const u32x4* s0 = L.dOr + (size_t)(ks * 3) * 64 + lane;
+        a0.h = s0[0]; a0.m = s0[64]; a0.l = s0[128];
+        a1.h = s0[192]; a1.m = s0[256]; a1.l = s0[320];
+        acc0 = mfma_bf16(a0.l, bw2[ks].h, acc0);
+        acc1 = mfma_bf16(a1.l, bw2[ks + 1].h, acc1);
+        acc0 = mfma_bf16(a0.h, bw2[ks].l, acc0);
+        acc1 = mfma_bf16(a1.h, bw2[ks + 1].l, acc1);
+        acc0 = mfma_bf16(a0.m, bw2[ks].m, acc0);
+        acc1 = mfma_bf16(a1.m, bw2[ks + 1].m, acc1);
+        acc0 = mfma_bf16(a0.m, bw2[ks].h, acc0);
+        acc1 = mfma_bf16(a1.m, bw2[ks + 1].h, acc1);
+        acc0 = mfma_bf16(a0.h, bw2[ks].m, acc0);
+        acc1 = mfma_bf16(a1.h, bw2[ks + 1].m, acc1);
+        acc0 = mfma_bf16(a0.h, bw2[ks].h, acc0);
+        acc1 = mfma_bf16(a1.h, bw2[ks + 1].h, acc1);
+      }
+      // dU = dt * ssp'(pre) (C layout: lane = hidden unit, register = pair row); registers 0..7 / 8..15 are the
+      // elements of k-steps 0 / 1 of the contraction over pair rows
+      Frag3 du[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] = (acc0[8 * s + e] + acc1[8 * s + e]) * dssp_from_out(tc[8 * s + e]);
+          bsum1 += v[e];
+        }
+        du[s] = split8(v);
+      }
+      // dW1[h][g] += sum_rows dU[row][h] * rbf(d_row)[g]
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Frag3 b0, b1;
+        const u32x4* s0 = L.rbf + (size_t)(s * 3) * 64 + lane;
+        b0.h = s0[0]; b0.m = s0[64]; b0.l = s0[128];
+        b1.h = s0[384]; b1.m = s0[448]; b1.l = s0[512];
+        accw1[0] = mfma_bf16(du[s].l, b0.h, accw1[0]);
+        accw1[1] = mfma_bf16(du[s].l, b1.h, accw1[1]);
+        accw1[0] = mfma_bf16(du[s].h, b0.l, accw1[0]);
+        accw1[1] = mfma_bf16(du[s].h, b1.l, accw1[1]);
+        accw1[0] = mfma_bf16(du[s].m, b0.m, accw1[0]);
+        accw1[1] = mfma_bf16(du[s].m, b1.m, accw1[1]);
+        accw1[0] = mfma_bf16(du[s].m, b0.h, accw1[0]);
+        accw1[1] = mfma_bf16(du[s].m, b1.h, accw1[1]);
+        accw1[0] = mfma_bf16(du[s].h, b0.m, accw1[0]);
+        accw1[1] = mfma_bf16(du[s].h, b1.m, accw1[1]);
+        accw1[0] = mfma_bf16(du[s].h, b0.h, accw1[0]);
+        accw1[1] = mfma_bf16(du[s].h, b1.h, accw1[1]);
+      }
+    } else {
+      // dW2[c][h] += sum_rows dO[row][c] * t[row][h]
+      Frag3 tb[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tc[8 * s + e];
+        tb[s] = split8(v);
+      }
+      constexpr int CP = CB >= 2 ? 2 : 1;
+#pragma unroll
+      for (int cb = 0; cb < CB; cb += CP) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          Frag3 a[CP];
+#pragma unroll
+          for (int u = 0; u < CP; ++u) {
+            const u32x4* s0 = L.dOf + (size_t)(((cb + u) * 2 + s) * 3) * 64 + lane;
+            a[u].h = s0[0]; a[u].m = s0[64]; a[u].l = s0[128];
+          }
+#pragma unroll
+          for (int u = 0; u < CP; ++u) accw2[cb + u] = mfma_bf16(a[u].l, tb[s].h, accw2[cb + u]);
+#pragma unroll
+          for (int u = 0; u < CP; ++u) accw2[cb + u] = mfma_bf16(a[u].h, tb[s].l, accw2[cb + u]);
+#pragma unroll
+          for (int u = 0; u < CP; ++u) accw2[cb + u] = mfma_bf16(a[u].m, tb[s].m, accw2[cb + u]);
+#pragma unroll
+          for (int u = 0; u < CP; ++u) accw2[cb + u] = mfma_bf16(a[u].m, tb[s].h, accw2[cb + u]);
+#pragma unroll
+          for (int u = 0; u < CP; ++u) accw2[cb + u] = mfma_bf16(a[u].h, tb[s].m, accw2[cb + u]);
+#pragma unroll
+          for (int u = 0; u < CP; ++u) accw2[cb + u] = mfma_bf16(a[u].h, tb[s].h, accw2[cb + u]);
+        }
       }
     }
   }
-  // one partial per block: wave w writes rows [32w, 32w+32) of [F][G] and of [F]
+  // ---- one partial per block
   const size_t pb = (size_t)l * gridDim.x + blockIdx.x;
-  float* Pw = partial_w1 + pb * F * G;
+  if constexpr (roleA) {
+    float* Pw = partial_w1 + pb * F * G;
 #pragma unroll
-  for (int g2 = 0; g2 < 2; ++g2) {
-    const int gg = 32 * g2 + j;
-    if (gg < G) {
+    for (int gb = 0; gb < 2; ++gb) {
+      const int gg = 32 * gb + j;
+      if (gg < G) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Pw[(size_t)(32 * wave + c_row(r, lane)) * G + gg] = accw[g2][r];
+        for (int r = 0; r < 16; ++r) Pw[(size_t)(32 * hs + c_row(r, lane)) * G + gg] = accw1[gb][r];
+      }
     }
+    const float s = bsum1 + __shfl_xor(bsum1, 32, 64);
+    if (kh == 0) partial_b1[pb * F + 32 * hs + j] = s;
+  } else {
+    float* Pw = partial_w2 + pb * F * F;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Pw[(size_t)(32 * cb + c_row(r, lane)) * F + 32 * hs + j] = accw2[cb][r];
   }
-  const float s = bsum + __shfl_xor(bsum, 32, 64);
-  if (kh == 0) partial_b1[pb * F + col] = s;
+  // db2: every thread holds the sum over its (k-step, half) share of the rows for channel f_c
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(L.dOr);  // [4][F]
+  red[(2 * f_ks + f_kh) * F + f_c] = bsum2;
+  __syncthreads();
+  if (tid < F) partial_b2[pb * F + tid] = (red[tid] + red[F + tid]) + (red[2 * F + tid] + red[3 * F + tid]);
 }
 
-// ------------------------------------------------------------------------------------------------ kernel B
+// The two roles run separate instantiations of the body (their register sets differ: W2 fragments + dW1
+// accumulators against dW2 accumulators); the branch is wave-uniform and both sides execute the same barriers.
 template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void k_filter_bwd_b(const float* __restrict__ pair_d,
-                                                             const float* __restrict__ pair_c,
-                                                             const uint8_t* __restrict__ pair_flag,
-                                                             const int32_t* __restrict__ pair_i,
-                                                             const int32_t* __restrict__ pair_j, int P, int N,
-                                                             GeosslFilterGradIn g, const float* __restrict__ T,
-                                                             float* __restrict__ partial_w2,
-                                                             float* __restrict__ partial_b2) {
-  constexpr int F = 32 * NW, NCB = F / 32;  // accumulator blocks per wave; block c holds columns {NCB*j + c}
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const TileLds<F> L(smem);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
-  const int l = blockIdx.y;
-  const float* __restrict__ x = g.x[l];
-  const float* __restrict__ dagg = g.dagg[l];
-  const size_t lbase = (size_t)l * P;
-  const int nrow = 32 * wave + j;  // dW2 row (= filter output channel n) this lane feeds as A operand
-  f32x16 acc[NCB];
-#pragma unroll
-  for (int c = 0; c < NCB; ++c)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
-  float bsum = 0.0f;
-  const int ntiles = (P + TR - 1) / TR;
-  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
-  const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
-  int alo_next = t_begin < t_end ? pair_i[t_begin * TR] : 0;
-  for (int t = t_begin; t < t_end; ++t) {
-    const int r0 = t * TR;
-    const int alo = alo_next;
-    if (t + 1 < t_end) alo_next = pair_i[r0 + TR];
-    // B fragments of the whole tile first: row 2kk+kh of T, this lane's NCB consecutive columns.  They do not depend on
-    // the dO tile, so the 32 loads fly while the tile is being built; the MFMA loop below then touches LDS only.
-    float bv[TR / 2][NCB];
-    {
-      const float* tbase = T + lbase * F + NCB * j;
-#pragma unroll
-      for (int kk = 0; kk < TR / 2; ++kk) {
-        const int row = min(r0 + 2 * kk + kh, P - 1);  // rows past P have dO = 0
-        if constexpr (NCB == 4) {
-          const float4 v = *reinterpret_cast<const float4*>(tbase + (size_t)row * F);
-          bv[kk][0] = v.x; bv[kk][1] = v.y; bv[kk][2] = v.z; bv[kk][3] = v.w;
-        } else if constexpr (NCB == 2) {
-          const float2 v = *reinterpret_cast<const float2*>(tbase + (size_t)row * F);
-          bv[kk][0] = v.x; bv[kk][1] = v.y;
-        } else {
-          bv[kk][0] = tbase[(size_t)row * F];
-        }
-      }
-    }
-    build_dO_tile<F, NW>(L, pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, r0, alo, x, dagg, tid);
-    const float* abase = L.dO + nrow * TS + kh;  // A[i = n][kslot kh] of k-step kk = dO[row 2kk+kh][n] = abase[2kk]
-    float a_cur = abase[0];
-#pragma unroll
-    for (int kk = 0; kk < TR / 2; ++kk) {
-      const float a_nxt = abase[2 * (kk + 1 < TR / 2 ? kk + 1 : kk)];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int c = 0; c < NCB; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, bv[kk][c], acc[c], 0, 0, 0);
-      bsum += a_cur;
-      a_cur = a_nxt;
-    }
-  }
-  const size_t pb = (size_t)l * gridDim.x + blockIdx.x;
-  float* Pw = partial_w2 + pb * F * F;
-#pragma unroll
-  for (int c = 0; c < NCB; ++c) {
-    const int k = NCB * j + c;  // accumulator block c holds columns {NCB*j + c}
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Pw[(size_t)(32 * wave + c_row(r, lane)) * F + k] = acc[c][r];
-  }
-  const float s = bsum + __shfl_xor(bsum, 32, 64);
-  if (kh == 0) partial_b2[pb * F + nrow] = s;
+__global__ __launch_bounds__(128 * NW) void k_filter_bwd(const float* __restrict__ pair_d,
+                                                         const float* __restrict__ pair_c,
+                                                         const uint8_t* __restrict__ pair_flag,
+                                                         const int32_t* __restrict__ pair_i,
+                                                         const int32_t* __restrict__ pair_j, int P, int N,
+                                                         GeosslFilterWeights w, GeosslFilterGradIn g, int G,
+                                                         const float* __restrict__ offset, float coeff,
+                                                         const float* __restrict__ T,
+                                                         float* __restrict__ partial_w1,
+                                                         float* __restrict__ partial_b1,
+                                                         float* __restrict__ partial_w2,
+                                                         float* __restrict__ partial_b2) {
+  if ((int)(threadIdx.x >> 6) < NW)
+    filter_bwd_body<NW, true>(pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, w, g, G, offset, coeff, T, partial_w1,
+                              partial_b1, partial_w2, partial_b2);
+  else
+    filter_bwd_body<NW, false>(pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, w, g, G, offset, coeff, T, partial_w1,
+                               partial_b1, partial_w2, partial_b2);
 }
 
 inline int blocks_per_layer(int L, int ntiles) {
-  int b = 512 / (L > 0 ? L : 1);  // two blocks per CU
+  int b = 256 / (L > 0 ? L : 1);  // one block per CU
   if (b < 1) b = 1;
   if (b > ntiles) b = ntiles;
   return b;
@@ -379,15 +419,12 @@ extern "C" int geossl_cfconv_filter_bwd(const float* pair_d, const float* pair_c
   float* pb1 = pw1 + (size_t)L * nb * F * G;       // [L][nb][F]
   float* pw2 = pb1 + (size_t)L * nb * F;           // [L][nb][F][F]
   float* pb2 = pw2 + (size_t)L * nb * F * F;       // [L][nb][F]
-#define LAUNCH(NW)                                                                                                  \
-  do {                                                                                                              \
-    const size_t lds = TileLds<32 * NW>::bytes();                                                                   \
-    allow_big_lds(&k_filter_bwd_a<NW>);                                                                             \
-    allow_big_lds(&k_filter_bwd_b<NW>);                                                                             \
-    hipLaunchKernelGGL((k_filter_bwd_a<NW>), grid, dim3(64 * NW), lds, stream, pair_d, pair_c, pair_flag, pair_i,   \
-                       pair_j, (int)P, (int)N, *w, *g, G, offset, coeff, T, pw1, pb1);                                      \
-    hipLaunchKernelGGL((k_filter_bwd_b<NW>), grid, dim3(64 * NW), lds, stream, pair_d, pair_c, pair_flag, pair_i,   \
-                       pair_j, (int)P, (int)N, *g, T, pw2, pb2);                                                            \
+#define LAUNCH(NW)                                                                                                 \
+  do {                                                                                                             \
+    const size_t lds = BwdLds<32 * NW>::bytes();                                                                   \
+    allow_big_lds(&k_filter_bwd<NW>);                                                                              \
+    hipLaunchKernelGGL((k_filter_bwd<NW>), grid, dim3(128 * NW), lds, stream, pair_d, pair_c, pair_flag, pair_i,   \
+                       pair_j, (int)P, (int)N, *w, *g, G, offset, coeff, T, pw1, pb1, pw2, pb2);                   \
   } while (0)
   if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
 #undef LAUNCH

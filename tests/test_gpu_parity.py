@@ -4,6 +4,7 @@ same seeded inputs.  Tolerances (BASELINE.json north_star): radius-graph edge in
 fp32 outputs / loss <= 1e-5 relative; parameter gradients <= 1e-4 relative (fp32 reductions over up
 to ~3e5 rows in a different order)."""
 import json
+import math
 
 import numpy as np
 import pytest
@@ -127,6 +128,40 @@ def test_mfma_tile_layout_asymmetric():
     w = torch.arange(128 * 128, dtype=torch.float32, device=DEV).view(128, 128) * 1e-3
     assert torch.equal(ops.linear(x, w).cpu(), w.t().cpu())
     assert torch.equal(ops.linear(x, w, transB=False).cpu(), w.cpu())
+
+
+@pytest.mark.parametrize("F,G,P", [(128, 51, 1000), (128, 50, 77), (64, 20, 333), (32, 9, 64), (128, 64, 4099)])
+def test_filter_network_forward_vs_fp64(F, G, P):
+    """geossl_cfconv_filter_fwd through the C ABI against an fp64 evaluation of schnet.py:141-145,186-187,205-207.
+    The products run as 3-way bf16 splits on the matrix pipe (csrc/split.h): the bound checked here, 2e-6 of the
+    tensor scale, is the accuracy of an fp32 GEMM chain, i.e. the splitting costs no precision."""
+    import ctypes as C
+    from geossl_amd import _lib
+    from geossl_amd._lib import call, ptr, stream
+    gen = torch.Generator().manual_seed(F + G + P)
+    L, cutoff = 3, 5.0
+    d = (torch.rand(P, generator=gen) * 1.1 * cutoff).to(DEV)
+    c = (0.5 * (torch.cos(d * math.pi / cutoff) + 1.0)).contiguous()
+    offset = torch.linspace(0.0, cutoff, G).to(DEV)
+    coeff = -0.5 / float(offset[1] - offset[0]) ** 2
+    ws = []
+    for l in range(L):
+        ws.append([(torch.randn(F, G, generator=gen) / G ** 0.5).to(DEV), (0.3 * torch.randn(F, generator=gen)).to(DEV),
+                   (torch.randn(F, F, generator=gen) / F ** 0.5).to(DEV), (0.3 * torch.randn(F, generator=gen)).to(DEV)])
+    fw = _lib.FilterWeights()
+    for l, w in enumerate(ws):
+        fw.w1[l], fw.b1[l], fw.w2[l], fw.b2[l] = (ptr(x) for x in w)
+    Wf = torch.full((L, P, F), float("nan"), device=DEV)
+    T = torch.full((L, P, F), float("nan"), device=DEV)
+    call("geossl_cfconv_filter_fwd", ptr(d), ptr(c), P, C.byref(fw), L, F, G, ptr(offset), coeff, ptr(T), ptr(Wf), stream())
+    d64 = d.double()
+    rbf = torch.exp(coeff * (d64[:, None] - offset.double()[None, :]) ** 2)
+    for l, (w1, b1, w2, b2) in enumerate(ws):
+        t64 = torch.nn.functional.softplus(rbf @ w1.double().t() + b1.double()) - math.log(2.0)
+        wf64 = (t64 @ w2.double().t() + b2.double()) * c.double()[:, None]
+        for got, ref, name in ((T[l], t64, "t"), (Wf[l], wf64, "Wf")):
+            err = float((got.double() - ref).abs().max() / ref.abs().max())
+            assert err < 2e-6, (name, l, err)
 
 
 # ------------------------------------------------------------------------------------------- SchNet (K2-K4)
