@@ -71,7 +71,6 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
                                                 float* __restrict__ partial_b1, float* __restrict__ partial_w2,
                                                 float* __restrict__ partial_b2) {
   constexpr int F = 32 * NW, NT = 128 * NW, KC = F / 16, CB = F / 32, AS = BwdLds<F>::AS, Q = F / 4;
-  constexpr int NPRE = (ATOM_CAP * Q + NT - 1) / NT;  // float4 per thread and array for the atom window
   static_assert(TR * (F / 8) == NT && CB * 2 * 64 == NT, "one dOr and one dOf fragment lane per thread");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
   const BwdLds<F> L(smem_raw);
@@ -114,69 +113,83 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
   const int ntiles = (P + TR - 1) / TR;
   const int per = (ntiles + gridDim.x - 1) / gridDim.x;  // contiguous tile range per block (atom reuse in L2)
   const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
-  int alo_next = t_begin < t_end ? pair_i[t_begin * TR] : 0;
-  for (int t = t_begin; t < t_end; ++t) {
-    const int r0 = t * TR;
-    const int alo = alo_next;
-    if (t + 1 < t_end) alo_next = pair_i[r0 + TR];  // one tile ahead: the next build needs it before anything else
-    // ---- requests of this tile: atom window (speculative, fixed size), row descriptors, saved activations
-    const int nwin = min(ATOM_CAP, N - alo);
-    float4 px[NPRE], pdg[NPRE];
-    {
-      const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)alo * F);
-      const float4* d4 = reinterpret_cast<const float4*>(dagg + (size_t)alo * F);
+  // Global requests run one tile ahead of their use (they fly during the MFMA phase of the previous tile): the atom
+  // window and the row descriptors are fetched and staged by the role-B waves (which have the registers to spare),
+  // the saved activations by every wave for its own hidden unit.  `alo` = first atom of a tile's window
+  // (= pair_i[r0]: pair slots are lexicographic inside a molecule) is fetched two tiles ahead.
+  constexpr int NTB = 64 * NW;                              // staging threads (role B)
+  constexpr int NPRE = (ATOM_CAP * Q + NTB - 1) / NTB;      // float4 per staging thread and array
+  const int stid = tid - NTB;                               // role B: 0 .. NTB-1
+  float4 px[roleA ? 1 : NPRE], pdg[roleA ? 1 : NPRE];
+  int ai = 0, aj = 0, alo = 0, alo_next = 0;
+  float m0 = 0.0f, m1 = 0.0f, dd = 0.0f;
+  float tc[16];
+  auto request = [&](int tt, int alo_t) {  // everything tile tt needs from global memory
+    const int rr0 = tt * TR;
+    if constexpr (!roleA) {
+      const int nwin = min(ATOM_CAP, N - alo_t);
+      const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)alo_t * F);
+      const float4* d4 = reinterpret_cast<const float4*>(dagg + (size_t)alo_t * F);
 #pragma unroll
       for (int u = 0; u < NPRE; ++u) {
-        const int i = tid + NT * u;
+        const int i = stid + NTB * u;
         const bool ok = i < nwin * Q;
         px[u] = ok ? x4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         pdg[u] = ok ? d4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       }
-    }
-    int ai = 0, aj = 0;
-    float m0 = 0.0f, m1 = 0.0f, dd = 0.0f;
-    if (wave == 0 && lane < TR) {  // one pair row per lane
-      const int row = r0 + lane;
-      const bool ok = row < P;
-      const int q = ok ? row : P - 1;
-      ai = pair_i[q];
-      aj = pair_j[q];
-      const unsigned fl = ok ? pair_flag[q] : 0u;
-      const float c = pair_c[q];
-      m0 = (fl & 1u) ? c : 0.0f;
-      m1 = (fl & 2u) ? c : 0.0f;
-      dd = pair_d[q];
+      if (stid < TR) {  // one pair row per lane of the first role-B wave
+        const int row = rr0 + stid;
+        const bool ok = row < P;
+        const int q = ok ? row : P - 1;
+        ai = pair_i[q];
+        aj = pair_j[q];
+        const unsigned fl = ok ? pair_flag[q] : 0u;
+        const float c = pair_c[q];
+        m0 = (fl & 1u) ? c : 0.0f;
+        m1 = (fl & 2u) ? c : 0.0f;
+        dd = pair_d[q];
+      }
     }
     // saved hidden activation of this lane's hidden unit: role A in C layout (register r <-> row c_row(r)), role B
     // in B-fragment layout (k-step s, element e <-> row 16s + 8kh + e); rows past P are clamped (their dO is 0)
-    float tc[16];
     if constexpr (roleA) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tc[r] = Tcol[(size_t)min(r0 + c_row(r, lane), P - 1) * F];
+      for (int r = 0; r < 16; ++r) tc[r] = Tcol[(size_t)min(rr0 + c_row(r, lane), P - 1) * F];
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tc[r] = Tcol[(size_t)min(r0 + 16 * (r >> 3) + 8 * kh + (r & 7), P - 1) * F];
+      for (int r = 0; r < 16; ++r) tc[r] = Tcol[(size_t)min(rr0 + 16 * (r >> 3) + 8 * kh + (r & 7), P - 1) * F];
     }
+  };
+  if (t_begin < t_end) {
+    alo = pair_i[t_begin * TR];
+    if (t_begin + 1 < t_end) alo_next = pair_i[(t_begin + 1) * TR];
+    request(t_begin, alo);
+  }
+  for (int t = t_begin; t < t_end; ++t) {
+    const int r0 = t * TR;
+    const int nwin = min(ATOM_CAP, N - alo);
     __syncthreads();  // previous tile fully consumed: LDS may be overwritten
-    if (wave == 0) {
-      int amax = lane < TR ? aj + 1 : 0;
+    if constexpr (!roleA) {
+      if (wave == NW) {
+        int amax = lane < TR ? aj + 1 : 0;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o, 64));
-      const bool staged0 = amax - alo <= ATOM_CAP;
-      if (lane < TR) {
-        L.tdd[lane] = dd;
-        L.desc[lane] = staged0 ? make_int4((ai - alo) * AS, (aj - alo) * AS, __float_as_int(m0), __float_as_int(m1))
-                               : make_int4(ai, aj, __float_as_int(m0), __float_as_int(m1));
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o, 64));
+        const bool staged0 = amax - alo <= ATOM_CAP;
+        if (lane < TR) {
+          L.tdd[lane] = dd;
+          L.desc[lane] = staged0 ? make_int4((ai - alo) * AS, (aj - alo) * AS, __float_as_int(m0), __float_as_int(m1))
+                                 : make_int4(ai, aj, __float_as_int(m0), __float_as_int(m1));
+        }
+        if (lane == 0) *L.s_amax = amax;
       }
-      if (lane == 0) *L.s_amax = amax;
-    }
 #pragma unroll
-    for (int u = 0; u < NPRE; ++u) {
-      const int i = tid + NT * u;
-      if (i < nwin * Q) {
-        const int a = i / Q, q4 = i - a * Q;
-        *reinterpret_cast<float4*>(L.xs + a * AS + 4 * q4) = px[u];
-        *reinterpret_cast<float4*>(L.ds + a * AS + 4 * q4) = pdg[u];
+      for (int u = 0; u < NPRE; ++u) {
+        const int i = stid + NTB * u;
+        if (i < nwin * Q) {
+          const int a = i / Q, q4 = i - a * Q;
+          *reinterpret_cast<float4*>(L.xs + a * AS + 4 * q4) = px[u];
+          *reinterpret_cast<float4*>(L.ds + a * AS + 4 * q4) = pdg[u];
+        }
       }
     }
     __syncthreads();
@@ -242,30 +255,27 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
       dst[64] = f.m;
       dst[128] = f.l;
     }
+    float tcur[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tcur[r] = tc[r];
     __syncthreads();
+    {  // requests of the next tile: in flight during this tile's MFMA phase
+      const int alo_t = alo_next;
+      alo = alo_t;
+      if (t + 2 < t_end) alo_next = pair_i[(t + 2) * TR];
+      if (t + 1 < t_end) request(t + 1, alo_t);
+    }
     if constexpr (roleA) {
-      // dt = dO W2 for this wave's hidden units; two accumulators (even / odd k-steps) keep dependent MFMAs apart
-      f32x16 acc0, acc1;
+      // dt = dO W2 for this wave's hidden units (back-to-back MFMAs on one accumulator forward SrcC without a stall)
+      f32x16 acc0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+      for (int r = 0; r < 16; ++r) acc0[r] = 0.0f;
 #pragma unroll
-      for (int ks = 0; ks < KC; ks += 2) {
-        Frag3 a0, a1;
+      for (int ks = 0; ks < KC; ++ks) {
+        Frag3 a0;
         const u32x4* s0 = L.dOr + (size_t)(ks * 3) * 64 + lane;
         a0.h = s0[0]; a0.m = s0[64]; a0.l = s0[128];
-        a1.h = s0[192]; a1.m = s0[256]; a1.l = s0[320];
-        acc0 = mfma_bf16(a0.l, bw2[ks].h, acc0);
-        acc1 = mfma_bf16(a1.l, bw2[ks + 1].h, acc1);
-        acc0 = mfma_bf16(a0.h, bw2[ks].l, acc0);
-        acc1 = mfma_bf16(a1.h, bw2[ks + 1].l, acc1);
-        acc0 = mfma_bf16(a0.m, bw2[ks].m, acc0);
-        acc1 = mfma_bf16(a1.m, bw2[ks + 1].m, acc1);
-        acc0 = mfma_bf16(a0.m, bw2[ks].h, acc0);
-        acc1 = mfma_bf16(a1.m, bw2[ks + 1].h, acc1);
-        acc0 = mfma_bf16(a0.h, bw2[ks].m, acc0);
-        acc1 = mfma_bf16(a1.h, bw2[ks + 1].m, acc1);
-        acc0 = mfma_bf16(a0.h, bw2[ks].h, acc0);
-        acc1 = mfma_bf16(a1.h, bw2[ks + 1].h, acc1);
+        mma6(acc0, a0, bw2[ks]);
       }
       // dU = dt * ssp'(pre) (C layout: lane = hidden unit, register = pair row); registers 0..7 / 8..15 are the
       // elements of k-steps 0 / 1 of the contraction over pair rows
@@ -275,7 +285,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          v[e] = (acc0[8 * s + e] + acc1[8 * s + e]) * dssp_from_out(tc[8 * s + e]);
+          v[e] = acc0[8 * s + e] * dssp_from_out(tcur[8 * s + e]);
           bsum1 += v[e];
         }
         du[s] = split8(v);
@@ -307,7 +317,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
       for (int s = 0; s < 2; ++s) {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = tc[8 * s + e];
+        for (int e = 0; e < 8; ++e) v[e] = tcur[8 * s + e];
         tb[s] = split8(v);
       }
       constexpr int CP = CB >= 2 ? 2 : 1;
