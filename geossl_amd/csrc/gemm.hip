@@ -4,6 +4,7 @@
 // Replaces the ATen Linear call sites of the hot path: schnet.py:99,101,166,189,191 and their autograd.
 #include "common.h"
 #include "geossl_hip.h"
+#include "split.h"
 #include "tn.h"
 
 using namespace geossl;
@@ -99,11 +100,154 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, con
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row GEMM on the bf16 matrix pipe (split.h), evaluated transposed: Y^T = B^T X^T with the weight as the A
+// operand (pre-split fragments in LDS, formatted once per block) and the rows of X on the lanes: lane (row j, half
+// kh) loads its own 32 contiguous bytes of X per k-step straight into B-fragment order, and the C layout hands every
+// lane 4 consecutive output columns of its row per register group - bias / ssp / ssp' / residual and the store work
+// on 16-byte pieces with no transposition.  A wave owns 32 rows; output columns are processed 32 at a time so the
+// epilogue operands of a column block are requested before its MFMAs.  K % 16 == 0, K <= 128.
+template <int KS>
+__global__ __launch_bounds__(512) void k_linear_split(const float* __restrict__ X, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, const float* __restrict__ res,
+                                                      const float* __restrict__ tprev, float* __restrict__ Y, int R,
+                                                      int NO, int nmb, int ldx, int ldy, int transB, int flags) {
+  constexpr int K = 16 * KS;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  u32x4* Wf = reinterpret_cast<u32x4*>(smem_raw);  // [nmb][KS][3][64] A fragments of the block's weight columns
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
+  const int n0 = blockIdx.y * 32 * nmb;
+  const int nrb = (R + 31) / 32;
+  int rb = blockIdx.x * 8 + wave;
+  // the first row block's X is requested before the weights are formatted (independent latencies overlap)
+  float4 xr[2 * KS];
+  auto request_x = [&](int rbi) {
+    const float4* xp = reinterpret_cast<const float4*>(X + (size_t)min(32 * rbi + j, R - 1) * ldx + 8 * kh);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      xr[2 * ks] = xp[4 * ks];
+      xr[2 * ks + 1] = xp[4 * ks + 1];
+    }
+  };
+  if (rb < nrb) request_x(rb);
+  for (int i = tid; i < nmb * KS * 64; i += 512) {
+    const int ln = i & 63, ks = (i >> 6) % KS, mb = i / (64 * KS);
+    const int n = n0 + 32 * mb + (ln & 31), k0 = 16 * ks + 8 * (ln >> 5);
+    float v[8];
+    if (n < NO) {
+      if (transB) {
+        const float4 lo = *reinterpret_cast<const float4*>(W + (size_t)n * K + k0);
+        const float4 hi = *reinterpret_cast<const float4*>(W + (size_t)n * K + k0 + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = W[(size_t)(k0 + e) * NO + n];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+    }
+    const Frag3 f = split8(v);
+    u32x4* dst = Wf + ((size_t)(mb * KS + ks) * 3) * 64 + ln;
+    dst[0] = f.h;
+    dst[64] = f.m;
+    dst[128] = f.l;
+  }
+  __syncthreads();
+  for (; rb < nrb; rb += gridDim.x * 8) {
+    Frag3 xf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float v[8] = {xr[2 * ks].x, xr[2 * ks].y, xr[2 * ks].z, xr[2 * ks].w,
+                          xr[2 * ks + 1].x, xr[2 * ks + 1].y, xr[2 * ks + 1].z, xr[2 * ks + 1].w};
+      xf[ks] = split8(v);
+    }
+    const int row = 32 * rb + j;
+    if (rb + gridDim.x * 8 < nrb) request_x(rb + gridDim.x * 8);
+    for (int mb = 0; mb < nmb; ++mb) {
+      const int cb = n0 + 32 * mb + 4 * kh;  // this lane's columns: cb + 8q + {0..3}
+      const size_t o = (size_t)row * ldy + cb;
+      float4 e0[4], e1[4];  // epilogue operands, requested before the MFMAs of the block
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = row < R && cb + 8 * q < NO;
+        e0[q] = (flags & GEOSSL_EPI_MUL_DSSP) && ok ? *reinterpret_cast<const float4*>(tprev + o + 8 * q)
+                                                    : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        e1[q] = (flags & GEOSSL_EPI_RESIDUAL) && ok ? *reinterpret_cast<const float4*>(res + o + 8 * q)
+                                                    : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if ((flags & GEOSSL_EPI_BIAS) && cb + 8 * q < NO) b = *reinterpret_cast<const float4*>(bias + cb + 8 * q);
+        acc[4 * q] = b.x;
+        acc[4 * q + 1] = b.y;
+        acc[4 * q + 2] = b.z;
+        acc[4 * q + 3] = b.w;
+      }
+      Frag3 af, an;
+      {
+        const u32x4* src = Wf + ((size_t)(mb * KS) * 3) * 64 + lane;
+        af.h = src[0]; af.m = src[64]; af.l = src[128];
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+          const u32x4* src = Wf + ((size_t)(mb * KS + ks + 1) * 3) * 64 + lane;
+          an.h = src[0]; an.m = src[64]; an.l = src[128];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma6(acc, af, xf[ks]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 1 < KS) af = an;
+      }
+      if (row < R) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (cb + 8 * q >= NO) continue;
+          float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+          if (flags & GEOSSL_EPI_SSP) { v.x = ssp(v.x); v.y = ssp(v.y); v.z = ssp(v.z); v.w = ssp(v.w); }
+          if (flags & GEOSSL_EPI_MUL_DSSP) {
+            v.x *= dssp_from_out(e0[q].x); v.y *= dssp_from_out(e0[q].y);
+            v.z *= dssp_from_out(e0[q].z); v.w *= dssp_from_out(e0[q].w);
+          }
+          if (flags & GEOSSL_EPI_RESIDUAL) { v.x += e1[q].x; v.y += e1[q].y; v.z += e1[q].z; v.w += e1[q].w; }
+          *reinterpret_cast<float4*>(Y + o + 8 * q) = v;
+        }
+      }
+    }
+  }
+}
+
 extern "C" int geossl_linear(const float* X, int ldx, const float* W, const float* bias, const float* res,
                              const float* tprev, float* Y, int ldy, int64_t R, int K, int NO, int transB, int flags,
                              hipStream_t stream) {
   if (R <= 0) return 0;
   if (K % 8 != 0 || K > 256 || NO > 256) return (int)hipErrorInvalidValue;
+  if (ldx < K || ldy < NO || (ldx & 3) || (ldy & 3) || (NO & 3)) return (int)hipErrorInvalidValue;
+  if (K % 16 == 0 && K <= 128 && (K == 32 || K == 64 || K == 128)) {
+    const int KS = K / 16;
+    int nmb = (NO + 31) / 32;                 // 32-column blocks of the output
+    const int cap = 144 / (3 * KS);            // weight fragments of one block <= 144 KB of LDS
+    int ny = 1;
+    while ((nmb + ny - 1) / ny > cap) ++ny;
+    nmb = (nmb + ny - 1) / ny;
+    const int nrb = (int)((R + 31) / 32);
+    int nx = (nrb + 7) / 8;
+    if (nx > 256) nx = 256;
+    const size_t lds = (size_t)nmb * KS * 3 * 1024;
+#define LAUNCH_S(KSV)                                                                                             \
+  do {                                                                                                            \
+    allow_big_lds(&k_linear_split<KSV>);                                                                          \
+    hipLaunchKernelGGL((k_linear_split<KSV>), dim3(nx, ny), dim3(512), lds, stream, X, W, bias, res, tprev, Y,    \
+                       (int)R, NO, nmb, ldx, ldy, transB, flags);                                                 \
+  } while (0)
+    if (KS == 8) LAUNCH_S(8); else if (KS == 4) LAUNCH_S(4); else LAUNCH_S(2);
+#undef LAUNCH_S
+    GEOSSL_CHECK_LAUNCH();
+    return 0;
+  }
   const int ntiles = (int)((R + 127) / 128);
   const int NOp = (NO + 31) / 32 * 32;
   // split the output columns over gridDim.y when there are too few row tiles to fill 256 CUs
@@ -112,7 +256,6 @@ extern "C" int geossl_linear(const float* X, int ldx, const float* W, const floa
   const int ny = NOp / (32 * NC);
   dim3 grid(ntiles < 1024 ? ntiles : 1024, ny);
   const size_t lds = ((size_t)((K * (32 * NC + 1) + 3) & ~3) + 4 * 512) * sizeof(float);
-  if (ldx < K || ldy < NO || (ldx & 3) || (ldy & 3) || (NO & 3)) return (int)hipErrorInvalidValue;
 #define LAUNCH(NCV)                                                                                               \
   do {                                                                                                            \
     if (lds > 64 * 1024)                                                                                          \
