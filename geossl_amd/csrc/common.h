@@ -197,6 +197,19 @@ __device__ __forceinline__ void transpose_c_block(float* stage, int lane, ValFn 
   }
 }
 
+// Keep a loaded value opaque to the optimiser.  `ok ? p[i] : 0` (and a load followed by a select on the same
+// condition) is compiled to a predicated branch around the load with a full s_waitcnt vmcnt(0) per element, which
+// serialises a batch of independent requests; load from a clamped (always valid) address, pin the value with this,
+// then select.
+__device__ __forceinline__ float pin(float v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ float4 pin(float4 v) {
+  asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
