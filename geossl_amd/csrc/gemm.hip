@@ -102,67 +102,98 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, con
 
 // ------------------------------------------------------------------------------------------------
 // Row GEMM on the bf16 matrix pipe (split.h), evaluated transposed: Y^T = B^T X^T with the weight as the A
-// operand (pre-split fragments in LDS, formatted once per block) and the rows of X on the lanes: lane (row j, half
-// kh) loads its own 32 contiguous bytes of X per k-step straight into B-fragment order, and the C layout hands every
-// lane 4 consecutive output columns of its row per register group - bias / ssp / ssp' / residual and the store work
-// on 16-byte pieces with no transposition.  A wave owns 32 rows; output columns are processed 32 at a time so the
-// epilogue operands of a column block are requested before its MFMAs.  K % 16 == 0, K <= 128.
+// operand (pre-split fragments in LDS, formatted once per block) and the rows of X on the lanes.  A wave owns 32
+// rows.  The vector-memory pipe pays per 128-byte line an instruction touches, so nothing is loaded or stored
+// "one row per lane" (32 lines per instruction): X, the epilogue operands and Y all move as fully coalesced
+// 16-byte-per-lane accesses (8 lanes per 128-byte row segment, 8 lines per instruction) and are re-shaped between
+// that layout and the MFMA layouts (B fragment: lane = row, 8 consecutive k; C: lane = row, 4 consecutive columns
+// per register group) through a wave-private 32x32 LDS stage (row stride 36 floats: conflict-free both ways).
+// Output columns are processed 32 at a time so the epilogue operands of a column block are requested before its
+// MFMAs.  K % 32 == 0, K <= 128.
+constexpr int LSS = 36;  // row stride of the wave-private stage, floats
 template <int KS>
 __global__ __launch_bounds__(512) void k_linear_split(const float* __restrict__ X, const float* __restrict__ W,
                                                       const float* __restrict__ bias, const float* __restrict__ res,
                                                       const float* __restrict__ tprev, float* __restrict__ Y, int R,
                                                       int NO, int nmb, int ldx, int ldy, int transB, int flags) {
-  constexpr int K = 16 * KS;
+  constexpr int K = 16 * KS, NCH = KS / 2;  // NCH 32-column chunks of X
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
   u32x4* Wf = reinterpret_cast<u32x4*>(smem_raw);  // [nmb][KS][3][64] A fragments of the block's weight columns
+  float* bias_s = reinterpret_cast<float*>(Wf + (size_t)nmb * KS * 3 * 64);  // [32*nmb]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
+  float* stage = bias_s + 32 * nmb + wave * (32 * LSS);
   const int n0 = blockIdx.y * 32 * nmb;
   const int nrb = (R + 31) / 32;
-  int rb = blockIdx.x * 8 + wave;
+  const int cr = lane >> 3, c4 = 4 * (lane & 7);  // coalesced access role: row 8u + cr, columns c4 .. c4+3
+  // Work split.  The per-wave cost of a row block is MFMA + vector work on the same SIMD and two waves of a SIMD
+  // do not overlap them, so the launch is balanced over SIMDs, not over waves: waves 0-3 of a block (one per
+  // SIMD) take whole row blocks, round-robin over all blocks; the row blocks left over after the last full round
+  // are cut into (row block, column block) tasks and given to waves 4-7.  All 8 waves format the weights.
+  const int nprim = 4 * gridDim.x;
+  const int n_whole = nrb >= nprim ? (nrb / nprim) * nprim : nrb;  // row blocks processed whole
+  const int n_tasks = (nrb - n_whole) * nmb;                      // (row block, column block) tasks
+  const bool primary = wave < 4;
+  const int slot = blockIdx.x + gridDim.x * (wave & 3);
+  int item = slot;  // primary: row block; secondary: task index
+  auto item_rb = [&](int it) { return primary ? it : n_whole + it / nmb; };
+  const int item_end = primary ? n_whole : n_tasks;
   // the first row block's X is requested before the weights are formatted (independent latencies overlap)
-  float4 xr[2 * KS];
+  float4 xr[NCH][4];
   auto request_x = [&](int rbi) {
-    const float4* xp = reinterpret_cast<const float4*>(X + (size_t)min(32 * rbi + j, R - 1) * ldx + 8 * kh);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      xr[2 * ks] = xp[4 * ks];
-      xr[2 * ks + 1] = xp[4 * ks + 1];
-    }
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        xr[c][u] = *reinterpret_cast<const float4*>(X + (size_t)min(32 * rbi + 8 * u + cr, R - 1) * ldx + 32 * c + c4);
   };
-  if (rb < nrb) request_x(rb);
-  float* bias_s = reinterpret_cast<float*>(Wf + (size_t)nmb * KS * 3 * 64);  // [32*nmb]
+  if (item < item_end) request_x(item_rb(item));
   for (int i = tid; i < 32 * nmb; i += 512)
     bias_s[i] = (flags & GEOSSL_EPI_BIAS) && n0 + i < NO ? bias[n0 + i] : 0.0f;
-  // weight formatting, four fragment lanes per thread at a time: all global loads first, then split + LDS writes
-  for (int i0 = tid; i0 < nmb * KS * 64; i0 += 4 * 512) {
+  // weight formatting, four fragment lanes per thread at a time: all global loads first (clamped addresses, no
+  // predicated loads), then split + LDS writes.  transB: thread <-> (n, 8 consecutive k): consecutive threads read
+  // consecutive 32 bytes of W.  !transB: thread <-> fragment lane, the eight k are strided rows of W, a half-wave
+  // reads 128 contiguous bytes of each.
+  const int nitems = nmb * KS * 64;
+  for (int i0 = tid; i0 < nitems; i0 += 4 * 512) {
     float v[4][8];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = i0 + 512 * u;
-      const int ln = i & 63, ks = (i >> 6) % KS, mb = i / (64 * KS);
-      const int n = n0 + 32 * mb + (ln & 31), k0 = 16 * ks + 8 * (ln >> 5);
-      if (i < nmb * KS * 64 && n < NO) {
-        if (transB) {
-          const float4 lo = *reinterpret_cast<const float4*>(W + (size_t)n * K + k0);
-          const float4 hi = *reinterpret_cast<const float4*>(W + (size_t)n * K + k0 + 4);
-          v[u][0] = lo.x; v[u][1] = lo.y; v[u][2] = lo.z; v[u][3] = lo.w;
-          v[u][4] = hi.x; v[u][5] = hi.y; v[u][6] = hi.z; v[u][7] = hi.w;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[u][e] = W[(size_t)(k0 + e) * NO + n];
-        }
+      const int i = min(i0 + 512 * u, nitems - 1);
+      if (transB) {
+        const int n = min(n0 + i / (2 * KS), NO - 1), k8 = i % (2 * KS);
+        const float4 lo = *reinterpret_cast<const float4*>(W + (size_t)n * K + 8 * k8);
+        const float4 hi = *reinterpret_cast<const float4*>(W + (size_t)n * K + 8 * k8 + 4);
+        v[u][0] = lo.x; v[u][1] = lo.y; v[u][2] = lo.z; v[u][3] = lo.w;
+        v[u][4] = hi.x; v[u][5] = hi.y; v[u][6] = hi.z; v[u][7] = hi.w;
       } else {
+        const int ln = i & 63, ks = (i >> 6) % KS, mb = i / (64 * KS);
+        const int n = min(n0 + 32 * mb + (ln & 31), NO - 1), k0 = 16 * ks + 8 * (ln >> 5);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[u][e] = 0.0f;
+        for (int e = 0; e < 8; ++e) v[u][e] = W[(size_t)(k0 + e) * NO + n];
       }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + 512 * u;
-      if (i < nmb * KS * 64) {
-        const int ln = i & 63, ks = (i >> 6) % KS, mb = i / (64 * KS);
+      int nl, ks, khh;  // column within the block, k-step, k half of this item
+      if (transB) {
+        nl = i / (2 * KS);
+        ks = (i % (2 * KS)) >> 1;
+        khh = i & 1;
+      } else {
+        nl = 32 * (i / (64 * KS)) + (i & 31);
+        ks = (i >> 6) % KS;
+        khh = (i >> 5) & 1;
+      }
+      const bool ok = n0 + nl < NO;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = pin(v[u][e]);
+        v[u][e] = ok ? t : 0.0f;
+      }
+      if (i < nitems) {
         const Frag3 f = split8(v[u]);
-        u32x4* dst = Wf + ((size_t)(mb * KS + ks) * 3) * 64 + ln;
+        u32x4* dst = Wf + ((size_t)((nl >> 5) * KS + ks) * 3) * 64 + (nl & 31) + 32 * khh;
         dst[0] = f.h;
         dst[64] = f.m;
         dst[128] = f.l;
@@ -170,27 +201,39 @@ __global__ __launch_bounds__(512) void k_linear_split(const float* __restrict__ 
     }
   }
   __syncthreads();
-  for (; rb < nrb; rb += gridDim.x * 8) {
+  for (; item < item_end; item += nprim) {
+    const int rb = item_rb(item);
+    const int mb_begin = primary ? 0 : item % nmb, mb_end = primary ? nmb : mb_begin + 1;
+    // X: coalesced registers -> stage -> B fragments (lane = row j, k = 16ks + 8kh + e)
     Frag3 xf[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const float v[8] = {xr[2 * ks].x, xr[2 * ks].y, xr[2 * ks].z, xr[2 * ks].w,
-                          xr[2 * ks + 1].x, xr[2 * ks + 1].y, xr[2 * ks + 1].z, xr[2 * ks + 1].w};
-      xf[ks] = split8(v);
-    }
-    const int row = 32 * rb + j;
-    if (rb + gridDim.x * 8 < nrb) request_x(rb + gridDim.x * 8);
-    for (int mb = 0; mb < nmb; ++mb) {
-      const int cb = n0 + 32 * mb + 4 * kh;  // this lane's columns: cb + 8q + {0..3}
-      const size_t o = (size_t)row * ldy + cb;
-      float4 e0[4], e1[4];  // epilogue operands, requested before the MFMAs of the block
+    for (int c = 0; c < NCH; ++c) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool ok = row < R && cb + 8 * q < NO;
-        e0[q] = (flags & GEOSSL_EPI_MUL_DSSP) && ok ? *reinterpret_cast<const float4*>(tprev + o + 8 * q)
-                                                    : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        e1[q] = (flags & GEOSSL_EPI_RESIDUAL) && ok ? *reinterpret_cast<const float4*>(res + o + 8 * q)
-                                                    : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(stage + (8 * u + cr) * LSS + c4) = xr[c][u];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const float4 lo = *reinterpret_cast<const float4*>(stage + j * LSS + 16 * s2 + 8 * kh);
+        const float4 hi = *reinterpret_cast<const float4*>(stage + j * LSS + 16 * s2 + 8 * kh + 4);
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        xf[2 * c + s2] = split8(v);
+      }
+    }
+    if (item + nprim < item_end) request_x(item_rb(item + nprim));
+    for (int mb = mb_begin; mb < mb_end; ++mb) {
+      const int cb = n0 + 32 * mb;
+      // epilogue operands in the coalesced layout, requested before the MFMAs of the block.  No branch on the
+      // (uniform) flags: an unused operand is read from the first 16 bytes of W (always valid) and ignored -
+      // branches would let the compiler sink the loads below the MFMA loop, behind a vmcnt(0) each
+      float4 e0[4], e1[4];
+      {
+        const bool use0 = flags & GEOSSL_EPI_MUL_DSSP, use1 = flags & GEOSSL_EPI_RESIDUAL;
+        const int cc = min(cb + c4, NO - 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const size_t oc = (size_t)min(32 * rb + 8 * u + cr, R - 1) * ldy + cc;
+          e0[u] = *reinterpret_cast<const float4*>(use0 ? tprev + oc : W);
+          e1[u] = *reinterpret_cast<const float4*>(use1 ? res + oc : W);
+        }
       }
       f32x16 acc;
 #pragma unroll
@@ -217,19 +260,22 @@ __global__ __launch_bounds__(512) void k_linear_split(const float* __restrict__ 
         __builtin_amdgcn_sched_barrier(0);
         if (ks + 1 < KS) af = an;
       }
-      if (row < R) {
+      // C layout (lane = row j, columns 8q + 4kh + {0..3}) -> stage -> coalesced layout
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (cb + 8 * q >= NO) continue;
-          float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-          if (flags & GEOSSL_EPI_SSP) { v.x = ssp(v.x); v.y = ssp(v.y); v.z = ssp(v.z); v.w = ssp(v.w); }
-          if (flags & GEOSSL_EPI_MUL_DSSP) {
-            v.x *= dssp_from_out(e0[q].x); v.y *= dssp_from_out(e0[q].y);
-            v.z *= dssp_from_out(e0[q].z); v.w *= dssp_from_out(e0[q].w);
-          }
-          if (flags & GEOSSL_EPI_RESIDUAL) { v.x += e1[q].x; v.y += e1[q].y; v.z += e1[q].z; v.w += e1[q].w; }
-          *reinterpret_cast<float4*>(Y + o + 8 * q) = v;
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(stage + j * LSS + 8 * q + 4 * kh) =
+            make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // arithmetic unconditional (keeps the operand loads up front), store predicated
+        float4 v = *reinterpret_cast<const float4*>(stage + (8 * u + cr) * LSS + c4);
+        if (flags & GEOSSL_EPI_SSP) { v.x = ssp(v.x); v.y = ssp(v.y); v.z = ssp(v.z); v.w = ssp(v.w); }
+        if (flags & GEOSSL_EPI_MUL_DSSP) {
+          v.x *= dssp_from_out(e0[u].x); v.y *= dssp_from_out(e0[u].y);
+          v.z *= dssp_from_out(e0[u].z); v.w *= dssp_from_out(e0[u].w);
         }
+        if (flags & GEOSSL_EPI_RESIDUAL) { v.x += e1[u].x; v.y += e1[u].y; v.z += e1[u].z; v.w += e1[u].w; }
+        const int row = 32 * rb + 8 * u + cr;
+        if (row < R && cb + c4 < NO) *reinterpret_cast<float4*>(Y + (size_t)row * ldy + cb + c4) = v;
       }
     }
   }
@@ -241,17 +287,17 @@ extern "C" int geossl_linear(const float* X, int ldx, const float* W, const floa
   if (R <= 0) return 0;
   if (K % 8 != 0 || K > 256 || NO > 256) return (int)hipErrorInvalidValue;
   if (ldx < K || ldy < NO || (ldx & 3) || (ldy & 3) || (NO & 3)) return (int)hipErrorInvalidValue;
-  if (K % 16 == 0 && K <= 128 && (K == 32 || K == 64 || K == 128)) {
+  if (K == 32 || K == 64 || K == 128) {
     const int KS = K / 16;
     int nmb = (NO + 31) / 32;                 // 32-column blocks of the output
-    const int cap = 144 / (3 * KS);            // weight fragments of one block <= 144 KB of LDS
+    const int cap = 108 / (3 * KS);            // weight fragments of one block <= 108 KB of LDS (stages: 36 KB)
     int ny = 1;
     while ((nmb + ny - 1) / ny > cap) ++ny;
     nmb = (nmb + ny - 1) / ny;
     const int nrb = (int)((R + 31) / 32);
-    int nx = (nrb + 7) / 8;
+    int nx = (nrb + 3) / 4;  // whole row blocks go to four waves per block (one per SIMD)
     if (nx > 256) nx = 256;
-    const size_t lds = (size_t)nmb * KS * 3 * 1024 + (size_t)nmb * 32 * sizeof(float);
+    const size_t lds = (size_t)nmb * KS * 3 * 1024 + (size_t)(nmb * 32 + 8 * 32 * LSS) * sizeof(float);
 #define LAUNCH_S(KSV)                                                                                             \
   do {                                                                                                            \
     allow_big_lds(&k_linear_split<KSV>);                                                                          \
