@@ -134,6 +134,11 @@ class _SchNetCore(torch.autograd.Function):
         if P > 0:
             call("geossl_cfconv_filter_fwd", ptr(pair_d), ptr(pair_c), P, C.byref(fw), L, F, G, ptr(cfg["offset"]),
                  cfg["coeff"], ptr(T), ptr(Wf), st)
+        # operand images of the 3L square Linear weights, one launch (each is used by a launch over all atoms of
+        # both views; geossl_linear would otherwise re-shape it in every block)
+        pw = ops.prepare_linear([lp[k] for lp in layers for k in (4, 5, 7)], transB=True)
+        if pw is not None:
+            layers = [lp[:4] + [pw[3 * l], pw[3 * l + 1], lp[6], pw[3 * l + 2], lp[8]] for l, lp in enumerate(layers)]
         hs, xs, aggs, ts = [], [], [], []
         for l, lp in enumerate(layers):
             x = ops.linear(h, lp[4])                                    # conv.lin1 (no bias)   :189
@@ -182,12 +187,14 @@ class _SchNetCore(torch.autograd.Function):
         probs.append((du, sv["h_last"], g_head[0], g_head[1]))
         daggs = [None] * L
         keep = [dh_out, du]
+        pw = ops.prepare_linear([lp[k] for lp in layers for k in (4, 5, 7)], transB=False)  # backward-input images
         for l in reversed(range(L)):
             lp, gl = layers[l], g_layers[l]
-            dy = ops.linear(dh, lp[7], transB=False, tprev=sv["ts"][l])       # through lin and act
-            dagg = ops.linear(dy, lp[5], transB=False)                         # through conv.lin2
+            w_lin1, w_lin2, w_lin = (pw[3 * l], pw[3 * l + 1], pw[3 * l + 2]) if pw is not None else (lp[4], lp[5], lp[7])
+            dy = ops.linear(dh, w_lin, transB=False, tprev=sv["ts"][l])        # through lin and act
+            dagg = ops.linear(dy, w_lin2, transB=False)                        # through conv.lin2
             dx = ops.aggregate(dagg, sv["Wf"][l], sv["pair_flag"], lay, swap=True)  # transposed graph
-            dh_new = ops.linear(dx, lp[4], transB=False, res=dh)               # through conv.lin1 + residual
+            dh_new = ops.linear(dx, w_lin1, transB=False, res=dh)              # through conv.lin1 + residual
             probs.append((dh, sv["ts"][l], gl[7], gl[8]))
             probs.append((dy, sv["aggs"][l], gl[5], gl[6]))
             probs.append((dx, sv["hs"][l], gl[4], None))

@@ -25,6 +25,10 @@ class FilterWeights(C.Structure):
     _fields_ = [("w1", vp * MAX_L), ("b1", vp * MAX_L), ("w2", vp * MAX_L), ("b2", vp * MAX_L)]
 
 
+class PrepareBatch(C.Structure):
+    _fields_ = [("W", vp * TN_MAX), ("image", vp * TN_MAX)]
+
+
 class FilterGradIn(C.Structure):
     _fields_ = [("x", vp * MAX_L), ("dagg", vp * MAX_L)]
 
@@ -68,6 +72,9 @@ PROTOTYPES = {
     "geossl_linear": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]),
     "geossl_tn_plan": (None, [i64, i32, P(i32), P(i32)]),
     "geossl_tn_workspace_floats": (i64, [i64, i32, i32, i32]),
+    "geossl_linear_image_words": (i64, [i32, i32]),
+    "geossl_linear_prepare": (i32, [P(PrepareBatch), i32, i32, i32, i32, vp]),
+    "geossl_linear_prepared": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp]),
     "geossl_linear_wgrad": (i32, [P(TnBatch), i32, i64, i32, i32, i32, i32, i32, vp, i32, vp]),
     "geossl_embedding_fwd": (i32, [vp, i64, vp, i32, i64, i32, vp, vp, vp]),
     "geossl_embedding_bwd_workspace_floats": (i64, [i32, i32]),

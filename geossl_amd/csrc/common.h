@@ -18,6 +18,9 @@
 #include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// native 16-byte vector: unlike the float4 struct it is a first-class value (arrays of it are always promoted to
+// registers; an array of float4 copied to LDS as a whole struct can end up in scratch memory)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define GEOSSL_MAX_LAYERS 12
 #define GEOSSL_PI_F 3.14159265358979323846f

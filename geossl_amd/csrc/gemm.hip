@@ -110,12 +110,73 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, con
 // per register group) through a wave-private 32x32 LDS stage (row stride 36 floats: conflict-free both ways).
 // Output columns are processed 32 at a time so the epilogue operands of a column block are requested before its
 // MFMAs.  K % 32 == 0, K <= 128.
+// Weight formatting shared by k_linear_split and k_linear_prepare.  A weight is cut into "items" of 8 contraction
+// indices of one output column (= one lane of one A fragment).  transB (torch layout [NO][K]): item <-> (n, 8
+// consecutive k), consecutive items are consecutive 32 bytes of W.  !transB ([K][NO]): item <-> fragment lane, the
+// eight k are strided rows of W and a half-wave reads 128 contiguous bytes of each.  Addresses are clamped (no
+// predicated loads); the caller zeroes columns past NO.
+template <int KS>
+__device__ __forceinline__ void load_weight_item(const float* __restrict__ W, int i, int n0, int NO, int transB,
+                                                 float (&v)[8]) {
+  constexpr int K = 16 * KS;
+  if (transB) {
+    const int n = min(n0 + i / (2 * KS), NO - 1), k8 = i % (2 * KS);
+    const float4 lo = *reinterpret_cast<const float4*>(W + (size_t)n * K + 8 * k8);
+    const float4 hi = *reinterpret_cast<const float4*>(W + (size_t)n * K + 8 * k8 + 4);
+    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+    v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+  } else {
+    const int ln = i & 63, ks = (i >> 6) % KS, mb = i / (64 * KS);
+    const int n = min(n0 + 32 * mb + (ln & 31), NO - 1), k0 = 16 * ks + 8 * (ln >> 5);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = W[(size_t)(k0 + e) * NO + n];
+  }
+}
+// column (relative to the first column of the item range), k-step and k half of item i
+template <int KS>
+__device__ __forceinline__ void weight_item_slot(int i, int transB, int& nl, int& ks, int& khh) {
+  if (transB) {
+    nl = i / (2 * KS);
+    ks = (i % (2 * KS)) >> 1;
+    khh = i & 1;
+  } else {
+    nl = 32 * (i / (64 * KS)) + (i & 31);
+    ks = (i >> 6) % KS;
+    khh = (i >> 5) & 1;
+  }
+}
+
+// image_z[mb][ks][piece][lane] (u32x4) for every 32-column block mb of weight z
+template <int KS>
+__global__ __launch_bounds__(256) void k_linear_prepare(GeosslPrepareBatch batch, int NO, int transB) {
+  const int z = blockIdx.y;
+  const float* __restrict__ W = batch.W[z];
+  u32x4* __restrict__ image = reinterpret_cast<u32x4*>(batch.image[z]);
+  const int nitems = ((NO + 31) / 32) * KS * 64;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nitems) return;
+  float v[8];
+  load_weight_item<KS>(W, i, 0, NO, transB, v);
+  int nl, ks, khh;
+  weight_item_slot<KS>(i, transB, nl, ks, khh);
+  if (nl >= NO) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+  }
+  const Frag3 f = split8(v);
+  u32x4* dst = image + ((size_t)((nl >> 5) * KS + ks) * 3) * 64 + (nl & 31) + 32 * khh;
+  dst[0] = f.h;
+  dst[64] = f.m;
+  dst[128] = f.l;
+}
+
 constexpr int LSS = 36;  // row stride of the wave-private stage, floats
 template <int KS>
 __global__ __launch_bounds__(512) void k_linear_split(const float* __restrict__ X, const float* __restrict__ W,
                                                       const float* __restrict__ bias, const float* __restrict__ res,
                                                       const float* __restrict__ tprev, float* __restrict__ Y, int R,
-                                                      int NO, int nmb, int ldx, int ldy, int transB, int flags) {
+                                                      int NO, int nmb, int ldx, int ldy, int transB, int flags,
+                                                      const u32x4* __restrict__ image) {
   constexpr int K = 16 * KS, NCH = KS / 2;  // NCH 32-column chunks of X
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
   u32x4* Wf = reinterpret_cast<u32x4*>(smem_raw);  // [nmb][KS][3][64] A fragments of the block's weight columns
@@ -138,65 +199,52 @@ __global__ __launch_bounds__(512) void k_linear_split(const float* __restrict__ 
   auto item_rb = [&](int it) { return primary ? it : n_whole + it / nmb; };
   const int item_end = primary ? n_whole : n_tasks;
   // the first row block's X is requested before the weights are formatted (independent latencies overlap)
-  float4 xr[NCH][4];
-  auto request_x = [&](int rbi) {
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        xr[c][u] = *reinterpret_cast<const float4*>(X + (size_t)min(32 * rbi + 8 * u + cr, R - 1) * ldx + 32 * c + c4);
-  };
-  if (item < item_end) request_x(item_rb(item));
+  f32x4 xr[NCH][4];
+#define REQUEST_X(rbi)                                                                                          \
+  do {                                                                                                          \
+    _Pragma("unroll") for (int c_ = 0; c_ < NCH; ++c_) _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_)         \
+        xr[c_][u_] = *reinterpret_cast<const f32x4*>(X + (size_t)min(32 * (rbi) + 8 * u_ + cr, R - 1) * ldx +  \
+                                                      32 * c_ + c4);                                            \
+  } while (0)
+  if (item < item_end) REQUEST_X(item_rb(item));
   for (int i = tid; i < 32 * nmb; i += 512)
     bias_s[i] = (flags & GEOSSL_EPI_BIAS) && n0 + i < NO ? bias[n0 + i] : 0.0f;
-  // weight formatting, four fragment lanes per thread at a time: all global loads first (clamped addresses, no
-  // predicated loads), then split + LDS writes.  transB: thread <-> (n, 8 consecutive k): consecutive threads read
-  // consecutive 32 bytes of W.  !transB: thread <-> fragment lane, the eight k are strided rows of W, a half-wave
-  // reads 128 contiguous bytes of each.
   const int nitems = nmb * KS * 64;
-  for (int i0 = tid; i0 < nitems; i0 += 4 * 512) {
-    float v[4][8];
+  if (image != nullptr) {
+    // prepared weights: the block's slice of the fragment image is copied as is (coalesced 16-byte loads, four in
+    // flight per thread)
+    const u32x4* src = image + (size_t)blockIdx.y * nitems * 3;
+    for (int i0 = tid; i0 < 3 * nitems; i0 += 4 * 512) {
+      u32x4 t[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = min(i0 + 512 * u, nitems - 1);
-      if (transB) {
-        const int n = min(n0 + i / (2 * KS), NO - 1), k8 = i % (2 * KS);
-        const float4 lo = *reinterpret_cast<const float4*>(W + (size_t)n * K + 8 * k8);
-        const float4 hi = *reinterpret_cast<const float4*>(W + (size_t)n * K + 8 * k8 + 4);
-        v[u][0] = lo.x; v[u][1] = lo.y; v[u][2] = lo.z; v[u][3] = lo.w;
-        v[u][4] = hi.x; v[u][5] = hi.y; v[u][6] = hi.z; v[u][7] = hi.w;
-      } else {
-        const int ln = i & 63, ks = (i >> 6) % KS, mb = i / (64 * KS);
-        const int n = min(n0 + 32 * mb + (ln & 31), NO - 1), k0 = 16 * ks + 8 * (ln >> 5);
+      for (int u = 0; u < 4; ++u) t[u] = src[min(i0 + 512 * u, 3 * nitems - 1)];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[u][e] = W[(size_t)(k0 + e) * NO + n];
-      }
+      for (int u = 0; u < 4; ++u)
+        if (i0 + 512 * u < 3 * nitems) Wf[i0 + 512 * u] = t[u];
     }
+  } else {
+    for (int i0 = tid; i0 < nitems; i0 += 4 * 512) {
+      float v[4][8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + 512 * u;
-      int nl, ks, khh;  // column within the block, k-step, k half of this item
-      if (transB) {
-        nl = i / (2 * KS);
-        ks = (i % (2 * KS)) >> 1;
-        khh = i & 1;
-      } else {
-        nl = 32 * (i / (64 * KS)) + (i & 31);
-        ks = (i >> 6) % KS;
-        khh = (i >> 5) & 1;
-      }
-      const bool ok = n0 + nl < NO;
+      for (int u = 0; u < 4; ++u) load_weight_item<KS>(W, min(i0 + 512 * u, nitems - 1), n0, NO, transB, v[u]);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float t = pin(v[u][e]);
-        v[u][e] = ok ? t : 0.0f;
-      }
-      if (i < nitems) {
-        const Frag3 f = split8(v[u]);
-        u32x4* dst = Wf + ((size_t)((nl >> 5) * KS + ks) * 3) * 64 + (nl & 31) + 32 * khh;
-        dst[0] = f.h;
-        dst[64] = f.m;
-        dst[128] = f.l;
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 512 * u;
+        int nl, ks, khh;
+        weight_item_slot<KS>(i, transB, nl, ks, khh);
+        const bool ok = n0 + nl < NO;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t = pin(v[u][e]);
+          v[u][e] = ok ? t : 0.0f;
+        }
+        if (i < nitems) {
+          const Frag3 f = split8(v[u]);
+          u32x4* dst = Wf + ((size_t)((nl >> 5) * KS + ks) * 3) * 64 + (nl & 31) + 32 * khh;
+          dst[0] = f.h;
+          dst[64] = f.m;
+          dst[128] = f.l;
+        }
       }
     }
   }
@@ -209,36 +257,35 @@ __global__ __launch_bounds__(512) void k_linear_split(const float* __restrict__ 
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(stage + (8 * u + cr) * LSS + c4) = xr[c][u];
+      for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(stage + (8 * u + cr) * LSS + c4) = xr[c][u];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const float4 lo = *reinterpret_cast<const float4*>(stage + j * LSS + 16 * s2 + 8 * kh);
-        const float4 hi = *reinterpret_cast<const float4*>(stage + j * LSS + 16 * s2 + 8 * kh + 4);
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + j * LSS + 16 * s2 + 8 * kh);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + j * LSS + 16 * s2 + 8 * kh + 4);
         const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         xf[2 * c + s2] = split8(v);
       }
     }
-    if (item + nprim < item_end) request_x(item_rb(item + nprim));
     for (int mb = mb_begin; mb < mb_end; ++mb) {
       const int cb = n0 + 32 * mb;
       // epilogue operands in the coalesced layout, requested before the MFMAs of the block.  No branch on the
       // (uniform) flags: an unused operand is read from the first 16 bytes of W (always valid) and ignored -
       // branches would let the compiler sink the loads below the MFMA loop, behind a vmcnt(0) each
-      float4 e0[4], e1[4];
+      f32x4 e0[4], e1[4];
       {
         const bool use0 = flags & GEOSSL_EPI_MUL_DSSP, use1 = flags & GEOSSL_EPI_RESIDUAL;
         const int cc = min(cb + c4, NO - 4);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const size_t oc = (size_t)min(32 * rb + 8 * u + cr, R - 1) * ldy + cc;
-          e0[u] = *reinterpret_cast<const float4*>(use0 ? tprev + oc : W);
-          e1[u] = *reinterpret_cast<const float4*>(use1 ? res + oc : W);
+          e0[u] = *reinterpret_cast<const f32x4*>(use0 ? tprev + oc : W);
+          e1[u] = *reinterpret_cast<const f32x4*>(use1 ? res + oc : W);
         }
       }
       f32x16 acc;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 b = *reinterpret_cast<const float4*>(bias_s + 32 * mb + 4 * kh + 8 * q);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + 32 * mb + 4 * kh + 8 * q);
         acc[4 * q] = b.x;
         acc[4 * q + 1] = b.y;
         acc[4 * q + 2] = b.z;
@@ -263,11 +310,11 @@ __global__ __launch_bounds__(512) void k_linear_split(const float* __restrict__ 
       // C layout (lane = row j, columns 8q + 4kh + {0..3}) -> stage -> coalesced layout
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(stage + j * LSS + 8 * q + 4 * kh) =
-            make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        *reinterpret_cast<f32x4*>(stage + j * LSS + 8 * q + 4 * kh) =
+            f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {  // arithmetic unconditional (keeps the operand loads up front), store predicated
-        float4 v = *reinterpret_cast<const float4*>(stage + (8 * u + cr) * LSS + c4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage + (8 * u + cr) * LSS + c4);
         if (flags & GEOSSL_EPI_SSP) { v.x = ssp(v.x); v.y = ssp(v.y); v.z = ssp(v.z); v.w = ssp(v.w); }
         if (flags & GEOSSL_EPI_MUL_DSSP) {
           v.x *= dssp_from_out(e0[u].x); v.y *= dssp_from_out(e0[u].y);
@@ -275,10 +322,69 @@ __global__ __launch_bounds__(512) void k_linear_split(const float* __restrict__ 
         }
         if (flags & GEOSSL_EPI_RESIDUAL) { v.x += e1[u].x; v.y += e1[u].y; v.z += e1[u].z; v.w += e1[u].w; }
         const int row = 32 * rb + 8 * u + cr;
-        if (row < R && cb + c4 < NO) *reinterpret_cast<float4*>(Y + (size_t)row * ldy + cb + c4) = v;
+        if (row < R && cb + c4 < NO) *reinterpret_cast<f32x4*>(Y + (size_t)row * ldy + cb + c4) = v;
       }
     }
+    // a wave rarely has a second item (R > 32 rows x 4 waves x 256 blocks); its X is requested here rather than
+    // before the MFMAs so that the 64 staging registers are not live across them
+    if (item + nprim < item_end) REQUEST_X(item_rb(item + nprim));
   }
+#undef REQUEST_X
+}
+
+// launch of the split kernel; W or image (exactly one non-null)
+static int launch_linear_split(const float* X, int ldx, const float* W, const u32x4* image, const float* bias,
+                               const float* res, const float* tprev, float* Y, int ldy, int64_t R, int K, int NO,
+                               int transB, int flags, hipStream_t stream) {
+  const int KS = K / 16;
+  int nmb = (NO + 31) / 32;                 // 32-column blocks of the output
+  const int cap = 108 / (3 * KS);            // weight fragments of one block <= 108 KB of LDS (stages: 36 KB)
+  int ny = 1;
+  while ((nmb + ny - 1) / ny > cap) ++ny;
+  if (image != nullptr && nmb % ny != 0) return (int)hipErrorInvalidValue;  // image slices must tile evenly
+  nmb = (nmb + ny - 1) / ny;
+  const int nrb = (int)((R + 31) / 32);
+  int nx = (nrb + 3) / 4;  // whole row blocks go to four waves per block (one per SIMD)
+  if (nx > 256) nx = 256;
+  const size_t lds = (size_t)nmb * KS * 3 * 1024 + (size_t)(nmb * 32 + 8 * 32 * LSS) * sizeof(float);
+#define LAUNCH_S(KSV)                                                                                             \
+  do {                                                                                                            \
+    allow_big_lds(&k_linear_split<KSV>);                                                                          \
+    hipLaunchKernelGGL((k_linear_split<KSV>), dim3(nx, ny), dim3(512), lds, stream, X, W, bias, res, tprev, Y,    \
+                       (int)R, NO, nmb, ldx, ldy, transB, flags, image);                                          \
+  } while (0)
+  if (KS == 8) LAUNCH_S(8); else if (KS == 4) LAUNCH_S(4); else LAUNCH_S(2);
+#undef LAUNCH_S
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int64_t geossl_linear_image_words(int K, int NO) {
+  if (!(K == 32 || K == 64 || K == 128) || NO <= 0 || NO > 256 || (NO & 3)) return 0;
+  return (int64_t)((NO + 31) / 32) * (K / 16) * 3 * 64 * 4;
+}
+
+extern "C" int geossl_linear_prepare(const GeosslPrepareBatch* batch, int nprob, int K, int NO, int transB,
+                                     hipStream_t stream) {
+  if (nprob <= 0) return 0;
+  if (nprob > GEOSSL_TN_MAX || geossl_linear_image_words(K, NO) == 0) return (int)hipErrorInvalidValue;
+  const int KS = K / 16, nitems = ((NO + 31) / 32) * KS * 64;
+  dim3 grid((nitems + 255) / 256, nprob);
+  if (KS == 8) hipLaunchKernelGGL((k_linear_prepare<8>), grid, dim3(256), 0, stream, *batch, NO, transB);
+  else if (KS == 4) hipLaunchKernelGGL((k_linear_prepare<4>), grid, dim3(256), 0, stream, *batch, NO, transB);
+  else hipLaunchKernelGGL((k_linear_prepare<2>), grid, dim3(256), 0, stream, *batch, NO, transB);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_linear_prepared(const float* X, int ldx, const uint32_t* image, const float* bias,
+                                      const float* res, const float* tprev, float* Y, int ldy, int64_t R, int K,
+                                      int NO, int flags, hipStream_t stream) {
+  if (R <= 0) return 0;
+  if (image == nullptr || geossl_linear_image_words(K, NO) == 0) return (int)hipErrorInvalidValue;
+  if (ldx < K || ldy < NO || (ldx & 3) || (ldy & 3)) return (int)hipErrorInvalidValue;
+  return launch_linear_split(X, ldx, reinterpret_cast<const float*>(image), reinterpret_cast<const u32x4*>(image), bias,
+                             res, tprev, Y, ldy, R, K, NO, 1, flags, stream);
 }
 
 extern "C" int geossl_linear(const float* X, int ldx, const float* W, const float* bias, const float* res,
@@ -287,28 +393,8 @@ extern "C" int geossl_linear(const float* X, int ldx, const float* W, const floa
   if (R <= 0) return 0;
   if (K % 8 != 0 || K > 256 || NO > 256) return (int)hipErrorInvalidValue;
   if (ldx < K || ldy < NO || (ldx & 3) || (ldy & 3) || (NO & 3)) return (int)hipErrorInvalidValue;
-  if (K == 32 || K == 64 || K == 128) {
-    const int KS = K / 16;
-    int nmb = (NO + 31) / 32;                 // 32-column blocks of the output
-    const int cap = 108 / (3 * KS);            // weight fragments of one block <= 108 KB of LDS (stages: 36 KB)
-    int ny = 1;
-    while ((nmb + ny - 1) / ny > cap) ++ny;
-    nmb = (nmb + ny - 1) / ny;
-    const int nrb = (int)((R + 31) / 32);
-    int nx = (nrb + 3) / 4;  // whole row blocks go to four waves per block (one per SIMD)
-    if (nx > 256) nx = 256;
-    const size_t lds = (size_t)nmb * KS * 3 * 1024 + (size_t)(nmb * 32 + 8 * 32 * LSS) * sizeof(float);
-#define LAUNCH_S(KSV)                                                                                             \
-  do {                                                                                                            \
-    allow_big_lds(&k_linear_split<KSV>);                                                                          \
-    hipLaunchKernelGGL((k_linear_split<KSV>), dim3(nx, ny), dim3(512), lds, stream, X, W, bias, res, tprev, Y,    \
-                       (int)R, NO, nmb, ldx, ldy, transB, flags);                                                 \
-  } while (0)
-    if (KS == 8) LAUNCH_S(8); else if (KS == 4) LAUNCH_S(4); else LAUNCH_S(2);
-#undef LAUNCH_S
-    GEOSSL_CHECK_LAUNCH();
-    return 0;
-  }
+  if (K == 32 || K == 64 || K == 128)
+    return launch_linear_split(X, ldx, W, nullptr, bias, res, tprev, Y, ldy, R, K, NO, transB, flags, stream);
   const int ntiles = (int)((R + 127) / 128);
   const int NOp = (NO + 31) / 32 * 32;
   // split the output columns over gridDim.y when there are too few row tiles to fill 256 CUs

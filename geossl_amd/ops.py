@@ -73,11 +73,44 @@ def gaussian_smearing(dist, offset, coeff):
     return out
 
 
+class PreparedWeight:
+    """MFMA operand image of a Linear weight (geossl_linear_prepare): `image` is an int32 tensor; K / NO are the
+    contraction and output widths of the product it was built for."""
+    __slots__ = ("image", "K", "NO")
+
+    def __init__(self, image, K, NO):
+        self.image, self.K, self.NO = image, K, NO
+
+
+def prepare_linear(weights, transB=True):
+    """Convert Linear weights (all the same shape) to their operand images in one launch per GEOSSL_TN_MAX weights.
+    transB as in `linear`.  Returns a list of PreparedWeight, or None when the shape has no prepared path."""
+    w0 = weights[0]
+    NO, K = (w0.size(0), w0.size(1)) if transB else (w0.size(1), w0.size(0))
+    words = int(_lib.load().geossl_linear_image_words(K, NO))
+    if words == 0:
+        return None
+    out = []
+    for lo in range(0, len(weights), _lib.TN_MAX):
+        chunk = weights[lo:lo + _lib.TN_MAX]
+        images = torch.empty(len(chunk), words, dtype=torch.int32, device=w0.device)
+        pb = _lib.PrepareBatch()
+        for i, w in enumerate(chunk):
+            assert w.shape == w0.shape and w.is_contiguous()
+            pb.W[i], pb.image[i] = ptr(w), ptr(images[i])
+        call("geossl_linear_prepare", C.byref(pb), len(chunk), K, NO, 1 if transB else 0, stream())
+        out += [PreparedWeight(images[i], K, NO) for i in range(len(chunk))]
+    return out
+
+
 def linear(x, w, bias=None, res=None, tprev=None, transB=True, flags=0, out=None, K=None, NO=None):
     """Y = epi(X @ Bm); transB: w is torch layout [NO][K] (forward) else [K][NO] (dX = dY @ W).
     x / out may be column slices of wider row-major tensors (row stride = x.stride(0) / out.stride(0));
-    K / NO default to the slice widths."""
+    K / NO default to the slice widths.  `w` may be a PreparedWeight (transB is then fixed by its image)."""
     R = x.size(0)
+    prepared = isinstance(w, PreparedWeight)
+    if prepared:
+        K, NO = w.K, w.NO
     K = x.size(1) if K is None else K
     NO = (w.size(0) if transB else w.size(1)) if NO is None else NO
     if out is None:
@@ -91,8 +124,12 @@ def linear(x, w, bias=None, res=None, tprev=None, transB=True, flags=0, out=None
     assert x.stride(1) == 1 and out.stride(1) == 1
     for aux in (res, tprev):
         assert aux is None or (aux.stride(0) == out.stride(0) and aux.stride(1) == 1)
-    call("geossl_linear", ptr(x), x.stride(0), ptr(w), ptr(bias), ptr(res), ptr(tprev), ptr(out), out.stride(0), R, K, NO,
-         1 if transB else 0, flags, stream())
+    if prepared:
+        call("geossl_linear_prepared", ptr(x), x.stride(0), ptr(w.image), ptr(bias), ptr(res), ptr(tprev), ptr(out),
+             out.stride(0), R, K, NO, flags, stream())
+    else:
+        call("geossl_linear", ptr(x), x.stride(0), ptr(w), ptr(bias), ptr(res), ptr(tprev), ptr(out), out.stride(0), R,
+             K, NO, 1 if transB else 0, flags, stream())
     return out
 
 

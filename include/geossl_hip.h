@@ -120,6 +120,22 @@ int geossl_cfconv_aggregate(const float* x, const float* Wf, const uint8_t* pair
 int geossl_linear(const float* X, int ldx, const float* W, const float* bias, const float* res, const float* tprev,
                   float* Y, int ldy, int64_t R, int K, int NO, int transB, int flags, hipStream_t stream);
 
+/* Prepared weights.  geossl_linear re-shapes W into its MFMA operand image (bf16 pieces in fragment order) in every
+ * block of every launch; a weight that is used by several launches between two optimiser steps (forward, backward,
+ * both views) can be converted once instead: geossl_linear_prepare builds the images of up to GEOSSL_TN_MAX
+ * weights of one shape in a single launch, geossl_linear_prepared is geossl_linear reading such an image
+ * (same arithmetic, bit-identical results).  geossl_linear_image_words: size of one image in 32-bit words, 0 if the
+ * shape has no prepared path (K not in {32, 64, 128}).                                                       */
+typedef struct {
+  const float* W[GEOSSL_TN_MAX];
+  uint32_t* image[GEOSSL_TN_MAX];
+} GeosslPrepareBatch;
+int64_t geossl_linear_image_words(int K, int NO);
+int geossl_linear_prepare(const GeosslPrepareBatch* batch, int nprob, int K, int NO, int transB, hipStream_t stream);
+int geossl_linear_prepared(const float* X, int ldx, const uint32_t* image, const float* bias, const float* res,
+                           const float* tprev, float* Y, int ldy, int64_t R, int K, int NO, int flags,
+                           hipStream_t stream);
+
 /* batched weight gradients: dW_z[m][n] (+)= sum_r A_z[r][m]*B_z[r][n], db_z[m] (+)= sum_r A_z[r][m];
  * lda / ldb / ldw: row strides of A_z, B_z, dW_z (M, N <= 128 per problem: wider layers are tiled by the caller)  */
 typedef struct {

@@ -121,6 +121,25 @@ def test_linear_and_ssp_epilogues_vs_torch():
         assert rel_err(db.cpu(), dy.double().sum(0).cpu()) < 1e-6
 
 
+def test_prepared_linear_is_bit_identical():
+    """geossl_linear_prepare + geossl_linear_prepared = geossl_linear (same arithmetic on a precomputed image)."""
+    from geossl_amd import ops, _lib
+    gen = torch.Generator().manual_seed(3)
+    for K, NO, R in ((128, 128, 1000), (128, 64, 77), (64, 128, 333), (32, 32, 40)):
+        x = torch.randn(R, K, generator=gen).to(DEV)
+        ws = [(torch.randn(NO, K, generator=gen) / K ** 0.5).to(DEV) for _ in range(3)]
+        b = torch.randn(NO, generator=gen).to(DEV)
+        res = torch.randn(R, NO, generator=gen).to(DEV)
+        for transB in (True, False):
+            wl = ws if transB else [w.t().contiguous() for w in ws]
+            pw = ops.prepare_linear(wl, transB=transB)
+            assert pw is not None
+            for w, p in zip(wl, pw):
+                a = ops.linear(x, w, bias=b, res=res, transB=transB, flags=_lib.EPI_SSP)
+                c = ops.linear(x, p, bias=b, res=res, flags=_lib.EPI_SSP)
+                assert torch.equal(a, c)
+
+
 def test_mfma_tile_layout_asymmetric():
     """A = I against an asymmetric B catches a transposed C-write (cdna guide: always test this)."""
     from geossl_amd import ops
