@@ -26,13 +26,6 @@ inline void allow_big_lds(K kernel) {
 }
 
 // k-major copy of layers.1.weight: W2T[k][m] = o2_w[m][k], padded to HP columns
-__global__ void k_transpose_pad(const float* __restrict__ W, int rows, int cols, int HP, float* __restrict__ out) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cols * HP; i += gridDim.x * blockDim.x) {
-    const int k = i / HP, m = i - k * HP;
-    out[i] = m < rows ? W[(size_t)m * cols + k] : 0.0f;
-  }
-}
-
 // A wave gathers h[u] + h[v] for NROWS rows (endpoints held by lanes 0..NROWS-1), eight rows at a time with all
 // sixteen row loads of a group in flight together.
 template <int F, int NROWS, class Store>
@@ -64,135 +57,6 @@ __device__ __forceinline__ void gather_endpoint_sum_rows(const float* __restrict
   }
 }
 
-template <int NC>
-__global__ __launch_bounds__(256) void k_ncsn_fwd(const float* __restrict__ h, const int64_t* __restrict__ batch,
-                                                  const int64_t* __restrict__ sei0, const int64_t* __restrict__ sei1,
-                                                  int S, const float* __restrict__ distance,
-                                                  const int64_t* __restrict__ noise_level,
-                                                  const float* __restrict__ dist_noise, GeosslNcsnWeights w,
-                                                  const float* __restrict__ W2T, float anneal_power,
-                                                  float* __restrict__ loss_e, GeosslNcsnSaved sv) {
-  constexpr int F = 32 * NC, H = F / 2, NC2 = (H + 31) / 32, HP = 32 * NC2;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* W1s = smem;             // [F][F]: W1s[k][n] = o1_w[n][k]
-  float* At = W1s + F * F;       // 4 x [32][F]
-  float* b1s = At + 4 * 32 * F;  // [F]
-  float* wls = b1s + F;          // [F]  last column of o1_w (multiplies the distance embedding)
-  float* b2s = wls + F;          // [HP]
-  float* w3s = b2s + HP;         // [HP]
-  float* iw1 = w3s + HP;         // [F]
-  float* ib1 = iw1 + F;          // [F]
-  float* iw2 = ib1 + F;          // [F]
-  float* stage = iw2 + F + (threadIdx.x >> 6) * 512;  // wave-private 16x32 transposition stage for wide stores
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
-  load_weight_T(w.o1_w, F, F, F + 1, W1s, F, F, F, tid, 256);
-  for (int i = tid; i < F; i += 256) {
-    b1s[i] = w.o1_b[i];
-    wls[i] = w.o1_w[(size_t)i * (F + 1) + F];
-    iw1[i] = w.in_w1[i];
-    ib1[i] = w.in_b1[i];
-    iw2[i] = w.in_w2[i];
-  }
-  for (int i = tid; i < HP; i += 256) {
-    b2s[i] = i < H ? w.o2_b[i] : 0.0f;
-    w3s[i] = i < H ? w.o3_w[i] : 0.0f;
-  }
-  __syncthreads();
-  const float ib2 = w.in_b2[0], b3 = w.o3_b[0];
-  float* Aw = At + wave * 32 * F;
-  const int ntiles = (S + 127) / 128;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int r0 = t * 128 + wave * 32;
-    const int row = r0 + j;
-    const bool valid = row < S;
-    const int64_t u = valid ? sei0[row] : 0, v = valid ? sei1[row] : 0;
-    float sigma = 1.0f, d = 0.0f, eps = 0.0f;
-    if (valid) {
-      sigma = w.sigmas[noise_level[batch[u]]];  // NCSN.py:187,191-192
-      d = distance[row];
-      eps = dist_noise[row];
-    }
-    const float pd = __fadd_rn(d, __fmul_rn(eps, sigma));  // :196
-    // distance embedding (:197): MLP 1 -> F -> 1 with relu; each half-wave sums half of the hidden units
-    float e = 0.0f;
-    for (int k = kh * (F / 2); k < (kh + 1) * (F / 2); ++k) e = fmaf(iw2[k], fmaxf(fmaf(iw1[k], pd, ib1[k]), 0.0f), e);
-    e += __shfl_xor(e, 32, 64);
-    const float emb = e + ib2;
-    // gather h[u] + h[v] (:201-203) into the A tile
-    gather_endpoint_sum_rows<F, 32>(h, u, v, lane, [&](int rr, int n, float val) { Aw[a_idx(rr, n, F)] = val; });
-    __syncthreads();
-    f32x16 acc[NC];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float er = __shfl(emb, c_row(r, lane), 64);
-#pragma unroll
-      for (int c = 0; c < NC; ++c) acc[c][r] = fmaf(er, wls[32 * c + j], b1s[32 * c + j]);
-    }
-    mma_tile<NC>(acc, Aw, F, W1s, F, F / 2, lane);
-    __syncthreads();  // every lane of the wave is done reading the feature tile
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float a1 = fmaxf(acc[c][r], 0.0f);
-        acc[c][r] = a1;
-        Aw[a_idx(c_row(r, lane), 32 * c + j, F)] = a1;
-      }
-      if (sv.a1 != nullptr)
-        store_c_block_x4(sv.a1 + (size_t)r0 * F + 32 * c, F, S - r0, stage, lane, [&](int r) { return acc[c][r]; });
-    }
-    __syncthreads();
-    f32x16 acc2[NC2];
-#pragma unroll
-    for (int c = 0; c < NC2; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[c][r] = b2s[32 * c + j];
-    mma_tile_gb<NC2>(acc2, Aw, F, W2T, HP, F / 2, lane);
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < NC2; ++c) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int col = 32 * c + j;
-        const float a2 = col < H ? fmaxf(acc2[c][r], 0.0f) : 0.0f;
-        acc2[c][r] = a2;
-        Aw[a_idx(c_row(r, lane), col, F)] = a2;
-      }
-      if (sv.a2 != nullptr) {
-        if (H % 32 == 0) {
-          store_c_block_x4(sv.a2 + (size_t)r0 * H + 32 * c, H, S - r0, stage, lane, [&](int r) { return acc2[c][r]; });
-        } else {  // H = 16 (F = 32): narrow path
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rr = c_row(r, lane), col = 32 * c + j;
-            if (col < H && r0 + rr < S) sv.a2[(size_t)(r0 + rr) * H + col] = acc2[c][r];
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // last layer (F/2 -> 1): row j, each half-wave sums half of the columns
-    float sc = 0.0f;
-    for (int k = kh * (HP / 2); k < (kh + 1) * (HP / 2); ++k) sc = fmaf(Aw[a_idx(j, k, F)], w3s[k], sc);
-    sc += __shfl_xor(sc, 32, 64);
-    const float out = sc + b3;
-    const float inv_sigma = 1.0f / sigma;
-    const float score = out * inv_sigma;                                          // :205
-    const float target = (-1.0f / (sigma * sigma)) * __fsub_rn(pd, d);            // :199
-    const float diff = score - target;
-    const float pw = powf(sigma, anneal_power);
-    if (valid && kh == 0) {
-      loss_e[row] = (0.5f * (diff * diff)) * pw;  // :209
-      if (sv.pd != nullptr) {
-        sv.pd[row] = pd;
-        sv.emb[row] = emb;
-        sv.gscale[row] = diff * pw * inv_sigma;  // d loss_e / d out
-      }
-    }
-    __syncthreads();
-  }
-}
-
 // fixed-order two-stage sum
 __global__ __launch_bounds__(256) void k_sum_partial(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
   __shared__ float red[256];
@@ -219,85 +83,6 @@ __global__ void k_loss_final(const float* __restrict__ partial, int nblk, const 
 #define GEOSSL_LOSS_BLOCKS 256
 
 // ---------------------------------------------------------------------------------------------- backward
-template <int NC>
-__global__ __launch_bounds__(256) void k_ncsn_bwd_rows(GeosslNcsnWeights w, GeosslNcsnSaved sv, int S,
-                                                       const int64_t* __restrict__ divisor, float out_scale,
-                                                       const float* __restrict__ gout, float* __restrict__ dz1,
-                                                       float* __restrict__ dfeat, float* __restrict__ demb,
-                                                       float* __restrict__ grow) {
-  constexpr int F = 32 * NC, H = F / 2, NC2 = (H + 31) / 32, HP = 32 * NC2;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* At = smem;              // 4 x [32][F]; both weight matrices are read from global memory (L2 resident),
-                                 // which keeps the block at 66 KB of LDS: two blocks per CU
-  float* wls = At + 4 * 32 * F;  // [F]
-  float* w3s = wls + F;          // [HP]
-  float* stage = w3s + HP + (threadIdx.x >> 6) * 512;  // wave-private 16x32 transposition stage for wide stores
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
-  for (int i = tid; i < F; i += 256) wls[i] = w.o1_w[(size_t)i * (F + 1) + F];
-  for (int i = tid; i < HP; i += 256) w3s[i] = i < H ? w.o3_w[i] : 0.0f;
-  __syncthreads();
-  const float scale = out_scale * (gout != nullptr ? gout[0] : 1.0f) / (float)divisor[0];
-  float* Aw = At + wave * 32 * F;
-  const int ntiles = (S + 127) / 128;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int r0 = t * 128 + wave * 32;
-    const int row = r0 + j;
-    const float gr = row < S ? sv.gscale[row] * scale : 0.0f;  // d L / d out_row
-    if (row < S && kh == 0) grow[row] = gr;
-    // da2[row][m] = gr * w3[m] * [a2 > 0]; lane = column m, the 32 row loads are issued together
-    for (int m = lane; m < HP; m += 64) {
-      float a2v[32];
-#pragma unroll
-      for (int rr = 0; rr < 32; ++rr) {
-        const int rw = min(r0 + rr, S - 1);
-        a2v[rr] = m < H ? sv.a2[(size_t)rw * H + m] : 0.0f;
-      }
-      const float w3m = w3s[m];
-#pragma unroll
-      for (int rr = 0; rr < 32; ++rr) {
-        const float g = __shfl(gr, rr, 64);
-        Aw[a_idx(rr, m, F)] = (r0 + rr < S && a2v[rr] > 0.0f) ? g * w3m : 0.0f;
-      }
-    }
-    __syncthreads();
-    f32x16 acc[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
-    // dz1 = (da2 @ o2_w) * [a1 > 0];  B[m][k] = o2_w[m][k] read straight from global (lanes = consecutive k)
-    mma_tile_gb<NC>(acc, Aw, F, w.o2_w, F, H / 2, lane);
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = c_row(r, lane), rw = r0 + rr, col = 32 * c + j;
-        float v = 0.0f;
-        if (rw < S) v = sv.a1[(size_t)rw * F + col] > 0.0f ? acc[c][r] : 0.0f;
-        acc[c][r] = v;
-        Aw[a_idx(rr, col, F)] = v;
-      }
-      store_c_block_x4(dz1 + (size_t)r0 * F + 32 * c, F, S - r0, stage, lane, [&](int r) { return acc[c][r]; });
-    }
-    __syncthreads();
-    // demb[row] = sum_n dz1[row][n] * o1_w[n][F]
-    float de = 0.0f;
-    for (int k = kh * (F / 2); k < (kh + 1) * (F / 2); ++k) de = fmaf(Aw[a_idx(j, k, F)], wls[k], de);
-    de += __shfl_xor(de, 32, 64);
-    if (row < S && kh == 0) demb[row] = de;
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
-    mma_tile_gb<NC>(acc, Aw, F, w.o1_w, F + 1, F / 2, lane);  // dfeat = dz1 @ o1_w[:, :F]
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-      store_c_block_x4(dfeat + (size_t)r0 * F + 32 * c, F, S - r0, stage, lane, [&](int r) { return acc[c][r]; });
-    __syncthreads();
-  }
-}
-
 struct NcsnW2Loader {  // A = da2 (rebuilt from grow, w3, a2 mask) [S][H], B = a1 [S][F]
   const float* grow;
   const float* w3;
@@ -474,37 +259,6 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
 
 }  // namespace
 
-extern "C" int64_t geossl_ddm_loss_fwd_workspace_floats(int F) {
-  const int H = F / 2, HP = (H + 31) / 32 * 32;
-  return (int64_t)F * HP;
-}
-
-extern "C" int geossl_ddm_loss_fwd(const float* h, const int64_t* batch, const int64_t* sei0, const int64_t* sei1,
-                                   int64_t S, const float* distance, const int64_t* noise_level,
-                                   const float* distance_noise, const GeosslNcsnWeights* w, int F, float anneal_power,
-                                   float* loss_e, const GeosslNcsnSaved* saved, float* workspace, hipStream_t stream) {
-  if (S <= 0) return 0;
-  if (F != 32 && F != 64 && F != 128) return (int)hipErrorInvalidValue;
-  const int H = F / 2, HP = (H + 31) / 32 * 32;
-  hipLaunchKernelGGL(k_transpose_pad, dim3(grid1d(F * HP, 256)), dim3(256), 0, stream, w->o2_w, H, F, HP, workspace);
-  GEOSSL_CHECK_LAUNCH();
-  GeosslNcsnSaved sv = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  if (saved != nullptr) sv = *saved;
-  const int ntiles = (int)((S + 127) / 128);
-  const size_t lds = ((size_t)F * F + 4 * 32 * F + 5 * F + 2 * HP + 4 * 512) * sizeof(float);
-  dim3 grid(ntiles < 256 ? ntiles : 256);
-#define LAUNCH(NCV)                                                                                              \
-  do {                                                                                                           \
-    allow_big_lds(&k_ncsn_fwd<NCV>);                                                                             \
-    hipLaunchKernelGGL((k_ncsn_fwd<NCV>), grid, dim3(256), lds, stream, h, batch, sei0, sei1, (int)S, distance,  \
-                       noise_level, distance_noise, *w, workspace, anneal_power, loss_e, sv);                    \
-  } while (0)
-  if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
-#undef LAUNCH
-  GEOSSL_CHECK_LAUNCH();
-  return 0;
-}
-
 extern "C" int64_t geossl_loss_reduce_workspace_floats(int64_t S) { return GEOSSL_LOSS_BLOCKS; }
 
 extern "C" int geossl_loss_reduce(const float* loss_e, int64_t S, const int64_t* stats_divisor, float out_scale,
@@ -513,27 +267,6 @@ extern "C" int geossl_loss_reduce(const float* loss_e, int64_t S, const int64_t*
   GEOSSL_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, stream, workspace, GEOSSL_LOSS_BLOCKS, stats_divisor, out_scale,
                      loss, accumulate);
-  GEOSSL_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int geossl_ddm_loss_bwd_rows(const GeosslNcsnWeights* w, const GeosslNcsnSaved* saved, int64_t S, int F,
-                                        const int64_t* stats_divisor, float out_scale, const float* gout, float* dz1,
-                                        float* dfeat, float* demb, float* grow, hipStream_t stream) {
-  if (S <= 0) return 0;
-  if (F != 32 && F != 64 && F != 128) return (int)hipErrorInvalidValue;
-  const int H = F / 2, HP = (H + 31) / 32 * 32;
-  const int ntiles = (int)((S + 127) / 128);
-  const size_t lds = ((size_t)4 * 32 * F + F + HP + 4 * 512) * sizeof(float);
-  dim3 grid(ntiles < 256 ? ntiles : 256);
-#define LAUNCH(NCV)                                                                                               \
-  do {                                                                                                            \
-    allow_big_lds(&k_ncsn_bwd_rows<NCV>);                                                                         \
-    hipLaunchKernelGGL((k_ncsn_bwd_rows<NCV>), grid, dim3(256), lds, stream, *w, *saved, (int)S, stats_divisor,   \
-                       out_scale, gout, dz1, dfeat, demb, grow);                                                  \
-  } while (0)
-  if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
-#undef LAUNCH
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
