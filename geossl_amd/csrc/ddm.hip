@@ -9,6 +9,7 @@
 #include "common.h"
 #include "geossl_hip.h"
 #include "tn.h"
+#include "wgrad.h"
 
 using namespace geossl;
 
@@ -83,46 +84,94 @@ __global__ void k_loss_final(const float* __restrict__ partial, int nblk, const 
 #define GEOSSL_LOSS_BLOCKS 256
 
 // ---------------------------------------------------------------------------------------------- backward
-struct NcsnW2Loader {  // A = da2 (rebuilt from grow, w3, a2 mask) [S][H], B = a1 [S][F]
+// output_mlp.layers.1: dW[m][n] = sum_s da2[s][m] a1[s][n] with da2 = grow * w3 * [a2 > 0] rebuilt from the saved a2
+struct NcsnW2Ops {
   const float* grow;
   const float* w3;
   const float* a2;
   const float* a1;
   int F, H;
-  template <int MP, int NP>
-  __device__ __forceinline__ void load(int z, int row0, int row_end, int M, int N, float* As, float* Bs, float* es,
-                                       int tid) const {
-    for (int i = tid; i < 64 * MP; i += 256) {
-      const int r = i / MP, m = i - r * MP, row = row0 + r;
-      float v = 0.0f;
-      if (row < row_end && m < M && a2[(size_t)row * H + m] > 0.0f) v = grow[row] * w3[m];
-      As[i] = v;
-    }
-    load_rows_f4<NP>(a1, F, N, row0, row_end, Bs, tid);
+  static constexpr bool kDot = false;
+  struct RawA { float a[2][8]; float g[2][8]; float w; };
+  struct RawB { float v[2][8]; };
+  __device__ __forceinline__ void prime_a(int, int col, int, int, int, RawA& r) const { r.w = w3[col]; }
+  __device__ __forceinline__ void prime_b(int, int, int, int, int, RawB&) const {}
+  __device__ __forceinline__ void request_a(int, int col, int row0, int row_end, int kh, RawA& r) const {
+    request_col8(a2, H, col, row0, row_end, kh, r.a);
+    request_col8(grow, 1, 0, row0, row_end, kh, r.g);
+  }
+  __device__ __forceinline__ void request_b(int, int col, int row0, int row_end, int kh, RawB& r) const {
+    request_col8(a1, F, col, row0, row_end, kh, r.v);
+  }
+  __device__ __forceinline__ void finish_a(int, int, int row0, int row_end, int kh, RawA& r, float (&out)[2][8],
+                                           float (&)[2][8]) const {
+    float a[2][8], g[2][8];
+    finish_col8(row0, row_end, kh, r.a, a);  // rows past row_end -> a = 0 -> da2 = 0
+    finish_col8(row0, row_end, kh, r.g, g);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) out[ks][e] = a[ks][e] > 0.0f ? g[ks][e] * r.w : 0.0f;
+  }
+  __device__ __forceinline__ void finish_b(int, int, int row0, int row_end, int kh, RawB& r, float (&out)[2][8]) const {
+    finish_col8(row0, row_end, kh, r.v, out);
   }
 };
 
-struct NcsnW1Loader {  // A = dz1 [S][F], B = h[u]+h[v] (rebuilt), e = emb
+// output_mlp.layers.0: dW[n][k<F] = sum_s dz1[s][n] (h[u_s] + h[v_s])[k];  dW[n][F] = sum_s dz1[s][n] emb[s].
+// The gathered operand needs the endpoints of a row before its data can be requested: the endpoint indices run one
+// iteration ahead of the data requests (two ahead of the use).
+struct NcsnW1Ops {
   const float* dz1;
   const float* h;
   const int64_t* sei0;
   const int64_t* sei1;
   const float* emb;
   int F;
-  template <int MP, int NP>
-  __device__ __forceinline__ void load(int z, int row0, int row_end, int M, int N, float* As, float* Bs, float* es,
-                                       int tid) const {
-    load_rows_f4<MP>(dz1, F, M, row0, row_end, As, tid);
-    const int lane = tid & 63, wave = tid >> 6;
-    const int myrow = row0 + 16 * wave + (lane & 15);
-    const bool ok = myrow < row_end;
-    const int64_t u = ok ? sei0[myrow] : 0, v = ok ? sei1[myrow] : 0;
-    const float keep = ok ? 1.0f : 0.0f;
-    float* Bw = Bs + 16 * wave * NP;  // NP == F here
-    gather_endpoint_sum_rows<NP, 16>(h, u, v, lane, [&](int rr, int n, float val) {
-      Bw[rr * NP + n] = val * __shfl(keep, rr, 64);
-    });
-    if (tid < 64) es[tid] = (row0 + tid < row_end) ? emb[row0 + tid] : 0.0f;
+  static constexpr bool kDot = true;
+  struct RawA { float v[2][8]; float e[2][8]; };
+  struct RawB { float hu[2][8]; float hv[2][8]; int u[2][8]; int v[2][8]; };
+  __device__ __forceinline__ void load_idx(int row0, int row_end, int kh, RawB& r) const {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int row = min(row0 + 16 * ks + 8 * kh + e, row_end - 1);
+        r.u[ks][e] = (int)sei0[row];
+        r.v[ks][e] = (int)sei1[row];
+      }
+  }
+  __device__ __forceinline__ void prime_a(int, int, int, int, int, RawA&) const {}
+  __device__ __forceinline__ void prime_b(int, int, int row0, int row_end, int kh, RawB& r) const {
+    load_idx(row0, row_end, kh, r);
+  }
+  __device__ __forceinline__ void request_a(int, int col, int row0, int row_end, int kh, RawA& r) const {
+    request_col8(dz1, F, col, row0, row_end, kh, r.v);
+    request_col8(emb, 1, 0, row0, row_end, kh, r.e);
+  }
+  __device__ __forceinline__ void request_b(int, int col, int row0, int row_end, int kh, RawB& r) const {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        r.hu[ks][e] = h[(size_t)r.u[ks][e] * F + col];
+        r.hv[ks][e] = h[(size_t)r.v[ks][e] * F + col];
+      }
+    load_idx(min(row0 + 32, row_end - 1), row_end, kh, r);  // endpoints of the following request
+  }
+  __device__ __forceinline__ void finish_a(int, int, int row0, int row_end, int kh, RawA& r, float (&out)[2][8],
+                                           float (&e)[2][8]) const {
+    finish_col8(row0, row_end, kh, r.v, out);
+    finish_col8(row0, row_end, kh, r.e, e);
+  }
+  __device__ __forceinline__ void finish_b(int, int, int row0, int row_end, int kh, RawB& r, float (&out)[2][8]) const {
+    float a[2][8], b[2][8];
+    finish_col8(row0, row_end, kh, r.hu, a);
+    finish_col8(row0, row_end, kh, r.hv, b);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) out[ks][e] = a[ks][e] + b[ks][e];
   }
 };
 
@@ -292,20 +341,25 @@ extern "C" int geossl_ddm_loss_bwd_weights(const float* h, const int64_t* sei0, 
                                            float* workspace, int accumulate, hipStream_t stream) {
   if (S <= 0) return 0;
   const int H = F / 2;
-  TnOut o;
+  WgradOut o;
   for (int z = 0; z < GEOSSL_TN_MAX; ++z) o.dW[z] = o.db[z] = o.dd[z] = nullptr;
+  int rc;
   // output_mlp.layers.1: dW[m][k] = sum_s da2[s][m] a1[s][k]
   o.dW[0] = grads->o2_w;
   o.db[0] = grads->o2_b;
-  NcsnW2Loader l2{grow, w->o3_w, saved->a2, saved->a1, F, H};
-  int rc = launch_tn(l2, 1, S, H, F, o, F, 1, workspace, accumulate, stream);
+  NcsnW2Ops l2{grow, w->o3_w, saved->a2, saved->a1, F, H};
+  if (F == 128) rc = launch_wgrad_split<2, 4>(l2, 1, S, H, F, o, F, 1, workspace, accumulate, stream);
+  else if (F == 64) rc = launch_wgrad_split<1, 2>(l2, 1, S, H, F, o, F, 1, workspace, accumulate, stream);
+  else rc = launch_wgrad_split<1, 1>(l2, 1, S, H, F, o, F, 1, workspace, accumulate, stream);
   if (rc) return rc;
   // output_mlp.layers.0: dW[n][k<F] = sum_s dz1[s][n] (h[u]+h[v])[s][k];  dW[n][F] = sum_s dz1[s][n] emb[s]
   o.dW[0] = grads->o1_w;
   o.db[0] = grads->o1_b;
   o.dd[0] = grads->o1_w + F;
-  NcsnW1Loader l1{dz1, h, sei0, sei1, saved->emb, F};
-  rc = launch_tn(l1, 1, S, F, F, o, F + 1, F + 1, workspace, accumulate, stream);
+  NcsnW1Ops l1{dz1, h, sei0, sei1, saved->emb, F};
+  if (F == 128) rc = launch_wgrad_split<4, 4>(l1, 1, S, F, F, o, F + 1, F + 1, workspace, accumulate, stream);
+  else if (F == 64) rc = launch_wgrad_split<2, 2>(l1, 1, S, F, F, o, F + 1, F + 1, workspace, accumulate, stream);
+  else rc = launch_wgrad_split<1, 1>(l1, 1, S, F, F, o, F + 1, F + 1, workspace, accumulate, stream);
   if (rc) return rc;
   int chunk, nblk;
   small_plan(S, &chunk, &nblk);

@@ -6,6 +6,7 @@
 #include "geossl_hip.h"
 #include "split.h"
 #include "tn.h"
+#include "wgrad.h"
 
 using namespace geossl;
 
@@ -473,172 +474,7 @@ extern "C" int64_t geossl_tn_workspace_floats(int64_t R, int M, int N, int nprob
   return tn_workspace_floats(R, M, N, nprob);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Column GEMM (weight gradient) of plain row-major operands on the bf16 matrix pipe (split.h):
-//     dW_z[m][n] = sum_r A_z[r][m] B_z[r][n],   db_z[m] = sum_r A_z[r][m].
-// The contraction runs over rows, so both operands are wanted feature-major (lane = column, 8 rows per lane):
-// each lane loads its column of 8 rows with eight 4-byte loads (a half-wave reads 128 contiguous bytes of a row),
-// splits them in registers and publishes the fragments in LDS; every wave then multiplies all M blocks against its
-// N block(s).  32 rows per iteration, the loads of the next iteration fly during the MFMAs; one partial per row
-// chunk, summed in chunk order by k_reduce_partials (no atomics).
-template <int NCM, int NCN>
-__global__ __launch_bounds__(256, 2) void k_wgrad_split(GeosslTnBatch batch, int lda, int ldb, int R, int chunk, int M,
-                                                        int N, float* __restrict__ partial,
-                                                        float* __restrict__ partial_bias) {
-  constexpr int NI = NCM + NCN, IPW = (NI + 3) / 4, T = NCM * NCN, TPW = (T + 3) / 4;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
-  u32x4* Fr = reinterpret_cast<u32x4*>(smem_raw);  // [NI][2 k-steps][3][64]: A blocks first, then B blocks
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
-  const int z = blockIdx.y;
-  const float* __restrict__ A = batch.A[z];
-  const float* __restrict__ B = batch.B[z];
-  const int row_begin = blockIdx.x * chunk, row_end = min(R, row_begin + chunk);
-  f32x16 acc[TPW];
-#pragma unroll
-  for (int i = 0; i < TPW; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-  float bsum[IPW];
-#pragma unroll
-  for (int u = 0; u < IPW; ++u) bsum[u] = 0.0f;
-  // operand column blocks converted by this wave: item it = wave + 4u; it < NCM -> A block it, else B block it-NCM
-  float raw[IPW][2][8];
-  auto request = [&](int row0) {
-#pragma unroll
-    for (int u = 0; u < IPW; ++u) {
-      const int it = wave + 4 * u;
-      if (it >= NI) continue;
-      const bool isA = it < NCM;
-      const int col = 32 * (isA ? it : it - NCM) + j;
-      const bool cok = col < (isA ? M : N);
-      const float* src = (isA ? A : B) + (cok ? col : 0);
-      const int ld = isA ? lda : ldb;
-      // clamped addresses, all eight requests first, then pin + select (see common.h: pin)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          raw[u][ks][e] = src[(size_t)min(row0 + 16 * ks + 8 * kh + e, row_end - 1) * ld];
-    }
-  };
-  auto mask = [&](int row0) {  // zero the rows past the chunk / columns past the operand (after the data arrived)
-#pragma unroll
-    for (int u = 0; u < IPW; ++u) {
-      const int it = wave + 4 * u;
-      if (it >= NI) continue;
-      const bool isA = it < NCM;
-      const bool cok = 32 * (isA ? it : it - NCM) + j < (isA ? M : N);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float v = pin(raw[u][ks][e]);
-          raw[u][ks][e] = cok && row0 + 16 * ks + 8 * kh + e < row_end ? v : 0.0f;
-        }
-    }
-  };
-  if (row_begin < row_end) request(row_begin);
-  for (int row0 = row_begin; row0 < row_end; row0 += 32) {
-    mask(row0);
-#pragma unroll
-    for (int u = 0; u < IPW; ++u) {
-      const int it = wave + 4 * u;
-      if (it >= NI) continue;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        if (it < NCM) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bsum[u] += raw[u][ks][e];
-        }
-        const Frag3 f = split8(raw[u][ks]);
-        u32x4* dst = Fr + (size_t)((it * 2 + ks) * 3) * 64 + lane;
-        dst[0] = f.h;
-        dst[64] = f.m;
-        dst[128] = f.l;
-      }
-    }
-    __syncthreads();
-    if (row0 + 32 < row_end) request(row0 + 32);  // in flight during the MFMAs
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      Frag3 af[TPW], bf[TPW];
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) {
-        const int t = wave + 4 * i;
-        if (t >= T) continue;
-        const u32x4* sa = Fr + (size_t)(((t / NCN) * 2 + ks) * 3) * 64 + lane;
-        const u32x4* sb = Fr + (size_t)(((NCM + t % NCN) * 2 + ks) * 3) * 64 + lane;
-        af[i].h = sa[0]; af[i].m = sa[64]; af[i].l = sa[128];
-        bf[i].h = sb[0]; bf[i].m = sb[64]; bf[i].l = sb[128];
-      }
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) if (wave + 4 * i < T) acc[i] = mfma_bf16(af[i].l, bf[i].h, acc[i]);
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) if (wave + 4 * i < T) acc[i] = mfma_bf16(af[i].h, bf[i].l, acc[i]);
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) if (wave + 4 * i < T) acc[i] = mfma_bf16(af[i].m, bf[i].m, acc[i]);
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) if (wave + 4 * i < T) acc[i] = mfma_bf16(af[i].m, bf[i].h, acc[i]);
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) if (wave + 4 * i < T) acc[i] = mfma_bf16(af[i].h, bf[i].m, acc[i]);
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) if (wave + 4 * i < T) acc[i] = mfma_bf16(af[i].h, bf[i].h, acc[i]);
-    }
-    __syncthreads();
-  }
-  const size_t pb = (size_t)z * gridDim.x + blockIdx.x;
-  float* Pp = partial + pb * M * N;
-#pragma unroll
-  for (int i = 0; i < TPW; ++i) {
-    const int t = wave + 4 * i;
-    if (t >= T) continue;
-    const int mb = t / NCN, nb = t % NCN, n = 32 * nb + j;
-    if (n >= N) continue;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = 32 * mb + c_row(r, lane);
-      if (m < M) Pp[(size_t)m * N + n] = acc[i][r];
-    }
-  }
-  if (partial_bias != nullptr) {
-#pragma unroll
-    for (int u = 0; u < IPW; ++u) {
-      const int it = wave + 4 * u;
-      if (it >= NCM) continue;
-      const float sb = bsum[u] + __shfl_xor(bsum[u], 32, 64);
-      if (kh == 0 && 32 * it + j < M) partial_bias[pb * M + 32 * it + j] = sb;
-    }
-  }
-}
-
-template <int NCM, int NCN>
-static int launch_wgrad_split(const GeosslTnBatch* batch, int nprob, int64_t R, int M, int N, int lda, int ldb, int ldw,
-                              float* workspace, int accumulate, hipStream_t stream) {
-  int chunk, nblk;
-  geossl_tn_plan(R, nprob, &chunk, &nblk);
-  float* partial = workspace;
-  float* pbias = partial + (size_t)nprob * nblk * M * N;
-  bool any_b = false;
-  for (int z = 0; z < nprob; ++z) any_b |= batch->db[z] != nullptr;
-  const size_t lds = (size_t)(NCM + NCN) * 2 * 3 * 1024;
-  allow_big_lds(&k_wgrad_split<NCM, NCN>);
-  hipLaunchKernelGGL((k_wgrad_split<NCM, NCN>), dim3(nblk, nprob), dim3(256), lds, stream, *batch, lda, ldb, (int)R,
-                     chunk, M, N, partial, any_b ? pbias : nullptr);
-  GEOSSL_CHECK_LAUNCH();
-  GeosslReduceBatch rb;
-  for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = z < nprob ? batch->dW[z] : nullptr;
-  const int len = M * N;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((len + 63) / 64, nprob), dim3(256), 0, stream, rb, partial, nblk, len, N,
-                     ldw, 1, accumulate);
-  if (any_b) {
-    for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = z < nprob ? batch->db[z] : nullptr;
-    hipLaunchKernelGGL(k_reduce_partials, dim3((M + 63) / 64, nprob), dim3(256), 0, stream, rb, pbias, nblk, M, M, M,
-                       1, accumulate);
-  }
-  GEOSSL_CHECK_LAUNCH();
-  return 0;
-}
-
+// Column GEMM (weight gradient) of plain row-major operands: k_wgrad_split<., ., PlainOps> (wgrad.h).
 extern "C" int geossl_linear_wgrad(const GeosslTnBatch* batch, int nprob, int64_t R, int M, int N, int lda, int ldb,
                                    int ldw, float* workspace, int accumulate, hipStream_t stream) {
   if (lda < M || ldb < N || ldw < N || (lda & 3) || (ldb & 3) || (M & 3) || (N & 3)) return (int)hipErrorInvalidValue;
@@ -646,7 +482,17 @@ extern "C" int geossl_linear_wgrad(const GeosslTnBatch* batch, int nprob, int64_
   if (nprob > GEOSSL_TN_MAX) return (int)hipErrorInvalidValue;
   {
     const int NCM = (M + 31) / 32, NCN = (N + 31) / 32;
-#define WG(a, b) if (NCM == a && NCN == b) return launch_wgrad_split<a, b>(batch, nprob, R, M, N, lda, ldb, ldw, workspace, accumulate, stream)
+    PlainOps ops;
+    ops.batch = *batch;
+    ops.lda = lda;
+    ops.ldb = ldb;
+    WgradOut out;
+    for (int z = 0; z < GEOSSL_TN_MAX; ++z) {
+      out.dW[z] = batch->dW[z];
+      out.db[z] = batch->db[z];
+      out.dd[z] = nullptr;
+    }
+#define WG(a, b) if (NCM == a && NCN == b) return launch_wgrad_split<a, b>(ops, nprob, R, M, N, out, ldw, 1, workspace, accumulate, stream)
     WG(4, 4); WG(4, 2); WG(2, 4); WG(2, 2); WG(1, 1); WG(1, 2); WG(2, 1); WG(4, 1); WG(1, 4);
 #undef WG
   }
