@@ -120,33 +120,31 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
   constexpr int NTB = 64 * NW;                              // staging threads (role B)
   constexpr int NPRE = (ATOM_CAP * Q + NTB - 1) / NTB;      // float4 per staging thread and array
   const int stid = tid - NTB;                               // role B: 0 .. NTB-1
-  float4 px[roleA ? 1 : NPRE], pdg[roleA ? 1 : NPRE];
+  f32x4 px[roleA ? 1 : NPRE], pdg[roleA ? 1 : NPRE];
   int ai = 0, aj = 0, alo = 0, alo_next = 0;
-  float m0 = 0.0f, m1 = 0.0f, dd = 0.0f;
+  float cval = 0.0f, dd = 0.0f;
+  unsigned fl_raw = 0u;
   float tc[16];
   auto request = [&](int tt, int alo_t) {  // everything tile tt needs from global memory
     const int rr0 = tt * TR;
     if constexpr (!roleA) {
+      // clamped addresses, no predication (a predicated load compiles to a branch with a full wait per element);
+      // slots past the window are never read back
       const int nwin = min(ATOM_CAP, N - alo_t);
-      const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)alo_t * F);
-      const float4* d4 = reinterpret_cast<const float4*>(dagg + (size_t)alo_t * F);
+      const f32x4* x4 = reinterpret_cast<const f32x4*>(x + (size_t)alo_t * F);
+      const f32x4* d4 = reinterpret_cast<const f32x4*>(dagg + (size_t)alo_t * F);
 #pragma unroll
       for (int u = 0; u < NPRE; ++u) {
-        const int i = stid + NTB * u;
-        const bool ok = i < nwin * Q;
-        px[u] = ok ? x4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        pdg[u] = ok ? d4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const int i = min(stid + NTB * u, nwin * Q - 1);
+        px[u] = x4[i];
+        pdg[u] = d4[i];
       }
       if (stid < TR) {  // one pair row per lane of the first role-B wave
-        const int row = rr0 + stid;
-        const bool ok = row < P;
-        const int q = ok ? row : P - 1;
+        const int q = min(rr0 + stid, P - 1);  // raw values only: nothing here waits for the loads
         ai = pair_i[q];
         aj = pair_j[q];
-        const unsigned fl = ok ? pair_flag[q] : 0u;
-        const float c = pair_c[q];
-        m0 = (fl & 1u) ? c : 0.0f;
-        m1 = (fl & 2u) ? c : 0.0f;
+        fl_raw = pair_flag[q];
+        cval = pair_c[q];
         dd = pair_d[q];
       }
     }
@@ -176,6 +174,8 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
         for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o, 64));
         const bool staged0 = amax - alo <= ATOM_CAP;
         if (lane < TR) {
+          const unsigned fl = r0 + lane < P ? fl_raw : 0u;  // rows past P contribute nothing
+          const float m0 = (fl & 1u) ? cval : 0.0f, m1 = (fl & 2u) ? cval : 0.0f;
           L.tdd[lane] = dd;
           L.desc[lane] = staged0 ? make_int4((ai - alo) * AS, (aj - alo) * AS, __float_as_int(m0), __float_as_int(m1))
                                  : make_int4(ai, aj, __float_as_int(m0), __float_as_int(m1));
@@ -187,8 +187,8 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
         const int i = stid + NTB * u;
         if (i < nwin * Q) {
           const int a = i / Q, q4 = i - a * Q;
-          *reinterpret_cast<float4*>(L.xs + a * AS + 4 * q4) = px[u];
-          *reinterpret_cast<float4*>(L.ds + a * AS + 4 * q4) = pdg[u];
+          *reinterpret_cast<f32x4*>(L.xs + a * AS + 4 * q4) = px[u];
+          *reinterpret_cast<f32x4*>(L.ds + a * AS + 4 * q4) = pdg[u];
         }
       }
     }
