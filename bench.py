@@ -24,7 +24,11 @@ sys.path.insert(0, REPO)
 
 F, L, G, CUTOFF, K_LEVELS = 128, 6, 51, 5.0, 50
 HBM_PEAK = 8.0e12       # B/s, spec (MI355X_MICROARCH.md)
-FP32_PEAK = 157.3e12    # FLOP/s, vector == f32-MFMA rate
+FP32_PEAK = 157.3e12    # FLOP/s, vector == f32-MFMA rate (they share the FP32 lanes on gfx950)
+BF16_PEAK = 2.5e15      # FLOP/s, dense bf16 MFMA (MI355X_MICROARCH.md)
+# The dense kernels evaluate every fp32 product as six bf16 MFMAs over an exact 3-way bf16 split of both operands
+# (csrc/split.h): the matrix-pipe ceiling in fp32-equivalent flops is BF16_PEAK / 6.
+SPLIT_PRODUCTS = 6
 # entry points whose launches are bracketed with HIP events inside the timed region
 TIMED = ("geossl_cfconv_filter_fwd", "geossl_cfconv_filter_bwd",
          "geossl_ddm_loss_fwd", "geossl_ddm_loss_bwd_rows", "geossl_ddm_loss_bwd_weights", "geossl_linear_wgrad")
@@ -33,7 +37,7 @@ TIMED = ("geossl_cfconv_filter_fwd", "geossl_cfconv_filter_bwd",
 # entry point -> prefix of the device kernels it launches (for the PMC traffic lookup)
 ENTRY_KERNELS = {"geossl_cfconv_filter_fwd": "k_filter_fwd", "geossl_cfconv_filter_bwd": "k_filter_bwd",
                  "geossl_ddm_loss_fwd": "k_ncsn_fwd", "geossl_ddm_loss_bwd_rows": "k_ncsn_bwd_rows",
-                 "geossl_linear_wgrad": "geossl::k_tn<4, 4, geossl::PlainLoader"}
+                 "geossl_linear_wgrad": "geossl::k_wgrad_split<4, 4, geossl::PlainOps"}
 
 
 def alg_model(n_atoms, n_edges, n_super):
@@ -147,6 +151,8 @@ def main():
             from geossl_amd import ops as _ops
             bt.radius_edge_index = _ops.radius_graph(bt.positions, 5.0, bt.batch)
         batches.append(bt)
+        if i == 0:
+            sizes0 = list(b["sizes"])
     # build the per-batch index structures once (part of collation, not of the step)
     gen = torch.Generator(device=dev)
     gen.manual_seed(777 + rank)
@@ -237,11 +243,22 @@ def main():
                     traffic = sum(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for v in ks)
             except (OSError, KeyError, ValueError):
                 pass
-            # the dense pair-row / super-edge-row kernels run on the f32 MFMA pipe: price them against it
-            roof = {"kernel": dom, "bound": "mfma", "achieved": ach_f / 1e12, "peak": FP32_PEAK / 1e12,
-                    "unit": "TFLOP/s", "frac": ach_f / FP32_PEAK, "traffic": traffic,
+            # the dense kernels run on the bf16 matrix pipe, six MFMAs per fp32 product (csrc/split.h): `achieved`
+            # is SURVEY 8(d)'s algorithmic fp32 flops (reference formulation: one filter evaluation per DIRECTED edge)
+            # over the measured launch time, `peak` the pipe's fp32-equivalent ceiling.  `executed_*` prices what the
+            # kernel really issues: one evaluation per undirected pair slot, G padded to 64, times six bf16 MFMAs.
+            peak = BF16_PEAK / SPLIT_PRODUCTS
+            roof = {"kernel": dom, "bound": "mfma", "achieved": ach_f / 1e12, "peak": peak / 1e12,
+                    "unit": "TFLOP/s", "frac": ach_f / peak, "traffic": traffic,
                     "avg_launch_ms": kern[dom][0], "launches_per_step": kern[dom][1], "timing": timing_mode,
-                    "algorithmic_GBps": ach_b / 1e9, "hbm_frac": ach_b / HBM_PEAK}
+                    "algorithmic_GBps": ach_b / 1e9, "hbm_frac": ach_b / HBM_PEAK,
+                    "peak_note": "2.5 PFLOP/s dense bf16 MFMA / 6 MFMAs per fp32 product"}
+            if dom in ("geossl_cfconv_filter_fwd", "geossl_cfconv_filter_bwd"):
+                P2 = 2 * sum(int(n) * (int(n) - 1) // 2 for n in sizes0)  # pair slots, both views
+                per_row = (2 * 64 * F + (2 if dom.endswith("fwd") else 4) * F * F)
+                exe = P2 * L * per_row * SPLIT_PRODUCTS
+                roof["executed_bf16_TFLOPs"] = exe / dur / 1e12
+                roof["executed_frac_of_bf16_peak"] = exe / dur / BF16_PEAK
         per_gpu = value / world
         out = {
             "metric": "molecules/s/GPU SchNet+DDM fwd+bwd (QM9-sized, bs=1024); % HBM roofline",
