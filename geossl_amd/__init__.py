@@ -18,5 +18,7 @@ def install_as_reference():
     from . import Geom3D, NCSN
     sys.modules.setdefault("Geom3D", Geom3D)
     sys.modules.setdefault("Geom3D.models", Geom3D.models)
+    from .Geom3D import dataloaders
+    sys.modules.setdefault("Geom3D.dataloaders", dataloaders)
     sys.modules.setdefault("NCSN", NCSN)
     return Geom3D, NCSN

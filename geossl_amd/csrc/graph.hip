@@ -92,6 +92,37 @@ __global__ void k_pair_index_fill(const int32_t* __restrict__ mol_ptr, const int
   }
 }
 
+// Device-side AtomTupleExtractor (dataloaders_AtomTuple.py:15-37, ratio = 1) + the node offset added by
+// BatchAtomTuple.from_data_list (:64-65).  option 0 = "combination": the n(n-1)/2 pairs i<j in lexicographic order
+// (itertools.combinations); option 1 = "permutation": the n(n-1) ordered pairs i != j in itertools.permutations
+// order ((0,1),(0,2),...,(1,0),(1,2),...).  tuple_ptr[m] = first output column of molecule m.
+__global__ void k_atom_tuples(const int32_t* __restrict__ mol_ptr, const int64_t* __restrict__ tuple_ptr, int B,
+                              int option, int64_t* __restrict__ out0, int64_t* __restrict__ out1) {
+  const int m = blockIdx.x;
+  if (m >= B) return;
+  const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0;
+  const int64_t base = tuple_ptr[m];
+  if (option == 0) {
+    for (int a = 0; a + 1 < n; ++a) {
+      const int64_t row = base + a * n - a * (a + 1) / 2 - a - 1;  // column of (a, b) = row + b
+      for (int b = a + 1 + threadIdx.x; b < n; b += blockDim.x) {
+        out0[row + b] = a0 + a;
+        out1[row + b] = a0 + b;
+      }
+    }
+  } else {
+    for (int a = 0; a < n; ++a) {
+      const int64_t row = base + (int64_t)a * (n - 1);
+      for (int b = threadIdx.x; b < n; b += blockDim.x) {
+        if (b == a) continue;
+        const int64_t c = row + (b < a ? b : b - 1);
+        out0[c] = a0 + a;
+        out1[c] = a0 + b;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------- radius graph
 // MODE 0: in-degree; MODE 1: edge list fill; MODE 2: pair-slot geometry.  One 64-lane block per molecule.
 template <int MODE>
@@ -251,6 +282,16 @@ extern "C" int geossl_pair_index_fill(const int32_t* mol_ptr, const int32_t* pai
   if (B <= 0) return 0;
   hipLaunchKernelGGL(k_pair_index_fill, dim3((unsigned)B), dim3(64), 0, stream, mol_ptr, pair_ptr, (int)B, pair_i,
                      pair_j);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_atom_tuples(const int32_t* mol_ptr, const int64_t* tuple_ptr, int64_t B, int option,
+                                  int64_t* out0, int64_t* out1, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (option != 0 && option != 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_atom_tuples, dim3((unsigned)B), dim3(64), 0, stream, mol_ptr, tuple_ptr, (int)B, option, out0,
+                     out1);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

@@ -45,6 +45,12 @@ int geossl_abi_version(void);
  *   pair_i/pair_j : atom ids (global) of every pair slot                                                   */
 int geossl_layout_build(const int64_t* batch, int64_t N, int64_t B, int32_t* mol_ptr, int32_t* pair_ptr,
                         int64_t* stats, hipStream_t stream);
+/* Device-side AtomTupleExtractor (dataloaders_AtomTuple.py:15-37 with ratio = 1) including the node offset of the
+ * collate (:64-65): super_edge_index rows out0 / out1.  option 0 = "combination" (i<j, itertools.combinations
+ * order), 1 = "permutation" (i != j, itertools.permutations order).  tuple_ptr[B+1] (int64): exclusive prefix sum
+ * of the per-molecule tuple counts n(n-1)/2 or n(n-1).                                                        */
+int geossl_atom_tuples(const int32_t* mol_ptr, const int64_t* tuple_ptr, int64_t B, int option, int64_t* out0,
+                       int64_t* out1, hipStream_t stream);
 int geossl_pair_index_fill(const int32_t* mol_ptr, const int32_t* pair_ptr, int64_t B, int32_t* pair_i,
                            int32_t* pair_j, hipStream_t stream);
 

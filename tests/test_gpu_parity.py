@@ -61,6 +61,27 @@ def test_radius_graph_edge_cases():
         ops.radius_graph(torch.zeros(3, 3, device=DEV), 5.0, torch.tensor([1, 0, 0], device=DEV))
 
 
+@pytest.mark.parametrize("option", ["combination", "permutation"])
+def test_device_atom_tuple_extractor_bit_exact(option):
+    """Device-side AtomTupleExtractor + collate offsets (N1) vs the oracle restatement of
+    dataloaders_AtomTuple.py:15-37,64-65: same tuples, same order, incl. 0/1-atom molecules."""
+    from geossl_amd.Geom3D.dataloaders import AtomTupleExtractor, BatchAtomTuple
+    from oracle import graph
+    sizes = [1, 2, 5, 18, 0, 29, 33, 1, 3]
+    rng = np.random.default_rng(5)
+    mols = [(rng.integers(0, 9, (n, 2)), rng.normal(size=(n, 3)).astype(np.float32)) for n in sizes if n > 0]
+    ref = graph.collate_np(mols, option=option)
+    nz = [n for n in sizes if n > 0]
+    bt = BatchAtomTuple.from_sizes(t(ref["x"], DEV), t(ref["positions"], DEV), nz, option=option)
+    assert torch.equal(bt.batch.cpu(), t(ref["batch"]))
+    assert torch.equal(bt.super_edge_index.cpu(), t(ref["super_edge_index"]))
+    assert bt.num_graphs == len(nz)
+    sei = AtomTupleExtractor(option=option)(bt.batch)
+    assert torch.equal(sei, bt.super_edge_index)
+    with pytest.raises(NotImplementedError):
+        AtomTupleExtractor(ratio=0.5)
+
+
 def test_pair_geometry_matches_edge_list():
     """The pair-slot form used inside SchNet carries exactly the canonical edge set."""
     from geossl_amd import ops
