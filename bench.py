@@ -261,7 +261,8 @@ def main():
                 roof["executed_frac_of_bf16_peak"] = exe / dur / BF16_PEAK
         per_gpu = value / world
         out = {
-            "metric": "molecules/s/GPU SchNet+DDM fwd+bwd (QM9-sized, bs=1024); % HBM roofline",
+            "metric": ("molecules/s/GPU SchNet+DDM fwd+bwd (QM9-sized, bs=1024); % HBM roofline" if args.model == "schnet"
+                       else "molecules/s/GPU PaiNN+DDM fwd+bwd (QM9-sized, bs=1024) [BASELINE config 5]"),
             "value": value, "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

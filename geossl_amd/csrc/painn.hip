@@ -9,6 +9,7 @@
 // edge order in registers — no atomics, bit-reproducible.
 #include "common.h"
 #include "geossl_hip.h"
+#include "tn.h"
 
 using namespace geossl;
 
@@ -196,15 +197,6 @@ __global__ __launch_bounds__(128) void k_painn_interaction_bwd(
   pb[f] = gb0; pb[F + f] = gb1; pb[2 * F + f] = gb2;
 }
 
-__global__ void k_partial_sum(const float* __restrict__ partial, int nblk, int len, float* __restrict__ out,
-                              int accumulate) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
-    float s = accumulate ? out[i] : 0.0f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * len + i];
-    out[i] = s;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ mixing
 // mm = mu_channel_mix(mu) [N][3][2F] -> ctx = [q, |mu_V|] [N][2F], dot = sum_xyz mu_V*mu_W  (painn.py:100-104,110)
 __global__ void k_painn_mix_pre_fwd(const float* __restrict__ q, const float* __restrict__ mm, int64_t N, int F,
@@ -328,7 +320,7 @@ extern "C" int geossl_painn_interaction_fwd(const float* q, const float* mu, con
   return 0;
 }
 
-#define GEOSSL_PAINN_BWD_BLOCKS 2048
+#define GEOSSL_PAINN_BWD_BLOCKS 512  // two per CU; one filter-gradient partial per block
 extern "C" int64_t geossl_painn_interaction_bwd_workspace_floats(int64_t N, int F, int R) {
   const int64_t nb = N < GEOSSL_PAINN_BWD_BLOCKS ? N : GEOSSL_PAINN_BWD_BLOCKS;
   return nb * (3 * (int64_t)F * R + 3 * F);
@@ -348,8 +340,15 @@ extern "C" int geossl_painn_interaction_bwd(const float* dq_out, const float* dm
   GEOSSL_PAINN_DISPATCH_R(k_painn_interaction_bwd, dim3(nb), dim3(F > 64 ? 128 : 64), 0, stream, dq_out, dmu_out, mu, xc,
                           idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, (int)N, F, dxc, dmu_in, pw, pb);
   GEOSSL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_partial_sum, dim3(grid1d(3 * F * R, 128)), dim3(128), 0, stream, pw, nb, 3 * F * R, dWf, accumulate);
-  hipLaunchKernelGGL(k_partial_sum, dim3(grid1d(3 * F, 128)), dim3(128), 0, stream, pb, nb, 3 * F, dbf, accumulate);
+  // fixed-order two-stage sums of the per-block partials (64 outputs x 4 slices of the block list per reduction block)
+  GeosslReduceBatch rb;
+  for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = nullptr;
+  rb.out[0] = dWf;
+  hipLaunchKernelGGL(geossl::k_reduce_partials, dim3((3 * F * R + 63) / 64, 1), dim3(256), 0, stream, rb, pw, nb, 3 * F * R,
+                     3 * F * R, 3 * F * R, 1, accumulate);
+  rb.out[0] = dbf;
+  hipLaunchKernelGGL(geossl::k_reduce_partials, dim3((3 * F + 63) / 64, 1), dim3(256), 0, stream, rb, pb, nb, 3 * F, 3 * F,
+                     3 * F, 1, accumulate);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

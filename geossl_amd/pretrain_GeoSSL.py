@@ -42,6 +42,20 @@ def _two_view_batch(batch_vec, num_graphs):
     return cached[0], cached[1]
 
 
+def _two_view_edges(batch_vec, edge_index, num_graphs):
+    """(batch ids, radius_edge_index) of the concatenated (clean ‖ perturbed) batch for PaiNN — the perturbed view
+    keeps the clean view's graph (PaiNN does not re-derive it) — cached on the edge_index tensor so the
+    incidence structures behind it are built once per batch."""
+    cached = getattr(edge_index, "_geossl_two_view", None)
+    key = (batch_vec._version, edge_index._version)
+    if cached is None or cached[2] != key:
+        b2 = torch.cat([batch_vec, batch_vec + num_graphs])
+        e2 = torch.cat([edge_index, edge_index + batch_vec.numel()], dim=1)
+        cached = (b2, e2, key)
+        edge_index._geossl_two_view = cached
+    return cached[0], cached[1]
+
+
 def do_DDM(args, batch, model, criterion=None, mu=0.0, sigma=0.3, num_neg=1, NCSN_models=None, noise=None,
            fuse_views=True, device_noise=False):
     """pretrain_GeoSSL.py:179-212 -> (loss, 0).
@@ -72,8 +86,14 @@ def do_DDM(args, batch, model, criterion=None, mu=0.0, sigma=0.3, num_neg=1, NCS
             _, molecule_3D_repr_01 = model(x_01, positions_01, batch.batch, return_latent=True)
             _, molecule_3D_repr_02 = model(x_02, positions_02, batch.batch, return_latent=True)
     elif args.model_3d == "painn":
-        _, molecule_3D_repr_01 = model(x_01, positions_01, batch.radius_edge_index, batch.batch, return_latent=True)
-        _, molecule_3D_repr_02 = model(x_02, positions_02, batch.radius_edge_index, batch.batch, return_latent=True)
+        if fuse_views:
+            b2, e2 = _two_view_edges(batch.batch, batch.radius_edge_index, batch.num_graphs)
+            N = positions.size(0)
+            _, h = model(torch.cat([x_01, x_02]), torch.cat([positions_01, positions_02]), e2, b2, return_latent=True)
+            molecule_3D_repr_01, molecule_3D_repr_02 = h[:N], h[N:]
+        else:
+            _, molecule_3D_repr_01 = model(x_01, positions_01, batch.radius_edge_index, batch.batch, return_latent=True)
+            _, molecule_3D_repr_02 = model(x_02, positions_02, batch.radius_edge_index, batch.batch, return_latent=True)
     else:
         raise Exception("3D model {} not included.".format(args.model_3d))
 

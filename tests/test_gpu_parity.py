@@ -508,7 +508,8 @@ def test_painn_radius_edge_index_matches_per_molecule_radius_graph():
     assert torch.equal(e.cpu(), t(g["radius_edge_index"]))
 
 
-def test_painn_do_ddm_golden():
+@pytest.mark.parametrize("fuse", [True, False])
+def test_painn_do_ddm_golden(fuse):
     from geossl_amd import pretrain_GeoSSL as pg
     g, d = load_golden("g7_painn"), load_golden("g7_painn_ddm")
     cfg = cfg_of(g)
@@ -517,7 +518,8 @@ def test_painn_do_ddm_golden():
     batch = pg.Batch(t(g["x"], DEV), t(g["positions"], DEV), t(g["batch"], DEV), t(g["super_edge_index"], DEV),
                      radius_edge_index=t(g["radius_edge_index"], DEV))
     noise = {k: t(d[k], DEV) for k in ("pos_noise", "noise_level_1", "dist_noise_1", "noise_level_2", "dist_noise_2")}
-    loss, _ = pg.do_DDM(pg.Args("painn"), batch, model, None, 0.0, 0.3, NCSN_models=(n1, n2), noise=noise)
+    loss, _ = pg.do_DDM(pg.Args("painn"), batch, model, None, 0.0, 0.3, NCSN_models=(n1, n2), noise=noise,
+                        fuse_views=fuse)
     assert rel_err(loss.detach().cpu(), d["loss"]) < TOL_OUT
     loss.backward()
     mods = {"model": unique_named_grads(model), "ncsn1": unique_named_grads(n1), "ncsn2": unique_named_grads(n2)}
