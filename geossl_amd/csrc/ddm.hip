@@ -27,37 +27,6 @@ inline void allow_big_lds(K kernel) {
 }
 
 // k-major copy of layers.1.weight: W2T[k][m] = o2_w[m][k], padded to HP columns
-// A wave gathers h[u] + h[v] for NROWS rows (endpoints held by lanes 0..NROWS-1), eight rows at a time with all
-// sixteen row loads of a group in flight together.
-template <int F, int NROWS, class Store>
-__device__ __forceinline__ void gather_endpoint_sum_rows(const float* __restrict__ h, int64_t my_u, int64_t my_v,
-                                                         int lane, Store store) {
-  constexpr int NV = (F + 63) / 64;
-#pragma unroll 1
-  for (int r4 = 0; r4 < NROWS; r4 += 8) {
-    float hu[8][NV], hv[8][NV];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int64_t uu = __shfl(my_u, r4 + q, 64), vv = __shfl(my_v, r4 + q, 64);
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const int n = lane + 64 * v;
-        if (n < F) {
-          hu[q][v] = h[uu * F + n];
-          hv[q][v] = h[vv * F + n];
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const int n = lane + 64 * v;
-        if (n < F) store(r4 + q, n, hu[q][v] + hv[q][v]);
-      }
-  }
-}
-
 // fixed-order two-stage sum
 __global__ __launch_bounds__(256) void k_sum_partial(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
   __shared__ float red[256];

@@ -496,17 +496,7 @@ extern "C" int geossl_linear_wgrad(const GeosslTnBatch* batch, int nprob, int64_
     WG(4, 4); WG(4, 2); WG(2, 4); WG(2, 2); WG(1, 1); WG(1, 2); WG(2, 1); WG(4, 1); WG(1, 4);
 #undef WG
   }
-  PlainLoader ld;
-  ld.batch = *batch;
-  ld.lda = lda;
-  ld.ldb = ldb;
-  TnOut out;
-  for (int z = 0; z < GEOSSL_TN_MAX; ++z) {
-    out.dW[z] = batch->dW[z];
-    out.db[z] = batch->db[z];
-    out.dd[z] = nullptr;
-  }
-  return launch_tn(ld, nprob, R, M, N, out, ldw, 1, workspace, accumulate, stream);
+  return (int)hipErrorInvalidValue;  // M, N <= 128 in blocks of 32, 64 or 128 columns
 }
 
 extern "C" int geossl_abi_version(void) { return GEOSSL_ABI_VERSION; }

@@ -172,10 +172,6 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
   }
 }
 
-// out_z[(i/ncols)*ld + (i%ncols)*cstride] = (accumulate ? out : 0) + sum_b partial[z][b][i]   (gemm.hip)
-__global__ void k_reduce_partials(GeosslReduceBatch batch, const float* __restrict__ partial, int nblk, int len,
-                                  int ncols, int ld, int cstride, int accumulate);
-
 // workspace: nprob * nblk * (M*N + 2*M) floats (geossl_tn_workspace_floats).  dW rows are written with leading
 // dimension dW_ld (>= N); dd is written with stride dd_stride (e.g. the last column of a [M][N+1] weight).
 template <int NCM, int NCN, class Ops>
