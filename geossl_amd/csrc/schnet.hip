@@ -68,7 +68,7 @@ __global__ __launch_bounds__(128) void k_aggregate(const float* __restrict__ x, 
     for (int p0 = 0; p0 < np; p0 += U) {
       float w[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) w[u] = wcol[(size_t)min(p0 + u, np - 1) * F];
+      for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(wcol + (size_t)min(p0 + u, np - 1) * F);  // streamed once
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (p0 + u < np) {

@@ -219,7 +219,8 @@ __device__ __forceinline__ void request_col8(const float* __restrict__ src, int 
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[ks][e] = src[(size_t)min(row0 + 16 * ks + 8 * kh + e, row_end - 1) * ld + col];
+    for (int e = 0; e < 8; ++e)  // every operand element is read exactly once: non-temporal
+      v[ks][e] = __builtin_nontemporal_load(src + (size_t)min(row0 + 16 * ks + 8 * kh + e, row_end - 1) * ld + col);
 }
 // helper: pin the arrived values (common.h) and zero the rows past row_end
 __device__ __forceinline__ void finish_col8(int row0, int row_end, int kh, const float (&raw)[2][8],
