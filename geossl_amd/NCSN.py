@@ -49,6 +49,24 @@ def _head_params(m):
 
 _FIELDS = ("in_w1", "in_b1", "in_w2", "in_b2", "o1_w", "o1_b", "o2_w", "o2_b", "o3_w", "o3_b")
 
+# Optional side stream for the head's weight-gradient kernels.  They depend only on the row pass of the head, while
+# the backbone's backward (a chain of small, latency-bound launches) needs nothing but dh: with a side stream set
+# (DDMTrainer does, and joins it before the optimiser step) the two run concurrently.  Off by default: a caller that
+# runs its own optimiser right after loss.backward() must see every gradient on the current stream.
+_SIDE = {"stream": None, "pending": []}
+
+
+def set_side_stream(stream):
+    _SIDE["stream"] = stream
+
+
+def join_side_stream():
+    """Make the current stream wait for the side-stream work and release the tensors kept alive for it."""
+    if _SIDE["pending"]:
+        for ev, _keep in _SIDE["pending"]:
+            torch.cuda.current_stream().wait_event(ev)
+        _SIDE["pending"].clear()
+
 
 class _NcsnLoss(torch.autograd.Function):
     @staticmethod
@@ -102,17 +120,31 @@ class _NcsnLoss(torch.autograd.Function):
         gout = gout.contiguous().to(torch.float32)
         call("geossl_ddm_loss_bwd_rows", C.byref(w), C.byref(sv), S, Fd, ptr(sel.stats), ctx.out_scale, ptr(gout),
              ptr(dz1), ptr(dfeat), ptr(demb), ptr(grow), st)
+        dh = None
+        if ctx.needs_input_grad[0]:  # first: the backbone's backward waits for nothing else
+            dh = torch.empty(N, Fd, dtype=torch.float32, device=dev)
+            call("geossl_incidence_gather", ptr(dfeat), ptr(sel.inc_ptr), ptr(sel.inc_idx), N, Fd, ptr(dh), 0, st)
         direct = all(p.grad is not None and p.grad.is_contiguous() and p.grad.is_cuda for p in ctx.params)
         grads = [p.grad for p in ctx.params] if direct else [torch.empty_like(p) for p in ps]
         g = _lib.NcsnGrads(*[ptr(t) for t in grads])
         nfl = _lib.load().geossl_ddm_loss_bwd_workspace_floats(S, Fd)
-        ws = torch.empty(nfl, dtype=torch.float32, device=dev)
-        call("geossl_ddm_loss_bwd_weights", ptr(h), ptr(sel.sei0), ptr(sel.sei1), S, Fd, C.byref(w), C.byref(sv),
-             ptr(dz1), ptr(demb), ptr(grow), C.byref(g), ptr(ws), 1 if direct else 0, st)
-        dh = None
-        if ctx.needs_input_grad[0]:
-            dh = torch.empty(N, Fd, dtype=torch.float32, device=dev)
-            call("geossl_incidence_gather", ptr(dfeat), ptr(sel.inc_ptr), ptr(sel.inc_idx), N, Fd, ptr(dh), 0, st)
+        side = _SIDE["stream"] if direct else None
+        if side is None:
+            ws = torch.empty(nfl, dtype=torch.float32, device=dev)
+            call("geossl_ddm_loss_bwd_weights", ptr(h), ptr(sel.sei0), ptr(sel.sei1), S, Fd, C.byref(w), C.byref(sv),
+                 ptr(dz1), ptr(demb), ptr(grow), C.byref(g), ptr(ws), 1 if direct else 0, st)
+        else:
+            main = torch.cuda.current_stream()
+            fork = torch.cuda.Event()
+            fork.record(main)
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                ws = torch.empty(nfl, dtype=torch.float32, device=dev)
+                call("geossl_ddm_loss_bwd_weights", ptr(h), ptr(sel.sei0), ptr(sel.sei1), S, Fd, C.byref(w), C.byref(sv),
+                     ptr(dz1), ptr(demb), ptr(grow), C.byref(g), ptr(ws), 1, stream())
+                done = torch.cuda.Event()
+                done.record(side)
+            _SIDE["pending"].append((done, (h, saved, dz1, demb, grow, ws, w, sv, ps, grads)))
         ctx.saved = None
         if direct:
             return (dh, None, None, None, None, None, None, None) + (None,) * len(grads)

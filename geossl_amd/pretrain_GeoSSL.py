@@ -163,7 +163,7 @@ class DDMTrainer:
     launch stay outside the graph."""
 
     def __init__(self, model, ncsn_01, ncsn_02, lr=5e-4, weight_decay=0.0, mu=0.0, sigma=0.3, model_3d="schnet",
-                 device_noise=True, use_graph=False):
+                 device_noise=True, use_graph=False, overlap_heads=True):
         from .optim import FlatParams, FusedAdam
         from .parallel import GradAllReduce
         self.model, self.n1, self.n2 = model, ncsn_01, ncsn_02
@@ -174,13 +174,23 @@ class DDMTrainer:
         self.opt = FusedAdam(self.flat, lr=lr, weight_decay=weight_decay)
         self.reduce = GradAllReduce(self.flat.grad)
         self.use_graph = use_graph
+        self.overlap_heads = overlap_heads  # head weight gradients on a side stream, concurrent with the backbone's backward
         self._g = None
+        self._side = None
 
     def _fwd_bwd(self, batch, noise):
+        from . import NCSN as _ncsn
         self.flat.zero_grad()
         loss, _ = do_DDM(self.args, batch, self.model, None, self.mu, self.sigma, NCSN_models=(self.n1, self.n2),
                          noise=noise, device_noise=self.device_noise)
-        loss.backward()
+        if self._side is None and self.overlap_heads:
+            self._side = torch.cuda.Stream()
+        _ncsn.set_side_stream(self._side)  # head weight gradients overlap the backbone's backward
+        try:
+            loss.backward()
+        finally:
+            _ncsn.set_side_stream(None)
+            _ncsn.join_side_stream()
         self.flat.rebind_grads()
         return loss.detach()
 
