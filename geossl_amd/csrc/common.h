@@ -34,14 +34,22 @@ __device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 *
 // v_exp_f32 / v_log_f32 (argument magnitude <= ~17 where it matters: absolute error < 1e-7), with a short
 // series for small exp(-|x|) where 1+z would lose the low bits.
 #define GEOSSL_SSP_SHIFT 0.693147182464599609375f  // float(torch.log(torch.tensor(2.0)))
+// exp(x) for x <= ~0.7 on the raw v_exp_f32 (2^x): no range reduction or denormal fix-up code (results below the
+// normal range flush to 0, which is what every caller wants), no branches
+__device__ __forceinline__ float exp_neg(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+// Branch-free: the library logf / a ternary around it compile to an exec-masked branch per element (plus the
+// s_nop padding of the exec hazards) - 64 of them per lane and row block in the filter kernels.  1 + z is in (1, 2],
+// so the raw v_log_f32 (log2, ~1 ulp) needs no denormal handling.
 __device__ __forceinline__ float ssp(float x) {
-  const float z = __expf(-fabsf(x));
-  const float l = z < 0.0078125f ? z * (1.0f - z * (0.5f - z * 0.33333334f)) : __logf(1.0f + z);
+  const float z = exp_neg(-fabsf(x));
+  const float lg = __builtin_amdgcn_logf(1.0f + z) * 0.693147180559945309417f;
+  const float sr = z * (1.0f - z * (0.5f - z * 0.33333334f));  // log1p series where 1 + z would lose the low bits
+  const float l = z < 0.0078125f ? sr : lg;
   return (fmaxf(x, 0.0f) + l) - GEOSSL_SSP_SHIFT;
 }
 // d ssp / dx = sigmoid(x), recovered from the saved output t = ssp(x):
 // exp(-softplus(x)) = 1 - sigmoid(x)  =>  sigmoid(x) = 1 - 0.5*exp(-t)   (0.5 = exp(-log 2))
-__device__ __forceinline__ float dssp_from_out(float t) { return 1.0f - 0.5f * __expf(-t); }
+__device__ __forceinline__ float dssp_from_out(float t) { return 1.0f - 0.5f * exp_neg(-t); }
 
 // A wave's C-layout 32x32 block (16 accumulator registers: lane = column, register = row) transposed through a
 // wave-private 16x32 LDS stage (2 KB) in two halves, handing each lane 16-byte row pieces:

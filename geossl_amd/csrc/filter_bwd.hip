@@ -247,7 +247,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float diff = L.tdd[16 * ks + kperm(e, ln >> 5)] - off;
-        v[e] = gg < G ? __expf(coeff * (diff * diff)) : 0.0f;
+        v[e] = gg < G ? exp_neg(coeff * (diff * diff)) : 0.0f;
       }
       const Frag3 f = split8(v);
       u32x4* dst = L.rbf + (size_t)((gb * 2 + ks) * 3) * 64 + ln;

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512) void k_filter_fwd(const float* __restrict__ pa
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float diff = d - o[e];
-          v[e] = __expf(coeff * (diff * diff));  // schnet.py:206-207 (padded centres meet zero weights)
+          v[e] = exp_neg(coeff * (diff * diff));  // schnet.py:206-207 (padded centres meet zero weights)
         }
       }
       const Frag3 bf = split8(v);
