@@ -81,7 +81,8 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
   const float* __restrict__ x = g.x[l];
   const float* __restrict__ dagg = g.dagg[l];
   const size_t lbase = (size_t)l * P;
-  const float* __restrict__ Tcol = T + lbase * F + 32 * hs + j;  // this lane's hidden unit
+  const float* __restrict__ Tl = T + lbase * F;   // uniform base: the per-lane part stays a 32-bit offset
+  const uint32_t tcol = 32 * hs + j;               // this lane's hidden unit
 
   // ---- role A: W2 slice as B fragments of dt = dO W2:  B[k = c = 16ks + 8kh + e][n = h] = W2[c][h]
   Frag3 bw2[roleA ? KC : 1];
@@ -152,10 +153,11 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
     // in B-fragment layout (k-step s, element e <-> row 16s + 8kh + e); rows past P are clamped (their dO is 0)
     if constexpr (roleA) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tc[r] = Tcol[(size_t)min(rr0 + c_row(r, lane), P - 1) * F];
+      for (int r = 0; r < 16; ++r) tc[r] = Tl[(uint32_t)min(rr0 + c_row(r, lane), P - 1) * (uint32_t)F + tcol];
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tc[r] = Tcol[(size_t)min(rr0 + 16 * (r >> 3) + 8 * kh + (r & 7), P - 1) * F];
+      for (int r = 0; r < 16; ++r)
+        tc[r] = Tl[(uint32_t)min(rr0 + 16 * (r >> 3) + 8 * kh + (r & 7), P - 1) * (uint32_t)F + tcol];
     }
   };
   if (t_begin < t_end) {
