@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void k_linear_prepare(GeosslPrepareBatch batch
 }
 
 constexpr int LSS = 36;  // row stride of the wave-private stage, floats
-template <int KS>
+// E0 / E1: the launch uses tprev (ssp' epilogue) / res (residual) - compile-time, so unused operands cost nothing
+template <int KS, bool E0, bool E1>
 __global__ __launch_bounds__(512) void k_linear_split(const float* __restrict__ X, const float* __restrict__ W,
                                                       const float* __restrict__ bias, const float* __restrict__ res,
                                                       const float* __restrict__ tprev, float* __restrict__ Y, int R,
@@ -267,22 +268,22 @@ __global__ __launch_bounds__(512) void k_linear_split(const float* __restrict__ 
         xf[2 * c + s2] = split8(v);
       }
     }
+    // epilogue operands in the coalesced layout, requested one column block ahead of their use (before the MFMAs of
+    // the previous block), clamped addresses
+    f32x4 e0[4], e1[4], e0n[4], e1n[4];
+    auto request_e = [&](int mb, f32x4 (&a)[4], f32x4 (&b)[4]) {
+      const int cc = min(n0 + 32 * mb + c4, NO - 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t oc = (size_t)min(32 * rb + 8 * u + cr, R - 1) * ldy + cc;
+        if (E0) a[u] = *reinterpret_cast<const f32x4*>(tprev + oc);
+        if (E1) b[u] = *reinterpret_cast<const f32x4*>(res + oc);
+      }
+    };
+    if (E0 || E1) request_e(mb_begin, e0, e1);
     for (int mb = mb_begin; mb < mb_end; ++mb) {
       const int cb = n0 + 32 * mb;
-      // epilogue operands in the coalesced layout, requested before the MFMAs of the block.  No branch on the
-      // (uniform) flags: an unused operand is read from the first 16 bytes of W (always valid) and ignored -
-      // branches would let the compiler sink the loads below the MFMA loop, behind a vmcnt(0) each
-      f32x4 e0[4], e1[4];
-      {
-        const bool use0 = flags & GEOSSL_EPI_MUL_DSSP, use1 = flags & GEOSSL_EPI_RESIDUAL;
-        const int cc = min(cb + c4, NO - 4);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const size_t oc = (size_t)min(32 * rb + 8 * u + cr, R - 1) * ldy + cc;
-          e0[u] = *reinterpret_cast<const f32x4*>(use0 ? tprev + oc : W);
-          e1[u] = *reinterpret_cast<const f32x4*>(use1 ? res + oc : W);
-        }
-      }
+      if ((E0 || E1) && mb + 1 < mb_end) request_e(mb + 1, e0n, e1n);
       f32x16 acc;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -317,13 +318,20 @@ __global__ __launch_bounds__(512) void k_linear_split(const float* __restrict__ 
       for (int u = 0; u < 4; ++u) {  // arithmetic unconditional (keeps the operand loads up front), store predicated
         f32x4 v = *reinterpret_cast<const f32x4*>(stage + (8 * u + cr) * LSS + c4);
         if (flags & GEOSSL_EPI_SSP) { v.x = ssp(v.x); v.y = ssp(v.y); v.z = ssp(v.z); v.w = ssp(v.w); }
-        if (flags & GEOSSL_EPI_MUL_DSSP) {
+        if (E0) {
           v.x *= dssp_from_out(e0[u].x); v.y *= dssp_from_out(e0[u].y);
           v.z *= dssp_from_out(e0[u].z); v.w *= dssp_from_out(e0[u].w);
         }
-        if (flags & GEOSSL_EPI_RESIDUAL) { v.x += e1[u].x; v.y += e1[u].y; v.z += e1[u].z; v.w += e1[u].w; }
+        if (E1) { v.x += e1[u].x; v.y += e1[u].y; v.z += e1[u].z; v.w += e1[u].w; }
         const int row = 32 * rb + 8 * u + cr;
         if (row < R && cb + c4 < NO) *reinterpret_cast<f32x4*>(Y + (size_t)row * ldy + cb + c4) = v;
+      }
+      if (E0 || E1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          e0[u] = e0n[u];
+          e1[u] = e1n[u];
+        }
       }
     }
     // a wave rarely has a second item (R > 32 rows x 4 waves x 256 blocks); its X is requested here rather than
@@ -348,14 +356,23 @@ static int launch_linear_split(const float* X, int ldx, const float* W, const u3
   int nx = (nrb + 3) / 4;  // whole row blocks go to four waves per block (one per SIMD)
   if (nx > 256) nx = 256;
   const size_t lds = (size_t)nmb * KS * 3 * 1024 + (size_t)(nmb * 32 + 8 * 32 * LSS) * sizeof(float);
+  const bool e0 = flags & GEOSSL_EPI_MUL_DSSP, e1 = flags & GEOSSL_EPI_RESIDUAL;
+#define LAUNCH_SE(KSV, A, B)                                                                                      \
+  do {                                                                                                            \
+    allow_big_lds(&k_linear_split<KSV, A, B>);                                                                    \
+    hipLaunchKernelGGL((k_linear_split<KSV, A, B>), dim3(nx, ny), dim3(512), lds, stream, X, W, bias, res, tprev, \
+                       Y, (int)R, NO, nmb, ldx, ldy, transB, flags, image);                                       \
+  } while (0)
 #define LAUNCH_S(KSV)                                                                                             \
   do {                                                                                                            \
-    allow_big_lds(&k_linear_split<KSV>);                                                                          \
-    hipLaunchKernelGGL((k_linear_split<KSV>), dim3(nx, ny), dim3(512), lds, stream, X, W, bias, res, tprev, Y,    \
-                       (int)R, NO, nmb, ldx, ldy, transB, flags, image);                                          \
+    if (e0 && e1) LAUNCH_SE(KSV, true, true);                                                                     \
+    else if (e0) LAUNCH_SE(KSV, true, false);                                                                     \
+    else if (e1) LAUNCH_SE(KSV, false, true);                                                                     \
+    else LAUNCH_SE(KSV, false, false);                                                                            \
   } while (0)
   if (KS == 8) LAUNCH_S(8); else if (KS == 4) LAUNCH_S(4); else LAUNCH_S(2);
 #undef LAUNCH_S
+#undef LAUNCH_SE
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
