@@ -320,7 +320,7 @@ extern "C" int geossl_painn_interaction_fwd(const float* q, const float* mu, con
   return 0;
 }
 
-#define GEOSSL_PAINN_BWD_BLOCKS 512  // two per CU; one filter-gradient partial per block
+#define GEOSSL_PAINN_BWD_BLOCKS 1536  // six per CU (the register budget of the kernel); one filter-gradient partial per block
 extern "C" int64_t geossl_painn_interaction_bwd_workspace_floats(int64_t N, int F, int R) {
   const int64_t nb = N < GEOSSL_PAINN_BWD_BLOCKS ? N : GEOSSL_PAINN_BWD_BLOCKS;
   return nb * (3 * (int64_t)F * R + 3 * F);
