@@ -31,6 +31,21 @@ def perturb(x, positions, mu, sigma, noise=None, device_noise=False, generator=N
     return x_perturb, positions_perturb
 
 
+class _SplitViews(torch.autograd.Function):
+    """h of the fused (clean ‖ perturbed) batch -> the two per-view halves.  Plain slicing would make autograd pad each
+    half's gradient to the full shape and add the two (two fills, two copies and an add over 2N x F); the backward
+    here is one concatenation."""
+
+    @staticmethod
+    def forward(ctx, h, n):
+        ctx.n = n
+        return h[:n], h[n:]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        return torch.cat([g1, g2]), None
+
+
 def _two_view_batch(batch_vec, num_graphs):
     """batch ids of the concatenated (clean ‖ perturbed) 2B-molecule batch + its layout, cached on
     the batch tensor object."""
@@ -81,7 +96,7 @@ def do_DDM(args, batch, model, criterion=None, mu=0.0, sigma=0.3, num_neg=1, NCS
             N = positions.size(0)
             _, h = model(torch.cat([x_01, x_02]), torch.cat([positions_01, positions_02]), b2, return_latent=True,
                          layout=lay2)
-            molecule_3D_repr_01, molecule_3D_repr_02 = h[:N], h[N:]
+            molecule_3D_repr_01, molecule_3D_repr_02 = _SplitViews.apply(h, N)
         else:
             _, molecule_3D_repr_01 = model(x_01, positions_01, batch.batch, return_latent=True)
             _, molecule_3D_repr_02 = model(x_02, positions_02, batch.batch, return_latent=True)
@@ -90,7 +105,7 @@ def do_DDM(args, batch, model, criterion=None, mu=0.0, sigma=0.3, num_neg=1, NCS
             b2, e2 = _two_view_edges(batch.batch, batch.radius_edge_index, batch.num_graphs)
             N = positions.size(0)
             _, h = model(torch.cat([x_01, x_02]), torch.cat([positions_01, positions_02]), e2, b2, return_latent=True)
-            molecule_3D_repr_01, molecule_3D_repr_02 = h[:N], h[N:]
+            molecule_3D_repr_01, molecule_3D_repr_02 = _SplitViews.apply(h, N)
         else:
             _, molecule_3D_repr_01 = model(x_01, positions_01, batch.radius_edge_index, batch.batch, return_latent=True)
             _, molecule_3D_repr_02 = model(x_02, positions_02, batch.radius_edge_index, batch.batch, return_latent=True)
