@@ -95,64 +95,65 @@ __global__ __launch_bounds__(512) void k_filter_fwd(const float* __restrict__ pa
         acc1[mb][4 * q + 2] = b.z;
         acc1[mb][4 * q + 3] = b.w;
       }
+    // rbf^T B fragments of all k-steps (every exp computed once)
+    Frag3 bfr[K1S];
 #pragma unroll
     for (int ks = 0; ks < K1S; ++ks) {
       float v[8];
-      {
-        const float4 o0 = *reinterpret_cast<const float4*>(offs + 16 * ks + 8 * kh);
-        const float4 o1 = *reinterpret_cast<const float4*>(offs + 16 * ks + 8 * kh + 4);
-        const float o[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+      const float4 o0 = *reinterpret_cast<const float4*>(offs + 16 * ks + 8 * kh);
+      const float4 o1 = *reinterpret_cast<const float4*>(offs + 16 * ks + 8 * kh + 4);
+      const float o[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float diff = d - o[e];
-          v[e] = exp_neg(coeff * (diff * diff));  // schnet.py:206-207 (padded centres meet zero weights)
+      for (int e = 0; e < 8; ++e) {
+        const float diff = d - o[e];
+        v[e] = exp_neg(coeff * (diff * diff));  // schnet.py:206-207 (padded centres meet zero weights)
+      }
+      bfr[ks] = split8(v);
+    }
+    // First GEMM one 32-feature block at a time, software-pipelined inside the wave: the bf16 MFMAs of block mb
+    // are interleaved with the ssp / split / store (vector work) of block mb-1 - the matrix pipe overlaps with vector
+    // instructions of the SAME wave only (split.h).  ssp output: t to HBM (row-major, 16 bytes per store) when
+    // training and, split, the B fragments of the second GEMM: registers 0..7 of block mb are k-step 2mb, registers
+    // 8..15 k-step 2mb+1, element e = register & 7.
+    Frag3 tb[K2S];
+    float* trow = Tout != nullptr ? Tout + (lbase + row) * F + 4 * kh : nullptr;
+    auto finish_block = [&](int mb) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ssp(acc1[mb][8 * half + e]);
+        if (trow != nullptr && live) {
+          *reinterpret_cast<float4*>(trow + 32 * mb + 16 * half) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(trow + 32 * mb + 16 * half + 8) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        tb[2 * mb + half] = split8(v);
+      }
+    };
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+#pragma unroll
+      for (int ks = 0; ks < K1S; ++ks) {
+        Frag3 af;
+        const u32x4* src = W1f + ((size_t)(mb * K1S + ks) * 3) * 64 + lane;
+        af.h = src[0];
+        af.m = src[64];
+        af.l = src[128];
+        mma6(acc1[mb], af, bfr[ks]);
+      }
+      if (mb > 0) {
+        finish_block(mb - 1);
+        // interleave: one MFMA, then a slice of the vector work of the previous block
+#pragma unroll
+        for (int i = 0; i < 6 * K1S; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
         }
       }
-      const Frag3 bf = split8(v);
-      Frag3 af[NMB];
-#pragma unroll
-      for (int mb = 0; mb < NMB; ++mb) {
-        const u32x4* src = W1f + ((size_t)(mb * K1S + ks) * 3) * 64 + lane;
-        af[mb].h = src[0];
-        af[mb].m = src[64];
-        af[mb].l = src[128];
-      }
-      // product-major, block-minor: consecutive MFMAs hit different accumulators
-#pragma unroll
-      for (int mb = 0; mb < NMB; ++mb) acc1[mb] = mfma_bf16(af[mb].l, bf.h, acc1[mb]);
-#pragma unroll
-      for (int mb = 0; mb < NMB; ++mb) acc1[mb] = mfma_bf16(af[mb].h, bf.l, acc1[mb]);
-#pragma unroll
-      for (int mb = 0; mb < NMB; ++mb) acc1[mb] = mfma_bf16(af[mb].m, bf.m, acc1[mb]);
-#pragma unroll
-      for (int mb = 0; mb < NMB; ++mb) acc1[mb] = mfma_bf16(af[mb].m, bf.h, acc1[mb]);
-#pragma unroll
-      for (int mb = 0; mb < NMB; ++mb) acc1[mb] = mfma_bf16(af[mb].h, bf.m, acc1[mb]);
-#pragma unroll
-      for (int mb = 0; mb < NMB; ++mb) acc1[mb] = mfma_bf16(af[mb].h, bf.h, acc1[mb]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // ssp; t to HBM (row-major, 16 bytes per store) when training; split into the B fragments of the second GEMM:
-    // registers 0..7 of block mb are k-step 2mb, registers 8..15 k-step 2mb+1, element e = register & 7
-    Frag3 tb[K2S];
-    {
-      float* trow = Tout != nullptr ? Tout + (lbase + row) * F + 4 * kh : nullptr;
-#pragma unroll
-      for (int mb = 0; mb < NMB; ++mb) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = ssp(acc1[mb][8 * half + e]);
-          if (trow != nullptr && live) {
-            *reinterpret_cast<float4*>(trow + 32 * mb + 16 * half) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(trow + 32 * mb + 16 * half + 8) = make_float4(v[4], v[5], v[6], v[7]);
-          }
-          tb[2 * mb + half] = split8(v);
-          __builtin_amdgcn_sched_barrier(0);  // one 8-register group at a time keeps the live set small
-        }
-      }
-    }
+    finish_block(NMB - 1);
+    __builtin_amdgcn_sched_barrier(0);
     // second GEMM, transposed, two 32-feature output blocks at a time
     constexpr int MP = NMB >= 2 ? 2 : 1;
     float* orow = Wf + (lbase + row) * F + 4 * kh;
