@@ -223,9 +223,19 @@ class DDMTrainer:
                 for _ in range(2):
                     self._fwd_bwd(sb, sn)
             torch.cuda.current_stream().wait_stream(side)
+            # nothing may be pending on the device when the capture starts (in a multi-rank job the collective's
+            # watchdog thread polls events of earlier all-reduces), and calls of other threads must not invalidate it
+            torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss = self._fwd_bwd(sb, sn)
+            try:
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    loss = self._fwd_bwd(sb, sn)
+            except Exception as e:  # capture is an optimisation: fall back to eager execution, loudly
+                import warnings
+                warnings.warn("HIP-graph capture of the DDM step failed (%s: %s); running eagerly" % (type(e).__name__, e))
+                torch.cuda.synchronize()
+                self.use_graph = False
+                return self._fwd_bwd(batch, noise)
             self._g = g = dict(key=key, graph=graph, batch=sb, noise=sn, loss=loss)
         g["batch"].x.copy_(batch.x)
         g["batch"].positions.copy_(batch.positions)
