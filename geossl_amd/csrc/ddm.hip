@@ -290,7 +290,7 @@ extern "C" int geossl_loss_reduce(const float* loss_e, int64_t S, const int64_t*
 }
 
 static inline void small_plan(int64_t S, int* chunk, int* nblk) {
-  int64_t c = (S + 511) / 512;
+  int64_t c = (S + 2047) / 2048;  // eight blocks per CU: the row loop of a thread is a chain of dependent batches
   if (c < 64) c = 64;
   *chunk = (int)c;
   *nblk = (int)((S + c - 1) / c);
