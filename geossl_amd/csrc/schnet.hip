@@ -107,9 +107,9 @@ __global__ void k_embedding_fwd(const int64_t* __restrict__ z, int64_t zs, const
   }
 }
 
-#define GEOSSL_EMB_CHUNKS 256
+#define GEOSSL_EMB_CHUNKS 512
 // block = one chunk of rows, thread f owns feature column f of a [classes][F] accumulator table in LDS (thread-private
-// columns: no barriers, rows added in row order); every row of dh is read once, eight rows in flight
+// columns: no barriers, rows added in row order); every row of dh is read once, sixteen rows in flight
 __global__ void k_embedding_bwd_partial(const int64_t* __restrict__ z, int64_t zs, const float* __restrict__ dh,
                                         int64_t N, int F, int C, float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -118,17 +118,18 @@ __global__ void k_embedding_bwd_partial(const int64_t* __restrict__ z, int64_t z
   const int64_t lo = chunk * per, hi = min((int64_t)N, lo + per);
   if (f >= F) return;
   for (int c = 0; c < C; ++c) smem[c * F + f] = 0.0f;
-  for (int64_t a0 = lo; a0 < hi; a0 += 8) {
-    float v[8];
-    int cls[8];
+  constexpr int U = 16;
+  for (int64_t a0 = lo; a0 < hi; a0 += U) {
+    float v[U];
+    int cls[U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int64_t a = min(a0 + u, hi - 1);
       v[u] = dh[a * F + f];
       cls[u] = (int)z[a * zs];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < U; ++u)
       if (a0 + u < hi && cls[u] >= 0 && cls[u] < C) smem[cls[u] * F + f] += v[u];
   }
   for (int c = 0; c < C; ++c) partial[((size_t)chunk * C + c) * F + f] = smem[c * F + f];
@@ -137,6 +138,7 @@ __global__ void k_embedding_bwd_reduce(const float* __restrict__ partial, int le
                                        int accumulate) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
     float s = accumulate ? dtable[i] : 0.0f;
+#pragma unroll 16
     for (int b = 0; b < GEOSSL_EMB_CHUNKS; ++b) s += partial[(size_t)b * len + i];
     dtable[i] = s;
   }
