@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--dataset-mols", type=int, default=100000, help="synthetic dataset size (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not capture forward+backward into a HIP graph")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="BASELINE config 1 (secondary line): SchNet forward only, one view, no autograd")
     ap.add_argument("--model", default="schnet", choices=["schnet", "painn"],
                     help="backbone: schnet = the headline configuration; painn = BASELINE config 5 (secondary line)")
     args = ap.parse_args()
@@ -166,6 +168,43 @@ def main():
             "dist_noise_2": torch.randn(S, 1, device=dev, generator=gen),
             "pos_noise": torch.empty_like(bt.positions).normal_(0.0, 0.3, generator=gen),
         }
+
+    if args.forward_only:
+        # BASELINE configs[1]: SchNet.forward(z, pos, batch) on a 1024-molecule batch, inference (no saved activations)
+        def fwd(i):
+            bt = batches[i % n_batches]
+            with torch.no_grad():
+                return model(bt.x[:, 0], bt.positions, bt.batch)
+        for i in range(args.warmup):
+            out = fwd(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = fwd(args.warmup + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        if rank == 0:
+            print(json.dumps({
+                "metric": "molecules/s/GPU SchNet forward-only (QM9-sized, bs=1024) [BASELINE config 1]",
+                "value": world * args.mols * args.steps / elapsed, "unit": "molecules/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "SchNet.forward F=128 L=6 G=51 cutoff=5A, bs=%d molecules/GPU x n=18 atoms, eager "
+                                       "launches (HBM-resident batches)" % args.mols,
+                           "parallelism": "dp%d" % world},
+                "roofline": None, "cpu_baseline": None, "out_checksum": float(out.double().sum())}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     def one_step(i):
         bt = batches[i % n_batches]
