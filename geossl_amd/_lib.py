@@ -123,11 +123,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("GEOSSL_HIP_LIB", LIB_PATH)  # override: A/B timing of two builds on one machine
+    if not os.path.exists(path):
         raise GeosslHipError(
             "libgeossl_hip.so is not built (%s). Run `python -m geossl_amd.build` (needs hipcc); "
-            "there is no CPU fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+            "there is no CPU fallback." % path)
+    lib = C.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
