@@ -39,13 +39,13 @@ __device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 *
 __device__ __forceinline__ float exp_neg(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 // Branch-free: the library logf / a ternary around it compile to an exec-masked branch per element (plus the
 // s_nop padding of the exec hazards) - 64 of them per lane and row block in the filter kernels.  1 + z is in (1, 2],
-// so the raw v_log_f32 (log2, ~1 ulp) needs no denormal handling.
+// so the raw v_log_f32 (log2, ~1 ulp) needs no denormal handling, and no log1p series is needed either: the
+// log term is added to max(x, 0) - log 2, so only its ABSOLUTE error (< 1e-7) matters - the same as in the
+// reference, which also forms log1p(exp(x)) - log 2 in fp32.
 __device__ __forceinline__ float ssp(float x) {
   const float z = exp_neg(-fabsf(x));
-  const float lg = __builtin_amdgcn_logf(1.0f + z) * 0.693147180559945309417f;
-  const float sr = z * (1.0f - z * (0.5f - z * 0.33333334f));  // log1p series where 1 + z would lose the low bits
-  const float l = z < 0.0078125f ? sr : lg;
-  return (fmaxf(x, 0.0f) + l) - GEOSSL_SSP_SHIFT;
+  const float l = __builtin_amdgcn_logf(1.0f + z);  // log2(1 + exp(-|x|))
+  return fmaf(l, 0.693147180559945309417f, fmaxf(x, 0.0f)) - GEOSSL_SSP_SHIFT;
 }
 // d ssp / dx = sigmoid(x), recovered from the saved output t = ssp(x):
 // exp(-softplus(x)) = 1 - sigmoid(x)  =>  sigmoid(x) = 1 - 0.5*exp(-t)   (0.5 = exp(-log 2))
