@@ -269,16 +269,24 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
     }
     if constexpr (roleA) {
       // dt = dO W2 for this wave's hidden units (back-to-back MFMAs on one accumulator forward SrcC without a stall)
-      f32x16 acc0;
+      f32x16 acc0, acc1;  // small-weight and large-weight piece products apart: better conditioned, and two
+                          // independent MFMA chains
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc0[r] = 0.0f;
+      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
 #pragma unroll
       for (int ks = 0; ks < KC; ++ks) {
         Frag3 a0;
         const u32x4* s0 = L.dOr + (size_t)(ks * 3) * 64 + lane;
         a0.h = s0[0]; a0.m = s0[64]; a0.l = s0[128];
-        mma6(acc0, a0, bw2[ks]);
+        acc1 = mfma_bf16(a0.l, bw2[ks].h, acc1);
+        acc0 = mfma_bf16(a0.m, bw2[ks].h, acc0);
+        acc1 = mfma_bf16(a0.h, bw2[ks].l, acc1);
+        acc0 = mfma_bf16(a0.h, bw2[ks].m, acc0);
+        acc1 = mfma_bf16(a0.m, bw2[ks].m, acc1);
+        acc0 = mfma_bf16(a0.h, bw2[ks].h, acc0);
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
       // dU = dt * ssp'(pre) (C layout: lane = hidden unit, register = pair row); registers 0..7 / 8..15 are the
       // elements of k-steps 0 / 1 of the contraction over pair rows
       Frag3 du[2];
