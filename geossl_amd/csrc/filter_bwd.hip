@@ -278,12 +278,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
         Frag3 a0;
         const u32x4* s0 = L.dOr + (size_t)(ks * 3) * 64 + lane;
         a0.h = s0[0]; a0.m = s0[64]; a0.l = s0[128];
-        acc1 = mfma_bf16(a0.l, bw2[ks].h, acc1);
-        acc0 = mfma_bf16(a0.m, bw2[ks].h, acc0);
-        acc1 = mfma_bf16(a0.h, bw2[ks].l, acc1);
-        acc0 = mfma_bf16(a0.h, bw2[ks].m, acc0);
-        acc1 = mfma_bf16(a0.m, bw2[ks].m, acc1);
-        acc0 = mfma_bf16(a0.h, bw2[ks].h, acc0);
+        mma6x2(acc1, acc0, a0, bw2[ks]);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
