@@ -40,24 +40,23 @@ struct BwdLds {
   u32x4* dOr;    // [KC][3][64]
   u32x4* dOf;    // [CB][2][3][64]
   u32x4* rbf;    // [2][2][3][64]
-  float* xs;     // [ATOM_CAP][AS]
-  float* ds;     // [ATOM_CAP][AS]
-  float* tdd;    // [TR] distances of the tile's rows
-  int4* desc;    // [TR] {offset of atom i, of atom j (LDS floats if staged, else atom index), C*flag0, C*flag1}
-  int* s_amax;   // [4]
+  // staging arrays, double buffered (buffer t & 1 serves tile t): written during the MFMA phase of tile t-1, read
+  // only by the build of tile t
+  static constexpr int STAGE_FLOATS = 2 * ATOM_CAP * AS + TR + 4 * TR + 4;  // xs, ds, tdd, desc (int4), flags
+  float* stage0;
+  __device__ float* xs(int b) const { return stage0 + b * STAGE_FLOATS; }                       // [ATOM_CAP][AS]
+  __device__ float* ds(int b) const { return xs(b) + ATOM_CAP * AS; }                            // [ATOM_CAP][AS]
+  __device__ float* tdd(int b) const { return ds(b) + ATOM_CAP * AS; }                           // [TR] distances
+  // [TR] {offset of atom i, of atom j (LDS floats if staged, else atom index), C*flag0, C*flag1}
+  __device__ int4* desc(int b) const { return reinterpret_cast<int4*>(tdd(b) + TR); }
+  __device__ int* flag(int b) const { return reinterpret_cast<int*>(desc(b) + TR); }             // [0] = window fits
   __device__ explicit BwdLds(uint8_t* smem) {
     dOr = reinterpret_cast<u32x4*>(smem);
     dOf = dOr + KC * 3 * 64;
     rbf = dOf + CB * 2 * 3 * 64;
-    xs = reinterpret_cast<float*>(rbf + 2 * 2 * 3 * 64);
-    ds = xs + ATOM_CAP * AS;
-    tdd = ds + ATOM_CAP * AS;
-    desc = reinterpret_cast<int4*>(tdd + TR);
-    s_amax = reinterpret_cast<int*>(desc + TR);
+    stage0 = reinterpret_cast<float*>(rbf + 2 * 2 * 3 * 64);
   }
-  static size_t bytes() {
-    return (size_t)(KC * 3 + CB * 6 + 12) * 1024 + (size_t)(2 * ATOM_CAP * AS + TR) * 4 + TR * 16 + 16;
-  }
+  static size_t bytes() { return (size_t)(KC * 3 + CB * 6 + 12) * 1024 + (size_t)2 * STAGE_FLOATS * 4; }
 };
 
 template <int NW, bool ROLE_A>
@@ -122,13 +121,13 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
   constexpr int NPRE = (ATOM_CAP * Q + NTB - 1) / NTB;      // float4 per staging thread and array
   const int stid = tid - NTB;                               // role B: 0 .. NTB-1
   f32x4 px[roleA ? 1 : NPRE], pdg[roleA ? 1 : NPRE];
-  int ai = 0, aj = 0, alo = 0, alo_next = 0;
+  int ai = 0, aj = 0;
   float cval = 0.0f, dd = 0.0f;
   unsigned fl_raw = 0u;
   float tc[16];
-  auto request = [&](int tt, int alo_t) {  // everything tile tt needs from global memory
-    const int rr0 = tt * TR;
+  auto request_atoms = [&](int tt, int alo_t) {  // role B: window of x / dagg rows + the row descriptors of tile tt
     if constexpr (!roleA) {
+      const int rr0 = tt * TR;
       // clamped addresses, no predication (a predicated load compiles to a branch with a full wait per element);
       // slots past the window are never read back
       const int nwin = min(ATOM_CAP, N - alo_t);
@@ -149,8 +148,11 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
         dd = pair_d[q];
       }
     }
-    // saved hidden activation of this lane's hidden unit: role A in C layout (register r <-> row c_row(r)), role B
-    // in B-fragment layout (k-step s, element e <-> row 16s + 8kh + e); rows past P are clamped (their dO is 0)
+  };
+  // saved hidden activation of this lane's hidden unit: role A in C layout (register r <-> row c_row(r)), role B in
+  // B-fragment layout (k-step s, element e <-> row 16s + 8kh + e); rows past P are clamped (their dO is 0)
+  auto request_t = [&](int tt) {
+    const int rr0 = tt * TR;
     if constexpr (roleA) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) tc[r] = Tl[(uint32_t)min(rr0 + c_row(r, lane), P - 1) * (uint32_t)F + tcol];
@@ -160,46 +162,62 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
         tc[r] = Tl[(uint32_t)min(rr0 + 16 * (r >> 3) + 8 * kh + (r & 7), P - 1) * (uint32_t)F + tcol];
     }
   };
-  if (t_begin < t_end) {
-    alo = pair_i[t_begin * TR];
-    if (t_begin + 1 < t_end) alo_next = pair_i[(t_begin + 1) * TR];
-    request(t_begin, alo);
-  }
-  for (int t = t_begin; t < t_end; ++t) {
-    const int r0 = t * TR;
-    const int nwin = min(ATOM_CAP, N - alo);
-    __syncthreads();  // previous tile fully consumed: LDS may be overwritten
+  // role B: publish the window + descriptors held in registers (requested earlier) as tile tt's staging buffer
+  auto publish = [&](int tt, int alo_t) {
     if constexpr (!roleA) {
+      const int bsel = tt & 1, rr0 = tt * TR;
+      const int nwin = min(ATOM_CAP, N - alo_t);
       if (wave == NW) {
         int amax = lane < TR ? aj + 1 : 0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o, 64));
-        const bool staged0 = amax - alo <= ATOM_CAP;
+        const bool staged0 = amax - alo_t <= ATOM_CAP;
         if (lane < TR) {
-          const unsigned fl = r0 + lane < P ? fl_raw : 0u;  // rows past P contribute nothing
+          const unsigned fl = rr0 + lane < P ? fl_raw : 0u;  // rows past P contribute nothing
           const float m0 = (fl & 1u) ? cval : 0.0f, m1 = (fl & 2u) ? cval : 0.0f;
-          L.tdd[lane] = dd;
-          L.desc[lane] = staged0 ? make_int4((ai - alo) * AS, (aj - alo) * AS, __float_as_int(m0), __float_as_int(m1))
-                                 : make_int4(ai, aj, __float_as_int(m0), __float_as_int(m1));
+          L.tdd(bsel)[lane] = dd;
+          L.desc(bsel)[lane] = staged0 ? make_int4((ai - alo_t) * AS, (aj - alo_t) * AS, __float_as_int(m0), __float_as_int(m1))
+                                       : make_int4(ai, aj, __float_as_int(m0), __float_as_int(m1));
         }
-        if (lane == 0) *L.s_amax = amax;
+        if (lane == 0) L.flag(bsel)[0] = staged0 ? 1 : 0;
       }
+      float* xs = L.xs(bsel);
+      float* ds = L.ds(bsel);
 #pragma unroll
       for (int u = 0; u < NPRE; ++u) {
         const int i = stid + NTB * u;
         if (i < nwin * Q) {
           const int a = i / Q, q4 = i - a * Q;
-          *reinterpret_cast<f32x4*>(L.xs + a * AS + 4 * q4) = px[u];
-          *reinterpret_cast<f32x4*>(L.ds + a * AS + 4 * q4) = pdg[u];
+          *reinterpret_cast<f32x4*>(xs + a * AS + 4 * q4) = px[u];
+          *reinterpret_cast<f32x4*>(ds + a * AS + 4 * q4) = pdg[u];
         }
       }
     }
-    __syncthreads();
-    const bool staged = *L.s_amax - alo <= ATOM_CAP;
+  };
+  // prologue: tile t_begin published, atoms of tile t_begin + 1 in flight, activations of tile t_begin in flight.
+  // alo_a = first atom of the window of the tile whose atoms are held in registers, alo_b = of the tile after it
+  // (= pair_i[r0]: pair slots are lexicographic inside a molecule; fetched one step ahead of their use).
+  int alo_a = 0, alo_b = 0;
+  if (t_begin < t_end) {
+    alo_a = pair_i[t_begin * TR];
+    request_atoms(t_begin, alo_a);
+    request_t(t_begin);
+    publish(t_begin, alo_a);
+    if (t_begin + 1 < t_end) {
+      alo_a = pair_i[(t_begin + 1) * TR];
+      request_atoms(t_begin + 1, alo_a);
+      if (t_begin + 2 < t_end) alo_b = pair_i[(t_begin + 2) * TR];
+    }
+  }
+  for (int t = t_begin; t < t_end; ++t) {
+    const int r0 = t * TR;
+    const int bsel = t & 1;
+    __syncthreads();  // previous tile fully consumed; this tile's staging buffer published
+    const bool staged = L.flag(bsel)[0] != 0;
     // ---- tile build: every thread one dOr fragment lane, one dOf fragment lane, (half the threads) one rbf lane
     auto build = [&](const float* xb, const float* db, int stride) {
       {  // dOr: A[m = row][k = c = 16 r_ks + 8 r_kh + e]
-        const int4 q = L.desc[r_row];
+        const int4 q = L.desc(bsel)[r_row];
         const float qm0 = __int_as_float(q.z), qm1 = __int_as_float(q.w);
         const int c0 = 16 * r_ks + 8 * r_kh;
         const float* di = db + (size_t)q.x * stride + c0;
@@ -226,7 +244,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int4 q = L.desc[16 * f_ks + 8 * f_kh + e];
+          const int4 q = L.desc(bsel)[16 * f_ks + 8 * f_kh + e];
           const float qm0 = __int_as_float(q.z), qm1 = __int_as_float(q.w);
           v[e] = qm0 * (db[(size_t)q.x * stride + f_c] * xb[(size_t)q.y * stride + f_c]) +
                  qm1 * (db[(size_t)q.y * stride + f_c] * xb[(size_t)q.x * stride + f_c]);
@@ -239,7 +257,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
         dst[128] = f.l;
       }
     };
-    if (staged) build(L.xs, L.ds, 1);  // descriptors hold LDS float offsets
+    if (staged) build(L.xs(bsel), L.ds(bsel), 1);  // descriptors hold LDS float offsets
     else build(x, dagg, F);            // a run of tiny molecules: operands straight from global memory
     for (int it = tid; it < 2 * 2 * 64; it += NT) {  // rbf: B[k = row = 16ks + kperm(e, kh)][n = g]
       const int ln = it & 63, ks = (it >> 6) & 1, gb = it >> 7;
@@ -248,7 +266,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float diff = L.tdd[16 * ks + kperm(e, ln >> 5)] - off;
+        const float diff = L.tdd(bsel)[16 * ks + kperm(e, ln >> 5)] - off;
         v[e] = gg < G ? exp_neg(coeff * (diff * diff)) : 0.0f;
       }
       const Frag3 f = split8(v);
@@ -261,11 +279,16 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
 #pragma unroll
     for (int r = 0; r < 16; ++r) tcur[r] = tc[r];
     __syncthreads();
-    {  // requests of the next tile: in flight during this tile's MFMA phase
-      const int alo_t = alo_next;
-      alo = alo_t;
-      if (t + 2 < t_end) alo_next = pair_i[(t + 2) * TR];
-      if (t + 1 < t_end) request(t + 1, alo_t);
+    // While this tile is multiplied: publish the next tile's staging buffer (its atoms were requested one tile ago
+    // and have arrived), request the atoms of the tile after it and the next tile's saved activations.
+    if (t + 1 < t_end) {
+      publish(t + 1, alo_a);
+      if (t + 2 < t_end) {
+        alo_a = alo_b;
+        request_atoms(t + 2, alo_a);
+        if (t + 3 < t_end) alo_b = pair_i[(t + 3) * TR];
+      }
+      request_t(t + 1);
     }
     if constexpr (roleA) {
       // dt = dO W2 for this wave's hidden units (back-to-back MFMAs on one accumulator forward SrcC without a stall)
