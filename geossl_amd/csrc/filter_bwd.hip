@@ -7,20 +7,23 @@
 //     dt = dO W2 ;  dU = dt * ssp'(.) ;  dW1 += dU^T rbf ;  db1 += sum dU ;  dW2 += dO^T t ;  db2 += sum dO.
 //
 // A block works on 32-row tiles of pair slots.  A tile touches the atoms of at most a few molecules, so rows
-// a_lo.. of x_l and dagg_l are staged in LDS with coalesced 16-byte loads; from them all threads build, pre-split
+// a_lo.. of x_l and dagg_l are staged in LDS with coalesced 16-byte loads (double buffered: the staging arrays of tile
+// t+1 are published during the MFMA phase of tile t, two barriers per tile); from them the block builds, pre-split
 // into bf16 pieces and laid out as ready-made MFMA fragments (lane i at byte 16 i: conflict-free ds_read_b128),
-//     dOr : dO as A operand with the pair row on M and the channel c on K      (for dt = dO W2)
-//     dOf : dO as A operand with the channel c on M and the pair row on K      (for dW2 = dO^T t)
-//     rbf : Gaussian smearing as B operand with the pair row on K              (for dW1 = dU^T rbf)
-// The waves of a block are split by the hidden unit h they own (32 each) and by role:
-//   role A (waves 0..NW-1):  dt for its h slice (W2 slice as B fragments in registers), dU in place; the C layout of
-//       dt (lane = h, register = pair row in `kperm` order) IS the A-fragment layout of dW1's contraction over pair
-//       rows, so dU is split in registers and multiplied with the rbf fragments: dU never leaves the wave;
-//   role B (waves NW..2NW-1): loads the t slice of its h directly in B-fragment layout (lane = h, 8 pair rows),
-//       splits it in registers and accumulates dW2[:, h slice] against the dOf fragments.
-// T is read from HBM once (the second read of a slice hits L2), the dO tile is built once.  Weight-gradient
-// accumulators stay in registers across all tiles of a block; one partial per block, fixed-order reduction
-// afterwards (no atomics).
+//     dOr : dO as A operand with the pair row on M and the channel c on K      (for dt = dO W2; one lane per thread)
+//     rbf : Gaussian smearing as B operand with the pair row on K              (for dW1 = dU^T rbf; role-B threads)
+//     tf  : the saved activation t as B operand with the pair row on K         (for dW2 = dO^T t; role-A waves, from
+//           the C-layout registers they hold anyway)
+// The waves of a block are split by role:
+//   role A (waves 0..NW-1), hidden units [32w, 32w+32):  dt for its slice (W2 slice as B fragments in registers), dU
+//       in place; the C layout of dt (lane = h, register = pair row in `kperm` order) IS the A-fragment layout of
+//       dW1's contraction over pair rows, so dU is split in registers and multiplied with the rbf fragments;
+//   role B (waves NW..2NW-1), filter channels [32w, 32w+32):  dO with the channel on M is NOT evaluated a second
+//       time - the dOr fragments of the wave's channel block go through the matrix pipe against a 16 x 32 selection
+//       matrix (6 MFMAs), which lands them transposed in C layout = fragment order, exactly (a bf16 piece times
+//       1.0); then dW2[channel block, all h] against the tf fragments, db2 from the same registers.
+// T is read from HBM once, the dO tile is evaluated once.  Weight-gradient accumulators stay in registers across all
+// tiles of a block; one partial per block, fixed-order reduction afterwards (no atomics).
 #include "common.h"
 #include "geossl_hip.h"
 #include "split.h"
@@ -38,7 +41,7 @@ struct BwdLds {
   static constexpr int AS = F + 4;  // staged atom row stride (16-byte aligned rows)
   static constexpr int KC = F / 16, CB = F / 32;
   u32x4* dOr;    // [KC][3][64]
-  u32x4* dOf;    // [CB][2][3][64]
+  u32x4* dOf;    // [CB][2][3][64]  (tf: t fragments, hidden-unit block x k-step x piece)
   u32x4* rbf;    // [2][2][3][64]
   // staging arrays, double buffered (buffer t & 1 serves tile t): written during the MFMA phase of tile t-1, read
   // only by the build of tile t
@@ -70,7 +73,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
                                                 float* __restrict__ partial_b1, float* __restrict__ partial_w2,
                                                 float* __restrict__ partial_b2) {
   constexpr int F = 32 * NW, NT = 128 * NW, KC = F / 16, CB = F / 32, AS = BwdLds<F>::AS, Q = F / 4;
-  static_assert(TR * (F / 8) == NT && CB * 2 * 64 == NT, "one dOr and one dOf fragment lane per thread");
+  static_assert(TR * (F / 8) == NT, "one dOr fragment lane per thread");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
   const BwdLds<F> L(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
@@ -86,7 +89,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
   // ---- role A: W2 slice as B fragments of dt = dO W2:  B[k = c = 16ks + 8kh + e][n = h] = W2[c][h]
   Frag3 bw2[roleA ? KC : 1];
   f32x16 accw1[2];             // role A: dW1 rows [32hs, +32) x gaussians [0, 64): lane = g, register = h
-  f32x16 accw2[roleA ? 1 : CB];  // role B: dW2 rows c (register) x this slice's h (lane)
+  f32x16 accw2[roleA ? 1 : CB];  // role B: dW2 rows c of this wave's channel block (register) x all h (lane), per h block
   float bsum1 = 0.0f, bsum2 = 0.0f;
   if constexpr (roleA) {
     const float* w2 = w.w2[l] + 32 * hs + j;
@@ -107,9 +110,18 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
 #pragma unroll
       for (int r = 0; r < 16; ++r) accw2[cb][r] = 0.0f;
   }
+  // role B: selection matrices of the matrix-pipe transposition, as B fragments: step q (channels 16q..16q+15 of the
+  // wave's block), lane (n = j, half kh), element e:  1.0 (bf16 0x3F80) iff 16q + 8kh + e == j
+  u32x4 ident[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int w2i = 0; w2i < 4; ++w2i) {
+      const int e0 = 16 * q + 8 * kh + 2 * w2i;
+      ident[q][w2i] = (e0 == j ? 0x3F80u : 0u) | (e0 + 1 == j ? 0x3F800000u : 0u);
+    }
   // fragment-lane roles of this thread in the tile build
   const int r_row = tid & 31, r_kh = (tid >> 5) & 1, r_ks = tid >> 6;         // dOr: row, k half, k-step (c)
-  const int f_c = 32 * (tid / 128) + (tid & 31), f_kh = (tid >> 5) & 1, f_ks = (tid >> 6) & 1;  // dOf
   const int ntiles = (P + TR - 1) / TR;
   const int per = (ntiles + gridDim.x - 1) / gridDim.x;  // contiguous tile range per block (atom reuse in L2)
   const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
@@ -152,14 +164,10 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
   // saved hidden activation of this lane's hidden unit: role A in C layout (register r <-> row c_row(r)), role B in
   // B-fragment layout (k-step s, element e <-> row 16s + 8kh + e); rows past P are clamped (their dO is 0)
   auto request_t = [&](int tt) {
-    const int rr0 = tt * TR;
     if constexpr (roleA) {
+      const int rr0 = tt * TR;
 #pragma unroll
       for (int r = 0; r < 16; ++r) tc[r] = Tl[(uint32_t)min(rr0 + c_row(r, lane), P - 1) * (uint32_t)F + tcol];
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        tc[r] = Tl[(uint32_t)min(rr0 + 16 * (r >> 3) + 8 * kh + (r & 7), P - 1) * (uint32_t)F + tcol];
     }
   };
   // role B: publish the window + descriptors held in registers (requested earlier) as tile tt's staging buffer
@@ -240,40 +248,40 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
         dst[64] = f.m;
         dst[128] = f.l;
       }
-      {  // dOf: A[m = c][k = row = 16 f_ks + 8 f_kh + e]
+    };
+    if (staged) build(L.xs(bsel), L.ds(bsel), 1);  // descriptors hold LDS float offsets
+    else build(x, dagg, F);            // a run of tiny molecules: operands straight from global memory
+    if constexpr (roleA) {
+      // t slice of this wave's hidden units as B fragments of dW2's contraction over pair rows: the C layout held in
+      // tc (lane = h, register r <-> row c_row(r)) is the fragment layout with k-step s <-> registers 8s..8s+7
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int4 q = L.desc(bsel)[16 * f_ks + 8 * f_kh + e];
-          const float qm0 = __int_as_float(q.z), qm1 = __int_as_float(q.w);
-          v[e] = qm0 * (db[(size_t)q.x * stride + f_c] * xb[(size_t)q.y * stride + f_c]) +
-                 qm1 * (db[(size_t)q.y * stride + f_c] * xb[(size_t)q.x * stride + f_c]);
-          bsum2 += v[e];
-        }
+        for (int e = 0; e < 8; ++e) v[e] = tc[8 * s2 + e];
         const Frag3 f = split8(v);
-        u32x4* dst = L.dOf + (size_t)(((f_c >> 5) * 2 + f_ks) * 3) * 64 + ((f_c & 31) + 32 * f_kh);
+        u32x4* dst = L.dOf + (size_t)((hs * 2 + s2) * 3) * 64 + lane;
         dst[0] = f.h;
         dst[64] = f.m;
         dst[128] = f.l;
       }
-    };
-    if (staged) build(L.xs(bsel), L.ds(bsel), 1);  // descriptors hold LDS float offsets
-    else build(x, dagg, F);            // a run of tiny molecules: operands straight from global memory
-    for (int it = tid; it < 2 * 2 * 64; it += NT) {  // rbf: B[k = row = 16ks + kperm(e, kh)][n = g]
-      const int ln = it & 63, ks = (it >> 6) & 1, gb = it >> 7;
-      const int gg = 32 * gb + (ln & 31);
-      const float off = gg < G ? offset[gg] : 0.0f;
-      float v[8];
+    } else {
+      for (int it = tid - NT / 2; it < 2 * 2 * 64; it += NT / 2) {  // rbf: B[k = row = 16ks + kperm(e, kh)][n = g]
+        const int ln = it & 63, ks = (it >> 6) & 1, gb = it >> 7;
+        const int gg = 32 * gb + (ln & 31);
+        const float off = gg < G ? offset[gg] : 0.0f;
+        float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float diff = L.tdd(bsel)[16 * ks + kperm(e, ln >> 5)] - off;
-        v[e] = gg < G ? exp_neg(coeff * (diff * diff)) : 0.0f;
+        for (int e = 0; e < 8; ++e) {
+          const float diff = L.tdd(bsel)[16 * ks + kperm(e, ln >> 5)] - off;
+          v[e] = gg < G ? exp_neg(coeff * (diff * diff)) : 0.0f;
+        }
+        const Frag3 f = split8(v);
+        u32x4* dst = L.rbf + (size_t)((gb * 2 + ks) * 3) * 64 + ln;
+        dst[0] = f.h;
+        dst[64] = f.m;
+        dst[128] = f.l;
       }
-      const Frag3 f = split8(v);
-      u32x4* dst = L.rbf + (size_t)((gb * 2 + ks) * 3) * 64 + ln;
-      dst[0] = f.h;
-      dst[64] = f.m;
-      dst[128] = f.l;
     }
     float tcur[16];
 #pragma unroll
@@ -339,38 +347,58 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
         accw1[1] = mfma_bf16(du[s].h, b1.h, accw1[1]);
       }
     } else {
-      // dW2[c][h] += sum_rows dO[row][c] * t[row][h]
-      Frag3 tb[2];
+      // Role B wave w owns filter output channels c in [32w, 32w+32).  Its dO^T fragments (lane = c, 8 pair rows) come
+      // from the dOr fragments through the matrix pipe: D = dOr_piece * I (I = 16 x 32 selection of the channel block)
+      // lands in C layout - lane = c, register = pair row in kperm order - i.e. in fragment order, and every value is
+      // an exact bf16 number (one piece times 1), so packing is exact.  No second evaluation of dO in the other
+      // orientation, no LDS traffic for it.
+      f32x16 tp[3];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        float v[8];
+      for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = tcur[8 * s + e];
-        tb[s] = split8(v);
+        for (int r = 0; r < 16; ++r) tp[pc][r] = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const u32x4* s0 = L.dOr + (size_t)((2 * hs + q) * 3) * 64 + lane;
+        tp[0] = mfma_bf16(s0[0], ident[q], tp[0]);
+        tp[1] = mfma_bf16(s0[64], ident[q], tp[1]);
+        tp[2] = mfma_bf16(s0[128], ident[q], tp[2]);
       }
+      Frag3 da[2];  // A fragments of dW2 = dO^T t: k-step s <-> registers 8s..8s+7
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          da[s2].h[q] = pk_bf16(tp[0][8 * s2 + 2 * q], tp[0][8 * s2 + 2 * q + 1]);
+          da[s2].m[q] = pk_bf16(tp[1][8 * s2 + 2 * q], tp[1][8 * s2 + 2 * q + 1]);
+          da[s2].l[q] = pk_bf16(tp[2][8 * s2 + 2 * q], tp[2][8 * s2 + 2 * q + 1]);
+        }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bsum2 += (tp[0][r] + tp[1][r]) + tp[2][r];  // db2: rows of this half-wave
+      // dW2[c][h] += sum_rows dO[row][c] * t[row][h], all four 32-wide blocks of h (t fragments published by role A)
       constexpr int CP = CB >= 2 ? 2 : 1;
 #pragma unroll
-      for (int cb = 0; cb < CB; cb += CP) {
+      for (int hb = 0; hb < CB; hb += CP) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          Frag3 a[CP];
+        for (int s2 = 0; s2 < 2; ++s2) {
+          Frag3 tb[CP];
 #pragma unroll
           for (int u = 0; u < CP; ++u) {
-            const u32x4* s0 = L.dOf + (size_t)(((cb + u) * 2 + s) * 3) * 64 + lane;
-            a[u].h = s0[0]; a[u].m = s0[64]; a[u].l = s0[128];
+            const u32x4* s0 = L.dOf + (size_t)(((hb + u) * 2 + s2) * 3) * 64 + lane;
+            tb[u].h = s0[0]; tb[u].m = s0[64]; tb[u].l = s0[128];
           }
 #pragma unroll
-          for (int u = 0; u < CP; ++u) accw2[cb + u] = mfma_bf16(a[u].l, tb[s].h, accw2[cb + u]);
+          for (int u = 0; u < CP; ++u) accw2[hb + u] = mfma_bf16(da[s2].l, tb[u].h, accw2[hb + u]);
 #pragma unroll
-          for (int u = 0; u < CP; ++u) accw2[cb + u] = mfma_bf16(a[u].h, tb[s].l, accw2[cb + u]);
+          for (int u = 0; u < CP; ++u) accw2[hb + u] = mfma_bf16(da[s2].h, tb[u].l, accw2[hb + u]);
 #pragma unroll
-          for (int u = 0; u < CP; ++u) accw2[cb + u] = mfma_bf16(a[u].m, tb[s].m, accw2[cb + u]);
+          for (int u = 0; u < CP; ++u) accw2[hb + u] = mfma_bf16(da[s2].m, tb[u].m, accw2[hb + u]);
 #pragma unroll
-          for (int u = 0; u < CP; ++u) accw2[cb + u] = mfma_bf16(a[u].m, tb[s].h, accw2[cb + u]);
+          for (int u = 0; u < CP; ++u) accw2[hb + u] = mfma_bf16(da[s2].m, tb[u].h, accw2[hb + u]);
 #pragma unroll
-          for (int u = 0; u < CP; ++u) accw2[cb + u] = mfma_bf16(a[u].h, tb[s].m, accw2[cb + u]);
+          for (int u = 0; u < CP; ++u) accw2[hb + u] = mfma_bf16(da[s2].h, tb[u].m, accw2[hb + u]);
 #pragma unroll
-          for (int u = 0; u < CP; ++u) accw2[cb + u] = mfma_bf16(a[u].h, tb[s].h, accw2[cb + u]);
+          for (int u = 0; u < CP; ++u) accw2[hb + u] = mfma_bf16(da[s2].h, tb[u].h, accw2[hb + u]);
         }
       }
     }
@@ -392,16 +420,13 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
   } else {
     float* Pw = partial_w2 + pb * F * F;
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
+    for (int hb = 0; hb < CB; ++hb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Pw[(size_t)(32 * cb + c_row(r, lane)) * F + 32 * hs + j] = accw2[cb][r];
+      for (int r = 0; r < 16; ++r) Pw[(size_t)(32 * hs + c_row(r, lane)) * F + 32 * hb + j] = accw2[hb][r];
+    // db2[c]: each half-wave summed the pair rows its registers hold
+    const float sb2 = bsum2 + __shfl_xor(bsum2, 32, 64);
+    if (kh == 0) partial_b2[pb * F + 32 * hs + j] = sb2;
   }
-  // db2: every thread holds the sum over its (k-step, half) share of the rows for channel f_c
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(L.dOr);  // [4][F]
-  red[(2 * f_ks + f_kh) * F + f_c] = bsum2;
-  __syncthreads();
-  if (tid < F) partial_b2[pb * F + tid] = (red[tid] + red[F + tid]) + (red[2 * F + tid] + red[3 * F + tid]);
 }
 
 // The two roles run separate instantiations of the body (their register sets differ: W2 fragments + dW1
