@@ -304,12 +304,23 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
                           // independent MFMA chains
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+      {
+        Frag3 a0, an;  // fragments of the next k-step are requested before this step's MFMAs issue
+        {
+          const u32x4* s0 = L.dOr + lane;
+          a0.h = s0[0]; a0.m = s0[64]; a0.l = s0[128];
+        }
 #pragma unroll
-      for (int ks = 0; ks < KC; ++ks) {
-        Frag3 a0;
-        const u32x4* s0 = L.dOr + (size_t)(ks * 3) * 64 + lane;
-        a0.h = s0[0]; a0.m = s0[64]; a0.l = s0[128];
-        mma6x2(acc1, acc0, a0, bw2[ks]);
+        for (int ks = 0; ks < KC; ++ks) {
+          if (ks + 1 < KC) {
+            const u32x4* s0 = L.dOr + (size_t)((ks + 1) * 3) * 64 + lane;
+            an.h = s0[0]; an.m = s0[64]; an.l = s0[128];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mma6x2(acc1, acc0, a0, bw2[ks]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (ks + 1 < KC) a0 = an;
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
