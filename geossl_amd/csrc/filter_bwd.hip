@@ -503,16 +503,12 @@ extern "C" int geossl_cfconv_filter_bwd(const float* pair_d, const float* pair_c
   if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
 #undef LAUNCH
   GEOSSL_CHECK_LAUNCH();
-  GeosslReduceBatch rb;
-  auto reduce = [&](float* const* dst, const float* partial, int nblk, int len, int ncols) {
-    for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = z < L ? dst[z] : nullptr;
-    hipLaunchKernelGGL(k_reduce_partials, dim3((len + 63) / 64, L), dim3(256), 0, stream, rb, partial, nblk, len, ncols,
-                       ncols, 1, accumulate);
-  };
-  reduce(out->dw1, pw1, nb, F * G, G);
-  reduce(out->db1, pb1, nb, F, F);
-  reduce(out->dw2, pw2, nb, F * F, F);
-  reduce(out->db2, pb2, nb, F, F);
+  ReduceMulti rm;  // the four fixed-order partial sums in one launch
+  rm.add(pw1, F * G, G, G, 1, out->dw1, L);
+  rm.add(pb1, F, F, F, 1, out->db1, L);
+  rm.add(pw2, F * F, F, F, 1, out->dw2, L);
+  rm.add(pb2, F, F, F, 1, out->db2, L);
+  hipLaunchKernelGGL(k_reduce_multi, dim3(rm.blocks(), L), dim3(256), 0, stream, rm, nb, accumulate);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

@@ -11,6 +11,33 @@ namespace geossl {
 __global__ void k_reduce_partials(GeosslReduceBatch batch, const float* __restrict__ partial, int nblk, int len,
                                   int ncols, int ld, int cstride, int accumulate);
 
+// Several reductions of one producer kernel in ONE launch (they share nblk and the z dimension): segment g covers
+// blockIdx.x in [xoff[g], xoff[g+1]).
+struct ReduceSeg {
+  const float* partial;  // [z][nblk][len]
+  int len, ncols, ld, cstride;
+  float* out[GEOSSL_TN_MAX];
+};
+struct ReduceMulti {
+  int nseg;
+  int xoff[5];
+  ReduceSeg seg[4];
+  ReduceMulti() : nseg(0) { xoff[0] = 0; }
+  void add(const float* partial, int len, int ncols, int ld, int cstride, float* const* out, int nz) {
+    ReduceSeg& g = seg[nseg];
+    g.partial = partial;
+    g.len = len;
+    g.ncols = ncols;
+    g.ld = ld;
+    g.cstride = cstride;
+    for (int z = 0; z < GEOSSL_TN_MAX; ++z) g.out[z] = z < nz ? out[z] : nullptr;
+    xoff[nseg + 1] = xoff[nseg] + (len + 63) / 64;
+    ++nseg;
+  }
+  int blocks() const { return xoff[nseg]; }
+};
+__global__ void k_reduce_multi(ReduceMulti m, int nblk, int accumulate);
+
 inline int64_t tn_workspace_floats(int64_t R, int M, int N, int nprob) {
   int chunk, nblk;
   geossl_tn_plan(R, nprob, &chunk, &nblk);

@@ -194,21 +194,11 @@ int launch_wgrad_split(const Ops& ops, int nprob, int64_t R, int M, int N, const
   hipLaunchKernelGGL((k_wgrad_split<NCM, NCN, Ops>), dim3(nblk, nprob), dim3(256), lds, stream, ops, (int)R, chunk, M,
                      N, partial, any_b ? pbias : nullptr, any_d ? pdot : nullptr);
   GEOSSL_CHECK_LAUNCH();
-  GeosslReduceBatch rb;
-  for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = z < nprob ? out.dW[z] : nullptr;
-  const int len = M * N;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((len + 63) / 64, nprob), dim3(256), 0, stream, rb, partial, nblk, len, N,
-                     dW_ld, 1, accumulate);
-  if (any_b) {
-    for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = z < nprob ? out.db[z] : nullptr;
-    hipLaunchKernelGGL(k_reduce_partials, dim3((M + 63) / 64, nprob), dim3(256), 0, stream, rb, pbias, nblk, M, M, M,
-                       1, accumulate);
-  }
-  if (any_d) {
-    for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = z < nprob ? out.dd[z] : nullptr;
-    hipLaunchKernelGGL(k_reduce_partials, dim3((M + 63) / 64, nprob), dim3(256), 0, stream, rb, pdot, nblk, M, M, M,
-                       dd_stride, accumulate);
-  }
+  ReduceMulti rm;  // dW, db and dd partial sums in one launch
+  rm.add(partial, M * N, N, dW_ld, 1, out.dW, nprob);
+  if (any_b) rm.add(pbias, M, M, M, 1, out.db, nprob);
+  if (any_d) rm.add(pdot, M, M, M, dd_stride, out.dd, nprob);
+  hipLaunchKernelGGL(k_reduce_multi, dim3(rm.blocks(), nprob), dim3(256), 0, stream, rm, nblk, accumulate);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
