@@ -213,15 +213,15 @@ __global__ __launch_bounds__(512) void k_linear_split(const float* __restrict__ 
     bias_s[i] = (flags & GEOSSL_EPI_BIAS) && n0 + i < NO ? bias[n0 + i] : 0.0f;
   const int nitems = nmb * KS * 64;
   if (image != nullptr) {
-    // prepared weights: the block's slice of the fragment image is copied as is (coalesced 16-byte loads, four in
-    // flight per thread)
+    // prepared weights: the block's slice of the fragment image is copied as is (coalesced 16-byte loads, twelve in
+    // flight per thread = the whole 96 KB image of a 128 x 128 weight in one round trip)
     const u32x4* src = image + (size_t)blockIdx.y * nitems * 3;
-    for (int i0 = tid; i0 < 3 * nitems; i0 += 4 * 512) {
-      u32x4 t[4];
+    for (int i0 = tid; i0 < 3 * nitems; i0 += 12 * 512) {
+      u32x4 t[12];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) t[u] = src[min(i0 + 512 * u, 3 * nitems - 1)];
+      for (int u = 0; u < 12; ++u) t[u] = src[min(i0 + 512 * u, 3 * nitems - 1)];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 12; ++u)
         if (i0 + 512 * u < 3 * nitems) Wf[i0 + 512 * u] = t[u];
     }
   } else {
