@@ -72,6 +72,8 @@ PROTOTYPES = {
     "geossl_linear": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]),
     "geossl_tn_plan": (None, [i64, i32, P(i32), P(i32)]),
     "geossl_tn_workspace_floats": (i64, [i64, i32, i32, i32]),
+    "geossl_row_normalize_fwd": (i32, [vp, i64, i32, f32, vp, vp, vp]),
+    "geossl_row_normalize_bwd": (i32, [vp, vp, vp, i64, i32, f32, vp, vp]),
     "geossl_atom_tuples": (i32, [vp, vp, i64, i32, vp, vp, vp]),
     "geossl_linear_image_words": (i64, [i32, i32]),
     "geossl_linear_prepare": (i32, [P(PrepareBatch), i32, i32, i32, i32, vp]),

@@ -173,6 +173,39 @@ __global__ void k_segment_reduce_bwd(const float* __restrict__ dout, const int32
   }
 }
 
+// ----------------------------------------------------------------------------------- F.normalize(h, dim=-1)
+// pretrain_GeoSSL.py:193-195 (--normalize): y = h / max(||h||_2, eps), one wave per row; the norm is kept for the
+// backward  dh = (g - y (g . y)) / max(||h||, eps)   (zero gradient through the clamp when ||h|| < eps, like ATen).
+__global__ __launch_bounds__(256) void k_row_normalize_fwd(const float* __restrict__ h, int64_t N, int F, float eps,
+                                                           float* __restrict__ y, float* __restrict__ norm) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float* hr = h + row * F;
+  float ss = 0.0f;
+  for (int f = lane; f < F; f += 64) ss = fmaf(hr[f], hr[f], ss);
+  ss = wave_sum(ss);
+  const float nr = sqrtf(ss), den = fmaxf(nr, eps);
+  for (int f = lane; f < F; f += 64) y[row * F + f] = hr[f] / den;
+  if (lane == 0 && norm != nullptr) norm[row] = nr;
+}
+__global__ __launch_bounds__(256) void k_row_normalize_bwd(const float* __restrict__ g, const float* __restrict__ y,
+                                                           const float* __restrict__ norm, int64_t N, int F, float eps,
+                                                           float* __restrict__ dh) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float* gr = g + row * F;
+  const float* yr = y + row * F;
+  float dot = 0.0f;
+  for (int f = lane; f < F; f += 64) dot = fmaf(gr[f], yr[f], dot);
+  dot = wave_sum(dot);
+  const float nr = norm[row];
+  const bool clamped = nr < eps;  // y = h / eps there: the norm does not depend on h
+  const float inv = 1.0f / fmaxf(nr, eps);
+  for (int f = lane; f < F; f += 64) dh[row * F + f] = (clamped ? gr[f] : gr[f] - yr[f] * dot) * inv;
+}
+
 template <typename K>
 inline void allow_big_lds(K kernel) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -206,6 +239,22 @@ extern "C" int geossl_cfconv_aggregate(const float* x, const float* Wf, const ui
   allow_big_lds(&k_aggregate);
   hipLaunchKernelGGL(k_aggregate, dim3((unsigned)B), dim3(F > 64 ? 128 : 64), lds, stream, x, Wf, pair_flag, mol_ptr,
                      pair_ptr, (int)B, F, max_n, swap, out);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_row_normalize_fwd(const float* h, int64_t N, int F, float eps, float* y, float* norm,
+                                        hipStream_t stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(k_row_normalize_fwd, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, h, N, F, eps, y, norm);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int geossl_row_normalize_bwd(const float* g, const float* y, const float* norm, int64_t N, int F, float eps,
+                                        float* dh, hipStream_t stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(k_row_normalize_bwd, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, g, y, norm, N, F, eps,
+                     dh);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

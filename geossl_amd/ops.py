@@ -179,3 +179,31 @@ def add_scaled(a, b, alpha=1.0):
     out = torch.empty_like(a)
     call("geossl_axpy", ptr(a), ptr(b), float(alpha), a.numel(), ptr(out), stream())
     return out
+
+
+class _RowNormalize(torch.autograd.Function):
+    """F.normalize(h, dim=-1) (pretrain_GeoSSL.py:193-195) on the HIP path."""
+
+    @staticmethod
+    def forward(ctx, h, eps):
+        h = _f32(h)
+        N, F = h.shape
+        y = torch.empty_like(h)
+        norm = torch.empty(N, dtype=torch.float32, device=h.device) if ctx.needs_input_grad[0] else None
+        call("geossl_row_normalize_fwd", ptr(h), N, F, float(eps), ptr(y), ptr(norm), stream())
+        ctx.save_for_backward(y, norm)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, norm = ctx.saved_tensors
+        N, F = y.shape
+        dh = torch.empty_like(y)
+        call("geossl_row_normalize_bwd", ptr(g.contiguous()), ptr(y), ptr(norm), N, F, ctx.eps, ptr(dh), stream())
+        return dh, None
+
+
+def row_normalize(h, eps=1e-12):
+    _lib.require_cuda(h)
+    return _RowNormalize.apply(h, eps)

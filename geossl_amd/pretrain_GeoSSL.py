@@ -112,8 +112,9 @@ def do_DDM(args, batch, model, criterion=None, mu=0.0, sigma=0.3, num_neg=1, NCS
     else:
         raise Exception("3D model {} not included.".format(args.model_3d))
 
-    if getattr(args, "normalize", False):
-        raise NotImplementedError("--normalize (pretrain_GeoSSL.py:193-195) is unset in the DDM scripts and not built")
+    if getattr(args, "normalize", False):  # :193-195
+        molecule_3D_repr_01 = ops.row_normalize(molecule_3D_repr_01)
+        molecule_3D_repr_02 = ops.row_normalize(molecule_3D_repr_02)
 
     super_edge_index = batch.super_edge_index
     distance_01 = ops.pair_distance(positions_01, super_edge_index[0], super_edge_index[1])  # :199-201

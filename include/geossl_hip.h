@@ -169,6 +169,12 @@ int geossl_embedding_bwd(const int64_t* z, int64_t z_stride, const float* dh, in
  * mean = sum / max(count,1).  _bwd: dh[a] = dout[batch[a]] (/count).                                          */
 int geossl_segment_reduce_fwd(const float* h, const int32_t* mol_ptr, int64_t B, int F, int mean, float* out,
                               hipStream_t stream);
+/* F.normalize(h, dim=-1) of the optional --normalize branch of do_DDM (pretrain_GeoSSL.py:193-195):
+ * y = h / max(||h||_2, eps) per row; norm[N] (may be NULL in inference) is kept for the backward
+ * dh = (g - y (g . y)) / max(||h||, eps).                                                                     */
+int geossl_row_normalize_fwd(const float* h, int64_t N, int F, float eps, float* y, float* norm, hipStream_t stream);
+int geossl_row_normalize_bwd(const float* g, const float* y, const float* norm, int64_t N, int F, float eps,
+                             float* dh, hipStream_t stream);
 int geossl_segment_reduce_bwd(const float* dout, const int32_t* mol_ptr, int64_t B, int F, int mean, float* dh,
                               int accumulate, hipStream_t stream);
 

@@ -439,6 +439,54 @@ def test_do_ddm_golden(tag, fuse):
             assert rel_err(got, g[k]) < TOL_GRAD, k
 
 
+def test_row_normalize_vs_torch():
+    """geossl_row_normalize_fwd/bwd against F.normalize (the --normalize branch, pretrain_GeoSSL.py:193-195), incl. an
+    all-zero row (clamped norm: y = 0, gradient g / eps like ATen) and a row below eps."""
+    from geossl_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    h = torch.randn(333, 128, generator=gen)
+    h[7] = 0.0
+    h[9] = 1e-20
+    g = torch.randn(333, 128, generator=gen)
+    a = h.clone().to(DEV).requires_grad_()
+    ya = ops.row_normalize(a)
+    ya.backward(g.to(DEV))
+    b = h.clone().double().requires_grad_()
+    yb = torch.nn.functional.normalize(b, dim=-1)
+    yb.backward(g.double())
+    assert rel_err(ya.detach().cpu(), yb.detach()) < 1e-6
+    keep = torch.ones(333, dtype=torch.bool)
+    keep[7] = keep[9] = False  # clamped rows: gradients are g / 1e-12, compared on their own scale
+    assert rel_err(a.grad.cpu()[keep], b.grad[keep]) < 1e-6
+    assert rel_err(a.grad.cpu()[~keep], b.grad[~keep]) < 1e-5
+
+
+def test_do_ddm_normalize_vs_oracle():
+    """do_DDM with args.normalize (L2-normalised node features before the heads) against the oracle."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    from oracle import nets
+    cfg = dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=5.0, node_class=9,
+               readout="mean")
+    b = make_batch(24, seed=4, mode="B")
+    nz = draw_noise(b, seed=5)
+    model = product_schnet(cfg, DEV)
+    n1, n2 = product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9)
+    batch = pg.Batch.from_numpy(b, DEV)
+    noise = {k: t(v, DEV) for k, v in nz.items()}
+    loss, _ = pg.do_DDM(pg.Args("schnet", normalize=True), batch, model, None, 0.0, 0.3, NCSN_models=(n1, n2), noise=noise)
+    loss.backward()
+    Pm, P1, P2 = schnet_oracle_params(cfg), ncsn_oracle_params(128, 50), ncsn_oracle_params(128, 50, 0.9)
+    ref = nets.do_ddm_schnet(Pm, P1, P2, t(b["x"]), t(b["positions"]), t(b["batch"]), t(b["super_edge_index"]),
+                             t(nz["pos_noise"]), t(nz["noise_level_1"]), t(nz["dist_noise_1"]), t(nz["noise_level_2"]),
+                             t(nz["dist_noise_2"]), 5.0, 6, 2, "mean", normalize=True)
+    ref.backward()
+    assert rel_err(loss.detach().cpu(), ref.detach()) < TOL_OUT
+    g = unique_named_grads(model)
+    for k in ("lin2.weight", "interactions.0.mlp.0.weight", "interactions.5.conv.lin1.weight", "embedding.weight"):
+        assert rel_err(g[k].cpu(), Pm[k].grad) < TOL_GRAD, k
+
+
 def test_ddm_full_size_vs_oracle_sample_and_determinism():
     """BASELINE config (1024 molecules, n=18, r=5 A): the loss is reproducible bit for bit across two
     runs (no atomics anywhere), and equals the oracle on a 64-molecule slice of the same batch."""
