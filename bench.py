@@ -118,15 +118,15 @@ def main():
     from geossl_amd import pretrain_GeoSSL as pg
     from geossl_amd.Geom3D.models import SchNet
     from geossl_amd.NCSN import NCSN_version_03
-    from geossl_amd.parallel import init_distributed
+    from geossl_amd.parallel import init_distributed, local_device
     from geossl_amd.synthetic import make_batch
     import torch.distributed as dist
 
     rank, local_rank, world = init_distributed()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_device(local_rank))
+    torch.cuda.set_device(dev)
     _lib.load()
 
     torch.manual_seed(1234)  # identical initial weights on every rank

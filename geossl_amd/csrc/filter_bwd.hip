@@ -41,7 +41,7 @@ struct BwdLds {
   static constexpr int AS = F + 4;  // staged atom row stride (16-byte aligned rows)
   static constexpr int KC = F / 16, CB = F / 32;
   u32x4* dOr;    // [KC][3][64]
-  u32x4* dOf;    // [CB][2][3][64]  (tf: t fragments, hidden-unit block x k-step x piece)
+  u32x4* tf;     // [CB][2][3][64]  t fragments: hidden-unit block x k-step x piece
   u32x4* rbf;    // [2][2][3][64]
   // staging arrays, double buffered (buffer t & 1 serves tile t): written during the MFMA phase of tile t-1, read
   // only by the build of tile t
@@ -55,8 +55,8 @@ struct BwdLds {
   __device__ int* flag(int b) const { return reinterpret_cast<int*>(desc(b) + TR); }             // [0] = window fits
   __device__ explicit BwdLds(uint8_t* smem) {
     dOr = reinterpret_cast<u32x4*>(smem);
-    dOf = dOr + KC * 3 * 64;
-    rbf = dOf + CB * 2 * 3 * 64;
+    tf = dOr + KC * 3 * 64;
+    rbf = tf + CB * 2 * 3 * 64;
     stage0 = reinterpret_cast<float*>(rbf + 2 * 2 * 3 * 64);
   }
   static size_t bytes() { return (size_t)(KC * 3 + CB * 6 + 12) * 1024 + (size_t)2 * STAGE_FLOATS * 4; }
@@ -222,7 +222,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
     const int bsel = t & 1;
     __syncthreads();  // previous tile fully consumed; this tile's staging buffer published
     const bool staged = L.flag(bsel)[0] != 0;
-    // ---- tile build: every thread one dOr fragment lane, one dOf fragment lane, (half the threads) one rbf lane
+    // ---- tile build: every thread one dOr fragment lane; role A publishes its tf lanes, role B its rbf lanes
     auto build = [&](const float* xb, const float* db, int stride) {
       {  // dOr: A[m = row][k = c = 16 r_ks + 8 r_kh + e]
         const int4 q = L.desc(bsel)[r_row];
@@ -260,7 +260,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = tc[8 * s2 + e];
         const Frag3 f = split8(v);
-        u32x4* dst = L.dOf + (size_t)((hs * 2 + s2) * 3) * 64 + lane;
+        u32x4* dst = L.tf + (size_t)((hs * 2 + s2) * 3) * 64 + lane;
         dst[0] = f.h;
         dst[64] = f.m;
         dst[128] = f.l;
@@ -395,7 +395,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
           Frag3 tb[CP];
 #pragma unroll
           for (int u = 0; u < CP; ++u) {
-            const u32x4* s0 = L.dOf + (size_t)(((hb + u) * 2 + s2) * 3) * 64 + lane;
+            const u32x4* s0 = L.tf + (size_t)(((hb + u) * 2 + s2) * 3) * 64 + lane;
             tb[u].h = s0[0]; tb[u].m = s0[64]; tb[u].l = s0[128];
           }
 #pragma unroll

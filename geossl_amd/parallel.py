@@ -22,11 +22,18 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # GEOSSL_DIST_BACKEND=gloo: the N>1 code path on a box with fewer GPUs than ranks (ranks then share
+            # devices, see local_device) - a test aid, RCCL ("nccl") is the production transport
+            backend = os.environ.get("GEOSSL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def local_device(local_rank):
+    """Device index of this rank: LOCAL_RANK, wrapped only when ranks outnumber the visible GPUs (gloo test runs)."""
+    return local_rank % max(1, torch.cuda.device_count())
 
 
 def shard_molecules(num_mols, rank, world):

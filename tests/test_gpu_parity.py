@@ -620,6 +620,75 @@ def test_trainer_graph_replay_matches_eager():
     assert losses[True] == losses[False], losses
 
 
+_RANK_WORKER = r"""
+import os, sys
+sys.path.insert(0, {repo!r})
+sys.path.insert(0, os.path.join({repo!r}, "tests")); sys.path.insert(0, os.path.join({repo!r}, "tests", "golden"))
+import torch, torch.distributed as dist
+from geossl_amd import pretrain_GeoSSL as pg
+from geossl_amd.parallel import init_distributed, local_device, shard_batch_numpy
+from geossl_amd.synthetic import draw_noise, make_batch
+from helpers import product_ncsn, product_schnet, t
+rank, local_rank, world = init_distributed()          # GEOSSL_DIST_BACKEND=gloo: both ranks on cuda:0
+dev = torch.device("cuda", local_device(local_rank))
+torch.cuda.set_device(dev)
+cfg = dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=5.0, node_class=9,
+           readout="mean")
+tr = pg.DDMTrainer(product_schnet(cfg, dev), product_ncsn(128, 50, 2, dev), product_ncsn(128, 50, 2, dev, scale=0.9),
+                   lr=5e-4, use_graph=True)
+losses = []
+for step in range(3):
+    mine = shard_batch_numpy(make_batch(64, seed=step, mode="A"), rank, world)
+    noise = {{k: t(v, dev) for k, v in draw_noise(mine, seed=100 + 10 * step + rank).items()}}
+    losses.append(float(tr.step(pg.Batch.from_numpy(mine, dev), noise, structure_key=("A", 32, 18))))
+assert tr.use_graph, "capture fell back to eager"
+torch.save(dict(losses=losses, params=tr.flat.flat.cpu()), os.path.join({out!r}, "rank%d.pt" % rank))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_trainer_matches_single_process(tmp_path):
+    """The N>1 step on the device path: two ranks (gloo transport, sharing cuda:0 - the box has one GPU) shard each
+    batch by whole molecules, replay their captured forward+backward, all-reduce the flat gradient and apply Adam.
+    One process doing the same reduction by hand (sum of the two shard gradients, grad_scale 1/2) must land on
+    bit-identical parameters: the sum of two floats does not depend on the transport."""
+    import os
+    import subprocess
+    import sys
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.parallel import shard_batch_numpy
+    from geossl_amd.synthetic import draw_noise, make_batch
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rank_worker.py"
+    script.write_text(_RANK_WORKER.format(repo=repo, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2", GEOSSL_DIST_BACKEND="gloo")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=False)
+    assert torch.equal(r0["params"], r1["params"])  # replicas stay in lock step
+
+    cfg = dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=5.0, node_class=9,
+               readout="mean")
+    tr = pg.DDMTrainer(product_schnet(cfg, DEV), product_ncsn(128, 50, 2, DEV),
+                       product_ncsn(128, 50, 2, DEV, scale=0.9), lr=5e-4, use_graph=False)
+    for step in range(3):
+        full = make_batch(64, seed=step, mode="A")
+        total, losses = None, []
+        for rank in range(2):
+            mine = shard_batch_numpy(full, rank, 2)
+            noise = {k: t(v, DEV) for k, v in draw_noise(mine, seed=100 + 10 * step + rank).items()}
+            losses.append(float(tr._fwd_bwd(pg.Batch.from_numpy(mine, DEV), noise)))
+            total = tr.flat.grad.clone() if total is None else total + tr.flat.grad
+        tr.flat.grad.copy_(total)
+        tr.opt.step(grad_scale=0.5)
+        assert losses == [r0["losses"][step], r1["losses"][step]]
+    assert torch.equal(tr.flat.flat.cpu(), r0["params"])
+
+
 def test_trainer_step_reduces_loss():
     from geossl_amd import pretrain_GeoSSL as pg
     from geossl_amd.synthetic import draw_noise, make_batch
