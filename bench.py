@@ -326,6 +326,7 @@ def main():
         if args.model != "schnet":
             out["roofline"] = None  # the byte/flop model of SURVEY 8(d) is SchNet's; the PaiNN line reports throughput only
             out["step_roofline"] = None
+        out["cpu_baseline"] = None  # timed on rank 0 at N=1 only
         if world == 1 and not args.no_cpu_baseline and args.model == "schnet":
             out["cpu_baseline"] = cpu_baseline(seed=1000)
         print(json.dumps(out))
