@@ -110,7 +110,8 @@ class _SchNetCore(torch.autograd.Function):
         L, F, G = cfg["L"], cfg["F"], cfg["G"]
         dev = pos.device
         N = pos.size(0)
-        training = any(ctx.needs_input_grad[4:])
+        want_params = any(ctx.needs_input_grad[4:])
+        training = want_params or ctx.needs_input_grad[1]  # activations are kept for either backward
         ps = [p.detach().contiguous() for p in params]
         emb_w, head = ps[0], ps[1 + 9 * L:]
         layers = [ps[1 + 9 * l: 1 + 9 * (l + 1)] for l in range(L)]
@@ -153,6 +154,8 @@ class _SchNetCore(torch.autograd.Function):
         if training:
             ctx.lay, ctx.cfg = lay, cfg
             ctx.z = z
+            ctx.pos = pos
+            ctx.want_params = want_params
             ctx.ps = ps
             ctx.params = params
             ctx.saved = dict(pair_d=pair_d, pair_c=pair_c, pair_flag=pair_flag, Wf=Wf, T=T, hs=hs, xs=xs, aggs=aggs,
@@ -160,11 +163,10 @@ class _SchNetCore(torch.autograd.Function):
         return hout
 
     @staticmethod
-    def backward(ctx, dhout):
-        if ctx.needs_input_grad[1]:
-            raise NotImplementedError("gradient w.r.t. positions (force matching, finetune_md17.py:46) is not built "
-                                      "yet — SURVEY.md §8(f) N3")
+    @torch.autograd.function.once_differentiable  # first order only: create_graph=True (finetune_md17.py:46) cannot
+    def backward(ctx, dhout):                      # differentiate the force again - that raises, loudly
         cfg, lay, sv, ps = ctx.cfg, ctx.lay, ctx.saved, ctx.ps
+        want_pos, want_params = ctx.needs_input_grad[1], ctx.want_params
         L, F, G = cfg["L"], cfg["F"], cfg["G"]
         dev = dhout.device
         N = dhout.size(0)
@@ -173,8 +175,8 @@ class _SchNetCore(torch.autograd.Function):
         layers = [ps[1 + 9 * l: 1 + 9 * (l + 1)] for l in range(L)]
         # When every parameter already owns a dense .grad (DDMTrainer's flat gradient buffer) the kernels accumulate
         # straight into it and the node returns no parameter gradients: no temporaries, no AccumulateGrad adds.
-        direct = _direct_grads(ctx.params)
-        grads = [p.grad for p in ctx.params] if direct else [torch.empty_like(p) for p in ps]
+        direct = want_params and _direct_grads(ctx.params)
+        grads = [p.grad for p in ctx.params] if direct else [torch.empty_like(p) if want_params else None for p in ps]
         accum = 1 if direct else 0
         g_emb, g_head = grads[0], grads[1 + 9 * L:]
         g_layers = [grads[1 + 9 * l: 1 + 9 * (l + 1)] for l in range(L)]
@@ -201,38 +203,51 @@ class _SchNetCore(torch.autograd.Function):
             daggs[l] = dagg
             keep += [dh, dy, dx]
             dh = dh_new
-        # every atom-row weight gradient in one batched launch
-        ops.linear_wgrad(probs, N, F, F, accumulate=bool(accum))
-        # embedding table
-        nfl = _lib.load().geossl_embedding_bwd_workspace_floats(emb_w.size(0), F)
-        ws = torch.empty(nfl, dtype=torch.float32, device=dev)
-        z = ctx.z
-        call("geossl_embedding_bwd", ptr(z), z.stride(0) if z.numel() else 1, ptr(dh), emb_w.size(0), N, F,
-             ptr(g_emb), ptr(ws), accum, st)
-        # continuous-filter network weights, all blocks at once
         P = lay.P
-        if P > 0:
-            fw = _lib.FilterWeights()
-            gin = _lib.FilterGradIn()
-            gout = _lib.FilterGradOut()
-            for l, lp in enumerate(layers):
-                fw.w1[l], fw.b1[l], fw.w2[l], fw.b2[l] = ptr(lp[0]), ptr(lp[1]), ptr(lp[2]), ptr(lp[3])
-                gin.x[l], gin.dagg[l] = ptr(sv["xs"][l]), ptr(daggs[l])
-                gl = g_layers[l]
-                gout.dw1[l], gout.db1[l], gout.dw2[l], gout.db2[l] = ptr(gl[0]), ptr(gl[1]), ptr(gl[2]), ptr(gl[3])
-            nfl = _lib.load().geossl_cfconv_filter_bwd_workspace_floats(P, L, F, G)
-            ws2 = torch.empty(nfl, dtype=torch.float32, device=dev)
-            call("geossl_cfconv_filter_bwd", ptr(sv["pair_d"]), ptr(sv["pair_c"]), ptr(sv["pair_flag"]),
-                 ptr(lay.pair_i), ptr(lay.pair_j), P, N, C.byref(fw), C.byref(gin), L, F, G, ptr(cfg["offset"]),
-                 cfg["coeff"], ptr(sv["T"]), C.byref(gout), ptr(ws2), accum, st)
-        elif not direct:
-            for gl in g_layers:
-                for k in range(4):
-                    gl[k].zero_()
-        ctx.saved = None
+        fw = _lib.FilterWeights()
+        gin = _lib.FilterGradIn()
+        for l, lp in enumerate(layers):
+            fw.w1[l], fw.b1[l], fw.w2[l], fw.b2[l] = ptr(lp[0]), ptr(lp[1]), ptr(lp[2]), ptr(lp[3])
+            gin.x[l], gin.dagg[l] = ptr(sv["xs"][l]), ptr(daggs[l])
+        if want_params:
+            # every atom-row weight gradient in one batched launch
+            ops.linear_wgrad(probs, N, F, F, accumulate=bool(accum))
+            # embedding table
+            nfl = _lib.load().geossl_embedding_bwd_workspace_floats(emb_w.size(0), F)
+            ws = torch.empty(nfl, dtype=torch.float32, device=dev)
+            z = ctx.z
+            call("geossl_embedding_bwd", ptr(z), z.stride(0) if z.numel() else 1, ptr(dh), emb_w.size(0), N, F,
+                 ptr(g_emb), ptr(ws), accum, st)
+            # continuous-filter network weights, all blocks at once
+            if P > 0:
+                gout = _lib.FilterGradOut()
+                for l, gl in enumerate(g_layers):
+                    gout.dw1[l], gout.db1[l], gout.dw2[l], gout.db2[l] = ptr(gl[0]), ptr(gl[1]), ptr(gl[2]), ptr(gl[3])
+                nfl = _lib.load().geossl_cfconv_filter_bwd_workspace_floats(P, L, F, G)
+                ws2 = torch.empty(nfl, dtype=torch.float32, device=dev)
+                call("geossl_cfconv_filter_bwd", ptr(sv["pair_d"]), ptr(sv["pair_c"]), ptr(sv["pair_flag"]),
+                     ptr(lay.pair_i), ptr(lay.pair_j), P, N, C.byref(fw), C.byref(gin), L, F, G, ptr(cfg["offset"]),
+                     cfg["coeff"], ptr(sv["T"]), C.byref(gout), ptr(ws2), accum, st)
+            elif not direct:
+                for gl in g_layers:
+                    for k in range(4):
+                        gl[k].zero_()
+        dpos = None
+        if want_pos:
+            # positions enter through the edge lengths only (schnet.py:93): dL/dd per pair slot and block, then the
+            # derivative of the norm applied to both atoms of every slot (finetune_md17.py:46, first order)
+            dpos = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+            if P > 0:
+                dd = torch.empty(L, P, dtype=torch.float32, device=dev)
+                call("geossl_cfconv_filter_dpos", ptr(sv["pair_d"]), ptr(sv["pair_c"]), ptr(sv["pair_flag"]),
+                     ptr(lay.pair_i), ptr(lay.pair_j), P, C.byref(fw), C.byref(gin), L, F, G, ptr(cfg["offset"]),
+                     cfg["coeff"], cfg["cutoff"], ptr(sv["T"]), ptr(sv["Wf"]), ptr(dd), st)
+                call("geossl_pair_position_grad", ptr(ctx.pos), ptr(sv["pair_d"]), ptr(dd), ptr(lay.mol_ptr),
+                     ptr(lay.pair_ptr), lay.B, P, L, ptr(dpos), st)
+        # ctx.saved stays: finetune_md17.py:46 differentiates with retain_graph=True and runs this node again
         if direct:
-            return (None, None, None, None) + (None,) * len(grads)
-        return (None, None, None, None) + tuple(grads)
+            return (None, dpos, None, None) + (None,) * len(grads)
+        return (None, dpos, None, None) + tuple(grads)
 
 
 class _SegmentReduce(torch.autograd.Function):

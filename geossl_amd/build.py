@@ -8,7 +8,7 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgeossl_hip.so")
-SOURCES = ["gemm.hip", "graph.hip", "schnet.hip", "filter_fwd.hip", "filter_bwd.hip", "ncsn_rows.hip", "ddm.hip", "painn.hip"]
+SOURCES = ["gemm.hip", "graph.hip", "schnet.hip", "filter_fwd.hip", "filter_bwd.hip", "filter_dpos.hip", "ncsn_rows.hip", "ddm.hip", "painn.hip"]
 HEADERS = ["common.h", "split.h", "tn.h", os.path.join(REPO, "include", "geossl_hip.h")]
 
 

@@ -112,6 +112,19 @@ int geossl_cfconv_filter_bwd(const float* pair_d, const float* pair_c, const uin
                              const float* T, const GeosslFilterGradOut* out, float* workspace, int accumulate,
                              hipStream_t stream);
 
+/* ---- position gradient through K1-K4 (first order) — the d/d pos of finetune_md17.py:46 through
+ * schnet.py:91-93 (edge length), :186-187 (cosine envelope) and :205-207 (Gaussian smearing); SURVEY 8(f) N3.
+ * Same inputs as geossl_cfconv_filter_bwd plus the filter rows Wf; dd[l][p] = dL/dd_p contributed by block l:
+ *   C'(d)/C(d)^2 * sum_c dO[p][c] Wf[p][c]  +  sum_h ((W2^T dO) * ssp'(.))[h] * (W1 rbf'(d))[h].
+ * geossl_pair_position_grad sums dd over l and applies d|pos_a - pos_b|/d pos to both atoms of every pair slot:
+ *   dpos[a] = sum_b (sum_l dd[l][slot(a,b)]) * (pos[a] - pos[b]) / d(a,b)        (fixed order, no atomics).   */
+int geossl_cfconv_filter_dpos(const float* pair_d, const float* pair_c, const uint8_t* pair_flag, const int32_t* pair_i,
+                              const int32_t* pair_j, int64_t P, const GeosslFilterWeights* w,
+                              const GeosslFilterGradIn* g, int L, int F, int G, const float* offset, float coeff,
+                              float cutoff, const float* T, const float* Wf, float* dd, hipStream_t stream);
+int geossl_pair_position_grad(const float* pos, const float* pair_d, const float* dd, const int32_t* mol_ptr,
+                              const int32_t* pair_ptr, int64_t B, int64_t P, int L, float* dpos, hipStream_t stream);
+
 /* ---- neighbour aggregation (K4) — MessagePassing.propagate(aggr="add") with message x_j * W
  * (schnet.py:190,194-195): out[i] = sum over edges (j -> i), j ascending, of x[j] * Wf[slot(i,j)].
  * swap = 1 runs the transposed graph (backward w.r.t. x): out[j] = sum over edges (j -> i) of x[i]*Wf.       */

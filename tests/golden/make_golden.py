@@ -300,5 +300,30 @@ def g8():
     print("wrote state_dict_keys.json", {k: v.get("num_params") for k, v in spec.items()})
 
 
+def g9():
+    """Forces as finetune_md17.py:33,46 computes them (pred_energy -> -grad w.r.t. positions), on the reference
+    SchNet: energy_b = sum_f out[b, f] * cos(f) stands in for graph_pred_linear."""
+    red = dict(hidden_channels=32, num_filters=32, num_interactions=2, num_gaussians=8, cutoff=5.0,
+               node_class=9, readout="add")
+    full = dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=5.0,
+                node_class=9, readout="add")
+    for tag, cfg, sizes, seed in (("reduced", red, RAGGED, 14), ("full_r5", full, [18, 18, 7, 30, 2], 15)):
+        b = make_batch(0, seed=seed, sizes=sizes)
+        batch = Batch(b)
+        model = fill_module_(SchNet(**cfg))
+        positions = batch.positions.clone().requires_grad_(True)
+        out = model(batch.x[:, 0], positions, batch.batch)
+        w = torch.cos(torch.arange(out.size(1), dtype=torch.float32))
+        pred_energy = (out * w).sum(dim=1)
+        pred_force = -torch.autograd.grad(outputs=pred_energy, inputs=positions,
+                                          grad_outputs=torch.ones_like(pred_energy), create_graph=True,
+                                          retain_graph=True)[0]
+        save("g9_schnet_forces_" + tag, x=batch.x, positions=batch.positions, batch=batch.batch,
+             energy=pred_energy, force=pred_force.detach(), cfg=json.dumps({k: v for k, v in cfg.items()}))
+
+
 if __name__ == "__main__":
-    g1_g2(); g3(); g4(); g5(); g6(); g7(); g8()
+    only = sys.argv[1:]
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9):
+        if not only or fn.__name__ in only:
+            fn()

@@ -235,6 +235,63 @@ def test_schnet_param_grads_golden(tag):
             assert rel_err(grads[k[5:]].cpu(), g[k]) < TOL_GRAD, k
 
 
+def _energy_and_force(model, x, pos, batch):
+    pos = pos.clone().requires_grad_(True)
+    out = model(x[:, 0], pos, batch)
+    w = torch.cos(torch.arange(out.size(1), dtype=torch.float32, device=out.device))
+    energy = (out * w).sum(dim=1)
+    # exactly the call of finetune_md17.py:46 / :99 (create_graph=True, then detached by the evaluation loop)
+    force = -torch.autograd.grad(outputs=energy, inputs=pos, grad_outputs=torch.ones_like(energy), create_graph=True,
+                                 retain_graph=True)[0]
+    return energy, force, pos
+
+
+@pytest.mark.parametrize("tag", ["reduced", "full_r5"])
+def test_schnet_forces_golden(tag):
+    """SURVEY 8(f) N3, first order: -dE/dpos through the HIP path against the forces of the unmodified reference."""
+    g = load_golden("g9_schnet_forces_" + tag)
+    model = product_schnet(cfg_of(g), DEV)
+    energy, force, _ = _energy_and_force(model, t(g["x"], DEV), t(g["positions"], DEV), t(g["batch"], DEV))
+    assert_close(energy.detach().cpu(), g["energy"], TOL_OUT, "energy")
+    assert rel_err(force.detach().cpu(), g["force"]) < TOL_GRAD
+
+
+def test_schnet_forces_vs_fp64_oracle_and_param_grads_unchanged():
+    """Ragged synthetic batch (tiny, mid-size and > 32-atom molecules, F = 128, L = 6): forces against the oracle
+    evaluated in fp64; asking for the position gradient leaves the parameter gradients bit-identical; a second
+    differentiation of the force (training on it, finetune_md17.py:51-54) is refused loudly."""
+    from geossl_amd.synthetic import make_batch
+    from oracle import nets
+    cfg = dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=5.0, node_class=9,
+               readout="add")
+    b = make_batch(0, seed=21, sizes=[1, 2, 3, 18, 18, 40, 9, 33, 5])
+    model = product_schnet(cfg, DEV)
+    x, pos, bat = t(b["x"], DEV), t(b["positions"], DEV), t(b["batch"], DEV)
+    energy, force, pos_g = _energy_and_force(model, x, pos, bat)
+    P64 = {k: v.double() for k, v in schnet_oracle_params(cfg).items()}
+    p64 = t(b["positions"]).double().requires_grad_(True)
+    out64 = nets.schnet_forward(P64, t(b["x"])[:, 0], p64, t(b["batch"]), 5.0, 6, "add")
+    e64 = (out64 * torch.cos(torch.arange(128, dtype=torch.float64))).sum(dim=1)
+    f64 = -torch.autograd.grad(e64.sum(), p64)[0]
+    assert rel_err(energy.detach().cpu().double(), e64.detach()) < TOL_OUT
+    assert rel_err(force.detach().cpu().double(), f64) < TOL_GRAD
+    # per-molecule net force vanishes (translation invariance)
+    net = torch.zeros(len(b["sizes"]), 3, dtype=torch.float64).index_add_(0, t(b["batch"]), force.detach().cpu().double())
+    assert float(net.abs().max()) < 1e-4 * float(f64.abs().max())
+    # parameter gradients with and without the position gradient in the same backward
+    model.zero_grad()
+    energy.sum().backward(inputs=[pos_g] + list(model.parameters()))
+    with_pos = {k: v.clone() for k, v in unique_named_grads(model).items()}
+    model.zero_grad()
+    out = model(x[:, 0], pos, bat)
+    ((out * torch.cos(torch.arange(128, dtype=torch.float32, device=DEV))).sum()).backward()
+    for k, v in unique_named_grads(model).items():
+        assert torch.equal(v, with_pos[k]), k
+    # second order is not built
+    with pytest.raises(RuntimeError):
+        (force ** 2).sum().backward()
+
+
 def test_schnet_no_grad_and_state_dict_roundtrip(tmp_path):
     g = load_golden("g4_schnet_reduced")
     cfg = cfg_of(g)

@@ -123,6 +123,21 @@ def test_g4_schnet_forward_and_grads(tag):
             assert rel_err(P[k[5:]].grad, g[k]) < 5e-6, k
 
 
+@pytest.mark.parametrize("tag", ["reduced", "full_r5"])
+def test_g9_schnet_forces(tag):
+    """Position gradient (finetune_md17.py:46) of the oracle against the forces of the unmodified reference."""
+    g = load_golden("g9_schnet_forces_" + tag)
+    cfg = json.loads(str(g["cfg"]))
+    P = schnet_params(cfg)
+    pos = t(g["positions"]).clone().requires_grad_(True)
+    out = nets.schnet_forward(P, t(g["x"])[:, 0], pos, t(g["batch"]), cfg["cutoff"], cfg["num_interactions"],
+                              cfg["readout"])
+    energy = (out * torch.cos(torch.arange(out.size(1), dtype=torch.float32))).sum(dim=1)
+    assert rel_err(energy, g["energy"]) < 1e-5  # a cos-weighted sum over the features: cancellation, not drift
+    force = -torch.autograd.grad(energy.sum(), pos)[0]
+    assert rel_err(force, g["force"]) < 2e-5  # two fp32 evaluations in different summation orders
+
+
 @pytest.mark.parametrize("tag", ["comb_K50_p2", "comb_K30_p0.05", "comb_K50_p5_last1", "perm_K30_p10"])
 def test_g5_ncsn(tag):
     g = load_golden("g5_ncsn_" + tag)
