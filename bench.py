@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="do not capture forward+backward into a HIP graph")
     ap.add_argument("--forward-only", action="store_true",
                     help="BASELINE config 1 (secondary line): SchNet forward only, one view, no autograd")
+    ap.add_argument("--forces", action="store_true",
+                    help="secondary line (SURVEY 8(f) N3): SchNet energy + forces, i.e. forward and the first-order "
+                         "position gradient of finetune_md17.py:46, frozen weights, one view")
     ap.add_argument("--model", default="schnet", choices=["schnet", "painn"],
                     help="backbone: schnet = the headline configuration; painn = BASELINE config 5 (secondary line)")
     args = ap.parse_args()
@@ -169,10 +172,19 @@ def main():
             "pos_noise": torch.empty_like(bt.positions).normal_(0.0, 0.3, generator=gen),
         }
 
-    if args.forward_only:
-        # BASELINE configs[1]: SchNet.forward(z, pos, batch) on a 1024-molecule batch, inference (no saved activations)
+    if args.forces:
+        for p_ in model.parameters():
+            p_.requires_grad_(False)
+        wvec = torch.cos(torch.arange(F, dtype=torch.float32, device=dev))
+    if args.forward_only or args.forces:
+        # BASELINE configs[1]: SchNet.forward(z, pos, batch) on a 1024-molecule batch, inference (no saved activations);
+        # --forces adds pred_force = -grad(pred_energy, positions) (finetune_md17.py:46,99)
         def fwd(i):
             bt = batches[i % n_batches]
+            if args.forces:
+                pos = bt.positions.detach().requires_grad_(True)
+                energy = (model(bt.x[:, 0], pos, bt.batch) * wvec).sum(dim=1)
+                return -torch.autograd.grad(energy, pos, torch.ones_like(energy))[0]
             with torch.no_grad():
                 return model(bt.x[:, 0], bt.positions, bt.batch)
         for i in range(args.warmup):
@@ -193,12 +205,13 @@ def main():
             elapsed = float(tt.item())
         if rank == 0:
             print(json.dumps({
-                "metric": "molecules/s/GPU SchNet forward-only (QM9-sized, bs=1024) [BASELINE config 1]",
+                "metric": ("molecules/s/GPU SchNet energy + forces (QM9-sized, bs=1024) [SURVEY 8(f) N3]" if args.forces
+                           else "molecules/s/GPU SchNet forward-only (QM9-sized, bs=1024) [BASELINE config 1]"),
                 "value": world * args.mols * args.steps / elapsed, "unit": "molecules/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "SchNet.forward F=128 L=6 G=51 cutoff=5A, bs=%d molecules/GPU x n=18 atoms, eager "
-                                       "launches (HBM-resident batches)" % args.mols,
+                "config": {"workload": "SchNet.forward%s F=128 L=6 G=51 cutoff=5A, bs=%d molecules/GPU x n=18 atoms, eager "
+                                       "launches (HBM-resident batches)" % (" + d/dpos" if args.forces else "", args.mols),
                            "parallelism": "dp%d" % world},
                 "roofline": None, "cpu_baseline": None, "out_checksum": float(out.double().sum())}))
         if world > 1:

@@ -4,19 +4,21 @@
 //
 // Positions enter SchNet through the length d_p of each pair slot p = (i < j) alone (the radius graph is discrete):
 //     Wf_l[p][c] = C(d_p) * O_l[p][c],   O_l = W2_l t + b2_l,   t = ssp(u),   u = W1_l rbf(d_p) + b1_l.
-// With the upstream gradient of the filter rows (never stored; rebuilt from the per-layer atom tensors, as in
-// filter_bwd.hip)
-//     dO_l[p][c] = C(d_p) * ( flag0 * dagg_l[i][c] * x_l[j][c]  +  flag1 * dagg_l[j][c] * x_l[i][c] ),
-// the two paths into d_p are the envelope and the Gaussian smearing:
-//     dL/dd_p = sum_l [ C'(d_p) / C(d_p)^2 * sum_c dO_l[p][c] Wf_l[p][c]
-//                       + sum_h dU_l[p][h] * v_l[p][h] ],
-//     dU = (W2^T dO) * ssp'(u),      v = W1 rbf'(d_p),     rbf'_g(d) = 2 coeff (d - mu_g) rbf_g(d).
+// The derivative of a filter row along its one input is propagated FORWARD through the filter network (a
+// Jacobian-vector product with the scalar tangent d), which keeps every product in the orientation the forward
+// kernel uses and needs no transposition of gathered data:
+//     rbf'_g(d) = 2 coeff (d - mu_g) rbf_g(d),   z = W2 ( ssp'(u) * (W1 rbf'(d)) ) = dO/dd,
+//     J[p][c]  = dWf[p][c]/dd = C(d) z[c] + C'(d)/C(d) * Wf[p][c],
+// and contracted with the upstream gradient of the row (never stored; rebuilt from the per-layer atom tensors as in
+// filter_bwd.hip):
+//     dL/dd_p = sum_l sum_c ( flag0 * dagg_l[i][c] * x_l[j][c] + flag1 * dagg_l[j][c] * x_l[i][c] ) * J_l[p][c].
 //
 // Same organisation as the filter forward (filter_fwd.hip): fp32 results on the bf16 matrix pipe (split.h), both
-// products evaluated TRANSPOSED with the pair rows on the lanes and the weights (W2^T, W1) as pre-split A fragments
-// in LDS; a wave owns 32 pair rows of one layer end to end.  dO^T is built directly in B-fragment layout from
-// 16-byte gathers of the atom rows (L2 resident); W2^T dO^T and W1 rbf'^T land in the same C layout (lane = pair
-// row, register = hidden unit), so dU * v is a register-wise product followed by one cross-half shuffle.
+// products evaluated TRANSPOSED with the pair rows on the lanes and the weights as pre-split A fragments in LDS (the
+// very fragments of the forward); a wave owns 32 pair rows of one layer end to end; ssp'(u) comes from the saved
+// activations T.  z lands in C layout (lane = pair row, register = 4 consecutive channels per group), which is also
+// the layout of 16-byte gathers of the atom rows (L2 resident) and of the filter row, so the contraction is
+// register-wise followed by one cross-half shuffle.
 // Output: dd[l][p], summed over l and scattered to the atoms by k_pair_position_grad (fixed order, no atomics).
 #include "common.h"
 #include "geossl_hip.h"
@@ -38,8 +40,8 @@ __global__ __launch_bounds__(512) void k_filter_dpos(const float* __restrict__ p
                                                      float* __restrict__ dd) {
   constexpr int F = 32 * NMB, K2S = F / 16;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
-  u32x4* W2Tf = reinterpret_cast<u32x4*>(smem_raw);         // [NMB][K2S][3][64] A fragments of W2^T (rows = h, k = c)
-  u32x4* W1f = W2Tf + NMB * K2S * 3 * 64;                   // [NMB][K1S][3][64] A fragments of W1   (rows = h, k = g)
+  u32x4* W2f = reinterpret_cast<u32x4*>(smem_raw);          // [NMB][K2S][3][64] A fragments of W2 (rows = c, k = h)
+  u32x4* W1f = W2f + NMB * K2S * 3 * 64;                    // [NMB][K1S][3][64] A fragments of W1 (rows = h, k = g)
   float* offs = reinterpret_cast<float*>(W1f + NMB * K1S * 3 * 64);  // [16*K1S] Gaussian centres, zero padded
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
   const int l = blockIdx.y;
@@ -47,13 +49,12 @@ __global__ __launch_bounds__(512) void k_filter_dpos(const float* __restrict__ p
     const float* __restrict__ w2 = w.w2[l];
     for (int i = tid; i < NMB * K2S * 64; i += 512) {
       const int ln = i & 63, ks = (i >> 6) % K2S, mb = i / (64 * K2S);
-      // A[m = h][k = c], c = 16ks + kperm(e, half): the contraction index of this GEMM is the filter channel
-      const float* col = w2 + 32 * mb + (ln & 31);
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = col[(size_t)(16 * ks + kperm(e, ln >> 5)) * F];
+      // contraction-index permutation kperm (split.h): elements 0..3 <- hidden units 4kh.., 4..7 <- 8+4kh..
+      const float* row = w2 + (size_t)(32 * mb + (ln & 31)) * F + 16 * ks + 4 * (ln >> 5);
+      const float4 lo = *reinterpret_cast<const float4*>(row), hi = *reinterpret_cast<const float4*>(row + 8);
+      const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
       const Frag3 f = split8(v);
-      u32x4* dst = W2Tf + ((size_t)(mb * K2S + ks) * 3) * 64 + ln;
+      u32x4* dst = W2f + ((size_t)(mb * K2S + ks) * 3) * 64 + ln;
       dst[0] = f.h;
       dst[64] = f.m;
       dst[128] = f.l;
@@ -84,37 +85,15 @@ __global__ __launch_bounds__(512) void k_filter_dpos(const float* __restrict__ p
   for (int rb = blockIdx.x * 8 + wave; rb < nrb; rb += gridDim.x * 8) {
     const int row = 32 * rb + j;
     const bool live = row < P;
-    const int rc = live ? row : P - 1;  // clamped: every address below is valid, dead rows are masked by m0 = m1 = 0
+    const int rc = live ? row : P - 1;  // clamped: every address below is valid, dead rows are masked by f0 = f1 = 0
     const float d = pair_d[rc];
     const float cw = pair_c[rc];
     const unsigned fl = live ? pair_flag[rc] : 0u;
-    const float m0 = (fl & 1u) ? cw : 0.0f, m1 = (fl & 2u) ? cw : 0.0f;
     const float* __restrict__ di = dagg + (size_t)pair_i[rc] * F + 4 * kh;
     const float* __restrict__ dj = dagg + (size_t)pair_j[rc] * F + 4 * kh;
     const float* __restrict__ xi = x + (size_t)pair_i[rc] * F + 4 * kh;
     const float* __restrict__ xj = x + (size_t)pair_j[rc] * F + 4 * kh;
     const float* __restrict__ wrow = Wf + (lbase + rc) * F + 4 * kh;
-    // dO^T as B fragments of the contraction over the filter channels (element e of k-step ks <-> channel
-    // 16ks + kperm(e, kh): two 16-byte pieces per operand), and the envelope path sum_c dO * Wf
-    Frag3 dof[K2S];
-    float s1 = 0.0f;
-#pragma unroll
-    for (int ks = 0; ks < K2S; ++ks) {
-      float v[8];
-#pragma unroll
-      for (int h4 = 0; h4 < 2; ++h4) {
-        const int c = 16 * ks + 8 * h4;
-        const float4 a = *reinterpret_cast<const float4*>(di + c), b = *reinterpret_cast<const float4*>(xj + c);
-        const float4 cc = *reinterpret_cast<const float4*>(dj + c), e4 = *reinterpret_cast<const float4*>(xi + c);
-        const float4 wf = *reinterpret_cast<const float4*>(wrow + c);
-        v[4 * h4 + 0] = m0 * (a.x * b.x) + m1 * (cc.x * e4.x);
-        v[4 * h4 + 1] = m0 * (a.y * b.y) + m1 * (cc.y * e4.y);
-        v[4 * h4 + 2] = m0 * (a.z * b.z) + m1 * (cc.z * e4.z);
-        v[4 * h4 + 3] = m0 * (a.w * b.w) + m1 * (cc.w * e4.w);
-        s1 += (v[4 * h4] * wf.x + v[4 * h4 + 1] * wf.y) + (v[4 * h4 + 2] * wf.z + v[4 * h4 + 3] * wf.w);
-      }
-      dof[ks] = split8(v);
-    }
     // rbf'^T B fragments: lane (row, half kh) differentiates the 8 Gaussians of its k-step for its own row
     Frag3 bfr[K1S];
 #pragma unroll
@@ -130,17 +109,23 @@ __global__ __launch_bounds__(512) void k_filter_dpos(const float* __restrict__ p
       }
       bfr[ks] = split8(v);
     }
-    // per 32-wide block of hidden units: dt^T = W2^T dO^T, v^T = W1 rbf'^T (same C layout), dU = dt * ssp'(u)
+    // hidden block mb: du/dd = W1 rbf' (C layout: lane = pair row, register = hidden unit), times ssp'(u) from the
+    // saved activations, split in registers into the two B fragments (k-steps 2mb, 2mb+1) of the second product,
+    // which are consumed at once by the z accumulators of ALL output blocks - nothing of the block stays live
     const float* __restrict__ trow = T + (lbase + rc) * F + 4 * kh;
-    float s2 = 0.0f;
+    f32x16 z[NMB];
+#pragma unroll
+    for (int u = 0; u < NMB; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[u][r] = 0.0f;
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
       float4 tq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) tq[q] = *reinterpret_cast<const float4*>(trow + 32 * mb + 8 * q);
-      f32x16 at0, at1, av;
+      f32x16 a1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) at0[r] = at1[r] = av[r] = 0.0f;
+      for (int r = 0; r < 16; ++r) a1[r] = 0.0f;
 #pragma unroll
       for (int ks = 0; ks < K1S; ++ks) {
         Frag3 af;
@@ -148,30 +133,62 @@ __global__ __launch_bounds__(512) void k_filter_dpos(const float* __restrict__ p
         af.h = src[0];
         af.m = src[64];
         af.l = src[128];
-        mma6(av, af, bfr[ks]);
+        mma6(a1, af, bfr[ks]);
       }
+      Frag3 tb[2];
 #pragma unroll
-      for (int ks = 0; ks < K2S; ++ks) {
-        Frag3 af;
-        const u32x4* src = W2Tf + ((size_t)(mb * K2S + ks) * 3) * 64 + lane;
-        af.h = src[0];
-        af.m = src[64];
-        af.l = src[128];
-        mma6x2(at0, at1, af, dof[ks]);
+      for (int half = 0; half < 2; ++half) {
+        const float4 t0 = tq[2 * half], t1 = tq[2 * half + 1];
+        const float v[8] = {a1[8 * half] * dssp_from_out(t0.x),     a1[8 * half + 1] * dssp_from_out(t0.y),
+                            a1[8 * half + 2] * dssp_from_out(t0.z), a1[8 * half + 3] * dssp_from_out(t0.w),
+                            a1[8 * half + 4] * dssp_from_out(t1.x), a1[8 * half + 5] * dssp_from_out(t1.y),
+                            a1[8 * half + 6] * dssp_from_out(t1.z), a1[8 * half + 7] * dssp_from_out(t1.w)};
+        tb[half] = split8(v);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int u = 0; u < NMB; ++u) {
+          Frag3 af;
+          const u32x4* src = W2f + ((size_t)(u * K2S + 2 * mb + half) * 3) * 64 + lane;
+          af.h = src[0];
+          af.m = src[64];
+          af.l = src[128];
+          mma6(z[u], af, tb[half]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // contraction with the upstream gradient of the filter row, one 32-channel block of gathers in flight at a time.
+    // envelope: C(d) = (cos(pi d / r_c) + 1) / 2  (schnet.py:186);  Wf = C * O
+    const float cp = -0.5f * (GEOSSL_PI_F / cutoff) * sinf(d * GEOSSL_PI_F / cutoff);
+    const float kappa = cw > 0.0f ? cp / cw : 0.0f;
+    const float f0 = (fl & 1u) ? 1.0f : 0.0f, f1 = (fl & 2u) ? 1.0f : 0.0f;
+    float tot = 0.0f;
+#pragma unroll
+    for (int u = 0; u < NMB; ++u) {
+      float4 a[4], b[4], cc[4], e4[4], wf[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 32 * u + 8 * q;
+        a[q] = *reinterpret_cast<const float4*>(di + c);
+        b[q] = *reinterpret_cast<const float4*>(xj + c);
+        cc[q] = *reinterpret_cast<const float4*>(dj + c);
+        e4[q] = *reinterpret_cast<const float4*>(xi + c);
+        wf[q] = *reinterpret_cast<const float4*>(wrow + c);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float t4[4] = {tq[q].x, tq[q].y, tq[q].z, tq[q].w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = 4 * q + i;
-          s2 += ((at0[r] + at1[r]) * dssp_from_out(t4[i])) * av[r];
-        }
+        const float gx = f0 * (a[q].x * b[q].x) + f1 * (cc[q].x * e4[q].x);
+        const float gy = f0 * (a[q].y * b[q].y) + f1 * (cc[q].y * e4[q].y);
+        const float gz = f0 * (a[q].z * b[q].z) + f1 * (cc[q].z * e4[q].z);
+        const float gw = f0 * (a[q].w * b[q].w) + f1 * (cc[q].w * e4[q].w);
+        tot += (gx * (cw * z[u][4 * q] + kappa * wf[q].x) + gy * (cw * z[u][4 * q + 1] + kappa * wf[q].y)) +
+               (gz * (cw * z[u][4 * q + 2] + kappa * wf[q].z) + gw * (cw * z[u][4 * q + 3] + kappa * wf[q].w));
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // envelope: C(d) = (cos(pi d / r_c) + 1) / 2  (schnet.py:186);  sum_c dO Wf = C^2 sum_c dWf O
-    const float cp = -0.5f * (GEOSSL_PI_F / cutoff) * sinf(d * GEOSSL_PI_F / cutoff);
-    float tot = s2 + (cw > 0.0f ? cp * (s1 / (cw * cw)) : 0.0f);
     tot += __shfl_xor(tot, 32, 64);
     if (live && kh == 0) dd[lbase + row] = tot;
   }

@@ -115,7 +115,8 @@ int geossl_cfconv_filter_bwd(const float* pair_d, const float* pair_c, const uin
 /* ---- position gradient through K1-K4 (first order) — the d/d pos of finetune_md17.py:46 through
  * schnet.py:91-93 (edge length), :186-187 (cosine envelope) and :205-207 (Gaussian smearing); SURVEY 8(f) N3.
  * Same inputs as geossl_cfconv_filter_bwd plus the filter rows Wf; dd[l][p] = dL/dd_p contributed by block l:
- *   C'(d)/C(d)^2 * sum_c dO[p][c] Wf[p][c]  +  sum_h ((W2^T dO) * ssp'(.))[h] * (W1 rbf'(d))[h].
+ *   sum_c (flag0*dagg[i][c]*x[j][c] + flag1*dagg[j][c]*x[i][c]) * dWf[p][c]/dd,
+ *   dWf/dd = C(d) * W2 (ssp'(.) * (W1 rbf'(d)))  +  C'(d)/C(d) * Wf        (the filter row differentiated forward).
  * geossl_pair_position_grad sums dd over l and applies d|pos_a - pos_b|/d pos to both atoms of every pair slot:
  *   dpos[a] = sum_b (sum_l dd[l][slot(a,b)]) * (pos[a] - pos[b]) / d(a,b)        (fixed order, no atomics).   */
 int geossl_cfconv_filter_dpos(const float* pair_d, const float* pair_c, const uint8_t* pair_flag, const int32_t* pair_i,
