@@ -171,6 +171,8 @@ class _PaiNNCore(torch.autograd.Function):
         F_, L, R = cfg["F"], cfg["L"], cfg["R"]
         dev, N, E = pos.device, pos.size(0), el.E
         st = stream()
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("PaiNN: gradient w.r.t. positions is not built (SchNet has it, first order)")
         training = any(ctx.needs_input_grad[4:])
         ps = [p.detach().contiguous() for p in params]
         emb_w, fw, fb = ps[0], ps[1], ps[2]
