@@ -107,6 +107,11 @@ def main():
     ap.add_argument("--mols", type=int, default=1024, help="molecules per GPU per step")
     ap.add_argument("--dataset-mols", type=int, default=100000, help="synthetic dataset size (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cutoff", type=float, default=5.0,
+                    help="SchNet radius: 5 A = BASELINE's bench configuration, 10 A = the reference's default (config.py:114)")
+    ap.add_argument("--set", default="A", choices=["A", "B"], dest="molset",
+                    help="synthetic molecule sizes (SURVEY 8d): A = 18 atoms each (the headline), B = ragged 2..33 atoms "
+                         "(every batch its own index structure: eager launches, no graph replay)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture forward+backward into a HIP graph")
     ap.add_argument("--forward-only", action="store_true",
                     help="BASELINE config 1 (secondary line): SchNet forward only, one view, no autograd")
@@ -116,6 +121,10 @@ def main():
     ap.add_argument("--model", default="schnet", choices=["schnet", "painn"],
                     help="backbone: schnet = the headline configuration; painn = BASELINE config 5 (secondary line)")
     args = ap.parse_args()
+    global CUTOFF
+    CUTOFF = args.cutoff
+    if args.molset == "B":
+        args.no_graph = True
 
     from geossl_amd import _lib
     from geossl_amd import pretrain_GeoSSL as pg
@@ -149,7 +158,7 @@ def main():
     n_batches = max(1, min(args.dataset_mols // (args.mols * world), total_steps))
     batches, shapes = [], []
     for i in range(n_batches):
-        b = make_batch(args.mols, seed=1000 * (rank + 1) + i, mode="A")
+        b = make_batch(args.mols, seed=1000 * (rank + 1) + i, mode=args.molset)
         bt = pg.Batch.from_numpy(b, dev)
         bt.num_graphs  # cached python int
         if args.model == "painn":  # precomputed on the clean geometry, like MoleculeDataset3DRadius (datasets_3D_Radius.py:120)
@@ -210,8 +219,10 @@ def main():
                 "value": world * args.mols * args.steps / elapsed, "unit": "molecules/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "SchNet.forward%s F=128 L=6 G=51 cutoff=5A, bs=%d molecules/GPU x n=18 atoms, eager "
-                                       "launches (HBM-resident batches)" % (" + d/dpos" if args.forces else "", args.mols),
+                "config": {"workload": "SchNet.forward%s F=128 L=6 G=51 cutoff=%gA, bs=%d molecules/GPU x %s atoms, eager "
+                                       "launches (HBM-resident batches)"
+                                       % (" + d/dpos" if args.forces else "", CUTOFF, args.mols,
+                                          "n=18" if args.molset == "A" else "n~clip(N(18,4),2,33) (set B)"),
                            "parallelism": "dp%d" % world},
                 "roofline": None, "cpu_baseline": None, "out_checksum": float(out.double().sum())}))
         if world > 1:
@@ -222,7 +233,7 @@ def main():
     def one_step(i):
         bt = batches[i % n_batches]
         # set A: every batch has the same index structure (1024 x 18 atoms) -> one captured graph serves all
-        return trainer.step(bt, draw(bt, i), structure_key=("setA", args.mols, 18))
+        return trainer.step(bt, draw(bt, i), structure_key=("setA", args.mols, 18) if args.molset == "A" else None)
 
     # one untimed priming step ahead of the W warm-up steps: builds the cached index structures and captures the HIP
     # graph, so that even --warmup 0 times steady-state steps
@@ -322,9 +333,10 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("pretrain_GeoSSL.py --GeoSSL_option=DDM step, %s, "
-                                    "bs=%d molecules/GPU x n=18 atoms, %d pre-collated device-resident batches/GPU"
-                                    % ("SchNet F=128 L=6 G=51 cutoff=5A" if args.model == "schnet"
-                                       else "PaiNN F=128 L=3 rbf=20 cutoff=5A (BASELINE config 5)", args.mols, n_batches)),
+                                    "bs=%d molecules/GPU x %s atoms, %d pre-collated device-resident batches/GPU"
+                                    % ("SchNet F=128 L=6 G=51 cutoff=%gA" % CUTOFF if args.model == "schnet"
+                                       else "PaiNN F=128 L=3 rbf=20 cutoff=5A (BASELINE config 5)", args.mols,
+                                       "n=18" if args.molset == "A" else "n~clip(N(18,4),2,33) (set B)", n_batches)),
                        "molecules_per_gpu_per_step": args.mols, "atoms": N, "directed_edges": E, "super_edges": S,
                        "parallelism": "dp%d" % world,
                        "execution": "HIP graph replay of fwd+bwd, eager all-reduce + Adam" if trainer.use_graph else "eager"},
