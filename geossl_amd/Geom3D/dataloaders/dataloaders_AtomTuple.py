@@ -57,6 +57,7 @@ class BatchAtomTuple:
         """x [N, C] int64, positions [N, 3] f32 (already concatenated, on the GPU), sizes [B] atoms per molecule.
         ``radius``: also build ``radius_edge_index`` on the given geometry (datasets_3D_Radius.py:120)."""
         _lib.require_cuda(x, positions)
+        host_sizes = None if torch.is_tensor(sizes) and sizes.is_cuda else [int(n) for n in sizes]
         sizes = torch.as_tensor(sizes, dtype=torch.int64, device=x.device)
         B = int(sizes.numel())
         batch = torch.repeat_interleave(torch.arange(B, dtype=torch.int64, device=x.device), sizes)  # :61
@@ -65,6 +66,9 @@ class BatchAtomTuple:
         if radius is not None:
             from ... import ops
             rei = ops.radius_graph(positions, radius, batch)
+        if host_sizes is not None and option == "combination":
+            from ...layout import prepare_batch
+            prepare_batch(batch, sei, host_sizes)  # the step's index structures, no device read-back
         return cls(x, positions, batch, sei, rei, B)
 
     @property

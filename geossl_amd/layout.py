@@ -18,14 +18,23 @@ class MolLayout:
     pair_i[p] < pair_j[p].
     """
 
-    def __init__(self, batch, num_graphs=None):
+    def __init__(self, batch, num_graphs=None, sizes=None):
+        """``sizes``: atoms per molecule as HOST integers, when the caller collated the batch itself (a loader does):
+        the two scalars the allocation below needs (largest molecule, number of pair slots) then come from the host
+        and nothing waits for the device — without it they are read back from the layout kernel, which drains the
+        stream once per new batch."""
         _lib.require_cuda(batch)
         if batch.dtype != torch.long or batch.dim() != 1:
             raise ValueError("batch must be a 1-D int64 tensor")
         batch = batch.contiguous()
         self.N = int(batch.numel())
         dev = batch.device
-        if self.N == 0:
+        if sizes is not None:
+            sizes = [int(n) for n in sizes]
+            if sum(sizes) != self.N or (num_graphs is not None and int(num_graphs) != len(sizes)):
+                raise ValueError("sizes do not match the batch vector")
+            self.B = len(sizes)
+        elif self.N == 0:
             self.B = int(num_graphs or 0)
         else:
             self.B = int(num_graphs) if num_graphs is not None else int(batch[-1].item()) + 1  # :75-78
@@ -36,10 +45,13 @@ class MolLayout:
         if B > 0:
             call("geossl_layout_build", ptr(batch), self.N, B, ptr(self.mol_ptr), ptr(self.pair_ptr), ptr(stats),
                  stream())
-        max_n, P, bad, _ = stats.tolist()
-        if bad:
-            raise ValueError("batch vector must be sorted ascending with ids in [0, num_graphs) "
-                             "(collated batches are; dataloaders_AtomTuple.py:61,72)")
+        if sizes is not None:
+            max_n, P = max(sizes, default=0), sum(n * (n - 1) // 2 for n in sizes)
+        else:
+            max_n, P, bad, _ = stats.tolist()
+            if bad:
+                raise ValueError("batch vector must be sorted ascending with ids in [0, num_graphs) "
+                                 "(collated batches are; dataloaders_AtomTuple.py:61,72)")
         self.max_n, self.P = int(max_n), int(P)
         self.pair_i = torch.empty(self.P, dtype=torch.int32, device=dev)
         self.pair_j = torch.empty(self.P, dtype=torch.int32, device=dev)
@@ -95,13 +107,27 @@ class SuperEdgeLayout:
         self._versions = (batch._version, sei._version)
 
 
-def get_super_edge_layout(batch, super_edge_index, num_graphs):
+def get_super_edge_layout(batch, super_edge_index, num_graphs, validate=True):
     lay = getattr(super_edge_index, "_geossl_layout", None)
     if (lay is None or lay._versions != (batch._version, super_edge_index._version)
             or lay.S != super_edge_index.size(1) or lay.N != batch.numel()):
-        lay = SuperEdgeLayout(batch, super_edge_index, num_graphs)
+        lay = SuperEdgeLayout(batch, super_edge_index, num_graphs, validate=validate)
         super_edge_index._geossl_layout = lay
     return lay
+
+
+def prepare_batch(batch_vec, super_edge_index, sizes):
+    """Collation-time construction of every position-independent index structure the DDM step reads (two-view
+    molecule layout, super-edge incidence lists) from HOST molecule sizes: no read-back from the device, so a
+    loader that calls this for batch k+1 does not stall behind the kernels of batch k.  The structures are cached on
+    the tensors and found by the step (get_layout / pretrain_GeoSSL._two_view_batch / get_super_edge_layout)."""
+    sizes = [int(n) for n in sizes]
+    B = len(sizes)
+    b2 = torch.cat([batch_vec, batch_vec + B])
+    batch_vec._geossl_two_view = (b2, MolLayout(b2, 2 * B, sizes=sizes + sizes), batch_vec._version)
+    if super_edge_index is not None:
+        # the caller built super_edge_index from the same sizes (AtomTupleExtractor): its grouping needs no check
+        get_super_edge_layout(batch_vec, super_edge_index, B, validate=False)
 
 
 class EdgeLayout:

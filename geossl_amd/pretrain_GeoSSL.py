@@ -150,7 +150,11 @@ class Batch:
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         rei = t(d["radius_edge_index"]) if "radius_edge_index" in d else None
         ng = int(len(d["sizes"])) if "sizes" in d else None
-        return cls(t(d["x"]), t(d["positions"]), t(d["batch"]), t(d["super_edge_index"]), rei, ng)
+        out = cls(t(d["x"]), t(d["positions"]), t(d["batch"]), t(d["super_edge_index"]), rei, ng)
+        if "sizes" in d:  # collation knows the molecule sizes on the host: index structures without a device read-back
+            from .layout import prepare_batch
+            prepare_batch(out.batch, out.super_edge_index, d["sizes"])
+        return out
 
     def to(self, device):
         mv = lambda a: None if a is None else a.to(device)
