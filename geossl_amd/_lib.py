@@ -71,7 +71,7 @@ PROTOTYPES = {
     "geossl_cfconv_filter_dpos": (i32, [vp, vp, vp, vp, vp, i64, P(FilterWeights), P(FilterGradIn), i32, i32, i32, vp, f32,
                                         f32, vp, vp, vp, vp]),
     "geossl_pair_position_grad": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, vp, vp]),
-    "geossl_cfconv_aggregate": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]),
+    "geossl_cfconv_aggregate": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]),
     "geossl_linear": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]),
     "geossl_tn_plan": (None, [i64, i32, P(i32), P(i32)]),
     "geossl_tn_workspace_floats": (i64, [i64, i32, i32, i32]),

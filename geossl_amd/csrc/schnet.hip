@@ -33,11 +33,14 @@ __global__ void k_rbf(const float* __restrict__ d, int64_t E, const float* __res
 __global__ __launch_bounds__(128) void k_aggregate(const float* __restrict__ x, const float* __restrict__ Wf,
                                                    const uint8_t* __restrict__ pair_flag,
                                                    const int32_t* __restrict__ mol_ptr,
-                                                   const int32_t* __restrict__ pair_ptr, int B, int F, int max_n,
+                                                   const int32_t* __restrict__ pair_ptr,
+                                                   const int32_t* __restrict__ order, int B, int F, int max_n,
                                                    int swap, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int m = blockIdx.x;
-  if (m >= B) return;
+  if ((int)blockIdx.x >= B) return;
+  // a thread walks the n(n-1)/2 pair slots of its molecule serially: with ragged molecules the largest ones are
+  // started first (order = molecules by descending size), so that none of them begins in the last round of blocks
+  const int m = order != nullptr ? order[blockIdx.x] : (int)blockIdx.x;
   const int f = threadIdx.x;  // one feature column per thread
   const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m], np = n * (n - 1) / 2;
   float* xs = smem;                // [max_n][F]
@@ -230,15 +233,15 @@ extern "C" int geossl_rbf_fwd(const float* d, int64_t E, const float* offset, in
 }
 
 extern "C" int geossl_cfconv_aggregate(const float* x, const float* Wf, const uint8_t* pair_flag,
-                                       const int32_t* mol_ptr, const int32_t* pair_ptr, int64_t B, int max_n, int F,
-                                       int swap, float* out, hipStream_t stream) {
+                                       const int32_t* mol_ptr, const int32_t* pair_ptr, const int32_t* order, int64_t B,
+                                       int max_n, int F, int swap, float* out, hipStream_t stream) {
   if (B <= 0) return 0;
   if (max_n > 255 || F > 128) return (int)hipErrorInvalidValue;
   const size_t lds = (size_t)2 * max_n * F * sizeof(float) + (size_t)(max_n * (max_n - 1) / 2) + 16;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   allow_big_lds(&k_aggregate);
   hipLaunchKernelGGL(k_aggregate, dim3((unsigned)B), dim3(F > 64 ? 128 : 64), lds, stream, x, Wf, pair_flag, mol_ptr,
-                     pair_ptr, (int)B, F, max_n, swap, out);
+                     pair_ptr, order, (int)B, F, max_n, swap, out);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

@@ -58,6 +58,12 @@ class MolLayout:
         if self.P > 0:
             call("geossl_pair_index_fill", ptr(self.mol_ptr), ptr(self.pair_ptr), B, ptr(self.pair_i),
                  ptr(self.pair_j), stream())
+        # molecules by descending size: the sequence in which the per-molecule blocks of the aggregation are started
+        # (ops.aggregate); identity when all sizes are equal
+        self.order = None
+        if B > 1:
+            nat = self.mol_ptr[1:] - self.mol_ptr[:-1]
+            self.order = torch.argsort(nat, descending=True, stable=True).to(torch.int32)
         self.device = dev
         self._batch_version = batch._version
 

@@ -153,7 +153,7 @@ def aggregate(x, Wf_l, pair_flag, layout, swap=False):
     N, F = x.shape
     out = torch.empty_like(x)
     call("geossl_cfconv_aggregate", ptr(x), ptr(Wf_l), ptr(pair_flag), ptr(layout.mol_ptr), ptr(layout.pair_ptr),
-         layout.B, layout.max_n, F, 1 if swap else 0, ptr(out), stream())
+         ptr(layout.order), layout.B, layout.max_n, F, 1 if swap else 0, ptr(out), stream())
     return out
 
 

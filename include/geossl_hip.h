@@ -128,10 +128,12 @@ int geossl_pair_position_grad(const float* pos, const float* pair_d, const float
 
 /* ---- neighbour aggregation (K4) — MessagePassing.propagate(aggr="add") with message x_j * W
  * (schnet.py:190,194-195): out[i] = sum over edges (j -> i), j ascending, of x[j] * Wf[slot(i,j)].
- * swap = 1 runs the transposed graph (backward w.r.t. x): out[j] = sum over edges (j -> i) of x[i]*Wf.       */
+ * swap = 1 runs the transposed graph (backward w.r.t. x): out[j] = sum over edges (j -> i) of x[i]*Wf.
+ * order (may be NULL): a permutation of the molecules, the sequence in which they are started (largest first for
+ * ragged batches; it does not change any result).                                                              */
 int geossl_cfconv_aggregate(const float* x, const float* Wf, const uint8_t* pair_flag, const int32_t* mol_ptr,
-                            const int32_t* pair_ptr, int64_t B, int max_n, int F, int swap, float* out,
-                            hipStream_t stream);
+                            const int32_t* pair_ptr, const int32_t* order, int64_t B, int max_n, int F, int swap,
+                            float* out, hipStream_t stream);
 
 /* ---- atom-row Linear — ATen Linear at schnet.py:99,101,166,189,191 and its autograd.
  * Y[r][n] = epi(sum_k X[r][k] * Bm[k][n]); transB=1: W is torch layout [NO][K] (forward);
