@@ -26,72 +26,105 @@ __global__ void k_rbf(const float* __restrict__ d, int64_t E, const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------- K4
-// One wave per molecule.  Lane f owns feature columns f, f+64, ... of every atom row of the molecule, so the
-// LDS copy of x and the accumulators are thread-private (no barriers, no atomics); each filter row is read
-// once and applied in both directions.  Separate multiply and add (no FMA) in ascending source order: the
-// same rounding sequence as a sequential index_add over the canonical edge list.
-__global__ __launch_bounds__(128) void k_aggregate(const float* __restrict__ x, const float* __restrict__ Wf,
-                                                   const uint8_t* __restrict__ pair_flag,
-                                                   const int32_t* __restrict__ mol_ptr,
-                                                   const int32_t* __restrict__ pair_ptr,
-                                                   const int32_t* __restrict__ order, int B, int F, int max_n,
-                                                   int swap, float* __restrict__ out) {
+// One wave per molecule.  A lane owns VW = F/64 adjacent feature columns of every atom row of the molecule, so the
+// LDS copy of x and the accumulators are lane-private (one barrier after staging, no atomics); each filter row is
+// read once and applied in both directions.  Separate multiply and add (no FMA contraction) in ascending source
+// order: the same rounding sequence as a sequential index_add over the canonical edge list.
+//
+// The walk over the n(n-1)/2 pair slots is serial per lane and was instruction bound (47 instructions per slot and
+// column): everything about a slot that is the same for all lanes - its flags, the pair (a, b), row ends - is kept
+// in scalar registers (the flag byte goes through v_readfirstlane, so its branches are scalar branches), and the two
+// columns of a lane move as 8-byte accesses and packed fp32 operations.  With ragged molecules the blocks are
+// started largest molecule first (`order`): the largest one bounds the launch from below.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int VW>
+struct AggVec;
+template <>
+struct AggVec<1> {
+  typedef float type;
+};
+template <>
+struct AggVec<2> {
+  typedef f32x2 type;
+};
+
+template <int VW>
+__global__ __launch_bounds__(64) void k_aggregate(const float* __restrict__ x, const float* __restrict__ Wf,
+                                                  const uint8_t* __restrict__ pair_flag,
+                                                  const int32_t* __restrict__ mol_ptr,
+                                                  const int32_t* __restrict__ pair_ptr,
+                                                  const int32_t* __restrict__ order, int B, int F, int max_n, int swap,
+                                                  float* __restrict__ out) {
+#pragma clang fp contract(off)
+  typedef typename AggVec<VW>::type V;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((int)blockIdx.x >= B) return;
-  // a thread walks the n(n-1)/2 pair slots of its molecule serially: with ragged molecules the largest ones are
-  // started first (order = molecules by descending size), so that none of them begins in the last round of blocks
   const int m = order != nullptr ? order[blockIdx.x] : (int)blockIdx.x;
-  const int f = threadIdx.x;  // one feature column per thread
+  const int lane = threadIdx.x, f = VW * lane;  // first of this lane's columns
+  const bool col = f < F;
   const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m], np = n * (n - 1) / 2;
   float* xs = smem;                // [max_n][F]
   float* acc = smem + max_n * F;   // [max_n][F]
   uint8_t* sfl = reinterpret_cast<uint8_t*>(smem + 2 * max_n * F);  // [np] edge flags of the pair slots
-  for (int a = 0; a + 1 < n; ++a) {
-    const int row = a * n - a * (a + 1) / 2 - a - 1;
-    for (int b = a + 1 + threadIdx.x; b < n; b += blockDim.x) {
-      unsigned fl = pair_flag[base + row + b];
-      if (swap) fl = ((fl & 1u) << 1) | ((fl >> 1) & 1u);
-      sfl[row + b] = (uint8_t)fl;
-    }
+  for (int p = lane; p < np; p += 64) {
+    unsigned fl = pair_flag[base + p];
+    if (swap) fl = ((fl & 1u) << 1) | ((fl >> 1) & 1u);
+    sfl[p] = (uint8_t)fl;
   }
-  if (f < F)
+  if (col)
     for (int i = 0; i < n; ++i) {
-      xs[i * F + f] = x[(size_t)(a0 + i) * F + f];
-      acc[i * F + f] = 0.0f;
+      *reinterpret_cast<V*>(xs + i * F + f) = *reinterpret_cast<const V*>(x + (size_t)(a0 + i) * F + f);
+      *reinterpret_cast<V*>(acc + i * F + f) = V(0.0f);
     }
   __syncthreads();
-  if (f < F) {
+  if (col && np > 0) {
     const float* __restrict__ wcol = Wf + (size_t)base * F + f;
-    // flat walk over the pair slots (a < b, lexicographic) with eight filter rows in flight; the accumulator of the
-    // current row atom a lives in a register (it starts from the LDS value, which already holds every earlier source
+    // lane-relative LDS offsets (floats) of the rows a and b advance by F per step: no multiplies in the walk
+    const float* xl = xs + f;
+    float* al = acc + f;
+    // flat walk over the pair slots (a < b, lexicographic) with U filter rows in flight; the accumulator of the
+    // current row atom a lives in registers (it starts from the LDS value, which already holds every earlier source
     // a' < a, so the summation order per target stays ascending in the source index)
-    int a = 0, b = 1;
-    float xa = n > 0 ? xs[f] : 0.0f, acc_a = 0.0f;
-    constexpr int U = 16;  // filter rows in flight per thread
+    int ao = 0, bo = F, b = 1, a = 0;
+    V xa = *reinterpret_cast<const V*>(xl), acc_a = V(0.0f);
+    constexpr int U = 16;
     for (int p0 = 0; p0 < np; p0 += U) {
-      float w[U];
+      V w[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(wcol + (size_t)min(p0 + u, np - 1) * F);  // streamed once
+      for (int u = 0; u < U; ++u)
+        w[u] = __builtin_nontemporal_load(reinterpret_cast<const V*>(wcol + (size_t)min(p0 + u, np - 1) * F));
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (p0 + u < np) {
-          const unsigned fl = sfl[p0 + u];
-          if (fl & 1u) acc_a = __fadd_rn(acc_a, __fmul_rn(xs[b * F + f], w[u]));                  // edge b -> a
-          if (fl & 2u) acc[b * F + f] = __fadd_rn(acc[b * F + f], __fmul_rn(xa, w[u]));           // edge a -> b
+          const unsigned fl = __builtin_amdgcn_readfirstlane((unsigned)sfl[p0 + u]);  // the same for every lane
+          if (fl & 1u) {  // edge b -> a
+            const V t = *reinterpret_cast<const V*>(xl + bo) * w[u];
+            acc_a = acc_a + t;
+          }
+          if (fl & 2u) {  // edge a -> b
+            const V t = xa * w[u];
+            *reinterpret_cast<V*>(al + bo) = *reinterpret_cast<const V*>(al + bo) + t;
+          }
+          bo += F;
           if (++b == n) {  // row a finished: publish its sum, move to the next row atom
-            acc[a * F + f] = acc_a;
+            *reinterpret_cast<V*>(al + ao) = acc_a;
             ++a;
+            ao += F;
             b = a + 1;
-            if (a < n) {
-              xa = xs[a * F + f];
-              acc_a = acc[a * F + f];
+            bo = ao + F;
+            if (b < n) {  // (the last row atom has no partner: nothing more to read)
+              xa = *reinterpret_cast<const V*>(xl + ao);
+              acc_a = *reinterpret_cast<const V*>(al + ao);
             }
           }
         }
       }
     }
-    for (int i = 0; i < n; ++i) out[(size_t)(a0 + i) * F + f] = acc[i * F + f];
   }
+  if (col)
+    for (int i = 0; i < n; ++i)
+      *reinterpret_cast<V*>(out + (size_t)(a0 + i) * F + f) = *reinterpret_cast<const V*>(acc + i * F + f);
 }
 
 // --------------------------------------------------------------------------------------------- embedding
@@ -239,9 +272,15 @@ extern "C" int geossl_cfconv_aggregate(const float* x, const float* Wf, const ui
   if (max_n > 255 || F > 128) return (int)hipErrorInvalidValue;
   const size_t lds = (size_t)2 * max_n * F * sizeof(float) + (size_t)(max_n * (max_n - 1) / 2) + 16;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-  allow_big_lds(&k_aggregate);
-  hipLaunchKernelGGL(k_aggregate, dim3((unsigned)B), dim3(F > 64 ? 128 : 64), lds, stream, x, Wf, pair_flag, mol_ptr,
-                     pair_ptr, order, (int)B, F, max_n, swap, out);
+  if (F > 64) {
+    allow_big_lds(&k_aggregate<2>);
+    hipLaunchKernelGGL(k_aggregate<2>, dim3((unsigned)B), dim3(64), lds, stream, x, Wf, pair_flag, mol_ptr, pair_ptr,
+                       order, (int)B, F, max_n, swap, out);
+  } else {
+    allow_big_lds(&k_aggregate<1>);
+    hipLaunchKernelGGL(k_aggregate<1>, dim3((unsigned)B), dim3(64), lds, stream, x, Wf, pair_flag, mol_ptr, pair_ptr,
+                       order, (int)B, F, max_n, swap, out);
+  }
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
