@@ -26,6 +26,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace geossl {
 
+// hipcc contracts a * b + c into an fma wherever it can (-ffp-contract=fast), and __fmul_rn / __fadd_rn are plain
+// operators to it.  Where the reference's own rounding sequence matters (edge decisions of the radius graph, the
+// message sum), the arithmetic goes through these helpers: the pragma clears the contract flag of their operations.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+// fl32(fl32(fl32(x*x) + fl32(y*y)) + fl32(z*z))
+__device__ __forceinline__ float norm2_rn(float x, float y, float z) {
+#pragma clang fp contract(off)
+  const float xx = x * x, yy = y * y, zz = z * z;
+  return (xx + yy) + zz;
+}
+
 __device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // ShiftedSoftplus (schnet.py:210-216): F.softplus(x) (beta 1, threshold 20) - fp32(log 2).

@@ -12,9 +12,8 @@ using namespace geossl;
 namespace {
 
 __device__ __forceinline__ float dist2_nofma(const float* pi, const float* pj) {
-  // fl32(fl32(fl32(dx*dx)+fl32(dy*dy))+fl32(dz*dz)), d = x_j - x_i; explicit _rn ops so nothing is contracted
-  const float dx = __fsub_rn(pj[0], pi[0]), dy = __fsub_rn(pj[1], pi[1]), dz = __fsub_rn(pj[2], pi[2]);
-  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+  // fl32(fl32(fl32(dx*dx)+fl32(dy*dy))+fl32(dz*dz)), d = x_j - x_i, nothing contracted (common.h)
+  return norm2_rn(pj[0] - pi[0], pj[1] - pi[1], pj[2] - pi[2]);
 }
 
 // ---------------------------------------------------------------------------------------------- layout
@@ -185,7 +184,7 @@ __global__ __launch_bounds__(64) void k_radius(const float* __restrict__ pos, co
         const float d = sqrtf(d2);
         pair_d[row + b] = d;
         // CFConv envelope, schnet.py:186: 0.5 * (cos(d * PI / cutoff) + 1.0), fp32 op by op
-        pair_c[row + b] = 0.5f * (cosf(__fdiv_rn(__fmul_rn(d, GEOSSL_PI_F), cutoff)) + 1.0f);
+        pair_c[row + b] = 0.5f * (cosf(mul_rn(d, GEOSSL_PI_F) / cutoff) + 1.0f);
         pair_flag[row + b] = (uint8_t)(f0 | (f1 << 1));
       }
     }
@@ -251,9 +250,7 @@ __global__ void k_pair_distance(const float* __restrict__ pos, const int64_t* __
                                 const int64_t* __restrict__ sei1, int S, float* __restrict__ out) {
   for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += gridDim.x * blockDim.x) {
     const int64_t u = sei0[s], v = sei1[s];
-    const float dx = __fsub_rn(pos[3 * u], pos[3 * v]), dy = __fsub_rn(pos[3 * u + 1], pos[3 * v + 1]),
-                dz = __fsub_rn(pos[3 * u + 2], pos[3 * v + 2]);
-    out[s] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    out[s] = sqrtf(norm2_rn(pos[3 * u] - pos[3 * v], pos[3 * u + 1] - pos[3 * v + 1], pos[3 * u + 2] - pos[3 * v + 2]));
   }
 }
 

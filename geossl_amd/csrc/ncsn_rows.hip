@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512) void k_ncsn_fwd(const float* __restrict__ h, c
     };
     gather(0, gq[0]);
     if (rb + gridDim.x * 8 < nrb) cur = load_row(rb + gridDim.x * 8);  // next row block's scalars
-    const float pd = __fadd_rn(in.d, __fmul_rn(in.eps, in.sigma));  // :196
+    const float pd = add_rn(in.d, mul_rn(in.eps, in.sigma));  // :196
     // distance embedding (:197): MLP 1 -> F -> 1 with relu; each half-wave sums half of the hidden units
     float e = 0.0f;
 #pragma unroll 4
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(512) void k_ncsn_fwd(const float* __restrict__ h, c
     const float out = sc + b3;
     const float inv_sigma = 1.0f / in.sigma;
     const float score = out * inv_sigma;                                            // :205
-    const float target = (-1.0f / (in.sigma * in.sigma)) * __fsub_rn(pd, in.d);     // :199
+    const float target = (-1.0f / (in.sigma * in.sigma)) * (pd - in.d);              // :199
     const float diff = score - target;
     const float pw = powf(in.sigma, anneal_power);
     if (valid && kh == 0) {

@@ -30,11 +30,11 @@ __global__ void k_painn_edge_geom(const float* __restrict__ pos, const int64_t* 
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = idx_i[e], j = idx_j[e];
     const float rx = pos[3 * i] - pos[3 * j], ry = pos[3 * i + 1] - pos[3 * j + 1], rz = pos[3 * i + 2] - pos[3 * j + 2];
-    const float d = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz)));
+    const float d = sqrtf(norm2_rn(rx, ry, rz));
     dir[3 * e] = rx / d;
     dir[3 * e + 1] = ry / d;
     dir[3 * e + 2] = rz / d;
-    const float c = 0.5f * (cosf(__fdiv_rn(__fmul_rn(d, GEOSSL_PI_F), cutoff)) + 1.0f);
+    const float c = 0.5f * (cosf(mul_rn(d, GEOSSL_PI_F) / cutoff) + 1.0f);
     fcut[e] = d < cutoff ? c : 0.0f;
     for (int r = 0; r < R; ++r) {
       const float w = widths[r];
