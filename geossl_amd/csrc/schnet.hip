@@ -31,10 +31,9 @@ __global__ void k_rbf(const float* __restrict__ d, int64_t E, const float* __res
 // read once and applied in both directions.  Separate multiply and add (no FMA contraction) in ascending source
 // order: the same rounding sequence as a sequential index_add over the canonical edge list.
 //
-// The walk over the n(n-1)/2 pair slots is serial per lane and was instruction bound (47 instructions per slot and
-// column): everything about a slot that is the same for all lanes - its flags, the pair (a, b), row ends - is kept
-// in scalar registers (the flag byte goes through v_readfirstlane, so its branches are scalar branches), and the two
-// columns of a lane move as 8-byte accesses and packed fp32 operations.  With ragged molecules the blocks are
+// The walk over the n(n-1)/2 pair slots is serial per lane; everything about a slot that is the same for all lanes
+// - its flags, the pair (a, b), row ends - is kept in scalar registers, and the two columns of a lane move as 8-byte
+// accesses and packed fp32 operations (details at the walk).  With ragged molecules the blocks are
 // started largest molecule first (`order`): the largest one bounds the launch from below.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -80,43 +79,77 @@ __global__ __launch_bounds__(64) void k_aggregate(const float* __restrict__ x, c
   __syncthreads();
   if (col && np > 0) {
     const float* __restrict__ wcol = Wf + (size_t)base * F + f;
-    // lane-relative LDS offsets (floats) of the rows a and b advance by F per step: no multiplies in the walk
     const float* xl = xs + f;
     float* al = acc + f;
-    // flat walk over the pair slots (a < b, lexicographic) with U filter rows in flight; the accumulator of the
-    // current row atom a lives in registers (it starts from the LDS value, which already holds every earlier source
-    // a' < a, so the summation order per target stays ascending in the source index)
-    int ao = 0, bo = F, b = 1, a = 0;
-    V xa = *reinterpret_cast<const V*>(xl), acc_a = V(0.0f);
-    constexpr int U = 16;
-    for (int p0 = 0; p0 < np; p0 += U) {
-      V w[U];
+    // Walk by row atom a, U consecutive partners b at a time (a chunk never crosses a row, so its U accumulator rows
+    // are distinct): the flags of the chunk become two scalar bit masks (one LDS read + ballots), the U rows of x and
+    // of the accumulators are requested together and the U filter rows of the NEXT chunk are already in flight - no
+    // wait inside a chunk depends on another.  Slots past the end of a row are computed on clamped rows and dropped
+    // by selects (not by multiplying with zero: the sums stay bit-exact).  The accumulator of the row atom lives in
+    // registers; it starts from the LDS value, which already holds every earlier source a' < a, so the summation
+    // order per target stays ascending in the source index.
+    constexpr int U = 8, D = 4;  // D chunks (32 filter rows, 16 KB per wave) requested ahead of the one in work: a
+                                 // wave's stream is bound by the memory round trip, and with ragged molecules
+                                 // (LDS sized for the largest) only half as many waves are resident
+    V w[D][U];
+    auto request = [&](int a, int b0, V (&dst)[U]) {
+      const int rs = a * n - a * (a + 1) / 2 - a - 1;   // slot of (a, b) = rs + b
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        w[u] = __builtin_nontemporal_load(reinterpret_cast<const V*>(wcol + (size_t)min(p0 + u, np - 1) * F));
+        dst[u] = __builtin_nontemporal_load(
+            reinterpret_cast<const V*>(wcol + (uint32_t)(rs + min(b0 + u, n - 1)) * (uint32_t)F));  // streamed once
+    };
+    auto advance = [&](int& a, int& b0) {
+      b0 += U;
+      if (b0 >= n) {
+        ++a;
+        b0 = a + 1;
+      }
+    };
+    int a = 0, b0 = 1, ap = 0, bp = 1;  // chunk in work, next chunk to request
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (p0 + u < np) {
-          const unsigned fl = __builtin_amdgcn_readfirstlane((unsigned)sfl[p0 + u]);  // the same for every lane
-          if (fl & 1u) {  // edge b -> a
-            const V t = *reinterpret_cast<const V*>(xl + bo) * w[u];
-            acc_a = acc_a + t;
+    for (int k = 0; k < D; ++k)
+      if (ap < n - 1) {
+        request(ap, bp, w[k]);
+        advance(ap, bp);
+      }
+    V xa = *reinterpret_cast<const V*>(xl), acc_a = V(0.0f);
+    while (a < n - 1) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        if (a < n - 1) {
+          const int rs = a * n - a * (a + 1) / 2 - a - 1;
+          const unsigned flv = (lane < U && b0 + lane < n) ? (unsigned)sfl[rs + b0 + lane] : 0u;
+          const unsigned long long m0 = __builtin_amdgcn_ballot_w64((flv & 1u) != 0u);  // edge b -> a
+          const unsigned long long m1 = __builtin_amdgcn_ballot_w64((flv & 2u) != 0u);  // edge a -> b
+          V xb[U], ab[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int bo = min(b0 + u, n - 1) * F;
+            xb[u] = *reinterpret_cast<const V*>(xl + bo);
+            ab[u] = *reinterpret_cast<const V*>(al + bo);
           }
-          if (fl & 2u) {  // edge a -> b
-            const V t = xa * w[u];
-            *reinterpret_cast<V*>(al + bo) = *reinterpret_cast<const V*>(al + bo) + t;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const V t0 = xb[u] * w[k][u];
+            const V s0 = acc_a + t0;
+            acc_a = ((m0 >> u) & 1ull) ? s0 : acc_a;
+            const V t1 = xa * w[k][u];
+            const V s1 = ab[u] + t1;
+            if ((m1 >> u) & 1ull) *reinterpret_cast<V*>(al + (b0 + u) * F) = s1;   // uniform: a scalar branch
           }
-          bo += F;
-          if (++b == n) {  // row a finished: publish its sum, move to the next row atom
-            *reinterpret_cast<V*>(al + ao) = acc_a;
-            ++a;
-            ao += F;
-            b = a + 1;
-            bo = ao + F;
-            if (b < n) {  // (the last row atom has no partner: nothing more to read)
-              xa = *reinterpret_cast<const V*>(xl + ao);
-              acc_a = *reinterpret_cast<const V*>(al + ao);
+          const int a_was = a;
+          advance(a, b0);
+          if (a != a_was) {  // row finished: publish its sum, move to the next row atom
+            *reinterpret_cast<V*>(al + a_was * F) = acc_a;
+            if (a < n - 1) {
+              xa = *reinterpret_cast<const V*>(xl + a * F);
+              acc_a = *reinterpret_cast<const V*>(al + a * F);
             }
+          }
+          if (ap < n - 1) {  // refill this buffer
+            request(ap, bp, w[k]);
+            advance(ap, bp);
           }
         }
       }

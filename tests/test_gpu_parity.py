@@ -727,6 +727,8 @@ _RANK_WORKER = r"""
 import os, sys
 sys.path.insert(0, {repo!r})
 sys.path.insert(0, os.path.join({repo!r}, "tests")); sys.path.insert(0, os.path.join({repo!r}, "tests", "golden"))
+import faulthandler
+faulthandler.dump_traceback_later(120, exit=True)   # a stuck rank reports where and leaves; nothing lingers on the GPU
 import torch, torch.distributed as dist
 from geossl_amd import pretrain_GeoSSL as pg
 from geossl_amd.parallel import init_distributed, local_device, shard_batch_numpy
@@ -765,11 +767,27 @@ def test_two_rank_trainer_matches_single_process(tmp_path):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "rank_worker.py"
     script.write_text(_RANK_WORKER.format(repo=repo, out=str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2", GEOSSL_DIST_BACKEND="gloo")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
-             for r in range(2)]
-    for p in procs:
-        assert p.wait(timeout=600) == 0
+    import socket
+    with socket.socket() as sock:  # a port nobody holds right now
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", GEOSSL_DIST_BACKEND="gloo")
+    logs = [open(tmp_path / ("rank%d.log" % r), "w") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=logs[r], stderr=subprocess.STDOUT) for r in range(2)]
+    try:
+        codes = [p.wait(timeout=180) for p in procs]
+    except subprocess.TimeoutExpired:
+        codes = None
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+        for f in logs:
+            f.close()
+    tails = "\n".join(open(tmp_path / ("rank%d.log" % r)).read()[-1500:] for r in range(2))
+    assert codes == [0, 0], tails
     r0 = torch.load(tmp_path / "rank0.pt", weights_only=False)
     r1 = torch.load(tmp_path / "rank1.pt", weights_only=False)
     assert torch.equal(r0["params"], r1["params"])  # replicas stay in lock step
