@@ -99,6 +99,19 @@ def cpu_baseline(seed, n_mols=1024, timed=2, max_threads=16):
                       "median %.2f s/step" % (n_mols, timed, med)}
 
 
+def measured_step_traffic(mols_per_s):
+    """FETCH_SIZE + WRITE_SIZE of every kernel of a step, from the committed rocprofv3 PMC passes over
+    tools/prof_step.py (4 eager steps of the same 1024-molecule workload): what the step really moves through HBM,
+    next to SURVEY 8(d)'s algorithmic figure (which prices the reference's unfused formulation)."""
+    try:
+        pm = json.load(open(os.path.join(REPO, "profiles", "r01_hbm_traffic_pmc.json")))["kernels"]
+        tot = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in pm.values())
+        per_mol = tot / 4 / 1024
+        return {"measured_MB_per_mol": per_mol / 1e6, "measured_hbm_frac": per_mol * mols_per_s / HBM_PEAK}
+    except (OSError, KeyError, ValueError):
+        return {"measured_MB_per_mol": None, "measured_hbm_frac": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,6 +361,7 @@ def main():
                        "execution": "HIP graph replay of fwd+bwd, eager all-reduce + Adam" if trainer.use_graph else "eager"},
             "roofline": roof,
             "step_roofline": {"hbm_frac": step_bytes * (per_gpu / args.mols) / HBM_PEAK,
+                              **measured_step_traffic(per_gpu),
                               "fp32_frac": step_flops * (per_gpu / args.mols) / FP32_PEAK,
                               "alg_MB_per_mol": step_bytes / args.mols / 1e6,
                               "alg_MFLOP_per_mol": step_flops / args.mols / 1e6},
