@@ -204,7 +204,11 @@ class _PaiNNCore(torch.autograd.Function):
             mm = ops.linear(mu2.view(3 * N, F_), mw)                         # mu_channel_mix        :100
             cx, dot = torch.empty(N, 2 * F_, **f32), torch.empty(N, F_, **f32)
             call("geossl_painn_mix_pre_fwd", ptr(q2), ptr(mm), N, F_, cfg["eps"], ptr(cx), ptr(dot), st)  # :101-104
-            u1 = ops.linear(cx, i0w, bias=i0b)                               # Dense(2F, F, silu)    :105
+            # Dense(2F, F, silu) :105 - a contraction over 2F columns is two passes of the F-wide row GEMM (the split
+            # kernel holds one K <= 128 weight image in LDS): the second adds onto the first through the residual operand
+            i0a, i0c = i0w[:, :F_].contiguous(), i0w[:, F_:].contiguous()
+            u1 = ops.linear(cx[:, :F_], i0a, bias=i0b)
+            ops.linear(cx[:, F_:], i0c, res=u1, out=u1)
             s1 = torch.empty_like(u1)
             call("geossl_silu_fwd", ptr(u1), u1.numel(), ptr(s1), st)
             xx = torch.empty(N, 3 * F_, **f32)
@@ -271,7 +275,9 @@ class _PaiNNCore(torch.autograd.Function):
             dq2 = torch.empty(N, F_, **f32)
             call("geossl_painn_mix_pre_bwd", ptr(dq_cur), ptr(dctx), ptr(sv["cx"]), ptr(sv["mm"]), N, F_, ptr(dq2),
                  ptr(dmm), st)
-            dmu2 = ops.linear(dmm, mw, transB=False, res=dmu_cur.view(3 * N, F_))   # d mu (after interaction)
+            # d mu (after interaction): contraction over the 2F columns of dmm in two F-wide passes
+            dmu2 = ops.linear(dmm[:, :F_], mw[:F_], transB=False, res=dmu_cur.view(3 * N, F_))
+            ops.linear(dmm[:, F_:], mw[F_:], transB=False, res=dmu2, out=dmu2)
             for c in range(2):
                 add(3 * N, 2 * F_, F_, F_, dmm[:, c * F_:(c + 1) * F_], sv["mu2"].view(3 * N, F_),
                     gmw[c * F_:(c + 1) * F_], None)
