@@ -82,6 +82,32 @@ def test_device_atom_tuple_extractor_bit_exact(option):
         AtomTupleExtractor(ratio=0.5)
 
 
+def test_layout_from_host_sizes_equals_layout_from_device_scan():
+    """Collation-time layouts (layout.prepare_batch: molecule sizes known on the host, nothing read back from the
+    device) are the same structures the lazy path derives from the batch vector, and the step finds them."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.layout import MolLayout, get_super_edge_layout
+    from geossl_amd.synthetic import make_batch
+    b = make_batch(0, seed=9, sizes=[1, 2, 5, 18, 29, 33, 3, 1, 40])
+    bat = t(b["batch"], DEV)
+    a, c = MolLayout(bat), MolLayout(bat, sizes=list(b["sizes"]))
+    assert (a.N, a.B, a.P, a.max_n) == (c.N, c.B, c.P, c.max_n)
+    for k in ("mol_ptr", "pair_ptr", "pair_i", "pair_j", "order"):
+        assert torch.equal(getattr(a, k), getattr(c, k)), k
+    sizes_sorted = torch.tensor(b["sizes"])[a.order.cpu().long()]
+    assert bool((sizes_sorted[:-1] >= sizes_sorted[1:]).all())  # largest molecule first
+    with pytest.raises(ValueError):
+        MolLayout(bat, sizes=list(b["sizes"])[:-1])
+    batch = pg.Batch.from_numpy(b, DEV)       # builds the two-view layout and the super-edge lists from b["sizes"]
+    b2, lay2 = pg._two_view_batch(batch.batch, batch.num_graphs)
+    ref2 = MolLayout(b2)
+    assert lay2.P == ref2.P and torch.equal(lay2.pair_i, ref2.pair_i) and torch.equal(lay2.pair_ptr, ref2.pair_ptr)
+    se = get_super_edge_layout(batch.batch, batch.super_edge_index, batch.num_graphs)
+    from geossl_amd.layout import SuperEdgeLayout
+    ref = SuperEdgeLayout(batch.batch, batch.super_edge_index, batch.num_graphs)
+    assert torch.equal(se.se_ptr, ref.se_ptr) and torch.equal(se.inc_ptr, ref.inc_ptr) and torch.equal(se.inc_idx, ref.inc_idx)
+
+
 def test_pair_geometry_matches_edge_list():
     """The pair-slot form used inside SchNet carries exactly the canonical edge set."""
     from geossl_amd import ops
