@@ -4,7 +4,7 @@ perturbed view + 2x NCSN_version_03 + backward + Adam), bs = 1024 molecules per 
 Molecule3D-shaped batches (n = 18 atoms, 5 A cutoff), fp32.  BASELINE.json configs[2] (the
 configuration the metric is quoted on); SURVEY.md §8(d) defines inputs, byte/flop model and protocol.
 
-    python bench.py --gpus 1 --steps 30 --warmup 5
+    python bench.py --gpus 1 --steps 100 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -65,16 +65,18 @@ def alg_model(n_atoms, n_edges, n_super):
     return step_bytes, step_flops, per_kernel
 
 
-def cpu_baseline(seed, n_mols=1024, timed=2, max_threads=16):
+def cpu_baseline(seed, n_mols=512, timed=3, max_threads=None):
     """The CPU oracle (pure-torch restatement pinned to the reference by golden vectors) on a bounded
-    sample of the same workload: DDM step fwd+bwd + Adam on `n_mols` molecules."""
+    sample of the same workload: DDM step fwd+bwd + Adam on `n_mols` of the 1024 molecules of a bench batch,
+    1 warm-up + `timed` timed steps on every host core (SURVEY 8(d) / BASELINE.md 3)."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
     from geossl_amd.synthetic import draw_noise, make_batch
     from helpers import ncsn_oracle_params, schnet_oracle_params, t
     from oracle import nets
-    # the step is ~150 small ATen ops: beyond ~16 threads torch's CPU backend only adds fork/join overhead
-    cores = min(os.cpu_count() or 1, max_threads)
+    cores = os.cpu_count() or 1
+    if max_threads:
+        cores = min(cores, max_threads)
     torch.set_num_threads(cores)
     cfg = dict(hidden_channels=F, num_filters=F, num_interactions=L, num_gaussians=G, cutoff=CUTOFF, node_class=9,
                readout="mean")
@@ -95,28 +97,46 @@ def cpu_baseline(seed, n_mols=1024, timed=2, max_threads=16):
         times.append(time.perf_counter() - t0)
     med = float(np.median(times[1:]))
     return {"value": n_mols / med, "unit": "molecules/s", "cores": cores, "kind": "port",
-            "sample": "oracle DDM step (fwd+bwd+Adam) on %d of the 1024 molecules, 1 warm-up + %d timed steps, "
-                      "median %.2f s/step" % (n_mols, timed, med)}
+            "sample": "oracle DDM step (fwd+bwd+Adam) on %d molecules of the bench shape (n=18, 5 A), 1 warm-up + %d "
+                      "timed steps on %d torch threads, median %.2f s/step" % (n_mols, timed, cores, med)}
 
 
-def measured_step_traffic(mols_per_s):
+def pmc_file(workload):
+    """The newest committed rocprofv3 PMC summary (tools/pmc_traffic.py) that was recorded for `workload` (the file
+    names its own workload and the commit it was taken on); None when there is none - traffic figures of another
+    workload or of an unknown build are not reported."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic_pmc.json")), reverse=True):
+        try:
+            pm = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if pm.get("workload") == workload and "kernels" in pm:
+            return pm, os.path.basename(path)
+    return None, None
+
+
+def measured_step_traffic(pm, src, mols_per_s):
     """FETCH_SIZE + WRITE_SIZE of every kernel of a step, from the committed rocprofv3 PMC passes over
-    tools/prof_step.py (4 eager steps of the same 1024-molecule workload): what the step really moves through HBM,
-    next to SURVEY 8(d)'s algorithmic figure (which prices the reference's unfused formulation)."""
-    try:
-        pm = json.load(open(os.path.join(REPO, "profiles", "r01_hbm_traffic_pmc.json")))["kernels"]
-        tot = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in pm.values())
-        per_mol = tot / 4 / 1024
-        return {"measured_MB_per_mol": per_mol / 1e6, "measured_hbm_frac": per_mol * mols_per_s / HBM_PEAK}
-    except (OSError, KeyError, ValueError):
-        return {"measured_MB_per_mol": None, "measured_hbm_frac": None}
+    tools/prof_step.py (eager steps of the same workload): what the step really moves through HBM, next to
+    SURVEY 8(d)'s algorithmic figure (which prices the reference's unfused formulation)."""
+    if pm is None:
+        return {"measured_MB_per_mol": None, "measured_hbm_frac": None, "measured_from": None}
+    tot = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in pm["kernels"].values())
+    per_mol = tot / pm["steps"] / pm["molecules_per_step"]
+    return {"measured_MB_per_mol": per_mol / 1e6, "measured_hbm_frac": per_mol * mols_per_s / HBM_PEAK,
+            "measured_from": "%s @ %s" % (src, pm.get("git_head"))}
+
+
+def workload_id(model, mols, molset, cutoff):
+    return "%s/ddm-step/mols=%d/set=%s/cutoff=%g" % (model, mols, molset, cutoff)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mols", type=int, default=1024, help="molecules per GPU per step")
     ap.add_argument("--dataset-mols", type=int, default=100000, help="synthetic dataset size (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -246,7 +266,9 @@ def main():
     def one_step(i):
         bt = batches[i % n_batches]
         # set A: every batch has the same index structure (1024 x 18 atoms) -> one captured graph serves all
-        return trainer.step(bt, draw(bt, i), structure_key=("setA", args.mols, 18) if args.molset == "A" else None)
+        # (PaiNN: the precomputed radius_edge_index differs from batch to batch, and a captured graph binds it - eager)
+        key = ("setA", args.mols, 18) if (args.molset == "A" and args.model == "schnet") else None
+        return trainer.step(bt, draw(bt, i), structure_key=key)
 
     # one untimed priming step ahead of the W warm-up steps: builds the cached index structures and captures the HIP
     # graph, so that even --warmup 0 times steady-state steps
@@ -304,6 +326,7 @@ def main():
         E = int(ops.radius_graph(bt.positions, CUTOFF, bt.batch).size(1))
         N, S = bt.positions.size(0), bt.super_edge_index.size(1)
         step_bytes, step_flops, per_kernel = alg_model(N, E, S)
+        pm, pm_src = pmc_file(workload_id(args.model, args.mols, args.molset, CUTOFF))
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * args.mols * args.steps / elapsed
         kern = {}
@@ -318,32 +341,31 @@ def main():
             fl, by = per_kernel[dom]
             dur = kern[dom][0] * 1e-3
             ach_f, ach_b = fl / dur, by / dur
-            # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_hbm_traffic_pmc.json),
-            # summed over the kernels the entry point launches
+            # HBM bytes per launch from the committed rocprofv3 PMC passes of THIS workload (else null), summed over
+            # the kernels the entry point launches
             traffic = None
-            try:
-                pm = json.load(open(os.path.join(REPO, "profiles", "r01_hbm_traffic_pmc.json")))["kernels"]
-                ks = [v for k, v in pm.items() if k.startswith(ENTRY_KERNELS.get(dom, "\0"))]
+            if pm is not None:
+                ks = [v for k, v in pm["kernels"].items() if k.startswith(ENTRY_KERNELS.get(dom, "\0"))]
                 if ks:
                     traffic = sum(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for v in ks)
-            except (OSError, KeyError, ValueError):
-                pass
-            # the dense kernels run on the bf16 matrix pipe, six MFMAs per fp32 product (csrc/split.h): `achieved`
-            # is SURVEY 8(d)'s algorithmic fp32 flops (reference formulation: one filter evaluation per DIRECTED edge)
-            # over the measured launch time, `peak` the pipe's fp32-equivalent ceiling.  `executed_*` prices what the
-            # kernel really issues: one evaluation per undirected pair slot, G padded to 64, times six bf16 MFMAs.
-            peak = BF16_PEAK / SPLIT_PRODUCTS
-            roof = {"kernel": dom, "bound": "mfma", "achieved": ach_f / 1e12, "peak": peak / 1e12,
-                    "unit": "TFLOP/s", "frac": ach_f / peak, "traffic": traffic,
+            # The dense kernels run on the bf16 matrix pipe, six MFMAs per fp32 product (csrc/split.h).
+            # `frac` = what the kernel really issues (one filter evaluation per UNDIRECTED pair slot, G padded to 64,
+            # times six bf16 MFMAs) over the dense bf16 MFMA peak: the pipe's utilisation.  `frac_algorithmic` credits
+            # SURVEY 8(d)'s fp32 flops of the reference formulation (one evaluation per DIRECTED edge) against the
+            # pipe's fp32-equivalent ceiling (peak / 6) - the exact halving by symmetry shows up there, not in `frac`.
+            roof = {"kernel": dom, "bound": "mfma", "unit": "TFLOP/s", "traffic": traffic,
+                    "traffic_from": ("%s @ %s" % (pm_src, pm.get("git_head"))) if traffic is not None else None,
                     "avg_launch_ms": kern[dom][0], "launches_per_step": kern[dom][1], "timing": timing_mode,
-                    "algorithmic_GBps": ach_b / 1e9, "hbm_frac": ach_b / HBM_PEAK,
-                    "peak_note": "2.5 PFLOP/s dense bf16 MFMA / 6 MFMAs per fp32 product"}
+                    "algorithmic_TFLOPs": ach_f / 1e12, "frac_algorithmic": ach_f / (BF16_PEAK / SPLIT_PRODUCTS),
+                    "algorithmic_GBps": ach_b / 1e9, "hbm_frac": ach_b / HBM_PEAK}
             if dom in ("geossl_cfconv_filter_fwd", "geossl_cfconv_filter_bwd"):
                 P2 = 2 * sum(int(n) * (int(n) - 1) // 2 for n in sizes0)  # pair slots, both views
                 per_row = (2 * 64 * F + (2 if dom.endswith("fwd") else 4) * F * F)
                 exe = P2 * L * per_row * SPLIT_PRODUCTS
-                roof["executed_bf16_TFLOPs"] = exe / dur / 1e12
-                roof["executed_frac_of_bf16_peak"] = exe / dur / BF16_PEAK
+            else:  # other entry points issue their algorithmic flops, six MFMAs per product
+                exe = fl * SPLIT_PRODUCTS
+            roof.update({"achieved": exe / dur / 1e12, "peak": BF16_PEAK / 1e12, "frac": exe / dur / BF16_PEAK,
+                         "peak_note": "executed bf16 MFMA flops (6 per fp32 product) over the 2.5 PFLOP/s dense bf16 peak"})
         per_gpu = value / world
         out = {
             "metric": ("molecules/s/GPU SchNet+DDM fwd+bwd (QM9-sized, bs=1024); % HBM roofline" if args.model == "schnet"
@@ -361,7 +383,7 @@ def main():
                        "execution": "HIP graph replay of fwd+bwd, eager all-reduce + Adam" if trainer.use_graph else "eager"},
             "roofline": roof,
             "step_roofline": {"hbm_frac": step_bytes * (per_gpu / args.mols) / HBM_PEAK,
-                              **measured_step_traffic(per_gpu),
+                              **measured_step_traffic(pm, pm_src, per_gpu),
                               "fp32_frac": step_flops * (per_gpu / args.mols) / FP32_PEAK,
                               "alg_MB_per_mol": step_bytes / args.mols / 1e6,
                               "alg_MFLOP_per_mol": step_flops / args.mols / 1e6},

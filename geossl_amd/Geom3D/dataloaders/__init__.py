@@ -1,1 +1,2 @@
-from .dataloaders_AtomTuple import AtomTupleExtractor, BatchAtomTuple  # noqa: F401
+from .dataloaders_AtomTuple import (AtomTupleExtractor, BatchAtomTuple, Data,  # noqa: F401
+                                    DataLoaderAtomTuple)

@@ -125,6 +125,12 @@ class PaiNN(nn.Module):
         layers.append(Dense(neurons[-2], neurons[-1], activation=None))
         return nn.Sequential(*layers)
 
+    def check_status(self):
+        """Synchronous form of the deferred index check (drains the stream)."""
+        st = self.__dict__.get("_geossl_status")
+        if st is not None:
+            st.check()
+
     def _params(self):
         ps = [self.embedding.weight, self.filter_net.weight, self.filter_net.bias]
         for blk in self.interactions:
@@ -148,10 +154,14 @@ class PaiNN(nn.Module):
         atomic_numbers = x[:, 0] if x.dim() == 2 else x  # painn.py:226-229
         lay = get_layout(batch)
         el = get_edge_layout(batch, radius_edge_index, lay.B)
+        status = _lib.module_status(self, positions.device, "atomic number out of range for the embedding table "
+                                    "(max_z=%d)" % self.embedding.num_embeddings)
+        status.poll()  # an out-of-range atomic number seen by an earlier call raises here (IndexError, like Embedding)
         cfg = dict(F=self.n_atom_basis, L=self.n_interactions, R=self.radial_basis.n_rbf, cutoff=float(self.cutoff),
                    offsets=self.radial_basis.offsets, widths=self.radial_basis.widths,
-                   eps=float(self.mixing[0].epsilon))
+                   eps=float(self.mixing[0].epsilon), status=status, debug=bool(os.environ.get("GEOSSL_DEBUG")))
         q = _PaiNNCore.apply(atomic_numbers, positions.contiguous(), el, cfg, *self._params())
+        status.arm()
         from .schnet import _SegmentReduce
         h = _SegmentReduce.apply(q, lay, self.readout)  # painn.py:266
         if return_latent:
@@ -184,7 +194,9 @@ class _PaiNNCore(torch.autograd.Function):
              ptr(cfg["widths"]), R, ptr(dirv), ptr(fcut), ptr(phi), st)
         q = torch.empty(N, F_, **f32)
         call("geossl_embedding_fwd", ptr(z), z.stride(0) if z.numel() else 1, ptr(emb_w), emb_w.size(0), N, F_, ptr(q),
-             None, st)                                                      # painn.py:247 (row 0 is the zero padding row)
+             ptr(cfg["status"].word), st)                                   # painn.py:247 (row 0 is the zero padding row)
+        if cfg["debug"]:
+            cfg["status"].check()
         mu = torch.zeros(N, 3, F_, **f32)                                    # :249
         inc_ptr, inc_idx = el.inc["i"]
         saved = []
@@ -233,7 +245,7 @@ class _PaiNNCore(torch.autograd.Function):
         dev, N = dq.device, dq.size(0)
         st = stream()
         f32 = dict(dtype=torch.float32, device=dev)
-        direct = all(p.grad is not None and p.grad.is_contiguous() and p.grad.is_cuda for p in ctx.params)
+        direct = _lib.direct_grads_enabled(ctx.params)  # opt-in (DDMTrainer); otherwise gradients go through autograd
         grads = [p.grad for p in ctx.params] if direct else [torch.zeros_like(p) for p in ps]
         acc = 1 if direct else 0
         g_emb, g_fw, g_fb = grads[0], grads[1], grads[2]

@@ -26,16 +26,37 @@ from ._atomic_mass import atomic_masses
 SUPPORTED_F = (32, 64, 128)
 
 
+class _Ssp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        call("geossl_ssp_fwd", ptr(x), x.numel(), ptr(y), stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        call("geossl_ssp_bwd", ptr(y), ptr(dy.contiguous()), y.numel(), ptr(dx), stream())
+        return dx
+
+
 class ShiftedSoftplus(torch.nn.Module):
-    """schnet.py:210-216.  Only evaluated inside the fused kernels; kept as a module so the
-    Sequential indices (mlp.0 / mlp.2) and the module tree match the reference."""
+    """schnet.py:210-216.  Inside SchNet it is evaluated by the fused kernels (GEMM epilogues); the module keeps the
+    Sequential indices (mlp.0 / mlp.2) and the module tree of the reference, and called on its own it runs the
+    same device function as an element-wise launch."""
 
     def __init__(self):
         super().__init__()
         self.shift = torch.log(torch.tensor(2.0)).item()
 
     def forward(self, x):
-        raise RuntimeError("ShiftedSoftplus is fused into the HIP kernels and is not called on its own")
+        _lib.require_cuda(x)
+        if x.dtype != torch.float32:
+            raise TypeError("expected float32, got %s" % x.dtype)
+        return _Ssp.apply(x)
 
 
 class GaussianSmearing(torch.nn.Module):
@@ -97,11 +118,6 @@ def _core_params(model):
     return ps
 
 
-def _direct_grads(params):
-    return all(p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 and p.grad.is_cuda
-               for p in params)
-
-
 class _SchNetCore(torch.autograd.Function):
     """(z, pos) -> atom features after the head (schnet.py:89-101) as ONE autograd node."""
 
@@ -118,11 +134,13 @@ class _SchNetCore(torch.autograd.Function):
         st = stream()
         # embedding (schnet.py:89); z is usually the strided view x[:, 0]
         h = torch.empty(N, F, dtype=torch.float32, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev) if cfg["debug"] else None
+        # an atom type outside the table raises in the reference (Embedding); here the kernel flags it in the model's
+        # status word, which forward() polls without draining the stream (synchronously under GEOSSL_DEBUG)
+        status = cfg["status"]
         call("geossl_embedding_fwd", ptr(z), z.stride(0) if z.numel() else 1, ptr(emb_w), emb_w.size(0), N, F, ptr(h),
-             ptr(status), st)
-        if status is not None and int(status.item()):
-            raise IndexError("atom type out of range for the embedding table")
+             ptr(status.word), st)
+        if cfg["debug"]:
+            status.check()
         # radius graph + edge length + envelope (schnet.py:91-93,186)
         pair_d, pair_c, pair_flag = ops.pair_geometry(pos, lay, cfg["cutoff"])
         P = lay.P
@@ -173,9 +191,10 @@ class _SchNetCore(torch.autograd.Function):
         st = stream()
         emb_w, head = ps[0], ps[1 + 9 * L:]
         layers = [ps[1 + 9 * l: 1 + 9 * (l + 1)] for l in range(L)]
-        # When every parameter already owns a dense .grad (DDMTrainer's flat gradient buffer) the kernels accumulate
-        # straight into it and the node returns no parameter gradients: no temporaries, no AccumulateGrad adds.
-        direct = want_params and _direct_grads(ctx.params)
+        # Inside _lib.direct_grads() (DDMTrainer, which owns the flat gradient buffer behind every p.grad) the kernels
+        # accumulate straight into p.grad and the node returns no parameter gradients: no temporaries, no
+        # AccumulateGrad adds.  Everywhere else the gradients go back through autograd like any other node's.
+        direct = want_params and _lib.direct_grads_enabled(ctx.params)
         grads = [p.grad for p in ctx.params] if direct else [torch.empty_like(p) if want_params else None for p in ps]
         accum = 1 if direct else 0
         g_emb, g_head = grads[0], grads[1 + 9 * L:]
@@ -311,6 +330,16 @@ class SchNet(torch.nn.Module):
         if self.atomref is not None:
             self.atomref.weight.data.copy_(self.initial_atomref)
 
+    def _status_word(self, device):
+        return _lib.module_status(self, device, "atom type out of range for the embedding table (node_class=%d)"
+                                  % self.embedding.num_embeddings)
+
+    def check_status(self):
+        """Synchronous form of the deferred index check (drains the stream)."""
+        st = self.__dict__.get("_geossl_status")
+        if st is not None:
+            st.check()
+
     def _check_supported(self):
         F = self.hidden_channels
         if self.num_filters != F or F not in SUPPORTED_F:
@@ -329,12 +358,15 @@ class SchNet(torch.nn.Module):
         lay = layout if layout is not None else get_layout(batch)
         if lay.N != pos.size(0):
             raise ValueError("layout does not match the number of atoms")
+        status = self._status_word(pos.device)
+        status.poll()  # an out-of-range atom type seen by an earlier call raises here (IndexError, like Embedding)
         cfg = dict(L=self.num_interactions, F=self.hidden_channels, G=self.num_gaussians, cutoff=float(self.cutoff),
                    offset=self.distance_expansion.offset, coeff=float(self.distance_expansion.coeff),
-                   debug=bool(os.environ.get("GEOSSL_DEBUG")))
+                   debug=bool(os.environ.get("GEOSSL_DEBUG")), status=status)
         if pos.dtype != torch.float32:
             raise TypeError("positions must be float32")
         h = _SchNetCore.apply(z, pos.contiguous(), lay, cfg, *_core_params(self))
+        status.arm()
         if not self.dipole and self.mean is not None and self.std is not None:
             h = h * self.std + self.mean
         if not self.dipole and self.atomref is not None:

@@ -124,7 +124,7 @@ class _NcsnLoss(torch.autograd.Function):
         if ctx.needs_input_grad[0]:  # first: the backbone's backward waits for nothing else
             dh = torch.empty(N, Fd, dtype=torch.float32, device=dev)
             call("geossl_incidence_gather", ptr(dfeat), ptr(sel.inc_ptr), ptr(sel.inc_idx), N, Fd, ptr(dh), 0, st)
-        direct = all(p.grad is not None and p.grad.is_contiguous() and p.grad.is_cuda for p in ctx.params)
+        direct = _lib.direct_grads_enabled(ctx.params)  # opt-in (DDMTrainer); otherwise gradients go through autograd
         grads = [p.grad for p in ctx.params] if direct else [torch.empty_like(p) for p in ps]
         g = _lib.NcsnGrads(*[ptr(t) for t in grads])
         nfl = _lib.load().geossl_ddm_loss_bwd_workspace_floats(S, Fd)

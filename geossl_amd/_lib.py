@@ -64,6 +64,8 @@ PROTOTYPES = {
     "geossl_radius_graph_fill": (i32, [vp, vp, i64, i32, f32, i32, vp, vp, vp, vp, vp]),
     "geossl_pair_geometry": (i32, [vp, vp, vp, i64, i32, f32, i32, f32, vp, vp, vp, vp]),
     "geossl_rbf_fwd": (i32, [vp, i64, vp, i32, f32, vp, vp]),
+    "geossl_ssp_fwd": (i32, [vp, i64, vp, vp]),
+    "geossl_ssp_bwd": (i32, [vp, vp, i64, vp, vp]),
     "geossl_cfconv_filter_fwd": (i32, [vp, vp, i64, P(FilterWeights), i32, i32, i32, vp, f32, vp, vp, vp]),
     "geossl_cfconv_filter_bwd_workspace_floats": (i64, [i64, i32, i32, i32]),
     "geossl_cfconv_filter_bwd": (i32, [vp, vp, vp, vp, vp, i64, i64, P(FilterWeights), P(FilterGradIn), i32, i32, i32, vp,
@@ -165,6 +167,72 @@ def require_cuda(*tensors):
         if t is not None and not t.is_cuda:
             raise GeosslHipError(
                 "geossl_amd runs on MI355X only: got a %s tensor. The HIP path has no CPU fallback." % t.device.type)
+
+
+
+# ---- direct gradient accumulation (opt-in) -------------------------------------------------------------------------
+# The custom autograd nodes can accumulate parameter gradients straight into dense ``p.grad`` buffers and return None
+# for the parameter inputs (no temporaries, no AccumulateGrad adds).  That bypasses autograd's contract -
+# ``torch.autograd.grad(loss, params)``, tensor hooks and bucketed reducers never see those gradients - so it only
+# happens inside this context, which DDMTrainer (owner of the flat gradient buffer) opens around ``loss.backward()``.
+# A process-wide flag, not a thread-local: autograd runs the backward of CUDA nodes on its own device thread.
+_DIRECT = {"depth": 0}
+
+
+class direct_grads:
+    def __enter__(self):
+        _DIRECT["depth"] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _DIRECT["depth"] -= 1
+        return False
+
+
+def direct_grads_enabled(params):
+    """True when the caller opted in AND every parameter owns a dense fp32 CUDA ``.grad`` to accumulate into."""
+    return _DIRECT["depth"] > 0 and all(
+        p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 and p.grad.is_cuda
+        for p in params)
+
+
+class StatusWord:
+    """Device-side error word of a module (e.g. "an atom type was outside the embedding table", which the reference
+    reports as an IndexError from ``Embedding``): kernels set it, nothing resets it.  Checked WITHOUT draining the
+    stream: ``arm()`` queues an async copy into pinned host memory plus an event, ``poll()`` reads the copy once that
+    event has completed - the error surfaces one or two calls late instead of costing a sync per step.
+    ``check()`` synchronises (tests, GEOSSL_DEBUG, end of an epoch)."""
+
+    def __init__(self, device, message):
+        self.word = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.event = None
+        self.message = message
+
+    def poll(self):
+        if self.event is not None and self.event.query():
+            self.event = None
+            if int(self.host[0]):
+                raise IndexError(self.message)
+
+    def arm(self):
+        if self.event is None and not torch.cuda.is_current_stream_capturing():
+            self.host.copy_(self.word, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+
+    def check(self):
+        if int(self.word.item()):
+            raise IndexError(self.message)
+
+
+def module_status(module, device, message):
+    """The StatusWord of an nn.Module, created on first use (a plain attribute: not a buffer, not in state_dict)."""
+    st = module.__dict__.get("_geossl_status")
+    if st is None or st.word.device != device:
+        st = StatusWord(device, message)
+        module.__dict__["_geossl_status"] = st
+    return st
 
 
 # Optional per-entry-point HIP-event timing (bench.py): {entry point name: [(start_event, end_event), ...]}.

@@ -8,8 +8,18 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgeossl_hip.so")
-SOURCES = ["gemm.hip", "graph.hip", "schnet.hip", "filter_fwd.hip", "filter_bwd.hip", "filter_dpos.hip", "ncsn_rows.hip", "ddm.hip", "painn.hip"]
-HEADERS = ["common.h", "split.h", "tn.h", os.path.join(REPO, "include", "geossl_hip.h")]
+
+
+def _sources():
+    """Every .hip file of csrc/ is a translation unit of the library; every header (csrc/*.h, include/*.h) is a
+    dependency of all of them."""
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    inc = os.path.join(REPO, "include")
+    return hs + [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
 
 
 def _newest(paths):
@@ -19,7 +29,7 @@ def _newest(paths):
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    deps = [os.path.join(CSRC, s) for s in _sources()] + _headers()
     return _newest(deps) > os.path.getmtime(LIB_PATH)
 
 
@@ -30,7 +40,7 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
-    for s in SOURCES:
+    for s in _sources():
         obj = os.path.join(LIB_DIR, s.replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(REPO, "include"),
                "-I", CSRC, "-Wno-pass-failed", "-c", os.path.join(CSRC, s), "-o", obj]

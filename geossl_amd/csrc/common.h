@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // native 16-byte vector: unlike the float4 struct it is a first-class value (arrays of it are always promoted to
 // registers; an array of float4 copied to LDS as a whole struct can end up in scratch memory)
@@ -25,6 +27,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
   } while (0)
 
 namespace geossl {
+
+// Opt a kernel into the full 160 KB of LDS: one attribute call per (kernel, device) - the attribute belongs to the
+// device's copy of the code object, so a process that drives two devices sets it on each - remembered in a small
+// table keyed by the kernel's ADDRESS (instantiations of one kernel template share a pointer type, so a flag per
+// template instantiation of this helper would be shared between them).  Keeps the call out of graph capture too.
+inline void allow_big_lds_ptr(const void* kernel) {
+  struct Seen { const void* fn; int dev; };
+  static Seen seen[512];
+  static int nseen = 0;
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < nseen; ++i)
+    if (seen[i].fn == kernel && seen[i].dev == dev) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (dev >= 0 && nseen < 512) seen[nseen++] = Seen{kernel, dev};
+}
+template <typename K>
+inline void allow_big_lds(K kernel) { allow_big_lds_ptr(reinterpret_cast<const void*>(kernel)); }
+
 
 // hipcc contracts a * b + c into an fma wherever it can (-ffp-contract=fast), and __fmul_rn / __fadd_rn are plain
 // operators to it.  Where the reference's own rounding sequence matters (edge decisions of the radius graph, the

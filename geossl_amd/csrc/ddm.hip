@@ -20,12 +20,6 @@ inline int grid1d(int64_t n, int block, int cap = 2048) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-template <typename K>
-inline void allow_big_lds(K kernel) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-}
-
 // k-major copy of layers.1.weight: W2T[k][m] = o2_w[m][k], padded to HP columns
 // fixed-order two-stage sum
 __global__ __launch_bounds__(256) void k_sum_partial(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {

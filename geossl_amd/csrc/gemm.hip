@@ -423,9 +423,7 @@ extern "C" int geossl_linear(const float* X, int ldx, const float* W, const floa
   const size_t lds = ((size_t)((K * (32 * NC + 1) + 3) & ~3) + 4 * 512) * sizeof(float);
 #define LAUNCH(NCV)                                                                                               \
   do {                                                                                                            \
-    if (lds > 64 * 1024)                                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear<NCV>),                                    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                          \
+    if (lds > 64 * 1024) allow_big_lds(&k_linear<NCV>);                                                           \
     hipLaunchKernelGGL((k_linear<NCV>), grid, dim3(256), lds, stream, X, W, bias, res, tprev, Y, (int)R, K, NO,   \
                        ldx, ldy, transB, flags);                                                                  \
   } while (0)

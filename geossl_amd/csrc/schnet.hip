@@ -25,6 +25,16 @@ __global__ void k_rbf(const float* __restrict__ d, int64_t E, const float* __res
   }
 }
 
+// ------------------------------------------------------------------------- ShiftedSoftplus on its own (schnet.py:210-216)
+__global__ void k_ssp_fwd(const float* __restrict__ x, int64_t n, float* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = ssp(x[i]);
+}
+__global__ void k_ssp_bwd(const float* __restrict__ y, const float* __restrict__ dy, int64_t n, float* __restrict__ dx) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dx[i] = dy[i] * dssp_from_out(y[i]);
+}
+
 // ---------------------------------------------------------------------------------------------------- K4
 // One wave per molecule.  A lane owns VW = F/64 adjacent feature columns of every atom row of the molecule, so the
 // LDS copy of x and the accumulators are lane-private (one barrier after staging, no atomics); each filter row is
@@ -275,12 +285,6 @@ __global__ __launch_bounds__(256) void k_row_normalize_bwd(const float* __restri
   for (int f = lane; f < F; f += 64) dh[row * F + f] = (clamped ? gr[f] : gr[f] - yr[f] * dot) * inv;
 }
 
-template <typename K>
-inline void allow_big_lds(K kernel) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-}
-
 inline int blocks_per_layer(int L, int ntiles) {
   int b = 256 / (L > 0 ? L : 1);
   if (b < 1) b = 1;
@@ -294,6 +298,19 @@ extern "C" int geossl_rbf_fwd(const float* d, int64_t E, const float* offset, in
                               hipStream_t stream) {
   if (E <= 0) return 0;
   hipLaunchKernelGGL(k_rbf, dim3(grid1d(E * G, 256)), dim3(256), 0, stream, d, E, offset, G, coeff, out);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_ssp_fwd(const float* x, int64_t n, float* y, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_ssp_fwd, dim3(grid1d(n, 256)), dim3(256), 0, stream, x, n, y);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int geossl_ssp_bwd(const float* y, const float* dy, int64_t n, float* dx, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_ssp_bwd, dim3(grid1d(n, 256)), dim3(256), 0, stream, y, dy, n, dx);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

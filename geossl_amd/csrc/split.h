@@ -33,16 +33,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <typename K>
-inline void allow_big_lds(K kernel) {
-  static bool done = false;  // one attribute call per kernel instantiation (keeps it out of graph capture too)
-  if (!done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    done = true;
-  }
-}
-
 // element e (0..7) of half kh of a 16-wide k-step <-> index (e&3) + 8*(e>>2) + 4*kh of the step: registers
 // 0..7 / 8..15 of a C-layout accumulator are then elements 0..7 of two consecutive k-steps
 __device__ __forceinline__ int kperm(int e, int kh) { return (e & 3) + 8 * (e >> 2) + 4 * kh; }

@@ -18,7 +18,10 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # a process group is created for world > 1, and for a single rank when a backend is named explicitly
+    # (GEOSSL_DIST_BACKEND / backend=): the 1-rank RCCL group is how a 1-GPU box exercises the real transport
+    explicit = backend or os.environ.get("GEOSSL_DIST_BACKEND")
+    if (world > 1 or explicit) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -67,9 +70,12 @@ class GradAllReduce:
     def __init__(self, flat_grad, world=None, async_op=False):
         self.buf = flat_grad
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        # with an initialised group the collective is always issued, also for a single rank (a 1-rank sum is the
+        # identity, bit for bit): the same code path as N ranks
+        self.active = dist.is_initialized() or self.world > 1
 
     def __call__(self):
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
             return 1.0 / self.world  # folded into the optimizer's grad_scale: no extra pass over the buffer
         return 1.0

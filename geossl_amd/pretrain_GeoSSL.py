@@ -207,7 +207,8 @@ class DDMTrainer:
             self._side = torch.cuda.Stream()
         _ncsn.set_side_stream(self._side)  # head weight gradients overlap the backbone's backward
         try:
-            loss.backward()
+            with _lib.direct_grads():  # every p.grad is a view of self.flat.grad: kernels accumulate into it directly
+                loss.backward()
         finally:
             _ncsn.set_side_stream(None)
             _ncsn.join_side_stream()
@@ -217,6 +218,14 @@ class DDMTrainer:
     _NOISE_KEYS = ("pos_noise", "noise_level_1", "dist_noise_1", "noise_level_2", "dist_noise_2")
 
     def _graph_fwd_bwd(self, batch, noise, key):
+        # The captured graph binds every index structure of the capture batch (batch vector, super_edge_index, and for
+        # PaiNN the precomputed radius_edge_index with its incidence lists, which differ from batch to batch even when
+        # the molecule sizes agree): only x, positions and the noise tensors are refreshed before a replay.  The
+        # caller's structure_key vouches for batch / super_edge_index; radius_edge_index is identified here by tensor
+        # object and version, so a different edge list re-captures instead of silently replaying the old one.
+        rei = batch.radius_edge_index if self.args.model_3d == "painn" else None
+        if rei is not None:
+            key = (key, id(rei), rei._version, int(rei.size(1)))
         g = self._g
         if g is None or g["key"] != key:
             sb = Batch(batch.x.clone(), batch.positions.clone(), batch.batch, batch.super_edge_index,
@@ -254,6 +263,10 @@ class DDMTrainer:
             loss = self._graph_fwd_bwd(batch, noise, structure_key)
         else:
             loss = self._fwd_bwd(batch, noise)
+        st = self.model.__dict__.get("_geossl_status")
+        if st is not None:  # deferred index check of the backbone (a replayed graph cannot queue the host copy itself)
+            st.poll()
+            st.arm()
         scale = self.reduce()
         self.opt.step(grad_scale=scale)
         return loss

@@ -77,6 +77,12 @@ int geossl_pair_geometry(const float* pos, const int32_t* mol_ptr, const int32_t
 int geossl_rbf_fwd(const float* d, int64_t E, const float* offset, int G, float coeff, float* out,
                    hipStream_t stream);
 
+/* ---- ShiftedSoftplus as a stand-alone op — ShiftedSoftplus.forward, schnet.py:210-216 (the module is usable on its
+ * own in the reference; inside the hot path it is fused into the GEMM epilogues):  y = softplus(x) - log 2;
+ * backward from the saved OUTPUT: dx = dy * sigmoid(x) = dy * (1 - 0.5 exp(-y)).                                 */
+int geossl_ssp_fwd(const float* x, int64_t n, float* y, hipStream_t stream);
+int geossl_ssp_bwd(const float* y, const float* dy, int64_t n, float* dx, hipStream_t stream);
+
 /* ---- continuous-filter network for all interaction blocks (K3) — InteractionBlock.mlp applied in
  * CFConv.forward, schnet.py:141-145,186-187:  Wf_l[p] = (ssp(rbf(d_p) A1_l^T + b1_l) A2_l^T + b2_l) * C(d_p),
  * C(d) = 0.5*(cos(d*pi/cutoff)+1).  One launch covers every layer l < L and every pair slot p < P.

@@ -322,8 +322,129 @@ def g9():
              energy=pred_energy, force=pred_force.detach(), cfg=json.dumps({k: v for k, v in cfg.items()}))
 
 
+def g10():
+    """Training on forces (finetune_md17.py:46-54): pred_force = -grad(E, pos, create_graph=True), then a loss on the
+    force (and the energy) is back-propagated into the parameters - the second differentiation of the path.  The
+    'actual' energies / forces are closed-form fillers; criterion = MSE."""
+    red = dict(hidden_channels=32, num_filters=32, num_interactions=2, num_gaussians=8, cutoff=5.0,
+               node_class=9, readout="add")
+    full = dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=5.0,
+                node_class=9, readout="add")
+    for tag, cfg, sizes, seed in (("reduced", red, RAGGED, 24), ("full_r5", full, [18, 18, 7, 30, 2], 25)):
+        b = make_batch(0, seed=seed, sizes=sizes)
+        batch = Batch(b)
+        model = fill_module_(SchNet(**cfg))
+        positions = batch.positions.clone().requires_grad_(True)
+        out = model(batch.x[:, 0], positions, batch.batch)
+        w = torch.cos(torch.arange(out.size(1), dtype=torch.float32))
+        pred_energy = (out * w).sum(dim=1)
+        pred_force = -torch.autograd.grad(outputs=pred_energy, inputs=positions,
+                                          grad_outputs=torch.ones_like(pred_energy), create_graph=True,
+                                          retain_graph=True)[0]
+        N, B = positions.size(0), out.size(0)
+        actual_energy = 0.3 * torch.sin(0.7 * torch.arange(B, dtype=torch.float32))
+        actual_force = 0.2 * torch.cos(0.31 * torch.arange(3 * N, dtype=torch.float32)).view(N, 3)
+        crit = torch.nn.MSELoss()
+        loss = 1.0 * crit(pred_energy, actual_energy) + 10.0 * crit(pred_force, actual_force)
+        loss.backward()
+        arrs = dict(x=batch.x, positions=batch.positions, batch=batch.batch, energy=pred_energy, force=pred_force.detach(),
+                    actual_energy=actual_energy, actual_force=actual_force, loss=loss, grad_pos=positions.grad,
+                    cfg=json.dumps({k: v for k, v in cfg.items()}))
+        seen = set()
+        for name, p in model.named_parameters():
+            if p.grad is None or id(p) in seen:
+                continue
+            seen.add(id(p))
+            arrs["gsum/" + name] = grad_summary(p.grad)
+            if tag == "reduced":
+                arrs["grad/" + name] = p.grad
+        save("g10_schnet_force_training_" + tag, **arrs)
+
+
+def g11():
+    """The reference's own loader surface (Geom3D/dataloaders/dataloaders_AtomTuple.py, imported unmodified on top of
+    the Data shim): AtomTupleExtractor as a per-molecule transform (ratio 1 and 0.5, both options; the ratio < 1 draw
+    uses the global numpy stream, seeded here) and BatchAtomTuple.from_data_list."""
+    from Geom3D.dataloaders.dataloaders_AtomTuple import AtomTupleExtractor, BatchAtomTuple
+    from torch_geometric.data import Data
+    sizes = [1, 2, 5, 18, 7, 3]
+    b = make_batch(0, seed=41, sizes=sizes)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    out = dict(x=b["x"], positions=b["positions"], sizes=np.asarray(sizes))
+    for option in ("combination", "permutation"):
+        for ratio in (1, 0.5):
+            np.random.seed(123)
+            ext = AtomTupleExtractor(ratio=ratio, option=option)
+            mols = []
+            for m in range(len(sizes)):
+                d = Data(x=torch.from_numpy(b["x"][off[m]:off[m + 1]]),
+                         positions=torch.from_numpy(b["positions"][off[m]:off[m + 1]]))
+                d.radius_edge_index = radius_graph(d.positions, r=5.0, loop=False)
+                mols.append(ext(d))
+            bt = BatchAtomTuple.from_data_list(mols)
+            tag = "%s_%g" % (option, ratio)
+            out["sei/" + tag] = bt.super_edge_index
+            out["batch/" + tag] = bt.batch
+            out["rei/" + tag] = bt.radius_edge_index
+            out["num_graphs/" + tag] = bt.num_graphs
+            assert torch.equal(bt.x, torch.from_numpy(b["x"])) and torch.equal(bt.positions, torch.from_numpy(b["positions"]))
+    save("g11_loader", **out)
+
+
+def g12():
+    """Three steps of the DDM training loop body (pretrain_GeoSSL.py:234-260 with the optimizer of :333-343: stock
+    torch.optim.Adam over the three parameter groups backbone / NCSN_01 / NCSN_02, lr 5e-4, weight decay 0), every
+    random draw captured per step.  Parameters after step 3 (summaries; full tensors for the reduced config)."""
+    ns = extract_ddm()
+    for tag, cfg, sizes in [
+        ("reduced", dict(hidden_channels=32, num_filters=32, num_interactions=2, num_gaussians=8, cutoff=5.0,
+                         node_class=9, readout="mean"), [5, 18, 2, 9, 33]),
+        ("full", dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=5.0,
+                      node_class=9, readout="mean"), [18, 18, 18, 12, 25, 1]),
+    ]:
+        b = make_batch(0, seed=51, sizes=sizes)
+        batch = Batch(b)
+        emb = cfg["hidden_channels"]
+        model = fill_module_(SchNet(**cfg))
+        n1 = fill_module_(NCSN_version_03(emb, 10.0, 0.01, 50, "symmetry", 2))
+        n2 = fill_module_(NCSN_version_03(emb, 10.0, 0.01, 50, "symmetry", 2))
+        with torch.no_grad():
+            for p in n2.parameters():
+                if p.requires_grad:
+                    p.mul_(0.9)
+        ns["NCSN_model_01"], ns["NCSN_model_02"] = n1, n2
+        args = Args()
+        args.model_3d = "schnet"
+        model_param_group = [{"params": model.parameters(), "lr": 5e-4}, {"params": n1.parameters(), "lr": 5e-4},
+                             {"params": n2.parameters(), "lr": 5e-4}]
+        optimizer = torch.optim.Adam(model_param_group, lr=5e-4, weight_decay=0)
+        arrs = dict(x=batch.x, positions=batch.positions, batch=batch.batch, super_edge_index=batch.super_edge_index,
+                    cfg=json.dumps(cfg))
+        torch.manual_seed(8)
+        for step in range(3):
+            with Capture() as cap:
+                loss, _ = ns["do_DDM"](args, batch, model, criterion=None, mu=0.0, sigma=0.3)
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+            arrs["loss/%d" % step] = loss.detach()
+            arrs["pos_noise/%d" % step] = cap.log["normal"][0]
+            arrs["noise_level_1/%d" % step], arrs["dist_noise_1/%d" % step] = cap.log["randint"][0], cap.log["randn_like"][0]
+            arrs["noise_level_2/%d" % step], arrs["dist_noise_2/%d" % step] = cap.log["randint"][1], cap.log["randn_like"][1]
+        for mname, m in (("model", model), ("ncsn1", n1), ("ncsn2", n2)):
+            seen = set()
+            for name, p in m.named_parameters():
+                if id(p) in seen or not p.requires_grad:
+                    continue
+                seen.add(id(p))
+                arrs["psum/%s/%s" % (mname, name)] = grad_summary(p.detach())
+                if tag == "reduced":
+                    arrs["param/%s/%s" % (mname, name)] = p.detach()
+        save("g12_ddm_trajectory_" + tag, **arrs)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9):
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12):
         if not only or fn.__name__ in only:
             fn()

@@ -1,0 +1,391 @@
+"""GPU parity tests added in round 2: the RCCL transport with a single rank, full-size / degenerate PaiNN batches,
+the ShiftedSoftplus threshold points on the HIP path, a three-step training trajectory against the reference, the
+reference-shaped loader surface on the device, the autograd contract of the custom nodes, deferred index checks."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, load_golden, max_abs_rel, rel_err
+from helpers import (cfg_of, grad_summary, ncsn_oracle_params, product_ncsn, product_schnet, schnet_oracle_params, t,
+                     unique_named_grads)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL_OUT, TOL_GRAD = 1e-5, 1e-4
+FULL = dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=5.0, node_class=9,
+            readout="mean")
+PAINN = dict(n_atom_basis=128, n_interactions=3, n_rbf=20, cutoff=5.0, max_z=9, n_out=1, readout="add")
+NOISE_KEYS = ("pos_noise", "noise_level_1", "dist_noise_1", "noise_level_2", "dist_noise_2")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded():
+    from geossl_amd import _lib
+    _lib.load()
+
+
+# ------------------------------------------------------------------------------------------------ RCCL, one rank
+_RCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, {repo!r})
+sys.path.insert(0, os.path.join({repo!r}, "tests")); sys.path.insert(0, os.path.join({repo!r}, "tests", "golden"))
+import faulthandler
+faulthandler.dump_traceback_later(150, exit=True)
+import torch, torch.distributed as dist
+from geossl_amd import pretrain_GeoSSL as pg
+from geossl_amd.parallel import init_distributed, local_device
+from geossl_amd.synthetic import draw_noise, make_batch
+from helpers import product_ncsn, product_schnet, t
+rank, local_rank, world = init_distributed()          # GEOSSL_DIST_BACKEND=nccl, WORLD_SIZE=1: a 1-rank RCCL group
+assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+dev = torch.device("cuda", local_device(local_rank))
+torch.cuda.set_device(dev)
+cfg = dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=5.0, node_class=9,
+           readout="mean")
+tr = pg.DDMTrainer(product_schnet(cfg, dev), product_ncsn(128, 50, 2, dev), product_ncsn(128, 50, 2, dev, scale=0.9),
+                   lr=5e-4, use_graph=True)
+assert tr.reduce.active
+losses = []
+for step in range(4):
+    b = make_batch(64, seed=step, mode="A")
+    noise = {{k: t(v, dev) for k, v in draw_noise(b, seed=100 + step).items()}}
+    losses.append(float(tr.step(pg.Batch.from_numpy(b, dev), noise, structure_key=("A", 64, 18))))
+assert tr.use_graph, "capture fell back to eager"
+torch.cuda.synchronize()
+torch.save(dict(losses=losses, params=tr.flat.flat.cpu()), os.path.join({out!r}, "rccl.pt"))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_single_rank_rccl_all_reduce_with_graph_capture(tmp_path):
+    """The production transport on a 1-GPU box: a 1-rank `nccl` (= RCCL) process group, DDMTrainer(use_graph=True).
+    dist.all_reduce on RCCL, its watchdog thread and the HIP-graph capture of forward + backward meet here; a 1-rank
+    sum is the identity, so parameters after four steps must be bit-identical to a run without any group."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER.format(repo=repo, out=str(tmp_path)))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               GEOSSL_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    log = tmp_path / "rccl.log"
+    with open(log, "w") as f:
+        p = subprocess.Popen([sys.executable, str(script)], env=env, stdout=f, stderr=subprocess.STDOUT)
+        try:
+            code = p.wait(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+            code = None
+    assert code == 0, open(log).read()[-3000:]
+    got = torch.load(tmp_path / "rccl.pt", weights_only=False)
+    tr = pg.DDMTrainer(product_schnet(FULL, DEV), product_ncsn(128, 50, 2, DEV),
+                       product_ncsn(128, 50, 2, DEV, scale=0.9), lr=5e-4, use_graph=True)
+    assert not tr.reduce.active
+    losses = []
+    for step in range(4):
+        b = make_batch(64, seed=step, mode="A")
+        noise = {k: t(v, DEV) for k, v in draw_noise(b, seed=100 + step).items()}
+        losses.append(float(tr.step(pg.Batch.from_numpy(b, DEV), noise, structure_key=("A", 64, 18))))
+    assert losses == got["losses"]
+    assert torch.equal(tr.flat.flat.cpu(), got["params"])
+
+
+# ------------------------------------------------------------------------------------------------ S7 thresholds
+def test_shifted_softplus_threshold_points_on_the_hip_path():
+    """G2 (ShiftedSoftplus of the unmodified reference on a grid incl. +-20, +-25, 19.999, 20.001: softplus switches to
+    the identity above its threshold 20) through the HIP ssp(): ops.linear with an identity weight and EPI_SSP, the
+    stand-alone module, and its derivative."""
+    from geossl_amd import _lib, ops
+    from geossl_amd.Geom3D.models.schnet import ShiftedSoftplus
+    g = load_golden("g1_g2_smearing_ssp")
+    x, y = t(g["ssp_x"], DEV), g["ssp_y"]
+    n = x.numel()
+    rows = (n + 31) // 32
+    X = torch.zeros(rows, 32, device=DEV)
+    X.view(-1)[:n] = x
+    got = ops.linear(X, torch.eye(32, device=DEV), flags=_lib.EPI_SSP).view(-1)[:n].cpu()
+    # the identity product is exact (each output is one x times 1.0), so this is ssp() itself; 2e-7 absolute:
+    # float32 resolution of the reference's own log1p(exp(x)) - log 2 near |y| ~ 1, 1e-6 relative for large |x|
+    err = (got.double() - torch.from_numpy(y).double()).abs()
+    assert float((err / (1.0 + torch.from_numpy(y).double().abs())).max()) < 2e-7, float(err.max())
+    mod = ShiftedSoftplus()
+    xs = x.clone().requires_grad_(True)
+    ys = mod(xs)
+    assert torch.equal(ys.detach().cpu(), got)
+    ys.sum().backward()
+    assert max_abs_rel(xs.grad.cpu(), torch.sigmoid(torch.from_numpy(g["ssp_x"]).double())) < 2e-7
+
+
+# ------------------------------------------------------------------------------------------------ D4 trajectory
+@pytest.mark.parametrize("tag", ["reduced", "full"])
+@pytest.mark.parametrize("mode", ["stock_adam", "trainer"])
+def test_three_step_training_trajectory_vs_reference(tag, mode):
+    """Fixture G12: three steps of the training-loop body (pretrain_GeoSSL.py:258-260) of the unmodified reference with
+    stock torch.optim.Adam over the three parameter groups (:333-343).  `stock_adam`: the same loop on the product
+    modules (do_DDM + torch.optim.Adam: gradients travel through autograd, no flat buffer).  `trainer`: DDMTrainer
+    (flat buffer, direct accumulation, fused Adam).  Losses per step and parameters after step 3 at 1e-5."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    g = load_golden("g12_ddm_trajectory_" + tag)
+    cfg = cfg_of(g)
+    F = cfg["hidden_channels"]
+    model = product_schnet(cfg, DEV)
+    n1, n2 = product_ncsn(F, 50, 2, DEV), product_ncsn(F, 50, 2, DEV, scale=0.9)
+    batch = pg.Batch(t(g["x"], DEV), t(g["positions"], DEV), t(g["batch"], DEV), t(g["super_edge_index"], DEV))
+    if mode == "stock_adam":
+        opt = torch.optim.Adam([{"params": model.parameters(), "lr": 5e-4}, {"params": n1.parameters(), "lr": 5e-4},
+                                {"params": n2.parameters(), "lr": 5e-4}], lr=5e-4, weight_decay=0)
+    else:
+        tr = pg.DDMTrainer(model, n1, n2, lr=5e-4)
+    for step in range(3):
+        noise = {k: t(g["%s/%d" % (k, step)], DEV) for k in NOISE_KEYS}
+        if mode == "stock_adam":
+            loss, _ = pg.do_DDM(pg.Args("schnet"), batch, model, None, 0.0, 0.3, NCSN_models=(n1, n2), noise=noise)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        else:
+            loss = tr.step(batch, noise)
+        assert rel_err(loss.detach().cpu(), g["loss/%d" % step]) < TOL_OUT, step
+    mods = {"model": dict(model.named_parameters()), "ncsn1": dict(n1.named_parameters()),
+            "ncsn2": dict(n2.named_parameters())}
+    for k in g:
+        if k.startswith("psum/") or k.startswith("param/"):
+            _, m, name = k.split("/", 2)
+            p = mods[m][name].detach().cpu()
+            got = grad_summary(p) if k.startswith("psum/") else p
+            assert rel_err(got, g[k]) < TOL_OUT, k
+
+
+# ------------------------------------------------------------------------------------------------ autograd contract
+def test_parameter_gradients_go_through_autograd_outside_the_trainer():
+    """Outside DDMTrainer the custom nodes return parameter gradients like any autograd node, whatever state p.grad is
+    in: torch.autograd.grad works, .grad is not touched by it, tensor hooks fire, backward() accumulates."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    g = load_golden("g6_ddm_reduced")
+    cfg = cfg_of(g)
+    model = product_schnet(cfg, DEV)
+    n1, n2 = product_ncsn(32, 50, 2, DEV), product_ncsn(32, 50, 2, DEV, scale=0.9)
+    batch = pg.Batch(t(g["x"], DEV), t(g["positions"], DEV), t(g["batch"], DEV), t(g["super_edge_index"], DEV))
+    noise = {k: t(g[k], DEV) for k in NOISE_KEYS}
+    params = [p for m in (model, n1, n2) for p in m.parameters() if p.requires_grad]
+    for p in params:  # dense grads already present: the case the old inference-by-state got wrong
+        p.grad = torch.full_like(p, 7.0)
+    fired = []
+    model.lin2.weight.register_hook(lambda gr: fired.append(gr.clone()))
+    loss, _ = pg.do_DDM(pg.Args("schnet"), batch, model, None, 0.0, 0.3, NCSN_models=(n1, n2), noise=noise)
+    grads = torch.autograd.grad(loss, params, retain_graph=True)
+    assert all(gr is not None for gr in grads) and len(fired) == 1
+    assert all(bool((p.grad == 7.0).all()) for p in params)  # autograd.grad leaves .grad alone
+    loss.backward()
+    for p, gr in zip(params, grads):
+        assert torch.equal(p.grad, gr + 7.0)  # accumulated by AccumulateGrad on top of what was there
+    named = unique_named_grads(model)
+    for k in g:
+        if k.startswith("grad/model/"):
+            assert rel_err((named[k[11:]] - 7.0).cpu(), g[k]) < TOL_GRAD, k
+
+
+def test_out_of_range_atom_type_is_reported():
+    """The reference raises IndexError from Embedding for an atom type outside the table (e.g. node_class=9 fed raw
+    atomic numbers).  The HIP path flags it on the device: check_status() reports it synchronously, and a later forward
+    reports it without anyone asking."""
+    from geossl_amd.synthetic import make_batch
+    model = product_schnet(FULL, DEV)
+    b = make_batch(4, seed=3)
+    x = t(b["x"], DEV)
+    x[5, 0] = 17
+    with torch.no_grad():
+        model(x[:, 0], t(b["positions"], DEV), t(b["batch"], DEV))
+    with pytest.raises(IndexError):
+        model.check_status()
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        for _ in range(3):  # the deferred copy has landed by now: the next forward raises on entry
+            model(x[:, 0], t(b["positions"], DEV), t(b["batch"], DEV))
+
+
+# ------------------------------------------------------------------------------------------------ loader surface
+def test_reference_loader_surface_feeds_the_ddm_step():
+    """pretrain_GeoSSL.py:289-301 as written: AtomTupleExtractor transform per molecule, DataLoaderAtomTuple,
+    batch.to(device), do_DDM.  Same loss as the step on the pre-collated batch."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.Geom3D.dataloaders import AtomTupleExtractor, Data, DataLoaderAtomTuple
+    g = load_golden("g6_ddm_reduced")
+    sizes = np.bincount(g["batch"]).tolist()
+    ext = AtomTupleExtractor(ratio=1, option="combination")
+    off, dataset = 0, []
+    for n in sizes:
+        dataset.append(ext(Data(x=torch.from_numpy(g["x"][off:off + n]), positions=torch.from_numpy(g["positions"][off:off + n]))))
+        off += n
+    loader = DataLoaderAtomTuple(dataset, batch_size=len(sizes), shuffle=False)
+    (batch,) = list(loader)
+    batch = batch.to(DEV)
+    assert batch.batch.is_cuda and torch.equal(batch.super_edge_index.cpu(), t(g["super_edge_index"]))
+    assert getattr(batch.batch, "_geossl_two_view", None) is not None  # index structures built at .to(), from host sizes
+    cfg = cfg_of(g)
+    model = product_schnet(cfg, DEV)
+    n1, n2 = product_ncsn(32, 50, 2, DEV), product_ncsn(32, 50, 2, DEV, scale=0.9)
+    noise = {k: t(g[k], DEV) for k in NOISE_KEYS}
+    loss, _ = pg.do_DDM(pg.Args("schnet"), batch, model, None, 0.0, 0.3, NCSN_models=(n1, n2), noise=noise)
+    assert rel_err(loss.detach().cpu(), g["loss"]) < TOL_OUT
+
+
+@pytest.mark.parametrize("option", ["combination", "permutation"])
+def test_atom_tuple_extractor_ratio_on_batch_vector(option):
+    """ratio < 1 on the collated path: the same np.random.choice calls in molecule order as the per-molecule
+    transform of the reference (fixture G11, seed 123)."""
+    from geossl_amd.Geom3D.dataloaders import AtomTupleExtractor
+    g = load_golden("g11_loader")
+    bvec = t(g["batch/%s_0.5" % option], DEV)
+    np.random.seed(123)
+    sei = AtomTupleExtractor(ratio=0.5, option=option)(bvec)
+    assert sei.is_cuda and torch.equal(sei.cpu(), t(g["sei/%s_0.5" % option]))
+    full = AtomTupleExtractor(ratio=1, option=option)(bvec)
+    assert torch.equal(full.cpu(), t(g["sei/%s_1" % option]))
+
+
+# ------------------------------------------------------------------------------------------------ PaiNN (config 5)
+def _painn(cfg=PAINN):
+    from filler import fill_module_
+    from geossl_amd.Geom3D.models import PaiNN
+    return fill_module_(PaiNN(**cfg)).to(DEV)
+
+
+def _painn_oracle_params(cfg=PAINN):
+    from test_oracle_golden import painn_params
+    return painn_params(cfg)
+
+
+def _painn_batch(b, radius=5.0):
+    from geossl_amd import ops
+    from geossl_amd import pretrain_GeoSSL as pg
+    bt = pg.Batch.from_numpy(b, DEV)
+    bt.x[:, 0].clamp_(max=8)
+    bt.radius_edge_index = ops.radius_graph(bt.positions, radius, bt.batch)  # datasets_3D_Radius.py:120 on the device
+    return bt
+
+
+@pytest.mark.parametrize("molset", ["A", "B"])
+def test_painn_full_size_determinism_and_oracle_slice(molset):
+    """Config 5 at the bench size: a 1024-molecule PaiNN + DDM step (hydrogens included) twice - bit-identical loss
+    and gradients - and its first 64 molecules against oracle.nets.do_ddm_painn on the same noise."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.parallel import shard_batch_numpy
+    from geossl_amd.synthetic import draw_noise, make_batch
+    from oracle import graph, nets
+    b = make_batch(1024, seed=77, mode=molset)
+    nz = draw_noise(b, seed=78)
+    runs = []
+    for _ in range(2):
+        model = _painn()
+        n1, n2 = product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9)
+        bt = _painn_batch(b)
+        noise = {k: t(v, DEV) for k, v in nz.items()}
+        loss, _ = pg.do_DDM(pg.Args("painn"), bt, model, None, 0.0, 0.3, NCSN_models=(n1, n2), noise=noise)
+        loss.backward()
+        gr = torch.cat([p.grad.reshape(-1) for m in (model, n1, n2) for p in m.parameters() if p.grad is not None])
+        runs.append((float(loss), gr.cpu()))
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    assert np.isfinite(runs[0][0]) and bool(torch.isfinite(runs[0][1]).all())
+    # 64-molecule slice against the oracle
+    small = shard_batch_numpy(b, 0, 16)
+    n_at, S = small["positions"].shape[0], small["super_edge_index"].shape[1]
+    nzs = dict(pos_noise=nz["pos_noise"][:n_at], noise_level_1=nz["noise_level_1"][:64], dist_noise_1=nz["dist_noise_1"][:S],
+               noise_level_2=nz["noise_level_2"][:64], dist_noise_2=nz["dist_noise_2"][:S])
+    model = _painn()
+    n1, n2 = product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9)
+    bt = _painn_batch(small)
+    loss, _ = pg.do_DDM(pg.Args("painn"), bt, model, None, 0.0, 0.3, NCSN_models=(n1, n2),
+                        noise={k: t(v, DEV) for k, v in nzs.items()})
+    loss.backward()
+    rei = graph.collate_np([(small["x"][small["batch"] == m], small["positions"][small["batch"] == m])
+                            for m in range(64)], radius=5.0)["radius_edge_index"]
+    assert np.array_equal(rei, bt.radius_edge_index.cpu().numpy())
+    P, P1, P2 = _painn_oracle_params(), ncsn_oracle_params(128, 50), ncsn_oracle_params(128, 50, 0.9)
+    xs = t(small["x"]).clone()
+    ref = nets.do_ddm_painn(P, P1, P2, xs, t(small["positions"]), t(small["batch"]), t(rei),
+                            t(small["super_edge_index"]), t(nzs["pos_noise"]), t(nzs["noise_level_1"]),
+                            t(nzs["dist_noise_1"]), t(nzs["noise_level_2"]), t(nzs["dist_noise_2"]), 128, 3, 5.0, 2, "add")
+    ref.backward()
+    assert rel_err(loss.detach().cpu(), ref.detach()) < TOL_OUT
+    named = unique_named_grads(model)
+    for k, v in P.items():
+        if v.grad is not None:
+            assert rel_err(named[k].cpu(), v.grad) < TOL_GRAD, k
+
+
+def test_painn_degenerate_batch_vs_oracle():
+    """Ragged / degenerate molecules through PaiNN: a 1-atom molecule (no edges at all), a 2-atom molecule farther apart
+    than the cutoff (E = 0 for the molecule, isolated atoms), an atom with no in-edges inside a larger molecule, next
+    to ordinary ones - forward and parameter gradients against oracle.nets.painn_forward."""
+    from oracle import graph, nets
+    rng = np.random.default_rng(12)
+    from geossl_amd.synthetic import make_batch
+    b = make_batch(0, seed=13, sizes=[1, 2, 9, 18, 1, 5])
+    pos = b["positions"].copy()
+    off = np.concatenate([[0], np.cumsum(b["sizes"])])
+    pos[off[1] + 1] = pos[off[1]] + np.array([9.0, 0.0, 0.0], np.float32)      # 2-atom molecule beyond the cutoff
+    pos[off[2] + 8] = pos[off[2]] + np.array([0.0, 30.0, 0.0], np.float32)     # atom 8 of the 9-atom molecule: isolated
+    x = b["x"].copy()
+    x[:, 0] = rng.integers(0, 9, size=len(x))
+    x[off[3]:off[3] + 3, 0] = 0                                                # hydrogens (padding row)
+    mols = [(x[off[m]:off[m + 1]], pos[off[m]:off[m + 1]]) for m in range(len(b["sizes"]))]
+    c = graph.collate_np(mols, radius=5.0)
+    e = c["radius_edge_index"]
+    deg = np.bincount(e[0], minlength=len(x))
+    assert deg[0] == 0 and deg[off[1]] == 0 and deg[off[2] + 8] == 0 and deg[off[4]] == 0
+    model = _painn()
+    out, q = model(t(c["x"], DEV), t(c["positions"], DEV), t(e, DEV), t(c["batch"], DEV), return_latent=True)
+    loss = (out ** 2).sum() + 0.5 * (q ** 2).sum()
+    loss.backward()
+    P = _painn_oracle_params()
+    o_ref, q_ref = nets.painn_forward(P, t(c["x"]), t(c["positions"]), t(e), t(c["batch"]), 128, 3, 5.0, "add",
+                                      return_latent=True)
+    ((o_ref ** 2).sum() + 0.5 * (q_ref ** 2).sum()).backward()
+    assert_close(out.detach().cpu(), o_ref.detach(), TOL_OUT, "out")
+    assert_close(q.detach().cpu(), q_ref.detach(), TOL_OUT, "q")
+    named = unique_named_grads(model)
+    for k, v in P.items():
+        if v.grad is not None:
+            assert rel_err(named[k].cpu(), v.grad) < TOL_GRAD, k
+    # a batch with no edges at all (every molecule a single atom): the embedding passes through the mixing blocks
+    ones = graph.collate_np([(x[i:i + 1], pos[i:i + 1]) for i in range(4)], radius=5.0)
+    assert ones["radius_edge_index"].shape == (2, 0)
+    out1 = model(t(ones["x"], DEV), t(ones["positions"], DEV), t(ones["radius_edge_index"], DEV), t(ones["batch"], DEV))
+    ref1 = nets.painn_forward(P, t(ones["x"]), t(ones["positions"]), t(ones["radius_edge_index"]), t(ones["batch"]),
+                              128, 3, 5.0, "add")
+    assert_close(out1.detach().cpu(), ref1.detach(), TOL_OUT, "out (E = 0)")
+
+
+def test_painn_trainer_graph_replay_follows_the_edge_list():
+    """A captured graph binds radius_edge_index (and its incidence lists); batches with the same molecule sizes but
+    different geometry have different edge lists.  DDMTrainer(use_graph=True) must give the eager losses on every batch
+    (it re-captures when the edge list is another tensor), not replay batch 0's edges."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    batches = [make_batch(32, seed=200 + i, mode="A") for i in range(3)]
+    bts = [_painn_batch(b) for b in batches]
+    assert len({int(bt.radius_edge_index.size(1)) for bt in bts}) > 1 or not torch.equal(bts[0].radius_edge_index,
+                                                                                          bts[1].radius_edge_index)
+    losses = {}
+    for use_graph in (False, True):
+        tr = pg.DDMTrainer(_painn(), product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9), lr=5e-4,
+                           model_3d="painn", use_graph=use_graph)
+        out = []
+        for step in range(6):
+            b, bt = batches[step % 3], bts[step % 3]
+            noise = {k: t(v, DEV) for k, v in draw_noise(b, seed=300 + step).items()}
+            out.append(float(tr.step(bt, noise, structure_key=("A", 32, 18))))
+        losses[use_graph] = out
+    assert losses[True] == losses[False], losses

@@ -206,3 +206,55 @@ def test_gradient_allreduce_world2_gloo(tmp_path):
                                 if p.requires_grad]))
     want = (flats[0] + flats[1]) / 2
     assert float((r0["flat"] - want).abs().max() / want.abs().max()) < 1e-6
+
+
+def _loader_molecules(g):
+    from geossl_amd.Geom3D.dataloaders import Data
+    sizes, off, mols = g["sizes"].tolist(), 0, []
+    from oracle import graph
+    for n in sizes:
+        pos = g["positions"][off:off + n]
+        mols.append(Data(x=torch.from_numpy(g["x"][off:off + n]), positions=torch.from_numpy(pos),
+                         radius_edge_index=torch.from_numpy(graph.radius_graph_np(pos, 5.0))))
+        off += n
+    return mols
+
+
+@pytest.mark.parametrize("option", ["combination", "permutation"])
+@pytest.mark.parametrize("ratio", [1, 0.5])
+def test_reference_loader_surface_matches_reference(option, ratio):
+    """AtomTupleExtractor()(data) as a per-molecule transform + BatchAtomTuple.from_data_list
+    (dataloaders_AtomTuple.py:15-37,46-78) against fixture G11 = the unmodified reference's own classes on the same
+    molecules; ratio < 1 uses the same np.random.choice stream."""
+    from geossl_amd.Geom3D.dataloaders import AtomTupleExtractor, BatchAtomTuple
+    g = load_golden("g11_loader")
+    np.random.seed(123)
+    ext = AtomTupleExtractor(ratio=ratio, option=option)
+    mols = [ext(d) for d in _loader_molecules(g)]
+    assert mols[0].super_edge_index.shape == (2, 0) and mols[0].super_edge_index.dtype == torch.long  # 1-atom molecule
+    bt = BatchAtomTuple.from_data_list(mols)
+    tag = "%s_%g" % (option, ratio)
+    assert torch.equal(bt.super_edge_index, torch.from_numpy(g["sei/" + tag]))
+    assert torch.equal(bt.batch, torch.from_numpy(g["batch/" + tag]))
+    assert torch.equal(bt.radius_edge_index, torch.from_numpy(g["rei/" + tag]))
+    assert torch.equal(bt.x, torch.from_numpy(g["x"])) and torch.equal(bt.positions, torch.from_numpy(g["positions"]))
+    assert bt.num_graphs == int(g["num_graphs/" + tag]) == len(g["sizes"])
+    assert all(v.is_contiguous() for v in (bt.x, bt.positions, bt.batch, bt.super_edge_index))
+
+
+def test_dataloader_atom_tuple_batches_like_the_reference():
+    """DataLoaderAtomTuple(dataset, batch_size, shuffle, **kw) (dataloaders_AtomTuple.py:81-88): a torch DataLoader
+    whose batches are BatchAtomTuple.from_data_list of consecutive molecules (shuffle off)."""
+    from geossl_amd.Geom3D.dataloaders import AtomTupleExtractor, BatchAtomTuple, DataLoaderAtomTuple
+    g = load_golden("g11_loader")
+    ext = AtomTupleExtractor(ratio=1, option="combination")
+    dataset = [ext(d) for d in _loader_molecules(g)]
+    loader = DataLoaderAtomTuple(dataset, batch_size=4, shuffle=False, num_workers=0)
+    batches = list(loader)
+    assert [b.num_graphs for b in batches] == [4, 2]
+    ref = BatchAtomTuple.from_data_list(dataset[:4])
+    for k in ("x", "positions", "batch", "super_edge_index", "radius_edge_index"):
+        assert torch.equal(batches[0][k], ref[k]), k
+    # second batch renumbers from 0 (node offsets restart per batch, :57-66)
+    assert int(batches[1].batch.min()) == 0 and int(batches[1].super_edge_index.min()) == 0
+    assert isinstance(DataLoaderAtomTuple(dataset).sampler, torch.utils.data.RandomSampler)  # shuffle=True default

@@ -230,3 +230,72 @@ def test_g7_painn_forward_grads_and_ddm():
         if k.startswith("gsum/"):
             _, m, name = k.split("/", 2)
             assert rel_err(grad_summary({"model": P, "ncsn1": P1, "ncsn2": P2}[m][name].grad), d[k]) < 2e-5, k
+
+
+@pytest.mark.parametrize("tag", ["reduced", "full_r5"])
+def test_g10_force_training_double_backward(tag):
+    """finetune_md17.py:46-54 on the oracle: force = -grad(E, pos, create_graph=True), a loss on energy and force,
+    backward into the parameters (second differentiation) - against the unmodified reference."""
+    g = load_golden("g10_schnet_force_training_" + tag)
+    cfg = json.loads(str(g["cfg"]))
+    P = schnet_params(cfg)
+    pos = t(g["positions"]).clone().requires_grad_(True)
+    out = nets.schnet_forward(P, t(g["x"])[:, 0], pos, t(g["batch"]), cfg["cutoff"], cfg["num_interactions"],
+                              cfg["readout"])
+    energy = (out * torch.cos(torch.arange(out.size(1), dtype=torch.float32))).sum(dim=1)
+    force = -torch.autograd.grad(energy, pos, torch.ones_like(energy), create_graph=True, retain_graph=True)[0]
+    crit = torch.nn.MSELoss()
+    loss = 1.0 * crit(energy, t(g["actual_energy"])) + 10.0 * crit(force, t(g["actual_force"]))
+    assert rel_err(loss, g["loss"]) < 2e-5
+    loss.backward()
+    assert rel_err(pos.grad, g["grad_pos"]) < 5e-5
+    for k in g:
+        if k.startswith("gsum/"):
+            assert rel_err(grad_summary(P[k[5:]].grad), g[k]) < 5e-5, k
+        if k.startswith("grad/"):
+            assert rel_err(P[k[5:]].grad, g[k]) < 5e-5, k
+
+
+def test_g11_collate_and_tuple_extractor_vs_reference_loader():
+    """oracle.graph.collate_np against BatchAtomTuple.from_data_list / AtomTupleExtractor of the unmodified reference
+    (ratio = 1, both options, with a per-molecule radius_edge_index)."""
+    g = load_golden("g11_loader")
+    sizes = g["sizes"].tolist()
+    mols, off = [], 0
+    for n in sizes:
+        mols.append((g["x"][off:off + n], g["positions"][off:off + n]))
+        off += n
+    for option in ("combination", "permutation"):
+        c = graph.collate_np(mols, option, radius=5.0)
+        assert np.array_equal(c["super_edge_index"], g["sei/%s_1" % option])
+        assert np.array_equal(c["batch"], g["batch/%s_1" % option])
+        assert np.array_equal(c["radius_edge_index"], g["rei/%s_1" % option])
+        assert int(g["num_graphs/%s_1" % option]) == len(sizes)
+
+
+@pytest.mark.parametrize("tag", ["reduced", "full"])
+def test_g12_three_step_trajectory(tag):
+    """Three DDM steps with stock torch.optim.Adam over the three parameter groups (pretrain_GeoSSL.py:258-260,
+    333-343) on the oracle: losses and parameters after step 3 against the unmodified reference."""
+    g = load_golden("g12_ddm_trajectory_" + tag)
+    cfg = json.loads(str(g["cfg"]))
+    F = cfg["hidden_channels"]
+    Pm, P1, P2 = schnet_params(cfg), ncsn_params(F, 50), ncsn_params(F, 50, 0.9)
+    groups = [{"params": [p for p in P.values() if p.requires_grad], "lr": 5e-4} for P in (Pm, P1, P2)]
+    opt = torch.optim.Adam(groups, lr=5e-4, weight_decay=0)
+    for step in range(3):
+        loss = nets.do_ddm_schnet(Pm, P1, P2, t(g["x"]), t(g["positions"]), t(g["batch"]), t(g["super_edge_index"]),
+                                  t(g["pos_noise/%d" % step]), t(g["noise_level_1/%d" % step]),
+                                  t(g["dist_noise_1/%d" % step]), t(g["noise_level_2/%d" % step]),
+                                  t(g["dist_noise_2/%d" % step]), cfg["cutoff"], cfg["num_interactions"], 2,
+                                  cfg["readout"])
+        assert rel_err(loss, g["loss/%d" % step]) < 1e-5, step
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    for k in g:
+        if k.startswith("psum/") or k.startswith("param/"):
+            _, m, name = k.split("/", 2)
+            p = {"model": Pm, "ncsn1": P1, "ncsn2": P2}[m][name].detach()
+            got = grad_summary(p) if k.startswith("psum/") else p
+            assert rel_err(got, g[k]) < 1e-5, k

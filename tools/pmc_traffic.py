@@ -37,11 +37,18 @@ def per_kernel(path, counter):
 
 
 def main():
+    """argv: fetch.csv write.csv [steps] [molecules_per_step] [workload id] [git head]
+    (the last four are written into the summary: bench.py only reports these figures for the same workload)."""
     f = per_kernel(sys.argv[1], "FETCH_SIZE")
     w = per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on tools/prof_step.py, "
-                    "bs=1024 molecules (both views). Units KB->bytes (x1024); FETCH_SIZE doubled per "
-                    "MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); WRITE_SIZE uncorrected.",
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    mols = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+    workload = sys.argv[5] if len(sys.argv) > 5 else "schnet/ddm-step/mols=1024/set=A/cutoff=5"
+    head = sys.argv[6] if len(sys.argv) > 6 else None
+    out = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on tools/prof_step.py (eager DDM "
+                    "steps, both views). Units KB->bytes (x1024); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 "
+                    "reports half of wide coalesced reads); WRITE_SIZE uncorrected.",
+           "workload": workload, "steps": steps, "molecules_per_step": mols, "git_head": head,
            "kernels": {}}
     for k in f:
         out["kernels"][k] = {"launches": f[k][1], "fetch_bytes_per_launch": 2.0 * 1024.0 * f[k][0],
