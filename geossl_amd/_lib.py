@@ -210,7 +210,9 @@ class StatusWord:
         self.message = message
 
     def poll(self):
-        if self.event is not None and self.event.query():
+        if self.event is None or torch.cuda.is_current_stream_capturing():  # no event queries inside a capture
+            return
+        if self.event.query():
             self.event = None
             if int(self.host[0]):
                 raise IndexError(self.message)

@@ -78,8 +78,7 @@ def test_device_atom_tuple_extractor_bit_exact(option):
     assert bt.num_graphs == len(nz)
     sei = AtomTupleExtractor(option=option)(bt.batch)
     assert torch.equal(sei, bt.super_edge_index)
-    with pytest.raises(NotImplementedError):
-        AtomTupleExtractor(ratio=0.5)
+    assert bt.positions.is_cuda and bt["x"] is bt.x  # item access like torch_geometric.data.Data
 
 
 def test_layout_from_host_sizes_equals_layout_from_device_scan():
