@@ -65,10 +65,12 @@ def alg_model(n_atoms, n_edges, n_super):
     return step_bytes, step_flops, per_kernel
 
 
-def cpu_baseline(seed, n_mols=512, timed=3, max_threads=None):
+def cpu_baseline(seed, n_mols=512, timed=3, max_threads=32):
     """The CPU oracle (pure-torch restatement pinned to the reference by golden vectors) on a bounded
     sample of the same workload: DDM step fwd+bwd + Adam on `n_mols` of the 1024 molecules of a bench batch,
-    1 warm-up + `timed` timed steps on every host core (SURVEY 8(d) / BASELINE.md 3)."""
+    1 warm-up + `timed` timed steps (SURVEY 8(d) / BASELINE.md 3).  Threads: every host core up to `max_threads` - the
+    step is ~150 small ATen ops, and beyond a few dozen threads torch's CPU backend only adds fork/join time (all
+    cores of a 100+-core GPU host made the step several times SLOWER than 16 threads); the count used is reported."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
     from geossl_amd.synthetic import draw_noise, make_batch
@@ -98,7 +100,8 @@ def cpu_baseline(seed, n_mols=512, timed=3, max_threads=None):
     med = float(np.median(times[1:]))
     return {"value": n_mols / med, "unit": "molecules/s", "cores": cores, "kind": "port",
             "sample": "oracle DDM step (fwd+bwd+Adam) on %d molecules of the bench shape (n=18, 5 A), 1 warm-up + %d "
-                      "timed steps on %d torch threads, median %.2f s/step" % (n_mols, timed, cores, med)}
+                      "timed steps on %d torch threads (host has %d cores; capped at %d), median %.2f s/step"
+                      % (n_mols, timed, cores, os.cpu_count() or 1, max_threads, med)}
 
 
 def pmc_file(workload):

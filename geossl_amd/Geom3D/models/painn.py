@@ -323,7 +323,6 @@ class _PaiNNCore(torch.autograd.Function):
             g_emb.add_(tmp)
         else:
             g_emb.copy_(tmp)
-        ctx.saved = None
         if direct:
             return (None, None, None, None) + (None,) * len(grads)
         return (None, None, None, None) + tuple(grads)

@@ -153,22 +153,46 @@ class _SchNetCore(torch.autograd.Function):
         if P > 0:
             call("geossl_cfconv_filter_fwd", ptr(pair_d), ptr(pair_c), P, C.byref(fw), L, F, G, ptr(cfg["offset"]),
                  cfg["coeff"], ptr(T), ptr(Wf), st)
-        # operand images of the 3L square Linear weights, one launch (each is used by a launch over all atoms of
-        # both views; geossl_linear would otherwise re-shape it in every block)
-        pw = ops.prepare_linear([lp[k] for lp in layers for k in (4, 5, 7)], transB=True)
-        if pw is not None:
-            layers = [lp[:4] + [pw[3 * l], pw[3 * l + 1], lp[6], pw[3 * l + 2], lp[8]] for l, lp in enumerate(layers)]
         hs, xs, aggs, ts = [], [], [], []
-        for l, lp in enumerate(layers):
-            x = ops.linear(h, lp[4])                                    # conv.lin1 (no bias)   :189
-            agg = ops.aggregate(x, Wf[l], pair_flag, lay)               # propagate(add)        :190
-            t = ops.linear(agg, lp[5], bias=lp[6], flags=_lib.EPI_SSP)  # conv.lin2 + act       :191,165
-            hn = ops.linear(t, lp[7], bias=lp[8], res=h)                # lin + residual        :166,97
-            if training:
-                hs.append(h); xs.append(x); aggs.append(agg); ts.append(t)
-            h = hn
-        u = ops.linear(h, head[0], bias=head[1], flags=_lib.EPI_SSP)    # lin1 + act            :99-100
-        hout = ops.linear(u, head[2], bias=head[3])                     # lin2                  :101
+        heads = None
+        if cfg["chain"]:
+            # The row-local layers between two aggregations run as ONE launch each (geossl_linear_chain): conv.lin2 + act,
+            # lin + residual and the next block's conv.lin1 (after the last block: the head).  Operand images of all
+            # 3L + 2 square weights from one launch.
+            img = ops.prepare_chain([lp[k] for lp in layers for k in (4, 5, 7)] + [head[0], head[2]], transB=True)
+            i_lin1, i_lin2, i_lin = img[0:3 * L:3], img[1:3 * L:3], img[2:3 * L:3]
+            x, = ops.linear_chain(h, [dict(image=i_lin1[0])])                                    # conv.lin1     :189
+            for l, lp in enumerate(layers):
+                agg = ops.aggregate(x, Wf[l], pair_flag, lay)                                    # propagate(add) :190
+                stages = [dict(image=i_lin2[l], bias=lp[6], flags=_lib.EPI_SSP),                  # conv.lin2 + act :191,165
+                          dict(image=i_lin[l], bias=lp[8], res=h)]                                # lin + residual  :166,97
+                if l + 1 < L:
+                    stages.append(dict(image=i_lin1[l + 1]))                                      # next conv.lin1  :189
+                    t, hn, xn = ops.linear_chain(agg, stages)
+                else:
+                    stages += [dict(image=img[3 * L], bias=head[1], flags=_lib.EPI_SSP),          # lin1 + act      :99-100
+                               dict(image=img[3 * L + 1], bias=head[3])]                          # lin2            :101
+                    t, hn, u, hout = ops.linear_chain(agg, stages)
+                    xn = None
+                if training:
+                    hs.append(h); xs.append(x); aggs.append(agg); ts.append(t)
+                h, x = hn, xn
+        else:
+            # operand images of the 3L square Linear weights, one launch (each is used by a launch over all atoms of
+            # both views; geossl_linear would otherwise re-shape it in every block)
+            pw = ops.prepare_linear([lp[k] for lp in layers for k in (4, 5, 7)], transB=True)
+            if pw is not None:
+                layers = [lp[:4] + [pw[3 * l], pw[3 * l + 1], lp[6], pw[3 * l + 2], lp[8]] for l, lp in enumerate(layers)]
+            for l, lp in enumerate(layers):
+                x = ops.linear(h, lp[4])                                    # conv.lin1 (no bias)   :189
+                agg = ops.aggregate(x, Wf[l], pair_flag, lay)               # propagate(add)        :190
+                t = ops.linear(agg, lp[5], bias=lp[6], flags=_lib.EPI_SSP)  # conv.lin2 + act       :191,165
+                hn = ops.linear(t, lp[7], bias=lp[8], res=h)                # lin + residual        :166,97
+                if training:
+                    hs.append(h); xs.append(x); aggs.append(agg); ts.append(t)
+                h = hn
+            u = ops.linear(h, head[0], bias=head[1], flags=_lib.EPI_SSP)    # lin1 + act            :99-100
+            hout = ops.linear(u, head[2], bias=head[3])                     # lin2                  :101
         if training:
             ctx.lay, ctx.cfg = lay, cfg
             ctx.z = z
@@ -201,27 +225,49 @@ class _SchNetCore(torch.autograd.Function):
         g_layers = [grads[1 + 9 * l: 1 + 9 * (l + 1)] for l in range(L)]
         dh_out = dhout.contiguous()
         probs = []  # (A = dY, B = X, dW, db)
-        # head: hout = u W2^T + b2, u = ssp(h W1^T + b1)
-        du = ops.linear(dh_out, head[2], transB=False, tprev=sv["u"])
-        dh = ops.linear(du, head[0], transB=False)
-        probs.append((dh_out, sv["u"], g_head[2], g_head[3]))
-        probs.append((du, sv["h_last"], g_head[0], g_head[1]))
         daggs = [None] * L
-        keep = [dh_out, du]
-        pw = ops.prepare_linear([lp[k] for lp in layers for k in (4, 5, 7)], transB=False)  # backward-input images
-        for l in reversed(range(L)):
-            lp, gl = layers[l], g_layers[l]
-            w_lin1, w_lin2, w_lin = (pw[3 * l], pw[3 * l + 1], pw[3 * l + 2]) if pw is not None else (lp[4], lp[5], lp[7])
-            dy = ops.linear(dh, w_lin, transB=False, tprev=sv["ts"][l])        # through lin and act
-            dagg = ops.linear(dy, w_lin2, transB=False)                        # through conv.lin2
-            dx = ops.aggregate(dagg, sv["Wf"][l], sv["pair_flag"], lay, swap=True)  # transposed graph
-            dh_new = ops.linear(dx, w_lin1, transB=False, res=dh)              # through conv.lin1 + residual
-            probs.append((dh, sv["ts"][l], gl[7], gl[8]))
-            probs.append((dy, sv["aggs"][l], gl[5], gl[6]))
-            probs.append((dx, sv["hs"][l], gl[4], None))
-            daggs[l] = dagg
-            keep += [dh, dy, dx]
-            dh = dh_new
+        if cfg["chain"]:
+            # the same chains walked backwards: [head.lin2, head.lin1 + act', lin_{L-1} + act', conv.lin2_{L-1}], then per
+            # block  dX through conv.lin1_l (+ the residual branch), lin_{l-1} + act', conv.lin2_{l-1}
+            img = ops.prepare_chain([lp[k] for lp in layers for k in (4, 5, 7)] + [head[0], head[2]], transB=False)
+            i_lin1, i_lin2, i_lin = img[0:3 * L:3], img[1:3 * L:3], img[2:3 * L:3]
+            du, dh, dy, dagg = ops.linear_chain(dh_out, [dict(image=img[3 * L + 1], tprev=sv["u"]), dict(image=img[3 * L]),
+                                                         dict(image=i_lin[L - 1], tprev=sv["ts"][L - 1]),
+                                                         dict(image=i_lin2[L - 1])])
+            probs.append((dh_out, sv["u"], g_head[2], g_head[3]))
+            probs.append((du, sv["h_last"], g_head[0], g_head[1]))
+            for l in reversed(range(L)):
+                gl = g_layers[l]
+                dx = ops.aggregate(dagg, sv["Wf"][l], sv["pair_flag"], lay, swap=True)   # transposed graph
+                probs.append((dh, sv["ts"][l], gl[7], gl[8]))
+                probs.append((dy, sv["aggs"][l], gl[5], gl[6]))
+                probs.append((dx, sv["hs"][l], gl[4], None))
+                daggs[l] = dagg
+                stages = [dict(image=i_lin1[l], res=dh)]                                  # through conv.lin1 + residual
+                if l > 0:
+                    stages += [dict(image=i_lin[l - 1], tprev=sv["ts"][l - 1]), dict(image=i_lin2[l - 1])]
+                    dh, dy, dagg = ops.linear_chain(dx, stages)
+                else:
+                    dh, = ops.linear_chain(dx, stages)
+        else:
+            # head: hout = u W2^T + b2, u = ssp(h W1^T + b1)
+            du = ops.linear(dh_out, head[2], transB=False, tprev=sv["u"])
+            dh = ops.linear(du, head[0], transB=False)
+            probs.append((dh_out, sv["u"], g_head[2], g_head[3]))
+            probs.append((du, sv["h_last"], g_head[0], g_head[1]))
+            pw = ops.prepare_linear([lp[k] for lp in layers for k in (4, 5, 7)], transB=False)  # backward-input images
+            for l in reversed(range(L)):
+                lp, gl = layers[l], g_layers[l]
+                w_lin1, w_lin2, w_lin = (pw[3 * l], pw[3 * l + 1], pw[3 * l + 2]) if pw is not None else (lp[4], lp[5], lp[7])
+                dy = ops.linear(dh, w_lin, transB=False, tprev=sv["ts"][l])        # through lin and act
+                dagg = ops.linear(dy, w_lin2, transB=False)                        # through conv.lin2
+                dx = ops.aggregate(dagg, sv["Wf"][l], sv["pair_flag"], lay, swap=True)  # transposed graph
+                dh_new = ops.linear(dx, w_lin1, transB=False, res=dh)              # through conv.lin1 + residual
+                probs.append((dh, sv["ts"][l], gl[7], gl[8]))
+                probs.append((dy, sv["aggs"][l], gl[5], gl[6]))
+                probs.append((dx, sv["hs"][l], gl[4], None))
+                daggs[l] = dagg
+                dh = dh_new
         P = lay.P
         fw = _lib.FilterWeights()
         gin = _lib.FilterGradIn()
@@ -362,7 +408,8 @@ class SchNet(torch.nn.Module):
         status.poll()  # an out-of-range atom type seen by an earlier call raises here (IndexError, like Embedding)
         cfg = dict(L=self.num_interactions, F=self.hidden_channels, G=self.num_gaussians, cutoff=float(self.cutoff),
                    offset=self.distance_expansion.offset, coeff=float(self.distance_expansion.coeff),
-                   debug=bool(os.environ.get("GEOSSL_DEBUG")), status=status)
+                   debug=bool(os.environ.get("GEOSSL_DEBUG")), status=status,
+                   chain=self.num_interactions >= 1 and not os.environ.get("GEOSSL_NO_CHAIN"))
         if pos.dtype != torch.float32:
             raise TypeError("positions must be float32")
         h = _SchNetCore.apply(z, pos.contiguous(), lay, cfg, *_core_params(self))

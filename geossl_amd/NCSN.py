@@ -145,7 +145,6 @@ class _NcsnLoss(torch.autograd.Function):
                 done = torch.cuda.Event()
                 done.record(side)
             _SIDE["pending"].append((done, (h, saved, dz1, demb, grow, ws, w, sv, ps, grads)))
-        ctx.saved = None
         if direct:
             return (dh, None, None, None, None, None, None, None) + (None,) * len(grads)
         return (dh, None, None, None, None, None, None, None) + tuple(grads)

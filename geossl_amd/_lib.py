@@ -29,6 +29,17 @@ class PrepareBatch(C.Structure):
     _fields_ = [("W", vp * TN_MAX), ("image", vp * TN_MAX)]
 
 
+CHAIN_MAX = 4
+
+
+class ChainStage(C.Structure):
+    _fields_ = [("image", vp), ("bias", vp), ("res", vp), ("tprev", vp), ("out", vp), ("ld", i32), ("flags", i32)]
+
+
+class Chain(C.Structure):
+    _fields_ = [("nstage", i32), ("st", ChainStage * CHAIN_MAX)]
+
+
 class FilterGradIn(C.Structure):
     _fields_ = [("x", vp * MAX_L), ("dagg", vp * MAX_L)]
 
@@ -83,6 +94,9 @@ PROTOTYPES = {
     "geossl_linear_image_words": (i64, [i32, i32]),
     "geossl_linear_prepare": (i32, [P(PrepareBatch), i32, i32, i32, i32, vp]),
     "geossl_linear_prepared": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp]),
+    "geossl_chain_image_words": (i64, [i32]),
+    "geossl_chain_prepare": (i32, [P(PrepareBatch), i32, i32, i32, vp]),
+    "geossl_linear_chain": (i32, [vp, i32, P(Chain), i64, i32, vp]),
     "geossl_linear_wgrad": (i32, [P(TnBatch), i32, i64, i32, i32, i32, i32, i32, vp, i32, vp]),
     "geossl_embedding_fwd": (i32, [vp, i64, vp, i32, i64, i32, vp, vp, vp]),
     "geossl_embedding_bwd_workspace_floats": (i64, [i32, i32]),

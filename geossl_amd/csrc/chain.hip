@@ -1,0 +1,275 @@
+// Chains of atom-row Linear layers in ONE launch.
+//
+// Between two neighbour aggregations SchNet applies three row-local Linear layers back to back (schnet.py:191 conv.lin2,
+// :165-166 act + lin with the residual of :97, then the next block's conv.lin1 at :189; after the last block lin2, lin
+// and the head :99-101), and so does the backward pass (dX through conv.lin1 + residual, through lin and act, through
+// conv.lin2).  As separate launches each of them is one non-overlapped read / multiply / drain pass over 36 864 rows
+// (19-27 us per dispatch, ~13 us of it fixed); here a wave keeps its 32 rows in registers across the whole chain:
+//
+//   * every product is evaluated transposed on the bf16 matrix pipe (split.h): Y^T = W X^T, weight fragments as the A
+//     operand, the wave's rows on the lanes; with the contraction index in `kperm` order the C layout of one product
+//     (lane = row, registers = 4 consecutive columns per group) IS the B-operand layout of the next, so a stage's result
+//     is activated, stored (16-byte row pieces), split and consumed without leaving the registers;
+//   * a stage needs its 96 KB operand image (F = 128) only one 32-column block at a time: the blocks ("chunks", 24 KB)
+//     of all stages stream through a six-slot LDS ring by LDS-DMA (global_load_lds, no staging registers), five chunks
+//     ahead of the one being multiplied; one wait + barrier per chunk, placed after the chunk's MFMAs, where everything
+//     outstanding (the DMA of later chunks, the stores of the previous epilogue) is at least one MFMA loop old;
+//   * four waves per block, one per SIMD, up to 512 registers each (two sets of split fragments are live at a time).
+//
+// Stage s:  Y_s = epi_s( X_s W_s^T + b_s ),  X_{s+1} = Y_s;  epi = [ssp] [* ssp'(tprev)] [+ res], like geossl_linear.
+#include "common.h"
+#include "geossl_hip.h"
+#include "split.h"
+
+using namespace geossl;
+
+namespace {
+
+// image_z[mb][ks][piece][lane] (u32x4) with the contraction index of every k-step in kperm order:
+//   lane (n = lane & 31, kh = lane >> 5), element e  <->  B[k = 16 ks + kperm(e, kh)][n]
+template <int KS>
+__global__ __launch_bounds__(256) void k_chain_prepare(GeosslPrepareBatch batch, int NO, int transB) {
+  constexpr int K = 16 * KS;
+  const int z = blockIdx.y;
+  const float* __restrict__ W = batch.W[z];
+  u32x4* __restrict__ image = reinterpret_cast<u32x4*>(batch.image[z]);
+  const int nitems = (NO / 32) * KS * 64;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nitems) return;
+  const int ln = i & 63, ks = (i >> 6) % KS, mb = i / (64 * KS);
+  const int n = 32 * mb + (ln & 31), kh = ln >> 5;
+  float v[8];
+  if (transB) {  // W [NO][K]: B[k][n] = W[n][k]
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + 16 * ks + 4 * kh);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + 16 * ks + 8 + 4 * kh);
+    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+    v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+  } else {       // W [K][NO]: B[k][n] = W[k][n]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = W[(size_t)(16 * ks + kperm(e, kh)) * NO + n];
+  }
+  const Frag3 f = split8(v);
+  u32x4* dst = image + ((size_t)(mb * KS + ks) * 3) * 64 + ln;
+  dst[0] = f.h;
+  dst[64] = f.m;
+  dst[128] = f.l;
+}
+
+constexpr int CHAIN_SLOTS = 6;
+// ring depth: the chunk after the one in work must have been requested at least one barrier earlier (>= 2 slots)
+constexpr int chain_slots(int nch) { return nch < 2 ? 2 : (nch < CHAIN_SLOTS ? nch : CHAIN_SLOTS); }
+
+template <int KS, int NS>
+__global__ __launch_bounds__(256, 1) void k_row_chain(GeosslChain ch, const float* __restrict__ X, int ldx, int R) {
+  constexpr int F = 16 * KS, NMB = KS / 2, NCH = NS * NMB;
+  constexpr int CHUNK = KS * 3 * 64;                          // u32x4 per chunk (one 32-column block of one stage)
+  constexpr int NSLOT = chain_slots(NCH);
+  constexpr int PPW = (KS * 3) / 4;                            // 1 KB pieces of a chunk per wave (KS * 3 pieces, 4 waves)
+  static_assert((KS * 3) % 4 == 0 || KS == 2, "pieces split evenly over the four waves");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  u32x4* ring = reinterpret_cast<u32x4*>(smem_raw);                          // [NSLOT][CHUNK]
+  float* bias_s = reinterpret_cast<float*>(ring + (size_t)NSLOT * CHUNK);    // [NS][F]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nrb = (R + 31) / 32, ngroups = (nrb + 3) / 4;
+  int my_groups = 0;
+  for (int g = blockIdx.x; g < ngroups; g += gridDim.x) ++my_groups;
+  const int total = my_groups * NCH;                          // chunks this block streams (the chain once per group)
+  // LDS-DMA of stream position cc (chunk cc % NCH of the chain) into slot cc % NSLOT: this wave's share of the pieces
+  auto issue = [&](int cc) {
+    const int c = cc % NCH, s = c / NMB, mb = c - s * NMB;
+    const u32x4* src = reinterpret_cast<const u32x4*>(ch.st[s].image) + (size_t)mb * CHUNK;
+    u32x4* dst = ring + (size_t)(cc % NSLOT) * CHUNK;
+    if constexpr (KS == 2) {  // 6 pieces: waves 0, 1 take two, waves 2, 3 one
+      for (int p = wave; p < KS * 3; p += 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(dst + p * 64), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int u = 0; u < PPW; ++u) {
+        const int p = wave * PPW + u;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(dst + p * 64), 16, 0, 0);
+      }
+    }
+  };
+  for (int cc = 0; cc < NSLOT && cc < total; ++cc) issue(cc);
+  for (int i = tid; i < NS * F; i += 256) {
+    const int s = i / F;
+    bias_s[i] = ch.st[s].bias != nullptr ? ch.st[s].bias[i - s * F] : 0.0f;
+  }
+  int cc = 0;  // stream position of the chunk in work
+  for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int rb = 4 * g + wave;
+    const int row = 32 * rb + j;
+    const bool live = row < R;
+    const size_t rowc = (size_t)min(row, R - 1);
+    // this wave's 32 rows of X as B fragments (kperm order: columns 16ks + 4kh + {0..3} and 16ks + 8 + 4kh + {0..3})
+    Frag3 xf[KS], yf[KS];
+    {
+      const float* xr = X + rowc * ldx + 4 * kh;
+      f32x4 raw[KS][2];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        raw[ks][0] = *reinterpret_cast<const f32x4*>(xr + 16 * ks);
+        raw[ks][1] = *reinterpret_cast<const f32x4*>(xr + 16 * ks + 8);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float v[8] = {raw[ks][0].x, raw[ks][0].y, raw[ks][0].z, raw[ks][0].w,
+                            raw[ks][1].x, raw[ks][1].y, raw[ks][1].z, raw[ks][1].w};
+        xf[ks] = split8(v);
+      }
+    }
+    if (cc == 0) __syncthreads();  // first group: chunks 0 .. NSLOT-1 landed (the barrier waits for the DMA), biases staged
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const GeosslChainStage st = ch.st[s];
+      const int flags = st.flags;
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb, ++cc) {
+        // epilogue operands of this chunk (row pieces in C layout), requested ahead of the MFMAs
+        f32x4 tp[4], rs[4];
+        const size_t eo = rowc * st.ld + 32 * mb + 4 * kh;
+        if (st.tprev != nullptr) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) tp[q] = *reinterpret_cast<const f32x4*>(st.tprev + eo + 8 * q);
+        }
+        if (st.res != nullptr) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rs[q] = *reinterpret_cast<const f32x4*>(st.res + eo + 8 * q);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + s * F + 32 * mb + 8 * q + 4 * kh);
+          acc[4 * q] = b.x;
+          acc[4 * q + 1] = b.y;
+          acc[4 * q + 2] = b.z;
+          acc[4 * q + 3] = b.w;
+        }
+        {
+          const u32x4* Ws = ring + (size_t)(cc % NSLOT) * CHUNK + lane;
+          Frag3 af, an;
+          af.h = Ws[0]; af.m = Ws[64]; af.l = Ws[128];
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+              const u32x4* src = Ws + (size_t)((ks + 1) * 3) * 64;
+              an.h = src[0]; an.m = src[64]; an.l = src[128];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma6(acc, af, xf[ks]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < KS) af = an;
+          }
+        }
+        // every wave is done with this slot; the DMA issued so far has landed (the barrier drains it): refill the slot
+        __syncthreads();
+        if (cc + NSLOT < total) issue(cc + NSLOT);
+        // epilogue in registers: lane = row, register 4q + e = column 32mb + 8q + 4kh + e
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[r];
+        if (flags & GEOSSL_EPI_SSP) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = ssp(v[r]);
+        }
+        if (st.tprev != nullptr) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v[4 * q] *= dssp_from_out(tp[q].x);
+            v[4 * q + 1] *= dssp_from_out(tp[q].y);
+            v[4 * q + 2] *= dssp_from_out(tp[q].z);
+            v[4 * q + 3] *= dssp_from_out(tp[q].w);
+          }
+        }
+        if (st.res != nullptr) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v[4 * q] += rs[q].x;
+            v[4 * q + 1] += rs[q].y;
+            v[4 * q + 2] += rs[q].z;
+            v[4 * q + 3] += rs[q].w;
+          }
+        }
+        if (st.out != nullptr && live) {
+          float* o = st.out + (size_t)row * st.ld + 32 * mb + 4 * kh;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(o + 8 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        }
+        if (s + 1 < NS) {  // registers 0..7 / 8..15 are k-steps 2mb / 2mb+1 of the next stage (kperm)
+          const float lo[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+          const float hi[8] = {v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]};
+          yf[2 * mb] = split8(lo);
+          yf[2 * mb + 1] = split8(hi);
+        }
+      }
+      if (s + 1 < NS) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = yf[ks];
+      }
+    }
+  }
+}
+
+template <int KS>
+int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipStream_t stream) {
+  constexpr int NMB = KS / 2, CHUNK_BYTES = KS * 3 * 1024;
+  const int nrb = (int)((R + 31) / 32), ngroups = (nrb + 3) / 4;
+  const int grid = ngroups < 256 ? ngroups : 256;
+  const int nslot = chain_slots(ch.nstage * NMB);
+  const size_t lds = (size_t)nslot * CHUNK_BYTES + (size_t)ch.nstage * 16 * KS * sizeof(float);
+#define LAUNCH_NS(NSV)                                                                                           \
+  do {                                                                                                           \
+    allow_big_lds(&k_row_chain<KS, NSV>);                                                                        \
+    hipLaunchKernelGGL((k_row_chain<KS, NSV>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R);          \
+  } while (0)
+  switch (ch.nstage) {
+    case 1: LAUNCH_NS(1); break;
+    case 2: LAUNCH_NS(2); break;
+    case 3: LAUNCH_NS(3); break;
+    case 4: LAUNCH_NS(4); break;
+    default: return (int)hipErrorInvalidValue;
+  }
+#undef LAUNCH_NS
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t geossl_chain_image_words(int F) {
+  if (F != 32 && F != 64 && F != 128) return 0;
+  return (int64_t)(F / 32) * (F / 16) * 3 * 64 * 4;
+}
+
+extern "C" int geossl_chain_prepare(const GeosslPrepareBatch* batch, int nprob, int F, int transB, hipStream_t stream) {
+  if (nprob <= 0) return 0;
+  if (nprob > GEOSSL_TN_MAX || geossl_chain_image_words(F) == 0) return (int)hipErrorInvalidValue;
+  const int KS = F / 16, nitems = (F / 32) * KS * 64;
+  dim3 grid((nitems + 255) / 256, nprob);
+  if (KS == 8) hipLaunchKernelGGL((k_chain_prepare<8>), grid, dim3(256), 0, stream, *batch, F, transB);
+  else if (KS == 4) hipLaunchKernelGGL((k_chain_prepare<4>), grid, dim3(256), 0, stream, *batch, F, transB);
+  else hipLaunchKernelGGL((k_chain_prepare<2>), grid, dim3(256), 0, stream, *batch, F, transB);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_linear_chain(const float* X, int ldx, const GeosslChain* chain, int64_t R, int F,
+                                   hipStream_t stream) {
+  if (R <= 0) return 0;
+  if (chain == nullptr || chain->nstage < 1 || chain->nstage > GEOSSL_CHAIN_MAX || geossl_chain_image_words(F) == 0)
+    return (int)hipErrorInvalidValue;
+  if (ldx < F || (ldx & 3)) return (int)hipErrorInvalidValue;
+  for (int s = 0; s < chain->nstage; ++s) {
+    const GeosslChainStage& st = chain->st[s];
+    if (st.image == nullptr) return (int)hipErrorInvalidValue;
+    if ((st.out != nullptr || st.res != nullptr || st.tprev != nullptr) && (st.ld < F || (st.ld & 3)))
+      return (int)hipErrorInvalidValue;
+  }
+  if (F == 128) return launch_chain<8>(*chain, X, ldx, R, stream);
+  if (F == 64) return launch_chain<4>(*chain, X, ldx, R, stream);
+  return launch_chain<2>(*chain, X, ldx, R, stream);
+}

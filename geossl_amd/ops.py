@@ -133,6 +133,50 @@ def linear(x, w, bias=None, res=None, tprev=None, transB=True, flags=0, out=None
     return out
 
 
+def prepare_chain(weights, transB=True):
+    """Operand images (geossl_chain_prepare) of square F x F Linear weights for `linear_chain`, one launch per
+    GEOSSL_TN_MAX weights.  transB as in `linear`.  Returns a list of int32 tensors, or None if F has no chain path."""
+    w0 = weights[0]
+    F = w0.size(0)
+    words = int(_lib.load().geossl_chain_image_words(F)) if w0.size(1) == F else 0
+    if words == 0:
+        return None
+    out = []
+    for lo in range(0, len(weights), _lib.TN_MAX):
+        chunk = weights[lo:lo + _lib.TN_MAX]
+        images = torch.empty(len(chunk), words, dtype=torch.int32, device=w0.device)
+        pb = _lib.PrepareBatch()
+        for i, w in enumerate(chunk):
+            assert w.shape == w0.shape and w.is_contiguous()
+            pb.W[i], pb.image[i] = ptr(w), ptr(images[i])
+        call("geossl_chain_prepare", C.byref(pb), len(chunk), F, 1 if transB else 0, stream())
+        out += [images[i] for i in range(len(chunk))]
+    return out
+
+
+def linear_chain(x, stages):
+    """Several F -> F Linear layers applied to the rows of x back to back in one launch (geossl_linear_chain).
+    stages: list of dicts with `image` (from prepare_chain) and optional `bias`, `res`, `tprev`, `flags`, `store`
+    (default True: the stage's result is written to a new [R, F] tensor).  Returns the list of stored results
+    (None where store is False)."""
+    R, F = x.shape
+    assert x.stride(1) == 1 and 1 <= len(stages) <= _lib.CHAIN_MAX
+    ch = _lib.Chain()
+    ch.nstage = len(stages)
+    outs = []
+    for s, sd in enumerate(stages):
+        st = ch.st[s]
+        o = torch.empty(R, F, dtype=torch.float32, device=x.device) if sd.get("store", True) else None
+        for aux in (sd.get("res"), sd.get("tprev")):
+            assert aux is None or (aux.stride(0) == F and aux.stride(1) == 1 and aux.size(0) == R)
+        st.image, st.bias, st.res, st.tprev, st.out = (ptr(sd["image"]), ptr(sd.get("bias")), ptr(sd.get("res")),
+                                                       ptr(sd.get("tprev")), ptr(o))
+        st.ld, st.flags = F, int(sd.get("flags", 0))
+        outs.append(o)
+    call("geossl_linear_chain", ptr(x), x.stride(0), C.byref(ch), R, F, stream())
+    return outs
+
+
 def linear_wgrad(problems, R, M, N, accumulate=False, lda=None, ldb=None, ldw=None):
     """Batched weight gradients.  problems: list of (A [R,M], B [R,N], dW [M,N], db [M] or None); lda/ldb/ldw are
     the row strides when A / B / dW are column slices of wider tensors."""

@@ -164,6 +164,32 @@ int geossl_linear_prepared(const float* X, int ldx, const uint32_t* image, const
                            const float* tprev, float* Y, int ldy, int64_t R, int K, int NO, int flags,
                            hipStream_t stream);
 
+/* Chains of square atom-row Linear layers in one launch.  Between two neighbour aggregations the reference applies
+ * three row-local layers back to back - conv.lin2 (schnet.py:191), act + lin + residual (:165-166,97), the next
+ * block's conv.lin1 (:189); after the last block lin2, lin and the head (:99-101) - and autograd walks the same chains
+ * backwards.  Stage s: Y_s = epi_s(X_s W_s^T + b_s), X_{s+1} = Y_s, with geossl_linear's epilogue (flags:
+ * GEOSSL_EPI_SSP; tprev != NULL: * ssp'(tprev); res != NULL: + res) and Y_s stored to `out` when it is not NULL
+ * (row stride ld, shared with res / tprev).  Every stage is F -> F, F in {32, 64, 128}.  `image`: operand image of the
+ * stage's weight from geossl_chain_prepare (transB as in geossl_linear: 1 = W is [NO][K] (forward), 0 = W is [K][NO]
+ * (dX = dY W)), geossl_chain_image_words(F) 32-bit words each.                                                    */
+#define GEOSSL_CHAIN_MAX 4
+typedef struct {
+  const uint32_t* image;
+  const float* bias;  /* may be NULL */
+  const float* res;   /* may be NULL */
+  const float* tprev; /* may be NULL */
+  float* out;         /* may be NULL: the stage's result is only consumed by the next stage */
+  int ld;
+  int flags;
+} GeosslChainStage;
+typedef struct {
+  int nstage;
+  GeosslChainStage st[GEOSSL_CHAIN_MAX];
+} GeosslChain;
+int64_t geossl_chain_image_words(int F);
+int geossl_chain_prepare(const GeosslPrepareBatch* batch, int nprob, int F, int transB, hipStream_t stream);
+int geossl_linear_chain(const float* X, int ldx, const GeosslChain* chain, int64_t R, int F, hipStream_t stream);
+
 /* batched weight gradients: dW_z[m][n] (+)= sum_r A_z[r][m]*B_z[r][n], db_z[m] (+)= sum_r A_z[r][m];
  * lda / ldb / ldw: row strides of A_z, B_z, dW_z (M, N <= 128 per problem: wider layers are tiled by the caller)  */
 typedef struct {

@@ -322,7 +322,9 @@ def test_painn_full_size_determinism_and_oracle_slice(molset):
     named = unique_named_grads(model)
     for k, v in P.items():
         if v.grad is not None:
-            assert rel_err(named[k].cpu(), v.grad) < TOL_GRAD, k
+            # the embedding gradient sums the per-atom gradients of ~130 atoms per type with heavy cancellation: two
+            # fp32 evaluations in different summation orders differ by a few 1e-4 there (the SchNet tests see the same)
+            assert rel_err(named[k].cpu(), v.grad) < (3e-4 if k == "embedding.weight" else TOL_GRAD), k
 
 
 def test_painn_degenerate_batch_vs_oracle():
@@ -389,3 +391,82 @@ def test_painn_trainer_graph_replay_follows_the_edge_list():
             out.append(float(tr.step(bt, noise, structure_key=("A", 32, 18))))
         losses[use_graph] = out
     assert losses[True] == losses[False], losses
+
+
+# ------------------------------------------------------------------------------------------------ chained row GEMMs
+@pytest.mark.parametrize("F,R", [(128, 36864), (128, 77), (64, 1000), (32, 33), (128, 32 * 1100 + 5)])
+@pytest.mark.parametrize("transB", [True, False])
+def test_linear_chain_vs_fp64(F, R, transB):
+    """geossl_linear_chain (up to four F -> F layers in one launch, results passed on in registers) against an fp64
+    evaluation of the same chain, every epilogue form, stored and unstored stages, ragged row counts, a grid that gives
+    some blocks a second row group (R > 256 blocks x 128 rows)."""
+    from geossl_amd import _lib, ops
+    torch.manual_seed(F + R)
+    X = torch.randn(R, F, device=DEV)
+    Ws = [torch.randn(F, F, device=DEV) / F ** 0.5 for _ in range(4)]
+    bs = [torch.randn(F, device=DEV) * 0.1 for _ in range(4)]
+    res = torch.randn(R, F, device=DEV)
+    tprev = torch.randn(R, F, device=DEV)
+    imgs = ops.prepare_chain(Ws, transB=transB)
+    mm = (lambda a, w: a @ w.double().T) if transB else (lambda a, w: a @ w.double())
+    ssp64 = lambda v: torch.nn.functional.softplus(v) - float(np.log(2.0))
+
+    def ref_chain(n):
+        y, outs = X.double(), []
+        for s in range(n):
+            y = mm(y, Ws[s])
+            if s != 2:
+                y = y + bs[s].double()
+            if s == 0:
+                y = ssp64(y)
+            if s == 1:
+                y = y + res.double()
+            if s == 2:
+                y = y * (1.0 - 0.5 * torch.exp(-tprev.double()))
+            outs.append(y)
+        return outs
+
+    for n in (1, 2, 3, 4):
+        stages = [dict(image=imgs[0], bias=bs[0], flags=_lib.EPI_SSP), dict(image=imgs[1], bias=bs[1], res=res, store=(n != 3)),
+                  dict(image=imgs[2], tprev=tprev), dict(image=imgs[3], bias=bs[3])][:n]
+        got = ops.linear_chain(X, stages)
+        want = ref_chain(n)
+        for s in range(n):
+            if got[s] is None:
+                assert s == 1 and n == 3
+                continue
+            scale = float(want[s].abs().max())
+            assert float((got[s].double() - want[s]).abs().max()) < 3e-6 * scale * (s + 1), (n, s)
+    # a chain is deterministic, and a one-stage chain agrees with geossl_linear to rounding
+    a = ops.linear_chain(X, [dict(image=imgs[0], bias=bs[0], flags=_lib.EPI_SSP)])[0]
+    b = ops.linear_chain(X, [dict(image=imgs[0], bias=bs[0], flags=_lib.EPI_SSP)])[0]
+    assert torch.equal(a, b)
+    c = ops.linear(X, Ws[0], bias=bs[0], flags=_lib.EPI_SSP, transB=transB)
+    assert max_abs_rel(a, c) < 2e-6
+
+
+def test_schnet_chain_path_matches_per_layer_launches():
+    """The chained atom-row path (default) against the one-launch-per-Linear path (GEOSSL_NO_CHAIN=1) on the full
+    configuration: same loss and gradients to rounding (both pinned to the reference by the golden tests)."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    b = make_batch(64, seed=5, mode="B")
+    nz = draw_noise(b, seed=6)
+    res = {}
+    for tag, env in (("chain", None), ("per_layer", "1")):
+        if env is None:
+            os.environ.pop("GEOSSL_NO_CHAIN", None)
+        else:
+            os.environ["GEOSSL_NO_CHAIN"] = env
+        try:
+            model = product_schnet(FULL, DEV)
+            n1, n2 = product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9)
+            loss, _ = pg.do_DDM(pg.Args("schnet"), pg.Batch.from_numpy(b, DEV), model, None, 0.0, 0.3,
+                                NCSN_models=(n1, n2), noise={k: t(v, DEV) for k, v in nz.items()})
+            loss.backward()
+            res[tag] = (float(loss), {k: v.clone() for k, v in unique_named_grads(model).items()})
+        finally:
+            os.environ.pop("GEOSSL_NO_CHAIN", None)
+    assert abs(res["chain"][0] - res["per_layer"][0]) < 1e-6 * abs(res["per_layer"][0])
+    for k, v in res["per_layer"][1].items():
+        assert rel_err(res["chain"][1][k], v) < 2e-5, k
