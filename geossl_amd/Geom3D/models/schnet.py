@@ -170,9 +170,9 @@ class _SchNetCore(torch.autograd.Function):
                     stages.append(dict(image=i_lin1[l + 1]))                                      # next conv.lin1  :189
                     t, hn, xn = ops.linear_chain(agg, stages)
                 else:
-                    stages += [dict(image=img[3 * L], bias=head[1], flags=_lib.EPI_SSP),          # lin1 + act      :99-100
-                               dict(image=img[3 * L + 1], bias=head[3])]                          # lin2            :101
-                    t, hn, u, hout = ops.linear_chain(agg, stages)
+                    stages.append(dict(image=img[3 * L], bias=head[1], flags=_lib.EPI_SSP))       # lin1 + act      :99-100
+                    t, hn, u = ops.linear_chain(agg, stages)
+                    hout, = ops.linear_chain(u, [dict(image=img[3 * L + 1], bias=head[3])])       # lin2            :101
                     xn = None
                 if training:
                     hs.append(h); xs.append(x); aggs.append(agg); ts.append(t)
@@ -205,10 +205,23 @@ class _SchNetCore(torch.autograd.Function):
         return hout
 
     @staticmethod
-    @torch.autograd.function.once_differentiable  # first order only: create_graph=True (finetune_md17.py:46) cannot
-    def backward(ctx, dhout):                      # differentiate the force again - that raises, loudly
-        cfg, lay, sv, ps = ctx.cfg, ctx.lay, ctx.saved, ctx.ps
+    def backward(ctx, dhout):
         want_pos, want_params = ctx.needs_input_grad[1], ctx.want_params
+        if torch.is_grad_enabled():
+            # autograd runs a backward with grad mode ON only under create_graph=True (finetune_md17.py:46,99): the
+            # gradients may be differentiated again (training on forces, :51-54).  They are still computed by the fused
+            # first-order kernels, but as the outputs of a node that knows how to be differentiated
+            # (geossl_amd/higher_order.py); evaluation loops that detach the force never pay for that.
+            from ...higher_order import SchNetGradNode
+            dpos, grads = SchNetGradNode.run(ctx, dhout, want_pos, want_params)
+            return (None, dpos, None, None) + tuple(grads)
+        dpos, grads = _SchNetCore.fused_backward(ctx, dhout, want_pos, want_params, allow_direct=True)
+        return (None, dpos, None, None) + tuple(grads)
+
+    @staticmethod
+    def fused_backward(ctx, dhout, want_pos, want_params, allow_direct):
+        """First-order gradients by the fused kernels -> (dpos or None, [one entry per parameter, None = not returned])."""
+        cfg, lay, sv, ps = ctx.cfg, ctx.lay, ctx.saved, ctx.ps
         L, F, G = cfg["L"], cfg["F"], cfg["G"]
         dev = dhout.device
         N = dhout.size(0)
@@ -218,7 +231,7 @@ class _SchNetCore(torch.autograd.Function):
         # Inside _lib.direct_grads() (DDMTrainer, which owns the flat gradient buffer behind every p.grad) the kernels
         # accumulate straight into p.grad and the node returns no parameter gradients: no temporaries, no
         # AccumulateGrad adds.  Everywhere else the gradients go back through autograd like any other node's.
-        direct = want_params and _lib.direct_grads_enabled(ctx.params)
+        direct = want_params and allow_direct and _lib.direct_grads_enabled(ctx.params)
         grads = [p.grad for p in ctx.params] if direct else [torch.empty_like(p) if want_params else None for p in ps]
         accum = 1 if direct else 0
         g_emb, g_head = grads[0], grads[1 + 9 * L:]
@@ -227,13 +240,12 @@ class _SchNetCore(torch.autograd.Function):
         probs = []  # (A = dY, B = X, dW, db)
         daggs = [None] * L
         if cfg["chain"]:
-            # the same chains walked backwards: [head.lin2, head.lin1 + act', lin_{L-1} + act', conv.lin2_{L-1}], then per
+            # the same chains walked backwards: [head.lin2 + act', head.lin1], [lin_{L-1} + act', conv.lin2_{L-1}], then per
             # block  dX through conv.lin1_l (+ the residual branch), lin_{l-1} + act', conv.lin2_{l-1}
             img = ops.prepare_chain([lp[k] for lp in layers for k in (4, 5, 7)] + [head[0], head[2]], transB=False)
             i_lin1, i_lin2, i_lin = img[0:3 * L:3], img[1:3 * L:3], img[2:3 * L:3]
-            du, dh, dy, dagg = ops.linear_chain(dh_out, [dict(image=img[3 * L + 1], tprev=sv["u"]), dict(image=img[3 * L]),
-                                                         dict(image=i_lin[L - 1], tprev=sv["ts"][L - 1]),
-                                                         dict(image=i_lin2[L - 1])])
+            du, dh = ops.linear_chain(dh_out, [dict(image=img[3 * L + 1], tprev=sv["u"]), dict(image=img[3 * L])])
+            dy, dagg = ops.linear_chain(dh, [dict(image=i_lin[L - 1], tprev=sv["ts"][L - 1]), dict(image=i_lin2[L - 1])])
             probs.append((dh_out, sv["u"], g_head[2], g_head[3]))
             probs.append((du, sv["h_last"], g_head[0], g_head[1]))
             for l in reversed(range(L)):
@@ -311,8 +323,8 @@ class _SchNetCore(torch.autograd.Function):
                      ptr(lay.pair_ptr), lay.B, P, L, ptr(dpos), st)
         # ctx.saved stays: finetune_md17.py:46 differentiates with retain_graph=True and runs this node again
         if direct:
-            return (None, dpos, None, None) + (None,) * len(grads)
-        return (None, dpos, None, None) + tuple(grads)
+            return dpos, [None] * len(grads)
+        return dpos, list(grads)
 
 
 class _SegmentReduce(torch.autograd.Function):

@@ -29,7 +29,7 @@ class PrepareBatch(C.Structure):
     _fields_ = [("W", vp * TN_MAX), ("image", vp * TN_MAX)]
 
 
-CHAIN_MAX = 4
+CHAIN_MAX = 3
 
 
 class ChainStage(C.Structure):
@@ -85,6 +85,7 @@ PROTOTYPES = {
                                         f32, vp, vp, vp, vp]),
     "geossl_pair_position_grad": (i32, [vp, vp, vp, vp, vp, i64, i64, i32, vp, vp]),
     "geossl_cfconv_aggregate": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]),
+    "geossl_pair_product": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]),
     "geossl_linear": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]),
     "geossl_tn_plan": (None, [i64, i32, P(i32), P(i32)]),
     "geossl_tn_workspace_floats": (i64, [i64, i32, i32, i32]),

@@ -11,10 +11,12 @@
 //     (lane = row, registers = 4 consecutive columns per group) IS the B-operand layout of the next, so a stage's result
 //     is activated, stored (16-byte row pieces), split and consumed without leaving the registers;
 //   * a stage needs its 96 KB operand image (F = 128) only one 32-column block at a time: the blocks ("chunks", 24 KB)
-//     of all stages stream through a six-slot LDS ring by LDS-DMA (global_load_lds, no staging registers), five chunks
-//     ahead of the one being multiplied; one wait + barrier per chunk, placed after the chunk's MFMAs, where everything
+//     of all stages stream through an LDS ring by LDS-DMA (global_load_lds, no staging registers), two chunks ahead of
+//     the one being multiplied; one wait + barrier per chunk, placed after the chunk's MFMAs, where everything
 //     outstanding (the DMA of later chunks, the stores of the previous epilogue) is at least one MFMA loop old;
-//   * four waves per block, one per SIMD, up to 512 registers each (two sets of split fragments are live at a time).
+//   * four waves per block, 256 registers per wave (two sets of split fragments are live at a time: chains are cut at
+//     three stages, a fourth would spill) and a three-slot ring (72 KB), so two blocks share a CU: one wave's stores,
+//     DMA issue and barrier waits are covered by its SIMD neighbour.
 //
 // Stage s:  Y_s = epi_s( X_s W_s^T + b_s ),  X_{s+1} = Y_s;  epi = [ssp] [* ssp'(tprev)] [+ res], like geossl_linear.
 #include "common.h"
@@ -55,12 +57,27 @@ __global__ __launch_bounds__(256) void k_chain_prepare(GeosslPrepareBatch batch,
   dst[128] = f.l;
 }
 
-constexpr int CHAIN_SLOTS = 6;
+#ifdef CHAIN_TIMING
+__device__ long long chain_dbg[8 * 64];
+#define CHAIN_MARK(slot)                                                                     \
+  do {                                                                                       \
+    if (blockIdx.x == 7 && threadIdx.x == 64 && g == blockIdx.x) chain_dbg[dbg_n++ * 8 + (slot)] = clock64(); \
+  } while (0)
+#else
+#define CHAIN_MARK(slot) do {} while (0)
+#endif
+#ifndef CHAIN_SLOTS_N
+#define CHAIN_SLOTS_N 3
+#endif
+#ifndef CHAIN_WPS
+#define CHAIN_WPS 2
+#endif
+constexpr int CHAIN_SLOTS = CHAIN_SLOTS_N;
 // ring depth: the chunk after the one in work must have been requested at least one barrier earlier (>= 2 slots)
 constexpr int chain_slots(int nch) { return nch < 2 ? 2 : (nch < CHAIN_SLOTS ? nch : CHAIN_SLOTS); }
 
 template <int KS, int NS>
-__global__ __launch_bounds__(256, 1) void k_row_chain(GeosslChain ch, const float* __restrict__ X, int ldx, int R) {
+__global__ __launch_bounds__(256, CHAIN_WPS) void k_row_chain(GeosslChain ch, const float* __restrict__ X, int ldx, int R) {
   constexpr int F = 16 * KS, NMB = KS / 2, NCH = NS * NMB;
   constexpr int CHUNK = KS * 3 * 64;                          // u32x4 per chunk (one 32-column block of one stage)
   constexpr int NSLOT = chain_slots(NCH);
@@ -99,11 +116,15 @@ __global__ __launch_bounds__(256, 1) void k_row_chain(GeosslChain ch, const floa
     bias_s[i] = ch.st[s].bias != nullptr ? ch.st[s].bias[i - s * F] : 0.0f;
   }
   int cc = 0;  // stream position of the chunk in work
+#ifdef CHAIN_TIMING
+  int dbg_n = 0;
+#endif
   for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const int rb = 4 * g + wave;
     const int row = 32 * rb + j;
     const bool live = row < R;
     const size_t rowc = (size_t)min(row, R - 1);
+    CHAIN_MARK(0);
     // this wave's 32 rows of X as B fragments (kperm order: columns 16ks + 4kh + {0..3} and 16ks + 8 + 4kh + {0..3})
     Frag3 xf[KS], yf[KS];
     {
@@ -128,6 +149,7 @@ __global__ __launch_bounds__(256, 1) void k_row_chain(GeosslChain ch, const floa
       const int flags = st.flags;
 #pragma unroll
       for (int mb = 0; mb < NMB; ++mb, ++cc) {
+        CHAIN_MARK(1);
         // epilogue operands of this chunk (row pieces in C layout), requested ahead of the MFMAs
         f32x4 tp[4], rs[4];
         const size_t eo = rowc * st.ld + 32 * mb + 4 * kh;
@@ -159,14 +181,23 @@ __global__ __launch_bounds__(256, 1) void k_row_chain(GeosslChain ch, const floa
               an.h = src[0]; an.m = src[64]; an.l = src[128];
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifdef CHAIN_ABLATE_MFMA
+            acc[0] += __uint_as_float(af.h[0] ^ xf[ks].h[0]) + __uint_as_float(af.l[3] ^ xf[ks].m[1]);
+#else
             mma6(acc, af, xf[ks]);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if (ks + 1 < KS) af = an;
           }
         }
+        CHAIN_MARK(2);
         // every wave is done with this slot; the DMA issued so far has landed (the barrier drains it): refill the slot
         __syncthreads();
+        CHAIN_MARK(3);
+#ifndef CHAIN_ABLATE_DMA
         if (cc + NSLOT < total) issue(cc + NSLOT);
+#endif
+        CHAIN_MARK(5);
         // epilogue in registers: lane = row, register 4q + e = column 32mb + 8q + 4kh + e
         float v[16];
 #pragma unroll
@@ -193,12 +224,18 @@ __global__ __launch_bounds__(256, 1) void k_row_chain(GeosslChain ch, const floa
             v[4 * q + 3] += rs[q].w;
           }
         }
+        CHAIN_MARK(6);
+#ifdef CHAIN_ABLATE_STORE
+        if (st.out != nullptr && live && flags == 12345) {
+#else
         if (st.out != nullptr && live) {
+#endif
           float* o = st.out + (size_t)row * st.ld + 32 * mb + 4 * kh;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             *reinterpret_cast<f32x4*>(o + 8 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
         }
+        CHAIN_MARK(4);
         if (s + 1 < NS) {  // registers 0..7 / 8..15 are k-steps 2mb / 2mb+1 of the next stage (kperm)
           const float lo[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
           const float hi[8] = {v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]};
@@ -218,7 +255,7 @@ template <int KS>
 int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipStream_t stream) {
   constexpr int NMB = KS / 2, CHUNK_BYTES = KS * 3 * 1024;
   const int nrb = (int)((R + 31) / 32), ngroups = (nrb + 3) / 4;
-  const int grid = ngroups < 256 ? ngroups : 256;
+  const int grid = ngroups < 2048 ? ngroups : 2048;  // two blocks per CU are resident (72 KB of LDS, <= 256 registers)
   const int nslot = chain_slots(ch.nstage * NMB);
   const size_t lds = (size_t)nslot * CHUNK_BYTES + (size_t)ch.nstage * 16 * KS * sizeof(float);
 #define LAUNCH_NS(NSV)                                                                                           \
@@ -230,7 +267,6 @@ int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipS
     case 1: LAUNCH_NS(1); break;
     case 2: LAUNCH_NS(2); break;
     case 3: LAUNCH_NS(3); break;
-    case 4: LAUNCH_NS(4); break;
     default: return (int)hipErrorInvalidValue;
   }
 #undef LAUNCH_NS
@@ -239,6 +275,12 @@ int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipS
 }
 
 }  // namespace
+
+#ifdef CHAIN_TIMING
+extern "C" int geossl_chain_debug_read(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(chain_dbg), sizeof(long long) * 8 * 64);
+}
+#endif
 
 extern "C" int64_t geossl_chain_image_words(int F) {
   if (F != 32 && F != 64 && F != 128) return 0;

@@ -35,6 +35,29 @@ __global__ void k_ssp_bwd(const float* __restrict__ y, const float* __restrict__
     dx[i] = dy[i] * dssp_from_out(y[i]);
 }
 
+// ------------------------------------------------------------------------------------------ d aggregate / d filter
+// out[p][c] = f0 * a[i][c] * b[j][c] + f1 * a[j][c] * b[i][c]   for pair slot p = (i < j), f0 / f1 its two edge flags
+// (exchanged when swap): the gradient of the neighbour aggregation (k_aggregate) with respect to the filter rows, as a
+// tensor - used where the filter gradient itself has to stay differentiable (second-order path); the first-order path
+// never materialises it (filter_bwd.hip).
+__global__ void k_pair_product(const float* __restrict__ a, const float* __restrict__ b,
+                               const int32_t* __restrict__ pair_i, const int32_t* __restrict__ pair_j,
+                               const uint8_t* __restrict__ pair_flag, int64_t P, int F, int swap,
+                               float* __restrict__ out) {
+  const int Q = F / 4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < P * Q; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = idx / Q;
+    const int c = 4 * (int)(idx - p * Q);
+    unsigned fl = pair_flag[p];
+    if (swap) fl = ((fl & 1u) << 1) | ((fl >> 1) & 1u);
+    const float f0 = (fl & 1u) ? 1.0f : 0.0f, f1 = (fl & 2u) ? 1.0f : 0.0f;
+    const size_t oi = (size_t)pair_i[p] * F + c, oj = (size_t)pair_j[p] * F + c;
+    const f32x4 ai = *reinterpret_cast<const f32x4*>(a + oi), aj = *reinterpret_cast<const f32x4*>(a + oj);
+    const f32x4 bi = *reinterpret_cast<const f32x4*>(b + oi), bj = *reinterpret_cast<const f32x4*>(b + oj);
+    *reinterpret_cast<f32x4*>(out + (size_t)p * F + c) = f0 * (ai * bj) + f1 * (aj * bi);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------- K4
 // One wave per molecule.  A lane owns VW = F/64 adjacent feature columns of every atom row of the molecule, so the
 // LDS copy of x and the accumulators are lane-private (one barrier after staging, no atomics); each filter row is
@@ -311,6 +334,17 @@ extern "C" int geossl_ssp_fwd(const float* x, int64_t n, float* y, hipStream_t s
 extern "C" int geossl_ssp_bwd(const float* y, const float* dy, int64_t n, float* dx, hipStream_t stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_ssp_bwd, dim3(grid1d(n, 256)), dim3(256), 0, stream, y, dy, n, dx);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_pair_product(const float* a, const float* b, const int32_t* pair_i, const int32_t* pair_j,
+                                   const uint8_t* pair_flag, int64_t P, int F, int swap, float* out,
+                                   hipStream_t stream) {
+  if (P <= 0) return 0;
+  if (F & 3) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_pair_product, dim3(grid1d(P * (F / 4), 256)), dim3(256), 0, stream, a, b, pair_i, pair_j,
+                     pair_flag, P, F, swap, out);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

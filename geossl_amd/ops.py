@@ -201,6 +201,15 @@ def aggregate(x, Wf_l, pair_flag, layout, swap=False):
     return out
 
 
+def pair_product(a, b, layout, pair_flag, swap=False):
+    """d aggregate / d filter rows as a tensor [P, F]: f0 a[i] b[j] + f1 a[j] b[i] per pair slot."""
+    N, F = a.shape
+    out = torch.empty(layout.P, F, dtype=torch.float32, device=a.device)
+    call("geossl_pair_product", ptr(a), ptr(b), ptr(layout.pair_i), ptr(layout.pair_j), ptr(pair_flag), layout.P, F,
+         1 if swap else 0, ptr(out), stream())
+    return out
+
+
 def segment_reduce(h, layout, reduce):
     """torch_scatter.scatter(h, batch, dim=0, reduce) for a sorted batch (schnet.py:115)."""
     out = torch.empty(layout.B, h.size(1), dtype=torch.float32, device=h.device)

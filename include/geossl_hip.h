@@ -141,6 +141,13 @@ int geossl_cfconv_aggregate(const float* x, const float* Wf, const uint8_t* pair
                             const int32_t* pair_ptr, const int32_t* order, int64_t B, int max_n, int F, int swap,
                             float* out, hipStream_t stream);
 
+/* Gradient of geossl_cfconv_aggregate with respect to the filter rows, as a tensor:
+ * out[p][c] = f0 a[i][c] b[j][c] + f1 a[j][c] b[i][c] for pair slot p = (i < j) with edge flags f0 (j -> i), f1 (i -> j)
+ * (exchanged when swap = 1).  The first-order path never materialises it (geossl_cfconv_filter_bwd); the second-order
+ * path (training on forces, finetune_md17.py:46-54) keeps it differentiable.                                      */
+int geossl_pair_product(const float* a, const float* b, const int32_t* pair_i, const int32_t* pair_j,
+                        const uint8_t* pair_flag, int64_t P, int F, int swap, float* out, hipStream_t stream);
+
 /* ---- atom-row Linear — ATen Linear at schnet.py:99,101,166,189,191 and its autograd.
  * Y[r][n] = epi(sum_k X[r][k] * Bm[k][n]); transB=1: W is torch layout [NO][K] (forward);
  * transB=0: W is [K][NO] (backward w.r.t. input: dX = dY W).  K % 8 == 0, K,NO <= 256.  ldx / ldy: row strides of
@@ -172,7 +179,7 @@ int geossl_linear_prepared(const float* X, int ldx, const uint32_t* image, const
  * (row stride ld, shared with res / tprev).  Every stage is F -> F, F in {32, 64, 128}.  `image`: operand image of the
  * stage's weight from geossl_chain_prepare (transB as in geossl_linear: 1 = W is [NO][K] (forward), 0 = W is [K][NO]
  * (dX = dY W)), geossl_chain_image_words(F) 32-bit words each.                                                    */
-#define GEOSSL_CHAIN_MAX 4
+#define GEOSSL_CHAIN_MAX 3
 typedef struct {
   const uint32_t* image;
   const float* bias;  /* may be NULL */
