@@ -118,6 +118,37 @@ def _core_params(model):
     return ps
 
 
+_SIDE_STREAMS = {}
+
+
+def _run_sections(lay, cfg, run_rows):
+    """run_rows(a0, a1, m0, m1, order) for every independent section of the batch: the first on the current stream, the
+    others on side streams forked from it and joined back (also inside a HIP-graph capture, where they become parallel
+    branches).  Every tensor the sections touch was allocated on the current stream before the fork."""
+    secs = lay.sections if (cfg["split"] and lay.sections) else [(0, lay.N, 0, lay.B, lay.order)]
+    if len(secs) == 1:
+        run_rows(*secs[0])
+        return
+    main = torch.cuda.current_stream()
+    fork = torch.cuda.Event()
+    fork.record(main)
+    joins = []
+    for k, sec in enumerate(secs[1:]):
+        key = (main.device.index, k)
+        side = _SIDE_STREAMS.get(key)
+        if side is None:
+            side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=main.device)
+        side.wait_event(fork)
+        with torch.cuda.stream(side):
+            run_rows(*sec)
+            done = torch.cuda.Event()
+            done.record(side)
+        joins.append(done)
+    run_rows(*secs[0])
+    for done in joins:
+        main.wait_event(done)
+
+
 class _SchNetCore(torch.autograd.Function):
     """(z, pos) -> atom features after the head (schnet.py:89-101) as ONE autograd node."""
 
@@ -158,25 +189,35 @@ class _SchNetCore(torch.autograd.Function):
         if cfg["chain"]:
             # The row-local layers between two aggregations run as ONE launch each (geossl_linear_chain): conv.lin2 + act,
             # lin + residual and the next block's conv.lin1 (after the last block: the head).  Operand images of all
-            # 3L + 2 square weights from one launch.
+            # 3L + 2 square weights from one launch.  Independent sections of the batch (the two views of a DDM step)
+            # run on two streams: one section's aggregation (bound by the filter stream from HBM) overlaps the other's
+            # chain (bound by latencies and the matrix pipe).
             img = ops.prepare_chain([lp[k] for lp in layers for k in (4, 5, 7)] + [head[0], head[2]], transB=True)
             i_lin1, i_lin2, i_lin = img[0:3 * L:3], img[1:3 * L:3], img[2:3 * L:3]
-            x, = ops.linear_chain(h, [dict(image=i_lin1[0])])                                    # conv.lin1     :189
-            for l, lp in enumerate(layers):
-                agg = ops.aggregate(x, Wf[l], pair_flag, lay)                                    # propagate(add) :190
-                stages = [dict(image=i_lin2[l], bias=lp[6], flags=_lib.EPI_SSP),                  # conv.lin2 + act :191,165
-                          dict(image=i_lin[l], bias=lp[8], res=h)]                                # lin + residual  :166,97
-                if l + 1 < L:
-                    stages.append(dict(image=i_lin1[l + 1]))                                      # next conv.lin1  :189
-                    t, hn, xn = ops.linear_chain(agg, stages)
-                else:
-                    stages.append(dict(image=img[3 * L], bias=head[1], flags=_lib.EPI_SSP))       # lin1 + act      :99-100
-                    t, hn, u = ops.linear_chain(agg, stages)
-                    hout, = ops.linear_chain(u, [dict(image=img[3 * L + 1], bias=head[3])])       # lin2            :101
-                    xn = None
-                if training:
-                    hs.append(h); xs.append(x); aggs.append(agg); ts.append(t)
-                h, x = hn, xn
+            full = lambda: torch.empty(N, F, dtype=torch.float32, device=dev)
+            hs, xs, aggs, ts = [h] + [full() for _ in range(L)], [full() for _ in range(L)], [full() for _ in range(L)], \
+                [full() for _ in range(L)]
+            u, hout = full(), full()
+
+            def run_rows(a0, a1, m0, m1, order):
+                rows = lambda t_: t_[a0:a1]
+                ops.linear_chain(rows(hs[0]), [dict(image=i_lin1[0], out=rows(xs[0]))])              # conv.lin1   :189
+                for l, lp in enumerate(layers):
+                    ops.aggregate(xs[l], Wf[l], pair_flag, lay, out=aggs[l], mols=(m0, m1, order))   # propagate   :190
+                    stages = [dict(image=i_lin2[l], bias=lp[6], flags=_lib.EPI_SSP, out=rows(ts[l])),  # conv.lin2 + act
+                              dict(image=i_lin[l], bias=lp[8], res=rows(hs[l]), out=rows(hs[l + 1]))]  # lin + residual
+                    if l + 1 < L:
+                        stages.append(dict(image=i_lin1[l + 1], out=rows(xs[l + 1])))                  # next conv.lin1
+                    else:
+                        stages.append(dict(image=img[3 * L], bias=head[1], flags=_lib.EPI_SSP, out=rows(u)))  # :99-100
+                    ops.linear_chain(rows(aggs[l]), stages)
+                ops.linear_chain(rows(u), [dict(image=img[3 * L + 1], bias=head[3], out=rows(hout))])  # lin2        :101
+
+            _run_sections(lay, cfg, run_rows)
+            h = hs[L]
+            hs = hs[:L]
+            if not training:
+                hs, xs, aggs, ts = [], [], [], []
         else:
             # operand images of the 3L square Linear weights, one launch (each is used by a launch over all atoms of
             # both views; geossl_linear would otherwise re-shape it in every block)
@@ -241,26 +282,40 @@ class _SchNetCore(torch.autograd.Function):
         daggs = [None] * L
         if cfg["chain"]:
             # the same chains walked backwards: [head.lin2 + act', head.lin1], [lin_{L-1} + act', conv.lin2_{L-1}], then per
-            # block  dX through conv.lin1_l (+ the residual branch), lin_{l-1} + act', conv.lin2_{l-1}
+            # block  dX through conv.lin1_l (+ the residual branch), lin_{l-1} + act', conv.lin2_{l-1}; sections of the
+            # batch on two streams like the forward
             img = ops.prepare_chain([lp[k] for lp in layers for k in (4, 5, 7)] + [head[0], head[2]], transB=False)
             i_lin1, i_lin2, i_lin = img[0:3 * L:3], img[1:3 * L:3], img[2:3 * L:3]
-            du, dh = ops.linear_chain(dh_out, [dict(image=img[3 * L + 1], tprev=sv["u"]), dict(image=img[3 * L])])
-            dy, dagg = ops.linear_chain(dh, [dict(image=i_lin[L - 1], tprev=sv["ts"][L - 1]), dict(image=i_lin2[L - 1])])
+            full = lambda: torch.empty(N, F, dtype=torch.float32, device=dev)
+            du = full()
+            dhs = [full() for _ in range(L + 1)]      # dhs[l] = gradient at the input of block l (dhs[L]: at the head's input)
+            dys, dxs = [full() for _ in range(L)], [full() for _ in range(L)]
+            daggs = [full() for _ in range(L)]
+
+            def run_rows(a0, a1, m0, m1, order):
+                rows = lambda t_: t_[a0:a1]
+                ops.linear_chain(rows(dh_out), [dict(image=img[3 * L + 1], tprev=rows(sv["u"]), out=rows(du)),
+                                                dict(image=img[3 * L], out=rows(dhs[L]))])
+                ops.linear_chain(rows(dhs[L]), [dict(image=i_lin[L - 1], tprev=rows(sv["ts"][L - 1]), out=rows(dys[L - 1])),
+                                                dict(image=i_lin2[L - 1], out=rows(daggs[L - 1]))])
+                for l in reversed(range(L)):
+                    ops.aggregate(daggs[l], sv["Wf"][l], sv["pair_flag"], lay, swap=True, out=dxs[l],
+                                  mols=(m0, m1, order))                                        # transposed graph
+                    stages = [dict(image=i_lin1[l], res=rows(dhs[l + 1]), out=rows(dhs[l]))]      # conv.lin1 + residual
+                    if l > 0:
+                        stages += [dict(image=i_lin[l - 1], tprev=rows(sv["ts"][l - 1]), out=rows(dys[l - 1])),
+                                   dict(image=i_lin2[l - 1], out=rows(daggs[l - 1]))]
+                    ops.linear_chain(rows(dxs[l]), stages)
+
+            _run_sections(lay, cfg, run_rows)
             probs.append((dh_out, sv["u"], g_head[2], g_head[3]))
             probs.append((du, sv["h_last"], g_head[0], g_head[1]))
             for l in reversed(range(L)):
                 gl = g_layers[l]
-                dx = ops.aggregate(dagg, sv["Wf"][l], sv["pair_flag"], lay, swap=True)   # transposed graph
-                probs.append((dh, sv["ts"][l], gl[7], gl[8]))
-                probs.append((dy, sv["aggs"][l], gl[5], gl[6]))
-                probs.append((dx, sv["hs"][l], gl[4], None))
-                daggs[l] = dagg
-                stages = [dict(image=i_lin1[l], res=dh)]                                  # through conv.lin1 + residual
-                if l > 0:
-                    stages += [dict(image=i_lin[l - 1], tprev=sv["ts"][l - 1]), dict(image=i_lin2[l - 1])]
-                    dh, dy, dagg = ops.linear_chain(dx, stages)
-                else:
-                    dh, = ops.linear_chain(dx, stages)
+                probs.append((dhs[l + 1], sv["ts"][l], gl[7], gl[8]))
+                probs.append((dys[l], sv["aggs"][l], gl[5], gl[6]))
+                probs.append((dxs[l], sv["hs"][l], gl[4], None))
+            dh = dhs[0]
         else:
             # head: hout = u W2^T + b2, u = ssp(h W1^T + b1)
             du = ops.linear(dh_out, head[2], transB=False, tprev=sv["u"])
@@ -421,7 +476,8 @@ class SchNet(torch.nn.Module):
         cfg = dict(L=self.num_interactions, F=self.hidden_channels, G=self.num_gaussians, cutoff=float(self.cutoff),
                    offset=self.distance_expansion.offset, coeff=float(self.distance_expansion.coeff),
                    debug=bool(os.environ.get("GEOSSL_DEBUG")), status=status,
-                   chain=self.num_interactions >= 1 and not os.environ.get("GEOSSL_NO_CHAIN"))
+                   chain=self.num_interactions >= 1 and not os.environ.get("GEOSSL_NO_CHAIN"),
+                   split=not os.environ.get("GEOSSL_NO_SPLIT"))
         if pos.dtype != torch.float32:
             raise TypeError("positions must be float32")
         h = _SchNetCore.apply(z, pos.contiguous(), lay, cfg, *_core_params(self))

@@ -166,7 +166,10 @@ def linear_chain(x, stages):
     outs = []
     for s, sd in enumerate(stages):
         st = ch.st[s]
-        o = torch.empty(R, F, dtype=torch.float32, device=x.device) if sd.get("store", True) else None
+        o = sd.get("out")  # a preallocated [R, F] destination (e.g. a row slice of a larger tensor) ...
+        if o is None and sd.get("store", True):  # ... or a new tensor, unless the stage is not stored at all
+            o = torch.empty(R, F, dtype=torch.float32, device=x.device)
+        assert o is None or (o.stride(0) == F and o.stride(1) == 1 and o.size(0) == R)
         for aux in (sd.get("res"), sd.get("tprev")):
             assert aux is None or (aux.stride(0) == F and aux.stride(1) == 1 and aux.size(0) == R)
         st.image, st.bias, st.res, st.tprev, st.out = (ptr(sd["image"]), ptr(sd.get("bias")), ptr(sd.get("res")),
@@ -193,11 +196,24 @@ def linear_wgrad(problems, R, M, N, accumulate=False, lda=None, ldb=None, ldw=No
              stream())
 
 
-def aggregate(x, Wf_l, pair_flag, layout, swap=False):
+def aggregate(x, Wf_l, pair_flag, layout, swap=False, out=None, mols=None):
+    """x, out: full [N, F] tensors (rows are addressed by global atom index).  mols = (m0, m1, order): only molecules
+    m0 .. m1-1 are processed (their rows of `out` written), started in the sequence `order` (int32 global molecule ids,
+    or None for m0, m0+1, ...): independent sections of a batch can then run on different streams."""
     N, F = x.shape
-    out = torch.empty_like(x)
-    call("geossl_cfconv_aggregate", ptr(x), ptr(Wf_l), ptr(pair_flag), ptr(layout.mol_ptr), ptr(layout.pair_ptr),
-         ptr(layout.order), layout.B, layout.max_n, F, 1 if swap else 0, ptr(out), stream())
+    if out is None:
+        out = torch.empty_like(x)
+    if mols is None:
+        mp, pp, order, B = ptr(layout.mol_ptr), ptr(layout.pair_ptr), layout.order, layout.B
+    else:
+        m0, m1, order = mols
+        B = m1 - m0
+        if order is not None:  # ids are global: the pointer arrays stay whole
+            mp, pp = ptr(layout.mol_ptr), ptr(layout.pair_ptr)
+        else:                  # molecule blockIdx.x of the launch is m0 + blockIdx.x: shift the (int32) pointer arrays
+            mp, pp = ptr(layout.mol_ptr) + 4 * m0, ptr(layout.pair_ptr) + 4 * m0
+    call("geossl_cfconv_aggregate", ptr(x), ptr(Wf_l), ptr(pair_flag), mp, pp, ptr(order), B, layout.max_n, F,
+         1 if swap else 0, ptr(out), stream())
     return out
 
 

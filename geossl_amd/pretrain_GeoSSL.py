@@ -52,7 +52,9 @@ def _two_view_batch(batch_vec, num_graphs):
     cached = getattr(batch_vec, "_geossl_two_view", None)
     if cached is None or cached[2] != batch_vec._version:
         b2 = torch.cat([batch_vec, batch_vec + num_graphs])
-        cached = (b2, MolLayout(b2, 2 * num_graphs), batch_vec._version)
+        lay2 = MolLayout(b2, 2 * num_graphs)
+        lay2.set_halves()
+        cached = (b2, lay2, batch_vec._version)
         batch_vec._geossl_two_view = cached
     return cached[0], cached[1]
 

@@ -175,12 +175,12 @@ def painn_forward(P, x, positions, radius_edge_index, batch, n_atom_basis, n_int
     phi = torch.exp(coeff * torch.pow(d_ij[..., None] - offsets, 2))  # painn_utils.py:101-102 (E,1,R)
     cut = P["cutoff_fn.cutoff"]
     fcut = 0.5 * (torch.cos(d_ij * math.pi / cut) + 1.0)  # painn_utils.py:152
-    fcut = fcut * (d_ij < cut).float()  # :154
+    fcut = fcut * (d_ij < cut).to(d_ij.dtype)  # :154 (.float() there; dtype-generic so the oracle also runs in fp64)
     filters = F.linear(phi, P["filter_net.weight"], P["filter_net.bias"]) * fcut[..., None]  # :241
     filter_list = torch.split(filters, 3 * F_, dim=-1)  # :245
     emb = P["embedding.weight"]
     q = F.embedding(z, emb, padding_idx=0)[:, None]  # :247
-    mu = torch.zeros((q.shape[0], 3, q.shape[2]))  # :249
+    mu = torch.zeros((q.shape[0], 3, q.shape[2]), dtype=q.dtype)  # :249
     for i in range(n_interactions):  # :251-253
         p = "interactions.%d.interatomic_context_net." % i
         xx = F.linear(F.silu(F.linear(q, P[p + "0.weight"], P[p + "0.bias"])), P[p + "1.weight"], P[p + "1.bias"])  # :53
@@ -188,9 +188,9 @@ def painn_forward(P, x, positions, radius_edge_index, batch, n_atom_basis, n_int
         muj = mu[idx_j]  # :55
         xx = filter_list[i] * xj  # :56
         dq, dmuR, dmumu = torch.split(xx, F_, dim=-1)  # :58
-        dq = torch.zeros((n_atoms,) + tuple(dq.shape[1:])).index_add(0, idx_i, dq)  # :59
+        dq = torch.zeros((n_atoms,) + tuple(dq.shape[1:]), dtype=dq.dtype).index_add(0, idx_i, dq)  # :59
         dmu = dmuR * dir_ij[..., None] + dmumu * muj  # :60
-        dmu = torch.zeros((n_atoms,) + tuple(dmu.shape[1:])).index_add(0, idx_i, dmu)  # :61
+        dmu = torch.zeros((n_atoms,) + tuple(dmu.shape[1:]), dtype=dmu.dtype).index_add(0, idx_i, dmu)  # :61
         q = q + dq  # :63
         mu = mu + dmu  # :64
         m = "mixing.%d." % i

@@ -319,12 +319,22 @@ def test_painn_full_size_determinism_and_oracle_slice(molset):
                             t(nzs["dist_noise_1"]), t(nzs["noise_level_2"]), t(nzs["dist_noise_2"]), 128, 3, 5.0, 2, "add")
     ref.backward()
     assert rel_err(loss.detach().cpu(), ref.detach()) < TOL_OUT
+    # Gradients that sum thousands of per-edge / per-atom terms with heavy cancellation (filter_net.weight, the embedding
+    # table) differ between two fp32 evaluations in different summation orders by more than 1e-4: judge both against
+    # the same oracle evaluated in fp64, and require the HIP path to be as close to it as the fp32 oracle is.
+    dd = lambda d: {k: (v.detach().double().requires_grad_(v.requires_grad) if v.is_floating_point() else v)
+                    for k, v in d.items()}
+    P64, P164, P264 = dd(P), dd(P1), dd(P2)
+    ref64 = nets.do_ddm_painn(P64, P164, P264, xs, t(small["positions"]).double(), t(small["batch"]), t(rei),
+                              t(small["super_edge_index"]), t(nzs["pos_noise"]).double(), t(nzs["noise_level_1"]),
+                              t(nzs["dist_noise_1"]).double(), t(nzs["noise_level_2"]), t(nzs["dist_noise_2"]).double(),
+                              128, 3, 5.0, 2, "add")
+    ref64.backward()
     named = unique_named_grads(model)
     for k, v in P.items():
         if v.grad is not None:
-            # the embedding gradient sums the per-atom gradients of ~130 atoms per type with heavy cancellation: two
-            # fp32 evaluations in different summation orders differ by a few 1e-4 there (the SchNet tests see the same)
-            assert rel_err(named[k].cpu(), v.grad) < (3e-4 if k == "embedding.weight" else TOL_GRAD), k
+            e_hip, e_f32 = rel_err(named[k].cpu().double(), P64[k].grad), rel_err(v.grad.double(), P64[k].grad)
+            assert e_hip < max(TOL_GRAD, 2.0 * e_f32), (k, e_hip, e_f32)
 
 
 def test_painn_degenerate_batch_vs_oracle():
