@@ -189,9 +189,9 @@ class _SchNetCore(torch.autograd.Function):
         if cfg["chain"]:
             # The row-local layers between two aggregations run as ONE launch each (geossl_linear_chain): conv.lin2 + act,
             # lin + residual and the next block's conv.lin1 (after the last block: the head).  Operand images of all
-            # 3L + 2 square weights from one launch.  Independent sections of the batch (the two views of a DDM step)
-            # run on two streams: one section's aggregation (bound by the filter stream from HBM) overlaps the other's
-            # chain (bound by latencies and the matrix pipe).
+            # 3L + 2 square weights from one launch.  With GEOSSL_SPLIT_VIEWS=1 the independent sections of the batch (the
+            # two views of a DDM step) run on two streams (one section's HBM-bound aggregation beside the other's
+            # latency-bound chain); measured 265 k vs 268 k molecules/s without it on one box, so it is off by default.
             img = ops.prepare_chain([lp[k] for lp in layers for k in (4, 5, 7)] + [head[0], head[2]], transB=True)
             i_lin1, i_lin2, i_lin = img[0:3 * L:3], img[1:3 * L:3], img[2:3 * L:3]
             full = lambda: torch.empty(N, F, dtype=torch.float32, device=dev)
@@ -477,7 +477,7 @@ class SchNet(torch.nn.Module):
                    offset=self.distance_expansion.offset, coeff=float(self.distance_expansion.coeff),
                    debug=bool(os.environ.get("GEOSSL_DEBUG")), status=status,
                    chain=self.num_interactions >= 1 and not os.environ.get("GEOSSL_NO_CHAIN"),
-                   split=not os.environ.get("GEOSSL_NO_SPLIT"))
+                   split=bool(os.environ.get("GEOSSL_SPLIT_VIEWS")))
         if pos.dtype != torch.float32:
             raise TypeError("positions must be float32")
         h = _SchNetCore.apply(z, pos.contiguous(), lay, cfg, *_core_params(self))

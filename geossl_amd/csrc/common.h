@@ -132,6 +132,23 @@ __device__ __forceinline__ float4 pin(float4 v) {
   return v;
 }
 
+// sum_b p[b * stride], b in [b0, b1), in index order with a compensation term (Kahan): the partials of a weight gradient
+// can cancel to a small fraction of their magnitudes, and a plain running fp32 sum over a few hundred of them then
+// loses 3-4 digits of the RESULT (seen on PaiNN's filter_net.weight with ragged molecules: 7e-4 against fp64, while a
+// blocked fp32 sum is at 1e-6).  Still a fixed order: bit-reproducible.
+__device__ __forceinline__ float kahan_sum_strided(const float* __restrict__ p, int b0, int b1, int stride) {
+#pragma clang fp reassociate(off) contract(off)
+  float s = 0.0f, c = 0.0f;
+#pragma unroll 4
+  for (int b = b0; b < b1; ++b) {
+    const float y = p[(size_t)b * stride] - c;
+    const float t = s + y;
+    c = (t - s) - y;
+    s = t;
+  }
+  return s;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

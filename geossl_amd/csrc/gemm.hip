@@ -441,22 +441,6 @@ extern "C" int geossl_linear(const float* X, int ldx, const float* W, const floa
 // ------------------------------------------------------------------------------------------------
 // Column GEMM (weight gradient), plain operands — template in tn.h.
 namespace geossl {
-// sum_b p[b * stride], b in [b0, b1), in index order with a compensation term (Kahan): the partials of a weight gradient
-// can cancel to a small fraction of their magnitudes, and a plain running fp32 sum over a few hundred of them then
-// loses 3-4 digits of the RESULT (seen on PaiNN's filter_net.weight with ragged molecules: 7e-4 against fp64, while a
-// blocked fp32 sum is at 1e-6).  Still a fixed order: bit-reproducible.
-__device__ __forceinline__ float kahan_sum_strided(const float* __restrict__ p, int b0, int b1, int stride) {
-#pragma clang fp reassociate(off) contract(off)
-  float s = 0.0f, c = 0.0f;
-#pragma unroll 4
-  for (int b = b0; b < b1; ++b) {
-    const float y = p[(size_t)b * stride] - c;
-    const float t = s + y;
-    c = (t - s) - y;
-    s = t;
-  }
-  return s;
-}
 // several reductions in one launch (tn.h: ReduceMulti); same arithmetic and order as k_reduce_partials
 __global__ __launch_bounds__(256) void k_reduce_multi(ReduceMulti m, int nblk, int accumulate) {
   __shared__ float red[4][64];

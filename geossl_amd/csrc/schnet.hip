@@ -236,16 +236,6 @@ __global__ void k_embedding_bwd_partial(const int64_t* __restrict__ z, int64_t z
   }
   for (int c = 0; c < C; ++c) partial[((size_t)chunk * C + c) * F + f] = smem[c * F + f];
 }
-__global__ void k_embedding_bwd_reduce(const float* __restrict__ partial, int len, float* __restrict__ dtable,
-                                       int accumulate) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
-    float s = accumulate ? dtable[i] : 0.0f;
-#pragma unroll 16
-    for (int b = 0; b < GEOSSL_EMB_CHUNKS; ++b) s += partial[(size_t)b * len + i];
-    dtable[i] = s;
-  }
-}
-
 // ----------------------------------------------------------------------------------------------- readout
 __global__ void k_segment_reduce_fwd(const float* __restrict__ h, const int32_t* __restrict__ mol_ptr, int B, int F,
                                      int mean, float* __restrict__ out) {
@@ -406,9 +396,13 @@ extern "C" int geossl_embedding_bwd(const int64_t* z, int64_t z_stride, const fl
   hipLaunchKernelGGL(k_embedding_bwd_partial, dim3(GEOSSL_EMB_CHUNKS), dim3((F + 63) / 64 * 64),
                      (size_t)num_classes * F * sizeof(float), stream, z, z_stride, dh, N, F, num_classes, workspace);
   GEOSSL_CHECK_LAUNCH();
+  // fixed-order sum of the per-chunk tables: 64 outputs x 4 slices of the chunk list per block, compensated (tn.h)
   const int len = num_classes * F;
-  hipLaunchKernelGGL(k_embedding_bwd_reduce, dim3(grid1d(len, 256)), dim3(256), 0, stream, workspace, len, dtable,
-                     accumulate);
+  GeosslReduceBatch rb;
+  for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = nullptr;
+  rb.out[0] = dtable;
+  hipLaunchKernelGGL(geossl::k_reduce_partials, dim3((len + 63) / 64, 1), dim3(256), 0, stream, rb, workspace,
+                     GEOSSL_EMB_CHUNKS, len, len, len, 1, accumulate);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

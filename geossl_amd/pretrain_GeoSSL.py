@@ -181,11 +181,12 @@ class DDMTrainer:
     ``use_graph=True``: forward + backward of batches that share one index structure (same
     ``batch`` / ``super_edge_index`` contents, identified by the caller's ``structure_key``) are
     captured once into a HIP graph and replayed; positions, atom types and the five noise tensors
-    are copied into the graph's static buffers before each replay.  The all-reduce and the Adam
-    launch stay outside the graph."""
+    are copied into the graph's static buffers before each replay.  A loader with ragged molecules
+    passes one key per batch (e.g. its index in the epoch): up to ``max_graphs`` graphs are kept,
+    all in one shared memory pool.  The all-reduce and the Adam launch stay outside the graph."""
 
     def __init__(self, model, ncsn_01, ncsn_02, lr=5e-4, weight_decay=0.0, mu=0.0, sigma=0.3, model_3d="schnet",
-                 device_noise=True, use_graph=False, overlap_heads=True):
+                 device_noise=True, use_graph=False, overlap_heads=True, max_graphs=256):
         from .optim import FlatParams, FusedAdam
         from .parallel import GradAllReduce
         self.model, self.n1, self.n2 = model, ncsn_01, ncsn_02
@@ -197,7 +198,7 @@ class DDMTrainer:
         self.reduce = GradAllReduce(self.flat.grad)
         self.use_graph = use_graph
         self.overlap_heads = overlap_heads  # head weight gradients on a side stream, concurrent with the backbone's backward
-        self._g = None
+        self._graphs, self._pool, self.max_graphs = {}, None, max_graphs
         self._side = None
 
     def _fwd_bwd(self, batch, noise):
@@ -224,41 +225,54 @@ class DDMTrainer:
         # PaiNN the precomputed radius_edge_index with its incidence lists, which differ from batch to batch even when
         # the molecule sizes agree): only x, positions and the noise tensors are refreshed before a replay.  The
         # caller's structure_key vouches for batch / super_edge_index; radius_edge_index is identified here by tensor
-        # object and version, so a different edge list re-captures instead of silently replaying the old one.
+        # object and version, so a different edge list gets its own capture instead of silently replaying the old one.
         rei = batch.radius_edge_index if self.args.model_3d == "painn" else None
         if rei is not None:
             key = (key, id(rei), rei._version, int(rei.size(1)))
-        g = self._g
-        if g is None or g["key"] != key:
-            sb = Batch(batch.x.clone(), batch.positions.clone(), batch.batch, batch.super_edge_index,
-                       batch.radius_edge_index, batch.num_graphs)
-            sn = {k: noise[k].clone() for k in self._NOISE_KEYS}
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):  # warm-up off the capture: builds the cached layouts, sets kernel attributes
-                for _ in range(2):
-                    self._fwd_bwd(sb, sn)
-            torch.cuda.current_stream().wait_stream(side)
-            # nothing may be pending on the device when the capture starts (in a multi-rank job the collective's
-            # watchdog thread polls events of earlier all-reduces), and calls of other threads must not invalidate it
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            try:
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    loss = self._fwd_bwd(sb, sn)
-            except Exception as e:  # capture is an optimisation: fall back to eager execution, loudly
-                import warnings
-                warnings.warn("HIP-graph capture of the DDM step failed (%s: %s); running eagerly" % (type(e).__name__, e))
-                torch.cuda.synchronize()
-                self.use_graph = False
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._capture(batch, noise, key)
+            if g is None:  # capture failed: eager from now on
                 return self._fwd_bwd(batch, noise)
-            self._g = g = dict(key=key, graph=graph, batch=sb, noise=sn, loss=loss)
         g["batch"].x.copy_(batch.x)
         g["batch"].positions.copy_(batch.positions)
         for k in self._NOISE_KEYS:
             g["noise"][k].copy_(noise[k])
         g["graph"].replay()
         return g["loss"]
+
+    def _capture(self, batch, noise, key):
+        """One HIP graph per structure key.  Ragged batches (every batch its own index structure) get one graph each -
+        captured once, replayed every epoch; all graphs share ONE memory pool (their activations are dead between
+        steps), so the device memory of N graphs is that of the largest, plus the static inputs and the loss of each."""
+        while len(self._graphs) >= self.max_graphs:
+            self._graphs.pop(next(iter(self._graphs)))
+        sb = Batch(batch.x.clone(), batch.positions.clone(), batch.batch, batch.super_edge_index,
+                   batch.radius_edge_index, batch.num_graphs)
+        sn = {k: noise[k].clone() for k in self._NOISE_KEYS}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up off the capture: builds the cached layouts, sets kernel attributes
+            for _ in range(2 if not self._graphs else 1):
+                self._fwd_bwd(sb, sn)
+        torch.cuda.current_stream().wait_stream(side)
+        # nothing may be pending on the device when the capture starts (in a multi-rank job the collective's
+        # watchdog thread polls events of earlier all-reduces), and calls of other threads must not invalidate it
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
+                loss = self._fwd_bwd(sb, sn)
+        except Exception as e:  # capture is an optimisation: fall back to eager execution, loudly
+            import warnings
+            warnings.warn("HIP-graph capture of the DDM step failed (%s: %s); running eagerly" % (type(e).__name__, e))
+            torch.cuda.synchronize()
+            self.use_graph = False
+            return None
+        if self._pool is None:
+            self._pool = graph.pool()
+        g = self._graphs[key] = dict(graph=graph, batch=sb, noise=sn, loss=loss)
+        return g
 
     def step(self, batch, noise=None, structure_key=None):
         if self.use_graph and structure_key is not None and noise is not None and all(k in noise for k in self._NOISE_KEYS):
