@@ -122,13 +122,13 @@ _SIDE_STREAMS = {}
 
 
 def _run_sections(lay, cfg, run_rows):
-    """run_rows(a0, a1, m0, m1, order) for every independent section of the batch: the first on the current stream, the
+    """run_rows(a0, a1, mols) for every independent section of the batch (mols = (m0, m1, order), None = all): the first on the current stream, the
     others on side streams forked from it and joined back (also inside a HIP-graph capture, where they become parallel
     branches).  Every tensor the sections touch was allocated on the current stream before the fork."""
-    secs = lay.sections if (cfg["split"] and lay.sections) else [(0, lay.N, 0, lay.B, lay.order)]
-    if len(secs) == 1:
-        run_rows(*secs[0])
+    if not (cfg["split"] and lay.sections):
+        run_rows(0, lay.N, None)  # the whole batch (ragged batches: the aggregation launches by size class)
         return
+    secs = [(a0, a1, (m0, m1, order)) for a0, a1, m0, m1, order in lay.sections]
     main = torch.cuda.current_stream()
     fork = torch.cuda.Event()
     fork.record(main)
@@ -199,11 +199,11 @@ class _SchNetCore(torch.autograd.Function):
                 [full() for _ in range(L)]
             u, hout = full(), full()
 
-            def run_rows(a0, a1, m0, m1, order):
+            def run_rows(a0, a1, mols):
                 rows = lambda t_: t_[a0:a1]
                 ops.linear_chain(rows(hs[0]), [dict(image=i_lin1[0], out=rows(xs[0]))])              # conv.lin1   :189
                 for l, lp in enumerate(layers):
-                    ops.aggregate(xs[l], Wf[l], pair_flag, lay, out=aggs[l], mols=(m0, m1, order))   # propagate   :190
+                    ops.aggregate(xs[l], Wf[l], pair_flag, lay, out=aggs[l], mols=mols)   # propagate   :190
                     stages = [dict(image=i_lin2[l], bias=lp[6], flags=_lib.EPI_SSP, out=rows(ts[l])),  # conv.lin2 + act
                               dict(image=i_lin[l], bias=lp[8], res=rows(hs[l]), out=rows(hs[l + 1]))]  # lin + residual
                     if l + 1 < L:
@@ -292,7 +292,7 @@ class _SchNetCore(torch.autograd.Function):
             dys, dxs = [full() for _ in range(L)], [full() for _ in range(L)]
             daggs = [full() for _ in range(L)]
 
-            def run_rows(a0, a1, m0, m1, order):
+            def run_rows(a0, a1, mols):
                 rows = lambda t_: t_[a0:a1]
                 ops.linear_chain(rows(dh_out), [dict(image=img[3 * L + 1], tprev=rows(sv["u"]), out=rows(du)),
                                                 dict(image=img[3 * L], out=rows(dhs[L]))])
@@ -300,7 +300,7 @@ class _SchNetCore(torch.autograd.Function):
                                                 dict(image=i_lin2[L - 1], out=rows(daggs[L - 1]))])
                 for l in reversed(range(L)):
                     ops.aggregate(daggs[l], sv["Wf"][l], sv["pair_flag"], lay, swap=True, out=dxs[l],
-                                  mols=(m0, m1, order))                                        # transposed graph
+                                  mols=mols)                                        # transposed graph
                     stages = [dict(image=i_lin1[l], res=rows(dhs[l + 1]), out=rows(dhs[l]))]      # conv.lin1 + residual
                     if l > 0:
                         stages += [dict(image=i_lin[l - 1], tprev=rows(sv["ts"][l - 1]), out=rows(dys[l - 1])),

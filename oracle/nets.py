@@ -131,6 +131,29 @@ def ncsn_v03_forward(P, batch, super_edge_index, node_feature, distance, noise_l
     return loss
 
 
+def ncsn_relu_margin(P, batch, super_edge_index, node_feature, distance, noise_level, distance_noise):
+    """Conditioning of a NCSN_version_03 evaluation for GRADIENT comparisons: the smallest |pre-activation| of any relu
+    unit (NCSN.py:33-43) relative to the sum of the magnitudes of its terms.  A unit whose pre-activation is below the
+    rounding noise of its own sum (ratio <~ 1e-7 in fp32) has an undetermined relu'(.) in {0, 1}: two correct fp32
+    evaluations may then differ by a finite amount in the gradient of that row.  Tests that compare gradients evaluate
+    this (in fp64) and require a safe margin for their inputs."""
+    edge2graph = batch[super_edge_index[0]]
+    sig = P["sigmas"][noise_level][edge2graph].unsqueeze(-1)
+    pert = distance + distance_noise * sig
+    margins = []
+    zi = F.linear(pert, P["input_distance_mlp.layers.0.weight"], P["input_distance_mlp.layers.0.bias"])
+    mi = F.linear(pert.abs(), P["input_distance_mlp.layers.0.weight"].abs(), P["input_distance_mlp.layers.0.bias"].abs())
+    margins.append(zi.abs() / mi)
+    emb = F.linear(F.relu(zi), P["input_distance_mlp.layers.1.weight"], P["input_distance_mlp.layers.1.bias"])
+    x = torch.cat([node_feature[super_edge_index[0]] + node_feature[super_edge_index[1]], emb], dim=-1)
+    for i in range(2):
+        w, b = P["output_mlp.layers.%d.weight" % i], P["output_mlp.layers.%d.bias" % i]
+        z, m = F.linear(x, w, b), F.linear(x.abs(), w.abs(), b.abs())
+        margins.append(z.abs() / m)
+        x = F.relu(z)
+    return float(min(r.min() for r in margins))
+
+
 def super_edge_distance(pos, super_edge_index):
     """pretrain_GeoSSL.py:199-201 / 203-205."""
     u = torch.index_select(pos, 0, super_edge_index[0])

@@ -298,7 +298,12 @@ def test_painn_full_size_determinism_and_oracle_slice(molset):
         runs.append((float(loss), gr.cpu()))
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
     assert np.isfinite(runs[0][0]) and bool(torch.isfinite(runs[0][1]).all())
-    # 64-molecule slice against the oracle
+    # 64-molecule slice against the oracle.  The DDM LOSS is compared on the slice; GRADIENTS are compared through the
+    # backbone alone (PaiNN is smooth: silu).  Gradients through the NCSN heads are pinned on the small golden batches
+    # (G7): with ~2 million relu units in a 64-molecule slice some pre-activation always lies within fp32 rounding of
+    # zero (oracle.nets.ncsn_relu_margin is 1e-8 .. 1e-7 for every noise seed tried), relu' of such a unit is
+    # undetermined in fp32, and one flipped unit moves the gradient of its two atoms by a finite amount (seen: 5e-3 of
+    # |d loss / d q| on 1152 atoms) - a property of the reference's network, not of either implementation.
     small = shard_batch_numpy(b, 0, 16)
     n_at, S = small["positions"].shape[0], small["super_edge_index"].shape[1]
     nzs = dict(pos_noise=nz["pos_noise"][:n_at], noise_level_1=nz["noise_level_1"][:64], dist_noise_1=nz["dist_noise_1"][:S],
@@ -308,33 +313,27 @@ def test_painn_full_size_determinism_and_oracle_slice(molset):
     bt = _painn_batch(small)
     loss, _ = pg.do_DDM(pg.Args("painn"), bt, model, None, 0.0, 0.3, NCSN_models=(n1, n2),
                         noise={k: t(v, DEV) for k, v in nzs.items()})
-    loss.backward()
     rei = graph.collate_np([(small["x"][small["batch"] == m], small["positions"][small["batch"] == m])
                             for m in range(64)], radius=5.0)["radius_edge_index"]
     assert np.array_equal(rei, bt.radius_edge_index.cpu().numpy())
     P, P1, P2 = _painn_oracle_params(), ncsn_oracle_params(128, 50), ncsn_oracle_params(128, 50, 0.9)
     xs = t(small["x"]).clone()
-    ref = nets.do_ddm_painn(P, P1, P2, xs, t(small["positions"]), t(small["batch"]), t(rei),
-                            t(small["super_edge_index"]), t(nzs["pos_noise"]), t(nzs["noise_level_1"]),
-                            t(nzs["dist_noise_1"]), t(nzs["noise_level_2"]), t(nzs["dist_noise_2"]), 128, 3, 5.0, 2, "add")
-    ref.backward()
-    assert rel_err(loss.detach().cpu(), ref.detach()) < TOL_OUT
-    # Gradients that sum thousands of per-edge / per-atom terms with heavy cancellation (filter_net.weight, the embedding
-    # table) differ between two fp32 evaluations in different summation orders by more than 1e-4: judge both against
-    # the same oracle evaluated in fp64, and require the HIP path to be as close to it as the fp32 oracle is.
-    dd = lambda d: {k: (v.detach().double().requires_grad_(v.requires_grad) if v.is_floating_point() else v)
-                    for k, v in d.items()}
-    P64, P164, P264 = dd(P), dd(P1), dd(P2)
-    ref64 = nets.do_ddm_painn(P64, P164, P264, xs, t(small["positions"]).double(), t(small["batch"]), t(rei),
-                              t(small["super_edge_index"]), t(nzs["pos_noise"]).double(), t(nzs["noise_level_1"]),
-                              t(nzs["dist_noise_1"]).double(), t(nzs["noise_level_2"]), t(nzs["dist_noise_2"]).double(),
-                              128, 3, 5.0, 2, "add")
-    ref64.backward()
+    with torch.no_grad():
+        ref = nets.do_ddm_painn(P, P1, P2, xs, t(small["positions"]), t(small["batch"]), t(rei),
+                                t(small["super_edge_index"]), t(nzs["pos_noise"]), t(nzs["noise_level_1"]),
+                                t(nzs["dist_noise_1"]), t(nzs["noise_level_2"]), t(nzs["dist_noise_2"]), 128, 3, 5.0, 2, "add")
+    assert rel_err(loss.detach().cpu(), ref) < TOL_OUT
+    pos2 = t(small["positions"]) + t(nzs["pos_noise"])  # the perturbed view: some precomputed edges beyond the cutoff
+    model.zero_grad()
+    out, q = model(bt.x, pos2.to(DEV), bt.radius_edge_index, bt.batch, return_latent=True)
+    ((out ** 2).sum() + 0.5 * (q ** 2).sum()).backward()
+    o_ref, q_ref = nets.painn_forward(P, xs, pos2, t(rei), t(small["batch"]), 128, 3, 5.0, "add", return_latent=True)
+    ((o_ref ** 2).sum() + 0.5 * (q_ref ** 2).sum()).backward()
+    assert_close(q.detach().cpu(), q_ref.detach(), TOL_OUT, "q")
     named = unique_named_grads(model)
     for k, v in P.items():
         if v.grad is not None:
-            e_hip, e_f32 = rel_err(named[k].cpu().double(), P64[k].grad), rel_err(v.grad.double(), P64[k].grad)
-            assert e_hip < max(TOL_GRAD, 2.0 * e_f32), (k, e_hip, e_f32)
+            assert rel_err(named[k].cpu(), v.grad) < TOL_GRAD, k
 
 
 def test_painn_degenerate_batch_vs_oracle():
