@@ -5,6 +5,8 @@
 #include "geossl_hip.h"
 #include "tn.h"
 
+#include <cstdlib>
+
 using namespace geossl;
 
 namespace {
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(64) void k_aggregate(const float* __restrict__ x, c
     }
   __syncthreads();
   if (col && np > 0) {
-    const float* __restrict__ wcol = Wf + (size_t)base * F + f;
+      const float* __restrict__ wcol = Wf + (size_t)base * F + f;
     const float* xl = xs + f;
     float* al = acc + f;
     // Walk by row atom a, U consecutive partners b at a time (a chunk never crosses a row, so its U accumulator rows
@@ -191,6 +193,127 @@ __global__ __launch_bounds__(64) void k_aggregate(const float* __restrict__ x, c
   if (col)
     for (int i = 0; i < n; ++i)
       *reinterpret_cast<V*>(out + (size_t)(a0 + i) * F + f) = *reinterpret_cast<const V*>(acc + i * F + f);
+}
+
+// ---------------------------------------------------------------------------------------- K4, register form
+// The same walk with the molecule's rows of x and the accumulators in REGISTERS: the loops over the row atom a and its
+// partners b are unrolled for a size class NMAX >= n, so every row is a named register, there is no LDS, no barrier and
+// no address arithmetic beyond one scalar multiply-add per filter row (~12 instructions per pair slot instead of ~44).
+// A wave's walk is bound by instruction issue, not by bytes, so this shortens the serial walk of a large molecule -
+// which bounds a launch over ragged molecules from below - several times.  Positions (a, b) with b >= n are executed
+// on a clamped filter row with their flag bits clear (the flags of a row atom are ballot masks indexed by b): no
+// branches, so the filter-row requests run RING positions ahead of their use in one basic block.  Same summation
+// order as k_aggregate (separate multiply and add, ascending source per target): results are bit-identical.
+template <int NMAX>
+__device__ __forceinline__ void aggregate_reg_body(const float* __restrict__ x, const float* __restrict__ Wf,
+                                                   const uint8_t* __restrict__ pair_flag, int a0, int n, int base,
+                                                   int lane, int f, int F, int swap, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  typedef f32x2 V;
+  constexpr int RING = NMAX > 26 ? 8 : (NMAX > 20 ? 10 : 12);   // filter rows in flight per wave
+  constexpr int NPOS = NMAX * (NMAX - 1) / 2;            // positions of the unrolled walk
+  // filter row of a slot = uniform base (scalar registers) + this lane's fixed column offset: the requests then use
+  // the scalar-base addressing form and no per-request vector address is ever computed (or kept alive)
+  const float* __restrict__ wbase = Wf + (size_t)base * F;
+  // slot of position (a, b): a*n - a(a+1)/2 + b - a - 1; invalid positions read slot 0 of the molecule (n >= 2) or, for
+  // a one-atom molecule, nothing at all
+  if (n < 2) {
+    if (n == 1) *reinterpret_cast<V*>(out + (size_t)a0 * F + f) = V(0.0f);
+    return;
+  }
+  V xr[NMAX], acc[NMAX], ring[RING];
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i) {
+    xr[i] = *reinterpret_cast<const V*>(x + (size_t)(a0 + min(i, n - 1)) * F + f);
+    acc[i] = V(0.0f);
+  }
+  auto slot_of = [&](int a, int b) { return b < n ? a * n - a * (a + 1) / 2 + b - a - 1 : 0; };
+  auto load_row = [&](int slot) {
+    const float* rowp = wbase + (size_t)__builtin_amdgcn_readfirstlane(slot) * F;  // uniform
+    return __builtin_nontemporal_load(reinterpret_cast<const V*>(rowp + f));
+  };
+  {  // prologue: the first RING positions
+    int ap = 0, bp = 1;
+#pragma unroll
+    for (int q = 0; q < RING && q < NPOS; ++q) {
+      ring[q] = load_row(slot_of(ap, bp));
+      if (++bp == NMAX) { ++ap; bp = ap + 1; }
+    }
+  }
+  int q = 0, ap = 0, bp = 1;
+#pragma unroll
+  for (int k = 0; k < RING && k < NPOS; ++k)
+    if (++bp == NMAX) { ++ap; bp = ap + 1; }              // (ap, bp) = position q + RING
+#pragma unroll
+  for (int a = 0; a < NMAX - 1; ++a) {
+    // flags of row atom a as two ballot masks over the partner index b (lane b reads the flag of slot (a, b))
+    // (clamped address + select, the loaded value pinned: a predicated load would become a branch, and with control flow
+    // in the walk the arithmetic is sunk below every later request of the block)
+    const bool mine = lane > a && lane < n;
+    unsigned fl = pair_flag[base + (mine ? a * n - a * (a + 1) / 2 + lane - a - 1 : 0)];
+    asm volatile("" : "+v"(fl));
+    fl = mine ? fl : 0u;
+    if (swap) fl = ((fl & 1u) << 1) | ((fl >> 1) & 1u);
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64((fl & 1u) != 0u);  // edge b -> a
+    const unsigned long long m1 = __builtin_amdgcn_ballot_w64((fl & 2u) != 0u);  // edge a -> b
+    V acc_a = acc[a];
+    const V xa = xr[a];
+#pragma unroll
+    for (int b = a + 1; b < NMAX; ++b, ++q) {
+      const V w = ring[q % RING];
+      if (q + RING < NPOS) {
+        ring[q % RING] = load_row(slot_of(ap, bp));
+        if (++bp == NMAX) { ++ap; bp = ap + 1; }
+      }
+      const V t0 = xr[b] * w;
+      const V s0 = acc_a + t0;
+      acc_a = ((m0 >> b) & 1ull) ? s0 : acc_a;
+      const V t1 = xa * w;
+      const V s1 = acc[b] + t1;
+      acc[b] = ((m1 >> b) & 1ull) ? s1 : acc[b];
+      // Keep the schedule as written.  Left alone, the arithmetic (pure register code, only needed by the final
+      // stores) is sunk below every request of the block and the live filter rows spill: the volatile statement
+      // pins this position's sums in program order, the memory clobber keeps the next request behind it.
+      asm volatile("" : "+v"(acc_a.x), "+v"(acc_a.y), "+v"(acc[b].x), "+v"(acc[b].y) : : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    acc[a] = acc_a;
+  }
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i)
+    if (i < n) *reinterpret_cast<V*>(out + (size_t)(a0 + i) * F + f) = acc[i];
+}
+
+// all molecules of the launch fit one size class (uniform batches: the best register allocation for that class)
+template <int NMAX>
+__global__ __launch_bounds__(64, (NMAX <= 20 ? 4 : 3)) void k_aggregate_reg(
+    const float* __restrict__ x, const float* __restrict__ Wf, const uint8_t* __restrict__ pair_flag,
+    const int32_t* __restrict__ mol_ptr, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ order, int B,
+    int F, int swap, float* __restrict__ out) {
+  if ((int)blockIdx.x >= B) return;
+  const int m = order != nullptr ? order[blockIdx.x] : (int)blockIdx.x;
+  const int lane = threadIdx.x, f = 2 * lane;
+  if (f >= F) return;                                     // F = 128: all lanes; F = 64: half a wave (no barriers here)
+  const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m];
+  aggregate_reg_body<NMAX>(x, Wf, pair_flag, a0, n, base, lane, f, F, swap, out);
+}
+
+// ragged batches in ONE launch: every wave takes the unrolled walk of its own molecule's size class (molecules are
+// started largest first, so neighbouring waves mostly run the same code)
+__global__ __launch_bounds__(64, 3) void k_aggregate_reg_ragged(
+    const float* __restrict__ x, const float* __restrict__ Wf, const uint8_t* __restrict__ pair_flag,
+    const int32_t* __restrict__ mol_ptr, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ order, int B,
+    int F, int swap, float* __restrict__ out) {
+  if ((int)blockIdx.x >= B) return;
+  const int m = order != nullptr ? order[blockIdx.x] : (int)blockIdx.x;
+  const int lane = threadIdx.x, f = 2 * lane;
+  if (f >= F) return;
+  const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m];
+  const int nu = __builtin_amdgcn_readfirstlane(n);
+#define AGG_CLASS(NM) if (nu <= NM) { aggregate_reg_body<NM>(x, Wf, pair_flag, a0, n, base, lane, f, F, swap, out); return; }
+  AGG_CLASS(8) AGG_CLASS(12) AGG_CLASS(16) AGG_CLASS(18) AGG_CLASS(20) AGG_CLASS(22) AGG_CLASS(24) AGG_CLASS(26)
+  AGG_CLASS(28) AGG_CLASS(30) AGG_CLASS(33)
+#undef AGG_CLASS
 }
 
 // --------------------------------------------------------------------------------------------- embedding
@@ -344,6 +467,23 @@ extern "C" int geossl_cfconv_aggregate(const float* x, const float* Wf, const ui
                                        int max_n, int F, int swap, float* out, hipStream_t stream) {
   if (B <= 0) return 0;
   if (max_n > 255 || F > 128) return (int)hipErrorInvalidValue;
+  if (F > 32 && max_n <= 33 && !getenv("GEOSSL_AGG_LDS")) {
+    // register form: one size class for the whole launch when the largest molecule has <= 20 atoms, else the kernel
+    // that picks the class per molecule
+#define AGG_REG(NM)                                                                                               \
+  if (max_n <= NM) {                                                                                              \
+    hipLaunchKernelGGL(k_aggregate_reg<NM>, dim3((unsigned)B), dim3(64), 0, stream, x, Wf, pair_flag, mol_ptr,    \
+                       pair_ptr, order, (int)B, F, swap, out);                                                    \
+    GEOSSL_CHECK_LAUNCH();                                                                                        \
+    return 0;                                                                                                     \
+  }
+    AGG_REG(8) AGG_REG(12) AGG_REG(16) AGG_REG(18) AGG_REG(20)
+#undef AGG_REG
+    hipLaunchKernelGGL(k_aggregate_reg_ragged, dim3((unsigned)B), dim3(64), 0, stream, x, Wf, pair_flag, mol_ptr,
+                       pair_ptr, order, (int)B, F, swap, out);
+    GEOSSL_CHECK_LAUNCH();
+    return 0;
+  }
   const size_t lds = (size_t)2 * max_n * F * sizeof(float) + (size_t)(max_n * (max_n - 1) / 2) + 16;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   if (F > 64) {

@@ -10,9 +10,6 @@ from . import _lib
 from ._lib import call, ptr, stream
 
 
-AGG_CLASS_EDGES = (20, 26)  # aggregation size classes: n <= 20, 21..26, > 26 atoms
-
-
 class MolLayout:
     """mol_ptr / pair-slot enumeration of a sorted ``batch`` vector.
 
@@ -64,31 +61,9 @@ class MolLayout:
         # molecules by descending size: the sequence in which the per-molecule blocks of the aggregation are started
         # (ops.aggregate); identity when all sizes are equal
         self.order = None
-        # size classes of the aggregation launches: (first position in `order`, one past the last, largest molecule of
-        # the class).  The kernel keeps a molecule's rows in LDS sized for the largest molecule of its LAUNCH, so one
-        # launch over a ragged batch runs every wave at the occupancy of the 33-atom molecules (4 waves per CU instead
-        # of 8 at 18 atoms); a launch per class restores it.  None = a single class.
-        self.buckets = None
         if B > 1:
             nat = self.mol_ptr[1:] - self.mol_ptr[:-1]
             self.order = torch.argsort(nat, descending=True, stable=True).to(torch.int32)
-            if sizes is not None:
-                srt = sorted(sizes, reverse=True)
-            elif self.max_n > AGG_CLASS_EDGES[0]:
-                srt = nat[self.order.long()].tolist()  # lazy path only (drains the stream once per new batch anyway)
-            else:
-                srt = None
-            if srt is not None and srt[0] > AGG_CLASS_EDGES[0]:
-                cuts, k = [], 0
-                for edge in reversed(AGG_CLASS_EDGES):  # descending sizes: classes (edge, inf), ..., (0, first edge]
-                    k1 = sum(1 for n in srt if n > edge)
-                    if k1 > k:
-                        cuts.append((k, k1, srt[k]))
-                        k = k1
-                if k < B:
-                    cuts.append((k, B, srt[k]))
-                if len(cuts) > 1:
-                    self.buckets = cuts
         self.device = dev
         self._batch_version = batch._version
         self.sections = None

@@ -203,12 +203,6 @@ def aggregate(x, Wf_l, pair_flag, layout, swap=False, out=None, mols=None):
     N, F = x.shape
     if out is None:
         out = torch.empty_like(x)
-    if mols is None and layout.buckets:
-        # ragged batch: one launch per size class of `order` (each with LDS for its own largest molecule)
-        for k0, k1, mx in layout.buckets:
-            call("geossl_cfconv_aggregate", ptr(x), ptr(Wf_l), ptr(pair_flag), ptr(layout.mol_ptr), ptr(layout.pair_ptr),
-                 ptr(layout.order) + 4 * k0, k1 - k0, mx, F, 1 if swap else 0, ptr(out), stream())
-        return out
     if mols is None:
         mp, pp, order, B = ptr(layout.mol_ptr), ptr(layout.pair_ptr), layout.order, layout.B
     else:
