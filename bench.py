@@ -31,7 +31,9 @@ BF16_PEAK = 2.5e15      # FLOP/s, dense bf16 MFMA (MI355X_MICROARCH.md)
 SPLIT_PRODUCTS = 6
 # entry points whose launches are bracketed with HIP events inside the timed region
 TIMED = ("geossl_cfconv_filter_fwd", "geossl_cfconv_filter_bwd",
-         "geossl_ddm_loss_fwd", "geossl_ddm_loss_bwd_rows", "geossl_ddm_loss_bwd_weights", "geossl_linear_wgrad")
+         "geossl_ddm_loss_fwd", "geossl_ddm_loss_bwd_rows", "geossl_ddm_loss_bwd_weights", "geossl_linear_wgrad",
+         "geossl_painn_interaction_fwd", "geossl_painn_interaction_bwd")
+PAINN_L, PAINN_R = 3, 20  # config.py:118-121 defaults of the reference's PaiNN (n_interactions, n_rbf)
 
 
 # entry point -> prefix of the device kernels it launches (for the PMC traffic lookup)
@@ -63,6 +65,73 @@ def alg_model(n_atoms, n_edges, n_super):
         "geossl_linear_wgrad": (2 * N * (3 * L + 2) * 2 * F * F, 2 * N * (3 * L + 2) * 8 * F),
     }
     return step_bytes, step_flops, per_kernel
+
+
+def alg_model_painn(n_atoms, n_edges, n_super):
+    """Algorithmic bytes / flops of one DDM step with the PaiNN backbone (BASELINE config 5), in the spirit of SURVEY
+    8(d): the reference formulation (painn.py:32-66,91-114,216-269), one HBM tensor at every boundary between its ATen /
+    torch_scatter ops, fp32 = 4 B, int64 = 8 B; backward modelled as 2x forward; both views.  SURVEY gives no PaiNN
+    figures, so the terms are listed here (E directed edges of the precomputed radius graph, N atoms, S super-edges,
+    F = 128 features, R = 20 radial functions, L = 3 interactions):
+      per edge, once per view     : r_ij, d, dir, phi, fcut (12+4+12+4R+4 W; 24+16 R) and filter_net [E, 3FL] (4R R, 12FL W)
+      per edge and interaction    : filter slice (12F R), x[idx_j] (12F R), W*x (12F W, 12F R), mu[idx_j] (12F R),
+                                    dmu [E,3,F] (12F W, 12F R), two index_add outputs are per atom      -> 84F
+      per atom and interaction    : context nets in/out, mu_channel_mix in/out, norms, products, residuals -> ~160F
+      flops per edge and interaction fwd: filter_net 2 R 3F + message products ~9F; per atom: Dense F->F, F->3F, mu mix
+                                    3 x (F -> 2F), Dense 2F->F, F->3F = 2(F^2 + 3F^2 + 6F^2 + 2F^2 + 3F^2) = 30 F^2
+    """
+    E, N, S = float(n_edges), float(n_atoms), float(n_super)
+    Lp, R = PAINN_L, PAINN_R
+    bytes_fwd_view = E * (76 + 8 * R + 12 * F * Lp + Lp * 84 * F) + N * (28 + Lp * 160 * F)
+    bytes_k5_view = S * (16 + 8 * F + 12)
+    step_bytes = 2 * 3 * (bytes_fwd_view + bytes_k5_view)
+    edge_fwd = 2 * R * 3 * F + 9 * F
+    node_fwd = 30 * F * F
+    ncsn_fwd = 2 * (F + 1) * F + 2 * F * (F // 2) + F + 4 * F
+    step_flops = 2 * 3 * (E * Lp * edge_fwd + N * Lp * node_fwd + S * ncsn_fwd)
+    per_kernel = {
+        # one launch = one interaction over both views (2E edges, 2N atoms); the backward also accumulates the
+        # filter_net gradient (another 2 R 3F per edge) and re-evaluates the filter
+        "geossl_painn_interaction_fwd": (2 * E * edge_fwd, 2 * E * (4 * R + 16 + 24 * F) + 2 * N * 32 * F),
+        "geossl_painn_interaction_bwd": (2 * E * (3 * 2 * R * 3 * F + 18 * F), 2 * E * (4 * R + 16 + 36 * F) + 2 * N * 56 * F),
+    }
+    return step_bytes, step_flops, per_kernel
+
+
+def cpu_baseline_painn(seed, n_mols=256, timed=3, max_threads=32):
+    """The CPU oracle's DDM step with the PaiNN backbone on a bounded sample (see cpu_baseline)."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+    from geossl_amd.synthetic import draw_noise, make_batch
+    from helpers import ncsn_oracle_params, t
+    from oracle import graph, nets
+    from test_oracle_golden import painn_params
+    cores = min(os.cpu_count() or 1, max_threads)
+    torch.set_num_threads(cores)
+    Pm = painn_params(dict(n_atom_basis=F, n_interactions=PAINN_L, n_rbf=PAINN_R, cutoff=5.0, max_z=9))
+    P1, P2 = ncsn_oracle_params(F, K_LEVELS), ncsn_oracle_params(F, K_LEVELS, 0.9)
+    params = [p for P in (Pm, P1, P2) for p in P.values() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=5e-4)
+    b = make_batch(n_mols, seed=seed, mode="A")
+    off = np.concatenate([[0], np.cumsum(b["sizes"])])
+    rei = t(graph.collate_np([(b["x"][off[m]:off[m + 1]], b["positions"][off[m]:off[m + 1]]) for m in range(n_mols)],
+                             radius=5.0)["radius_edge_index"])
+    times = []
+    for it in range(1 + timed):
+        nz = draw_noise(b, seed + it)
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = nets.do_ddm_painn(Pm, P1, P2, t(b["x"]), t(b["positions"]), t(b["batch"]), rei, t(b["super_edge_index"]),
+                                 t(nz["pos_noise"]), t(nz["noise_level_1"]), t(nz["dist_noise_1"]), t(nz["noise_level_2"]),
+                                 t(nz["dist_noise_2"]), F, PAINN_L, 5.0, 2, "add")
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times[1:]))
+    return {"value": n_mols / med, "unit": "molecules/s", "cores": cores, "kind": "port",
+            "sample": "oracle PaiNN DDM step (fwd+bwd+Adam) on %d molecules of the bench shape (n=18, 5 A), 1 warm-up + %d "
+                      "timed steps on %d torch threads (host has %d cores; capped at %d), median %.2f s/step"
+                      % (n_mols, timed, cores, os.cpu_count() or 1, max_threads, med)}
 
 
 def cpu_baseline(seed, n_mols=512, timed=3, max_threads=32):
@@ -333,7 +402,12 @@ def main():
         bt = batches[0]
         E = int(ops.radius_graph(bt.positions, CUTOFF, bt.batch).size(1))
         N, S = bt.positions.size(0), bt.super_edge_index.size(1)
-        step_bytes, step_flops, per_kernel = alg_model(N, E, S)
+        if args.model == "painn":
+            E = int(bt.radius_edge_index.size(1))  # the precomputed graph of the clean geometry (both views use it)
+            step_bytes, step_flops, per_kernel = alg_model_painn(N, E, S)
+            per_kernel.update({k: v for k, v in alg_model(N, E, S)[2].items() if k.startswith("geossl_ddm")})
+        else:
+            step_bytes, step_flops, per_kernel = alg_model(N, E, S)
         pm, pm_src = pmc_file(workload_id(args.model, args.mols, args.molset, CUTOFF))
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * args.mols * args.steps / elapsed
@@ -343,6 +417,7 @@ def main():
                 ms = [a.elapsed_time(b) for a, b in evs]
                 calls_per_step = len(ms) / prof_steps
                 kern[name] = (float(np.mean(ms)), calls_per_step)
+        kern = {k: v for k, v in kern.items() if k in per_kernel}
         dom = max(kern, key=lambda k: kern[k][0] * kern[k][1]) if kern else None
         roof = None
         if dom is not None:
@@ -366,14 +441,21 @@ def main():
                     "avg_launch_ms": kern[dom][0], "launches_per_step": kern[dom][1], "timing": timing_mode,
                     "algorithmic_TFLOPs": ach_f / 1e12, "frac_algorithmic": ach_f / (BF16_PEAK / SPLIT_PRODUCTS),
                     "algorithmic_GBps": ach_b / 1e9, "hbm_frac": ach_b / HBM_PEAK}
-            if dom in ("geossl_cfconv_filter_fwd", "geossl_cfconv_filter_bwd"):
+            if dom.startswith("geossl_painn"):
+                # PaiNN's interaction kernels are fp32 vector code over gathered rows (no matrix pipe): priced against
+                # HBM with the algorithmic bytes above, the fp32 vector fraction beside it
+                roof.update({"bound": "hbm", "unit": "GB/s", "achieved": ach_b / 1e9, "peak": HBM_PEAK / 1e9,
+                             "frac": ach_b / HBM_PEAK, "fp32_vector_frac": ach_f / FP32_PEAK,
+                             "peak_note": "algorithmic bytes of the launch over the 8 TB/s HBM3E spec"})
+            elif dom in ("geossl_cfconv_filter_fwd", "geossl_cfconv_filter_bwd"):
                 P2 = 2 * sum(int(n) * (int(n) - 1) // 2 for n in sizes0)  # pair slots, both views
                 per_row = (2 * 64 * F + (2 if dom.endswith("fwd") else 4) * F * F)
                 exe = P2 * L * per_row * SPLIT_PRODUCTS
             else:  # other entry points issue their algorithmic flops, six MFMAs per product
                 exe = fl * SPLIT_PRODUCTS
-            roof.update({"achieved": exe / dur / 1e12, "peak": BF16_PEAK / 1e12, "frac": exe / dur / BF16_PEAK,
-                         "peak_note": "executed bf16 MFMA flops (6 per fp32 product) over the 2.5 PFLOP/s dense bf16 peak"})
+            if not dom.startswith("geossl_painn"):
+                roof.update({"achieved": exe / dur / 1e12, "peak": BF16_PEAK / 1e12, "frac": exe / dur / BF16_PEAK,
+                             "peak_note": "executed bf16 MFMA flops (6 per fp32 product) over the 2.5 PFLOP/s dense bf16 peak"})
         per_gpu = value / world
         out = {
             "metric": ("molecules/s/GPU SchNet+DDM fwd+bwd (QM9-sized, bs=1024); % HBM roofline" if args.model == "schnet"
@@ -402,12 +484,9 @@ def main():
             "kernel_ms": {k: {"avg_ms": v[0], "per_step": v[1]} for k, v in kern.items()},
             "final_loss": final_loss,
         }
-        if args.model != "schnet":
-            out["roofline"] = None  # the byte/flop model of SURVEY 8(d) is SchNet's; the PaiNN line reports throughput only
-            out["step_roofline"] = None
         out["cpu_baseline"] = None  # timed on rank 0 at N=1 only
-        if world == 1 and not args.no_cpu_baseline and args.model == "schnet":
-            out["cpu_baseline"] = cpu_baseline(seed=1000)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(seed=1000) if args.model == "schnet" else cpu_baseline_painn(seed=1000)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

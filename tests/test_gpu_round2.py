@@ -526,3 +526,30 @@ def test_force_evaluation_with_create_graph_uses_the_fused_kernels():
         assert f.requires_grad == create_graph
         forces.append(f.detach())
     assert torch.equal(forces[0], forces[1])
+
+
+def test_standalone_mlp_module_matches_torch():
+    """MultiLayerPerceptron.forward (NCSN.py:33-43) as a module of its own - the two MLP shapes of NCSN_version_03 -
+    against torch.nn.functional on the same weights in fp64, values and gradients (weights, input)."""
+    from geossl_amd.NCSN import MultiLayerPerceptron
+    torch.manual_seed(3)
+    for dims, batch_shape in (((1, [128, 1]), (300,)), ((129, [128, 64, 1]), (7, 33))):
+        mlp = MultiLayerPerceptron(dims[0], dims[1], activation="relu").to(DEV)
+        for layer in mlp.layers:
+            torch.nn.init.normal_(layer.bias, std=0.1)
+        x = torch.randn(*batch_shape, dims[0], device=DEV, requires_grad=True)
+        y = mlp(x)
+        assert y.shape == (*batch_shape, dims[1][-1])
+        (y ** 2).sum().backward()
+        xr = x.detach().double().requires_grad_(True)
+        h = xr
+        ws = [(l.weight.detach().double().requires_grad_(True), l.bias.detach().double().requires_grad_(True)) for l in mlp.layers]
+        for i, (w, b_) in enumerate(ws):
+            h = torch.nn.functional.linear(h, w, b_)
+            if i < len(ws) - 1:
+                h = torch.relu(h)
+        (h ** 2).sum().backward()
+        assert max_abs_rel(y.detach(), h.detach()) < 2e-6
+        assert rel_err(x.grad, xr.grad) < 1e-5
+        for l, (w, b_) in zip(mlp.layers, ws):
+            assert rel_err(l.weight.grad, w.grad) < 1e-5 and rel_err(l.bias.grad, b_.grad) < 1e-5
