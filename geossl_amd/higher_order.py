@@ -28,9 +28,12 @@ def _mm_raw(a, b, mode):
         return ops.linear(a, b, transB=True)
     if mode == "nn":    # a [R, K] @ b[K, NO]
         return ops.linear(a, b, transB=False)
-    R, M, N = a.size(0), a.size(1), b.size(1)  # "tn": a[R, M]^T @ b[R, N]
+    R, M, N = a.size(0), a.size(1), b.size(1)  # "tn": a[R, M]^T @ b[R, N], tiled to the column GEMM's 128 x 128 limit
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-    ops.linear_wgrad([(a, b, out, None)], R, M, N)
+    for m0 in range(0, M, 128):
+        for n0 in range(0, N, 128):
+            mm, nn = min(128, M - m0), min(128, N - n0)
+            ops.linear_wgrad([(a[:, m0:], b[:, n0:], out[m0:, n0:], None)], R, mm, nn, lda=M, ldb=N, ldw=N)
     return out
 
 
