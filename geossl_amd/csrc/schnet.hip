@@ -210,7 +210,9 @@ __device__ __forceinline__ void aggregate_reg_body(const float* __restrict__ x, 
                                                    int lane, int f, int F, int swap, float* __restrict__ out) {
 #pragma clang fp contract(off)
   typedef f32x2 V;
-  constexpr int RING = NMAX > 26 ? 8 : (NMAX > 20 ? 10 : 12);   // filter rows in flight per wave
+  // filter rows in flight per wave: a wave's walk takes (positions / RING) memory round trips (~2 us each under load),
+  // so the large classes - whose single wave bounds a ragged launch from below - get the deeper ring
+  constexpr int RING = NMAX > 26 ? 24 : (NMAX > 20 ? 20 : (NMAX > 18 ? 12 : 16));
   constexpr int NPOS = NMAX * (NMAX - 1) / 2;            // positions of the unrolled walk
   // filter row of a slot = uniform base (scalar registers) + this lane's fixed column offset: the requests then use
   // the scalar-base addressing form and no per-request vector address is ever computed (or kept alive)
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(64, (NMAX <= 20 ? 4 : 3)) void k_aggregate_reg(
 
 // ragged batches in ONE launch: every wave takes the unrolled walk of its own molecule's size class (molecules are
 // started largest first, so neighbouring waves mostly run the same code)
-__global__ __launch_bounds__(64, 3) void k_aggregate_reg_ragged(
+__global__ __launch_bounds__(64, 2) void k_aggregate_reg_ragged(
     const float* __restrict__ x, const float* __restrict__ Wf, const uint8_t* __restrict__ pair_flag,
     const int32_t* __restrict__ mol_ptr, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ order, int B,
     int F, int swap, float* __restrict__ out) {
