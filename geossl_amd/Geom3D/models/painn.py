@@ -35,6 +35,15 @@ class Dense(nn.Linear):
         if self.bias is not None:
             self.bias_init(self.bias)
 
+    def forward(self, input):
+        """painn_utils.py:31-35 for stand-alone use (the energy head of create_output_layers(); inside PaiNN the Dense
+        layers run in the fused node): the product on the HIP row GEMM, differentiable to any order."""
+        from ...higher_order import _linear_wide
+        _lib.require_cuda(input)
+        lead = input.shape[:-1]
+        y = _linear_wide(input.reshape(-1, input.shape[-1]), self.weight, self.bias)
+        return self.activation(y).reshape(*lead, self.out_features)
+
 
 class GaussianRBF(nn.Module):
     """painn_utils.py:106-136 (non-trainable): offsets = linspace(start, cutoff, n_rbf), widths = |Δ|."""
@@ -149,10 +158,22 @@ class PaiNN(nn.Module):
             raise NotImplementedError("HIP path supports n_atom_basis in (32, 64, 128) and n_rbf in (8, 16, 20, 32)")
         if self.activation is not F.silu:
             raise NotImplementedError("HIP path implements the reference default activation F.silu")
-        if positions.requires_grad:
-            raise NotImplementedError("gradient w.r.t. positions is not built (SURVEY.md §8(f) N3)")
         atomic_numbers = x[:, 0] if x.dim() == 2 else x  # painn.py:226-229
         lay = get_layout(batch)
+        if positions.requires_grad and torch.is_grad_enabled():
+            # forces / training on forces (finetune_md17.py:38-54): the fused kernels have no position gradient; the
+            # forward runs as a graph of differentiable primitives instead (Dense layers on the HIP GEMMs)
+            from ...higher_order import painn_atom_features
+            cfg = dict(F=self.n_atom_basis, L=self.n_interactions, cutoff=float(self.cutoff),
+                       offsets=self.radial_basis.offsets, widths=self.radial_basis.widths,
+                       eps=float(self.mixing[0].epsilon))
+            if positions.dtype != torch.float32:
+                raise TypeError("positions must be float32")
+            q = painn_atom_features(atomic_numbers, positions, radius_edge_index[0], radius_edge_index[1], cfg,
+                                    self._params())
+            from .schnet import _SegmentReduce
+            h = _SegmentReduce.apply(q, lay, self.readout)
+            return (h, q) if return_latent else h
         el = get_edge_layout(batch, radius_edge_index, lay.B)
         status = _lib.module_status(self, positions.device, "atomic number out of range for the embedding table "
                                     "(max_z=%d)" % self.embedding.num_embeddings)

@@ -383,7 +383,9 @@ class _SchNetCore(torch.autograd.Function):
 
 
 class _SegmentReduce(torch.autograd.Function):
-    """torch_scatter.scatter(h, batch, dim=0, reduce) for a sorted batch (schnet.py:115)."""
+    """torch_scatter.scatter(h, batch, dim=0, reduce) for a sorted batch (schnet.py:115).  Its backward is the
+    expansion below and vice versa, so the pair is differentiable to any order (training on forces differentiates the
+    readout's backward with respect to its upstream gradient, i.e. the weights of the energy head)."""
 
     @staticmethod
     def forward(ctx, h, lay, reduce):
@@ -392,11 +394,23 @@ class _SegmentReduce(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        lay = ctx.lay
+        return _SegmentExpand.apply(dout, ctx.lay, ctx.reduce), None, None
+
+
+class _SegmentExpand(torch.autograd.Function):
+    """dh[a] = dout[molecule of a] (/ atoms of the molecule for "mean"): the adjoint of _SegmentReduce."""
+
+    @staticmethod
+    def forward(ctx, dout, lay, reduce):
+        ctx.lay, ctx.reduce = lay, reduce
         dh = torch.empty(lay.N, dout.size(1), dtype=torch.float32, device=dout.device)
         call("geossl_segment_reduce_bwd", ptr(dout.contiguous()), ptr(lay.mol_ptr), lay.B, dout.size(1),
-             1 if ctx.reduce == "mean" else 0, ptr(dh), 0, stream())
-        return dh, None, None
+             1 if reduce == "mean" else 0, ptr(dh), 0, stream())
+        return dh
+
+    @staticmethod
+    def backward(ctx, g):
+        return _SegmentReduce.apply(g, ctx.lay, ctx.reduce), None, None
 
 
 class SchNet(torch.nn.Module):

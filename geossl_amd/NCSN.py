@@ -40,25 +40,19 @@ class MultiLayerPerceptron(nn.Module):
     def forward(self, input):
         """NCSN.py:33-43 for stand-alone use of the module (inside NCSN_version_03 both MLPs are fused into
         geossl_ddm_loss_fwd/bwd): every layer's product runs on the HIP row GEMM (differentiable to any order,
-        geossl_amd/higher_order._MM; widths padded to the kernel's multiples of 8 / 4 with zeros), activation and
+        geossl_amd/higher_order._linear_wide; widths padded to the kernel's multiples of 8 / 4 with zeros), activation and
         dropout are the torch functions the reference calls."""
-        from .higher_order import _MM
+        from .higher_order import _linear_wide
         _lib.require_cuda(input)
         lead = input.shape[:-1]
         x = input.reshape(-1, input.shape[-1])
         for i, layer in enumerate(self.layers):
-            K, NO = layer.in_features, layer.out_features
-            Kp, NOp = (K + 7) // 8 * 8, (NO + 3) // 4 * 4
-            if max(Kp, NOp) > 256:
-                raise NotImplementedError("stand-alone MLP layers are limited to 256 features on the HIP row GEMM")
-            w = F.pad(layer.weight, (0, Kp - K, 0, NOp - NO))
-            y = _MM.apply(F.pad(x, (0, Kp - K)), w, "nt")[:, :NO] + layer.bias
+            x = _linear_wide(x, layer.weight, layer.bias)
             if i < len(self.layers) - 1:
                 if self.activation:
-                    y = self.activation(y)
+                    x = self.activation(x)
                 if self.dropout:
-                    y = self.dropout(y)
-            x = y
+                    x = self.dropout(x)
         return x.reshape(*lead, x.shape[-1])
 
 

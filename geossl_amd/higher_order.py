@@ -10,7 +10,9 @@ What runs where: every GEMM (``_MM``: the three forms X W^T, X W, A^T B are clos
 row / column GEMM kernels, the neighbour aggregation and its filter gradient (``_Agg`` / ``_PairProd``, closed as well)
 on geossl_cfconv_aggregate / geossl_pair_product, the radius graph on geossl_pair_geometry; the element-wise glue of
 this path (distance, Gaussian smearing, cosine envelope, softplus, bias adds) is plain torch on the same device -
-PyTorch's own derivative formulas carry the higher orders there.  Nothing here is on the DDM hot path.
+PyTorch's own derivative formulas carry the higher orders there.  PaiNN has no fused position-gradient kernels: with
+``positions.requires_grad`` its whole forward takes the primitive route (``painn_atom_features``).  Nothing here is on
+the DDM hot path.
 """
 import math
 
@@ -135,6 +137,60 @@ def schnet_atom_features(z, pos, lay, cfg, params):
         h = h + _linear(x, lin_w, lin_b)                                          # :166,97
     h = _ssp(_linear(h, head[0], head[1]))                                        # :99-100
     return _linear(h, head[2], head[3])                                           # :101
+
+
+def _linear_wide(x, w, b=None):
+    """x @ w^T + b for any width: contraction padded to a multiple of 8, output columns in slabs of <= 128 (the row
+    GEMM's limits), every slab a differentiable _MM."""
+    NO, K = w.shape
+    Kp, NOp = (K + 7) // 8 * 8, (NO + 3) // 4 * 4
+    if Kp != K or NOp != NO:
+        x, w = F.pad(x, (0, Kp - K)), F.pad(w, (0, Kp - K, 0, NOp - NO))
+    if Kp > 256:
+        raise NotImplementedError("the HIP row GEMM contracts over at most 256 features")
+    outs = [_MM.apply(x, w[c0:c0 + 128], "nt") for c0 in range(0, NOp, 128)]
+    y = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+    y = y[:, :NO] if NOp != NO else y
+    return y if b is None else y + b
+
+
+def painn_atom_features(z, pos, idx_i, idx_j, cfg, params):
+    """painn.py:230-255 (edge geometry .. last mixing block) as a graph of differentiable primitives - the route PaiNN
+    takes when its positions require a gradient (forces and training on forces, finetune_md17.py:38-54): every Dense
+    layer on the HIP row / column GEMMs, gathers, scatter-adds and element-wise glue in torch on the device.
+    `params` in PaiNN._params() order."""
+    Fd, L, cutoff = cfg["F"], cfg["L"], cfg["cutoff"]
+    emb_w, fw, fb = params[0], params[1], params[2]
+    inter = [params[3 + 4 * l: 7 + 4 * l] for l in range(L)]
+    mix = [params[3 + 4 * L + 5 * l: 8 + 4 * L + 5 * l] for l in range(L)]
+    n_atoms = pos.size(0)
+    r_ij = pos[idx_i] - pos[idx_j]                                                # :232
+    d_ij = torch.norm(r_ij, dim=1, keepdim=True)                                  # :236
+    dir_ij = r_ij / d_ij                                                          # :237
+    offsets, widths = cfg["offsets"], cfg["widths"]
+    phi = torch.exp((-0.5 / widths ** 2) * (d_ij - offsets) ** 2)                 # painn_utils.py:99-102  [E, R]
+    fcut = 0.5 * (torch.cos(d_ij * math.pi / cutoff) + 1.0) * (d_ij < cutoff).to(d_ij.dtype)   # :152-154
+    filters = _linear_wide(phi, fw, fb) * fcut                                    # :241  [E, L*3F]
+    q = F.embedding(z, emb_w, padding_idx=0)                                      # :247
+    mu = torch.zeros(n_atoms, 3, Fd, dtype=q.dtype, device=q.device)              # :249
+    for l in range(L):
+        c0w, c0b, c1w, c1b = inter[l]
+        x = _linear_wide(F.silu(_linear_wide(q, c0w, c0b)), c1w, c1b)             # :53
+        x = filters[:, l * 3 * Fd:(l + 1) * 3 * Fd] * x[idx_j]                    # :54,56
+        dq, dmuR, dmumu = torch.split(x, Fd, dim=-1)                              # :58
+        dq = torch.zeros_like(q).index_add(0, idx_i, dq)                          # :59
+        dmu = dmuR[:, None, :] * dir_ij[..., None] + dmumu[:, None, :] * mu[idx_j]   # :60
+        dmu = torch.zeros_like(mu).index_add(0, idx_i, dmu)                       # :61
+        q, mu = q + dq, mu + dmu                                                  # :63-64
+        i0w, i0b, i1w, i1b, mw = mix[l]
+        mu_mix = _linear_wide(mu.reshape(3 * n_atoms, Fd), mw).reshape(n_atoms, 3, 2 * Fd)   # :100
+        mu_V, mu_W = torch.split(mu_mix, Fd, dim=-1)                              # :101
+        mu_Vn = torch.sqrt(torch.sum(mu_V ** 2, dim=-2) + cfg["eps"])             # :102
+        x = _linear_wide(F.silu(_linear_wide(torch.cat([q, mu_Vn], dim=-1), i0w, i0b)), i1w, i1b)   # :104-105
+        dq_intra, dmu_intra, dqmu_intra = torch.split(x, Fd, dim=-1)              # :107
+        q = q + dq_intra + dqmu_intra * torch.sum(mu_V * mu_W, dim=1)             # :110,112
+        mu = mu + dmu_intra[:, None, :] * mu_W                                    # :108,113
+    return q
 
 
 class SchNetGradNode(torch.autograd.Function):

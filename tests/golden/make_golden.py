@@ -336,8 +336,10 @@ def g10():
         model = fill_module_(SchNet(**cfg))
         positions = batch.positions.clone().requires_grad_(True)
         out = model(batch.x[:, 0], positions, batch.batch)
-        w = torch.cos(torch.arange(out.size(1), dtype=torch.float32))
-        pred_energy = (out * w).sum(dim=1)
+        # graph_pred_linear of finetune_md17.py:33 (a Linear on the graph representation): its weights also receive a
+        # gradient THROUGH the force (the readout's backward is differentiated with respect to its upstream gradient)
+        graph_pred_linear = fill_module_(torch.nn.Linear(out.size(1), 1))
+        pred_energy = graph_pred_linear(out).squeeze(1)
         pred_force = -torch.autograd.grad(outputs=pred_energy, inputs=positions,
                                           grad_outputs=torch.ones_like(pred_energy), create_graph=True,
                                           retain_graph=True)[0]
@@ -358,7 +360,46 @@ def g10():
             arrs["gsum/" + name] = grad_summary(p.grad)
             if tag == "reduced":
                 arrs["grad/" + name] = p.grad
+        arrs["head_grad/weight"], arrs["head_grad/bias"] = graph_pred_linear.weight.grad, graph_pred_linear.bias.grad
         save("g10_schnet_force_training_" + tag, **arrs)
+
+
+def g13():
+    """finetune_md17.py:38-54 with the PaiNN backbone: model(x, positions, radius_edge_index, batch), the energy head of
+    model.create_output_layers(), pred_force = -grad(E, pos, create_graph=True), loss on energy and force, backward."""
+    cfg = dict(n_atom_basis=128, n_interactions=3, n_rbf=20, cutoff=5.0, max_z=9, n_out=1, readout="add")
+    b = make_batch(0, seed=61, sizes=[18, 9, 2, 14, 1])
+    b["x"][:3, 0] = 0
+    batch = Batch(b)
+    rei = []
+    for m in range(len(b["sizes"])):
+        sel = b["batch"] == m
+        off = int(np.nonzero(sel)[0][0])
+        rei.append(radius_graph(torch.from_numpy(b["positions"][sel]), r=5.0, loop=False) + off)
+    rei = torch.cat(rei, dim=1)
+    model = fill_module_(PaiNN(**cfg))
+    head = fill_module_(model.create_output_layers())
+    positions = batch.positions.clone().requires_grad_(True)
+    rep = model(batch.x, positions, rei, batch.batch)
+    pred_energy = head(rep).squeeze(1)
+    pred_force = -torch.autograd.grad(outputs=pred_energy, inputs=positions, grad_outputs=torch.ones_like(pred_energy),
+                                      create_graph=True, retain_graph=True)[0]
+    N, B = positions.size(0), rep.size(0)
+    actual_energy = 0.3 * torch.sin(0.7 * torch.arange(B, dtype=torch.float32))
+    actual_force = 0.2 * torch.cos(0.31 * torch.arange(3 * N, dtype=torch.float32)).view(N, 3)
+    crit = torch.nn.MSELoss()
+    loss = 1.0 * crit(pred_energy, actual_energy) + 10.0 * crit(pred_force, actual_force)
+    loss.backward()
+    arrs = dict(x=batch.x, positions=batch.positions, batch=batch.batch, radius_edge_index=rei, rep=rep.detach(),
+                energy=pred_energy.detach(), force=pred_force.detach(), actual_energy=actual_energy,
+                actual_force=actual_force, loss=loss.detach(), grad_pos=positions.grad,
+                cfg=json.dumps({k: v for k, v in cfg.items()}))
+    for name, p in model.named_parameters():
+        if p.grad is not None:
+            arrs["gsum/" + name] = grad_summary(p.grad)
+    for name, p in head.named_parameters():
+        arrs["head_grad/" + name] = p.grad
+    save("g13_painn_force_training", **arrs)
 
 
 def g11():
@@ -445,6 +486,6 @@ def g12():
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12):
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13):
         if not only or fn.__name__ in only:
             fn()

@@ -668,15 +668,6 @@ def test_painn_forward_and_grads_golden():
             assert rel_err(grad_summary(grads[k[5:]].cpu()), g[k]) < TOL_GRAD, k
 
 
-def test_painn_position_gradient_is_refused():
-    """A position gradient through PaiNN is not built: asking for one fails at the forward instead of returning None."""
-    g = load_golden("g7_painn")
-    model = _painn_model(cfg_of(g))
-    pos = t(g["positions_perturbed"], DEV).requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        model(t(g["x"], DEV), pos, t(g["radius_edge_index"], DEV), t(g["batch"], DEV))
-
-
 def test_painn_radius_edge_index_matches_per_molecule_radius_graph():
     """P0 / N4: radius_edge_index = per-molecule radius_graph on the clean geometry (datasets_3D_Radius.py:120)."""
     from geossl_amd import ops

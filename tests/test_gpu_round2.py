@@ -492,8 +492,9 @@ def test_training_on_forces_vs_reference(tag):
     model = product_schnet(cfg, DEV)
     pos = t(g["positions"], DEV).clone().requires_grad_(True)
     out = model(t(g["x"], DEV)[:, 0], pos, t(g["batch"], DEV))
-    w = torch.cos(torch.arange(out.size(1), dtype=torch.float32, device=DEV))
-    pred_energy = (out * w).sum(dim=1)
+    from filler import fill_module_
+    graph_pred_linear = fill_module_(torch.nn.Linear(out.size(1), 1)).to(DEV)   # finetune_md17.py:33
+    pred_energy = graph_pred_linear(out).squeeze(1)
     pred_force = -torch.autograd.grad(outputs=pred_energy, inputs=pos, grad_outputs=torch.ones_like(pred_energy),
                                       create_graph=True, retain_graph=True)[0]
     assert_close(pred_energy.detach().cpu(), g["energy"], TOL_OUT, "energy")
@@ -509,6 +510,40 @@ def test_training_on_forces_vs_reference(tag):
             assert rel_err(grad_summary(grads[k[5:]].cpu()), g[k]) < TOL_GRAD, k
         if k.startswith("grad/"):
             assert rel_err(grads[k[5:]].cpu(), g[k]) < TOL_GRAD, k
+    # the energy head's weights receive a gradient through the force as well (the readout's backward differentiated with
+    # respect to its upstream gradient)
+    assert rel_err(graph_pred_linear.weight.grad.cpu(), g["head_grad/weight"]) < TOL_GRAD
+    assert rel_err(graph_pred_linear.bias.grad.cpu(), g["head_grad/bias"]) < TOL_GRAD
+
+
+def test_painn_forces_and_training_on_forces_vs_reference():
+    """finetune_md17.py:38-54 with the PaiNN backbone and the energy head of create_output_layers(): forces, then a loss
+    on energy and force back-propagated into every parameter - fixture G13 (the unmodified reference; hydrogens, a
+    2-atom and a 1-atom molecule)."""
+    from filler import fill_module_
+    g = load_golden("g13_painn_force_training")
+    model = _painn(cfg_of(g))
+    head = fill_module_(model.create_output_layers()).to(DEV)
+    pos = t(g["positions"], DEV).clone().requires_grad_(True)
+    rep = model(t(g["x"], DEV), pos, t(g["radius_edge_index"], DEV), t(g["batch"], DEV))
+    assert_close(rep.detach().cpu(), g["rep"], TOL_OUT, "representation")
+    pred_energy = head(rep).squeeze(1)
+    pred_force = -torch.autograd.grad(outputs=pred_energy, inputs=pos, grad_outputs=torch.ones_like(pred_energy),
+                                      create_graph=True, retain_graph=True)[0]
+    assert rel_err(pred_energy.detach().cpu(), g["energy"]) < TOL_OUT
+    assert rel_err(pred_force.detach().cpu(), g["force"]) < TOL_GRAD
+    crit = torch.nn.MSELoss()
+    loss = 1.0 * crit(pred_energy, t(g["actual_energy"], DEV)) + 10.0 * crit(pred_force, t(g["actual_force"], DEV))
+    assert rel_err(loss.detach().cpu(), g["loss"]) < 1e-4
+    loss.backward()
+    assert rel_err(pos.grad.cpu(), g["grad_pos"]) < TOL_GRAD
+    grads = unique_named_grads(model)
+    assert float(grads["embedding.weight"][0].abs().max()) == 0.0
+    for k in g:
+        if k.startswith("gsum/"):
+            assert rel_err(grad_summary(grads[k[5:]].cpu()), g[k]) < TOL_GRAD, k
+    for name, p in head.named_parameters():
+        assert rel_err(p.grad.cpu(), g["head_grad/" + name]) < TOL_GRAD, name
 
 
 def test_force_evaluation_with_create_graph_uses_the_fused_kernels():

@@ -242,13 +242,16 @@ def test_g10_force_training_double_backward(tag):
     pos = t(g["positions"]).clone().requires_grad_(True)
     out = nets.schnet_forward(P, t(g["x"])[:, 0], pos, t(g["batch"]), cfg["cutoff"], cfg["num_interactions"],
                               cfg["readout"])
-    energy = (out * torch.cos(torch.arange(out.size(1), dtype=torch.float32))).sum(dim=1)
+    from filler import fill_module_
+    head = fill_module_(torch.nn.Linear(out.size(1), 1))  # graph_pred_linear, finetune_md17.py:33
+    energy = head(out).squeeze(1)
     force = -torch.autograd.grad(energy, pos, torch.ones_like(energy), create_graph=True, retain_graph=True)[0]
     crit = torch.nn.MSELoss()
     loss = 1.0 * crit(energy, t(g["actual_energy"])) + 10.0 * crit(force, t(g["actual_force"]))
     assert rel_err(loss, g["loss"]) < 2e-5
     loss.backward()
     assert rel_err(pos.grad, g["grad_pos"]) < 5e-5
+    assert rel_err(head.weight.grad, g["head_grad/weight"]) < 5e-5 and rel_err(head.bias.grad, g["head_grad/bias"]) < 5e-5
     for k in g:
         if k.startswith("gsum/"):
             assert rel_err(grad_summary(P[k[5:]].grad), g[k]) < 5e-5, k
@@ -299,3 +302,36 @@ def test_g12_three_step_trajectory(tag):
             p = {"model": Pm, "ncsn1": P1, "ncsn2": P2}[m][name].detach()
             got = grad_summary(p) if k.startswith("psum/") else p
             assert rel_err(got, g[k]) < 1e-5, k
+
+
+def test_g13_painn_force_training():
+    """finetune_md17.py:38-54 with PaiNN on the oracle (forces, loss on energy and force, second differentiation)."""
+    from filler import fill_module_
+    g = load_golden("g13_painn_force_training")
+    cfg = json.loads(str(g["cfg"]))
+    P = painn_params(cfg)
+    head = fill_module_(torch.nn.Sequential(torch.nn.Linear(128, 64), torch.nn.SiLU(), torch.nn.Linear(64, 1)))
+    head_ref_names = {"0.weight": "0.weight", "0.bias": "0.bias", "1.weight": "2.weight", "1.bias": "2.bias"}
+    # create_output_layers() = Sequential(Dense(F, F/2, silu), Dense(F/2, 1)): the filler keys are the Sequential indices
+    # 0 / 1 there; refill under those names so that both heads carry identical weights
+    from filler import fill_value
+    with torch.no_grad():
+        for ref_name, mine in head_ref_names.items():
+            p = dict(head.named_parameters())[mine]
+            p.copy_(fill_value(ref_name, tuple(p.shape)))
+    pos = t(g["positions"]).clone().requires_grad_(True)
+    rep = nets.painn_forward(P, t(g["x"]), pos, t(g["radius_edge_index"]), t(g["batch"]), 128, 3, 5.0, "add")
+    assert max_rel(rep, g["rep"]) < TOL
+    energy = head(rep).squeeze(1)
+    force = -torch.autograd.grad(energy, pos, torch.ones_like(energy), create_graph=True, retain_graph=True)[0]
+    assert rel_err(energy, g["energy"]) < 1e-5 and rel_err(force, g["force"]) < 2e-5
+    crit = torch.nn.MSELoss()
+    loss = 1.0 * crit(energy, t(g["actual_energy"])) + 10.0 * crit(force, t(g["actual_force"]))
+    assert rel_err(loss, g["loss"]) < 2e-5
+    loss.backward()
+    assert rel_err(pos.grad, g["grad_pos"]) < 5e-5
+    for k in g:
+        if k.startswith("gsum/"):
+            assert rel_err(grad_summary(P[k[5:]].grad), g[k]) < 5e-5, k
+    for ref_name, mine in head_ref_names.items():
+        assert rel_err(dict(head.named_parameters())[mine].grad, g["head_grad/" + ref_name]) < 5e-5, ref_name
