@@ -26,17 +26,57 @@ SSP_SHIFT = torch.log(torch.tensor(2.0)).item()  # schnet.py:213
 
 def _mm_raw(a, b, mode):
     a, b = a.contiguous(), b.contiguous()
-    if mode == "nt":    # a [R, K] @ b[NO, K]^T
-        return ops.linear(a, b, transB=True)
-    if mode == "nn":    # a [R, K] @ b[K, NO]
-        return ops.linear(a, b, transB=False)
+    if a.size(0) == 0:  # no rows (e.g. a batch without edges): the kernels are not launched
+        shape = {"nt": (0, b.size(0)), "nn": (0, b.size(1)), "tn": (a.size(1), b.size(1))}[mode]
+        return torch.zeros(shape, dtype=torch.float32, device=a.device)
+    try:
+        return _mm_launch(a, b, mode)
+    except Exception as e:
+        raise type(e)("%s [_MM %s: a %s, b %s]" % (e, mode, tuple(a.shape), tuple(b.shape))) from e
+
+
+def _pad2(t, rows, cols):
+    return t if (rows == t.size(0) and cols == t.size(1)) else F.pad(t, (0, cols - t.size(1), 0, rows - t.size(0)))
+
+
+def _up(n, m):
+    return (n + m - 1) // m * m
+
+
+def _mm_launch(a, b, mode):
+    """Raw products on the HIP GEMMs; widths are zero-padded to what the kernels take (contraction: multiples of 8,
+    outputs: multiples of 4; column GEMM tiles of 32 / 64 / 128) and the result is cut back."""
+    if mode in ("nt", "nn"):
+        R, K = a.shape
+        NO = b.size(0) if mode == "nt" else b.size(1)
+        Kp, NOp = _up(K, 8), _up(NO, 4)
+        a = _pad2(a, R, Kp)
+        outs = []
+        for c0 in range(0, NOp, 128):  # output slabs of <= 128 columns
+            c1 = min(c0 + 128, NOp)
+            y = None
+            for k0 in range(0, Kp, 256):  # contraction in passes of <= 256, accumulated through the residual operand
+                k1 = min(k0 + 256, Kp)
+                ak = a if (k0 == 0 and k1 == Kp) else a[:, k0:k1]
+                if mode == "nt":   # a [R, K] @ b[NO, K]^T
+                    w = _pad2(b[c0:min(c1, NO), k0:min(k1, K)], c1 - c0, k1 - k0)
+                    y = ops.linear(ak, w.contiguous(), transB=True, res=y, K=k1 - k0, NO=c1 - c0)
+                else:              # a [R, K] @ b[K, NO]
+                    w = _pad2(b[k0:min(k1, K), c0:min(c1, NO)], k1 - k0, c1 - c0)
+                    y = ops.linear(ak, w.contiguous(), transB=False, res=y, K=k1 - k0, NO=c1 - c0)
+            outs.append(y)
+        y = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+        return y[:, :NO].contiguous() if NOp != NO else y
     R, M, N = a.size(0), a.size(1), b.size(1)  # "tn": a[R, M]^T @ b[R, N], tiled to the column GEMM's 128 x 128 limit
-    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-    for m0 in range(0, M, 128):
-        for n0 in range(0, N, 128):
-            mm, nn = min(128, M - m0), min(128, N - n0)
-            ops.linear_wgrad([(a[:, m0:], b[:, n0:], out[m0:, n0:], None)], R, mm, nn, lda=M, ldb=N, ldw=N)
-    return out
+    tile = lambda n: 32 if n <= 32 else (64 if n <= 64 else 128)
+    Mp, Np = (_up(M, 128) if M > 128 else tile(M)), (_up(N, 128) if N > 128 else tile(N))
+    a, b = _pad2(a, R, Mp), _pad2(b, R, Np)
+    out = torch.empty(Mp, Np, dtype=torch.float32, device=a.device)
+    for m0 in range(0, Mp, 128):
+        for n0 in range(0, Np, 128):
+            mm, nn = min(128, Mp - m0), min(128, Np - n0)
+            ops.linear_wgrad([(a[:, m0:], b[:, n0:], out[m0:, n0:], None)], R, mm, nn, lda=Mp, ldb=Np, ldw=Np)
+    return out[:M, :N].contiguous() if (Mp != M or Np != N) else out
 
 
 class _MM(torch.autograd.Function):
@@ -140,17 +180,8 @@ def schnet_atom_features(z, pos, lay, cfg, params):
 
 
 def _linear_wide(x, w, b=None):
-    """x @ w^T + b for any width: contraction padded to a multiple of 8, output columns in slabs of <= 128 (the row
-    GEMM's limits), every slab a differentiable _MM."""
-    NO, K = w.shape
-    Kp, NOp = (K + 7) // 8 * 8, (NO + 3) // 4 * 4
-    if Kp != K or NOp != NO:
-        x, w = F.pad(x, (0, Kp - K)), F.pad(w, (0, Kp - K, 0, NOp - NO))
-    if Kp > 256:
-        raise NotImplementedError("the HIP row GEMM contracts over at most 256 features")
-    outs = [_MM.apply(x, w[c0:c0 + 128], "nt") for c0 in range(0, NOp, 128)]
-    y = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
-    y = y[:, :NO] if NOp != NO else y
+    """x @ w^T + b for any widths (the padding / slabbing to the kernels' shapes happens inside _MM)."""
+    y = _MM.apply(x, w, "nt")
     return y if b is None else y + b
 
 
