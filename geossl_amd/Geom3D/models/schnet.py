@@ -118,37 +118,6 @@ def _core_params(model):
     return ps
 
 
-_SIDE_STREAMS = {}
-
-
-def _run_sections(lay, cfg, run_rows):
-    """run_rows(a0, a1, mols) for every independent section of the batch (mols = (m0, m1, order), None = all): the first on the current stream, the
-    others on side streams forked from it and joined back (also inside a HIP-graph capture, where they become parallel
-    branches).  Every tensor the sections touch was allocated on the current stream before the fork."""
-    if not (cfg["split"] and lay.sections):
-        run_rows(0, lay.N, None)  # the whole batch (ragged batches: the aggregation launches by size class)
-        return
-    secs = [(a0, a1, (m0, m1, order)) for a0, a1, m0, m1, order in lay.sections]
-    main = torch.cuda.current_stream()
-    fork = torch.cuda.Event()
-    fork.record(main)
-    joins = []
-    for k, sec in enumerate(secs[1:]):
-        key = (main.device.index, k)
-        side = _SIDE_STREAMS.get(key)
-        if side is None:
-            side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=main.device)
-        side.wait_event(fork)
-        with torch.cuda.stream(side):
-            run_rows(*sec)
-            done = torch.cuda.Event()
-            done.record(side)
-        joins.append(done)
-    run_rows(*secs[0])
-    for done in joins:
-        main.wait_event(done)
-
-
 class _SchNetCore(torch.autograd.Function):
     """(z, pos) -> atom features after the head (schnet.py:89-101) as ONE autograd node."""
 
@@ -189,9 +158,8 @@ class _SchNetCore(torch.autograd.Function):
         if cfg["chain"]:
             # The row-local layers between two aggregations run as ONE launch each (geossl_linear_chain): conv.lin2 + act,
             # lin + residual and the next block's conv.lin1 (after the last block: the head).  Operand images of all
-            # 3L + 2 square weights from one launch.  With GEOSSL_SPLIT_VIEWS=1 the independent sections of the batch (the
-            # two views of a DDM step) run on two streams (one section's HBM-bound aggregation beside the other's
-            # latency-bound chain); measured 265 k vs 268 k molecules/s without it on one box, so it is off by default.
+            # 3L + 2 square weights from one launch.  (Running the two views of a DDM step as two parallel graph branches
+            # - lock-step or staggered by one aggregation - was measured and gave nothing: DESIGN.md section 7.)
             img = ops.prepare_chain([lp[k] for lp in layers for k in (4, 5, 7)] + [head[0], head[2]], transB=True)
             i_lin1, i_lin2, i_lin = img[0:3 * L:3], img[1:3 * L:3], img[2:3 * L:3]
             full = lambda: torch.empty(N, F, dtype=torch.float32, device=dev)
@@ -213,7 +181,7 @@ class _SchNetCore(torch.autograd.Function):
                     ops.linear_chain(rows(aggs[l]), stages)
                 ops.linear_chain(rows(u), [dict(image=img[3 * L + 1], bias=head[3], out=rows(hout))])  # lin2        :101
 
-            _run_sections(lay, cfg, run_rows)
+            run_rows(0, N, None)
             h = hs[L]
             hs = hs[:L]
             if not training:
@@ -282,8 +250,7 @@ class _SchNetCore(torch.autograd.Function):
         daggs = [None] * L
         if cfg["chain"]:
             # the same chains walked backwards: [head.lin2 + act', head.lin1], [lin_{L-1} + act', conv.lin2_{L-1}], then per
-            # block  dX through conv.lin1_l (+ the residual branch), lin_{l-1} + act', conv.lin2_{l-1}; sections of the
-            # batch on two streams like the forward
+            # block  dX through conv.lin1_l (+ the residual branch), lin_{l-1} + act', conv.lin2_{l-1}
             img = ops.prepare_chain([lp[k] for lp in layers for k in (4, 5, 7)] + [head[0], head[2]], transB=False)
             i_lin1, i_lin2, i_lin = img[0:3 * L:3], img[1:3 * L:3], img[2:3 * L:3]
             full = lambda: torch.empty(N, F, dtype=torch.float32, device=dev)
@@ -307,7 +274,7 @@ class _SchNetCore(torch.autograd.Function):
                                    dict(image=i_lin2[l - 1], out=rows(daggs[l - 1]))]
                     ops.linear_chain(rows(dxs[l]), stages)
 
-            _run_sections(lay, cfg, run_rows)
+            run_rows(0, N, None)
             probs.append((dh_out, sv["u"], g_head[2], g_head[3]))
             probs.append((du, sv["h_last"], g_head[0], g_head[1]))
             for l in reversed(range(L)):
@@ -490,8 +457,7 @@ class SchNet(torch.nn.Module):
         cfg = dict(L=self.num_interactions, F=self.hidden_channels, G=self.num_gaussians, cutoff=float(self.cutoff),
                    offset=self.distance_expansion.offset, coeff=float(self.distance_expansion.coeff),
                    debug=bool(os.environ.get("GEOSSL_DEBUG")), status=status,
-                   chain=self.num_interactions >= 1 and not os.environ.get("GEOSSL_NO_CHAIN"),
-                   split=bool(os.environ.get("GEOSSL_SPLIT_VIEWS")))
+                   chain=self.num_interactions >= 1 and not os.environ.get("GEOSSL_NO_CHAIN"))
         if pos.dtype != torch.float32:
             raise TypeError("positions must be float32")
         h = _SchNetCore.apply(z, pos.contiguous(), lay, cfg, *_core_params(self))

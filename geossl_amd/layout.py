@@ -66,25 +66,6 @@ class MolLayout:
             self.order = torch.argsort(nat, descending=True, stable=True).to(torch.int32)
         self.device = dev
         self._batch_version = batch._version
-        self.sections = None
-
-    def set_halves(self, sizes=None):
-        """Mark the layout as two independent halves of equal atom / molecule counts (the clean and the perturbed view of
-        a DDM step): sections = [(a0, a1, m0, m1, order)] with `order` the molecules of the section largest first (None
-        when they all have one size).  The atom-row kernels of the two sections can then run on two streams."""
-        B, N = self.B, self.N
-        if B < 2 or B % 2 or N % 2:
-            return
-        h = B // 2
-        orders = [None, None]
-        if self.order is not None:
-            uniform = sizes is not None and len(set(int(n) for n in sizes)) <= 1
-            if not uniform:
-                nat = (self.mol_ptr[1:] - self.mol_ptr[:-1])
-                for k in range(2):
-                    o = torch.argsort(nat[k * h:(k + 1) * h], descending=True, stable=True).to(torch.int32) + k * h
-                    orders[k] = o
-        self.sections = [(0, N // 2, 0, h, orders[0]), (N // 2, N, h, B, orders[1])]
 
 
 def get_layout(batch):
@@ -150,7 +131,6 @@ def prepare_batch(batch_vec, super_edge_index, sizes):
     B = len(sizes)
     b2 = torch.cat([batch_vec, batch_vec + B])
     lay2 = MolLayout(b2, 2 * B, sizes=sizes + sizes)
-    lay2.set_halves(sizes)
     batch_vec._geossl_two_view = (b2, lay2, batch_vec._version)
     if super_edge_index is not None:
         # the caller built super_edge_index from the same sizes (AtomTupleExtractor): its grouping needs no check

@@ -53,7 +53,6 @@ def _two_view_batch(batch_vec, num_graphs):
     if cached is None or cached[2] != batch_vec._version:
         b2 = torch.cat([batch_vec, batch_vec + num_graphs])
         lay2 = MolLayout(b2, 2 * num_graphs)
-        lay2.set_halves()
         cached = (b2, lay2, batch_vec._version)
         batch_vec._geossl_two_view = cached
     return cached[0], cached[1]
