@@ -68,6 +68,7 @@ _FIELDS = ("in_w1", "in_b1", "in_w2", "in_b2", "o1_w", "o1_b", "o2_w", "o2_b", "
 # the backbone's backward (a chain of small, latency-bound launches) needs nothing but dh: with a side stream set
 # (DDMTrainer does, and joins it before the optimiser step) the two run concurrently.  Off by default: a caller that
 # runs its own optimiser right after loss.backward() must see every gradient on the current stream.
+# Process-wide state (one process drives one GPU, parallel.py): set and cleared by DDMTrainer around loss.backward().
 _SIDE = {"stream": None, "pending": []}
 
 
