@@ -78,7 +78,9 @@ __global__ __launch_bounds__(512) void k_filter_fwd(const float* __restrict__ pa
   const size_t lbase = (size_t)l * P;
   const int nrb = (P + 31) / 32;
   // ---- main loop: a wave takes 32 pair rows through both GEMMs; no block-level synchronisation
-  for (int rb = blockIdx.x * 8 + wave; rb < nrb; rb += gridDim.x * 8) {
+  // row blocks dealt wave-index-major: the waves that get one block more than the others are then spread one per SIMD
+  // over all blocks instead of filling the first blocks (a SIMD's two waves share its matrix pipe)
+  for (int rb = blockIdx.x + gridDim.x * wave; rb < nrb; rb += gridDim.x * 8) {
     const int row = 32 * rb + j;
     const bool live = row < P;
     const float d = live ? pair_d[row] : 0.0f;

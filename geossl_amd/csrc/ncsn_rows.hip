@@ -55,7 +55,11 @@ __global__ __launch_bounds__(512) void k_ncsn_fwd(const float* __restrict__ h, c
     r.eps = dist_noise[rowc];
     return r;
   };
-  int rb = blockIdx.x * 8 + wave;
+  // Row blocks are dealt wave-index-major (all waves 0 of the grid first, then all waves 1, ...): when the row blocks
+  // do not divide evenly (4896 on 2048 waves at the bench size), the waves with one block more are then waves 0-3 of
+  // every block - one per SIMD - instead of all eight waves of the first blocks, whose SIMDs would carry 6 blocks
+  // against 4 elsewhere (a SIMD's two waves share its matrix pipe).
+  int rb = blockIdx.x + gridDim.x * wave;
   RowIn cur;
   if (rb < nrb) cur = load_row(rb);  // in flight while the weights are formatted
   // ---- one-time weight formatting
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(512) void k_ncsn_bwd_rows(GeosslNcsnWeights w, Geos
   __syncthreads();
   const float scale = out_scale * (gout != nullptr ? gout[0] : 1.0f) / (float)divisor[0];
   const int nrb = (S + 31) / 32;
-  for (int rb = blockIdx.x * 8 + wave; rb < nrb; rb += gridDim.x * 8) {
+  for (int rb = blockIdx.x + gridDim.x * wave; rb < nrb; rb += gridDim.x * 8) {  // wave-index-major, as in k_ncsn_fwd
     const int row = 32 * rb + j;
     const bool valid = row < S;
     const size_t rowc = (size_t)min(row, S - 1);
