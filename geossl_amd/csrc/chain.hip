@@ -23,6 +23,8 @@
 #include "geossl_hip.h"
 #include "split.h"
 
+#include <cstdlib>
+
 using namespace geossl;
 
 namespace {
@@ -251,25 +253,301 @@ __global__ __launch_bounds__(256, CHAIN_WPS) void k_row_chain(GeosslChain ch, co
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Eight-wave form with a balanced split.  At the bench size the chain has 1152 row blocks for 1024 SIMDs: with one wave
+// per row block every ninth SIMD carries two (the launch lasts two row-block times while 7/8 of the chip waits).  Here a
+// block has four REGULAR waves (one row block each, as above) and four TEAM waves that share a fifth row block: team
+// wave m computes output column block m of every stage - a quarter of the row block's work per SIMD - and the four
+// exchange their results between stages through LDS (split fragments, double buffered).  Per round a block takes 4 + 1
+// row blocks: 256 blocks x 5 cover 1280, so the 128 row blocks beyond 1024 cost a quarter row-block time on 128 CUs.
+// The team waves read their weight fragments straight from the operand image in L2 (all k-steps of their chunk
+// requested at once), they take part in every chunk barrier and in the LDS-DMA of the ring.
+template <int KS, int NS>
+__global__ __launch_bounds__(512, 2) void k_row_chain8(GeosslChain ch, const float* __restrict__ X, int ldx, int R) {
+  constexpr int F = 16 * KS, NMB = KS / 2, NCH = NS * NMB;
+  constexpr int CHUNK = KS * 3 * 64;
+  constexpr int NSLOT = chain_slots(NCH);
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  u32x4* ring = reinterpret_cast<u32x4*>(smem_raw);                          // [NSLOT][CHUNK]
+  u32x4* xchg = ring + (size_t)NSLOT * CHUNK;                                // [2][KS][3][64] team exchange
+  float* bias_s = reinterpret_cast<float*>(xchg + (size_t)2 * CHUNK);        // [NS][F]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nrb = (R + 31) / 32, B = gridDim.x;
+  const int rounds = (nrb + 5 * B - 1) / (5 * B);
+  const int total = rounds * NCH;
+  auto issue = [&](int cc) {
+    const int c = cc % NCH, s = c / NMB, mb = c - s * NMB;
+    const u32x4* src = reinterpret_cast<const u32x4*>(ch.st[s].image) + (size_t)mb * CHUNK;
+    u32x4* dst = ring + (size_t)(cc % NSLOT) * CHUNK;
+    for (int p = wave; p < KS * 3; p += 8)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 64 + lane),
+                                       (__attribute__((address_space(3))) void*)(dst + p * 64), 16, 0, 0);
+  };
+  for (int cc = 0; cc < NSLOT && cc < total; ++cc) issue(cc);
+  for (int i = tid; i < NS * F; i += 512) {
+    const int s = i / F;
+    bias_s[i] = ch.st[s].bias != nullptr ? ch.st[s].bias[i - s * F] : 0.0f;
+  }
+  // Order of one chunk iteration: MFMAs, epilogue in registers (this is where the chunk's tprev / res loads are
+  // waited for: the vector-memory counter is in order, so everything issued before them - the previous chunk's stores,
+  // the last LDS-DMA - is one MFMA loop old by then), barrier, then this chunk's stores and the next LDS-DMA.  Nothing
+  // young is outstanding at the barrier's vmcnt(0).
+  // the epilogue of one chunk: activation and epilogue operands; leaves the values in v
+  auto epilogue = [&](const GeosslChainStage& st, int mb, const f32x16& acc, const f32x4 (&tp)[4], const f32x4 (&rs)[4],
+                      float (&v)[16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[r];
+    if (st.flags & GEOSSL_EPI_SSP) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = ssp(v[r]);
+    }
+    if (st.tprev != nullptr) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[4 * q] *= dssp_from_out(tp[q].x);
+        v[4 * q + 1] *= dssp_from_out(tp[q].y);
+        v[4 * q + 2] *= dssp_from_out(tp[q].z);
+        v[4 * q + 3] *= dssp_from_out(tp[q].w);
+      }
+    }
+    if (st.res != nullptr) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[4 * q] += rs[q].x;
+        v[4 * q + 1] += rs[q].y;
+        v[4 * q + 2] += rs[q].z;
+        v[4 * q + 3] += rs[q].w;
+      }
+    }
+  };
+  auto store_v = [&](const GeosslChainStage& st, int mb, uint32_t ro, bool live, const float (&v)[16])
+                     __attribute__((always_inline)) {
+    if (st.out != nullptr && live) {
+      char* o = reinterpret_cast<char*>(st.out) + 128 * mb;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(o + 32 * q + ro) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    }
+  };
+  auto load_x = [&](uint32_t rowc, Frag3 (&xf)[KS]) __attribute__((always_inline)) {
+    const char* xb = reinterpret_cast<const char*>(X);
+    const uint32_t xo = rowc * (uint32_t)ldx * 4u + 16u * kh;
+    f32x4 raw[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      raw[ks][0] = *reinterpret_cast<const f32x4*>(xb + 64 * ks + xo);
+      raw[ks][1] = *reinterpret_cast<const f32x4*>(xb + 64 * ks + 32 + xo);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float v[8] = {raw[ks][0].x, raw[ks][0].y, raw[ks][0].z, raw[ks][0].w,
+                          raw[ks][1].x, raw[ks][1].y, raw[ks][1].z, raw[ks][1].w};
+      xf[ks] = split8(v);
+    }
+  };
+  int cc = 0;
+  for (int rd = 0; rd < rounds; ++rd) {
+    const int base = rd * 5 * B;
+    if (wave < 4) {
+      // ---- regular wave: one row block through the whole chain, weights from the ring
+      const int rb = base + 4 * (int)blockIdx.x + wave;
+      const int row = 32 * rb + j;
+      const bool live = row < R;
+      const uint32_t rowc = (uint32_t)min(row, R - 1);
+      Frag3 xf[KS], yf[KS];
+      load_x(rowc, xf);
+      __syncthreads();  // round start: (first round) chunks 0 .. NSLOT-1 landed, biases staged; the team's X is published
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const GeosslChainStage st = ch.st[s];
+        const uint32_t ro = rowc * (uint32_t)st.ld * 4u + 16u * kh;  // byte offset of this lane's row pieces (< 4 GB)
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb, ++cc) {
+          f32x4 tp[4], rs[4];
+          if (st.tprev != nullptr) {
+            const char* tb = reinterpret_cast<const char*>(st.tprev) + 128 * mb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tp[q] = *reinterpret_cast<const f32x4*>(tb + 32 * q + ro);
+          }
+          if (st.res != nullptr) {
+            const char* rbp = reinterpret_cast<const char*>(st.res) + 128 * mb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rs[q] = *reinterpret_cast<const f32x4*>(rbp + 32 * q + ro);
+          }
+          f32x16 acc;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + s * F + 32 * mb + 8 * q + 4 * kh);
+            acc[4 * q] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+          }
+          {
+            const u32x4* Ws = ring + (size_t)(cc % NSLOT) * CHUNK + lane;
+            Frag3 af, an;
+            af.h = Ws[0]; af.m = Ws[64]; af.l = Ws[128];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+              if (ks + 1 < KS) {
+                const u32x4* src = Ws + (size_t)((ks + 1) * 3) * 64;
+                an.h = src[0]; an.m = src[64]; an.l = src[128];
+              }
+              __builtin_amdgcn_sched_barrier(0);
+              mma6(acc, af, xf[ks]);
+              __builtin_amdgcn_sched_barrier(0);
+              if (ks + 1 < KS) af = an;
+            }
+          }
+          float v[16];
+          epilogue(st, mb, acc, tp, rs, v);
+          if (s + 1 < NS) {  // registers 0..7 / 8..15 are k-steps 2mb / 2mb+1 of the next stage (kperm)
+            const float lo[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+            const float hi[8] = {v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]};
+            yf[2 * mb] = split8(lo);
+            yf[2 * mb + 1] = split8(hi);
+          }
+          __syncthreads();  // every wave is done with this slot; the DMA issued so far has landed: refill the slot
+          store_v(st, mb, ro, live, v);
+          if (cc + NSLOT < total) issue(cc + NSLOT);
+        }
+        if (s + 1 < NS) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) xf[ks] = yf[ks];
+        }
+      }
+    } else {
+      // ---- team wave m: column block m of every stage of the block's shared row block
+      const int m = wave - 4;
+      const int rb = base + 4 * B + (int)blockIdx.x;
+      const bool active = m < NMB && rb < nrb;   // wave-uniform
+      const int row = 32 * rb + j;
+      const bool live = active && row < R;
+      const uint32_t rowc = (uint32_t)min(row, R - 1);
+      if (active) {  // this wave's quarter of the row block's X (k-steps 2m, 2m+1), split, into exchange buffer 1
+        const char* xb = reinterpret_cast<const char*>(X) + 128 * m;
+        const uint32_t xo = rowc * (uint32_t)ldx * 4u + 16u * kh;
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(xb + xo), r1 = *reinterpret_cast<const f32x4*>(xb + 32 + xo);
+        const f32x4 r2 = *reinterpret_cast<const f32x4*>(xb + 64 + xo), r3 = *reinterpret_cast<const f32x4*>(xb + 96 + xo);
+        const float lo[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        const float hi[8] = {r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+        const Frag3 f0 = split8(lo), f1 = split8(hi);
+        u32x4* xd = xchg + (size_t)CHUNK + (size_t)(2 * m * 3) * 64 + lane;
+        xd[0] = f0.h; xd[64] = f0.m; xd[128] = f0.l;
+        xd[192] = f1.h; xd[256] = f1.m; xd[320] = f1.l;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const GeosslChainStage st = ch.st[s];
+#pragma unroll
+        for (int mbc = 0; mbc < NMB; ++mbc, ++cc) {
+          float v[16];
+          uint32_t ro = 0;
+          if (active && mbc == 0) {
+            // all weight fragments of chunk (s, m) from the image (L2), requested before anything else
+            // (uniform base + 32-bit lane offset: scalar-base addressing, no per-load 64-bit address registers)
+            const char* img = reinterpret_cast<const char*>(st.image) + (size_t)(m * KS) * 3 * 1024;
+            const uint32_t voff = (uint32_t)lane * 16u;
+            Frag3 af[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+              const char* bk = img + ks * 3 * 1024;
+              asm volatile("" : "+s"(bk));  // keep the base scalar: loads become saddr + lane offset + immediate
+              af[ks].h = *reinterpret_cast<const u32x4*>(bk + voff);
+              af[ks].m = *reinterpret_cast<const u32x4*>(bk + 1024 + voff);
+              af[ks].l = *reinterpret_cast<const u32x4*>(bk + 2048 + voff);
+            }
+            f32x4 tp[4], rs[4];
+            ro = rowc * (uint32_t)st.ld * 4u + 16u * kh;
+            if (st.tprev != nullptr) {
+              const char* tb = reinterpret_cast<const char*>(st.tprev) + 128 * m;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) tp[q] = *reinterpret_cast<const f32x4*>(tb + 32 * q + ro);
+            }
+            if (st.res != nullptr) {
+              const char* rbp = reinterpret_cast<const char*>(st.res) + 128 * m;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) rs[q] = *reinterpret_cast<const f32x4*>(rbp + 32 * q + ro);
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + s * F + 32 * m + 8 * q + 4 * kh);
+              acc[4 * q] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+            }
+            {  // the row block's input of this stage: what the four team waves published one stage ago (or X)
+              const u32x4* xs = xchg + (size_t)((s + 1) & 1) * CHUNK + lane;
+              Frag3 xa, xn;
+              xa.h = xs[0]; xa.m = xs[64]; xa.l = xs[128];
+#pragma unroll
+              for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) {
+                  const u32x4* src = xs + (size_t)((ks + 1) * 3) * 64;
+                  xn.h = src[0]; xn.m = src[64]; xn.l = src[128];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma6(acc, af[ks], xa);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 1 < KS) xa = xn;
+              }
+            }
+            epilogue(st, m, acc, tp, rs, v);
+            if (s + 1 < NS) {  // publish this wave's two k-steps of the next stage's input
+              const float lo[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+              const float hi[8] = {v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]};
+              const Frag3 f0 = split8(lo), f1 = split8(hi);
+              u32x4* xd = xchg + (size_t)(s & 1) * CHUNK + (size_t)(2 * m * 3) * 64 + lane;
+              xd[0] = f0.h; xd[64] = f0.m; xd[128] = f0.l;
+              xd[192] = f1.h; xd[256] = f1.m; xd[320] = f1.l;
+            }
+          }
+          __syncthreads();
+          if (active && mbc == 0) store_v(st, m, ro, live, v);
+          if (cc + NSLOT < total) issue(cc + NSLOT);
+        }
+      }
+    }
+  }
+}
+
 template <int KS>
 int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipStream_t stream) {
   constexpr int NMB = KS / 2, CHUNK_BYTES = KS * 3 * 1024;
   const int nrb = (int)((R + 31) / 32), ngroups = (nrb + 3) / 4;
-  const int grid = ngroups < 2048 ? ngroups : 2048;  // two blocks per CU are resident (72 KB of LDS, <= 256 registers)
   const int nslot = chain_slots(ch.nstage * NMB);
-  const size_t lds = (size_t)nslot * CHUNK_BYTES + (size_t)ch.nstage * 16 * KS * sizeof(float);
+  static const bool four_waves = getenv("GEOSSL_CHAIN4") != nullptr;  // the four-wave form, kept for A/B runs
+  if (four_waves) {
+    const int grid = ngroups < 2048 ? ngroups : 2048;  // two blocks per CU are resident (72 KB of LDS, <= 256 registers)
+    const size_t lds = (size_t)nslot * CHUNK_BYTES + (size_t)ch.nstage * 16 * KS * sizeof(float);
 #define LAUNCH_NS(NSV)                                                                                           \
   do {                                                                                                           \
     allow_big_lds(&k_row_chain<KS, NSV>);                                                                        \
     hipLaunchKernelGGL((k_row_chain<KS, NSV>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R);          \
   } while (0)
-  switch (ch.nstage) {
-    case 1: LAUNCH_NS(1); break;
-    case 2: LAUNCH_NS(2); break;
-    case 3: LAUNCH_NS(3); break;
-    default: return (int)hipErrorInvalidValue;
-  }
+    switch (ch.nstage) {
+      case 1: LAUNCH_NS(1); break;
+      case 2: LAUNCH_NS(2); break;
+      case 3: LAUNCH_NS(3); break;
+      default: return (int)hipErrorInvalidValue;
+    }
 #undef LAUNCH_NS
+  } else {
+    // one block per CU; per round a block takes 4 row blocks (regular waves) + 1 shared by its team waves
+    const int want = (nrb + 4) / 5;
+    const int grid = want < 256 ? want : 256;
+    const size_t lds = (size_t)(nslot + 2) * CHUNK_BYTES + (size_t)ch.nstage * 16 * KS * sizeof(float);
+#define LAUNCH_NS8(NSV)                                                                                          \
+  do {                                                                                                           \
+    allow_big_lds(&k_row_chain8<KS, NSV>);                                                                       \
+    hipLaunchKernelGGL((k_row_chain8<KS, NSV>), dim3(grid), dim3(512), lds, stream, ch, X, ldx, (int)R);         \
+  } while (0)
+    switch (ch.nstage) {
+      case 1: LAUNCH_NS8(1); break;
+      case 2: LAUNCH_NS8(2); break;
+      case 3: LAUNCH_NS8(3); break;
+      default: return (int)hipErrorInvalidValue;
+    }
+#undef LAUNCH_NS8
+  }
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
