@@ -8,6 +8,7 @@ torch calls by default, or can be injected with ``noise_level=`` / ``distance_no
 tests, reproducible multi-GPU runs).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -129,35 +130,52 @@ class _NcsnLoss(torch.autograd.Function):
         S, Fd, N = sel.S, h.size(1), h.size(0)
         st = stream()
         sv = _lib.NcsnSaved(*[ptr(saved[k]) for k in ("a1", "a2", "pd", "emb", "gscale")])
-        dz1 = torch.empty(S, Fd, dtype=torch.float32, device=dev)
         dfeat = torch.empty(S, Fd, dtype=torch.float32, device=dev)
         demb = torch.empty(S, dtype=torch.float32, device=dev)
         grow = torch.empty(S, dtype=torch.float32, device=dev)
         gout = gout.contiguous().to(torch.float32)
-        call("geossl_ddm_loss_bwd_rows", C.byref(w), C.byref(sv), S, Fd, ptr(sel.stats), ctx.out_scale, ptr(gout),
-             ptr(dz1), ptr(dfeat), ptr(demb), ptr(grow), st)
+        direct = _lib.direct_grads_enabled(ctx.params)  # opt-in (DDMTrainer); otherwise gradients go through autograd
+        grads = [p.grad for p in ctx.params] if direct else [torch.empty_like(p) for p in ps]
+        g = _lib.NcsnGrads(*[ptr(t) for t in grads])
+        lib = _lib.load()
+        acc = 1 if direct else 0
+        split = os.environ.get("GEOSSL_NCSN_SPLIT_BWD") is not None  # the two-pass form (row pass, then column GEMMs)
+        if not split:
+            # one pass over the rows: dfeat / demb / grow and the gradients of both dense layers (ncsn_bwd.hip)
+            ws1 = torch.empty(int(lib.geossl_ddm_loss_bwd_fused_workspace_floats(S, Fd)), dtype=torch.float32, device=dev)
+            call("geossl_ddm_loss_bwd_fused", ptr(h), ptr(sel.sei0), ptr(sel.sei1), S, N, Fd, C.byref(w), C.byref(sv),
+                 ptr(sel.stats), ctx.out_scale, ptr(gout), ptr(dfeat), ptr(demb), ptr(grow), C.byref(g), ptr(ws1), acc, st)
+            dz1 = None
+        else:
+            dz1 = torch.empty(S, Fd, dtype=torch.float32, device=dev)
+            call("geossl_ddm_loss_bwd_rows", C.byref(w), C.byref(sv), S, Fd, ptr(sel.stats), ctx.out_scale, ptr(gout),
+                 ptr(dz1), ptr(dfeat), ptr(demb), ptr(grow), st)
         dh = None
         if ctx.needs_input_grad[0]:  # first: the backbone's backward waits for nothing else
             dh = torch.empty(N, Fd, dtype=torch.float32, device=dev)
             call("geossl_incidence_gather", ptr(dfeat), ptr(sel.inc_ptr), ptr(sel.inc_idx), N, Fd, ptr(dh), 0, st)
-        direct = _lib.direct_grads_enabled(ctx.params)  # opt-in (DDMTrainer); otherwise gradients go through autograd
-        grads = [p.grad for p in ctx.params] if direct else [torch.empty_like(p) for p in ps]
-        g = _lib.NcsnGrads(*[ptr(t) for t in grads])
-        nfl = _lib.load().geossl_ddm_loss_bwd_workspace_floats(S, Fd)
+        nfl = lib.geossl_ddm_loss_bwd_workspace_floats(S, Fd)
+
+        def rest(stream_handle):  # what is left of the weight gradients after the row pass
+            ws = torch.empty(nfl, dtype=torch.float32, device=dev)
+            if split:
+                call("geossl_ddm_loss_bwd_weights", ptr(h), ptr(sel.sei0), ptr(sel.sei1), S, Fd, C.byref(w), C.byref(sv),
+                     ptr(dz1), ptr(demb), ptr(grow), C.byref(g), ptr(ws), acc, stream_handle)
+            else:
+                call("geossl_ddm_loss_bwd_small", S, Fd, C.byref(w), C.byref(sv), ptr(demb), ptr(grow), C.byref(g),
+                     ptr(ws), acc, stream_handle)
+            return ws
+
         side = _SIDE["stream"] if direct else None
         if side is None:
-            ws = torch.empty(nfl, dtype=torch.float32, device=dev)
-            call("geossl_ddm_loss_bwd_weights", ptr(h), ptr(sel.sei0), ptr(sel.sei1), S, Fd, C.byref(w), C.byref(sv),
-                 ptr(dz1), ptr(demb), ptr(grow), C.byref(g), ptr(ws), 1 if direct else 0, st)
+            rest(st)
         else:
             main = torch.cuda.current_stream()
             fork = torch.cuda.Event()
             fork.record(main)
             side.wait_event(fork)
             with torch.cuda.stream(side):
-                ws = torch.empty(nfl, dtype=torch.float32, device=dev)
-                call("geossl_ddm_loss_bwd_weights", ptr(h), ptr(sel.sei0), ptr(sel.sei1), S, Fd, C.byref(w), C.byref(sv),
-                     ptr(dz1), ptr(demb), ptr(grow), C.byref(g), ptr(ws), 1, stream())
+                ws = rest(stream())
                 done = torch.cuda.Event()
                 done.record(side)
             _SIDE["pending"].append((done, (h, saved, dz1, demb, grow, ws, w, sv, ps, grads)))

@@ -324,6 +324,14 @@ extern "C" int geossl_ddm_loss_bwd_weights(const float* h, const int64_t* sei0, 
   else if (F == 64) rc = launch_wgrad_split<2, 2>(l1, 1, S, F, F, o, F + 1, F + 1, workspace, accumulate, stream);
   else rc = launch_wgrad_split<1, 1>(l1, 1, S, F, F, o, F + 1, F + 1, workspace, accumulate, stream);
   if (rc) return rc;
+  return geossl_ddm_loss_bwd_small(S, F, w, saved, demb, grow, grads, workspace, accumulate, stream);
+}
+
+// the narrow gradients: output_mlp.layers.2 (weight [1][F/2], bias) and the 1 -> F -> 1 distance embedding MLP
+extern "C" int geossl_ddm_loss_bwd_small(int64_t S, int F, const GeosslNcsnWeights* w, const GeosslNcsnSaved* saved,
+                                         const float* demb, const float* grow, const GeosslNcsnGrads* grads,
+                                         float* workspace, int accumulate, hipStream_t stream) {
+  if (S <= 0) return 0;
   int chunk, nblk;
   small_plan(S, &chunk, &nblk);
   hipLaunchKernelGGL(k_ncsn_small_partial, dim3(nblk), dim3(128), 0, stream, *w, *saved, grow, demb, (int)S, F, chunk,

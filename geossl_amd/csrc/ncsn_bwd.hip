@@ -1,0 +1,552 @@
+// Backward of the denoising-distance-matching head NCSN_version_03 (NCSN.py:168-220) in ONE pass over the super-edge
+// rows: the row gradients (ncsn_rows.hip: k_ncsn_bwd_rows computes the same quantities) AND the weight gradients of
+// the two dense layers of output_mlp, on the bf16 matrix pipe (split.h).  Nothing per-row is re-read: the separate
+// weight-gradient launches (wgrad.h with NcsnW1Ops / NcsnW2Ops) fetched a1, a2, dz1 and the gathered h_u + h_v a
+// second time from HBM with 4-byte column requests (0.36 ms per step for the two heads against 0.15 ms of row pass).
+//
+// Per super-edge row s = (u, v), with g = d loss / d out_row (saved gscale times the upstream scalar):
+//     dz2 = g w3 [a2 > 0]                       dW2 += dz2^T a1          db2 += sum dz2
+//     dz1 = (dz2 o2_w) [a1 > 0]                 dW1 += dz1^T [h_u + h_v, emb]      db1 += sum dz1
+//     dfeat = dz1 o1_w[:, :F]                   demb = dz1 . o1_w[:, F]
+//
+// A block of 2 NW waves (NW = F/32) works on one 32-row tile at a time; every wave owns a 32-wide feature block and
+// keeps its weight slice and its weight-gradient accumulators in registers for all tiles of the block:
+//   wave A_n (hidden units [32n, 32n+32) of layer 1):
+//       dz1 for its units, evaluated with the ROWS on M (dz2 fragments from LDS x its o2_w slice): the result has the
+//       unit on the lane and the rows in the registers (kperm order) - exactly the A-fragment layout of dW1's
+//       contraction over rows, and a1 is requested in that layout (16 4-byte loads of a column) for the mask;
+//       dW1[its units][all features] against the (h_u + h_v)^T fragments the B waves publish; the emb column and db1
+//       from the same registers; the pieces of dz1 go through the matrix pipe against a selection matrix (6 MFMAs,
+//       exact: a bf16 piece times 1.0) and land with the row on the lane - the B fragments of the next product - and
+//       are published; dW2[all units of layer 2][its columns] against its own a1 fragments (phase 2).
+//   wave B_k (features [32k, 32k+32) of layer 0's input):
+//       dfeat for its features (its o1_w^T slice x the published dz1 fragments, rows on N: 16-byte row-piece stores);
+//       builds, one tile ahead: the dz2 fragments (from a2, g, w3), (h_u + h_v)^T for its features (4-byte gathers of
+//       atom rows from L2: a half-wave reads 128 contiguous bytes of one atom) and - B_0, B_1 - dz2^T through the
+//       selection-matrix product, with db2.
+// Two barriers per tile (LDS-only: s_waitcnt lgkmcnt(0) + s_barrier, global requests stay in flight across them):
+// phase 1 is MFMA work of the A waves (78 per tile at F = 128) while the B waves build the next tile, phase 2 is
+// MFMA work of the B waves (48) and the A waves' dW2 (24).  Per SIMD and tile 156 MFMAs, the same as the two separate
+// passes together - but one read of a1 / a2 and no dz1 in HBM at all.
+// One partial per block for every weight gradient, summed in block order by k_reduce_multi (no atomics).
+#include "common.h"
+#include "geossl_hip.h"
+#include "split.h"
+#include "tn.h"
+
+using namespace geossl;
+
+namespace {
+
+constexpr int TR = 32;  // rows per tile
+
+__device__ __forceinline__ void lds_barrier() {
+  // LDS traffic of this wave done, then the block barrier; no vmcnt wait (no global data is exchanged between waves)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int NW>
+struct NbLds {
+  static constexpr int F = 32 * NW, H = F / 2, KHS = (H + 15) / 16, HMB = (H + 31) / 32, KS = F / 16;
+  u32x4* zb;    // [2][KHS][3][64]      dz2 as A fragments (lane = row, 8 consecutive units), double buffered
+  u32x4* dz2T;  // [HMB][2][3][64]      dz2^T as A fragments (lane = unit of layer 2, rows in kperm order)
+  u32x4* fT;    // [2][NW][2][3][64]    (h_u + h_v)^T as B fragments (lane = feature, rows in kperm order)
+  u32x4* dz1r;  // [KS][3][64]          dz1 as B fragments (lane = row, units in kperm order)
+  u32x4* abT;   // [NW][2][3][64]       a1^T as B fragments (lane = unit of layer 1, rows in kperm order)
+  int4* scal;   // [3][TR]              {u, v, g, emb} of a tile's rows, ring of three tiles
+  float* dep;   // [NW][TR]             demb partial of every A wave
+  float* wls;   // [F]                  o1_w[:, F]
+  __device__ explicit NbLds(uint8_t* smem) {
+    zb = reinterpret_cast<u32x4*>(smem);
+    dz2T = zb + 2 * KHS * 3 * 64;
+    fT = dz2T + HMB * 2 * 3 * 64;
+    dz1r = fT + 2 * NW * 2 * 3 * 64;
+    abT = dz1r + KS * 3 * 64;
+    scal = reinterpret_cast<int4*>(abT + NW * 2 * 3 * 64);
+    dep = reinterpret_cast<float*>(scal + 3 * TR);
+    wls = dep + NW * TR;
+  }
+  static size_t bytes() {
+    return (size_t)(2 * KHS * 3 + HMB * 6 + 2 * NW * 6 + KS * 3 + NW * 6) * 1024 + 3 * TR * sizeof(int4) +
+           (size_t)(NW * TR + F) * sizeof(float);
+  }
+};
+
+struct NcsnFusedArgs {
+  const float* h;
+  const int64_t* sei0;
+  const int64_t* sei1;
+  int S;
+  GeosslNcsnWeights w;
+  GeosslNcsnSaved sv;
+  const int64_t* divisor;
+  float out_scale;
+  const float* gout;
+  float* dfeat;
+  float* demb;
+  float* grow;
+  float* pw1;  // [nblk][F][F]
+  float* pd1;  // [nblk][F]      emb column of o1_w
+  float* pb1;  // [nblk][F]
+  float* pw2;  // [nblk][H][F]
+  float* pb2;  // [nblk][H]
+};
+
+// base (uniform) + 32-bit byte offset: the load takes its base from scalar registers, no 64-bit address per request
+__device__ __forceinline__ float ldg_off(const float* base, uint32_t byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ u32x4 pack8(const f32x16& t, int s) {
+  u32x4 w;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w[q] = pk_bf16(t[8 * s + 2 * q], t[8 * s + 2 * q + 1]);
+  return w;
+}
+__device__ __forceinline__ const u32x4& piece(const Frag3& f, int pc) { return pc == 0 ? f.h : (pc == 1 ? f.m : f.l); }
+
+template <int NW, bool ROLE_A>
+__device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
+  using L_t = NbLds<NW>;
+  constexpr int F = L_t::F, H = L_t::H, KHS = L_t::KHS, HMB = L_t::HMB, KS = L_t::KS, NT = 128 * NW;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  const L_t L(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb = ROLE_A ? wave : wave - NW;  // this wave's 32-wide feature block
+  const int S = a.S;
+  const int ntiles = (S + TR - 1) / TR;
+  const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * per, t_end = min(ntiles, t_begin + per);
+  const float scale = a.out_scale * (a.gout != nullptr ? a.gout[0] : 1.0f) / (float)a.divisor[0];
+  const uint32_t col = 32 * nb + j;  // this lane's feature
+
+  // ---------------------------------------------------------------- per-role constant state
+  Frag3 wreg[ROLE_A ? KHS : KS];  // A: o2_w[:, col] as B fragments (k = unit of layer 2, natural order)
+                                   // B: o1_w[:, col] as A fragments (k = unit of layer 1, kperm order)
+  f32x16 accw1[ROLE_A ? NW : 1];   // A: dW1[32nb + reg][32kb + lane]
+  f32x16 accw2[ROLE_A ? 1 : HMB];  // B: dW2[32mb + reg][32nb + lane]
+  float bsum = 0.0f, dsum = 0.0f;  // A: db1 / emb column of its unit;  B: db2 of its unit
+  u32x4 ident[2];                  // selection matrices of the matrix-pipe transpositions (B operand)
+  float w3r[8];
+  if constexpr (ROLE_A) {
+#pragma unroll
+    for (int ks = 0; ks < KHS; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int m = 16 * ks + 8 * kh + e;
+        v[e] = m < H ? a.w.o2_w[(size_t)m * F + col] : 0.0f;
+      }
+      wreg[ks] = split8(v);
+    }
+#pragma unroll
+    for (int kb = 0; kb < NW; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accw1[kb][r] = 0.0f;
+    // dz1^T (lane = unit, k = row 16s + kperm(e, kh)) -> row on the lane: B[k][n = row'] = [16s + kperm(e, kh) == row']
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k0 = 16 * s + kperm(2 * q, kh), k1 = 16 * s + kperm(2 * q + 1, kh);
+        ident[s][q] = (k0 == j ? 0x3F80u : 0u) | (k1 == j ? 0x3F800000u : 0u);
+      }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = a.w.o1_w[(size_t)(16 * ks + kperm(e, kh)) * (F + 1) + col];
+      wreg[ks] = split8(v);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int m = 16 * nb + 8 * kh + e;  // k-step nb of the dz2 fragments is built by this wave
+      w3r[e] = (nb < KHS && m < H) ? a.w.o3_w[m] : 0.0f;
+    }
+#pragma unroll
+    for (int mb = 0; mb < HMB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accw2[mb][r] = 0.0f;
+    // dz2 (lane = row, k = unit 16q' + 8kh + e, natural order) -> unit on the lane: B[k][n] = [16q + 8kh + e == n]
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k0 = 16 * q2 + 8 * kh + 2 * q;
+        ident[q2][q] = (k0 == j ? 0x3F80u : 0u) | (k0 + 1 == j ? 0x3F800000u : 0u);
+      }
+  }
+  for (int i = tid; i < F; i += NT) L.wls[i] = a.w.o1_w[(size_t)i * (F + 1) + F];
+
+  // ---------------------------------------------------------------- request / build steps (see the header)
+  // A wave 0, lanes 0..31: the row scalars of tile tt
+  int sc_u = 0, sc_v = 0;
+  float sc_g = 0.0f, sc_e = 0.0f;
+  auto load_scal = [&](int tt) {
+    if constexpr (ROLE_A) {
+      if (wave == 0) {
+        const int row = min(TR * tt + j, S - 1);
+        sc_u = (int)a.sei0[row];
+        sc_v = (int)a.sei1[row];
+        sc_g = a.sv.gscale[row];
+        sc_e = a.sv.emb[row];
+      }
+    }
+  };
+  auto put_scal = [&](int tt) {
+    if constexpr (ROLE_A) {
+      if (wave == 0 && lane < TR) {
+        const int row = TR * tt + lane;
+        const bool valid = row < S && tt < t_end;
+        const float gr = valid ? pin(sc_g) * scale : 0.0f;
+        L.scal[(tt % 3) * TR + lane] = make_int4(sc_u, sc_v, __float_as_int(gr), __float_as_int(sc_e));
+        if (valid) a.grow[row] = gr;
+      }
+    }
+  };
+  // A: a1 of the tile in C-layout order (register r <-> row c_row(r)), this lane's unit
+  float a1raw[16];
+  auto request_a1 = [&](int tt) {
+    if constexpr (ROLE_A) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        a1raw[r] = ldg_off(a.sv.a1, ((uint32_t)min(TR * tt + c_row(r, lane), S - 1) * (uint32_t)F + col) * 4u);
+    }
+  };
+  // B: a2 of this lane's row, units 16nb + 8kh .. +8 (k-step nb of the dz2 fragments)
+  f32x4 a2raw[2];
+  auto request_a2 = [&](int tt) {
+    if constexpr (!ROLE_A) {
+      if (nb < KHS) {
+        const uint32_t off = ((uint32_t)min(TR * tt + j, S - 1) * (uint32_t)H + (16 * nb + 8 * kh)) * 4u;
+        a2raw[0] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.sv.a2) + off);
+        a2raw[1] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.sv.a2) + 16 + off);
+      }
+    }
+  };
+  // B: h[u][col], h[v][col] for the 16 rows of this lane (C-layout order)
+  float hu[16], hv[16];
+  auto request_gather = [&](int tt) {
+    if constexpr (!ROLE_A) {
+      const int2* sc = reinterpret_cast<const int2*>(L.scal + (tt % 3) * TR);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int2 uv = sc[2 * c_row(r, lane)];  // .x, .y of the int4 entry
+        hu[r] = ldg_off(a.h, ((uint32_t)uv.x * (uint32_t)F + col) * 4u);
+        hv[r] = ldg_off(a.h, ((uint32_t)uv.y * (uint32_t)F + col) * 4u);
+      }
+    }
+  };
+  auto build_zb = [&](int tt) {
+    if constexpr (!ROLE_A) {
+      if (nb < KHS) {
+        const float gr = __int_as_float(L.scal[(tt % 3) * TR + j].z);
+        const float av[8] = {a2raw[0].x, a2raw[0].y, a2raw[0].z, a2raw[0].w, a2raw[1].x, a2raw[1].y, a2raw[1].z, a2raw[1].w};
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = pin(av[e]) > 0.0f ? gr * w3r[e] : 0.0f;
+        const Frag3 f = split8(v);
+        u32x4* dst = L.zb + (size_t)(((tt & 1) * KHS + nb) * 3) * 64 + lane;
+        dst[0] = f.h;
+        dst[64] = f.m;
+        dst[128] = f.l;
+      }
+    }
+  };
+  auto build_fT = [&](int tt) {
+    if constexpr (!ROLE_A) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = pin(hu[8 * s + e]) + pin(hv[8 * s + e]);  // NCSN.py:201-203
+        const Frag3 f = split8(v);
+        u32x4* dst = L.fT + (size_t)((((tt & 1) * NW + nb) * 2 + s) * 3) * 64 + lane;
+        dst[0] = f.h;
+        dst[64] = f.m;
+        dst[128] = f.l;
+      }
+    }
+  };
+
+  // ---------------------------------------------------------------- prologue
+  if (t_begin < t_end) {
+    load_scal(t_begin);
+    put_scal(t_begin);
+    load_scal(t_begin + 1);
+    put_scal(t_begin + 1);
+    load_scal(t_begin + 2);  // written in phase 1 of the first tile
+    request_a1(t_begin);
+    request_a2(t_begin);
+    __syncthreads();
+    request_gather(t_begin);
+    build_zb(t_begin);
+    build_fT(t_begin);
+    request_a2(t_begin + 1);
+    request_gather(t_begin + 1);
+  }
+  for (int t = t_begin; t < t_end; ++t) {
+    const int buf = t & 1;
+    lds_barrier();  // X(t): fragments and scalars of tile t published; everything of tile t-1 consumed
+    // =============================================================== phase 1
+    if constexpr (ROLE_A) {
+      put_scal(t + 2);
+      // ---- dz1^T for this wave's units: rows on M
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+      {
+        const u32x4* zs = L.zb + (size_t)(buf * KHS * 3) * 64 + lane;
+        Frag3 a0, an;
+        a0.h = zs[0]; a0.m = zs[64]; a0.l = zs[128];
+#pragma unroll
+        for (int ks = 0; ks < KHS; ++ks) {
+          if (ks + 1 < KHS) {
+            const u32x4* s0 = zs + (size_t)((ks + 1) * 3) * 64;
+            an.h = s0[0]; an.m = s0[64]; an.l = s0[128];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mma6x2(acc0, acc1, a0, wreg[ks]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (ks + 1 < KHS) a0 = an;
+        }
+      }
+      float v[16];
+      {
+        const int4* sc = L.scal + (t % 3) * TR;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          a1raw[r] = pin(a1raw[r]);
+          v[r] = a1raw[r] > 0.0f ? acc0[r] + acc1[r] : 0.0f;  // rows past S: dz2 = 0 there
+          bsum += v[r];
+          dsum = fmaf(v[r], __int_as_float(sc[c_row(r, lane)].w), dsum);
+        }
+      }
+      // a1^T of this wave's units as B fragments of dW2's contraction over rows (multiplied by the B wave that owns
+      // these columns of dW2); the registers are then free for the next tile's request
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float vv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[e] = a1raw[8 * s + e];
+        const Frag3 f = split8(vv);
+        u32x4* dst = L.abT + (size_t)((nb * 2 + s) * 3) * 64 + lane;
+        dst[0] = f.h;
+        dst[64] = f.m;
+        dst[128] = f.l;
+      }
+      request_a1(t + 1);
+      Frag3 da[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float vv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[e] = v[8 * s + e];
+        da[s] = split8(vv);
+      }
+      // ---- the pieces of dz1 with the row on the lane (exact), published as B fragments; demb partial
+      {
+        float wl[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wl[r] = L.wls[32 * nb + c_row(r, lane)];
+        float de = 0.0f;
+#pragma unroll
+        for (int pc = 2; pc >= 0; --pc) {  // smallest piece first
+          f32x16 tp;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tp[r] = 0.0f;
+          tp = mfma_bf16(piece(da[0], pc), ident[0], tp);
+          tp = mfma_bf16(piece(da[1], pc), ident[1], tp);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) de = fmaf(tp[r], wl[r], de);
+#pragma unroll
+          for (int half = 0; half < 2; ++half)
+            L.dz1r[(size_t)((2 * nb + half) * 3 + pc) * 64 + lane] = pack8(tp, half);
+        }
+        de += __shfl_xor(de, 32, 64);
+        if (kh == 0) L.dep[nb * TR + j] = de;
+      }
+      // ---- dW1[this wave's units][all features] += dz1^T (h_u + h_v)
+#pragma unroll
+      for (int kb = 0; kb < NW; ++kb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const u32x4* s0 = L.fT + (size_t)(((buf * NW + kb) * 2 + s) * 3) * 64 + lane;
+          Frag3 bf;
+          bf.h = s0[0]; bf.m = s0[64]; bf.l = s0[128];
+          mma6(accw1[kb], da[s], bf);
+        }
+    } else {
+      // ---- dz2^T for unit block nb of layer 2 through the selection matrix; db2
+      if (nb < HMB) {
+#pragma unroll
+        for (int pc = 2; pc >= 0; --pc) {
+          f32x16 tp;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tp[r] = 0.0f;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            if (2 * nb + q < KHS) {
+              const u32x4* s0 = L.zb + (size_t)((buf * KHS + 2 * nb + q) * 3 + pc) * 64 + lane;
+              tp = mfma_bf16(s0[0], ident[q], tp);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) bsum += tp[r];
+#pragma unroll
+          for (int s = 0; s < 2; ++s) L.dz2T[(size_t)((nb * 2 + s) * 3 + pc) * 64 + lane] = pack8(tp, s);
+        }
+      }
+      // ---- next tile's fragments (their requests have been in flight since phase 2 of the previous tile)
+      build_zb(t + 1);
+      build_fT(t + 1);
+    }
+    lds_barrier();  // Y(t): dz1 fragments, dz2^T fragments, demb partials, scalars of tile t+2 published
+    // =============================================================== phase 2
+    if constexpr (ROLE_A) {
+      load_scal(t + 3);
+    } else {
+      request_a2(t + 2);
+      request_gather(t + 2);
+      // ---- dfeat^T for this wave's features: rows on N
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+      {
+        const u32x4* zs = L.dz1r + lane;
+        Frag3 b0, bn;
+        b0.h = zs[0]; b0.m = zs[64]; b0.l = zs[128];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          if (ks + 1 < KS) {
+            const u32x4* s0 = zs + (size_t)((ks + 1) * 3) * 64;
+            bn.h = s0[0]; bn.m = s0[64]; bn.l = s0[128];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mma6x2(acc0, acc1, wreg[ks], b0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (ks + 1 < KS) b0 = bn;
+        }
+      }
+      f32x16 outp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) outp[r] = acc0[r] + acc1[r];
+      const int row = TR * t + j;
+      if (row < S) {
+        const uint32_t off = ((uint32_t)row * (uint32_t)F + 32 * nb + 4 * kh) * 4u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.dfeat) + 32 * q + off) =
+              f32x4{outp[4 * q], outp[4 * q + 1], outp[4 * q + 2], outp[4 * q + 3]};
+        if (nb == 0 && kh == 0) {
+          float de = 0.0f;
+#pragma unroll
+          for (int n2 = 0; n2 < NW; ++n2) de += L.dep[n2 * TR + j];
+          a.demb[row] = de;
+        }
+      }
+      // ---- dW2[all units of layer 2][this wave's columns] += dz2^T a1
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const u32x4* sb = L.abT + (size_t)((nb * 2 + s) * 3) * 64 + lane;
+        Frag3 bf;
+        bf.h = sb[0]; bf.m = sb[64]; bf.l = sb[128];
+#pragma unroll
+        for (int mb = 0; mb < HMB; ++mb) {
+          const u32x4* s0 = L.dz2T + (size_t)((mb * 2 + s) * 3) * 64 + lane;
+          Frag3 af;
+          af.h = s0[0]; af.m = s0[64]; af.l = s0[128];
+          mma6(accw2[mb], af, bf);
+        }
+      }
+    }
+  }
+  // ---------------------------------------------------------------- one partial per block
+  const size_t pb = blockIdx.x;
+  if constexpr (ROLE_A) {
+    float* P1 = a.pw1 + pb * F * F;
+#pragma unroll
+    for (int kb = 0; kb < NW; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) P1[(size_t)(32 * nb + c_row(r, lane)) * F + 32 * kb + j] = accw1[kb][r];
+    const float sb = bsum + __shfl_xor(bsum, 32, 64), sd = dsum + __shfl_xor(dsum, 32, 64);
+    if (kh == 0) {
+      a.pb1[pb * F + col] = sb;
+      a.pd1[pb * F + col] = sd;
+    }
+  } else {
+    float* P2 = a.pw2 + pb * H * F;
+#pragma unroll
+    for (int mb = 0; mb < HMB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * mb + c_row(r, lane);
+        if (m < H) P2[(size_t)m * F + col] = accw2[mb][r];
+      }
+    const float sb = bsum + __shfl_xor(bsum, 32, 64);
+    if (nb < HMB && kh == 0 && (int)col < H) a.pb2[pb * H + col] = sb;
+  }
+}
+
+// The two roles are separate instantiations of the body (different register sets); the branch is wave-uniform and
+// both sides execute the same barriers.
+template <int NW>
+__global__ __launch_bounds__(128 * NW) void k_ncsn_bwd_fused(NcsnFusedArgs a) {
+  if ((int)(threadIdx.x >> 6) < NW) ncsn_bwd_body<NW, true>(a);
+  else ncsn_bwd_body<NW, false>(a);
+}
+
+inline int fused_blocks(int64_t S) {
+  const int64_t ntiles = (S + TR - 1) / TR;
+  return (int)(ntiles < 256 ? ntiles : 256);  // one block per CU
+}
+
+}  // namespace
+
+extern "C" int64_t geossl_ddm_loss_bwd_fused_workspace_floats(int64_t S, int F) {
+  const int64_t nb = fused_blocks(S), H = F / 2;
+  return nb * ((int64_t)F * F + 2 * F + H * F + H);
+}
+
+extern "C" int geossl_ddm_loss_bwd_fused(const float* h, const int64_t* sei0, const int64_t* sei1, int64_t S, int64_t N,
+                                         int F, const GeosslNcsnWeights* w, const GeosslNcsnSaved* saved,
+                                         const int64_t* stats_divisor, float out_scale, const float* gout, float* dfeat,
+                                         float* demb, float* grow, const GeosslNcsnGrads* grads, float* workspace,
+                                         int accumulate, hipStream_t stream) {
+  if (S <= 0) return 0;
+  if (F != 32 && F != 64 && F != 128) return (int)hipErrorInvalidValue;
+  // 32-bit byte offsets inside the kernel
+  if (S * (int64_t)F * 4 >= ((int64_t)1 << 32) || N * (int64_t)F * 4 >= ((int64_t)1 << 32)) return (int)hipErrorInvalidValue;
+  const int nb = fused_blocks(S), H = F / 2;
+  NcsnFusedArgs a;
+  a.h = h; a.sei0 = sei0; a.sei1 = sei1; a.S = (int)S; a.w = *w; a.sv = *saved; a.divisor = stats_divisor;
+  a.out_scale = out_scale; a.gout = gout; a.dfeat = dfeat; a.demb = demb; a.grow = grow;
+  a.pw1 = workspace;
+  a.pd1 = a.pw1 + (size_t)nb * F * F;
+  a.pb1 = a.pd1 + (size_t)nb * F;
+  a.pw2 = a.pb1 + (size_t)nb * F;
+  a.pb2 = a.pw2 + (size_t)nb * H * F;
+#define LAUNCH(NWV)                                                                                      \
+  do {                                                                                                   \
+    allow_big_lds(&k_ncsn_bwd_fused<NWV>);                                                               \
+    hipLaunchKernelGGL((k_ncsn_bwd_fused<NWV>), dim3(nb), dim3(128 * NWV), NbLds<NWV>::bytes(), stream, a); \
+  } while (0)
+  if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
+#undef LAUNCH
+  GEOSSL_CHECK_LAUNCH();
+  ReduceMulti rm;  // the five fixed-order partial sums in one launch
+  float* o1w[1] = {grads->o1_w};
+  float* o1c[1] = {grads->o1_w + F};
+  float* o1b[1] = {grads->o1_b};
+  float* o2w[1] = {grads->o2_w};
+  float* o2b[1] = {grads->o2_b};
+  rm.add(a.pw1, F * F, F, F + 1, 1, o1w, 1);
+  rm.add(a.pd1, F, F, F, F + 1, o1c, 1);
+  rm.add(a.pb1, F, F, F, 1, o1b, 1);
+  rm.add(a.pw2, H * F, F, F, 1, o2w, 1);
+  rm.add(a.pb2, H, H, H, 1, o2b, 1);
+  hipLaunchKernelGGL(k_reduce_multi, dim3(rm.blocks(), 1), dim3(256), 0, stream, rm, nb, accumulate);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}

@@ -20,8 +20,8 @@ struct ReduceSeg {
 };
 struct ReduceMulti {
   int nseg;
-  int xoff[5];
-  ReduceSeg seg[4];
+  int xoff[7];
+  ReduceSeg seg[6];
   ReduceMulti() : nseg(0) { xoff[0] = 0; }
   void add(const float* partial, int len, int ncols, int ld, int cstride, float* const* out, int nz) {
     ReduceSeg& g = seg[nseg];

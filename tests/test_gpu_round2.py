@@ -588,3 +588,58 @@ def test_standalone_mlp_module_matches_torch():
         assert rel_err(x.grad, xr.grad) < 1e-5
         for l, (w, b_) in zip(mlp.layers, ws):
             assert rel_err(l.weight.grad, w.grad) < 1e-5 and rel_err(l.bias.grad, b_.grad) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,nmol", [(128, 40), (64, 23), (32, 9), (128, 700)])
+def test_ncsn_one_pass_backward_matches_two_pass_and_fp64(F, nmol, monkeypatch):
+    """ncsn_bwd.hip (row gradients + weight gradients of both dense layers in one pass) against the two-pass form
+    (ncsn_rows.hip + the column GEMMs of wgrad.h) on the same inputs, and against an fp64 evaluation of the oracle.
+    Ragged molecules, S not a multiple of the 32-row tile; 700 molecules give every block several tiles."""
+    from oracle import nets
+    from geossl_amd.Geom3D.dataloaders.dataloaders_AtomTuple import BatchAtomTuple
+    gen = torch.Generator().manual_seed(1234 + F + nmol)
+    sizes = torch.randint(2, 27, (nmol,), generator=gen).tolist()
+    N = sum(sizes)
+    K, power = 30, 2.0
+    x = torch.randint(0, 9, (N, 1), generator=gen)
+    pos = torch.randn(N, 3, generator=gen)
+    data = BatchAtomTuple.from_sizes(x.to(DEV), pos.to(DEV), sizes, option="combination")
+    sei = data.super_edge_index.cpu()
+    S = sei.size(1)
+    assert S % 32 != 0
+    h = torch.randn(N, F, generator=gen) * 0.5
+    dist = (pos[sei[0]] - pos[sei[1]]).norm(dim=-1, keepdim=True)
+    nl = torch.randint(0, K, (nmol,), generator=gen)
+    dn = torch.randn(S, 1, generator=gen)
+    P64 = {k: v.detach().double().requires_grad_(v.requires_grad) for k, v in ncsn_oracle_params(F, K).items()}
+    batch = data.batch.cpu()
+    # a relu unit within fp32 rounding of zero makes fp32 and fp64 evaluations differ by a finite amount in that row
+    well_conditioned = nets.ncsn_relu_margin(P64, batch, sei, h.double(), dist.double(), nl, dn.double()) > 1e-6
+    h64 = h.double().requires_grad_()
+    nets.ncsn_v03_forward(P64, batch, sei, h64, dist.double(), nl, dn.double(), power).backward()
+
+    def run(split):
+        if split:
+            monkeypatch.setenv("GEOSSL_NCSN_SPLIT_BWD", "1")
+        else:
+            monkeypatch.delenv("GEOSSL_NCSN_SPLIT_BWD", raising=False)
+        head = product_ncsn(F, K, power, DEV)
+        hh = h.to(DEV).clone().requires_grad_()
+        loss = head(data, hh, dist.to(DEV), noise_level=nl.to(DEV), distance_noise=dn.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+        out = {k: v.detach().cpu() for k, v in unique_named_grads(head).items()}
+        out["h"] = hh.grad.cpu()
+        return out
+
+    one, two = run(False), run(True)
+    truth = {k: P64[k].grad for k in one if k != "h"}
+    truth["h"] = h64.grad
+    for k in one:
+        assert rel_err(one[k], two[k]) < 2e-6, (k, rel_err(one[k], two[k]))
+        if well_conditioned:
+            assert rel_err(one[k], truth[k]) < 1e-5, (k, rel_err(one[k], truth[k]))
+    again = run(False)
+    for k in one:
+        assert torch.equal(one[k], again[k]), k  # fixed-order reductions: bit-reproducible
