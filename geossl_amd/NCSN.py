@@ -65,7 +65,8 @@ def _head_params(m):
 
 _FIELDS = ("in_w1", "in_b1", "in_w2", "in_b2", "o1_w", "o1_b", "o2_w", "o2_b", "o3_w", "o3_b")
 
-# Optional side stream for the head's weight-gradient kernels.  They depend only on the row pass of the head, while
+# Optional side stream for the head's weight-gradient kernels in the two-pass form (GEOSSL_NCSN_SPLIT_BWD; the default
+# one-pass backward has no separate weight-gradient kernels).  They depend only on the row pass of the head, while
 # the backbone's backward (a chain of small, latency-bound launches) needs nothing but dh: with a side stream set
 # (DDMTrainer does, and joins it before the optimiser step) the two run concurrently.  Off by default: a caller that
 # runs its own optimiser right after loss.backward() must see every gradient on the current stream.
@@ -141,7 +142,7 @@ class _NcsnLoss(torch.autograd.Function):
         acc = 1 if direct else 0
         split = os.environ.get("GEOSSL_NCSN_SPLIT_BWD") is not None  # the two-pass form (row pass, then column GEMMs)
         if not split:
-            # one pass over the rows: dfeat / demb / grow and the gradients of both dense layers (ncsn_bwd.hip)
+            # one pass over the rows: dfeat / demb / grow and every weight gradient of the head (ncsn_bwd.hip)
             ws1 = torch.empty(int(lib.geossl_ddm_loss_bwd_fused_workspace_floats(S, Fd)), dtype=torch.float32, device=dev)
             call("geossl_ddm_loss_bwd_fused", ptr(h), ptr(sel.sei0), ptr(sel.sei1), S, N, Fd, C.byref(w), C.byref(sv),
                  ptr(sel.stats), ctx.out_scale, ptr(gout), ptr(dfeat), ptr(demb), ptr(grow), C.byref(g), ptr(ws1), acc, st)
@@ -154,31 +155,25 @@ class _NcsnLoss(torch.autograd.Function):
         if ctx.needs_input_grad[0]:  # first: the backbone's backward waits for nothing else
             dh = torch.empty(N, Fd, dtype=torch.float32, device=dev)
             call("geossl_incidence_gather", ptr(dfeat), ptr(sel.inc_ptr), ptr(sel.inc_idx), N, Fd, ptr(dh), 0, st)
-        nfl = lib.geossl_ddm_loss_bwd_workspace_floats(S, Fd)
-
-        def rest(stream_handle):  # what is left of the weight gradients after the row pass
-            ws = torch.empty(nfl, dtype=torch.float32, device=dev)
-            if split:
+        if split:
+            nfl = lib.geossl_ddm_loss_bwd_workspace_floats(S, Fd)
+            side = _SIDE["stream"] if direct else None
+            if side is None:
+                ws = torch.empty(nfl, dtype=torch.float32, device=dev)
                 call("geossl_ddm_loss_bwd_weights", ptr(h), ptr(sel.sei0), ptr(sel.sei1), S, Fd, C.byref(w), C.byref(sv),
-                     ptr(dz1), ptr(demb), ptr(grow), C.byref(g), ptr(ws), acc, stream_handle)
+                     ptr(dz1), ptr(demb), ptr(grow), C.byref(g), ptr(ws), acc, st)
             else:
-                call("geossl_ddm_loss_bwd_small", S, Fd, C.byref(w), C.byref(sv), ptr(demb), ptr(grow), C.byref(g),
-                     ptr(ws), acc, stream_handle)
-            return ws
-
-        side = _SIDE["stream"] if direct else None
-        if side is None:
-            rest(st)
-        else:
-            main = torch.cuda.current_stream()
-            fork = torch.cuda.Event()
-            fork.record(main)
-            side.wait_event(fork)
-            with torch.cuda.stream(side):
-                ws = rest(stream())
-                done = torch.cuda.Event()
-                done.record(side)
-            _SIDE["pending"].append((done, (h, saved, dz1, demb, grow, ws, w, sv, ps, grads)))
+                main = torch.cuda.current_stream()
+                fork = torch.cuda.Event()
+                fork.record(main)
+                side.wait_event(fork)
+                with torch.cuda.stream(side):
+                    ws = torch.empty(nfl, dtype=torch.float32, device=dev)
+                    call("geossl_ddm_loss_bwd_weights", ptr(h), ptr(sel.sei0), ptr(sel.sei1), S, Fd, C.byref(w),
+                         C.byref(sv), ptr(dz1), ptr(demb), ptr(grow), C.byref(g), ptr(ws), 1, stream())
+                    done = torch.cuda.Event()
+                    done.record(side)
+                _SIDE["pending"].append((done, (h, saved, dz1, demb, grow, ws, w, sv, ps, grads)))
         if direct:
             return (dh, None, None, None, None, None, None, None) + (None,) * len(grads)
         return (dh, None, None, None, None, None, None, None) + tuple(grads)

@@ -120,7 +120,6 @@ PROTOTYPES = {
     "geossl_ddm_loss_bwd_fused_workspace_floats": (i64, [i64, i32]),
     "geossl_ddm_loss_bwd_fused": (i32, [vp, vp, vp, i64, i64, i32, P(NcsnWeights), P(NcsnSaved), vp, f32, vp, vp, vp, vp,
                                         P(NcsnGrads), vp, i32, vp]),
-    "geossl_ddm_loss_bwd_small": (i32, [i64, i32, P(NcsnWeights), P(NcsnSaved), vp, vp, P(NcsnGrads), vp, i32, vp]),
     "geossl_incidence_gather": (i32, [vp, vp, vp, i64, i32, vp, i32, vp]),
     "geossl_painn_edge_geom": (i32, [vp, vp, vp, i64, f32, vp, vp, i32, vp, vp, vp, vp]),
     "geossl_silu_fwd": (i32, [vp, i64, vp, vp]),

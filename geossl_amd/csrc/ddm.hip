@@ -271,6 +271,11 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
 
 }  // namespace
 
+namespace geossl {
+int launch_ncsn_small_reduce(const float* partial, int nblk, int F, const GeosslNcsnGrads& g, int accumulate,
+                             hipStream_t stream);
+}
+
 extern "C" int64_t geossl_loss_reduce_workspace_floats(int64_t S) { return GEOSSL_LOSS_BLOCKS; }
 
 extern "C" int geossl_loss_reduce(const float* loss_e, int64_t S, const int64_t* stats_divisor, float out_scale,
@@ -324,24 +329,22 @@ extern "C" int geossl_ddm_loss_bwd_weights(const float* h, const int64_t* sei0, 
   else if (F == 64) rc = launch_wgrad_split<2, 2>(l1, 1, S, F, F, o, F + 1, F + 1, workspace, accumulate, stream);
   else rc = launch_wgrad_split<1, 1>(l1, 1, S, F, F, o, F + 1, F + 1, workspace, accumulate, stream);
   if (rc) return rc;
-  return geossl_ddm_loss_bwd_small(S, F, w, saved, demb, grow, grads, workspace, accumulate, stream);
-}
-
-// the narrow gradients: output_mlp.layers.2 (weight [1][F/2], bias) and the 1 -> F -> 1 distance embedding MLP
-extern "C" int geossl_ddm_loss_bwd_small(int64_t S, int F, const GeosslNcsnWeights* w, const GeosslNcsnSaved* saved,
-                                         const float* demb, const float* grow, const GeosslNcsnGrads* grads,
-                                         float* workspace, int accumulate, hipStream_t stream) {
-  if (S <= 0) return 0;
   int chunk, nblk;
   small_plan(S, &chunk, &nblk);
   hipLaunchKernelGGL(k_ncsn_small_partial, dim3(nblk), dim3(128), 0, stream, *w, *saved, grow, demb, (int)S, F, chunk,
                      workspace);
   GEOSSL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_ncsn_small_reduce, dim3(F / 2 + 3 * F + 2), dim3(64), 0, stream, workspace, nblk, F, *grads,
-                     accumulate);
+  return launch_ncsn_small_reduce(workspace, nblk, F, *grads, accumulate, stream);
+}
+
+namespace geossl {
+int launch_ncsn_small_reduce(const float* partial, int nblk, int F, const GeosslNcsnGrads& g, int accumulate,
+                             hipStream_t stream) {
+  hipLaunchKernelGGL(k_ncsn_small_reduce, dim3(F / 2 + 3 * F + 2), dim3(64), 0, stream, partial, nblk, F, g, accumulate);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
+}  // namespace geossl
 
 extern "C" int geossl_incidence_gather(const float* dfeat, const int64_t* inc_ptr, const int32_t* inc_idx, int64_t N,
                                        int F, float* dh, int accumulate, hipStream_t stream) {

@@ -28,6 +28,9 @@
 // phase 1 is MFMA work of the A waves (78 per tile at F = 128) while the B waves build the next tile, phase 2 is
 // MFMA work of the B waves (48) and the A waves' dW2 (24).  Per SIMD and tile 156 MFMAs, the same as the two separate
 // passes together - but one read of a1 / a2 and no dz1 in HBM at all.
+// The narrow gradients (output_mlp.layers.2 and the 1 -> F -> 1 distance embedding) are per-unit sums over the rows of
+// quantities the tile already holds (g, demb, the perturbed distance; a2 again with the unit on the lane): VALU work of
+// the A waves in phase 2, where they have no MFMAs.
 // One partial per block for every weight gradient, summed in block order by k_reduce_multi (no atomics).
 #include "common.h"
 #include "geossl_hip.h"
@@ -35,6 +38,12 @@
 #include "tn.h"
 
 using namespace geossl;
+
+namespace geossl {
+// ddm.hip: sums the [nblk][H + 3F + 2] partials of the narrow gradients into o3_w, in_w2, in_w1, in_b1, o3_b, in_b2
+int launch_ncsn_small_reduce(const float* partial, int nblk, int F, const GeosslNcsnGrads& g, int accumulate,
+                             hipStream_t stream);
+}
 
 namespace {
 
@@ -54,7 +63,8 @@ struct NbLds {
   u32x4* dz1r;  // [KS][3][64]          dz1 as B fragments (lane = row, units in kperm order)
   u32x4* abT;   // [NW][2][3][64]       a1^T as B fragments (lane = unit of layer 1, rows in kperm order)
   int4* scal;   // [3][TR]              {u, v, g, emb} of a tile's rows, ring of three tiles
-  float* dep;   // [NW][TR]             demb partial of every A wave
+  float* pdv;   // [3][TR]              perturbed distance of the rows, same ring
+  float* dep;   // [TR][NW]             demb partial of every A wave
   float* wls;   // [F]                  o1_w[:, F]
   __device__ explicit NbLds(uint8_t* smem) {
     zb = reinterpret_cast<u32x4*>(smem);
@@ -63,12 +73,13 @@ struct NbLds {
     dz1r = fT + 2 * NW * 2 * 3 * 64;
     abT = dz1r + KS * 3 * 64;
     scal = reinterpret_cast<int4*>(abT + NW * 2 * 3 * 64);
-    dep = reinterpret_cast<float*>(scal + 3 * TR);
+    pdv = reinterpret_cast<float*>(scal + 3 * TR);
+    dep = pdv + 3 * TR;
     wls = dep + NW * TR;
   }
   static size_t bytes() {
     return (size_t)(2 * KHS * 3 + HMB * 6 + 2 * NW * 6 + KS * 3 + NW * 6) * 1024 + 3 * TR * sizeof(int4) +
-           (size_t)(NW * TR + F) * sizeof(float);
+           (size_t)(3 * TR + NW * TR + F) * sizeof(float);
   }
 };
 
@@ -90,11 +101,20 @@ struct NcsnFusedArgs {
   float* pb1;  // [nblk][F]
   float* pw2;  // [nblk][H][F]
   float* pb2;  // [nblk][H]
+  float* psm;  // [nblk][H + 3F + 2]   o3_w, in_w2, in_w1, in_b1, o3_b, in_b2 (layout of k_ncsn_small_partial, ddm.hip)
 };
 
 // base (uniform) + 32-bit byte offset: the load takes its base from scalar registers, no 64-bit address per request
 __device__ __forceinline__ float ldg_off(const float* base, uint32_t byte_off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+// row of C-layout register r for a lane of half kh, with 4*kh passed in: inside the tile loop it is an opaque copy
+// (fresh per iteration), so the sixteen row indices and everything derived from them are recomputed where they are
+// used - one VALU instruction each - instead of being hoisted out of the loop and held in (spilled) registers
+__device__ __forceinline__ int crow4(int r, int k4) { return (r & 3) + 8 * (r >> 2) + k4; }
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
 }
 __device__ __forceinline__ u32x4 pack8(const f32x16& t, int s) {
   u32x4 w;
@@ -128,7 +148,14 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
   float bsum = 0.0f, dsum = 0.0f;  // A: db1 / emb column of its unit;  B: db2 of its unit
   u32x4 ident[2];                  // selection matrices of the matrix-pipe transpositions (B operand)
   float w3r[8];
+  // A: the narrow gradients of this lane's unit: output_mlp.layers.2.weight (units < H) and the 1 -> F -> 1 distance
+  // embedding (NCSN.py:197); wave A_0 also sums g and demb over the rows (layers.2.bias, input_distance_mlp bias 2)
+  float s_o3 = 0.0f, s_w2 = 0.0f, s_w1 = 0.0f, s_b1 = 0.0f, s_g = 0.0f, s_d = 0.0f;
+  float iw1 = 0.0f, ib1 = 0.0f, iw2 = 0.0f;
   if constexpr (ROLE_A) {
+    iw1 = a.w.in_w1[col];
+    ib1 = a.w.in_b1[col];
+    iw2 = a.w.in_w2[col];
 #pragma unroll
     for (int ks = 0; ks < KHS; ++ks) {
       float v[8];
@@ -182,7 +209,7 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
   // ---------------------------------------------------------------- request / build steps (see the header)
   // A wave 0, lanes 0..31: the row scalars of tile tt
   int sc_u = 0, sc_v = 0;
-  float sc_g = 0.0f, sc_e = 0.0f;
+  float sc_g = 0.0f, sc_e = 0.0f, sc_p = 0.0f;
   auto load_scal = [&](int tt) {
     if constexpr (ROLE_A) {
       if (wave == 0) {
@@ -191,6 +218,7 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
         sc_v = (int)a.sei1[row];
         sc_g = a.sv.gscale[row];
         sc_e = a.sv.emb[row];
+        sc_p = a.sv.pd[row];
       }
     }
   };
@@ -201,17 +229,29 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
         const bool valid = row < S && tt < t_end;
         const float gr = valid ? pin(sc_g) * scale : 0.0f;
         L.scal[(tt % 3) * TR + lane] = make_int4(sc_u, sc_v, __float_as_int(gr), __float_as_int(sc_e));
+        L.pdv[(tt % 3) * TR + lane] = sc_p;
         if (valid) a.grow[row] = gr;
       }
     }
   };
   // A: a1 of the tile in C-layout order (register r <-> row c_row(r)), this lane's unit
   float a1raw[16];
-  auto request_a1 = [&](int tt) {
+  auto request_a1 = [&](int tt, int k4) {
     if constexpr (ROLE_A) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        a1raw[r] = ldg_off(a.sv.a1, ((uint32_t)min(TR * tt + c_row(r, lane), S - 1) * (uint32_t)F + col) * 4u);
+        a1raw[r] = ldg_off(a.sv.a1, ((uint32_t)min(TR * tt + crow4(r, k4), S - 1) * (uint32_t)F + col) * 4u);
+    }
+  };
+  // A (units < H): a2 of this lane's unit for rows 16kh .. 16kh+15 of the tile (layers.2.weight gradient, phase 2)
+  float a2t[16];
+  auto request_a2t = [&](int tt, int k4) {
+    if constexpr (ROLE_A) {
+      if (nb < HMB) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          a2t[i] = ldg_off(a.sv.a2, ((uint32_t)min(TR * tt + 4 * k4 + i, S - 1) * (uint32_t)H + min(col, (uint32_t)(H - 1))) * 4u);
+      }
     }
   };
   // B: a2 of this lane's row, units 16nb + 8kh .. +8 (k-step nb of the dz2 fragments)
@@ -227,12 +267,12 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
   };
   // B: h[u][col], h[v][col] for the 16 rows of this lane (C-layout order)
   float hu[16], hv[16];
-  auto request_gather = [&](int tt) {
+  auto request_gather = [&](int tt, int k4) {
     if constexpr (!ROLE_A) {
       const int2* sc = reinterpret_cast<const int2*>(L.scal + (tt % 3) * TR);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int2 uv = sc[2 * c_row(r, lane)];  // .x, .y of the int4 entry
+        const int2 uv = sc[2 * crow4(r, k4)];  // .x, .y of the int4 entry
         hu[r] = ldg_off(a.h, ((uint32_t)uv.x * (uint32_t)F + col) * 4u);
         hv[r] = ldg_off(a.h, ((uint32_t)uv.y * (uint32_t)F + col) * 4u);
       }
@@ -277,17 +317,18 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
     load_scal(t_begin + 1);
     put_scal(t_begin + 1);
     load_scal(t_begin + 2);  // written in phase 1 of the first tile
-    request_a1(t_begin);
+    request_a1(t_begin, 4 * kh);
     request_a2(t_begin);
     __syncthreads();
-    request_gather(t_begin);
+    request_gather(t_begin, 4 * kh);
     build_zb(t_begin);
     build_fT(t_begin);
     request_a2(t_begin + 1);
-    request_gather(t_begin + 1);
+    request_gather(t_begin + 1, 4 * kh);
   }
   for (int t = t_begin; t < t_end; ++t) {
     const int buf = t & 1;
+    int k4 = opaque(4 * kh);
     lds_barrier();  // X(t): fragments and scalars of tile t published; everything of tile t-1 consumed
     // =============================================================== phase 1
     if constexpr (ROLE_A) {
@@ -320,7 +361,7 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
           a1raw[r] = pin(a1raw[r]);
           v[r] = a1raw[r] > 0.0f ? acc0[r] + acc1[r] : 0.0f;  // rows past S: dz2 = 0 there
           bsum += v[r];
-          dsum = fmaf(v[r], __int_as_float(sc[c_row(r, lane)].w), dsum);
+          dsum = fmaf(v[r], __int_as_float(sc[crow4(r, k4)].w), dsum);
         }
       }
       // a1^T of this wave's units as B fragments of dW2's contraction over rows (multiplied by the B wave that owns
@@ -336,7 +377,6 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
         dst[64] = f.m;
         dst[128] = f.l;
       }
-      request_a1(t + 1);
       Frag3 da[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -349,7 +389,7 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
       {
         float wl[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) wl[r] = L.wls[32 * nb + c_row(r, lane)];
+        for (int r = 0; r < 16; ++r) wl[r] = L.wls[32 * nb + crow4(r, k4)];
         float de = 0.0f;
 #pragma unroll
         for (int pc = 2; pc >= 0; --pc) {  // smallest piece first
@@ -365,7 +405,7 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
             L.dz1r[(size_t)((2 * nb + half) * 3 + pc) * 64 + lane] = pack8(tp, half);
         }
         de += __shfl_xor(de, 32, 64);
-        if (kh == 0) L.dep[nb * TR + j] = de;
+        if (kh == 0) L.dep[j * NW + nb] = de;
       }
       // ---- dW1[this wave's units][all features] += dz1^T (h_u + h_v)
 #pragma unroll
@@ -402,13 +442,41 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
       build_zb(t + 1);
       build_fT(t + 1);
     }
+    k4 = opaque(4 * kh);
     lds_barrier();  // Y(t): dz1 fragments, dz2^T fragments, demb partials, scalars of tile t+2 published
     // =============================================================== phase 2
     if constexpr (ROLE_A) {
+      // this phase has no matrix work for the A waves: their requests for the next tile go out here, and the narrow
+      // gradients' a2 column (consumed below, behind the B waves' MFMAs)
+      request_a1(t + 1, k4);
+      request_a2t(t, k4);
       load_scal(t + 3);
+      // ---- narrow gradients: this lane's unit, rows 16kh .. 16kh+15
+      {
+        const int4* sc = L.scal + (t % 3) * TR;
+        const float* pdr = L.pdv + (t % 3) * TR;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int rl = 4 * k4 + i;
+          float de = 0.0f;
+#pragma unroll
+          for (int n2 = 0; n2 < NW; ++n2) de += L.dep[rl * NW + n2];  // 0 for rows past S
+          const float pd = pdr[rl];
+          const float pre = fmaf(iw1, pd, ib1);
+          s_w2 = fmaf(de, fmaxf(pre, 0.0f), s_w2);
+          const float dp = pre > 0.0f ? de * iw2 : 0.0f;
+          s_w1 = fmaf(dp, pd, s_w1);
+          s_b1 += dp;
+          if (nb < HMB) s_o3 = fmaf(__int_as_float(sc[rl].z), pin(a2t[i]), s_o3);
+          if (wave == 0 && j == i) {  // lanes (i, kh) of wave A_0: one per row
+            s_g += __int_as_float(sc[rl].z);
+            s_d += de;
+          }
+        }
+      }
     } else {
       request_a2(t + 2);
-      request_gather(t + 2);
+      request_gather(t + 2, k4);
       // ---- dfeat^T for this wave's features: rows on N
       f32x16 acc0, acc1;
 #pragma unroll
@@ -442,7 +510,7 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
         if (nb == 0 && kh == 0) {
           float de = 0.0f;
 #pragma unroll
-          for (int n2 = 0; n2 < NW; ++n2) de += L.dep[n2 * TR + j];
+          for (int n2 = 0; n2 < NW; ++n2) de += L.dep[j * NW + n2];
           a.demb[row] = de;
         }
       }
@@ -475,6 +543,22 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
       a.pb1[pb * F + col] = sb;
       a.pd1[pb * F + col] = sd;
     }
+    float* Ps = a.psm + pb * (H + 3 * F + 2);
+    const float t_o3 = s_o3 + __shfl_xor(s_o3, 32, 64), t_w2 = s_w2 + __shfl_xor(s_w2, 32, 64);
+    const float t_w1 = s_w1 + __shfl_xor(s_w1, 32, 64), t_b1 = s_b1 + __shfl_xor(s_b1, 32, 64);
+    if (kh == 0) {
+      if (nb < HMB && (int)col < H) Ps[col] = t_o3;
+      Ps[H + col] = t_w2;
+      Ps[H + F + col] = t_w1;
+      Ps[H + 2 * F + col] = t_b1;
+    }
+    if (wave == 0) {
+      const float tg = wave_sum(s_g), td = wave_sum(s_d);
+      if (lane == 0) {
+        Ps[H + 3 * F] = tg;
+        Ps[H + 3 * F + 1] = td;
+      }
+    }
   } else {
     float* P2 = a.pw2 + pb * H * F;
 #pragma unroll
@@ -506,7 +590,7 @@ inline int fused_blocks(int64_t S) {
 
 extern "C" int64_t geossl_ddm_loss_bwd_fused_workspace_floats(int64_t S, int F) {
   const int64_t nb = fused_blocks(S), H = F / 2;
-  return nb * ((int64_t)F * F + 2 * F + H * F + H);
+  return nb * ((int64_t)F * F + 2 * F + H * F + H + (H + 3 * F + 2));
 }
 
 extern "C" int geossl_ddm_loss_bwd_fused(const float* h, const int64_t* sei0, const int64_t* sei1, int64_t S, int64_t N,
@@ -527,6 +611,7 @@ extern "C" int geossl_ddm_loss_bwd_fused(const float* h, const int64_t* sei0, co
   a.pb1 = a.pd1 + (size_t)nb * F;
   a.pw2 = a.pb1 + (size_t)nb * F;
   a.pb2 = a.pw2 + (size_t)nb * H * F;
+  a.psm = a.pb2 + (size_t)nb * H;
 #define LAUNCH(NWV)                                                                                      \
   do {                                                                                                   \
     allow_big_lds(&k_ncsn_bwd_fused<NWV>);                                                               \
@@ -548,5 +633,5 @@ extern "C" int geossl_ddm_loss_bwd_fused(const float* h, const int64_t* sei0, co
   rm.add(a.pb2, H, H, H, 1, o2b, 1);
   hipLaunchKernelGGL(k_reduce_multi, dim3(rm.blocks(), 1), dim3(256), 0, stream, rm, nb, accumulate);
   GEOSSL_CHECK_LAUNCH();
-  return 0;
+  return launch_ncsn_small_reduce(a.psm, nb, F, *grads, accumulate, stream);
 }

@@ -297,18 +297,14 @@ int geossl_ddm_loss_bwd_weights(const float* h, const int64_t* sei0, const int64
                                 const GeosslNcsnWeights* w, const GeosslNcsnSaved* saved, const float* dz1,
                                 const float* demb, const float* grow, const GeosslNcsnGrads* grads,
                                 float* workspace, int accumulate, hipStream_t stream);
-/* The same backward in one pass over the rows (ncsn_bwd.hip): row gradients dfeat / demb / grow AND the weight
- * gradients of output_mlp.layers.0 / .1 (o1_w, o1_b, o2_w, o2_b of `grads`; the other members are not touched),
- * nothing per-row re-read and no dz1 in HBM.  h [N][F] is the head's input (the rows are gathered again).  The narrow
- * gradients (o3_*, in_*) come from geossl_ddm_loss_bwd_small (workspace: geossl_ddm_loss_bwd_workspace_floats). */
+/* The same backward in one pass over the rows (ncsn_bwd.hip): row gradients dfeat / demb / grow AND every weight
+ * gradient of the head (all members of `grads`), nothing per-row re-read and no dz1 in HBM.  h [N][F] is the head's
+ * input (its rows are gathered again for the layers.0 weight gradient).                                        */
 int64_t geossl_ddm_loss_bwd_fused_workspace_floats(int64_t S, int F);
 int geossl_ddm_loss_bwd_fused(const float* h, const int64_t* sei0, const int64_t* sei1, int64_t S, int64_t N, int F,
                               const GeosslNcsnWeights* w, const GeosslNcsnSaved* saved, const int64_t* stats_divisor,
                               float out_scale, const float* gout, float* dfeat, float* demb, float* grow,
                               const GeosslNcsnGrads* grads, float* workspace, int accumulate, hipStream_t stream);
-int geossl_ddm_loss_bwd_small(int64_t S, int F, const GeosslNcsnWeights* w, const GeosslNcsnSaved* saved,
-                              const float* demb, const float* grow, const GeosslNcsnGrads* grads, float* workspace,
-                              int accumulate, hipStream_t stream);
 int geossl_incidence_gather(const float* dfeat, const int64_t* inc_ptr, const int32_t* inc_idx, int64_t N, int F,
                             float* dh, int accumulate, hipStream_t stream);
 
