@@ -29,8 +29,8 @@
 // MFMA work of the B waves (48) and the A waves' dW2 (24).  Per SIMD and tile 156 MFMAs, the same as the two separate
 // passes together - but one read of a1 / a2 and no dz1 in HBM at all.
 // The narrow gradients (output_mlp.layers.2 and the 1 -> F -> 1 distance embedding) are per-unit sums over the rows of
-// quantities the tile already holds (g, demb, the perturbed distance; a2 again with the unit on the lane): VALU work of
-// the A waves in phase 2, where they have no MFMAs.
+// quantities the tile already holds (g, demb, the perturbed distance): VALU work of the A waves in phase 2, where they
+// have no MFMAs; layers.2.weight accumulates in the B waves where they turn a2 into the dz2 fragments.
 // One partial per block for every weight gradient, summed in block order by k_reduce_multi (no atomics).
 #include "common.h"
 #include "geossl_hip.h"
@@ -148,9 +148,9 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
   float bsum = 0.0f, dsum = 0.0f;  // A: db1 / emb column of its unit;  B: db2 of its unit
   u32x4 ident[2];                  // selection matrices of the matrix-pipe transpositions (B operand)
   float w3r[8];
-  // A: the narrow gradients of this lane's unit: output_mlp.layers.2.weight (units < H) and the 1 -> F -> 1 distance
-  // embedding (NCSN.py:197); wave A_0 also sums g and demb over the rows (layers.2.bias, input_distance_mlp bias 2)
-  float s_o3 = 0.0f, s_w2 = 0.0f, s_w1 = 0.0f, s_b1 = 0.0f, s_g = 0.0f, s_d = 0.0f;
+  // A: the narrow gradients of this lane's unit of the 1 -> F -> 1 distance embedding (NCSN.py:197); wave A_0 also sums
+  // g and demb over the rows (layers.2.bias, input_distance_mlp bias 2)
+  float s_w2 = 0.0f, s_w1 = 0.0f, s_b1 = 0.0f, s_g = 0.0f, s_d = 0.0f;
   float iw1 = 0.0f, ib1 = 0.0f, iw2 = 0.0f;
   if constexpr (ROLE_A) {
     iw1 = a.w.in_w1[col];
@@ -243,19 +243,9 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
         a1raw[r] = ldg_off(a.sv.a1, ((uint32_t)min(TR * tt + crow4(r, k4), S - 1) * (uint32_t)F + col) * 4u);
     }
   };
-  // A (units < H): a2 of this lane's unit for rows 16kh .. 16kh+15 of the tile (layers.2.weight gradient, phase 2)
-  float a2t[16];
-  auto request_a2t = [&](int tt, int k4) {
-    if constexpr (ROLE_A) {
-      if (nb < HMB) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-          a2t[i] = ldg_off(a.sv.a2, ((uint32_t)min(TR * tt + 4 * k4 + i, S - 1) * (uint32_t)H + min(col, (uint32_t)(H - 1))) * 4u);
-      }
-    }
-  };
   // B: a2 of this lane's row, units 16nb + 8kh .. +8 (k-step nb of the dz2 fragments)
   f32x4 a2raw[2];
+  float o3acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   auto request_a2 = [&](int tt) {
     if constexpr (!ROLE_A) {
       if (nb < KHS) {
@@ -285,7 +275,11 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
         const float av[8] = {a2raw[0].x, a2raw[0].y, a2raw[0].z, a2raw[0].w, a2raw[1].x, a2raw[1].y, a2raw[1].z, a2raw[1].w};
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = pin(av[e]) > 0.0f ? gr * w3r[e] : 0.0f;
+        for (int e = 0; e < 8; ++e) {
+          const float a2v = pin(av[e]);
+          v[e] = a2v > 0.0f ? gr * w3r[e] : 0.0f;
+          o3acc[e] = fmaf(gr, a2v, o3acc[e]);  // layers.2.weight gradient of unit 16nb + 8kh + e, this lane's rows
+        }
         const Frag3 f = split8(v);
         u32x4* dst = L.zb + (size_t)(((tt & 1) * KHS + nb) * 3) * 64 + lane;
         dst[0] = f.h;
@@ -446,10 +440,8 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
     lds_barrier();  // Y(t): dz1 fragments, dz2^T fragments, demb partials, scalars of tile t+2 published
     // =============================================================== phase 2
     if constexpr (ROLE_A) {
-      // this phase has no matrix work for the A waves: their requests for the next tile go out here, and the narrow
-      // gradients' a2 column (consumed below, behind the B waves' MFMAs)
+      // this phase has no matrix work for the A waves: their requests for the next tile go out here
       request_a1(t + 1, k4);
-      request_a2t(t, k4);
       load_scal(t + 3);
       // ---- narrow gradients: this lane's unit, rows 16kh .. 16kh+15
       {
@@ -467,7 +459,6 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
           const float dp = pre > 0.0f ? de * iw2 : 0.0f;
           s_w1 = fmaf(dp, pd, s_w1);
           s_b1 += dp;
-          if (nb < HMB) s_o3 = fmaf(__int_as_float(sc[rl].z), pin(a2t[i]), s_o3);
           if (wave == 0 && j == i) {  // lanes (i, kh) of wave A_0: one per row
             s_g += __int_as_float(sc[rl].z);
             s_d += de;
@@ -544,10 +535,9 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
       a.pd1[pb * F + col] = sd;
     }
     float* Ps = a.psm + pb * (H + 3 * F + 2);
-    const float t_o3 = s_o3 + __shfl_xor(s_o3, 32, 64), t_w2 = s_w2 + __shfl_xor(s_w2, 32, 64);
+    const float t_w2 = s_w2 + __shfl_xor(s_w2, 32, 64);
     const float t_w1 = s_w1 + __shfl_xor(s_w1, 32, 64), t_b1 = s_b1 + __shfl_xor(s_b1, 32, 64);
     if (kh == 0) {
-      if (nb < HMB && (int)col < H) Ps[col] = t_o3;
       Ps[H + col] = t_w2;
       Ps[H + F + col] = t_w1;
       Ps[H + 2 * F + col] = t_b1;
@@ -570,6 +560,17 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
       }
     const float sb = bsum + __shfl_xor(bsum, 32, 64);
     if (nb < HMB && kh == 0 && (int)col < H) a.pb2[pb * H + col] = sb;
+    if (nb < KHS) {  // layers.2.weight: sum this half-wave's 32 rows
+      float* Ps = a.psm + pb * (H + 3 * F + 2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = o3acc[e];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        const int m = 16 * nb + 8 * kh + e;
+        if (j == 0 && m < H) Ps[m] = v;
+      }
+    }
   }
 }
 
