@@ -67,6 +67,13 @@ __device__ __forceinline__ float norm2_rn(float x, float y, float z) {
   return (xx + yy) + zz;
 }
 
+// Block barrier for kernels whose waves exchange data through LDS only: this wave's LDS traffic done, then s_barrier.
+// __syncthreads() also waits for every outstanding GLOBAL request of the wave (vmcnt(0), part of its fence), which
+// ends the flight of requests issued one tile ahead and makes the block wait for the acknowledgement of every store.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // ShiftedSoftplus (schnet.py:210-216): F.softplus(x) (beta 1, threshold 20) - fp32(log 2).

@@ -220,7 +220,8 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
   for (int t = t_begin; t < t_end; ++t) {
     const int r0 = t * TR;
     const int bsel = t & 1;
-    __syncthreads();  // previous tile fully consumed; this tile's staging buffer published
+    lds_barrier();  // previous tile fully consumed; this tile's staging buffer published (LDS only: the requests for the
+                    // tiles ahead stay in flight; measured neutral against __syncthreads here)
     const bool staged = L.flag(bsel)[0] != 0;
     // ---- tile build: every thread one dOr fragment lane; role A publishes its tf lanes, role B its rbf lanes
     auto build = [&](const float* xb, const float* db, int stride) {
@@ -286,7 +287,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
     float tcur[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) tcur[r] = tc[r];
-    __syncthreads();
+    lds_barrier();
     // While this tile is multiplied: publish the next tile's staging buffer (its atoms were requested one tile ago
     // and have arrived), request the atoms of the tile after it and the next tile's saved activations.
     if (t + 1 < t_end) {

@@ -49,11 +49,6 @@ namespace {
 
 constexpr int TR = 32;  // rows per tile
 
-__device__ __forceinline__ void lds_barrier() {
-  // LDS traffic of this wave done, then the block barrier; no vmcnt wait (no global data is exchanged between waves)
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 template <int NW>
 struct NbLds {
   static constexpr int F = 32 * NW, H = F / 2, KHS = (H + 15) / 16, HMB = (H + 31) / 32, KS = F / 16;
