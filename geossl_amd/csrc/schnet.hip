@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64) void k_aggregate(const float* __restrict__ x, c
 // on a clamped filter row with their flag bits clear (the flags of a row atom are ballot masks indexed by b): no
 // branches, so the filter-row requests run RING positions ahead of their use in one basic block.  Same summation
 // order as k_aggregate (separate multiply and add, ascending source per target): results are bit-identical.
-template <int NMAX>
+template <int NMAX, int RING_ = 0>
 __device__ __forceinline__ void aggregate_reg_body(const float* __restrict__ x, const float* __restrict__ Wf,
                                                    const uint8_t* __restrict__ pair_flag, int a0, int n, int base,
                                                    int lane, int f, int F, int swap, float* __restrict__ out) {
@@ -212,15 +212,17 @@ __device__ __forceinline__ void aggregate_reg_body(const float* __restrict__ x, 
   typedef f32x2 V;
   // filter rows in flight per wave: a wave's walk takes (positions / RING) memory round trips (~2 us each under load),
   // so the large classes - whose single wave bounds a ragged launch from below - get the deeper ring
-  constexpr int RING = NMAX > 26 ? 24 : (NMAX > 20 ? 20 : (NMAX > 18 ? 12 : 16));
+  constexpr int RING = RING_ > 0 ? RING_ : (NMAX > 26 ? 24 : (NMAX > 20 ? 20 : (NMAX > 18 ? 12 : 16)));
   constexpr int NPOS = NMAX * (NMAX - 1) / 2;            // positions of the unrolled walk
   // filter row of a slot = uniform base (scalar registers) + this lane's fixed column offset: the requests then use
   // the scalar-base addressing form and no per-request vector address is ever computed (or kept alive)
   const float* __restrict__ wbase = Wf + (size_t)base * F;
   // slot of position (a, b): a*n - a(a+1)/2 + b - a - 1; invalid positions read slot 0 of the molecule (n >= 2) or, for
   // a one-atom molecule, nothing at all
+  const bool has_cols = f >= 0;  // a lane without channels (F = 64: lanes 32..63) only serves the flag ballots
+  f = has_cols ? f : 0;
   if (n < 2) {
-    if (n == 1) *reinterpret_cast<V*>(out + (size_t)a0 * F + f) = V(0.0f);
+    if (n == 1 && has_cols) *reinterpret_cast<V*>(out + (size_t)a0 * F + f) = V(0.0f);
     return;
   }
   V xr[NMAX], acc[NMAX], ring[RING];
@@ -283,7 +285,119 @@ __device__ __forceinline__ void aggregate_reg_body(const float* __restrict__ x, 
   }
 #pragma unroll
   for (int i = 0; i < NMAX; ++i)
-    if (i < n) *reinterpret_cast<V*>(out + (size_t)(a0 + i) * F + f) = acc[i];
+    if (i < n && has_cols) *reinterpret_cast<V*>(out + (size_t)(a0 + i) * F + f) = acc[i];
+}
+
+// One TARGET GROUP of a large molecule: the walk of aggregate_reg_body restricted to the positions that touch a target
+// atom in [G0, G1) = part P of K equal parts of the size class - rows a < G0 only at their partners b in the group
+// (edge a -> b), rows a in the group at all their partners.  Every sum of a target is still formed by one wave in
+// the order of the full walk (positions are dropped, never reordered): results stay bit-identical.  K waves then share
+// a molecule whose single walk would outlast the launch (ragged batches: the 26..33-atom molecules), each with
+// 1 - (1 - 1/K)^2 of its filter rows (0.75 for K = 2, 0.44 for K = 4); with fewer accumulators the ring is deeper.
+template <int NMAX, int K, int P>
+__device__ __forceinline__ void aggregate_reg_part(const float* __restrict__ x, const float* __restrict__ Wf,
+                                                   const uint8_t* __restrict__ pair_flag, int a0, int n, int base,
+                                                   int lane, int f, int F, int swap, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  typedef f32x2 V;
+  constexpr int G0 = (P * NMAX) / K, G1 = ((P + 1) * NMAX) / K, NG = G1 - G0;
+  constexpr int AEND = G1 < NMAX - 1 ? G1 : NMAX - 1;     // rows a in [0, AEND) have positions
+  constexpr int RING = 40;
+  // positions of row a: partners b in [bs(a), be(a))
+#define AGG_BS(a) ((a) < G0 ? G0 : (a) + 1)
+#define AGG_BE(a) ((a) < G0 ? G1 : NMAX)
+  constexpr int NPOS = G0 * NG + (AEND - G0) * NMAX - ((AEND * (AEND + 1)) / 2 - (G0 * (G0 + 1)) / 2);
+  const bool has_cols = f >= 0;  // (as in aggregate_reg_body)
+  f = has_cols ? f : 0;
+  const float* __restrict__ wbase = Wf + (size_t)base * F;
+  V xr[NMAX], acc[NG], ring[RING];
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i) xr[i] = *reinterpret_cast<const V*>(x + (size_t)(a0 + min(i, n - 1)) * F + f);
+#pragma unroll
+  for (int i = 0; i < NG; ++i) acc[i] = V(0.0f);
+  auto slot_of = [&](int a, int b) { return b < n ? a * n - a * (a + 1) / 2 + b - a - 1 : 0; };
+  auto load_row = [&](int slot) {
+    const float* rowp = wbase + (size_t)__builtin_amdgcn_readfirstlane(slot) * F;  // uniform
+    return __builtin_nontemporal_load(reinterpret_cast<const V*>(rowp + f));
+  };
+  {  // prologue: the first RING positions
+    int ap = 0, bp = AGG_BS(0);
+#pragma unroll
+    for (int q = 0; q < RING && q < NPOS; ++q) {
+      ring[q] = load_row(slot_of(ap, bp));
+      if (++bp == AGG_BE(ap)) { ++ap; bp = AGG_BS(ap); }
+    }
+  }
+  int q = 0, ap = 0, bp = AGG_BS(0);
+#pragma unroll
+  for (int k = 0; k < RING && k < NPOS; ++k)
+    if (++bp == AGG_BE(ap)) { ++ap; bp = AGG_BS(ap); }    // (ap, bp) = position q + RING
+  // flags of row atom a as two ballot masks over the partner index b (as in aggregate_reg_body)
+  auto row_flags = [&](int a, unsigned long long& m0, unsigned long long& m1) {
+    const bool mine = lane > a && lane < n;
+    unsigned fl = pair_flag[base + (mine ? a * n - a * (a + 1) / 2 + lane - a - 1 : 0)];
+    asm volatile("" : "+v"(fl));
+    fl = mine ? fl : 0u;
+    if (swap) fl = ((fl & 1u) << 1) | ((fl >> 1) & 1u);
+    m0 = __builtin_amdgcn_ballot_w64((fl & 1u) != 0u);  // edge b -> a
+    m1 = __builtin_amdgcn_ballot_w64((fl & 2u) != 0u);  // edge a -> b
+  };
+  auto next_row = [&]() {  // filter row of position q, and the request for position q + RING
+    const V w = ring[q % RING];
+    if (q + RING < NPOS) {
+      ring[q % RING] = load_row(slot_of(ap, bp));
+      if (++bp == AGG_BE(ap)) { ++ap; bp = AGG_BS(ap); }
+    }
+    ++q;
+    return w;
+  };
+  // (two loop nests with plain bounds: the unroller needs the trip counts)
+  // ---- rows before the group: only the edges a -> b into the group's targets
+#pragma unroll
+  for (int a = 0; a < G0; ++a) {
+    unsigned long long m0, m1;
+    row_flags(a, m0, m1);
+    const V xa = xr[a];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int b = G0 + i;
+      const V w = next_row();
+      const V t1 = xa * w;
+      const V s1 = acc[i] + t1;
+      acc[i] = ((m1 >> b) & 1ull) ? s1 : acc[i];
+      asm volatile("" : "+v"(acc[i].x), "+v"(acc[i].y) : : "memory");  // keep the schedule as written (see above)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- rows of the group: target a from every partner b, and target b while b is in the group
+#pragma unroll
+  for (int a = G0; a < AEND; ++a) {
+    unsigned long long m0, m1;
+    row_flags(a, m0, m1);
+    V acc_a = acc[a - G0];
+    const V xa = xr[a];
+#pragma unroll
+    for (int b = a + 1; b < NMAX; ++b) {
+      const V w = next_row();
+      const V t0 = xr[b] * w;
+      const V s0 = acc_a + t0;
+      acc_a = ((m0 >> b) & 1ull) ? s0 : acc_a;
+      if (b < G1) {
+        const V t1 = xa * w;
+        const V s1 = acc[b - G0] + t1;
+        acc[b - G0] = ((m1 >> b) & 1ull) ? s1 : acc[b - G0];
+        asm volatile("" : "+v"(acc[b - G0].x), "+v"(acc[b - G0].y) : : "memory");
+      }
+      asm volatile("" : "+v"(acc_a.x), "+v"(acc_a.y) : : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    acc[a - G0] = acc_a;
+  }
+#undef AGG_BS
+#undef AGG_BE
+#pragma unroll
+  for (int i = 0; i < NG; ++i)
+    if (G0 + i < n && has_cols) *reinterpret_cast<V*>(out + (size_t)(a0 + G0 + i) * F + f) = acc[i];
 }
 
 // all molecules of the launch fit one size class (uniform batches: the best register allocation for that class)
@@ -294,8 +408,9 @@ __global__ __launch_bounds__(64, (NMAX <= 20 ? 4 : 3)) void k_aggregate_reg(
     int F, int swap, float* __restrict__ out) {
   if ((int)blockIdx.x >= B) return;
   const int m = order != nullptr ? order[blockIdx.x] : (int)blockIdx.x;
-  const int lane = threadIdx.x, f = 2 * lane;
-  if (f >= F) return;                                     // F = 128: all lanes; F = 64: half a wave (no barriers here)
+  const int lane = threadIdx.x, f = 2 * lane < F ? 2 * lane : -2;
+  // F = 64: lanes 32..63 own no channels but stay (lane b also reads the flag of partner b, b up to 32): they work on
+  // column 0 and store nothing
   const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m];
   aggregate_reg_body<NMAX>(x, Wf, pair_flag, a0, n, base, lane, f, F, swap, out);
 }
@@ -308,14 +423,69 @@ __global__ __launch_bounds__(64, 2) void k_aggregate_reg_ragged(
     int F, int swap, float* __restrict__ out) {
   if ((int)blockIdx.x >= B) return;
   const int m = order != nullptr ? order[blockIdx.x] : (int)blockIdx.x;
-  const int lane = threadIdx.x, f = 2 * lane;
-  if (f >= F) return;
+  const int lane = threadIdx.x, f = 2 * lane < F ? 2 * lane : -2;  // -2: no channels (see k_aggregate_reg)
   const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m];
   const int nu = __builtin_amdgcn_readfirstlane(n);
 #define AGG_CLASS(NM) if (nu <= NM) { aggregate_reg_body<NM>(x, Wf, pair_flag, a0, n, base, lane, f, F, swap, out); return; }
   AGG_CLASS(8) AGG_CLASS(12) AGG_CLASS(16) AGG_CLASS(18) AGG_CLASS(20) AGG_CLASS(22) AGG_CLASS(24) AGG_CLASS(26)
   AGG_CLASS(28) AGG_CLASS(30) AGG_CLASS(33)
 #undef AGG_CLASS
+}
+
+// ragged batches with a host-built work list (layout.py: MolLayout.agg_work): entry = molecule | part << 28, largest
+// molecules first.  Molecules of fewer than AGG_K2_MIN atoms are one work item (from 21 atoms on with a deep ring of
+// filter-row requests: the walk of a large molecule is a chain of memory round trips), AGG_K2_MIN .. AGG_K4_MIN-1 atoms
+// two target groups, more atoms four (geossl_aggregate_parts gives the same mapping to the host).
+#ifndef AGG_K2_MIN
+#define AGG_K2_MIN 27
+#endif
+#ifndef AGG_K4_MIN
+#define AGG_K4_MIN 31
+#endif
+#ifndef AGG_RING_BIG
+#define AGG_RING_BIG 40
+#endif
+// a size class above 20 atoms (molecules of LO .. NM atoms): whole, two or four target groups, by the molecule's size;
+// only the forms a class can meet are instantiated
+template <int NM>
+__device__ __forceinline__ void aggregate_big(const float* __restrict__ x, const float* __restrict__ Wf,
+                                              const uint8_t* __restrict__ pair_flag, int a0, int n, int base, int lane,
+                                              int f, int F, int swap, float* __restrict__ out, int kparts, int part) {
+  constexpr int LO = NM == 33 ? 31 : NM - 1;
+#define AGG_PART(KK, PP) aggregate_reg_part<NM, KK, PP>(x, Wf, pair_flag, a0, n, base, lane, f, F, swap, out)
+  if (kparts == 1) {
+    if constexpr (LO < AGG_K2_MIN)
+      aggregate_reg_body<NM, AGG_RING_BIG>(x, Wf, pair_flag, a0, n, base, lane, f, F, swap, out);
+  } else if (kparts == 2) {
+    if constexpr (NM >= AGG_K2_MIN && LO < AGG_K4_MIN) {
+      if (part == 0) AGG_PART(2, 0); else AGG_PART(2, 1);
+    }
+  } else {
+    if constexpr (NM >= AGG_K4_MIN) {
+      if (part == 0) AGG_PART(4, 0); else if (part == 1) AGG_PART(4, 1);
+      else if (part == 2) AGG_PART(4, 2); else AGG_PART(4, 3);
+    }
+  }
+#undef AGG_PART
+}
+
+__global__ __launch_bounds__(64, 2) void k_aggregate_reg_work(
+    const float* __restrict__ x, const float* __restrict__ Wf, const uint8_t* __restrict__ pair_flag,
+    const int32_t* __restrict__ mol_ptr, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ work,
+    int nwork, int F, int swap, float* __restrict__ out) {
+  if ((int)blockIdx.x >= nwork) return;
+  const int wk = work[blockIdx.x];
+  const int m = wk & 0x0FFFFFFF, part = __builtin_amdgcn_readfirstlane((wk >> 28) & 7);
+  const int lane = threadIdx.x, f = 2 * lane < F ? 2 * lane : -2;  // -2: no channels (see k_aggregate_reg)
+  const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m];
+  const int nu = __builtin_amdgcn_readfirstlane(n);
+  const int kparts = nu < AGG_K2_MIN ? 1 : (nu < AGG_K4_MIN ? 2 : 4);
+#define AGG_CLASS(NM) if (nu <= NM) { aggregate_reg_body<NM>(x, Wf, pair_flag, a0, n, base, lane, f, F, swap, out); return; }
+#define AGG_CLASS_BIG(NM) if (nu <= NM) { aggregate_big<NM>(x, Wf, pair_flag, a0, n, base, lane, f, F, swap, out, kparts, part); return; }
+  AGG_CLASS(8) AGG_CLASS(12) AGG_CLASS(16) AGG_CLASS(18) AGG_CLASS(20)
+  AGG_CLASS_BIG(22) AGG_CLASS_BIG(24) AGG_CLASS_BIG(26) AGG_CLASS_BIG(28) AGG_CLASS_BIG(30) AGG_CLASS_BIG(33)
+#undef AGG_CLASS
+#undef AGG_CLASS_BIG
 }
 
 // --------------------------------------------------------------------------------------------- embedding
@@ -460,6 +630,22 @@ extern "C" int geossl_pair_product(const float* a, const float* b, const int32_t
   if (F & 3) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(k_pair_product, dim3(grid1d(P * (F / 4), 256)), dim3(256), 0, stream, a, b, pair_i, pair_j,
                      pair_flag, P, F, swap, out);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_aggregate_parts(int n) {  // work items of an n-atom molecule in geossl_cfconv_aggregate_work
+  if (n < AGG_K2_MIN || n > 33) return 1;
+  return n < AGG_K4_MIN ? 2 : 4;
+}
+
+extern "C" int geossl_cfconv_aggregate_work(const float* x, const float* Wf, const uint8_t* pair_flag,
+                                            const int32_t* mol_ptr, const int32_t* pair_ptr, const int32_t* work,
+                                            int64_t nwork, int max_n, int F, int swap, float* out, hipStream_t stream) {
+  if (nwork <= 0) return 0;
+  if (max_n > 33 || F > 128 || F <= 32) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_aggregate_reg_work, dim3((unsigned)nwork), dim3(64), 0, stream, x, Wf, pair_flag, mol_ptr,
+                     pair_ptr, work, (int)nwork, F, swap, out);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

@@ -4,6 +4,9 @@ Host-side mirror of what the reference gets from ``BatchAtomTuple.from_data_list
 (Geom3D/dataloaders/dataloaders_AtomTuple.py:46-78): ``batch`` is sorted, index tensors carry
 node offsets, ``num_graphs = batch[-1] + 1``.
 """
+import os
+
+import numpy as np
 import torch
 
 from . import _lib
@@ -64,6 +67,18 @@ class MolLayout:
         if B > 1:
             nat = self.mol_ptr[1:] - self.mol_ptr[:-1]
             self.order = torch.argsort(nat, descending=True, stable=True).to(torch.int32)
+        # ragged batches built from host sizes: the work list of the aggregation (geossl_cfconv_aggregate_work), molecules
+        # by descending size, the 21..33-atom ones as 2 or 4 work items (one group of target atoms each)
+        self.agg_work = None
+        if sizes is not None and 20 < self.max_n <= 33 and not os.environ.get("GEOSSL_AGG_NO_SPLIT"):
+            n_host = np.asarray(sizes, dtype=np.int64)
+            idx = np.argsort(-n_host, kind="stable")
+            lib = _lib.load()
+            table = np.array([lib.geossl_aggregate_parts(k) for k in range(34)], dtype=np.int64)
+            parts = table[n_host][idx]
+            mol = np.repeat(idx, parts)
+            part = np.concatenate([np.arange(k) for k in parts]) if len(parts) else np.zeros(0, np.int64)
+            self.agg_work = torch.from_numpy((mol | (part << 28)).astype(np.int32)).to(dev)
         self.device = dev
         self._batch_version = batch._version
 

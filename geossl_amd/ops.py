@@ -203,6 +203,11 @@ def aggregate(x, Wf_l, pair_flag, layout, swap=False, out=None, mols=None):
     N, F = x.shape
     if out is None:
         out = torch.empty_like(x)
+    work = getattr(layout, "agg_work", None)
+    if mols is None and work is not None and 32 < F <= 128:
+        call("geossl_cfconv_aggregate_work", ptr(x), ptr(Wf_l), ptr(pair_flag), ptr(layout.mol_ptr), ptr(layout.pair_ptr),
+             ptr(work), work.numel(), layout.max_n, F, 1 if swap else 0, ptr(out), stream())
+        return out
     if mols is None:
         mp, pp, order, B = ptr(layout.mol_ptr), ptr(layout.pair_ptr), layout.order, layout.B
     else:

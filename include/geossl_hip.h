@@ -140,6 +140,14 @@ int geossl_pair_position_grad(const float* pos, const float* pair_d, const float
 int geossl_cfconv_aggregate(const float* x, const float* Wf, const uint8_t* pair_flag, const int32_t* mol_ptr,
                             const int32_t* pair_ptr, const int32_t* order, int64_t B, int max_n, int F, int swap,
                             float* out, hipStream_t stream);
+/* The same aggregation from a host-built work list (ragged batches): work[i] = molecule | part << 28, in launch order
+ * (largest molecules first).  A molecule of n atoms has geossl_aggregate_parts(n) entries (1, 2 or 4: the 21..33-atom
+ * molecules are shared by that many waves, one group of target atoms each - every sum is still formed by one wave
+ * in the order of geossl_cfconv_aggregate, bit for bit).  max_n <= 33, 32 < F <= 128.                          */
+int geossl_aggregate_parts(int n);
+int geossl_cfconv_aggregate_work(const float* x, const float* Wf, const uint8_t* pair_flag, const int32_t* mol_ptr,
+                                 const int32_t* pair_ptr, const int32_t* work, int64_t nwork, int max_n, int F,
+                                 int swap, float* out, hipStream_t stream);
 
 /* Gradient of geossl_cfconv_aggregate with respect to the filter rows, as a tensor:
  * out[p][c] = f0 a[i][c] b[j][c] + f1 a[j][c] b[i][c] for pair slot p = (i < j) with edge flags f0 (j -> i), f1 (i -> j)

@@ -643,3 +643,51 @@ def test_ncsn_one_pass_backward_matches_two_pass_and_fp64(F, nmol, monkeypatch):
     again = run(False)
     for k in one:
         assert torch.equal(one[k], again[k]), k  # fixed-order reductions: bit-reproducible
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F", [128, 64])
+def test_aggregate_work_list_splits_large_molecules_bit_exact(F, monkeypatch):
+    """Ragged batch with host sizes: the 21..33-atom molecules are shared by 2 or 4 waves (one group of target atoms
+    each, geossl_cfconv_aggregate_work).  Every sum is still formed in the reference's order (sequential index_add per
+    target in ascending source order, schnet.py:190,194-195): bit for bit equal to that evaluation and to the one-wave
+    walk of geossl_cfconv_aggregate."""
+    from geossl_amd import ops, _lib
+    from geossl_amd.layout import MolLayout
+    from geossl_amd.synthetic import make_batch
+    sizes = list(make_batch(40, seed=11, mode="B")["sizes"]) + [1, 2, 33, 27, 26, 21, 22, 28, 30, 3, 24, 31, 20, 32]
+    batch = torch.arange(len(sizes), device=DEV).repeat_interleave(torch.tensor(sizes, device=DEV))
+    lay = MolLayout(batch, len(sizes), sizes=sizes)
+    parts = [_lib.load().geossl_aggregate_parts(int(n)) for n in sizes]
+    assert lay.agg_work is not None and lay.agg_work.numel() == sum(parts) and max(parts) == 4 and 2 in parts
+    wk = lay.agg_work.cpu().numpy()
+    assert sorted((wk & 0x0FFFFFFF).tolist()) == sorted(m for m, k in enumerate(parts) for _ in range(k))
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(lay.N, F, device=DEV, generator=g)
+    W = torch.randn(lay.P, F, device=DEV, generator=g)
+    flag = torch.randint(0, 4, (lay.P,), device=DEV, generator=g, dtype=torch.uint8)
+    xn, Wn, fn = x.cpu().numpy(), W.cpu().numpy(), flag.cpu().numpy()
+    pi, pj = lay.pair_i.cpu().numpy(), lay.pair_j.cpu().numpy()
+    monkeypatch.setenv("GEOSSL_AGG_NO_SPLIT", "1")
+    lay_one = MolLayout(batch, len(sizes), sizes=sizes)
+    assert lay_one.agg_work is None
+    for swap in (False, True):
+        out_t = ops.aggregate(x, W, flag, lay, swap=swap)
+        assert torch.equal(out_t, ops.aggregate(x, W, flag, lay_one, swap=swap))
+        out = out_t.cpu().numpy()
+        contrib = {}
+        for p in range(lay.P):
+            i, j, fl = int(pi[p]), int(pj[p]), int(fn[p])
+            if swap:
+                fl = ((fl & 1) << 1) | ((fl >> 1) & 1)
+            if fl & 1:
+                contrib.setdefault(i, []).append((j, p))
+            if fl & 2:
+                contrib.setdefault(j, []).append((i, p))
+        ref = np.zeros_like(xn)
+        for tgt, lst in contrib.items():
+            acc = np.zeros(F, dtype=np.float32)
+            for src, p in sorted(lst):
+                acc = (acc + (xn[src] * Wn[p]).astype(np.float32)).astype(np.float32)
+            ref[tgt] = acc
+        assert np.array_equal(out, ref), swap

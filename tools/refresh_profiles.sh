@@ -10,7 +10,6 @@ round=${1:-r02}; tag=${2:-vX}; head=${3:-unknown}
 out=gpurun_out/refresh_$tag
 mkdir -p "$out" profiles
 export TMPDIR=/tmp
-python bench.py | tail -1 > profiles/${round}_bench_${tag}.json
 rocprofv3 --kernel-trace -d "$out/trace" -o t -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
 { echo "# rocprofv3 --kernel-trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline, summarised by tools/rocpd_stats.py"
   python tools/rocpd_stats.py "$(ls "$out"/trace/*.db | head -1)" 60; } > profiles/${round}_bench_${tag}_kernel_stats.txt
@@ -18,4 +17,6 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_f" -o
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_w" -o w -- python3 tools/prof_step.py 4 > /dev/null 2>&1
 python tools/pmc_traffic.py "$out/pmc_f/f_counter_collection.csv" "$out/pmc_w/w_counter_collection.csv" 4 1024 \
   "schnet/ddm-step/mols=1024/set=A/cutoff=5" "$head" > profiles/${round}_hbm_traffic_pmc.json
+# the bench line last: its roofline.traffic is read from the PMC file written above (same build)
+python bench.py | tail -1 > profiles/${round}_bench_${tag}.json
 echo "wrote profiles/${round}_bench_${tag}.json, ${round}_bench_${tag}_kernel_stats.txt, ${round}_hbm_traffic_pmc.json"
