@@ -38,9 +38,13 @@ __global__ __launch_bounds__(256) void k_sum_partial(const float* __restrict__ x
 }
 __global__ void k_loss_final(const float* __restrict__ partial, int nblk, const int64_t* __restrict__ divisor,
                              float out_scale, float* __restrict__ loss, int accumulate) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (blockIdx.x != 0) return;
+  // one wave, fixed order: lane l sums partials l, l + 64, ... in sequence, then a butterfly over the lanes (a single
+  // thread walking the 256 partials was 11 us of dependent loads per head)
   float s = 0.0f;
-  for (int b = 0; b < nblk; ++b) s += partial[b];
+  for (int b = threadIdx.x; b < nblk; b += 64) s += partial[b];
+  s = wave_sum(s);
+  if (threadIdx.x != 0) return;
   const float v = (s / (float)divisor[0]) * out_scale;  // loss.mean() over max(edge2graph)+1 graphs, NCSN.py:210-212
   loss[0] = accumulate ? loss[0] + v : v;
 }
