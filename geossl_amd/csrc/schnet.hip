@@ -212,7 +212,10 @@ __device__ __forceinline__ void aggregate_reg_body(const float* __restrict__ x, 
   typedef f32x2 V;
   // filter rows in flight per wave: a wave's walk takes (positions / RING) memory round trips (~2 us each under load),
   // so the large classes - whose single wave bounds a ragged launch from below - get the deeper ring
-  constexpr int RING = RING_ > 0 ? RING_ : (NMAX > 26 ? 24 : (NMAX > 20 ? 20 : (NMAX > 18 ? 12 : 16)));
+#ifndef AGG_RING_SMALL
+#define AGG_RING_SMALL 16
+#endif
+  constexpr int RING = RING_ > 0 ? RING_ : (NMAX > 26 ? 24 : (NMAX > 20 ? 20 : (NMAX > 18 ? 12 : AGG_RING_SMALL)));
   constexpr int NPOS = NMAX * (NMAX - 1) / 2;            // positions of the unrolled walk
   // filter row of a slot = uniform base (scalar registers) + this lane's fixed column offset: the requests then use
   // the scalar-base addressing form and no per-request vector address is ever computed (or kept alive)
@@ -402,7 +405,10 @@ __device__ __forceinline__ void aggregate_reg_part(const float* __restrict__ x, 
 
 // all molecules of the launch fit one size class (uniform batches: the best register allocation for that class)
 template <int NMAX>
-__global__ __launch_bounds__(64, (NMAX <= 20 ? 4 : 3)) void k_aggregate_reg(
+#ifndef AGG_WPS_SMALL
+#define AGG_WPS_SMALL 4
+#endif
+__global__ __launch_bounds__(64, (NMAX <= 20 ? AGG_WPS_SMALL : 3)) void k_aggregate_reg(
     const float* __restrict__ x, const float* __restrict__ Wf, const uint8_t* __restrict__ pair_flag,
     const int32_t* __restrict__ mol_ptr, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ order, int B,
     int F, int swap, float* __restrict__ out) {
