@@ -33,6 +33,17 @@ using namespace geossl;
 
 namespace {
 
+#ifdef FB_TIMING
+__device__ long long fb_dbg[2 * 64 * 8];
+__device__ long long fb_dbg2[2 * 64];
+#define FB_MARK(slot)                                                                                   \
+  do {                                                                                                  \
+    if (blockIdx.x == 3 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == NW) && t - t_begin < 64) \
+      fb_dbg[((wave == 0 ? 0 : 1) * 64 + (t - t_begin)) * 8 + (slot)] = clock64();                      \
+  } while (0)
+#else
+#define FB_MARK(slot) do {} while (0)
+#endif
 constexpr int TR = 32;         // pair rows per tile
 constexpr int ATOM_CAP = 40;   // atoms staged per tile (two 18..20-atom molecules, or more smaller ones)
 
@@ -220,8 +231,10 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
   for (int t = t_begin; t < t_end; ++t) {
     const int r0 = t * TR;
     const int bsel = t & 1;
+    FB_MARK(0);
     lds_barrier();  // previous tile fully consumed; this tile's staging buffer published (LDS only: the requests for the
                     // tiles ahead stay in flight; measured neutral against __syncthreads here)
+    FB_MARK(1);
     const bool staged = L.flag(bsel)[0] != 0;
     // ---- tile build: every thread one dOr fragment lane; role A publishes its tf lanes, role B its rbf lanes
     auto build = [&](const float* xb, const float* db, int stride) {
@@ -287,11 +300,19 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
     float tcur[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) tcur[r] = tc[r];
+    FB_MARK(2);
     lds_barrier();
+    FB_MARK(3);
     // While this tile is multiplied: publish the next tile's staging buffer (its atoms were requested one tile ago
     // and have arrived), request the atoms of the tile after it and the next tile's saved activations.
     if (t + 1 < t_end) {
+#ifdef FB_TIMING
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (blockIdx.x == 3 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == NW) && t - t_begin < 64)
+        fb_dbg2[(wave == 0 ? 0 : 1) * 64 + (t - t_begin)] = clock64();
+#endif
       publish(t + 1, alo_a);
+      FB_MARK(7);
       if (t + 2 < t_end) {
         alo_a = alo_b;
         request_atoms(t + 2, alo_a);
@@ -299,6 +320,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
       }
       request_t(t + 1);
     }
+    FB_MARK(4);
     if constexpr (roleA) {
       // dt = dO W2 for this wave's hidden units (back-to-back MFMAs on one accumulator forward SrcC without a stall)
       f32x16 acc0, acc1;  // small-weight and large-weight piece products apart: better conditioned, and two
@@ -338,6 +360,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
         }
         du[s] = split8(v);
       }
+      FB_MARK(6);
       // dW1[h][g] += sum_rows dU[row][h] * rbf(d_row)[g]
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -376,6 +399,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
         tp[1] = mfma_bf16(s0[64], ident[q], tp[1]);
         tp[2] = mfma_bf16(s0[128], ident[q], tp[2]);
       }
+      FB_MARK(6);
       Frag3 da[2];  // A fragments of dW2 = dO^T t: k-step s <-> registers 8s..8s+7
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
@@ -414,6 +438,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
         }
       }
     }
+    FB_MARK(5);
   }
   // ---- one partial per block
   const size_t pb = (size_t)l * gridDim.x + blockIdx.x;
@@ -472,6 +497,15 @@ inline int blocks_per_layer(int L, int ntiles) {
 }
 
 }  // namespace
+
+#ifdef FB_TIMING
+extern "C" int geossl_filter_bwd_debug_read(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fb_dbg), sizeof(long long) * 2 * 64 * 8);
+}
+extern "C" int geossl_filter_bwd_debug_read2(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fb_dbg2), sizeof(long long) * 2 * 64);
+}
+#endif
 
 extern "C" int64_t geossl_cfconv_filter_bwd_workspace_floats(int64_t P, int L, int F, int G) {
   const int ntiles = (int)((P + TR - 1) / TR);
