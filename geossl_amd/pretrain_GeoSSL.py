@@ -196,7 +196,9 @@ class DDMTrainer:
         self.opt = FusedAdam(self.flat, lr=lr, weight_decay=weight_decay)
         self.reduce = GradAllReduce(self.flat.grad)
         self.use_graph = use_graph
-        self.overlap_heads = overlap_heads  # head weight gradients on a side stream, concurrent with the backbone's backward
+        # two-pass NCSN backward only (GEOSSL_NCSN_SPLIT_BWD): its weight-gradient kernels on a side stream, concurrent
+        # with the backbone's backward; the default one-pass backward has nothing to overlap
+        self.overlap_heads = overlap_heads
         self._graphs, self._pool, self.max_graphs = {}, None, max_graphs
         self._side = None
 
