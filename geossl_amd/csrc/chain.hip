@@ -509,13 +509,227 @@ __global__ __launch_bounds__(512, 2) void k_row_chain8(GeosslChain ch, const flo
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight-stationary form (F = 128): a block of four waves, one per SIMD, works on up to RB row blocks.  Wave m owns
+// output column block m of every stage: its 24 weight fragments of a stage sit in registers for all the block's row
+// blocks (no LDS ring, no LDS-DMA, no per-chunk barrier), the row blocks' inputs sit in LDS as split fragments (24 KB
+// per row block) and every wave walks them; a stage's results stay in registers (16 per row block) until all waves
+// are done reading the stage's input, then every wave writes its two k-steps of the next stage's input in place:
+// two LDS-only barriers per stage.  The stores of a row block are issued one row block late: every vector-memory
+// request of a wave completes in order, so the wait for the next epilogue operands also covers whatever was issued
+// before them.  WPS = 2: two such blocks per CU (RB = 3: 72 KB of LDS, 256 registers) that run out of step - the
+// memory phases of one fall into the arithmetic of the other; WPS = 1: one block per CU with RB = 5 and 512 registers
+// (epilogue operands requested one row block ahead).
+template <int NS, int RB, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const float* __restrict__ X, int ldx, int R) {
+  constexpr int KS = 8, F = 128;
+  constexpr int RBF = KS * 3 * 64;      // u32x4 per row block of fragments
+#ifndef CHAIN_CU_NEB2
+#define CHAIN_CU_NEB2 2
+#endif
+  constexpr int NEB = WPS == 1 ? 2 : CHAIN_CU_NEB2;  // buffers of epilogue operands (2: requested one row block ahead)
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  u32x4* xbuf = reinterpret_cast<u32x4*>(smem_raw);                       // [RB][KS][3][64]
+  float* bias_s = reinterpret_cast<float*>(xbuf + (size_t)RB * RBF);      // [NS][F]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const int m = __builtin_amdgcn_readfirstlane(tid >> 6);                  // this wave's column block
+  const int nrb = (R + 31) / 32;
+  // contiguous runs of row blocks: the first `extra` blocks take one more (they are the first to be placed on a CU, so
+  // a CU that holds two blocks holds at most one long one)
+  const int nblk = (int)gridDim.x, base = nrb / nblk, extra = nrb - base * nblk, b = (int)blockIdx.x;
+  const int rb0 = b * base + min(b, extra);
+  const int nloc = base + (b < extra ? 1 : 0);                             // <= RB, uniform
+  const uint32_t voff = (uint32_t)lane * 16u;
+  Frag3 af[KS];
+  auto request_weights = [&](const GeosslChainStage& st) __attribute__((always_inline)) {
+    const char* img = reinterpret_cast<const char*>(st.image) + (size_t)(m * KS) * 3 * 1024;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const char* bk = img + ks * 3 * 1024;
+      asm volatile("" : "+s"(bk));  // keep the base scalar: loads become saddr + lane offset + immediate
+      af[ks].h = *reinterpret_cast<const u32x4*>(bk + voff);
+      af[ks].m = *reinterpret_cast<const u32x4*>(bk + 1024 + voff);
+      af[ks].l = *reinterpret_cast<const u32x4*>(bk + 2048 + voff);
+    }
+  };
+  request_weights(ch.st[0]);
+  for (int i = tid; i < NS * F; i += 256) {
+    const int s = i / F;
+    bias_s[i] = ch.st[s].bias != nullptr ? ch.st[s].bias[i - s * F] : 0.0f;
+  }
+  // ---- X: this wave's 32 columns (k-steps 2m, 2m+1) of every row block, split, into the fragment buffer
+  {
+    f32x4 raw[RB][4];
+    const char* xb = reinterpret_cast<const char*>(X) + 128 * m;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const uint32_t rowc = (uint32_t)min(32 * (rb0 + min(i, nloc - 1)) + j, R - 1);
+      const uint32_t xo = rowc * (uint32_t)ldx * 4u + 16u * kh;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) raw[i][q] = *reinterpret_cast<const f32x4*>(xb + 32 * q + xo);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      if (i < nloc) {
+        const float lo[8] = {raw[i][0].x, raw[i][0].y, raw[i][0].z, raw[i][0].w, raw[i][1].x, raw[i][1].y, raw[i][1].z, raw[i][1].w};
+        const float hi[8] = {raw[i][2].x, raw[i][2].y, raw[i][2].z, raw[i][2].w, raw[i][3].x, raw[i][3].y, raw[i][3].z, raw[i][3].w};
+        const Frag3 f0 = split8(lo), f1 = split8(hi);
+        u32x4* xd = xbuf + (size_t)i * RBF + (size_t)(2 * m * 3) * 64 + lane;
+        xd[0] = f0.h; xd[64] = f0.m; xd[128] = f0.l;
+        xd[192] = f1.h; xd[256] = f1.m; xd[320] = f1.l;
+      }
+    }
+  }
+  lds_barrier();  // biases staged, fragments published
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const GeosslChainStage st = ch.st[s];
+    float vout[RB][16];
+    f32x4 tp[NEB][4], rs[NEB][4];
+    // Every vector-memory instruction of the stage loop is issued unconditionally (buffer addressing: a null operand
+    // is a zero-sized buffer whose loads return 0 and whose stores are dropped, rows past R get an out-of-range
+    // offset), so the number of requests between a load and its use is a constant and the wait for row block i's
+    // operands leaves the younger requests - the next row block's operands, the last stores - in flight.
+    const uint32_t nbytes = (uint32_t)R * (uint32_t)st.ld * 4u;
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st.tprev), 0, st.tprev != nullptr ? nbytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st.res), 0, st.res != nullptr ? nbytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(st.out, 0, st.out != nullptr ? nbytes : 0u, 0x00020000);
+    auto row_off = [&](int i) __attribute__((always_inline)) {
+      const int row = 32 * (rb0 + i) + j;
+      return row < R ? (uint32_t)row * (uint32_t)st.ld * 4u + 128u * m + 16u * kh : 0xFFFFFF00u;  // out of range (also + 96): dropped
+    };
+    auto request_epi = [&](int i, f32x4 (&t)[4], f32x4 (&r)[4]) __attribute__((always_inline)) {
+      const uint32_t ro = row_off(i);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, ro + 32 * q, 0, 0));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, ro + 32 * q, 0, 0));
+    };
+    auto store_rb = [&](int i) __attribute__((always_inline)) {
+      const uint32_t ro = row_off(i);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        __builtin_amdgcn_raw_buffer_store_b128(
+            __builtin_bit_cast(u32x4, f32x4{vout[i][4 * q], vout[i][4 * q + 1], vout[i][4 * q + 2], vout[i][4 * q + 3]}), rs_o,
+            ro + 32 * q, 0, 0);
+    };
+    if (NEB == 2) request_epi(0, tp[0], rs[0]);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      if (i < nloc) {
+        if (NEB == 2) {
+          if (i + 1 < nloc) request_epi(i + 1, tp[(i + 1) & 1], rs[(i + 1) & 1]);
+        } else {
+          request_epi(i, tp[0], rs[0]);  // ahead of this row block's MFMAs; the other block of the CU covers the rest
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_s + s * F + 32 * m + 8 * q + 4 * kh);
+          acc[4 * q] = bq.x; acc[4 * q + 1] = bq.y; acc[4 * q + 2] = bq.z; acc[4 * q + 3] = bq.w;
+        }
+        {
+          const u32x4* xs = xbuf + (size_t)i * RBF + lane;
+          Frag3 xa, xn;
+          xa.h = xs[0]; xa.m = xs[64]; xa.l = xs[128];
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+              const u32x4* src = xs + (size_t)((ks + 1) * 3) * 64;
+              xn.h = src[0]; xn.m = src[64]; xn.l = src[128];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma6(acc, af[ks], xa);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < KS) xa = xn;
+          }
+        }
+        // epilogue in registers: lane = row, register 4q + e = column 32m + 8q + 4kh + e
+        const f32x4(&t)[4] = tp[NEB == 2 ? (i & 1) : 0];
+        const f32x4(&r)[4] = rs[NEB == 2 ? (i & 1) : 0];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) vout[i][e] = acc[e];
+        if (st.flags & GEOSSL_EPI_SSP) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) vout[i][e] = ssp(vout[i][e]);
+        }
+        if (st.tprev != nullptr) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            vout[i][4 * q] *= dssp_from_out(t[q].x);
+            vout[i][4 * q + 1] *= dssp_from_out(t[q].y);
+            vout[i][4 * q + 2] *= dssp_from_out(t[q].z);
+            vout[i][4 * q + 3] *= dssp_from_out(t[q].w);
+          }
+        }
+        if (st.res != nullptr) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            vout[i][4 * q] += r[q].x;
+            vout[i][4 * q + 1] += r[q].y;
+            vout[i][4 * q + 2] += r[q].z;
+            vout[i][4 * q + 3] += r[q].w;
+          }
+        }
+        if (i > 0) store_rb(i - 1);      // one row block late (see the header)
+        if (i + 1 == nloc) store_rb(i);  // (register arrays are only ever indexed by unrolled constants)
+      }
+    }
+    if (s + 1 < NS) {
+      request_weights(ch.st[s + 1]);  // the fragments of this stage are dead; in flight across the exchange
+      lds_barrier();                  // every wave is done reading this stage's input
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        if (i < nloc) {  // registers 0..7 / 8..15 are k-steps 2m / 2m+1 of the next stage (kperm)
+          const float lo[8] = {vout[i][0], vout[i][1], vout[i][2], vout[i][3], vout[i][4], vout[i][5], vout[i][6], vout[i][7]};
+          const float hi[8] = {vout[i][8], vout[i][9], vout[i][10], vout[i][11], vout[i][12], vout[i][13], vout[i][14], vout[i][15]};
+          const Frag3 f0 = split8(lo), f1 = split8(hi);
+          u32x4* xd = xbuf + (size_t)i * RBF + (size_t)(2 * m * 3) * 64 + lane;
+          xd[0] = f0.h; xd[64] = f0.m; xd[128] = f0.l;
+          xd[192] = f1.h; xd[256] = f1.m; xd[320] = f1.l;
+        }
+      }
+      lds_barrier();
+    }
+  }
+}
+
 template <int KS>
 int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipStream_t stream) {
   constexpr int NMB = KS / 2, CHUNK_BYTES = KS * 3 * 1024;
   const int nrb = (int)((R + 31) / 32), ngroups = (nrb + 3) / 4;
   const int nslot = chain_slots(ch.nstage * NMB);
   static const bool four_waves = getenv("GEOSSL_CHAIN4") != nullptr;  // the four-wave form, kept for A/B runs
-  if (four_waves) {
+  static const bool eight_waves = getenv("GEOSSL_CHAIN8") != nullptr;  // the streaming eight-wave form, for A/B runs
+  // weight-stationary form: F = 128, and every row-piece offset must fit the 32-bit range of a buffer descriptor
+  bool cu_form = KS == 8 && !four_waves && !eight_waves;
+  for (int s2 = 0; s2 < ch.nstage; ++s2)
+    if ((int64_t)R * ch.st[s2].ld * 4 >= (int64_t)0xFFFFFF00u) cu_form = false;
+  if (cu_form) {
+    static const bool one_per_cu = getenv("GEOSSL_CHAIN_CU1") != nullptr;  // 512-register form, one block per CU
+    const int RBV = one_per_cu ? 5 : 3, slots = one_per_cu ? 256 : 512;
+    const int need = (nrb + RBV - 1) / RBV;                       // blocks so that none takes more than RB row blocks
+    const int fill = nrb < slots ? nrb : slots;                   // blocks so that every slot of the chip has work
+    const int grid = need > fill ? need : fill;
+    const size_t lds = (size_t)RBV * KS * 3 * 1024 + (size_t)ch.nstage * 16 * KS * sizeof(float);
+#define LAUNCH_CU(NSV)                                                                                           \
+  do {                                                                                                           \
+    if (one_per_cu) {                                                                                            \
+      allow_big_lds(&k_row_chain_cu<NSV, 5, 1>);                                                                 \
+      hipLaunchKernelGGL((k_row_chain_cu<NSV, 5, 1>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R);   \
+    } else {                                                                                                     \
+      allow_big_lds(&k_row_chain_cu<NSV, 3, 2>);                                                                 \
+      hipLaunchKernelGGL((k_row_chain_cu<NSV, 3, 2>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R);   \
+    }                                                                                                            \
+  } while (0)
+    switch (ch.nstage) {
+      case 1: LAUNCH_CU(1); break;
+      case 2: LAUNCH_CU(2); break;
+      case 3: LAUNCH_CU(3); break;
+      default: return (int)hipErrorInvalidValue;
+    }
+#undef LAUNCH_CU
+  } else if (four_waves) {
     const int grid = ngroups < 2048 ? ngroups : 2048;  // two blocks per CU are resident (72 KB of LDS, <= 256 registers)
     const size_t lds = (size_t)nslot * CHUNK_BYTES + (size_t)ch.nstage * 16 * KS * sizeof(float);
 #define LAUNCH_NS(NSV)                                                                                           \
