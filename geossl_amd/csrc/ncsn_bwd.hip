@@ -49,6 +49,17 @@ namespace {
 
 constexpr int TR = 32;  // rows per tile
 
+#ifdef NB_TIMING
+__device__ long long nb_dbg[2 * 32 * 8];
+#define NB_MARK(slot)                                                                              \
+  do {                                                                                             \
+    if (blockIdx.x == 5 && lane == 0 && (wave == 0 || wave == NW) && t - t_begin < 32)             \
+      nb_dbg[((wave == 0 ? 0 : 1) * 32 + (t - t_begin)) * 8 + (slot)] = clock64();                 \
+  } while (0)
+#else
+#define NB_MARK(slot) do {} while (0)
+#endif
+
 template <int NW>
 struct NbLds {
   static constexpr int F = 32 * NW, H = F / 2, KHS = (H + 15) / 16, HMB = (H + 31) / 32, KS = F / 16;
@@ -318,8 +329,10 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
   for (int t = t_begin; t < t_end; ++t) {
     const int buf = t & 1;
     int k4 = opaque(4 * kh);
+    NB_MARK(0);
     lds_barrier();  // X(t): fragments and scalars of tile t published; everything of tile t-1 consumed
     // =============================================================== phase 1
+    NB_MARK(1);
     if constexpr (ROLE_A) {
       put_scal(t + 2);
       // ---- dz1^T for this wave's units: rows on M
@@ -342,6 +355,7 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
           if (ks + 1 < KHS) a0 = an;
         }
       }
+      NB_MARK(5);
       float v[16];
       {
         const int4* sc = L.scal + (t % 3) * TR;
@@ -396,6 +410,7 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
         de += __shfl_xor(de, 32, 64);
         if (kh == 0) L.dep[j * NW + nb] = de;
       }
+      NB_MARK(6);
       // ---- dW1[this wave's units][all features] += dz1^T (h_u + h_v)
 #pragma unroll
       for (int kb = 0; kb < NW; ++kb)
@@ -427,12 +442,16 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
           for (int s = 0; s < 2; ++s) L.dz2T[(size_t)((nb * 2 + s) * 3 + pc) * 64 + lane] = pack8(tp, s);
         }
       }
+      NB_MARK(5);
       // ---- next tile's fragments (their requests have been in flight since phase 2 of the previous tile)
       build_zb(t + 1);
+      NB_MARK(6);
       build_fT(t + 1);
     }
     k4 = opaque(4 * kh);
+    NB_MARK(2);
     lds_barrier();  // Y(t): dz1 fragments, dz2^T fragments, demb partials, scalars of tile t+2 published
+    NB_MARK(3);
     // =============================================================== phase 2
     if constexpr (ROLE_A) {
       // this phase has no matrix work for the A waves: their requests for the next tile go out here
@@ -463,6 +482,7 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
     } else {
       request_a2(t + 2);
       request_gather(t + 2, k4);
+      NB_MARK(7);
       // ---- dfeat^T for this wave's features: rows on N
       f32x16 acc0, acc1;
 #pragma unroll
@@ -515,6 +535,7 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
         }
       }
     }
+    NB_MARK(4);
   }
   // ---------------------------------------------------------------- one partial per block
   const size_t pb = blockIdx.x;
@@ -583,6 +604,12 @@ inline int fused_blocks(int64_t S) {
 }
 
 }  // namespace
+
+#ifdef NB_TIMING
+extern "C" int geossl_ncsn_bwd_debug_read(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(nb_dbg), sizeof(long long) * 2 * 32 * 8);
+}
+#endif
 
 extern "C" int64_t geossl_ddm_loss_bwd_fused_workspace_floats(int64_t S, int F) {
   const int64_t nb = fused_blocks(S), H = F / 2;
