@@ -239,6 +239,16 @@ __device__ __forceinline__ void aggregate_reg_body(const float* __restrict__ x, 
     const float* rowp = wbase + (size_t)__builtin_amdgcn_readfirstlane(slot) * F;  // uniform
     return __builtin_nontemporal_load(reinterpret_cast<const V*>(rowp + f));
   };
+  // Flags of every row atom, requested before anything else: lane b holds the flag byte of slot (a, b).  A flag load
+  // inside the walk is the YOUNGEST request of the wave when its ballot needs it, and requests complete in order: it
+  // drained the whole ring of filter rows once per row atom (17 memory round trips per 18-atom molecule - the launch
+  // was latency bound at 4.6 TB/s where the same stream of filter rows alone reaches 6.5 TB/s).
+  unsigned flr[NMAX - 1];
+#pragma unroll
+  for (int a = 0; a < NMAX - 1; ++a) {
+    const bool mine = lane > a && lane < n;  // (clamped address + select below: a predicated load would become a branch)
+    flr[a] = pair_flag[base + (mine ? a * n - a * (a + 1) / 2 + lane - a - 1 : 0)];
+  }
   {  // prologue: the first RING positions
     int ap = 0, bp = 1;
 #pragma unroll
@@ -253,11 +263,10 @@ __device__ __forceinline__ void aggregate_reg_body(const float* __restrict__ x, 
     if (++bp == NMAX) { ++ap; bp = ap + 1; }              // (ap, bp) = position q + RING
 #pragma unroll
   for (int a = 0; a < NMAX - 1; ++a) {
-    // flags of row atom a as two ballot masks over the partner index b (lane b reads the flag of slot (a, b))
-    // (clamped address + select, the loaded value pinned: a predicated load would become a branch, and with control flow
-    // in the walk the arithmetic is sunk below every later request of the block)
+    // flags of row atom a as two ballot masks over the partner index b (the loaded value pinned: with control flow in
+    // the walk the arithmetic is sunk below every later request of the block)
     const bool mine = lane > a && lane < n;
-    unsigned fl = pair_flag[base + (mine ? a * n - a * (a + 1) / 2 + lane - a - 1 : 0)];
+    unsigned fl = flr[a];
     asm volatile("" : "+v"(fl));
     fl = mine ? fl : 0u;
     if (swap) fl = ((fl & 1u) << 1) | ((fl >> 1) & 1u);
@@ -323,6 +332,12 @@ __device__ __forceinline__ void aggregate_reg_part(const float* __restrict__ x, 
     const float* rowp = wbase + (size_t)__builtin_amdgcn_readfirstlane(slot) * F;  // uniform
     return __builtin_nontemporal_load(reinterpret_cast<const V*>(rowp + f));
   };
+  unsigned flr[AEND];  // flags of every row atom of this part, requested first (see aggregate_reg_body)
+#pragma unroll
+  for (int a = 0; a < AEND; ++a) {
+    const bool mine = lane > a && lane < n;
+    flr[a] = pair_flag[base + (mine ? a * n - a * (a + 1) / 2 + lane - a - 1 : 0)];
+  }
   {  // prologue: the first RING positions
     int ap = 0, bp = AGG_BS(0);
 #pragma unroll
@@ -338,7 +353,7 @@ __device__ __forceinline__ void aggregate_reg_part(const float* __restrict__ x, 
   // flags of row atom a as two ballot masks over the partner index b (as in aggregate_reg_body)
   auto row_flags = [&](int a, unsigned long long& m0, unsigned long long& m1) {
     const bool mine = lane > a && lane < n;
-    unsigned fl = pair_flag[base + (mine ? a * n - a * (a + 1) / 2 + lane - a - 1 : 0)];
+    unsigned fl = flr[a];
     asm volatile("" : "+v"(fl));
     fl = mine ? fl : 0u;
     if (swap) fl = ((fl & 1u) << 1) | ((fl >> 1) & 1u);
@@ -406,7 +421,7 @@ __device__ __forceinline__ void aggregate_reg_part(const float* __restrict__ x, 
 // all molecules of the launch fit one size class (uniform batches: the best register allocation for that class)
 template <int NMAX>
 #ifndef AGG_WPS_SMALL
-#define AGG_WPS_SMALL 4
+#define AGG_WPS_SMALL 3
 #endif
 __global__ __launch_bounds__(64, (NMAX <= 20 ? AGG_WPS_SMALL : 3)) void k_aggregate_reg(
     const float* __restrict__ x, const float* __restrict__ Wf, const uint8_t* __restrict__ pair_flag,
