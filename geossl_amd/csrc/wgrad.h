@@ -50,9 +50,15 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
   float bsum[SA], dsum[SA];
 #pragma unroll
   for (int u = 0; u < SA; ++u) bsum[u] = dsum[u] = 0.0f;
-  typename Ops::RawA ra[SA];
-  typename Ops::RawB rb[SB];
-  auto request = [&](int row0) {
+  // operand requests run PF row tiles ahead of their use (register sets in rotation); the block barriers are LDS-only,
+  // so the requests stay in flight across them
+#ifndef WGRAD_PF
+#define WGRAD_PF 2
+#endif
+  constexpr int PF = Ops::kDot ? 1 : WGRAD_PF;  // (the gathering policy keeps index state in its request set: one ahead)
+  typename Ops::RawA ra_[PF][SA];
+  typename Ops::RawB rb_[PF][SB];
+  auto request_into = [&](int row0, typename Ops::RawA (&ra)[SA], typename Ops::RawB (&rb)[SB]) {
 #pragma unroll
     for (int u = 0; u < SA; ++u)
       if (wave + 4 * u < NCM) ops.request_a(z, min(32 * (wave + 4 * u) + j, M - 1), row0, row_end, kh, ra[u]);
@@ -62,14 +68,20 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
   };
   if (row_begin < row_end) {
 #pragma unroll
-    for (int u = 0; u < SA; ++u)
-      if (wave + 4 * u < NCM) ops.prime_a(z, min(32 * (wave + 4 * u) + j, M - 1), row_begin, row_end, kh, ra[u]);
+    for (int p = 0; p < PF; ++p) {  // every request set carries its own per-column state
 #pragma unroll
-    for (int u = 0; u < SB; ++u)
-      if (wave + 4 * u < NCN) ops.prime_b(z, min(32 * (wave + 4 * u) + j, N - 1), row_begin, row_end, kh, rb[u]);
-    request(row_begin);
+      for (int u = 0; u < SA; ++u)
+        if (wave + 4 * u < NCM) ops.prime_a(z, min(32 * (wave + 4 * u) + j, M - 1), row_begin, row_end, kh, ra_[p][u]);
+#pragma unroll
+      for (int u = 0; u < SB; ++u)
+        if (wave + 4 * u < NCN) ops.prime_b(z, min(32 * (wave + 4 * u) + j, N - 1), row_begin, row_end, kh, rb_[p][u]);
+    }
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+      if (row_begin + 32 * p < row_end) request_into(row_begin + 32 * p, ra_[p], rb_[p]);
   }
-  for (int row0 = row_begin; row0 < row_end; row0 += 32) {
+  // one 32-row tile: operands of set (ra, rb) -> fragments -> MFMAs; the set is refilled with tile row0 + 32 PF
+  auto tile = [&](int row0, typename Ops::RawA (&ra)[SA], typename Ops::RawB (&rb)[SB]) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < SA; ++u) {
       const int blk = wave + 4 * u;
@@ -112,8 +124,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
         dst[128] = f.l;
       }
     }
-    __syncthreads();
-    if (row0 + 32 < row_end) request(row0 + 32);  // in flight during the MFMAs
+    lds_barrier();
+    if (row0 + 32 * PF < row_end) request_into(row0 + 32 * PF, ra, rb);  // in flight for PF tiles
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       // two tiles at a time: their twelve MFMAs alternate between the two accumulators
@@ -143,7 +155,12 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
 #undef GEOSSL_WG_STEP
       }
     }
-    __syncthreads();
+    lds_barrier();
+  };
+  for (int row0 = row_begin; row0 < row_end; row0 += 32 * PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+      if (row0 + 32 * p < row_end) tile(row0 + 32 * p, ra_[p], rb_[p]);  // (block-uniform condition)
   }
   const size_t pb = (size_t)z * gridDim.x + blockIdx.x;
   float* Pp = partial + pb * M * N;
