@@ -274,6 +274,7 @@ def main():
     # build the per-batch index structures once (part of collation, not of the step)
     gen = torch.Generator(device=dev)
     gen.manual_seed(777 + rank)
+    torch.cuda.manual_seed(777 + rank)  # the trainer's own noise draws: a different stream on every rank
 
     def draw(bt, step):
         S, B = bt.super_edge_index.size(1), bt.num_graphs
@@ -341,7 +342,7 @@ def main():
         # -> one captured graph per batch, all in one memory pool, captured once and replayed every epoch
         shared = args.molset == "A" and args.model == "schnet"
         key = ("setA", args.mols, 18) if shared else (args.molset, args.model, i % n_batches)
-        return trainer.step(bt, draw(bt, i), structure_key=key)
+        return trainer.step(bt, None, structure_key=key)  # the trainer draws the step's noise on the device itself
 
     # untimed priming ahead of the W warm-up steps: builds the cached index structures and captures the HIP graph(s)
     # (one step when all batches share a structure, one pass over the batches otherwise - the first epoch of a real

@@ -444,7 +444,7 @@ class SchNet(torch.nn.Module):
         if self.dipole:
             raise NotImplementedError("dipole readout (schnet.py:103-107,117-118) is off the GeoSSL path")
 
-    def forward(self, z, pos, batch=None, return_latent=False, layout=None):
+    def forward(self, z, pos, batch=None, return_latent=False, layout=None, latent_only=False):
         assert z.dim() == 1 and z.dtype == torch.long
         _lib.require_cuda(z, pos, batch)
         self._check_supported()
@@ -466,6 +466,8 @@ class SchNet(torch.nn.Module):
             h = h * self.std + self.mean
         if not self.dipole and self.atomref is not None:
             h = h + self.atomref(z)
+        if latent_only and return_latent:  # (extension) a caller that discards the readout, e.g. do_DDM: (None, h)
+            return None, h
         out = _SegmentReduce.apply(h, lay, self.readout)
         if self.scale is not None:
             out = self.scale * out

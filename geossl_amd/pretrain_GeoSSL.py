@@ -95,8 +95,9 @@ def do_DDM(args, batch, model, criterion=None, mu=0.0, sigma=0.3, num_neg=1, NCS
             num_graphs = batch.num_graphs
             b2, lay2 = _two_view_batch(batch.batch, num_graphs)
             N = positions.size(0)
+            # the readout is dead compute in this step (`_` at pretrain_GeoSSL.py:187): not evaluated
             _, h = model(torch.cat([x_01, x_02]), torch.cat([positions_01, positions_02]), b2, return_latent=True,
-                         layout=lay2)
+                         layout=lay2, latent_only=True)
             molecule_3D_repr_01, molecule_3D_repr_02 = _SplitViews.apply(h, N)
         else:
             _, molecule_3D_repr_01 = model(x_01, positions_01, batch.batch, return_latent=True)
@@ -180,7 +181,8 @@ class DDMTrainer:
     ``use_graph=True``: forward + backward of batches that share one index structure (same
     ``batch`` / ``super_edge_index`` contents, identified by the caller's ``structure_key``) are
     captured once into a HIP graph and replayed; positions, atom types and the five noise tensors
-    are copied into the graph's static buffers before each replay.  A loader with ragged molecules
+    are copied into the graph's static buffers before each replay (with ``noise=None`` and ``device_noise=True`` the
+    trainer makes the five draws itself, straight into those buffers).  A loader with ragged molecules
     passes one key per batch (e.g. its index in the epoch): up to ``max_graphs`` graphs are kept,
     all in one shared memory pool.  The all-reduce and the Adam launch stay outside the graph."""
 
@@ -231,16 +233,41 @@ class DDMTrainer:
         if rei is not None:
             key = (key, id(rei), rei._version, int(rei.size(1)))
         g = self._graphs.get(key)
+        own_noise = noise is None
         if g is None:
+            if own_noise:
+                noise = self._draw_noise(batch)  # this step's draws (the capture needs tensors to clone)
             g = self._capture(batch, noise, key)
             if g is None:  # capture failed: eager from now on
                 return self._fwd_bwd(batch, noise)
+            own_noise = False  # already drawn: copied below like a caller's
         g["batch"].x.copy_(batch.x)
         g["batch"].positions.copy_(batch.positions)
-        for k in self._NOISE_KEYS:
-            g["noise"][k].copy_(noise[k])
+        if own_noise:  # the step's own draws go straight into the graph's static inputs (no staging copies)
+            self._draw_noise(batch, into=g["noise"])
+        else:
+            for k in self._NOISE_KEYS:
+                g["noise"][k].copy_(noise[k])
         g["graph"].replay()
         return g["loss"]
+
+    def _draw_noise(self, batch, into=None):
+        """The five random draws of a step (perturb: pretrain_GeoSSL.py:72 with the draw made on the device; the heads:
+        NCSN.py:190,194), as tensors - new ones, or in place into `into`."""
+        dev = batch.positions.device
+        if into is None:
+            S, B = batch.super_edge_index.size(1), batch.num_graphs
+            into = {"pos_noise": torch.empty_like(batch.positions),
+                    "noise_level_1": torch.empty(B, dtype=torch.long, device=dev),
+                    "noise_level_2": torch.empty(B, dtype=torch.long, device=dev),
+                    "dist_noise_1": torch.empty(S, 1, dtype=torch.float32, device=dev),
+                    "dist_noise_2": torch.empty(S, 1, dtype=torch.float32, device=dev)}
+        into["pos_noise"].normal_(self.mu, self.sigma)
+        into["noise_level_1"].random_(0, self.n1.sigmas.size(0))
+        into["dist_noise_1"].normal_()
+        into["noise_level_2"].random_(0, self.n2.sigmas.size(0))
+        into["dist_noise_2"].normal_()
+        return into
 
     def _capture(self, batch, noise, key):
         """One HIP graph per structure key.  Ragged batches (every batch its own index structure) get one graph each -
@@ -276,7 +303,8 @@ class DDMTrainer:
         return g
 
     def step(self, batch, noise=None, structure_key=None):
-        if self.use_graph and structure_key is not None and noise is not None and all(k in noise for k in self._NOISE_KEYS):
+        if self.use_graph and structure_key is not None and (
+                (noise is None and self.device_noise) or (noise is not None and all(k in noise for k in self._NOISE_KEYS))):
             loss = self._graph_fwd_bwd(batch, noise, structure_key)
         else:
             loss = self._fwd_bwd(batch, noise)

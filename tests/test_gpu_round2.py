@@ -691,3 +691,43 @@ def test_aggregate_work_list_splits_large_molecules_bit_exact(F, monkeypatch):
                 acc = (acc + (xn[src] * Wn[p]).astype(np.float32)).astype(np.float32)
             ref[tgt] = acc
         assert np.array_equal(out, ref), swap
+
+
+@pytest.mark.gpu
+def test_trainer_draws_its_own_noise_into_the_graph_inputs():
+    """DDMTrainer.step(batch, None, structure_key=...) with device_noise=True: the five draws of the step are made on
+    the device straight into the captured graph's static inputs (no staging copies).  Same seed -> same losses as
+    passing the very same draws explicitly; successive steps see different noise."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import make_batch
+    cfg = dict(hidden_channels=128, num_filters=128, num_interactions=2, num_gaussians=51, cutoff=5.0, node_class=9)
+    b = make_batch(48, seed=5)
+    batch = pg.Batch.from_numpy(b, DEV)
+
+    def trainer():
+        return pg.DDMTrainer(product_schnet(cfg, DEV), product_ncsn(128, 50, 2.0, DEV), product_ncsn(128, 50, 2.0, DEV),
+                             device_noise=True, use_graph=True)
+
+    tr = trainer()
+    torch.cuda.manual_seed(99)
+    own = [float(tr.step(batch, None, structure_key="k")) for _ in range(3)]
+    assert all(np.isfinite(own)) and len(set(own)) == 3
+    tr2 = trainer()
+    torch.cuda.manual_seed(99)
+    explicit = []
+    for _ in range(3):
+        nz = tr2._draw_noise(batch)  # the same generator calls in the same order
+        explicit.append(float(tr2.step(batch, nz, structure_key="k")))
+    assert own == explicit
+
+
+@pytest.mark.gpu
+def test_schnet_latent_only_skips_the_readout():
+    g = load_golden("g4_schnet_reduced")
+    cfg = cfg_of(g)
+    model = product_schnet(cfg, DEV)
+    z, pos, batch = t(g["x"], DEV), t(g["positions"], DEV), t(g["batch"], DEV)
+    z = z[:, 0] if z.dim() == 2 else z
+    out, h = model(z, pos, batch, return_latent=True)
+    none, h2 = model(z, pos, batch, return_latent=True, latent_only=True)
+    assert none is None and torch.equal(h, h2)
