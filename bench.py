@@ -471,7 +471,7 @@ def main():
                                        "n=18" if args.molset == "A" else "n~clip(N(18,4),2,33) (set B)", n_batches)),
                        "molecules_per_gpu_per_step": args.mols, "atoms": N, "directed_edges": E, "super_edges": S,
                        "parallelism": "dp%d" % world,
-                       "execution": ("HIP graph replay of fwd+bwd (%d graph%s in one memory pool), eager all-reduce + Adam"
+                       "execution": ("per step: x / positions copied and the five noise draws made on the device into the graph's inputs, HIP graph replay of fwd+bwd (%d graph%s in one memory pool), eager all-reduce + Adam"
                                      % (len(trainer._graphs), "" if len(trainer._graphs) == 1 else "s"))
                        if trainer.use_graph else "eager"},
             "roofline": roof,
