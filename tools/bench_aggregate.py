@@ -9,8 +9,14 @@ from geossl_amd.synthetic import make_batch
 mols = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 dev, F = "cuda:0", 128
 out = {}
-for mode in ("A", "B"):
-    sizes = list(make_batch(mols, seed=3, mode=mode)["sizes"]) * 2       # two views
+import numpy as np
+for mode in ("A", "B", "U22", "U26", "M18_22"):
+    if mode in ("A", "B"):
+        sizes = list(make_batch(mols, seed=3, mode=mode)["sizes"]) * 2       # two views
+    elif mode == "M18_22":   # two classes only, interleaved
+        sizes = [18, 22] * mols
+    else:                    # uniform molecules of one large class (one code path, like set A)
+        sizes = [int(mode[1:])] * (2 * mols)
     batch = torch.arange(len(sizes), device=dev).repeat_interleave(torch.tensor(sizes, device=dev))
     lay = MolLayout(batch, len(sizes), sizes=sizes)
     x = torch.randn(lay.N, F, device=dev)
