@@ -221,32 +221,52 @@ class _PaiNNCore(torch.autograd.Function):
         mu = torch.zeros(N, 3, F_, **f32)                                    # :249
         inc_ptr, inc_idx = el.inc["i"]
         saved = []
+        # Every Dense layer here is a set of F x F row GEMMs (3F outputs = three, a 2F contraction = two with the
+        # residual operand): they run as one-stage launches of the chained row kernel (weights as fragments in
+        # registers, no per-launch weight formatting), on operand images built by one launch per pass.
+        blocks = []
         for l in range(L):
             c0w, c0b, c1w, c1b = inter[l]
-            u = ops.linear(q, c0w, bias=c0b)                                 # Dense(F, F, silu)      :27-30,53
+            i0w, i0b, i1w, i1b, mw = mix[l]
+            blocks += [c0w] + [c1w[c * F_:(c + 1) * F_] for c in range(3)] + [mw[:F_], mw[F_:]] + \
+                      [i0w[:, :F_].contiguous(), i0w[:, F_:].contiguous()] + [i1w[c * F_:(c + 1) * F_] for c in range(3)]
+        img = ops.prepare_chain(blocks, transB=True) if not os.environ.get("GEOSSL_PAINN_NO_CHAIN") else None
+        NB = 11  # blocks per layer, in the order above
+
+        def lin(x, w, k, bias=None, res=None, out=None):
+            if img is None:
+                return ops.linear(x, blocks[k], bias=bias, res=res, out=out)
+            return ops.linear_chain(x, [dict(image=img[k], bias=bias, res=res, out=out)])[0]
+
+        for l in range(L):
+            c0w, c0b, c1w, c1b = inter[l]
+            k0 = NB * l
+            u = lin(q, c0w, k0, bias=c0b)                                    # Dense(F, F, silu)      :27-30,53
             s = torch.empty_like(u)
             call("geossl_silu_fwd", ptr(u), u.numel(), ptr(s), st)
             xc = torch.empty(N, 3 * F_, **f32)
             for c, oc in enumerate(_split3(xc, F_)):                         # Dense(F, 3F)
-                ops.linear(s, c1w[c * F_:(c + 1) * F_], bias=c1b[c * F_:(c + 1) * F_], out=oc)
+                lin(s, c1w[c * F_:(c + 1) * F_], k0 + 1 + c, bias=c1b[c * F_:(c + 1) * F_], out=oc)
             q2, mu2 = torch.empty_like(q), torch.empty_like(mu)
             call("geossl_painn_interaction_fwd", ptr(q), ptr(mu), ptr(xc), ptr(el.idx_j), ptr(inc_ptr), ptr(inc_idx),
                  ptr(phi), ptr(fcut), ptr(dirv), ptr(fw[l * 3 * F_:(l + 1) * 3 * F_]), ptr(fb[l * 3 * F_:(l + 1) * 3 * F_]),
                  N, F_, R, ptr(q2), ptr(mu2), st)                            # :54-64
             i0w, i0b, i1w, i1b, mw = mix[l]
-            mm = ops.linear(mu2.view(3 * N, F_), mw)                         # mu_channel_mix        :100
+            mm = torch.empty(3 * N, 2 * F_, **f32)                           # mu_channel_mix        :100
+            for c in range(2):
+                lin(mu2.view(3 * N, F_), mw[c * F_:(c + 1) * F_], k0 + 4 + c, out=mm[:, c * F_:(c + 1) * F_])
             cx, dot = torch.empty(N, 2 * F_, **f32), torch.empty(N, F_, **f32)
             call("geossl_painn_mix_pre_fwd", ptr(q2), ptr(mm), N, F_, cfg["eps"], ptr(cx), ptr(dot), st)  # :101-104
             # Dense(2F, F, silu) :105 - a contraction over 2F columns is two passes of the F-wide row GEMM (the split
             # kernel holds one K <= 128 weight image in LDS): the second adds onto the first through the residual operand
             i0a, i0c = i0w[:, :F_].contiguous(), i0w[:, F_:].contiguous()
-            u1 = ops.linear(cx[:, :F_], i0a, bias=i0b)
-            ops.linear(cx[:, F_:], i0c, res=u1, out=u1)
+            u1 = lin(cx[:, :F_], i0a, k0 + 6, bias=i0b)
+            lin(cx[:, F_:], i0c, k0 + 7, res=u1, out=u1)
             s1 = torch.empty_like(u1)
             call("geossl_silu_fwd", ptr(u1), u1.numel(), ptr(s1), st)
             xx = torch.empty(N, 3 * F_, **f32)
             for c, oc in enumerate(_split3(xx, F_)):                         # Dense(F, 3F)
-                ops.linear(s1, i1w[c * F_:(c + 1) * F_], bias=i1b[c * F_:(c + 1) * F_], out=oc)
+                lin(s1, i1w[c * F_:(c + 1) * F_], k0 + 8 + c, bias=i1b[c * F_:(c + 1) * F_], out=oc)
             q3, mu3 = torch.empty_like(q), torch.empty_like(mu)
             call("geossl_painn_mix_post_fwd", ptr(q2), ptr(mu2), ptr(mm), ptr(xx), ptr(dot), N, F_, ptr(q3), ptr(mu3), st)
             if training:
@@ -282,6 +302,20 @@ class _PaiNNCore(torch.autograd.Function):
         def add(rows, lda, ldb, ldw, A, Bm, dW, db):
             groups.setdefault((rows, lda, ldb, ldw), []).append((A, Bm, dW, db))
 
+        blocks = []
+        for l in range(L):
+            c0w, c0b, c1w, c1b = inter[l]
+            i0w, i0b, i1w, i1b, mw = mix[l]
+            blocks += [c0w] + [c1w[c * F_:(c + 1) * F_] for c in range(3)] + [mw[:F_], mw[F_:]] + \
+                      [i0w[:, :F_].contiguous(), i0w[:, F_:].contiguous()] + [i1w[c * F_:(c + 1) * F_] for c in range(3)]
+        img = ops.prepare_chain(blocks, transB=False) if not os.environ.get("GEOSSL_PAINN_NO_CHAIN") else None
+        NB = 11
+
+        def lin_t(x, w, k, res=None, out=None):  # x @ w (the transposed use of a forward weight block)
+            if img is None:
+                return ops.linear(x, blocks[k], transB=False, res=res, out=out)
+            return ops.linear_chain(x, [dict(image=img[k], res=res, out=out)])[0]
+
         nfl = _lib.load().geossl_painn_interaction_bwd_workspace_floats(N, F_, R)
         ws = torch.empty(max(int(nfl), 1), **f32)
         keep = []
@@ -291,17 +325,20 @@ class _PaiNNCore(torch.autograd.Function):
             i0w, i0b, i1w, i1b, mw = mix[l]
             gc0w, gc0b, gc1w, gc1b = g_inter[l]
             gi0w, gi0b, gi1w, gi1b, gmw = g_mix[l]
+            k0 = NB * l
             # ---- mixing block
             dxx, dmm = torch.empty(N, 3 * F_, **f32), torch.empty(3 * N, 2 * F_, **f32)
             call("geossl_painn_mix_post_bwd", ptr(dq_cur), ptr(dmu_cur), ptr(sv["mm"]), ptr(sv["xx"]), ptr(sv["dot"]), N,
                  F_, ptr(dxx), ptr(dmm), st)
             ds1 = None
             for c, xs_ in enumerate(_split3(dxx, F_)):
-                ds1 = ops.linear(xs_, i1w[c * F_:(c + 1) * F_], transB=False, res=ds1)
+                ds1 = lin_t(xs_, i1w[c * F_:(c + 1) * F_], k0 + 8 + c, res=ds1)
                 add(N, 3 * F_, F_, F_, xs_, sv["s1"], gi1w[c * F_:(c + 1) * F_], gi1b[c * F_:(c + 1) * F_])
             du1 = torch.empty_like(ds1)
             call("geossl_silu_bwd", ptr(sv["u1"]), ptr(ds1), ds1.numel(), ptr(du1), st)
-            dctx = ops.linear(du1, i0w, transB=False)                      # [N][2F]
+            dctx = torch.empty(N, 2 * F_, **f32)                           # [N][2F] = du1 @ i0w
+            for c in range(2):
+                lin_t(du1, i0w[:, c * F_:(c + 1) * F_], k0 + 6 + c, out=dctx[:, c * F_:(c + 1) * F_])
             for c in range(2):
                 add(N, F_, 2 * F_, 2 * F_, du1, sv["cx"][:, c * F_:(c + 1) * F_], gi0w[:, c * F_:(c + 1) * F_],
                     gi0b if c == 0 else None)
@@ -309,8 +346,8 @@ class _PaiNNCore(torch.autograd.Function):
             call("geossl_painn_mix_pre_bwd", ptr(dq_cur), ptr(dctx), ptr(sv["cx"]), ptr(sv["mm"]), N, F_, ptr(dq2),
                  ptr(dmm), st)
             # d mu (after interaction): contraction over the 2F columns of dmm in two F-wide passes
-            dmu2 = ops.linear(dmm[:, :F_], mw[:F_], transB=False, res=dmu_cur.view(3 * N, F_))
-            ops.linear(dmm[:, F_:], mw[F_:], transB=False, res=dmu2, out=dmu2)
+            dmu2 = lin_t(dmm[:, :F_], mw[:F_], k0 + 4, res=dmu_cur.view(3 * N, F_))
+            lin_t(dmm[:, F_:], mw[F_:], k0 + 5, res=dmu2, out=dmu2)
             for c in range(2):
                 add(3 * N, 2 * F_, F_, F_, dmm[:, c * F_:(c + 1) * F_], sv["mu2"].view(3 * N, F_),
                     gmw[c * F_:(c + 1) * F_], None)
@@ -322,11 +359,11 @@ class _PaiNNCore(torch.autograd.Function):
                  ptr(g_fw[l * 3 * F_:(l + 1) * 3 * F_]), ptr(g_fb[l * 3 * F_:(l + 1) * 3 * F_]), ptr(ws), acc, st)
             ds = None
             for c, xs_ in enumerate(_split3(dxc, F_)):
-                ds = ops.linear(xs_, c1w[c * F_:(c + 1) * F_], transB=False, res=ds)
+                ds = lin_t(xs_, c1w[c * F_:(c + 1) * F_], k0 + 1 + c, res=ds)
                 add(N, 3 * F_, F_, F_, xs_, sv["s"], gc1w[c * F_:(c + 1) * F_], gc1b[c * F_:(c + 1) * F_])
             du = torch.empty_like(ds)
             call("geossl_silu_bwd", ptr(sv["u"]), ptr(ds), ds.numel(), ptr(du), st)
-            dq_in = ops.linear(du, c0w, transB=False, res=dq2)               # residual q2 = q + dq
+            dq_in = lin_t(du, c0w, k0, res=dq2)                              # residual q2 = q + dq
             add(N, F_, F_, F_, du, sv["q"], gc0w, gc0b)
             keep += [dxx, dmm, du1, dxc, du, dq2, dmu2]
             dq_cur, dmu_cur = dq_in, dmu_in

@@ -159,7 +159,7 @@ def linear_chain(x, stages):
     stages: list of dicts with `image` (from prepare_chain) and optional `bias`, `res`, `tprev`, `flags`, `store`
     (default True: the stage's result is written to a new [R, F] tensor).  Returns the list of stored results
     (None where store is False)."""
-    R, F = x.shape
+    R, F = x.shape  # (x may be a column slice: its row stride is passed)
     assert x.stride(1) == 1 and 1 <= len(stages) <= _lib.CHAIN_MAX
     ch = _lib.Chain()
     ch.nstage = len(stages)
@@ -169,12 +169,14 @@ def linear_chain(x, stages):
         o = sd.get("out")  # a preallocated [R, F] destination (e.g. a row slice of a larger tensor) ...
         if o is None and sd.get("store", True):  # ... or a new tensor, unless the stage is not stored at all
             o = torch.empty(R, F, dtype=torch.float32, device=x.device)
-        assert o is None or (o.stride(0) == F and o.stride(1) == 1 and o.size(0) == R)
-        for aux in (sd.get("res"), sd.get("tprev")):
-            assert aux is None or (aux.stride(0) == F and aux.stride(1) == 1 and aux.size(0) == R)
+        # out / res / tprev of a stage share one row stride (they may be column slices of wider row-major tensors)
+        rows_ = [a for a in (o, sd.get("res"), sd.get("tprev")) if a is not None]
+        ld = rows_[0].stride(0) if rows_ else F
+        for a in rows_:
+            assert a.stride(0) == ld and a.stride(1) == 1 and a.size(0) == R and a.size(1) == F
         st.image, st.bias, st.res, st.tprev, st.out = (ptr(sd["image"]), ptr(sd.get("bias")), ptr(sd.get("res")),
                                                        ptr(sd.get("tprev")), ptr(o))
-        st.ld, st.flags = F, int(sd.get("flags", 0))
+        st.ld, st.flags = ld, int(sd.get("flags", 0))
         outs.append(o)
     call("geossl_linear_chain", ptr(x), x.stride(0), C.byref(ch), R, F, stream())
     return outs
