@@ -180,7 +180,8 @@ class PaiNN(nn.Module):
         status.poll()  # an out-of-range atomic number seen by an earlier call raises here (IndexError, like Embedding)
         cfg = dict(F=self.n_atom_basis, L=self.n_interactions, R=self.radial_basis.n_rbf, cutoff=float(self.cutoff),
                    offsets=self.radial_basis.offsets, widths=self.radial_basis.widths,
-                   eps=float(self.mixing[0].epsilon), status=status, debug=bool(os.environ.get("GEOSSL_DEBUG")))
+                   eps=float(self.mixing[0].epsilon), status=status, debug=bool(os.environ.get("GEOSSL_DEBUG")),
+                   lay=lay)
         q = _PaiNNCore.apply(atomic_numbers, positions.contiguous(), el, cfg, *self._params())
         status.arm()
         from .schnet import _SegmentReduce
@@ -248,9 +249,10 @@ class _PaiNNCore(torch.autograd.Function):
             for c, oc in enumerate(_split3(xc, F_)):                         # Dense(F, 3F)
                 lin(s, c1w[c * F_:(c + 1) * F_], k0 + 1 + c, bias=c1b[c * F_:(c + 1) * F_], out=oc)
             q2, mu2 = torch.empty_like(q), torch.empty_like(mu)
-            call("geossl_painn_interaction_fwd", ptr(q), ptr(mu), ptr(xc), ptr(el.idx_j), ptr(inc_ptr), ptr(inc_idx),
+            lay = cfg["lay"]  # one block per molecule: the rows its edges read are staged in LDS once
+            call("geossl_painn_interaction_fwd_mol", ptr(q), ptr(mu), ptr(xc), ptr(el.idx_j), ptr(inc_ptr), ptr(inc_idx),
                  ptr(phi), ptr(fcut), ptr(dirv), ptr(fw[l * 3 * F_:(l + 1) * 3 * F_]), ptr(fb[l * 3 * F_:(l + 1) * 3 * F_]),
-                 N, F_, R, ptr(q2), ptr(mu2), st)                            # :54-64
+                 ptr(lay.mol_ptr), lay.B, lay.max_n, N, F_, R, ptr(q2), ptr(mu2), st)   # :54-64
             i0w, i0b, i1w, i1b, mw = mix[l]
             mm = torch.empty(3 * N, 2 * F_, **f32)                           # mu_channel_mix        :100
             for c in range(2):
@@ -316,7 +318,8 @@ class _PaiNNCore(torch.autograd.Function):
                 return ops.linear(x, blocks[k], transB=False, res=res, out=out)
             return ops.linear_chain(x, [dict(image=img[k], res=res, out=out)])[0]
 
-        nfl = _lib.load().geossl_painn_interaction_bwd_workspace_floats(N, F_, R)
+        lay = cfg["lay"]
+        nfl = _lib.load().geossl_painn_interaction_bwd_mol_workspace_floats(N, lay.B, F_, R)
         ws = torch.empty(max(int(nfl), 1), **f32)
         keep = []
         for l in reversed(range(L)):
@@ -353,9 +356,9 @@ class _PaiNNCore(torch.autograd.Function):
                     gmw[c * F_:(c + 1) * F_], None)
             # ---- interaction block
             dxc, dmu_in = torch.empty(N, 3 * F_, **f32), torch.empty(N, 3, F_, **f32)
-            call("geossl_painn_interaction_bwd", ptr(dq2), ptr(dmu2), ptr(sv["mu"]), ptr(sv["xc"]), ptr(el.idx_i),
+            call("geossl_painn_interaction_bwd_mol", ptr(dq2), ptr(dmu2), ptr(sv["mu"]), ptr(sv["xc"]), ptr(el.idx_i),
                  ptr(inc_ptr), ptr(inc_idx), ptr(phi), ptr(fcut), ptr(dirv), ptr(ps[1][l * 3 * F_:(l + 1) * 3 * F_]),
-                 ptr(ps[2][l * 3 * F_:(l + 1) * 3 * F_]), N, F_, R, ptr(dxc), ptr(dmu_in),
+                 ptr(ps[2][l * 3 * F_:(l + 1) * 3 * F_]), ptr(lay.mol_ptr), lay.B, lay.max_n, N, F_, R, ptr(dxc), ptr(dmu_in),
                  ptr(g_fw[l * 3 * F_:(l + 1) * 3 * F_]), ptr(g_fb[l * 3 * F_:(l + 1) * 3 * F_]), ptr(ws), acc, st)
             ds = None
             for c, xs_ in enumerate(_split3(dxc, F_)):

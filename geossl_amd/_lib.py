@@ -128,6 +128,11 @@ PROTOTYPES = {
     "geossl_silu_bwd": (i32, [vp, vp, i64, vp, vp]),
     "geossl_painn_interaction_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp]),
     "geossl_painn_interaction_bwd_workspace_floats": (i64, [i64, i32, i32]),
+    "geossl_painn_interaction_fwd_mol": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i64, i32, i32, vp,
+                                               vp, vp]),
+    "geossl_painn_interaction_bwd_mol_workspace_floats": (i64, [i64, i64, i32, i32]),
+    "geossl_painn_interaction_bwd_mol": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i64, i32, i32,
+                                               vp, vp, vp, vp, vp, i32, vp]),
     "geossl_painn_interaction_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp,
                                            vp, i32, vp]),
     "geossl_painn_mix_pre_fwd": (i32, [vp, vp, i64, i32, f32, vp, vp, vp]),

@@ -7,6 +7,8 @@
 // One block per atom, one thread per feature: the filter value W_ij = (phi(d) W^T + b) * fcut of the thread's three
 // channels is recomputed from the 20 radial basis values on the fly (never stored per edge), messages are summed in
 // edge order in registers — no atomics, bit-reproducible.
+#include <cstdlib>
+
 #include "common.h"
 #include "geossl_hip.h"
 #include "tn.h"
@@ -197,6 +199,201 @@ __global__ __launch_bounds__(128) void k_painn_interaction_bwd(
   pb[f] = gb0; pb[F + f] = gb1; pb[2 * F + f] = gb2;
 }
 
+// ------------------------------------------------------------------- interaction, one block per molecule
+// The per-atom kernels above read x[j] and mu[j] (forward) or the upstream gradients of atom i (backward) of every
+// edge straight from global memory: 6 (4) coalesced 512-byte rows per edge, 1.75 GB per layer call for 1024 molecules
+// in two views - they ran at the speed of those gathers.  An edge never leaves its molecule, so a block that owns a
+// whole molecule stages the rows of its atoms in LDS once (3 KB per atom forward, 2 KB backward) and every edge reads
+// LDS.  The atoms of the molecule are dealt to the block's thread groups (F threads each, one feature per thread);
+// the sums of an atom are formed by one thread in the edge order of the incidence list - bit for bit the per-atom
+// kernels' results.
+template <int R>
+__global__ __launch_bounds__(512) void k_painn_interaction_fwd_mol(
+    const float* __restrict__ q, const float* __restrict__ mu, const float* __restrict__ xc,
+    const int64_t* __restrict__ idx_j, const int64_t* __restrict__ inc_ptr, const int32_t* __restrict__ inc_idx,
+    const float* __restrict__ phi, const float* __restrict__ fcut, const float* __restrict__ dir,
+    const float* __restrict__ Wf, const float* __restrict__ bf, const int32_t* __restrict__ mol_ptr, int F,
+    float* __restrict__ q_out, float* __restrict__ mu_out) {
+  extern __shared__ __attribute__((aligned(16))) float sm_rows[];
+  const int m = blockIdx.x;
+  const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0;
+  float* xs = sm_rows;                     // [n][3F]
+  float* ms = sm_rows + (size_t)n * 3 * F;  // [n][3F]
+  {
+    const f32x4* xg = reinterpret_cast<const f32x4*>(xc + (size_t)a0 * 3 * F);
+    const f32x4* mg = reinterpret_cast<const f32x4*>(mu + (size_t)a0 * 3 * F);
+    const int cnt = n * 3 * F / 4;
+    for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+      reinterpret_cast<f32x4*>(xs)[t] = xg[t];
+      reinterpret_cast<f32x4*>(ms)[t] = mg[t];
+    }
+  }
+  const int G = blockDim.x / F, g = threadIdx.x / F, f = threadIdx.x - g * F;  // F is a multiple of 64: g is wave-uniform
+  float w0[R], w1[R], w2[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    w0[r] = Wf[(size_t)f * R + r];
+    w1[r] = Wf[(size_t)(F + f) * R + r];
+    w2[r] = Wf[(size_t)(2 * F + f) * R + r];
+  }
+  const float b0 = bf[f], b1 = bf[F + f], b2 = bf[2 * F + f];
+  __syncthreads();
+  for (int ia = g; ia < n; ia += G) {
+    const int i = a0 + ia;
+    float dq = 0.0f, dm0 = 0.0f, dm1 = 0.0f, dm2 = 0.0f;
+    const int64_t p0 = inc_ptr[i], p1 = inc_ptr[i + 1];
+    for (int64_t p = p0; p < p1; ++p) {
+      const int e = __builtin_amdgcn_readfirstlane(inc_idx[p]);  // uniform: edge data comes through scalar loads
+      const int jl = (int)idx_j[e] - a0;
+      const float* __restrict__ ph = phi + (size_t)e * R;
+      float W0 = b0, W1 = b1, W2 = b2;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float pr = ph[r];
+        W0 = fmaf(pr, w0[r], W0);
+        W1 = fmaf(pr, w1[r], W1);
+        W2 = fmaf(pr, w2[r], W2);
+      }
+      const float fc = fcut[e];
+      W0 *= fc; W1 *= fc; W2 *= fc;                                  // painn.py:241
+      const float* xj = xs + (size_t)jl * 3 * F;
+      const float x0 = W0 * xj[f], x1 = W1 * xj[F + f], x2 = W2 * xj[2 * F + f];  // :56
+      const float* mj = ms + (size_t)jl * 3 * F;
+      dq += x0;                                                      // :59
+      dm0 += x1 * dir[3 * e] + x2 * mj[f];                           // :60-61
+      dm1 += x1 * dir[3 * e + 1] + x2 * mj[F + f];
+      dm2 += x1 * dir[3 * e + 2] + x2 * mj[2 * F + f];
+    }
+    q_out[(size_t)i * F + f] = q[(size_t)i * F + f] + dq;            // :63
+    float* mo = mu_out + (size_t)i * 3 * F;
+    const float* mi = ms + (size_t)ia * 3 * F;
+    mo[f] = mi[f] + dm0;                                             // :64
+    mo[F + f] = mi[F + f] + dm1;
+    mo[2 * F + f] = mi[2 * F + f] + dm2;
+  }
+}
+
+// backward: persistent blocks over molecules; the upstream gradients of the molecule's atoms staged in LDS; the
+// filter-network gradient partials of the block's thread groups are summed through LDS: one partial per block
+template <int R>
+__global__ __launch_bounds__(512) void k_painn_interaction_bwd_mol(
+    const float* __restrict__ dq_out, const float* __restrict__ dmu_out, const float* __restrict__ mu,
+    const float* __restrict__ xc, const int64_t* __restrict__ idx_i, const int64_t* __restrict__ inc_ptr,
+    const int32_t* __restrict__ inc_idx, const float* __restrict__ phi, const float* __restrict__ fcut,
+    const float* __restrict__ dir, const float* __restrict__ Wf, const float* __restrict__ bf,
+    const int32_t* __restrict__ mol_ptr, int B, int max_n, int F, float* __restrict__ dxc, float* __restrict__ dmu_in,
+    float* __restrict__ partial_w, float* __restrict__ partial_b) {
+  extern __shared__ __attribute__((aligned(16))) float sm_rows[];
+  const int G = blockDim.x / F, g = threadIdx.x / F, f = threadIdx.x - g * F;
+  float w0[R], w1[R], w2[R], g0[R], g1[R], g2[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    w0[r] = Wf[(size_t)f * R + r];
+    w1[r] = Wf[(size_t)(F + f) * R + r];
+    w2[r] = Wf[(size_t)(2 * F + f) * R + r];
+    g0[r] = g1[r] = g2[r] = 0.0f;
+  }
+  const float b0 = bf[f], b1 = bf[F + f], b2 = bf[2 * F + f];
+  float gb0 = 0.0f, gb1 = 0.0f, gb2 = 0.0f;
+  for (int m = blockIdx.x; m < B; m += gridDim.x) {
+    const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0;
+    float* gqs = sm_rows;                  // [n][F]   dq_out rows
+    float* gms = sm_rows + (size_t)n * F;  // [n][3F]  dmu_out rows
+    __syncthreads();  // the previous molecule's rows are no longer read
+    {
+      const f32x4* a = reinterpret_cast<const f32x4*>(dq_out + (size_t)a0 * F);
+      const f32x4* b4 = reinterpret_cast<const f32x4*>(dmu_out + (size_t)a0 * 3 * F);
+      for (int t = threadIdx.x; t < n * F / 4; t += blockDim.x) reinterpret_cast<f32x4*>(gqs)[t] = a[t];
+      for (int t = threadIdx.x; t < n * 3 * F / 4; t += blockDim.x) reinterpret_cast<f32x4*>(gms)[t] = b4[t];
+    }
+    __syncthreads();
+    for (int ja = g; ja < n; ja += G) {
+      const int j = a0 + ja;
+      const float* __restrict__ xj = xc + (size_t)j * 3 * F;
+      const float* __restrict__ mj = mu + (size_t)j * 3 * F;
+      const float xj0 = xj[f], xj1 = xj[F + f], xj2 = xj[2 * F + f];
+      const float m0 = mj[f], m1 = mj[F + f], m2 = mj[2 * F + f];
+      float dx0 = 0.0f, dx1 = 0.0f, dx2 = 0.0f, dmj0 = 0.0f, dmj1 = 0.0f, dmj2 = 0.0f;
+      const int64_t p0 = inc_ptr[j], p1 = inc_ptr[j + 1];
+      for (int64_t p = p0; p < p1; ++p) {
+        const int e = __builtin_amdgcn_readfirstlane(inc_idx[p]);
+        const int il = (int)idx_i[e] - a0;
+        const float* __restrict__ ph = phi + (size_t)e * R;
+        float pr[R];
+        float W0 = b0, W1 = b1, W2 = b2;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          pr[r] = ph[r];
+          W0 = fmaf(pr[r], w0[r], W0);
+          W1 = fmaf(pr[r], w1[r], W1);
+          W2 = fmaf(pr[r], w2[r], W2);
+        }
+        const float fc = fcut[e];
+        W0 *= fc; W1 *= fc; W2 *= fc;
+        const float gq = gqs[(size_t)il * F + f];
+        const float* gm = gms + (size_t)il * 3 * F;
+        const float gm0 = gm[f], gm1 = gm[F + f], gm2 = gm[2 * F + f];
+        const float s1 = gm0 * dir[3 * e] + gm1 * dir[3 * e + 1] + gm2 * dir[3 * e + 2];
+        const float s2 = gm0 * m0 + gm1 * m1 + gm2 * m2;
+        dx0 = fmaf(gq, W0, dx0);
+        dx1 = fmaf(s1, W1, dx1);
+        dx2 = fmaf(s2, W2, dx2);
+        const float x2 = W2 * xj2;
+        dmj0 = fmaf(gm0, x2, dmj0);
+        dmj1 = fmaf(gm1, x2, dmj1);
+        dmj2 = fmaf(gm2, x2, dmj2);
+        // W_c = (b_c + sum_r phi_r w_c[r]) * fcut
+        const float t0 = gq * xj0 * fc, t1 = s1 * xj1 * fc, t2 = s2 * xj2 * fc;
+        gb0 += t0; gb1 += t1; gb2 += t2;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          g0[r] = fmaf(t0, pr[r], g0[r]);
+          g1[r] = fmaf(t1, pr[r], g1[r]);
+          g2[r] = fmaf(t2, pr[r], g2[r]);
+        }
+      }
+      float* dxo = dxc + (size_t)j * 3 * F;
+      dxo[f] = dx0; dxo[F + f] = dx1; dxo[2 * F + f] = dx2;
+      float* dmo = dmu_in + (size_t)j * 3 * F;
+      const float* gmj = gms + (size_t)ja * 3 * F;
+      dmo[f] = gmj[f] + dmj0;           // residual mu_out = mu + dmu  plus the edges that read mu[j]
+      dmo[F + f] = gmj[F + f] + dmj1;
+      dmo[2 * F + f] = gmj[2 * F + f] + dmj2;
+    }
+  }
+  // one partial per block: the groups' sums added in group order through LDS (3F (R + 1) floats <= the row stage)
+  __syncthreads();
+  float* red = sm_rows;  // [3F][R + 1]
+  for (int gg = 0; gg < G; ++gg) {
+    if (g == gg) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float* p0 = red + (size_t)f * (R + 1) + r;
+        float* p1 = red + (size_t)(F + f) * (R + 1) + r;
+        float* p2 = red + (size_t)(2 * F + f) * (R + 1) + r;
+        if (gg == 0) { *p0 = g0[r]; *p1 = g1[r]; *p2 = g2[r]; }
+        else { *p0 += g0[r]; *p1 += g1[r]; *p2 += g2[r]; }
+      }
+      float* q0 = red + (size_t)f * (R + 1) + R;
+      float* q1 = red + (size_t)(F + f) * (R + 1) + R;
+      float* q2 = red + (size_t)(2 * F + f) * (R + 1) + R;
+      if (gg == 0) { *q0 = gb0; *q1 = gb1; *q2 = gb2; }
+      else { *q0 += gb0; *q1 += gb1; *q2 += gb2; }
+    }
+    __syncthreads();
+  }
+  if (g == 0) {
+    float* pw = partial_w + (size_t)blockIdx.x * 3 * F * R;
+    float* pb = partial_b + (size_t)blockIdx.x * 3 * F;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) pw[(size_t)(c * F + f) * R + r] = red[(size_t)(c * F + f) * (R + 1) + r];
+      pb[c * F + f] = red[(size_t)(c * F + f) * (R + 1) + R];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ mixing
 // mm = mu_channel_mix(mu) [N][3][2F] -> ctx = [q, |mu_V|] [N][2F], dot = sum_xyz mu_V*mu_W  (painn.py:100-104,110)
 __global__ void k_painn_mix_pre_fwd(const float* __restrict__ q, const float* __restrict__ mm, int64_t N, int F,
@@ -341,6 +538,80 @@ extern "C" int geossl_painn_interaction_bwd(const float* dq_out, const float* dm
                           idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, (int)N, F, dxc, dmu_in, pw, pb);
   GEOSSL_CHECK_LAUNCH();
   // fixed-order two-stage sums of the per-block partials (64 outputs x 4 slices of the block list per reduction block)
+  GeosslReduceBatch rb;
+  for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = nullptr;
+  rb.out[0] = dWf;
+  hipLaunchKernelGGL(geossl::k_reduce_partials, dim3((3 * F * R + 63) / 64, 1), dim3(256), 0, stream, rb, pw, nb, 3 * F * R,
+                     3 * F * R, 3 * F * R, 1, accumulate);
+  rb.out[0] = dbf;
+  hipLaunchKernelGGL(geossl::k_reduce_partials, dim3((3 * F + 63) / 64, 1), dim3(256), 0, stream, rb, pb, nb, 3 * F, 3 * F,
+                     3 * F, 1, accumulate);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- the same two entry points with the molecule layout (mol_ptr [B+1] int32, max_n): one block per molecule.
+// F must be a multiple of 64 and the molecule's rows must fit the LDS; otherwise the per-atom kernels are used.
+static inline bool painn_mol_ok(int F, int max_n, size_t floats_per_atom) {
+  static const bool per_atom = getenv("GEOSSL_PAINN_PER_ATOM") != nullptr;  // the per-atom kernels, for A/B runs
+  return !per_atom && (F == 64 || F == 128) && max_n >= 1 && (size_t)max_n * floats_per_atom * sizeof(float) <= 150 * 1024;
+}
+#define GEOSSL_PAINN_BWD_MOL_BLOCKS 256  // one 512-thread block per CU (its register budget); one filter-gradient partial per block
+extern "C" int geossl_painn_interaction_fwd_mol(const float* q, const float* mu, const float* xc, const int64_t* idx_j,
+                                                const int64_t* inc_ptr, const int32_t* inc_idx, const float* phi,
+                                                const float* fcut, const float* dir, const float* Wf, const float* bf,
+                                                const int32_t* mol_ptr, int64_t B, int max_n, int64_t N, int F, int R,
+                                                float* q_out, float* mu_out, hipStream_t stream) {
+  if (N <= 0 || B <= 0) return 0;
+  if (!painn_mol_ok(F, max_n, (size_t)6 * F))
+    return geossl_painn_interaction_fwd(q, mu, xc, idx_j, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, N, F, R, q_out, mu_out,
+                                        stream);
+  const size_t lds = (size_t)max_n * 6 * F * sizeof(float);
+#define LAUNCH_FWD_MOL(RV)                                                                                         \
+  do {                                                                                                             \
+    allow_big_lds(&k_painn_interaction_fwd_mol<RV>);                                                               \
+    hipLaunchKernelGGL((k_painn_interaction_fwd_mol<RV>), dim3((unsigned)B), dim3(4 * F), lds, stream, q, mu, xc,  \
+                       idx_j, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, mol_ptr, F, q_out, mu_out);                \
+  } while (0)
+  if (R == 20) LAUNCH_FWD_MOL(20); else if (R == 16) LAUNCH_FWD_MOL(16); else if (R == 8) LAUNCH_FWD_MOL(8);
+  else if (R == 32) LAUNCH_FWD_MOL(32); else return (int)hipErrorInvalidValue;
+#undef LAUNCH_FWD_MOL
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int64_t geossl_painn_interaction_bwd_mol_workspace_floats(int64_t N, int64_t B, int F, int R) {
+  const int64_t a = geossl_painn_interaction_bwd_workspace_floats(N, F, R);  // (the per-atom form may be chosen)
+  const int64_t nb = B < GEOSSL_PAINN_BWD_MOL_BLOCKS ? B : GEOSSL_PAINN_BWD_MOL_BLOCKS;
+  const int64_t b = nb * (3 * (int64_t)F * R + 3 * F);
+  return a > b ? a : b;
+}
+extern "C" int geossl_painn_interaction_bwd_mol(const float* dq_out, const float* dmu_out, const float* mu,
+                                                const float* xc, const int64_t* idx_i, const int64_t* inc_ptr,
+                                                const int32_t* inc_idx, const float* phi, const float* fcut,
+                                                const float* dir, const float* Wf, const float* bf,
+                                                const int32_t* mol_ptr, int64_t B, int max_n, int64_t N, int F, int R,
+                                                float* dxc, float* dmu_in, float* dWf, float* dbf, float* workspace,
+                                                int accumulate, hipStream_t stream) {
+  if (N <= 0 || B <= 0) return 0;
+  size_t stage = (size_t)max_n * 4 * F, red = (size_t)3 * F * (R + 1);
+  if (!painn_mol_ok(F, max_n, (size_t)4 * F) || red * sizeof(float) > 150 * 1024)
+    return geossl_painn_interaction_bwd(dq_out, dmu_out, mu, xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, N, F, R,
+                                        dxc, dmu_in, dWf, dbf, workspace, accumulate, stream);
+  const int nb = (int)(B < GEOSSL_PAINN_BWD_MOL_BLOCKS ? B : GEOSSL_PAINN_BWD_MOL_BLOCKS);
+  const size_t lds = (stage > red ? stage : red) * sizeof(float);
+  float* pw = workspace;
+  float* pb = workspace + (size_t)nb * 3 * F * R;
+#define LAUNCH_BWD_MOL(RV)                                                                                          \
+  do {                                                                                                              \
+    allow_big_lds(&k_painn_interaction_bwd_mol<RV>);                                                                \
+    hipLaunchKernelGGL((k_painn_interaction_bwd_mol<RV>), dim3(nb), dim3(4 * F), lds, stream, dq_out, dmu_out, mu,  \
+                       xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, mol_ptr, (int)B, max_n, F, dxc, dmu_in, \
+                       pw, pb);                                                                                     \
+  } while (0)
+  if (R == 20) LAUNCH_BWD_MOL(20); else if (R == 16) LAUNCH_BWD_MOL(16); else if (R == 8) LAUNCH_BWD_MOL(8);
+  else if (R == 32) LAUNCH_BWD_MOL(32); else return (int)hipErrorInvalidValue;
+#undef LAUNCH_BWD_MOL
+  GEOSSL_CHECK_LAUNCH();
   GeosslReduceBatch rb;
   for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = nullptr;
   rb.out[0] = dWf;

@@ -339,6 +339,21 @@ int geossl_painn_interaction_bwd(const float* dq_out, const float* dmu_out, cons
                                  const float* fcut, const float* dir, const float* Wf, const float* bf, int64_t N, int F,
                                  int R, float* dxc, float* dmu_in, float* dWf, float* dbf, float* workspace,
                                  int accumulate, hipStream_t stream);
+/* The same two passes with the molecule layout (mol_ptr [B+1] int32, max_n atoms in the largest molecule): one block
+ * per molecule, the rows every edge of the molecule reads staged in LDS once (results identical bit for bit; falls back
+ * to the per-atom kernels when F is not 64 / 128 or a molecule's rows do not fit the LDS).                      */
+int geossl_painn_interaction_fwd_mol(const float* q, const float* mu, const float* xc, const int64_t* idx_j,
+                                     const int64_t* inc_ptr, const int32_t* inc_idx, const float* phi, const float* fcut,
+                                     const float* dir, const float* Wf, const float* bf, const int32_t* mol_ptr,
+                                     int64_t B, int max_n, int64_t N, int F, int R, float* q_out, float* mu_out,
+                                     hipStream_t stream);
+int64_t geossl_painn_interaction_bwd_mol_workspace_floats(int64_t N, int64_t B, int F, int R);
+int geossl_painn_interaction_bwd_mol(const float* dq_out, const float* dmu_out, const float* mu, const float* xc,
+                                     const int64_t* idx_i, const int64_t* inc_ptr, const int32_t* inc_idx,
+                                     const float* phi, const float* fcut, const float* dir, const float* Wf,
+                                     const float* bf, const int32_t* mol_ptr, int64_t B, int max_n, int64_t N, int F,
+                                     int R, float* dxc, float* dmu_in, float* dWf, float* dbf, float* workspace,
+                                     int accumulate, hipStream_t stream);
 int geossl_painn_mix_pre_fwd(const float* q, const float* mm, int64_t N, int F, float eps, float* ctx, float* dot,
                              hipStream_t stream);
 int geossl_painn_mix_post_fwd(const float* q, const float* mu, const float* mm, const float* xx, const float* dot,
