@@ -207,6 +207,39 @@ __global__ __launch_bounds__(128) void k_painn_interaction_bwd(
 // LDS.  The atoms of the molecule are dealt to the block's thread groups (F threads each, one feature per thread);
 // the sums of an atom are formed by one thread in the edge order of the incidence list - bit for bit the per-atom
 // kernels' results.
+// Per-wave stage of the edges of one atom: lane k fetches the data of the k-th edge of the chunk with ordinary vector
+// loads - its radial-basis row, cutoff value, direction and the atom at the other end - and writes them as one row of
+// EROW floats; the edge loop then reads a row with broadcast LDS reads.  (Fetched through the scalar unit inside the
+// loop, every edge paid a chain of L2 round trips: index -> row -> LDS address; the loop ran at ~1.2 us per edge.)
+constexpr int ECHUNK = 16;               // edges per chunk (an atom has ~16 incoming edges at 5 A)
+template <int R>
+struct EdgeStage {
+  static constexpr int EROW = ((R + 5 + 3) / 4) * 4;  // phi[R], fcut, dir[3], other atom (int bits), padded to 16 bytes
+  // lanes 0 .. cnt-1: edge inc_idx[pc + lane] -> row `lane` of the wave's stage
+  static __device__ __forceinline__ void fill(float* __restrict__ stage, int lane, int cnt, int64_t pc,
+                                              const int32_t* __restrict__ inc_idx, const int64_t* __restrict__ idx_other,
+                                              const float* __restrict__ phi, const float* __restrict__ fcut,
+                                              const float* __restrict__ dir) {
+    if (lane < cnt) {
+      const int e = inc_idx[pc + lane];
+      float* row = stage + lane * EROW;
+      const float* __restrict__ p = phi + (size_t)e * R;
+      if constexpr (R % 4 == 0) {
+#pragma unroll
+        for (int r = 0; r < R; r += 4) *reinterpret_cast<f32x4*>(row + r) = *reinterpret_cast<const f32x4*>(p + r);
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) row[r] = p[r];
+      }
+      row[R] = fcut[e];
+      row[R + 1] = dir[3 * e];
+      row[R + 2] = dir[3 * e + 1];
+      row[R + 3] = dir[3 * e + 2];
+      row[R + 4] = __int_as_float((int)idx_other[e]);
+    }
+  }
+};
+
 template <int R>
 __global__ __launch_bounds__(512) void k_painn_interaction_fwd_mol(
     const float* __restrict__ q, const float* __restrict__ mu, const float* __restrict__ xc,
@@ -219,6 +252,7 @@ __global__ __launch_bounds__(512) void k_painn_interaction_fwd_mol(
   const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0;
   float* xs = sm_rows;                     // [n][3F]
   float* ms = sm_rows + (size_t)n * 3 * F;  // [n][3F]
+  float* estage = sm_rows + (size_t)n * 6 * F + (threadIdx.x >> 6) * (ECHUNK * EdgeStage<R>::EROW);  // this wave's
   {
     const f32x4* xg = reinterpret_cast<const f32x4*>(xc + (size_t)a0 * 3 * F);
     const f32x4* mg = reinterpret_cast<const f32x4*>(mu + (size_t)a0 * 3 * F);
@@ -242,27 +276,31 @@ __global__ __launch_bounds__(512) void k_painn_interaction_fwd_mol(
     const int i = a0 + ia;
     float dq = 0.0f, dm0 = 0.0f, dm1 = 0.0f, dm2 = 0.0f;
     const int64_t p0 = inc_ptr[i], p1 = inc_ptr[i + 1];
-    for (int64_t p = p0; p < p1; ++p) {
-      const int e = __builtin_amdgcn_readfirstlane(inc_idx[p]);  // uniform: edge data comes through scalar loads
-      const int jl = (int)idx_j[e] - a0;
-      const float* __restrict__ ph = phi + (size_t)e * R;
+    const int lane_ = threadIdx.x & 63;
+    for (int64_t pc = p0; pc < p1; pc += ECHUNK) {
+     const int cnt = (int)min((int64_t)ECHUNK, p1 - pc);
+     EdgeStage<R>::fill(estage, lane_, cnt, pc, inc_idx, idx_j, phi, fcut, dir);  // (same wave writes and reads: in order)
+     for (int kk = 0; kk < cnt; ++kk) {
+      const float* row = estage + kk * EdgeStage<R>::EROW;             // broadcast reads
+      const int jl = __float_as_int(row[R + 4]) - a0;
       float W0 = b0, W1 = b1, W2 = b2;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float pr = ph[r];
+        const float pr = row[r];
         W0 = fmaf(pr, w0[r], W0);
         W1 = fmaf(pr, w1[r], W1);
         W2 = fmaf(pr, w2[r], W2);
       }
-      const float fc = fcut[e];
+      const float fc = row[R];
       W0 *= fc; W1 *= fc; W2 *= fc;                                  // painn.py:241
       const float* xj = xs + (size_t)jl * 3 * F;
       const float x0 = W0 * xj[f], x1 = W1 * xj[F + f], x2 = W2 * xj[2 * F + f];  // :56
       const float* mj = ms + (size_t)jl * 3 * F;
       dq += x0;                                                      // :59
-      dm0 += x1 * dir[3 * e] + x2 * mj[f];                           // :60-61
-      dm1 += x1 * dir[3 * e + 1] + x2 * mj[F + f];
-      dm2 += x1 * dir[3 * e + 2] + x2 * mj[2 * F + f];
+      dm0 += x1 * row[R + 1] + x2 * mj[f];                           // :60-61
+      dm1 += x1 * row[R + 2] + x2 * mj[F + f];
+      dm2 += x1 * row[R + 3] + x2 * mj[2 * F + f];
+     }
     }
     q_out[(size_t)i * F + f] = q[(size_t)i * F + f] + dq;            // :63
     float* mo = mu_out + (size_t)i * 3 * F;
@@ -299,6 +337,7 @@ __global__ __launch_bounds__(512) void k_painn_interaction_bwd_mol(
     const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0;
     float* gqs = sm_rows;                  // [n][F]   dq_out rows
     float* gms = sm_rows + (size_t)n * F;  // [n][3F]  dmu_out rows
+    float* estage = sm_rows + (size_t)max_n * 4 * F + (threadIdx.x >> 6) * (ECHUNK * EdgeStage<R>::EROW);  // this wave's
     __syncthreads();  // the previous molecule's rows are no longer read
     {
       const f32x4* a = reinterpret_cast<const f32x4*>(dq_out + (size_t)a0 * F);
@@ -315,25 +354,28 @@ __global__ __launch_bounds__(512) void k_painn_interaction_bwd_mol(
       const float m0 = mj[f], m1 = mj[F + f], m2 = mj[2 * F + f];
       float dx0 = 0.0f, dx1 = 0.0f, dx2 = 0.0f, dmj0 = 0.0f, dmj1 = 0.0f, dmj2 = 0.0f;
       const int64_t p0 = inc_ptr[j], p1 = inc_ptr[j + 1];
-      for (int64_t p = p0; p < p1; ++p) {
-        const int e = __builtin_amdgcn_readfirstlane(inc_idx[p]);
-        const int il = (int)idx_i[e] - a0;
-        const float* __restrict__ ph = phi + (size_t)e * R;
+      const int lane_ = threadIdx.x & 63;
+      for (int64_t pc = p0; pc < p1; pc += ECHUNK) {
+       const int cnt = (int)min((int64_t)ECHUNK, p1 - pc);
+       EdgeStage<R>::fill(estage, lane_, cnt, pc, inc_idx, idx_i, phi, fcut, dir);
+       for (int kk = 0; kk < cnt; ++kk) {
+        const float* row = estage + kk * EdgeStage<R>::EROW;
+        const int il = __float_as_int(row[R + 4]) - a0;
         float pr[R];
         float W0 = b0, W1 = b1, W2 = b2;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          pr[r] = ph[r];
+          pr[r] = row[r];
           W0 = fmaf(pr[r], w0[r], W0);
           W1 = fmaf(pr[r], w1[r], W1);
           W2 = fmaf(pr[r], w2[r], W2);
         }
-        const float fc = fcut[e];
+        const float fc = row[R];
         W0 *= fc; W1 *= fc; W2 *= fc;
         const float gq = gqs[(size_t)il * F + f];
         const float* gm = gms + (size_t)il * 3 * F;
         const float gm0 = gm[f], gm1 = gm[F + f], gm2 = gm[2 * F + f];
-        const float s1 = gm0 * dir[3 * e] + gm1 * dir[3 * e + 1] + gm2 * dir[3 * e + 2];
+        const float s1 = gm0 * row[R + 1] + gm1 * row[R + 2] + gm2 * row[R + 3];
         const float s2 = gm0 * m0 + gm1 * m1 + gm2 * m2;
         dx0 = fmaf(gq, W0, dx0);
         dx1 = fmaf(s1, W1, dx1);
@@ -351,6 +393,7 @@ __global__ __launch_bounds__(512) void k_painn_interaction_bwd_mol(
           g1[r] = fmaf(t1, pr[r], g1[r]);
           g2[r] = fmaf(t2, pr[r], g2[r]);
         }
+       }
       }
       float* dxo = dxc + (size_t)j * 3 * F;
       dxo[f] = dx0; dxo[F + f] = dx1; dxo[2 * F + f] = dx2;
@@ -566,7 +609,8 @@ extern "C" int geossl_painn_interaction_fwd_mol(const float* q, const float* mu,
   if (!painn_mol_ok(F, max_n, (size_t)6 * F))
     return geossl_painn_interaction_fwd(q, mu, xc, idx_j, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, N, F, R, q_out, mu_out,
                                         stream);
-  const size_t lds = (size_t)max_n * 6 * F * sizeof(float);
+  const size_t estage = (size_t)(4 * F / 64) * ECHUNK * (((R + 5 + 3) / 4) * 4);  // per-wave edge stages (floats)
+  const size_t lds = ((size_t)max_n * 6 * F + estage) * sizeof(float);
 #define LAUNCH_FWD_MOL(RV)                                                                                         \
   do {                                                                                                             \
     allow_big_lds(&k_painn_interaction_fwd_mol<RV>);                                                               \
@@ -598,7 +642,8 @@ extern "C" int geossl_painn_interaction_bwd_mol(const float* dq_out, const float
     return geossl_painn_interaction_bwd(dq_out, dmu_out, mu, xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, N, F, R,
                                         dxc, dmu_in, dWf, dbf, workspace, accumulate, stream);
   const int nb = (int)(B < GEOSSL_PAINN_BWD_MOL_BLOCKS ? B : GEOSSL_PAINN_BWD_MOL_BLOCKS);
-  const size_t lds = (stage > red ? stage : red) * sizeof(float);
+  const size_t estage = (size_t)(4 * F / 64) * ECHUNK * (((R + 5 + 3) / 4) * 4);  // per-wave edge stages (floats)
+  const size_t lds = ((stage + estage) > red ? (stage + estage) : red) * sizeof(float);
   float* pw = workspace;
   float* pb = workspace + (size_t)nb * 3 * F * R;
 #define LAUNCH_BWD_MOL(RV)                                                                                          \
