@@ -245,14 +245,24 @@ __global__ __launch_bounds__(512) void k_painn_interaction_fwd_mol(
     const float* __restrict__ q, const float* __restrict__ mu, const float* __restrict__ xc,
     const int64_t* __restrict__ idx_j, const int64_t* __restrict__ inc_ptr, const int32_t* __restrict__ inc_idx,
     const float* __restrict__ phi, const float* __restrict__ fcut, const float* __restrict__ dir,
-    const float* __restrict__ Wf, const float* __restrict__ bf, const int32_t* __restrict__ mol_ptr, int F,
-    float* __restrict__ q_out, float* __restrict__ mu_out) {
+    const float* __restrict__ Wf, const float* __restrict__ bf, const int32_t* __restrict__ mol_ptr, int B, int max_n,
+    int F, float* __restrict__ q_out, float* __restrict__ mu_out) {
   extern __shared__ __attribute__((aligned(16))) float sm_rows[];
-  const int m = blockIdx.x;
+  const int G = blockDim.x / F, g = threadIdx.x / F, f = threadIdx.x - g * F;  // F is a multiple of 64: g is wave-uniform
+  float w0[R], w1[R], w2[R];  // this thread's rows of the filter network: once per (persistent) block
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    w0[r] = Wf[(size_t)f * R + r];
+    w1[r] = Wf[(size_t)(F + f) * R + r];
+    w2[r] = Wf[(size_t)(2 * F + f) * R + r];
+  }
+  const float b0 = bf[f], b1 = bf[F + f], b2 = bf[2 * F + f];
+  float* estage = sm_rows + (size_t)max_n * 6 * F + (threadIdx.x >> 6) * (ECHUNK * EdgeStage<R>::EROW);  // this wave's
+  for (int m = blockIdx.x; m < B; m += gridDim.x) {
   const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0;
   float* xs = sm_rows;                     // [n][3F]
   float* ms = sm_rows + (size_t)n * 3 * F;  // [n][3F]
-  float* estage = sm_rows + (size_t)n * 6 * F + (threadIdx.x >> 6) * (ECHUNK * EdgeStage<R>::EROW);  // this wave's
+  __syncthreads();  // the previous molecule's rows are no longer read
   {
     const f32x4* xg = reinterpret_cast<const f32x4*>(xc + (size_t)a0 * 3 * F);
     const f32x4* mg = reinterpret_cast<const f32x4*>(mu + (size_t)a0 * 3 * F);
@@ -262,15 +272,6 @@ __global__ __launch_bounds__(512) void k_painn_interaction_fwd_mol(
       reinterpret_cast<f32x4*>(ms)[t] = mg[t];
     }
   }
-  const int G = blockDim.x / F, g = threadIdx.x / F, f = threadIdx.x - g * F;  // F is a multiple of 64: g is wave-uniform
-  float w0[R], w1[R], w2[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    w0[r] = Wf[(size_t)f * R + r];
-    w1[r] = Wf[(size_t)(F + f) * R + r];
-    w2[r] = Wf[(size_t)(2 * F + f) * R + r];
-  }
-  const float b0 = bf[f], b1 = bf[F + f], b2 = bf[2 * F + f];
   __syncthreads();
   for (int ia = g; ia < n; ia += G) {
     const int i = a0 + ia;
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(512) void k_painn_interaction_fwd_mol(
     mo[f] = mi[f] + dm0;                                             // :64
     mo[F + f] = mi[F + f] + dm1;
     mo[2 * F + f] = mi[2 * F + f] + dm2;
+  }
   }
 }
 
@@ -611,11 +613,14 @@ extern "C" int geossl_painn_interaction_fwd_mol(const float* q, const float* mu,
                                         stream);
   const size_t estage = (size_t)(4 * F / 64) * ECHUNK * (((R + 5 + 3) / 4) * 4);  // per-wave edge stages (floats)
   const size_t lds = ((size_t)max_n * 6 * F + estage) * sizeof(float);
+  // persistent blocks (the filter rows of a thread are fetched once per block): as many as fit the chip
+  const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+  const int nb = (int)(B < 256 * per_cu ? B : 256 * per_cu);
 #define LAUNCH_FWD_MOL(RV)                                                                                         \
   do {                                                                                                             \
     allow_big_lds(&k_painn_interaction_fwd_mol<RV>);                                                               \
-    hipLaunchKernelGGL((k_painn_interaction_fwd_mol<RV>), dim3((unsigned)B), dim3(4 * F), lds, stream, q, mu, xc,  \
-                       idx_j, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, mol_ptr, F, q_out, mu_out);                \
+    hipLaunchKernelGGL((k_painn_interaction_fwd_mol<RV>), dim3((unsigned)nb), dim3(4 * F), lds, stream, q, mu, xc, \
+                       idx_j, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, mol_ptr, (int)B, max_n, F, q_out, mu_out); \
   } while (0)
   if (R == 20) LAUNCH_FWD_MOL(20); else if (R == 16) LAUNCH_FWD_MOL(16); else if (R == 8) LAUNCH_FWD_MOL(8);
   else if (R == 32) LAUNCH_FWD_MOL(32); else return (int)hipErrorInvalidValue;
