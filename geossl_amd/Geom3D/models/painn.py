@@ -234,6 +234,15 @@ class _PaiNNCore(torch.autograd.Function):
         img = ops.prepare_chain(blocks, transB=True) if not os.environ.get("GEOSSL_PAINN_NO_CHAIN") else None
         NB = 11  # blocks per layer, in the order above
 
+        def lin_fan(x, ks, biases, outs):
+            """several F x F blocks of one wide Dense applied to the same rows: one launch (F = 128), else one each"""
+            if img is None or F_ != 128:
+                for k, b_, o_ in zip(ks, biases, outs):
+                    lin(x, None, k, bias=b_, out=o_)
+                return
+            ops.linear_chain(x, [dict(image=img[k], bias=b_, out=o_, same_input=(n_ > 0))
+                                 for n_, (k, b_, o_) in enumerate(zip(ks, biases, outs))])
+
         def lin(x, w, k, bias=None, res=None, out=None):
             if img is None:
                 return ops.linear(x, blocks[k], bias=bias, res=res, out=out)
@@ -246,8 +255,8 @@ class _PaiNNCore(torch.autograd.Function):
             s = torch.empty_like(u)
             call("geossl_silu_fwd", ptr(u), u.numel(), ptr(s), st)
             xc = torch.empty(N, 3 * F_, **f32)
-            for c, oc in enumerate(_split3(xc, F_)):                         # Dense(F, 3F)
-                lin(s, c1w[c * F_:(c + 1) * F_], k0 + 1 + c, bias=c1b[c * F_:(c + 1) * F_], out=oc)
+            lin_fan(s, [k0 + 1 + c for c in range(3)], [c1b[c * F_:(c + 1) * F_] for c in range(3)],
+                    _split3(xc, F_))                                         # Dense(F, 3F)
             q2, mu2 = torch.empty_like(q), torch.empty_like(mu)
             lay = cfg["lay"]  # one block per molecule: the rows its edges read are staged in LDS once
             call("geossl_painn_interaction_fwd_mol", ptr(q), ptr(mu), ptr(xc), ptr(el.idx_j), ptr(inc_ptr), ptr(inc_idx),
@@ -255,8 +264,7 @@ class _PaiNNCore(torch.autograd.Function):
                  ptr(lay.mol_ptr), lay.B, lay.max_n, N, F_, R, ptr(q2), ptr(mu2), st)   # :54-64
             i0w, i0b, i1w, i1b, mw = mix[l]
             mm = torch.empty(3 * N, 2 * F_, **f32)                           # mu_channel_mix        :100
-            for c in range(2):
-                lin(mu2.view(3 * N, F_), mw[c * F_:(c + 1) * F_], k0 + 4 + c, out=mm[:, c * F_:(c + 1) * F_])
+            lin_fan(mu2.view(3 * N, F_), [k0 + 4, k0 + 5], [None, None], [mm[:, :F_], mm[:, F_:]])
             cx, dot = torch.empty(N, 2 * F_, **f32), torch.empty(N, F_, **f32)
             call("geossl_painn_mix_pre_fwd", ptr(q2), ptr(mm), N, F_, cfg["eps"], ptr(cx), ptr(dot), st)  # :101-104
             # Dense(2F, F, silu) :105 - a contraction over 2F columns is two passes of the F-wide row GEMM (the split
@@ -267,8 +275,8 @@ class _PaiNNCore(torch.autograd.Function):
             s1 = torch.empty_like(u1)
             call("geossl_silu_fwd", ptr(u1), u1.numel(), ptr(s1), st)
             xx = torch.empty(N, 3 * F_, **f32)
-            for c, oc in enumerate(_split3(xx, F_)):                         # Dense(F, 3F)
-                lin(s1, i1w[c * F_:(c + 1) * F_], k0 + 8 + c, bias=i1b[c * F_:(c + 1) * F_], out=oc)
+            lin_fan(s1, [k0 + 8 + c for c in range(3)], [i1b[c * F_:(c + 1) * F_] for c in range(3)],
+                    _split3(xx, F_))                                         # Dense(F, 3F)
             q3, mu3 = torch.empty_like(q), torch.empty_like(mu)
             call("geossl_painn_mix_post_fwd", ptr(q2), ptr(mu2), ptr(mm), ptr(xx), ptr(dot), N, F_, ptr(q3), ptr(mu3), st)
             if training:
@@ -340,8 +348,12 @@ class _PaiNNCore(torch.autograd.Function):
             du1 = torch.empty_like(ds1)
             call("geossl_silu_bwd", ptr(sv["u1"]), ptr(ds1), ds1.numel(), ptr(du1), st)
             dctx = torch.empty(N, 2 * F_, **f32)                           # [N][2F] = du1 @ i0w
-            for c in range(2):
-                lin_t(du1, i0w[:, c * F_:(c + 1) * F_], k0 + 6 + c, out=dctx[:, c * F_:(c + 1) * F_])
+            if img is not None and F_ == 128:
+                ops.linear_chain(du1, [dict(image=img[k0 + 6], out=dctx[:, :F_]),
+                                       dict(image=img[k0 + 7], out=dctx[:, F_:], same_input=True)])
+            else:
+                for c in range(2):
+                    lin_t(du1, i0w[:, c * F_:(c + 1) * F_], k0 + 6 + c, out=dctx[:, c * F_:(c + 1) * F_])
             for c in range(2):
                 add(N, F_, 2 * F_, 2 * F_, du1, sv["cx"][:, c * F_:(c + 1) * F_], gi0w[:, c * F_:(c + 1) * F_],
                     gi0b if c == 0 else None)

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libgeossl_hip.so")
 
 MAX_L = 12
 TN_MAX = 32
-EPI_BIAS, EPI_SSP, EPI_RESIDUAL, EPI_MUL_DSSP = 1, 2, 4, 8
+EPI_BIAS, EPI_SSP, EPI_RESIDUAL, EPI_MUL_DSSP, CHAIN_SAME_INPUT = 1, 2, 4, 8, 16
 
 vp = C.c_void_p
 i64 = C.c_int64

@@ -677,6 +677,7 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
     }
     if (s + 1 < NS) {
       request_weights(ch.st[s + 1]);  // the fragments of this stage are dead; in flight across the exchange
+      if (ch.st[s + 1].flags & GEOSSL_CHAIN_SAME_INPUT) continue;  // the next stage reads the same input fragments
       lds_barrier();                  // every wave is done reading this stage's input
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
@@ -703,8 +704,12 @@ int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipS
   static const bool eight_waves = getenv("GEOSSL_CHAIN8") != nullptr;  // the streaming eight-wave form, for A/B runs
   // weight-stationary form: F = 128, and every row-piece offset must fit the 32-bit range of a buffer descriptor
   bool cu_form = KS == 8 && !four_waves && !eight_waves;
-  for (int s2 = 0; s2 < ch.nstage; ++s2)
+  bool same_input = false;
+  for (int s2 = 0; s2 < ch.nstage; ++s2) {
     if ((int64_t)R * ch.st[s2].ld * 4 >= (int64_t)0xFFFFFF00u) cu_form = false;
+    same_input |= (ch.st[s2].flags & GEOSSL_CHAIN_SAME_INPUT) != 0;
+  }
+  if (same_input && (!cu_form || (ch.st[0].flags & GEOSSL_CHAIN_SAME_INPUT))) return (int)hipErrorInvalidValue;
   if (cu_form) {
     static const bool one_per_cu = getenv("GEOSSL_CHAIN_CU1") != nullptr;  // 512-register form, one block per CU
     const int RBV = one_per_cu ? 5 : 3, slots = one_per_cu ? 256 : 512;

@@ -156,7 +156,8 @@ def prepare_chain(weights, transB=True):
 
 def linear_chain(x, stages):
     """Several F -> F Linear layers applied to the rows of x back to back in one launch (geossl_linear_chain).
-    stages: list of dicts with `image` (from prepare_chain) and optional `bias`, `res`, `tprev`, `flags`, `store`
+    stages: list of dicts with `image` (from prepare_chain) and optional `bias`, `res`, `tprev`, `flags`, `store`,
+    `same_input` (F = 128 only: the stage reads the input of the stage before it, not its result)
     (default True: the stage's result is written to a new [R, F] tensor).  Returns the list of stored results
     (None where store is False)."""
     R, F = x.shape  # (x may be a column slice: its row stride is passed)
@@ -176,7 +177,7 @@ def linear_chain(x, stages):
             assert a.stride(0) == ld and a.stride(1) == 1 and a.size(0) == R and a.size(1) == F
         st.image, st.bias, st.res, st.tprev, st.out = (ptr(sd["image"]), ptr(sd.get("bias")), ptr(sd.get("res")),
                                                        ptr(sd.get("tprev")), ptr(o))
-        st.ld, st.flags = ld, int(sd.get("flags", 0))
+        st.ld, st.flags = ld, int(sd.get("flags", 0)) | (_lib.CHAIN_SAME_INPUT if sd.get("same_input") else 0)
         outs.append(o)
     call("geossl_linear_chain", ptr(x), x.stride(0), C.byref(ch), R, F, stream())
     return outs

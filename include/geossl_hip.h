@@ -33,6 +33,8 @@ extern "C" {
 #define GEOSSL_EPI_SSP 2       /* ShiftedSoftplus (schnet.py:210-216) */
 #define GEOSSL_EPI_RESIDUAL 4  /* + res[r][n]   (h = h + block(h), schnet.py:97) */
 #define GEOSSL_EPI_MUL_DSSP 8  /* * d ssp/dx recovered from the saved ssp OUTPUT tprev[r][n] (backward) */
+#define GEOSSL_CHAIN_SAME_INPUT 16 /* geossl_linear_chain, F = 128: the stage takes the input of the stage before it
+                                      (several F -> F blocks of one wide Linear in one launch) instead of its result */
 
 int geossl_abi_version(void);
 
