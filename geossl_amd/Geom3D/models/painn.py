@@ -270,8 +270,12 @@ class _PaiNNCore(torch.autograd.Function):
             # Dense(2F, F, silu) :105 - a contraction over 2F columns is two passes of the F-wide row GEMM (the split
             # kernel holds one K <= 128 weight image in LDS): the second adds onto the first through the residual operand
             i0a, i0c = i0w[:, :F_].contiguous(), i0w[:, F_:].contiguous()
-            u1 = lin(cx[:, :F_], i0a, k0 + 6, bias=i0b)
-            lin(cx[:, F_:], i0c, k0 + 7, res=u1, out=u1)
+            if img is not None and F_ == 128:   # both F-wide passes in one launch (the second brings its own input)
+                u1 = ops.linear_chain(cx[:, :F_], [dict(image=img[k0 + 6], bias=i0b, store=False),
+                                                   dict(image=img[k0 + 7], x=cx[:, F_:], add_prev=True)])[1]
+            else:
+                u1 = lin(cx[:, :F_], i0a, k0 + 6, bias=i0b)
+                lin(cx[:, F_:], i0c, k0 + 7, res=u1, out=u1)
             s1 = torch.empty_like(u1)
             call("geossl_silu_fwd", ptr(u1), u1.numel(), ptr(s1), st)
             xx = torch.empty(N, 3 * F_, **f32)
@@ -327,6 +331,29 @@ class _PaiNNCore(torch.autograd.Function):
             return ops.linear_chain(x, [dict(image=img[k], res=res, out=out)])[0]
 
         lay = cfg["lay"]
+        def lin_t_sum(xs_list, ks, res=None):
+            """sum_c xs_c @ W_c (+ res): the passes of a contraction over a wide input, one launch at F = 128"""
+            if img is None or F_ != 128:
+                acc_ = res
+                for x_, k_ in zip(xs_list, ks):
+                    acc_ = lin_t(x_, None, k_, res=acc_)
+                return acc_
+            stages = []
+            for n_, (x_, k_) in enumerate(zip(xs_list, ks)):
+                sd = dict(image=img[k_], store=(n_ == len(ks) - 1))
+                if n_ == 0:
+                    sd["res"] = res
+                    if res is not None and len(ks) > 1:
+                        sd["store"] = False
+                else:
+                    sd.update(x=x_, add_prev=True)
+                stages.append(sd)
+            if res is not None and len(ks) > 1:
+                # the residual belongs to the stage that stores: move it there (the row stride must be the output's)
+                stages[0].pop("res")
+                stages[-1]["res"] = res
+            return ops.linear_chain(xs_list[0], stages)[-1]
+
         nfl = _lib.load().geossl_painn_interaction_bwd_mol_workspace_floats(N, lay.B, F_, R)
         ws = torch.empty(max(int(nfl), 1), **f32)
         keep = []
@@ -341,9 +368,8 @@ class _PaiNNCore(torch.autograd.Function):
             dxx, dmm = torch.empty(N, 3 * F_, **f32), torch.empty(3 * N, 2 * F_, **f32)
             call("geossl_painn_mix_post_bwd", ptr(dq_cur), ptr(dmu_cur), ptr(sv["mm"]), ptr(sv["xx"]), ptr(sv["dot"]), N,
                  F_, ptr(dxx), ptr(dmm), st)
-            ds1 = None
+            ds1 = lin_t_sum(_split3(dxx, F_), [k0 + 8 + c for c in range(3)])
             for c, xs_ in enumerate(_split3(dxx, F_)):
-                ds1 = lin_t(xs_, i1w[c * F_:(c + 1) * F_], k0 + 8 + c, res=ds1)
                 add(N, 3 * F_, F_, F_, xs_, sv["s1"], gi1w[c * F_:(c + 1) * F_], gi1b[c * F_:(c + 1) * F_])
             du1 = torch.empty_like(ds1)
             call("geossl_silu_bwd", ptr(sv["u1"]), ptr(ds1), ds1.numel(), ptr(du1), st)
@@ -361,8 +387,7 @@ class _PaiNNCore(torch.autograd.Function):
             call("geossl_painn_mix_pre_bwd", ptr(dq_cur), ptr(dctx), ptr(sv["cx"]), ptr(sv["mm"]), N, F_, ptr(dq2),
                  ptr(dmm), st)
             # d mu (after interaction): contraction over the 2F columns of dmm in two F-wide passes
-            dmu2 = lin_t(dmm[:, :F_], mw[:F_], k0 + 4, res=dmu_cur.view(3 * N, F_))
-            lin_t(dmm[:, F_:], mw[F_:], k0 + 5, res=dmu2, out=dmu2)
+            dmu2 = lin_t_sum([dmm[:, :F_], dmm[:, F_:]], [k0 + 4, k0 + 5], res=dmu_cur.view(3 * N, F_))
             for c in range(2):
                 add(3 * N, 2 * F_, F_, F_, dmm[:, c * F_:(c + 1) * F_], sv["mu2"].view(3 * N, F_),
                     gmw[c * F_:(c + 1) * F_], None)
@@ -372,9 +397,8 @@ class _PaiNNCore(torch.autograd.Function):
                  ptr(inc_ptr), ptr(inc_idx), ptr(phi), ptr(fcut), ptr(dirv), ptr(ps[1][l * 3 * F_:(l + 1) * 3 * F_]),
                  ptr(ps[2][l * 3 * F_:(l + 1) * 3 * F_]), ptr(lay.mol_ptr), lay.B, lay.max_n, N, F_, R, ptr(dxc), ptr(dmu_in),
                  ptr(g_fw[l * 3 * F_:(l + 1) * 3 * F_]), ptr(g_fb[l * 3 * F_:(l + 1) * 3 * F_]), ptr(ws), acc, st)
-            ds = None
+            ds = lin_t_sum(_split3(dxc, F_), [k0 + 1 + c for c in range(3)])
             for c, xs_ in enumerate(_split3(dxc, F_)):
-                ds = lin_t(xs_, c1w[c * F_:(c + 1) * F_], k0 + 1 + c, res=ds)
                 add(N, 3 * F_, F_, F_, xs_, sv["s"], gc1w[c * F_:(c + 1) * F_], gc1b[c * F_:(c + 1) * F_])
             du = torch.empty_like(ds)
             call("geossl_silu_bwd", ptr(sv["u"]), ptr(ds), ds.numel(), ptr(du), st)

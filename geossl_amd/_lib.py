@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libgeossl_hip.so")
 
 MAX_L = 12
 TN_MAX = 32
-EPI_BIAS, EPI_SSP, EPI_RESIDUAL, EPI_MUL_DSSP, CHAIN_SAME_INPUT = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_SSP, EPI_RESIDUAL, EPI_MUL_DSSP, CHAIN_SAME_INPUT, CHAIN_NEW_INPUT, CHAIN_ADD_PREV = 1, 2, 4, 8, 16, 32, 64
 
 vp = C.c_void_p
 i64 = C.c_int64
@@ -33,7 +33,8 @@ CHAIN_MAX = 3
 
 
 class ChainStage(C.Structure):
-    _fields_ = [("image", vp), ("bias", vp), ("res", vp), ("tprev", vp), ("out", vp), ("ld", i32), ("flags", i32)]
+    _fields_ = [("image", vp), ("bias", vp), ("res", vp), ("tprev", vp), ("out", vp), ("ld", i32), ("flags", i32),
+                ("xin", vp), ("ldxin", i32), ("pad_", i32)]
 
 
 class Chain(C.Structure):

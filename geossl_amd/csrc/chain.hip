@@ -525,9 +525,11 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
   constexpr int KS = 8, F = 128;
   constexpr int RBF = KS * 3 * 64;      // u32x4 per row block of fragments
 #ifndef CHAIN_CU_NEB2
-#define CHAIN_CU_NEB2 2
+#define CHAIN_CU_NEB2 1
 #endif
-  constexpr int NEB = WPS == 1 ? 2 : CHAIN_CU_NEB2;  // buffers of epilogue operands (2: requested one row block ahead)
+  // buffers of epilogue operands (2: requested one row block ahead; measured equal with two blocks per CU, where the
+  // 32 registers are better left to the allocator)
+  constexpr int NEB = WPS == 1 ? 2 : CHAIN_CU_NEB2;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
   u32x4* xbuf = reinterpret_cast<u32x4*>(smem_raw);                       // [RB][KS][3][64]
   float* bias_s = reinterpret_cast<float*>(xbuf + (size_t)RB * RBF);      // [NS][F]
@@ -557,14 +559,14 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
     const int s = i / F;
     bias_s[i] = ch.st[s].bias != nullptr ? ch.st[s].bias[i - s * F] : 0.0f;
   }
-  // ---- X: this wave's 32 columns (k-steps 2m, 2m+1) of every row block, split, into the fragment buffer
-  {
+  // ---- input rows: this wave's 32 columns (k-steps 2m, 2m+1) of every row block, split, into the fragment buffer
+  auto load_input = [&](const float* __restrict__ Xp, int ldxp) __attribute__((always_inline)) {
     f32x4 raw[RB][4];
-    const char* xb = reinterpret_cast<const char*>(X) + 128 * m;
+    const char* xb = reinterpret_cast<const char*>(Xp) + 128 * m;
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const uint32_t rowc = (uint32_t)min(32 * (rb0 + min(i, nloc - 1)) + j, R - 1);
-      const uint32_t xo = rowc * (uint32_t)ldx * 4u + 16u * kh;
+      const uint32_t xo = rowc * (uint32_t)ldxp * 4u + 16u * kh;
 #pragma unroll
       for (int q = 0; q < 4; ++q) raw[i][q] = *reinterpret_cast<const f32x4*>(xb + 32 * q + xo);
     }
@@ -579,12 +581,13 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
         xd[192] = f1.h; xd[256] = f1.m; xd[320] = f1.l;
       }
     }
-  }
+  };
+  load_input(X, ldx);
   lds_barrier();  // biases staged, fragments published
+  float vout[RB][16];  // a stage's results (this wave's column block of every row block)
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const GeosslChainStage st = ch.st[s];
-    float vout[RB][16];
     f32x4 tp[NEB][4], rs[NEB][4];
     // Every vector-memory instruction of the stage loop is issued unconditionally (buffer addressing: a null operand
     // is a zero-sized buffer whose loads return 0 and whose stores are dropped, rows past R get an out-of-range
@@ -647,8 +650,13 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
         // epilogue in registers: lane = row, register 4q + e = column 32m + 8q + 4kh + e
         const f32x4(&t)[4] = tp[NEB == 2 ? (i & 1) : 0];
         const f32x4(&r)[4] = rs[NEB == 2 ? (i & 1) : 0];
+        if (s > 0 && (st.flags & GEOSSL_CHAIN_ADD_PREV)) {  // + the result of the stage before (another pass over a wide input)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) vout[i][e] = acc[e];
+          for (int e = 0; e < 16; ++e) vout[i][e] += acc[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) vout[i][e] = acc[e];
+        }
         if (st.flags & GEOSSL_EPI_SSP) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) vout[i][e] = ssp(vout[i][e]);
@@ -679,6 +687,11 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
       request_weights(ch.st[s + 1]);  // the fragments of this stage are dead; in flight across the exchange
       if (ch.st[s + 1].flags & GEOSSL_CHAIN_SAME_INPUT) continue;  // the next stage reads the same input fragments
       lds_barrier();                  // every wave is done reading this stage's input
+      if (ch.st[s + 1].flags & GEOSSL_CHAIN_NEW_INPUT) {  // the next stage brings its own input rows
+        load_input(ch.st[s + 1].xin, ch.st[s + 1].ldxin);
+        lds_barrier();
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         if (i < nloc) {  // registers 0..7 / 8..15 are k-steps 2m / 2m+1 of the next stage (kperm)
@@ -707,9 +720,14 @@ int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipS
   bool same_input = false;
   for (int s2 = 0; s2 < ch.nstage; ++s2) {
     if ((int64_t)R * ch.st[s2].ld * 4 >= (int64_t)0xFFFFFF00u) cu_form = false;
-    same_input |= (ch.st[s2].flags & GEOSSL_CHAIN_SAME_INPUT) != 0;
+    same_input |= (ch.st[s2].flags & (GEOSSL_CHAIN_SAME_INPUT | GEOSSL_CHAIN_NEW_INPUT | GEOSSL_CHAIN_ADD_PREV)) != 0;
+    if ((ch.st[s2].flags & GEOSSL_CHAIN_NEW_INPUT) && (ch.st[s2].xin == nullptr || ch.st[s2].ldxin < 16 * KS ||
+                                                        (ch.st[s2].ldxin & 3)))
+      return (int)hipErrorInvalidValue;
   }
-  if (same_input && (!cu_form || (ch.st[0].flags & GEOSSL_CHAIN_SAME_INPUT))) return (int)hipErrorInvalidValue;
+  // the stage-input flags exist in the weight-stationary form only, and not on the first stage
+  if (same_input && (!cu_form || (ch.st[0].flags & (GEOSSL_CHAIN_SAME_INPUT | GEOSSL_CHAIN_NEW_INPUT | GEOSSL_CHAIN_ADD_PREV))))
+    return (int)hipErrorInvalidValue;
   if (cu_form) {
     static const bool one_per_cu = getenv("GEOSSL_CHAIN_CU1") != nullptr;  // 512-register form, one block per CU
     const int RBV = one_per_cu ? 5 : 3, slots = one_per_cu ? 256 : 512;

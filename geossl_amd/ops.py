@@ -157,7 +157,8 @@ def prepare_chain(weights, transB=True):
 def linear_chain(x, stages):
     """Several F -> F Linear layers applied to the rows of x back to back in one launch (geossl_linear_chain).
     stages: list of dicts with `image` (from prepare_chain) and optional `bias`, `res`, `tprev`, `flags`, `store`,
-    `same_input` (F = 128 only: the stage reads the input of the stage before it, not its result)
+    `same_input` (F = 128 only: the stage reads the input of the stage before it, not its result), `x` (F = 128 only:
+    the stage reads its own input rows) with `add_prev` (and adds the result of the stage before it)
     (default True: the stage's result is written to a new [R, F] tensor).  Returns the list of stored results
     (None where store is False)."""
     R, F = x.shape  # (x may be a column slice: its row stride is passed)
@@ -178,6 +179,13 @@ def linear_chain(x, stages):
         st.image, st.bias, st.res, st.tprev, st.out = (ptr(sd["image"]), ptr(sd.get("bias")), ptr(sd.get("res")),
                                                        ptr(sd.get("tprev")), ptr(o))
         st.ld, st.flags = ld, int(sd.get("flags", 0)) | (_lib.CHAIN_SAME_INPUT if sd.get("same_input") else 0)
+        xin = sd.get("x")  # the stage's own input rows (F = 128): one of several F-wide passes over a wide input
+        if xin is not None:
+            assert s > 0 and xin.stride(1) == 1 and xin.size(0) == R and xin.size(1) == F
+            st.xin, st.ldxin = ptr(xin), xin.stride(0)
+            st.flags |= _lib.CHAIN_NEW_INPUT | (_lib.CHAIN_ADD_PREV if sd.get("add_prev") else 0)
+        else:
+            st.xin, st.ldxin = None, 0
         outs.append(o)
     call("geossl_linear_chain", ptr(x), x.stride(0), C.byref(ch), R, F, stream())
     return outs

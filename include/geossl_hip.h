@@ -33,6 +33,9 @@ extern "C" {
 #define GEOSSL_EPI_SSP 2       /* ShiftedSoftplus (schnet.py:210-216) */
 #define GEOSSL_EPI_RESIDUAL 4  /* + res[r][n]   (h = h + block(h), schnet.py:97) */
 #define GEOSSL_EPI_MUL_DSSP 8  /* * d ssp/dx recovered from the saved ssp OUTPUT tprev[r][n] (backward) */
+#define GEOSSL_CHAIN_NEW_INPUT 32  /* geossl_linear_chain, F = 128: the stage reads its own input `xin` (a Linear over a
+                                      wide input = several F-wide passes in one launch) */
+#define GEOSSL_CHAIN_ADD_PREV 64   /* ... and adds the result of the stage before it (kept in registers) */
 #define GEOSSL_CHAIN_SAME_INPUT 16 /* geossl_linear_chain, F = 128: the stage takes the input of the stage before it
                                       (several F -> F blocks of one wide Linear in one launch) instead of its result */
 
@@ -198,6 +201,9 @@ typedef struct {
   float* out;         /* may be NULL: the stage's result is only consumed by the next stage */
   int ld;
   int flags;
+  const float* xin;   /* GEOSSL_CHAIN_NEW_INPUT: the stage's own input rows [R][F] (row stride ldxin), else NULL */
+  int ldxin;
+  int pad_;
 } GeosslChainStage;
 typedef struct {
   int nstage;
