@@ -67,8 +67,12 @@ __device__ __forceinline__ Frag3 split8(const float (&v)[8]) {
   return f;
 }
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
-                                                 0, 0);
+  const f32x16 r = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                           0, 0);
+#ifdef GEOSSL_MFMA_PAD
+  asm volatile("s_nop %0" ::"n"(GEOSSL_MFMA_PAD));
+#endif
+  return r;
 }
 // acc += A * B from piece fragments, smallest products first
 __device__ __forceinline__ void mma6(f32x16& acc, const Frag3& a, const Frag3& b) {
@@ -90,6 +94,44 @@ __device__ __forceinline__ void mma6x2(f32x16& acc_lo, f32x16& acc_hi, const Fra
   acc_hi = mfma_bf16(a.h, b.m, acc_hi);
   acc_lo = mfma_bf16(a.m, b.m, acc_lo);
   acc_hi = mfma_bf16(a.h, b.h, acc_hi);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Two fp16 pieces (filter forward): x = h + l with h = fp16(x), l = fp16(x - h) carries 22
+// significant bits when |x| >= 2^-3 and an absolute error <= 2^-25 below that (fp16's subnormal spacing), and a
+// product needs THREE MFMAs (l*h, h*l, h*h; the dropped l*l is <= 2^-22 relative) instead of the six of the bf16
+// scheme - half the matrix-pipe work, which is what bounds these kernels once the clock has settled under load.
+// fp16 has 5 exponent bits: the caller scales operands by powers of two (exact) so that the largest magnitude is in
+// [2^13, 2^14) and undoes the scales on the fp32 result.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+struct Frag2 {
+  u32x4 h, l;
+};
+__device__ __forceinline__ void split2h(float v0, float v1, uint32_t& h, uint32_t& l) {
+  const f16x2 p = {(_Float16)v0, (_Float16)v1};  // v_cvt_pk_f16_f32, round to nearest even
+  h = __builtin_bit_cast(uint32_t, p);
+  const f16x2 q = {(_Float16)(v0 - (float)p[0]), (_Float16)(v1 - (float)p[1])};
+  l = __builtin_bit_cast(uint32_t, q);
+}
+__device__ __forceinline__ Frag2 split8h(const float (&v)[8]) {
+  Frag2 f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t h, l;
+    split2h(v[2 * q], v[2 * q + 1], h, l);
+    f.h[q] = h;
+    f.l[q] = l;
+  }
+  return f;
+}
+__device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// power-of-two scale that brings a magnitude m into [2^13, 2^14) (1 for m = 0), and the exponent it used
+__device__ __forceinline__ float pow2_scale_to_2p14(float m, int& e) {
+  e = __builtin_amdgcn_frexp_expf(m);  // m = f * 2^e, f in [0.5, 1); 0 for m = 0
+  return __builtin_amdgcn_ldexpf(1.0f, 14 - e);
 }
 
 }  // namespace geossl
