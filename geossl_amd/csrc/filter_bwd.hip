@@ -489,6 +489,553 @@ __global__ __launch_bounds__(128 * NW) void k_filter_bwd(const float* __restrict
                                partial_b1, partial_w2, partial_b2);
 }
 
+// =====================================================================================================================
+// The same kernel on TWO fp16 pieces per operand (split.h: 3 MFMAs per product instead of 6, the selection-matrix
+// transposition on two pieces instead of three), the default.  The three-bf16-piece form above stays selectable with
+// GEOSSL_FILTER_BWD_BF16X3 for A/B runs.
+#define FBH_MARK(slot) do {} while (0)
+template <int F>
+struct BwdLdsH {
+  static constexpr int AS = F + 4;  // staged atom row stride (16-byte aligned rows)
+  static constexpr int KC = F / 16, CB = F / 32;
+  u32x4* dOr;    // [KC][2][64]
+  u32x4* tf;     // [CB][2][2][64]  t fragments: hidden-unit block x k-step x piece
+  u32x4* rbf;    // [2][2][2][64]
+  int* et;       // [CB] running exponent of each role-A wave's t fragments; [CB] = scratch word of the unstaged path
+  // staging arrays, double buffered (buffer t & 1 serves tile t): written during the MFMA phase of tile t-1, read
+  // only by the build of tile t
+  static constexpr int STAGE_FLOATS = 2 * ATOM_CAP * AS + TR + 4 * TR + 4 + 8;  // xs, ds, tdd, desc (int4), flags, window maxima
+  float* stage0;
+  __device__ float* xs(int b) const { return stage0 + b * STAGE_FLOATS; }                       // [ATOM_CAP][AS]
+  __device__ float* ds(int b) const { return xs(b) + ATOM_CAP * AS; }                            // [ATOM_CAP][AS]
+  __device__ float* tdd(int b) const { return ds(b) + ATOM_CAP * AS; }                           // [TR] distances
+  // [TR] {offset of atom i, of atom j (LDS floats if staged, else atom index), C*flag0, C*flag1}
+  __device__ int4* desc(int b) const { return reinterpret_cast<int4*>(tdd(b) + TR); }
+  __device__ int* flag(int b) const { return reinterpret_cast<int*>(desc(b) + TR); }             // [0] = window fits
+  __device__ float* wmax(int b) const { return reinterpret_cast<float*>(flag(b) + 4); }          // [CB][2] max |x|, max |dagg| of the window
+  __device__ explicit BwdLdsH(uint8_t* smem) {
+    dOr = reinterpret_cast<u32x4*>(smem);
+    tf = dOr + KC * 2 * 64;
+    rbf = tf + CB * 2 * 2 * 64;
+    et = reinterpret_cast<int*>(rbf + 2 * 2 * 2 * 64);
+    stage0 = reinterpret_cast<float*>(et + 8);
+  }
+  static size_t bytes() { return (size_t)(KC * 2 + CB * 4 + 8) * 1024 + 32 + (size_t)2 * STAGE_FLOATS * 4; }
+};
+
+template <int NW, bool ROLE_A>
+__device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair_d, const float* __restrict__ pair_c,
+                                                const uint8_t* __restrict__ pair_flag,
+                                                const int32_t* __restrict__ pair_i,
+                                                const int32_t* __restrict__ pair_j, int P, int N,
+                                                const GeosslFilterWeights& w, const GeosslFilterGradIn& g, int G,
+                                                const float* __restrict__ offset, float coeff,
+                                                const float* __restrict__ T, float* __restrict__ partial_w1,
+                                                float* __restrict__ partial_b1, float* __restrict__ partial_w2,
+                                                float* __restrict__ partial_b2) {
+  constexpr int F = 32 * NW, NT = 128 * NW, KC = F / 16, CB = F / 32, AS = BwdLdsH<F>::AS, Q = F / 4;
+  static_assert(TR * (F / 8) == NT, "one dOr fragment lane per thread");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  const BwdLdsH<F> L(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
+  constexpr bool roleA = ROLE_A;
+  const int hs = roleA ? wave : wave - NW;  // hidden-unit slice [32 hs, 32 hs + 32)
+  const int l = blockIdx.y;
+  const float* __restrict__ x = g.x[l];
+  const float* __restrict__ dagg = g.dagg[l];
+  const size_t lbase = (size_t)l * P;
+  const float* __restrict__ Tl = T + lbase * F;   // uniform base: the per-lane part stays a 32-bit offset
+  const uint32_t tcol = 32 * hs + j;               // this lane's hidden unit
+
+  // ---- role A: W2 slice as B fragments of dt = dO W2:  B[k = c = 16ks + 8kh + e][n = h] = W2[c][h]
+  Frag2 bw2[roleA ? KC : 1];
+  int e2 = 0, eL = 0;          // role A: exponents of max |W2 slice| and of its largest column L1 norm (bounds dt)
+  f32x16 accw1[2];             // role A: dW1 rows [32hs, +32) x gaussians [0, 64): lane = g, register = h
+  f32x16 accw2[roleA ? 1 : CB];  // role B: dW2 rows c of this wave's channel block (register) x all h (lane), per h block
+  float bsum1 = 0.0f, bsum2 = 0.0f;
+  if constexpr (roleA) {
+    const float* w2 = w.w2[l] + 32 * hs + j;
+    float wm = 0.0f, l1 = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KC; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = fabsf(w2[(size_t)(16 * ks + 8 * kh + e) * F]);
+        wm = fmaxf(wm, a);
+        l1 += a;
+      }
+    l1 += __shfl_xor(l1, 32, 64);  // the two halves of a lane pair hold the two halves of column h
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      wm = fmaxf(wm, __shfl_xor(wm, o, 64));
+      l1 = fmaxf(l1, __shfl_xor(l1, o, 64));
+    }
+    const float s2 = pow2_scale_to_2p14(wm, e2);
+    eL = __builtin_amdgcn_frexp_expf(l1);
+#pragma unroll
+    for (int ks = 0; ks < KC; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = w2[(size_t)(16 * ks + 8 * kh + e) * F] * s2;
+      bw2[ks] = split8h(v);
+    }
+#pragma unroll
+    for (int gb = 0; gb < 2; ++gb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accw1[gb][r] = 0.0f;
+  } else {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accw2[cb][r] = 0.0f;
+  }
+  // role B: selection matrices of the matrix-pipe transposition, as B fragments: step q (channels 16q..16q+15 of the
+  // wave's block), lane (n = j, half kh), element e:  1.0 (fp16 0x3C00) iff 16q + 8kh + e == j
+  u32x4 ident[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int w2i = 0; w2i < 4; ++w2i) {
+      const int e0 = 16 * q + 8 * kh + 2 * w2i;
+      ident[q][w2i] = (e0 == j ? 0x3C00u : 0u) | (e0 + 1 == j ? 0x3C000000u : 0u);
+    }
+  // fragment-lane roles of this thread in the tile build
+  const int r_row = tid & 31, r_kh = (tid >> 5) & 1, r_ks = tid >> 6;         // dOr: row, k half, k-step (c)
+  const int ntiles = (P + TR - 1) / TR;
+  const int per = (ntiles + gridDim.x - 1) / gridDim.x;  // contiguous tile range per block (atom reuse in L2)
+  const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
+  // Global requests run one tile ahead of their use (they fly during the MFMA phase of the previous tile): the atom
+  // window and the row descriptors are fetched and staged by the role-B waves (which have the registers to spare),
+  // the saved activations by every wave for its own hidden unit.  `alo` = first atom of a tile's window
+  // (= pair_i[r0]: pair slots are lexicographic inside a molecule) is fetched two tiles ahead.
+  constexpr int NTB = 64 * NW;                              // staging threads (role B)
+  constexpr int NPRE = (ATOM_CAP * Q + NTB - 1) / NTB;      // float4 per staging thread and array
+  const int stid = tid - NTB;                               // role B: 0 .. NTB-1
+  f32x4 px[roleA ? 1 : NPRE], pdg[roleA ? 1 : NPRE];
+  int ai = 0, aj = 0;
+  float cval = 0.0f, dd = 0.0f;
+  unsigned fl_raw = 0u;
+  float tc[16];
+  auto request_atoms = [&](int tt, int alo_t) {  // role B: window of x / dagg rows + the row descriptors of tile tt
+    if constexpr (!roleA) {
+      const int rr0 = tt * TR;
+      // clamped addresses, no predication (a predicated load compiles to a branch with a full wait per element);
+      // slots past the window are never read back
+      const int nwin = min(ATOM_CAP, N - alo_t);
+      const f32x4* x4 = reinterpret_cast<const f32x4*>(x + (size_t)alo_t * F);
+      const f32x4* d4 = reinterpret_cast<const f32x4*>(dagg + (size_t)alo_t * F);
+#pragma unroll
+      for (int u = 0; u < NPRE; ++u) {
+        const int i = min(stid + NTB * u, nwin * Q - 1);
+        px[u] = x4[i];
+        pdg[u] = d4[i];
+      }
+      if (stid < TR) {  // one pair row per lane of the first role-B wave
+        const int q = min(rr0 + stid, P - 1);  // raw values only: nothing here waits for the loads
+        ai = pair_i[q];
+        aj = pair_j[q];
+        fl_raw = pair_flag[q];
+        cval = pair_c[q];
+        dd = pair_d[q];
+      }
+    }
+  };
+  // saved hidden activation of this lane's hidden unit: role A in C layout (register r <-> row c_row(r)), role B in
+  // B-fragment layout (k-step s, element e <-> row 16s + 8kh + e); rows past P are clamped (their dO is 0)
+  auto request_t = [&](int tt) {
+    if constexpr (roleA) {
+      const int rr0 = tt * TR;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tc[r] = Tl[(uint32_t)min(rr0 + c_row(r, lane), P - 1) * (uint32_t)F + tcol];
+    }
+  };
+  // role B: publish the window + descriptors held in registers (requested earlier) as tile tt's staging buffer
+  auto publish = [&](int tt, int alo_t) {
+    if constexpr (!roleA) {
+      const int bsel = tt & 1, rr0 = tt * TR;
+      const int nwin = min(ATOM_CAP, N - alo_t);
+      if (wave == NW) {
+        int amax = lane < TR ? aj + 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o, 64));
+        const bool staged0 = amax - alo_t <= ATOM_CAP;
+        if (lane < TR) {
+          const unsigned fl = rr0 + lane < P ? fl_raw : 0u;  // rows past P contribute nothing
+          const float m0 = (fl & 1u) ? cval : 0.0f, m1 = (fl & 2u) ? cval : 0.0f;
+          L.tdd(bsel)[lane] = dd;
+          L.desc(bsel)[lane] = staged0 ? make_int4((ai - alo_t) * AS, (aj - alo_t) * AS, __float_as_int(m0), __float_as_int(m1))
+                                       : make_int4(ai, aj, __float_as_int(m0), __float_as_int(m1));
+        }
+        if (lane == 0) {
+          L.flag(bsel)[0] = staged0 ? 1 : 0;
+          L.et[CB] = 0;
+        }
+      }
+      float* xs = L.xs(bsel);
+      float* ds = L.ds(bsel);
+      float mx = 0.0f, md = 0.0f;  // largest |x|, |dagg| of the window (clamped duplicates are window values too)
+#pragma unroll
+      for (int u = 0; u < NPRE; ++u) {
+        const int i = stid + NTB * u;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(px[u][0]), fabsf(px[u][1]))), fmaxf(fabsf(px[u][2]), fabsf(px[u][3])));
+        md = fmaxf(fmaxf(md, fmaxf(fabsf(pdg[u][0]), fabsf(pdg[u][1]))), fmaxf(fabsf(pdg[u][2]), fabsf(pdg[u][3])));
+        if (i < nwin * Q) {
+          const int a = i / Q, q4 = i - a * Q;
+          *reinterpret_cast<f32x4*>(xs + a * AS + 4 * q4) = px[u];
+          *reinterpret_cast<f32x4*>(ds + a * AS + 4 * q4) = pdg[u];
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        md = fmaxf(md, __shfl_xor(md, o, 64));
+      }
+      if (lane == 0) {
+        L.wmax(bsel)[2 * (wave - NW)] = mx;
+        L.wmax(bsel)[2 * (wave - NW) + 1] = md;
+      }
+    }
+  };
+  // prologue: tile t_begin published, atoms of tile t_begin + 1 in flight, activations of tile t_begin in flight.
+  // alo_a = first atom of the window of the tile whose atoms are held in registers, alo_b = of the tile after it
+  // (= pair_i[r0]: pair slots are lexicographic inside a molecule; fetched one step ahead of their use).
+  int alo_a = 0, alo_b = 0;
+  // Operand scales (powers of two, split.h).  EO: running exponent of the block's dO values - 2^EO exceeds every |dO| met
+  // so far (bound: twice the product of the staged window's largest |x| and |dagg|); when a tile raises it, the weight
+  // gradient accumulators (which hold sums scaled by it) are scaled down by the same power of two.  ET: the same for the
+  // saved activations of one role-A wave's hidden units (published next to its fragments; the role-B waves follow it).
+  int EO = -126, ET = -126;
+  int ETs[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) ETs[cb] = -126;
+  if (t_begin < t_end) {
+    alo_a = pair_i[t_begin * TR];
+    request_atoms(t_begin, alo_a);
+    request_t(t_begin);
+    publish(t_begin, alo_a);
+    if (t_begin + 1 < t_end) {
+      alo_a = pair_i[(t_begin + 1) * TR];
+      request_atoms(t_begin + 1, alo_a);
+      if (t_begin + 2 < t_end) alo_b = pair_i[(t_begin + 2) * TR];
+    }
+  }
+  for (int t = t_begin; t < t_end; ++t) {
+    const int r0 = t * TR;
+    const int bsel = t & 1;
+    FBH_MARK(0);
+    lds_barrier();  // previous tile fully consumed; this tile's staging buffer published (LDS only: the requests for the
+                    // tiles ahead stay in flight; measured neutral against __syncthreads here)
+    FBH_MARK(1);
+    const bool staged = L.flag(bsel)[0] != 0;
+    // ---- tile build: every thread one dOr fragment lane; role A publishes its tf lanes, role B its rbf lanes
+    float v[8];
+    auto build = [&](const float* xb, const float* db, int stride) {
+      {  // dOr: A[m = row][k = c = 16 r_ks + 8 r_kh + e]
+        const int4 q = L.desc(bsel)[r_row];
+        const float qm0 = __int_as_float(q.z), qm1 = __int_as_float(q.w);
+        const int c0 = 16 * r_ks + 8 * r_kh;
+        const float* di = db + (size_t)q.x * stride + c0;
+        const float* dj = db + (size_t)q.y * stride + c0;
+        const float* xi = xb + (size_t)q.x * stride + c0;
+        const float* xj = xb + (size_t)q.y * stride + c0;
+#pragma unroll
+        for (int h4 = 0; h4 < 2; ++h4) {
+          const float4 a = *reinterpret_cast<const float4*>(di + 4 * h4), b = *reinterpret_cast<const float4*>(xj + 4 * h4);
+          const float4 c = *reinterpret_cast<const float4*>(dj + 4 * h4), d = *reinterpret_cast<const float4*>(xi + 4 * h4);
+          v[4 * h4 + 0] = qm0 * (a.x * b.x) + qm1 * (c.x * d.x);
+          v[4 * h4 + 1] = qm0 * (a.y * b.y) + qm1 * (c.y * d.y);
+          v[4 * h4 + 2] = qm0 * (a.z * b.z) + qm1 * (c.z * d.z);
+          v[4 * h4 + 3] = qm0 * (a.w * b.w) + qm1 * (c.w * d.w);
+        }
+      }
+    };
+    float bound;
+    if (staged) {
+      build(L.xs(bsel), L.ds(bsel), 1);  // descriptors hold LDS float offsets
+      float mx = 0.0f, md = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        mx = fmaxf(mx, L.wmax(bsel)[2 * i]);
+        md = fmaxf(md, L.wmax(bsel)[2 * i + 1]);
+      }
+      bound = 2.0f * mx * md;  // |dO| <= C (|dagg_i x_j| + |dagg_j x_i|), C <= 1
+    } else {
+      build(x, dagg, F);  // a run of tiny molecules: operands straight from global memory, exact largest magnitude
+      float m = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(L.et + CB), __float_as_uint(m));  // zeroed by publish()
+      lds_barrier();
+      bound = __uint_as_float(*reinterpret_cast<volatile unsigned*>(L.et + CB));
+    }
+    {
+      const int e_t = __builtin_amdgcn_readfirstlane(max(__builtin_amdgcn_frexp_expf(bound), -100));
+      if (e_t > EO) {
+        const float f = __builtin_amdgcn_ldexpf(1.0f, EO - e_t);
+        if constexpr (roleA) {
+#pragma unroll
+          for (int gb = 0; gb < 2; ++gb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accw1[gb][r] *= f;
+        } else {
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accw2[cb][r] *= f;
+        }
+        EO = e_t;
+      }
+      const float sO = __builtin_amdgcn_ldexpf(1.0f, 14 - EO);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= sO;
+      const Frag2 f = split8h(v);
+      u32x4* dst = L.dOr + (size_t)(r_ks * 2) * 64 + (r_row + 32 * r_kh);
+      dst[0] = f.h;
+      dst[64] = f.l;
+    }
+    if constexpr (roleA) {
+      // t slice of this wave's hidden units as B fragments of dW2's contraction over pair rows: the C layout held in
+      // tc (lane = h, register r <-> row c_row(r)) is the fragment layout with k-step s <-> registers 8s..8s+7
+      float tm = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tm = fmaxf(tm, fabsf(tc[r]));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o, 64));
+      ET = max(ET, __builtin_amdgcn_readfirstlane(max(__builtin_amdgcn_frexp_expf(tm), -100)));
+      const float sT = __builtin_amdgcn_ldexpf(1.0f, 14 - ET);
+      if (lane == 0) L.et[hs] = ET;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float u8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u8[e] = tc[8 * s2 + e] * sT;
+        const Frag2 f = split8h(u8);
+        u32x4* dst = L.tf + (size_t)((hs * 2 + s2) * 2) * 64 + lane;
+        dst[0] = f.h;
+        dst[64] = f.l;
+      }
+    } else {
+      for (int it = tid - NT / 2; it < 2 * 2 * 64; it += NT / 2) {  // rbf: B[k = row = 16ks + kperm(e, kh)][n = g]
+        const int ln = it & 63, ks = (it >> 6) & 1, gb = it >> 7;
+        const int gg = 32 * gb + (ln & 31);
+        const float off = gg < G ? offset[gg] : 0.0f;
+        float u8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float diff = L.tdd(bsel)[16 * ks + kperm(e, ln >> 5)] - off;
+          u8[e] = gg < G ? exp_neg(coeff * (diff * diff)) * 16384.0f : 0.0f;  // Gaussians are <= 1: fixed scale 2^14
+        }
+        const Frag2 f = split8h(u8);
+        u32x4* dst = L.rbf + (size_t)((gb * 2 + ks) * 2) * 64 + ln;
+        dst[0] = f.h;
+        dst[64] = f.l;
+      }
+    }
+    float tcur[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tcur[r] = tc[r];
+    FBH_MARK(2);
+    lds_barrier();
+    FBH_MARK(3);
+    // While this tile is multiplied: publish the next tile's staging buffer (its atoms were requested one tile ago
+    // and have arrived), request the atoms of the tile after it and the next tile's saved activations.
+    if (t + 1 < t_end) {
+#ifdef FB_TIMING
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (blockIdx.x == 3 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == NW) && t - t_begin < 64)
+        fb_dbg2[(wave == 0 ? 0 : 1) * 64 + (t - t_begin)] = clock64();
+#endif
+      publish(t + 1, alo_a);
+      FBH_MARK(7);
+      if (t + 2 < t_end) {
+        alo_a = alo_b;
+        request_atoms(t + 2, alo_a);
+        if (t + 3 < t_end) alo_b = pair_i[(t + 3) * TR];
+      }
+      request_t(t + 1);
+    }
+    FBH_MARK(4);
+    if constexpr (roleA) {
+      // dt = dO W2 for this wave's hidden units (back-to-back MFMAs on one accumulator forward SrcC without a stall)
+      f32x16 acc0, acc1;  // small-weight and large-weight piece products apart: better conditioned, and two
+                          // independent MFMA chains
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+      {
+        Frag2 a0, an;  // fragments of the next k-step are requested before this step's MFMAs issue
+        {
+          const u32x4* s0 = L.dOr + lane;
+          a0.h = s0[0]; a0.l = s0[64];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KC; ++ks) {
+          if (ks + 1 < KC) {
+            const u32x4* s0 = L.dOr + (size_t)((ks + 1) * 2) * 64 + lane;
+            an.h = s0[0]; an.l = s0[64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc1 = mfma_f16(a0.l, bw2[ks].h, acc1);
+          acc0 = mfma_f16(a0.h, bw2[ks].h, acc0);
+          acc1 = mfma_f16(a0.h, bw2[ks].l, acc1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (ks + 1 < KC) a0 = an;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
+      // dU = dt * ssp'(pre) (C layout: lane = hidden unit, register = pair row); registers 0..7 / 8..15 are the
+      // elements of k-steps 0 / 1 of the contraction over pair rows
+      // acc holds (2^(14-EO) dO)(2^(14-e2) W2); |dt| <= 2^EO * (largest column L1 norm of the W2 slice) < 2^(EO+eL)
+      const float kdt = __builtin_amdgcn_ldexpf(1.0f, EO + e2 - 28), sU = __builtin_amdgcn_ldexpf(1.0f, 14 - EO - eL);
+      Frag2 du[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float u8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dU = (acc0[8 * s + e] * kdt) * dssp_from_out(tcur[8 * s + e]);
+          bsum1 += dU;
+          u8[e] = dU * sU;
+        }
+        du[s] = split8h(u8);
+      }
+      FBH_MARK(6);
+      // dW1[h][g] += sum_rows dU[row][h] * rbf(d_row)[g]
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Frag2 b0, b1;
+        const u32x4* s0 = L.rbf + (size_t)(s * 2) * 64 + lane;
+        b0.h = s0[0]; b0.l = s0[64];
+        b1.h = s0[256]; b1.l = s0[320];
+        accw1[0] = mfma_f16(du[s].l, b0.h, accw1[0]);
+        accw1[1] = mfma_f16(du[s].l, b1.h, accw1[1]);
+        accw1[0] = mfma_f16(du[s].h, b0.l, accw1[0]);
+        accw1[1] = mfma_f16(du[s].h, b1.l, accw1[1]);
+        accw1[0] = mfma_f16(du[s].h, b0.h, accw1[0]);
+        accw1[1] = mfma_f16(du[s].h, b1.h, accw1[1]);
+      }
+    } else {
+      // Role B wave w owns filter output channels c in [32w, 32w+32).  Its dO^T fragments (lane = c, 8 pair rows) come
+      // from the dOr fragments through the matrix pipe: D = dOr_piece * I (I = 16 x 32 selection of the channel block)
+      // lands in C layout - lane = c, register = pair row in kperm order - i.e. in fragment order, and every value is
+      // an exact bf16 number (one piece times 1), so packing is exact.  No second evaluation of dO in the other
+      // orientation, no LDS traffic for it.
+      f32x16 tp[2];
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tp[pc][r] = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const u32x4* s0 = L.dOr + (size_t)((2 * hs + q) * 2) * 64 + lane;
+        tp[0] = mfma_f16(s0[0], ident[q], tp[0]);
+        tp[1] = mfma_f16(s0[64], ident[q], tp[1]);
+      }
+      FBH_MARK(6);
+      Frag2 da[2];  // A fragments of dW2 = dO^T t: k-step s <-> registers 8s..8s+7 (every value is an fp16 number)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f16x2 ph = {(_Float16)tp[0][8 * s2 + 2 * q], (_Float16)tp[0][8 * s2 + 2 * q + 1]};
+          const f16x2 pl = {(_Float16)tp[1][8 * s2 + 2 * q], (_Float16)tp[1][8 * s2 + 2 * q + 1]};
+          da[s2].h[q] = __builtin_bit_cast(uint32_t, ph);
+          da[s2].l[q] = __builtin_bit_cast(uint32_t, pl);
+        }
+      {
+        float rs = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rs += tp[0][r] + tp[1][r];
+        bsum2 += rs * __builtin_amdgcn_ldexpf(1.0f, EO - 14);  // db2: rows of this half-wave
+      }
+      // follow the activation scales of the role-A waves
+#pragma unroll
+      for (int hb = 0; hb < CB; ++hb) {
+        const int et = __builtin_amdgcn_readfirstlane(L.et[hb]);
+        if (et != ETs[hb]) {
+          const float f = __builtin_amdgcn_ldexpf(1.0f, ETs[hb] - et);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accw2[hb][r] *= f;
+          ETs[hb] = et;
+        }
+      }
+      // dW2[c][h] += sum_rows dO[row][c] * t[row][h], all four 32-wide blocks of h (t fragments published by role A)
+      constexpr int CP = CB >= 2 ? 2 : 1;
+#pragma unroll
+      for (int hb = 0; hb < CB; hb += CP) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          Frag2 tb[CP];
+#pragma unroll
+          for (int u = 0; u < CP; ++u) {
+            const u32x4* s0 = L.tf + (size_t)(((hb + u) * 2 + s2) * 2) * 64 + lane;
+            tb[u].h = s0[0]; tb[u].l = s0[64];
+          }
+#pragma unroll
+          for (int u = 0; u < CP; ++u) accw2[hb + u] = mfma_f16(da[s2].l, tb[u].h, accw2[hb + u]);
+#pragma unroll
+          for (int u = 0; u < CP; ++u) accw2[hb + u] = mfma_f16(da[s2].h, tb[u].l, accw2[hb + u]);
+#pragma unroll
+          for (int u = 0; u < CP; ++u) accw2[hb + u] = mfma_f16(da[s2].h, tb[u].h, accw2[hb + u]);
+        }
+      }
+    }
+    FBH_MARK(5);
+  }
+  // ---- one partial per block
+  const size_t pb = (size_t)l * gridDim.x + blockIdx.x;
+  if constexpr (roleA) {
+    float* Pw = partial_w1 + pb * F * G;
+    const float kw1 = __builtin_amdgcn_ldexpf(1.0f, EO + eL - 28);  // dU carried 2^(14-EO-eL), the Gaussians 2^14
+#pragma unroll
+    for (int gb = 0; gb < 2; ++gb) {
+      const int gg = 32 * gb + j;
+      if (gg < G) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Pw[(size_t)(32 * hs + c_row(r, lane)) * G + gg] = accw1[gb][r] * kw1;
+      }
+    }
+    const float s = bsum1 + __shfl_xor(bsum1, 32, 64);
+    if (kh == 0) partial_b1[pb * F + 32 * hs + j] = s;
+  } else {
+    float* Pw = partial_w2 + pb * F * F;
+#pragma unroll
+    for (int hb = 0; hb < CB; ++hb) {
+      const float kw2 = __builtin_amdgcn_ldexpf(1.0f, EO + ETs[hb] - 28);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Pw[(size_t)(32 * hs + c_row(r, lane)) * F + 32 * hb + j] = accw2[hb][r] * kw2;
+    }
+    // db2[c]: each half-wave summed the pair rows its registers hold
+    const float sb2 = bsum2 + __shfl_xor(bsum2, 32, 64);
+    if (kh == 0) partial_b2[pb * F + 32 * hs + j] = sb2;
+  }
+}
+
+// The two roles run separate instantiations of the body (their register sets differ: W2 fragments + dW1
+// accumulators against dW2 accumulators); the branch is wave-uniform and both sides execute the same barriers.
+template <int NW>
+__global__ __launch_bounds__(128 * NW) void k_filter_bwd_h(const float* __restrict__ pair_d,
+                                                         const float* __restrict__ pair_c,
+                                                         const uint8_t* __restrict__ pair_flag,
+                                                         const int32_t* __restrict__ pair_i,
+                                                         const int32_t* __restrict__ pair_j, int P, int N,
+                                                         GeosslFilterWeights w, GeosslFilterGradIn g, int G,
+                                                         const float* __restrict__ offset, float coeff,
+                                                         const float* __restrict__ T,
+                                                         float* __restrict__ partial_w1,
+                                                         float* __restrict__ partial_b1,
+                                                         float* __restrict__ partial_w2,
+                                                         float* __restrict__ partial_b2) {
+  if ((int)(threadIdx.x >> 6) < NW)
+    filter_bwd_body_h<NW, true>(pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, w, g, G, offset, coeff, T, partial_w1,
+                              partial_b1, partial_w2, partial_b2);
+  else
+    filter_bwd_body_h<NW, false>(pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, w, g, G, offset, coeff, T, partial_w1,
+                               partial_b1, partial_w2, partial_b2);
+}
+
 inline int blocks_per_layer(int L, int ntiles) {
   int b = 256 / (L > 0 ? L : 1);  // one block per CU
   if (b < 1) b = 1;
@@ -535,7 +1082,20 @@ extern "C" int geossl_cfconv_filter_bwd(const float* pair_d, const float* pair_c
     hipLaunchKernelGGL((k_filter_bwd<NW>), grid, dim3(128 * NW), lds, stream, pair_d, pair_c, pair_flag, pair_i,   \
                        pair_j, (int)P, (int)N, *w, *g, G, offset, coeff, T, pw1, pb1, pw2, pb2);                   \
   } while (0)
-  if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
+#define LAUNCH_H(NW)                                                                                               \
+  do {                                                                                                             \
+    const size_t lds = BwdLdsH<32 * NW>::bytes();                                                                  \
+    allow_big_lds(&k_filter_bwd_h<NW>);                                                                            \
+    hipLaunchKernelGGL((k_filter_bwd_h<NW>), grid, dim3(128 * NW), lds, stream, pair_d, pair_c, pair_flag, pair_i, \
+                       pair_j, (int)P, (int)N, *w, *g, G, offset, coeff, T, pw1, pb1, pw2, pb2);                   \
+  } while (0)
+  static const bool bf16x3 = getenv("GEOSSL_FILTER_BWD_BF16X3") != nullptr;
+  if (!bf16x3) {
+    if (F == 128) LAUNCH_H(4); else if (F == 64) LAUNCH_H(2); else LAUNCH_H(1);
+  } else {
+    if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
+  }
+#undef LAUNCH_H
 #undef LAUNCH
   GEOSSL_CHECK_LAUNCH();
   ReduceMulti rm;  // the four fixed-order partial sums in one launch
