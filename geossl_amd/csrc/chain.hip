@@ -39,6 +39,26 @@ __global__ __launch_bounds__(256) void k_chain_prepare(GeosslPrepareBatch batch,
   u32x4* __restrict__ image = reinterpret_cast<u32x4*>(batch.image[z]);
   const int nitems = (NO / 32) * KS * 64;
   const int i = blockIdx.x * 256 + threadIdx.x;
+  float sw = 1.0f;
+  if constexpr (KS == 8) {
+    // F = 128 (weight-stationary kernel): two fp16 pieces of W * 2^(14 - eW), eW = exponent of the largest |W| (split.h).
+    // Every block finds the largest magnitude of its (L2-resident) matrix itself.
+    __shared__ float red[4];
+    float mw = 0.0f;
+    const f32x4* W4 = reinterpret_cast<const f32x4*>(W);
+    for (int q = threadIdx.x; q < K * NO / 4; q += 256) {
+      const f32x4 a = W4[q];
+      mw = fmaxf(fmaxf(mw, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mw;
+    __syncthreads();
+    mw = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int eW;
+    sw = pow2_scale_to_2p14(mw, eW);
+    if (i == 0) reinterpret_cast<int*>(image)[(NO / 32) * KS * 2 * 64 * 4] = eW;
+  }
   if (i >= nitems) return;
   const int ln = i & 63, ks = (i >> 6) % KS, mb = i / (64 * KS);
   const int n = 32 * mb + (ln & 31), kh = ln >> 5;
@@ -52,11 +72,20 @@ __global__ __launch_bounds__(256) void k_chain_prepare(GeosslPrepareBatch batch,
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = W[(size_t)(16 * ks + kperm(e, kh)) * NO + n];
   }
-  const Frag3 f = split8(v);
-  u32x4* dst = image + ((size_t)(mb * KS + ks) * 3) * 64 + ln;
-  dst[0] = f.h;
-  dst[64] = f.m;
-  dst[128] = f.l;
+  if constexpr (KS == 8) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= sw;
+    const Frag2 f = split8h(v);
+    u32x4* dst = image + ((size_t)(mb * KS + ks) * 2) * 64 + ln;
+    dst[0] = f.h;
+    dst[64] = f.l;
+  } else {
+    const Frag3 f = split8(v);
+    u32x4* dst = image + ((size_t)(mb * KS + ks) * 3) * 64 + ln;
+    dst[0] = f.h;
+    dst[64] = f.m;
+    dst[128] = f.l;
+  }
 }
 
 #ifdef CHAIN_TIMING
@@ -523,7 +552,7 @@ __global__ __launch_bounds__(512, 2) void k_row_chain8(GeosslChain ch, const flo
 template <int NS, int RB, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const float* __restrict__ X, int ldx, int R) {
   constexpr int KS = 8, F = 128;
-  constexpr int RBF = KS * 3 * 64;      // u32x4 per row block of fragments
+  constexpr int RBF = KS * 2 * 64;      // u32x4 per row block of fragments (two fp16 pieces, split.h)
 #ifndef CHAIN_CU_NEB2
 #define CHAIN_CU_NEB2 1
 #endif
@@ -531,8 +560,9 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
   // 32 registers are better left to the allocator)
   constexpr int NEB = WPS == 1 ? 2 : CHAIN_CU_NEB2;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
-  u32x4* xbuf = reinterpret_cast<u32x4*>(smem_raw);                       // [RB][KS][3][64]
+  u32x4* xbuf = reinterpret_cast<u32x4*>(smem_raw);                       // [RB][KS][2][64]
   float* bias_s = reinterpret_cast<float*>(xbuf + (size_t)RB * RBF);      // [NS][F]
+  float* rmax = bias_s + NS * F;                                          // [RB][4][32] largest |value| of a row in a wave's columns
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
   const int m = __builtin_amdgcn_readfirstlane(tid >> 6);                  // this wave's column block
   const int nrb = (R + 31) / 32;
@@ -542,17 +572,32 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
   const int rb0 = b * base + min(b, extra);
   const int nloc = base + (b < extra ? 1 : 0);                             // <= RB, uniform
   const uint32_t voff = (uint32_t)lane * 16u;
-  Frag3 af[KS];
+  Frag2 af[KS];
+  int eW = 0;            // exponent of the stage's weight scale (stored behind the image by k_chain_prepare)
+  float krow[RB];        // 2^(e_row - 14) of the rows whose fragments sit in xbuf: undoes their scale
   auto request_weights = [&](const GeosslChainStage& st) __attribute__((always_inline)) {
-    const char* img = reinterpret_cast<const char*>(st.image) + (size_t)(m * KS) * 3 * 1024;
+    const char* img = reinterpret_cast<const char*>(st.image) + (size_t)(m * KS) * 2 * 1024;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const char* bk = img + ks * 3 * 1024;
+      const char* bk = img + ks * 2 * 1024;
       asm volatile("" : "+s"(bk));  // keep the base scalar: loads become saddr + lane offset + immediate
       af[ks].h = *reinterpret_cast<const u32x4*>(bk + voff);
-      af[ks].m = *reinterpret_cast<const u32x4*>(bk + 1024 + voff);
-      af[ks].l = *reinterpret_cast<const u32x4*>(bk + 2048 + voff);
+      af[ks].l = *reinterpret_cast<const u32x4*>(bk + 1024 + voff);
     }
+    eW = reinterpret_cast<const int*>(st.image)[4 * KS * 2 * 64 * 4];
+  };
+  // row maxima of this wave's 16 values per lane -> LDS (lane pair j / j + 32 holds the wave's 32 columns of row j)
+  auto publish_max = [&](int i, float mx) __attribute__((always_inline)) {
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (kh == 0) rmax[(i * 4 + m) * 32 + j] = mx;
+  };
+  // scale of row block i's rows from the four waves' maxima: returns 2^(14 - e), keeps 2^(e - 14)
+  auto row_scale = [&](int i) __attribute__((always_inline)) {
+    const float* r = rmax + (i * 4) * 32 + j;
+    const float mx = fmaxf(fmaxf(r[0], r[32]), fmaxf(r[64], r[96]));
+    const int e = max(__builtin_amdgcn_frexp_expf(mx), -100);
+    krow[i] = __builtin_amdgcn_ldexpf(1.0f, e - 14);
+    return __builtin_amdgcn_ldexpf(1.0f, 14 - e);
   };
   request_weights(ch.st[0]);
   for (int i = tid; i < NS * F; i += 256) {
@@ -573,12 +618,26 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       if (i < nloc) {
-        const float lo[8] = {raw[i][0].x, raw[i][0].y, raw[i][0].z, raw[i][0].w, raw[i][1].x, raw[i][1].y, raw[i][1].z, raw[i][1].w};
-        const float hi[8] = {raw[i][2].x, raw[i][2].y, raw[i][2].z, raw[i][2].w, raw[i][3].x, raw[i][3].y, raw[i][3].z, raw[i][3].w};
-        const Frag3 f0 = split8(lo), f1 = split8(hi);
-        u32x4* xd = xbuf + (size_t)i * RBF + (size_t)(2 * m * 3) * 64 + lane;
-        xd[0] = f0.h; xd[64] = f0.m; xd[128] = f0.l;
-        xd[192] = f1.h; xd[256] = f1.m; xd[320] = f1.l;
+        float mx = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          mx = fmaxf(fmaxf(mx, fmaxf(fabsf(raw[i][q].x), fabsf(raw[i][q].y))), fmaxf(fabsf(raw[i][q].z), fabsf(raw[i][q].w)));
+        publish_max(i, mx);
+      }
+    }
+    lds_barrier();  // the row maxima of all four waves
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      if (i < nloc) {
+        const float sr = row_scale(i);
+        const float lo[8] = {raw[i][0].x * sr, raw[i][0].y * sr, raw[i][0].z * sr, raw[i][0].w * sr,
+                             raw[i][1].x * sr, raw[i][1].y * sr, raw[i][1].z * sr, raw[i][1].w * sr};
+        const float hi[8] = {raw[i][2].x * sr, raw[i][2].y * sr, raw[i][2].z * sr, raw[i][2].w * sr,
+                             raw[i][3].x * sr, raw[i][3].y * sr, raw[i][3].z * sr, raw[i][3].w * sr};
+        const Frag2 f0 = split8h(lo), f1 = split8h(hi);
+        u32x4* xd = xbuf + (size_t)i * RBF + (size_t)(2 * m * 2) * 64 + lane;
+        xd[0] = f0.h; xd[64] = f0.l;
+        xd[128] = f1.h; xd[192] = f1.l;
       }
     }
   };
@@ -588,6 +647,7 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const GeosslChainStage st = ch.st[s];
+    const int eWs = eW;
     f32x4 tp[NEB][4], rs[NEB][4];
     // Every vector-memory instruction of the stage loop is issued unconditionally (buffer addressing: a null operand
     // is a zero-sized buffer whose loads return 0 and whose stores are dropped, rows past R get an out-of-range
@@ -627,24 +687,34 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
         }
         f32x16 acc;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_s + s * F + 32 * m + 8 * q + 4 * kh);
-          acc[4 * q] = bq.x; acc[4 * q + 1] = bq.y; acc[4 * q + 2] = bq.z; acc[4 * q + 3] = bq.w;
-        }
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
         {
           const u32x4* xs = xbuf + (size_t)i * RBF + lane;
-          Frag3 xa, xn;
-          xa.h = xs[0]; xa.m = xs[64]; xa.l = xs[128];
+          Frag2 xa, xn;
+          xa.h = xs[0]; xa.l = xs[64];
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
             if (ks + 1 < KS) {
-              const u32x4* src = xs + (size_t)((ks + 1) * 3) * 64;
-              xn.h = src[0]; xn.m = src[64]; xn.l = src[128];
+              const u32x4* src = xs + (size_t)((ks + 1) * 2) * 64;
+              xn.h = src[0]; xn.l = src[64];
             }
             __builtin_amdgcn_sched_barrier(0);
-            mma6(acc, af[ks], xa);
+            acc = mfma_f16(af[ks].l, xa.h, acc);
+            acc = mfma_f16(af[ks].h, xa.l, acc);
+            acc = mfma_f16(af[ks].h, xa.h, acc);
             __builtin_amdgcn_sched_barrier(0);
             if (ks + 1 < KS) xa = xn;
+          }
+        }
+        {  // undo the two operand scales (powers of two) and add the bias
+          const float kk = krow[i] * __builtin_amdgcn_ldexpf(1.0f, eWs - 14);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_s + s * F + 32 * m + 8 * q + 4 * kh);
+            acc[4 * q] = fmaf(acc[4 * q], kk, bq.x);
+            acc[4 * q + 1] = fmaf(acc[4 * q + 1], kk, bq.y);
+            acc[4 * q + 2] = fmaf(acc[4 * q + 2], kk, bq.z);
+            acc[4 * q + 3] = fmaf(acc[4 * q + 3], kk, bq.w);
           }
         }
         // epilogue in registers: lane = row, register 4q + e = column 32m + 8q + 4kh + e
@@ -679,6 +749,12 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
             vout[i][4 * q + 3] += r[q].w;
           }
         }
+        if (s + 1 < NS) {  // largest magnitudes of the results: scale of the next stage's input rows
+          float mx = 0.0f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fabsf(vout[i][e]));
+          publish_max(i, mx);
+        }
         if (i > 0) store_rb(i - 1);      // one row block late (see the header)
         if (i + 1 == nloc) store_rb(i);  // (register arrays are only ever indexed by unrolled constants)
       }
@@ -695,12 +771,17 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         if (i < nloc) {  // registers 0..7 / 8..15 are k-steps 2m / 2m+1 of the next stage (kperm)
-          const float lo[8] = {vout[i][0], vout[i][1], vout[i][2], vout[i][3], vout[i][4], vout[i][5], vout[i][6], vout[i][7]};
-          const float hi[8] = {vout[i][8], vout[i][9], vout[i][10], vout[i][11], vout[i][12], vout[i][13], vout[i][14], vout[i][15]};
-          const Frag3 f0 = split8(lo), f1 = split8(hi);
-          u32x4* xd = xbuf + (size_t)i * RBF + (size_t)(2 * m * 3) * 64 + lane;
-          xd[0] = f0.h; xd[64] = f0.m; xd[128] = f0.l;
-          xd[192] = f1.h; xd[256] = f1.m; xd[320] = f1.l;
+          const float sr = row_scale(i);
+          float lo[8], hi[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            lo[e] = vout[i][e] * sr;
+            hi[e] = vout[i][8 + e] * sr;
+          }
+          const Frag2 f0 = split8h(lo), f1 = split8h(hi);
+          u32x4* xd = xbuf + (size_t)i * RBF + (size_t)(2 * m * 2) * 64 + lane;
+          xd[0] = f0.h; xd[64] = f0.l;
+          xd[128] = f1.h; xd[192] = f1.l;
         }
       }
       lds_barrier();
@@ -715,11 +796,24 @@ int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipS
   const int nslot = chain_slots(ch.nstage * NMB);
   static const bool four_waves = getenv("GEOSSL_CHAIN4") != nullptr;  // the four-wave form, kept for A/B runs
   static const bool eight_waves = getenv("GEOSSL_CHAIN8") != nullptr;  // the streaming eight-wave form, for A/B runs
-  // weight-stationary form: F = 128, and every row-piece offset must fit the 32-bit range of a buffer descriptor
-  bool cu_form = KS == 8 && !four_waves && !eight_waves;
+  // weight-stationary form: F = 128 (its images are in the two-fp16-piece format: no other kernel reads them); every
+  // row-piece offset must fit the 32-bit range of a buffer descriptor: longer inputs run as two launches of half the rows
+  const bool cu_form = KS == 8;
   bool same_input = false;
   for (int s2 = 0; s2 < ch.nstage; ++s2) {
-    if ((int64_t)R * ch.st[s2].ld * 4 >= (int64_t)0xFFFFFF00u) cu_form = false;
+    if (cu_form && ((int64_t)R * ch.st[s2].ld * 4 >= (int64_t)0xFFFFFF00u || (int64_t)R * ldx * 4 >= (int64_t)0xFFFFFF00u)) {
+      const int64_t r0 = ((R / 2 + 31) / 32) * 32;
+      GeosslChain hi = ch;
+      for (int s3 = 0; s3 < ch.nstage; ++s3) {
+        GeosslChainStage& st = hi.st[s3];
+        if (st.out != nullptr) st.out += r0 * st.ld;
+        if (st.res != nullptr) st.res += r0 * st.ld;
+        if (st.tprev != nullptr) st.tprev += r0 * st.ld;
+        if (st.xin != nullptr) st.xin += r0 * st.ldxin;
+      }
+      const int rc = launch_chain<KS>(ch, X, ldx, r0, stream);
+      return rc != 0 ? rc : launch_chain<KS>(hi, X + r0 * ldx, ldx, R - r0, stream);
+    }
     same_input |= (ch.st[s2].flags & (GEOSSL_CHAIN_SAME_INPUT | GEOSSL_CHAIN_NEW_INPUT | GEOSSL_CHAIN_ADD_PREV)) != 0;
     if ((ch.st[s2].flags & GEOSSL_CHAIN_NEW_INPUT) && (ch.st[s2].xin == nullptr || ch.st[s2].ldxin < 16 * KS ||
                                                         (ch.st[s2].ldxin & 3)))
@@ -734,7 +828,7 @@ int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipS
     const int need = (nrb + RBV - 1) / RBV;                       // blocks so that none takes more than RB row blocks
     const int fill = nrb < slots ? nrb : slots;                   // blocks so that every slot of the chip has work
     const int grid = need > fill ? need : fill;
-    const size_t lds = (size_t)RBV * KS * 3 * 1024 + (size_t)ch.nstage * 16 * KS * sizeof(float);
+    const size_t lds = (size_t)RBV * KS * 2 * 1024 + (size_t)ch.nstage * 16 * KS * sizeof(float) + (size_t)RBV * 128 * sizeof(float);
 #define LAUNCH_CU(NSV)                                                                                           \
   do {                                                                                                           \
     if (one_per_cu) {                                                                                            \
