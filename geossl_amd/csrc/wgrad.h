@@ -1,5 +1,5 @@
-// Column GEMM (weight gradient) on the bf16 matrix pipe (split.h), shared by the atom-row Linear layers and the
-// NCSN head:       dW_z[m][n] = sum_r A_z[r][m] B_z[r][n]      (r < R, reduced over rows)
+// Column GEMM (weight gradient) on the matrix pipe with two fp16 pieces per operand (split.h), shared by the atom-row
+// Linear layers and the NCSN head:       dW_z[m][n] = sum_r A_z[r][m] B_z[r][n]      (r < R, reduced over rows)
 //                  db_z[m]    = sum_r A_z[r][m]                 (optional)
 //                  dd_z[m]    = sum_r A_z[r][m] e_z[r]          (optional, e = a per-row scalar)
 // The contraction runs over rows, so both operands are wanted feature-major (lane = column, 8 rows per lane): each
@@ -9,6 +9,9 @@
 // times a per-row scalar, a sum of two gathered atom rows) are rebuilt on the fly instead of being written to HBM
 // first.  32 rows per iteration, the requests of the next iteration fly during the MFMAs; one partial per row chunk,
 // summed in chunk order by k_reduce_partials (no atomics, bit-reproducible).
+// Operand scales: every 32-column operand block carries a running power-of-two exponent (the largest magnitude its
+// converting wave has met so far), published next to its fragments; an accumulator tile follows the sum of its two
+// blocks' exponents and is scaled down by the difference when one of them grows.
 //
 // Ops interface (row = row0 + 16 ks + 8 kh + e for element (ks, e) of a lane in half kh; `col` = operand column):
 //   struct RawA / RawB                     per-lane request state of one 32-row x 32-column operand block
@@ -38,7 +41,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
   constexpr int SA = (NCM + 3) / 4, SB = (NCN + 3) / 4;  // operand blocks converted per wave: A block wave + 4u
   constexpr int T = NCM * NCN, TPW = (T + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
-  u32x4* Fr = reinterpret_cast<u32x4*>(smem_raw);  // [NCM + NCN][2 k-steps][3][64]: A blocks first, then B blocks
+  u32x4* Fr = reinterpret_cast<u32x4*>(smem_raw);  // [NCM + NCN][2 k-steps][2][64]: A blocks first, then B blocks
+  int* eblk = reinterpret_cast<int*>(Fr + (size_t)(NCM + NCN) * 2 * 2 * 64);  // [NCM + NCN] running exponents
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
   const int z = blockIdx.y;
   const int row_begin = blockIdx.x * chunk, row_end = min(R, row_begin + chunk);
@@ -50,6 +54,25 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
   float bsum[SA], dsum[SA];
 #pragma unroll
   for (int u = 0; u < SA; ++u) bsum[u] = dsum[u] = 0.0f;
+  int ea[SA], eb[SB], eacc[TPW];  // running exponents: of the blocks this wave converts, of its accumulator tiles
+#pragma unroll
+  for (int u = 0; u < SA; ++u) ea[u] = -100;
+#pragma unroll
+  for (int u = 0; u < SB; ++u) eb[u] = -100;
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) eacc[i] = -200;
+  // scale of an operand block for this tile: wave-wide largest magnitude -> running exponent -> 2^(14 - e)
+  auto block_scale = [&](const float (&v)[2][8], int& e_run) __attribute__((always_inline)) {
+    float mx = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) mx = fmaxf(mx, fabsf(v[ks][q]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    e_run = max(e_run, __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_expf(mx)));
+    return __builtin_amdgcn_ldexpf(1.0f, 14 - e_run);
+  };
   // operand requests run PF row tiles ahead of their use (register sets in rotation); the block barriers are LDS-only,
   // so the requests stay in flight across them
 #ifndef WGRAD_PF
@@ -90,18 +113,23 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
       float v[2][8], e[2][8];
       ops.finish_a(z, min(col, M - 1), row0, row_end, kh, ra[u], v, e);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           if (col >= M) v[ks][q] = 0.0f;
           bsum[u] += v[ks][q];
           if (Ops::kDot) dsum[u] = fmaf(v[ks][q], e[ks][q], dsum[u]);
         }
-        const Frag3 f = split8(v[ks]);
-        u32x4* dst = Fr + (size_t)((blk * 2 + ks) * 3) * 64 + lane;
+      const float sc = block_scale(v, ea[u]);
+      if (lane == 0) eblk[blk] = ea[u];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[ks][q] *= sc;
+        const Frag2 f = split8h(v[ks]);
+        u32x4* dst = Fr + (size_t)((blk * 2 + ks) * 2) * 64 + lane;
         dst[0] = f.h;
-        dst[64] = f.m;
-        dst[128] = f.l;
+        dst[64] = f.l;
       }
     }
 #pragma unroll
@@ -111,46 +139,61 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
       const int col = 32 * blk + j;
       float v[2][8];
       ops.finish_b(z, min(col, N - 1), row0, row_end, kh, rb[u], v);
+      if (col >= N) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        if (col >= N) {
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[ks][q] = 0.0f;
-        }
-        const Frag3 f = split8(v[ks]);
-        u32x4* dst = Fr + (size_t)(((NCM + blk) * 2 + ks) * 3) * 64 + lane;
+      }
+      const float sc = block_scale(v, eb[u]);
+      if (lane == 0) eblk[NCM + blk] = eb[u];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[ks][q] *= sc;
+        const Frag2 f = split8h(v[ks]);
+        u32x4* dst = Fr + (size_t)(((NCM + blk) * 2 + ks) * 2) * 64 + lane;
         dst[0] = f.h;
-        dst[64] = f.m;
-        dst[128] = f.l;
+        dst[64] = f.l;
       }
     }
     lds_barrier();
     if (row0 + 32 * PF < row_end) request_into(row0 + 32 * PF, ra, rb);  // in flight for PF tiles
+    // the accumulator tiles follow their operand blocks' exponents
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int t = wave + 4 * i;
+      if (t >= T) continue;
+      const int en = __builtin_amdgcn_readfirstlane(eblk[t / NCN] + eblk[NCM + t % NCN]);
+      if (en != eacc[i]) {
+        const float f = __builtin_amdgcn_ldexpf(1.0f, eacc[i] - en);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] *= f;
+        eacc[i] = en;
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       // two tiles at a time: their twelve MFMAs alternate between the two accumulators
 #pragma unroll
       for (int i0 = 0; i0 < TPW; i0 += 2) {
-        Frag3 af[2], bf[2];
+        Frag2 af[2], bf[2];
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           const int t = wave + 4 * (i0 + d);
           if (i0 + d >= TPW || t >= T) continue;
-          const u32x4* sa = Fr + (size_t)(((t / NCN) * 2 + ks) * 3) * 64 + lane;
-          const u32x4* sb = Fr + (size_t)(((NCM + t % NCN) * 2 + ks) * 3) * 64 + lane;
-          af[d].h = sa[0]; af[d].m = sa[64]; af[d].l = sa[128];
-          bf[d].h = sb[0]; bf[d].m = sb[64]; bf[d].l = sb[128];
+          const u32x4* sa = Fr + (size_t)(((t / NCN) * 2 + ks) * 2) * 64 + lane;
+          const u32x4* sb = Fr + (size_t)(((NCM + t % NCN) * 2 + ks) * 2) * 64 + lane;
+          af[d].h = sa[0]; af[d].l = sa[64];
+          bf[d].h = sb[0]; bf[d].l = sb[64];
         }
 #define GEOSSL_WG_STEP(pa, pb)                                                              \
   _Pragma("unroll") for (int d = 0; d < 2; ++d) {                                           \
     if (i0 + d < TPW && wave + 4 * (i0 + d) < T)                                            \
-      acc[i0 + d] = mfma_bf16(af[d].pa, bf[d].pb, acc[i0 + d]);                             \
+      acc[i0 + d] = mfma_f16(af[d].pa, bf[d].pb, acc[i0 + d]);                              \
   }
         GEOSSL_WG_STEP(l, h)
         GEOSSL_WG_STEP(h, l)
-        GEOSSL_WG_STEP(m, m)
-        GEOSSL_WG_STEP(m, h)
-        GEOSSL_WG_STEP(h, m)
         GEOSSL_WG_STEP(h, h)
 #undef GEOSSL_WG_STEP
       }
@@ -170,10 +213,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
     if (t >= T) continue;
     const int mb = t / NCN, nb = t % NCN, n = 32 * nb + j;
     if (n >= N) continue;
+    const float kk = __builtin_amdgcn_ldexpf(1.0f, eacc[i] - 28);  // undo the two operand scales
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = 32 * mb + c_row(r, lane);
-      if (m < M) Pp[(size_t)m * N + n] = acc[i][r];
+      if (m < M) Pp[(size_t)m * N + n] = acc[i][r] * kk;
     }
   }
 #pragma unroll
@@ -206,7 +250,7 @@ int launch_wgrad_split(const Ops& ops, int nprob, int64_t R, int M, int N, const
     any_b |= out.db[z] != nullptr;
     any_d |= out.dd[z] != nullptr;
   }
-  const size_t lds = (size_t)(NCM + NCN) * 2 * 3 * 1024;
+  const size_t lds = (size_t)(NCM + NCN) * 2 * 2 * 1024 + (size_t)(NCM + NCN) * sizeof(int);
   allow_big_lds(&k_wgrad_split<NCM, NCN, Ops>);
   hipLaunchKernelGGL((k_wgrad_split<NCM, NCN, Ops>), dim3(nblk, nprob), dim3(256), lds, stream, ops, (int)R, chunk, M,
                      N, partial, any_b ? pbias : nullptr, any_d ? pdot : nullptr);
