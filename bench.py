@@ -26,9 +26,12 @@ F, L, G, CUTOFF, K_LEVELS = 128, 6, 51, 5.0, 50
 HBM_PEAK = 8.0e12       # B/s, spec (MI355X_MICROARCH.md)
 FP32_PEAK = 157.3e12    # FLOP/s, vector == f32-MFMA rate (they share the FP32 lanes on gfx950)
 BF16_PEAK = 2.5e15      # FLOP/s, dense bf16 MFMA (MI355X_MICROARCH.md)
-# The dense kernels evaluate every fp32 product as six bf16 MFMAs over an exact 3-way bf16 split of both operands
-# (csrc/split.h): the matrix-pipe ceiling in fp32-equivalent flops is BF16_PEAK / 6.
-SPLIT_PRODUCTS = 6
+# The dense kernels evaluate every fp32 product on the 16-bit matrix pipe (csrc/split.h): the filter network, the chained
+# row kernel and the weight-gradient GEMM as THREE fp16 MFMAs over a two-piece fp16 split of both operands (power-of-two
+# operand scales), the NCSN head still as six bf16 MFMAs over a three-piece bf16 split.  fp16 and bf16 MFMAs have the same
+# dense peak; the matrix-pipe ceiling in fp32-equivalent flops is that peak / (MFMAs per product).
+SPLIT_PRODUCTS_OF = {"geossl_cfconv_filter_fwd": 3, "geossl_cfconv_filter_bwd": 3, "geossl_linear_wgrad": 3}
+SPLIT_PRODUCTS_DEFAULT = 6
 # entry points whose launches are bracketed with HIP events inside the timed region
 TIMED = ("geossl_cfconv_filter_fwd", "geossl_cfconv_filter_bwd",
          "geossl_ddm_loss_fwd", "geossl_ddm_loss_bwd_rows", "geossl_ddm_loss_bwd_weights", "geossl_linear_wgrad",
@@ -432,11 +435,12 @@ def main():
                 ks = [v for k, v in pm["kernels"].items() if k.startswith(ENTRY_KERNELS.get(dom, "\0"))]
                 if ks:
                     traffic = sum(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for v in ks)
-            # The dense kernels run on the bf16 matrix pipe, six MFMAs per fp32 product (csrc/split.h).
+            # The dense kernels run on the 16-bit matrix pipe, SPLIT MFMAs per fp32 product (csrc/split.h).
             # `frac` = what the kernel really issues (one filter evaluation per UNDIRECTED pair slot, G padded to 64,
-            # times six bf16 MFMAs) over the dense bf16 MFMA peak: the pipe's utilisation.  `frac_algorithmic` credits
+            # times SPLIT MFMAs) over the dense 16-bit MFMA peak: the pipe's utilisation.  `frac_algorithmic` credits
             # SURVEY 8(d)'s fp32 flops of the reference formulation (one evaluation per DIRECTED edge) against the
-            # pipe's fp32-equivalent ceiling (peak / 6) - the exact halving by symmetry shows up there, not in `frac`.
+            # pipe's fp32-equivalent ceiling (peak / SPLIT) - the exact halving by symmetry shows up there, not in `frac`.
+            SPLIT_PRODUCTS = SPLIT_PRODUCTS_OF.get(dom, SPLIT_PRODUCTS_DEFAULT)
             roof = {"kernel": dom, "bound": "mfma", "unit": "TFLOP/s", "traffic": traffic,
                     "traffic_from": ("%s @ %s" % (pm_src, pm.get("git_head"))) if traffic is not None else None,
                     "avg_launch_ms": kern[dom][0], "launches_per_step": kern[dom][1], "timing": timing_mode,
@@ -452,11 +456,13 @@ def main():
                 P2 = 2 * sum(int(n) * (int(n) - 1) // 2 for n in sizes0)  # pair slots, both views
                 per_row = (2 * 64 * F + (2 if dom.endswith("fwd") else 4) * F * F)
                 exe = P2 * L * per_row * SPLIT_PRODUCTS
-            else:  # other entry points issue their algorithmic flops, six MFMAs per product
+            else:  # other entry points issue their algorithmic flops, SPLIT MFMAs per product
                 exe = fl * SPLIT_PRODUCTS
             if not dom.startswith("geossl_painn"):
                 roof.update({"achieved": exe / dur / 1e12, "peak": BF16_PEAK / 1e12, "frac": exe / dur / BF16_PEAK,
-                             "peak_note": "executed bf16 MFMA flops (6 per fp32 product) over the 2.5 PFLOP/s dense bf16 peak"})
+                             "mfma_per_fp32_product": SPLIT_PRODUCTS,
+                             "peak_note": "executed 16-bit MFMA flops (%d per fp32 product) over the 2.5 PFLOP/s dense peak at 2.4 GHz; "
+                                          "under this load the shader clock settles at 1.6-1.9 GHz (tools/filter_fwd_timing.py)" % SPLIT_PRODUCTS})
         per_gpu = value / world
         out = {
             "metric": ("molecules/s/GPU SchNet+DDM fwd+bwd (QM9-sized, bs=1024); % HBM roofline" if args.model == "schnet"

@@ -731,3 +731,131 @@ def test_schnet_latent_only_skips_the_readout():
     out, h = model(z, pos, batch, return_latent=True)
     none, h2 = model(z, pos, batch, return_latent=True, latent_only=True)
     assert none is None and torch.equal(h, h2)
+
+
+# ------------------------------------------------------------------- two-fp16-piece kernels: scales and accuracy
+def _filter_problem(nmol, seed, F=128, G=51, L=2, cutoff=5.0):
+    """A two-layer filter-network problem on synthetic molecules, through the raw C ABI: returns the tensors the
+    backward kernel consumes and an fp64 evaluation of what it must produce (schnet.py:141-145,186-195 differentiated
+    w.r.t. the filter weights)."""
+    import ctypes as C
+    import math
+    from geossl_amd import _lib, ops
+    from geossl_amd._lib import call, ptr, stream
+    from geossl_amd.layout import MolLayout
+    from geossl_amd.synthetic import make_batch
+    b = make_batch(nmol, seed=seed, mode="B")
+    sizes = [int(n) for n in b["sizes"]]
+    batch = torch.arange(len(sizes), device=DEV).repeat_interleave(torch.tensor(sizes, device=DEV))
+    lay = MolLayout(batch, len(sizes), sizes=sizes)
+    pos = torch.from_numpy(np.asarray(b["positions"], dtype=np.float32)).to(DEV)
+    pair_d, pair_c, pair_flag = ops.pair_geometry(pos, lay, cutoff)
+    gen = torch.Generator().manual_seed(seed)
+    N, P = lay.N, lay.P
+    offset = torch.linspace(0.0, cutoff, G).to(DEV)
+    coeff = -0.5 / float(offset[1] - offset[0]) ** 2
+    ws = [[(torch.randn(F, G, generator=gen) / G ** 0.5).to(DEV), (0.3 * torch.randn(F, generator=gen)).to(DEV),
+           (torch.randn(F, F, generator=gen) / F ** 0.5).to(DEV), (0.3 * torch.randn(F, generator=gen)).to(DEV)] for _ in range(L)]
+    xs = [torch.randn(N, F, generator=gen).to(DEV) for _ in range(L)]
+    daggs = [torch.randn(N, F, generator=gen).to(DEV) for _ in range(L)]
+    fw = _lib.FilterWeights()
+    for l, w in enumerate(ws):
+        fw.w1[l], fw.b1[l], fw.w2[l], fw.b2[l] = (ptr(x) for x in w)
+    Wf = torch.empty(L, P, F, device=DEV)
+    T = torch.empty(L, P, F, device=DEV)
+    call("geossl_cfconv_filter_fwd", ptr(pair_d), ptr(pair_c), P, C.byref(fw), L, F, G, ptr(offset), coeff, ptr(T), ptr(Wf), stream())
+
+    def run(daggs_):
+        gin, gout = _lib.FilterGradIn(), _lib.FilterGradOut()
+        outs = [[torch.zeros(F, G, device=DEV), torch.zeros(F, device=DEV), torch.zeros(F, F, device=DEV), torch.zeros(F, device=DEV)]
+                for _ in range(L)]
+        for l in range(L):
+            gin.x[l], gin.dagg[l] = ptr(xs[l]), ptr(daggs_[l])
+            gout.dw1[l], gout.db1[l], gout.dw2[l], gout.db2[l] = (ptr(o) for o in outs[l])
+        nfl = _lib.load().geossl_cfconv_filter_bwd_workspace_floats(P, L, F, G)
+        wsp = torch.empty(nfl, device=DEV)
+        call("geossl_cfconv_filter_bwd", ptr(pair_d), ptr(pair_c), ptr(pair_flag), ptr(lay.pair_i), ptr(lay.pair_j), P, N, C.byref(fw),
+             C.byref(gin), L, F, G, ptr(offset), coeff, ptr(T), C.byref(gout), ptr(wsp), 0, stream())
+        torch.cuda.synchronize()
+        return outs
+
+    def ref64(daggs_):
+        i, j = lay.pair_i.long(), lay.pair_j.long()
+        fl = pair_flag.long()
+        m0 = ((fl & 1) > 0).double() * pair_c.double()
+        m1 = ((fl & 2) > 0).double() * pair_c.double()
+        rbf = torch.exp(coeff * (pair_d.double()[:, None] - offset.double()[None, :]) ** 2)
+        outs = []
+        for l, (w1, b1, w2, b2) in enumerate(ws):
+            x, dg = xs[l].double(), daggs_[l].double()
+            dO = m0[:, None] * (dg[i] * x[j]) + m1[:, None] * (dg[j] * x[i])
+            u = rbf @ w1.double().t() + b1.double()
+            tt = torch.nn.functional.softplus(u) - math.log(2.0)
+            dU = (dO @ w2.double()) * torch.sigmoid(u)
+            outs.append([dU.t() @ rbf, dU.sum(0), dO.t() @ tt, dO.sum(0)])
+        return outs
+
+    return lay, daggs, run, ref64
+
+
+def _check_filter_grads(got, ref, tol, what):
+    for l, (g4, r4) in enumerate(zip(got, ref)):
+        for name, g, r in zip(("dw1", "db1", "dw2", "db2"), g4, r4):
+            err = float((g.double() - r).abs().max() / r.abs().max().clamp_min(1e-300))
+            assert err < tol, (what, l, name, err)
+
+
+def test_filter_backward_direct_vs_fp64_and_operand_scale_paths():
+    """geossl_cfconv_filter_bwd through the C ABI against fp64.  The kernel runs on two fp16 pieces per operand with
+    running power-of-two block scales (csrc/split.h, filter_bwd.hip): upstream gradients of ordinary size, tiny (1e-12),
+    large (1e+6), and with magnitudes that RISE and FALL by 2^30 along the atoms (so tiles late in a block's range raise
+    the running scale and the accumulators are rescaled) must all keep the accuracy of an fp32 GEMM chain."""
+    lay, daggs, run, ref64 = _filter_problem(nmol=300, seed=11)
+    N = lay.N
+    ramp = torch.exp2(torch.linspace(-20.0, 10.0, N, device=DEV).round())
+    cases = {"plain": daggs, "tiny": [d * 1e-12 for d in daggs], "large": [d * 1e6 for d in daggs],
+             "rising": [d * ramp[:, None] for d in daggs], "falling": [d * ramp.flip(0)[:, None] for d in daggs]}
+    for what, dg in cases.items():
+        _check_filter_grads(run(dg), ref64(dg), 3e-6, what)
+
+
+def test_filter_backward_is_exactly_linear_in_powers_of_two():
+    """Scaling the upstream gradient by 2^k scales every operand piece, every operand scale and every accumulator by an
+    exact power of two: the weight gradients must come out bit-identical up to that factor."""
+    lay, daggs, run, _ = _filter_problem(nmol=120, seed=5)
+    base = run(daggs)
+    for k in (-24, 17):
+        got = run([d * (2.0 ** k) for d in daggs])
+        for g4, b4 in zip(got, base):
+            for g, b0 in zip(g4, b4):
+                assert torch.equal(g, b0 * (2.0 ** k)), k
+
+
+@pytest.mark.parametrize("scale_w, scale_in", [(1e-3, 1.0), (30.0, 1.0), (1.0, 1e-9), (1.0, 1e5)])
+def test_chain_and_wgrad_keep_fp32_accuracy_at_any_operand_scale(scale_w, scale_in):
+    """The chained row kernel and the weight-gradient GEMM (two fp16 pieces, per-row / per-block / per-matrix power-of-two
+    scales) against fp64 with operands far from 1: rows whose magnitudes span 2^24 inside one launch included."""
+    from geossl_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    R, F = 5000, 128
+    rowmag = torch.exp2(torch.randint(-12, 13, (R, 1), generator=gen).float())
+    X = (torch.randn(R, F, generator=gen) * rowmag * scale_in).to(DEV)
+    Ws = [(torch.randn(F, F, generator=gen) / F ** 0.5 * scale_w).to(DEV) for _ in range(3)]
+    bs = [(0.1 * scale_w * scale_in * torch.randn(F, generator=gen)).to(DEV) for _ in range(3)]
+    imgs = ops.prepare_chain(Ws)
+    outs = [torch.empty(R, F, device=DEV) for _ in range(3)]
+    ops.linear_chain(X, [dict(image=imgs[s], bias=bs[s], out=outs[s]) for s in range(3)])
+    ref = X.double()
+    for s in range(3):
+        ref = ref @ Ws[s].double().t() + bs[s].double()
+        # per row: rows differ by 2^24 in size, each must be accurate at its own scale
+        err = ((outs[s].double() - ref).abs().amax(1) / ref.abs().amax(1).clamp_min(1e-300)).max()
+        assert float(err) < 3e-6 * (s + 1), (s, float(err))
+    A = X
+    B = (torch.randn(R, F, generator=gen) * rowmag.flip(0) * scale_w).to(DEV)
+    dW, db = torch.zeros(F, F, device=DEV), torch.zeros(F, device=DEV)
+    ops.linear_wgrad([(A, B, dW, db)], R, F, F)
+    refW = A.double().t() @ B.double()
+    assert float((dW.double() - refW).abs().max() / refW.abs().max()) < 3e-6
+    refb = A.double().sum(0)
+    assert float((db.double() - refb).abs().max() / refb.abs().max()) < 3e-6
