@@ -36,13 +36,22 @@ namespace {
 #ifdef FB_TIMING
 __device__ long long fb_dbg[2 * 64 * 8];
 __device__ long long fb_dbg2[2 * 64];
+__device__ long long fb_dbg3[64 * 4];
 #define FB_MARK(slot)                                                                                   \
   do {                                                                                                  \
     if (blockIdx.x == 3 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == NW) && t - t_begin < 64) \
       fb_dbg[((wave == 0 ? 0 : 1) * 64 + (t - t_begin)) * 8 + (slot)] = clock64();                      \
   } while (0)
+#define FB3(slot)                                                                                      \
+  do {                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if (blockIdx.x == 3 && blockIdx.y == 0 && lane == 0 && wave == NW && tt - t_begin < 64 && tt > t_begin) \
+      fb_dbg3[(tt - t_begin) * 4 + (slot)] = clock64();                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  } while (0)
 #else
 #define FB_MARK(slot) do {} while (0)
+#define FB3(slot) do {} while (0)
 #endif
 constexpr int TR = 32;         // pair rows per tile
 constexpr int ATOM_CAP = 40;   // atoms staged per tile (two 18..20-atom molecules, or more smaller ones)
@@ -187,9 +196,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
       const int bsel = tt & 1, rr0 = tt * TR;
       const int nwin = min(ATOM_CAP, N - alo_t);
       if (wave == NW) {
-        int amax = lane < TR ? aj + 1 : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o, 64));
+        const int amax = wave_max_i32(lane < TR ? aj + 1 : 0);
         const bool staged0 = amax - alo_t <= ATOM_CAP;
         if (lane < TR) {
           const unsigned fl = rr0 + lane < P ? fl_raw : 0u;  // rows past P contribute nothing
@@ -493,7 +500,11 @@ __global__ __launch_bounds__(128 * NW) void k_filter_bwd(const float* __restrict
 // The same kernel on TWO fp16 pieces per operand (split.h: 3 MFMAs per product instead of 6, the selection-matrix
 // transposition on two pieces instead of three), the default.  The three-bf16-piece form above stays selectable with
 // GEOSSL_FILTER_BWD_BF16X3 for A/B runs.
+#ifdef FB_TIMING
+#define FBH_MARK(slot) FB_MARK(slot)
+#else
 #define FBH_MARK(slot) do {} while (0)
+#endif
 template <int F>
 struct BwdLdsH {
   static constexpr int AS = F + 4;  // staged atom row stride (16-byte aligned rows)
@@ -616,9 +627,8 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
   float cval = 0.0f, dd = 0.0f;
   unsigned fl_raw = 0u;
   float tc[16];
-  auto request_atoms = [&](int tt, int alo_t) {  // role B: window of x / dagg rows + the row descriptors of tile tt
+  auto request_atoms = [&](int tt, int alo_t) {  // role B: window of x / dagg rows of tile tt; role A: its row descriptors
     if constexpr (!roleA) {
-      const int rr0 = tt * TR;
       // clamped addresses, no predication (a predicated load compiles to a branch with a full wait per element);
       // slots past the window are never read back
       const int nwin = min(ATOM_CAP, N - alo_t);
@@ -630,8 +640,9 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
         px[u] = x4[i];
         pdg[u] = d4[i];
       }
-      if (stid < TR) {  // one pair row per lane of the first role-B wave
-        const int q = min(rr0 + stid, P - 1);  // raw values only: nothing here waits for the loads
+    } else {
+      if (tid < TR) {  // the row descriptors: one pair row per lane of the first role-A wave (role B is the longer path)
+        const int q = min(tt * TR + tid, P - 1);  // raw values only: nothing here waits for the loads
         ai = pair_i[q];
         aj = pair_j[q];
         fl_raw = pair_flag[q];
@@ -649,15 +660,13 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
       for (int r = 0; r < 16; ++r) tc[r] = Tl[(uint32_t)min(rr0 + c_row(r, lane), P - 1) * (uint32_t)F + tcol];
     }
   };
-  // role B: publish the window + descriptors held in registers (requested earlier) as tile tt's staging buffer
+  // publish what was requested earlier as tile tt's staging buffer: role B the atom window (and its largest magnitudes),
+  // the first role-A wave the row descriptors (role B is the longer path of the phase)
   auto publish = [&](int tt, int alo_t) {
-    if constexpr (!roleA) {
+    if constexpr (roleA) {
       const int bsel = tt & 1, rr0 = tt * TR;
-      const int nwin = min(ATOM_CAP, N - alo_t);
-      if (wave == NW) {
-        int amax = lane < TR ? aj + 1 : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o, 64));
+      if (wave == 0) {
+        const int amax = wave_max_i32(lane < TR ? aj + 1 : 0);
         const bool staged0 = amax - alo_t <= ATOM_CAP;
         if (lane < TR) {
           const unsigned fl = rr0 + lane < P ? fl_raw : 0u;  // rows past P contribute nothing
@@ -671,6 +680,11 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
           L.et[CB] = 0;
         }
       }
+    } else {
+      const int bsel = tt & 1;
+      const int nwin = min(ATOM_CAP, N - alo_t);
+      FB3(0);
+      FB3(1);
       float* xs = L.xs(bsel);
       float* ds = L.ds(bsel);
       float mx = 0.0f, md = 0.0f;  // largest |x|, |dagg| of the window (clamped duplicates are window values too)
@@ -685,15 +699,14 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
           *reinterpret_cast<f32x4*>(ds + a * AS + 4 * q4) = pdg[u];
         }
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        md = fmaxf(md, __shfl_xor(md, o, 64));
-      }
+      FB3(2);
+      mx = wave_max(mx);
+      md = wave_max(md);
       if (lane == 0) {
         L.wmax(bsel)[2 * (wave - NW)] = mx;
         L.wmax(bsel)[2 * (wave - NW) + 1] = md;
       }
+      FB3(3);
     }
   };
   // prologue: tile t_begin published, atoms of tile t_begin + 1 in flight, activations of tile t_begin in flight.
@@ -764,8 +777,7 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
       float m = 0.0f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      m = wave_max(m);
       if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(L.et + CB), __float_as_uint(m));  // zeroed by publish()
       lds_barrier();
       bound = __uint_as_float(*reinterpret_cast<volatile unsigned*>(L.et + CB));
@@ -801,8 +813,7 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
       float tm = 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) tm = fmaxf(tm, fabsf(tc[r]));
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o, 64));
+      tm = wave_max(tm);
       ET = max(ET, __builtin_amdgcn_readfirstlane(max(__builtin_amdgcn_frexp_expf(tm), -100)));
       const float sT = __builtin_amdgcn_ldexpf(1.0f, 14 - ET);
       if (lane == 0) L.et[hs] = ET;
@@ -816,8 +827,7 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
         dst[0] = f.h;
         dst[64] = f.l;
       }
-    } else {
-      for (int it = tid - NT / 2; it < 2 * 2 * 64; it += NT / 2) {  // rbf: B[k = row = 16ks + kperm(e, kh)][n = g]
+      for (int it = tid; it < 2 * 2 * 64; it += NT / 2) {  // rbf: B[k = row = 16ks + kperm(e, kh)][n = g]
         const int ln = it & 63, ks = (it >> 6) & 1, gb = it >> 7;
         const int gg = 32 * gb + (ln & 31);
         const float off = gg < G ? offset[gg] : 0.0f;
@@ -1048,6 +1058,9 @@ inline int blocks_per_layer(int L, int ntiles) {
 #ifdef FB_TIMING
 extern "C" int geossl_filter_bwd_debug_read(long long* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fb_dbg), sizeof(long long) * 2 * 64 * 8);
+}
+extern "C" int geossl_filter_bwd_debug_read3(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fb_dbg3), sizeof(long long) * 64 * 4);
 }
 extern "C" int geossl_filter_bwd_debug_read2(long long* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fb_dbg2), sizeof(long long) * 2 * 64);

@@ -68,8 +68,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int q = 0; q < 8; ++q) mx = fmaxf(mx, fabsf(v[ks][q]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mx = wave_max(mx);
     e_run = max(e_run, __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_expf(mx)));
     return __builtin_amdgcn_ldexpf(1.0f, 14 - e_run);
   };

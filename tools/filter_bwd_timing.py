@@ -42,3 +42,12 @@ for role, nm in ((0, "A_0"), (1, "B_0")):
     print("   %-46s %7.0f" % ("(barrier 2 -> all earlier global requests done)", np.mean([v2[role, t] - m[t, 3] for t in ok])))
     for i, n in enumerate(names):
         print("   %-46s %7.0f" % (n, d[:, i].mean()))
+
+if hasattr(lib, "geossl_filter_bwd_debug_read3"):
+    b3 = (C.c_longlong * 256)()
+    lib.geossl_filter_bwd_debug_read3.argtypes = [C.c_void_p]
+    assert lib.geossl_filter_bwd_debug_read3(b3) == 0
+    m3 = np.array(list(b3), dtype=np.int64).reshape(64, 4)
+    ok = [t for t in range(3, 38) if m3[t, 0] and m3[t, 3]]
+    print("inside publish (wave B_0): descriptors %.0f, window stores + maxima %.0f, wave maxima %.0f" %
+          (np.mean([m3[t, 1] - m3[t, 0] for t in ok]), np.mean([m3[t, 2] - m3[t, 1] for t in ok]), np.mean([m3[t, 3] - m3[t, 2] for t in ok])))
