@@ -627,7 +627,9 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
   float cval = 0.0f, dd = 0.0f;
   unsigned fl_raw = 0u;
   float tc[16];
+  int ajw = 0;  // second atom of row (lane & 31) of the tile ahead: every wave takes the window decision itself
   auto request_atoms = [&](int tt, int alo_t) {  // role B: window of x / dagg rows of tile tt; role A: its row descriptors
+    ajw = pair_j[min(tt * TR + j, P - 1)];
     if constexpr (!roleA) {
       // clamped addresses, no predication (a predicated load compiles to a branch with a full wait per element);
       // slots past the window are never read back
@@ -662,12 +664,26 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
   };
   // publish what was requested earlier as tile tt's staging buffer: role B the atom window (and its largest magnitudes),
   // the first role-A wave the row descriptors (role B is the longer path of the phase)
+  // The staged window is STICKY: it stays as long as the next tile's atoms still fall inside it (pair slots are
+  // lexicographic, so a window that starts at some atom of a molecule serves the rest of that molecule and the next one) -
+  // about nine tiles in ten of 18-atom molecules skip the staging stores.  Every wave takes the decision from the same
+  // values (wab = buffer holding the window, walo = its first atom).
+  int wab = 0, walo = 0;
+  bool whave = false;
   auto publish = [&](int tt, int alo_t) {
+    const int amax = wave_max_i32(ajw + 1);
+    const bool fits = whave && alo_t >= walo && amax - walo <= ATOM_CAP;
+    const bool fresh = !fits && amax - alo_t <= ATOM_CAP;
+    if (fresh) {
+      wab ^= 1;
+      walo = alo_t;
+      whave = true;
+    }
+    const bool staged0 = fits || fresh;
+    alo_t = walo;  // descriptors are relative to the window in use
     if constexpr (roleA) {
       const int bsel = tt & 1, rr0 = tt * TR;
       if (wave == 0) {
-        const int amax = wave_max_i32(lane < TR ? aj + 1 : 0);
-        const bool staged0 = amax - alo_t <= ATOM_CAP;
         if (lane < TR) {
           const unsigned fl = rr0 + lane < P ? fl_raw : 0u;  // rows past P contribute nothing
           const float m0 = (fl & 1u) ? cval : 0.0f, m1 = (fl & 2u) ? cval : 0.0f;
@@ -677,11 +693,12 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
         }
         if (lane == 0) {
           L.flag(bsel)[0] = staged0 ? 1 : 0;
+          L.flag(bsel)[1] = wab;
           L.et[CB] = 0;
         }
       }
-    } else {
-      const int bsel = tt & 1;
+    } else if (fresh) {
+      const int bsel = wab;
       const int nwin = min(ATOM_CAP, N - alo_t);
       FB3(0);
       FB3(1);
@@ -740,6 +757,7 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
                     // tiles ahead stay in flight; measured neutral against __syncthreads here)
     FBH_MARK(1);
     const bool staged = L.flag(bsel)[0] != 0;
+    const int wsel = L.flag(bsel)[1];  // staging buffer that holds this tile's atom window
     // ---- tile build: every thread one dOr fragment lane; role A publishes its tf lanes, role B its rbf lanes
     float v[8];
     auto build = [&](const float* xb, const float* db, int stride) {
@@ -764,12 +782,12 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
     };
     float bound;
     if (staged) {
-      build(L.xs(bsel), L.ds(bsel), 1);  // descriptors hold LDS float offsets
+      build(L.xs(wsel), L.ds(wsel), 1);  // descriptors hold LDS float offsets
       float mx = 0.0f, md = 0.0f;
 #pragma unroll
       for (int i = 0; i < NW; ++i) {
-        mx = fmaxf(mx, L.wmax(bsel)[2 * i]);
-        md = fmaxf(md, L.wmax(bsel)[2 * i + 1]);
+        mx = fmaxf(mx, L.wmax(wsel)[2 * i]);
+        md = fmaxf(md, L.wmax(wsel)[2 * i + 1]);
       }
       bound = 2.0f * mx * md;  // |dO| <= C (|dagg_i x_j| + |dagg_j x_i|), C <= 1
     } else {
@@ -827,7 +845,11 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
         dst[0] = f.h;
         dst[64] = f.l;
       }
-      for (int it = tid; it < 2 * 2 * 64; it += NT / 2) {  // rbf: B[k = row = 16ks + kperm(e, kh)][n = g]
+    }
+    // Gaussian fragments: one builder wave per SIMD - role-A waves 0 .. NW/2-1 and role-B waves NW/2 .. NW-1 (the two
+    // roles' build phases are then about equally long)
+    if (NW == 1 ? roleA : (roleA ? hs < NW / 2 : hs >= NW / 2)) {
+      for (int it = 64 * hs + lane; it < 2 * 2 * 64; it += 64 * (NW == 1 ? 1 : NW)) {  // rbf: B[k = row = 16ks + kperm(e, kh)][n = g]
         const int ln = it & 63, ks = (it >> 6) & 1, gb = it >> 7;
         const int gg = 32 * gb + (ln & 31);
         const float off = gg < G ? offset[gg] : 0.0f;
