@@ -35,7 +35,8 @@ SPLIT_PRODUCTS_DEFAULT = 6
 # entry points whose launches are bracketed with HIP events inside the timed region
 TIMED = ("geossl_cfconv_filter_fwd", "geossl_cfconv_filter_bwd",
          "geossl_ddm_loss_fwd", "geossl_ddm_loss_bwd_rows", "geossl_ddm_loss_bwd_weights", "geossl_linear_wgrad",
-         "geossl_painn_interaction_fwd", "geossl_painn_interaction_bwd")
+         "geossl_painn_interaction_fwd", "geossl_painn_interaction_bwd",
+         "geossl_painn_interaction_fwd_mol", "geossl_painn_interaction_bwd_mol")
 PAINN_L, PAINN_R = 3, 20  # config.py:118-121 defaults of the reference's PaiNN (n_interactions, n_rbf)
 
 
@@ -98,6 +99,9 @@ def alg_model_painn(n_atoms, n_edges, n_super):
         "geossl_painn_interaction_fwd": (2 * E * edge_fwd, 2 * E * (4 * R + 16 + 24 * F) + 2 * N * 32 * F),
         "geossl_painn_interaction_bwd": (2 * E * (3 * 2 * R * 3 * F + 18 * F), 2 * E * (4 * R + 16 + 36 * F) + 2 * N * 56 * F),
     }
+    # the molecule-staged kernels (the default) do the same work per launch
+    per_kernel["geossl_painn_interaction_fwd_mol"] = per_kernel["geossl_painn_interaction_fwd"]
+    per_kernel["geossl_painn_interaction_bwd_mol"] = per_kernel["geossl_painn_interaction_bwd"]
     return step_bytes, step_flops, per_kernel
 
 
