@@ -261,7 +261,10 @@ __global__ __launch_bounds__(512) void k_filter_fwd(const float* __restrict__ pa
 // row of a pair by ITS largest magnitude (per lane pair: the row of pair j lives in lanes j and j + 32).  The biases
 // are added to the unscaled fp32 results (one FMA each), so the accumulators start from 0.
 template <int NMB, int K1S>
-__global__ __launch_bounds__(512) void k_filter_fwd_h(const float* __restrict__ pair_d,
+#ifndef FFH_THREADS
+#define FFH_THREADS 512
+#endif
+__global__ __launch_bounds__(FFH_THREADS) void k_filter_fwd_h(const float* __restrict__ pair_d,
                                                       const float* __restrict__ pair_c, int P,
                                                       GeosslFilterWeights w, int G,
                                                       const float* __restrict__ offset, float coeff,
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(512) void k_filter_fwd_h(const float* __restrict__ 
   float* b1s = reinterpret_cast<float*>(W1f + NMB * K1S * 2 * 64);  // [F]
   float* b2s = b1s + F;                                     // [F]
   float* offs = b2s + F;                                    // [16*K1S] Gaussian centres, zero padded
-  float* red = offs + 16 * K1S;                             // [16] block reduction of the two weight maxima
+  float* red = offs + 16 * K1S;                             // [32] block reduction of the two weight maxima
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
   const int l = blockIdx.y;
   float s1, s2;
@@ -281,8 +284,8 @@ __global__ __launch_bounds__(512) void k_filter_fwd_h(const float* __restrict__ 
     const float* __restrict__ w2 = w.w2[l];
     const float* __restrict__ w1 = w.w1[l];
     float m1 = 0.0f, m2 = 0.0f;
-    for (int i = tid; i < F * G; i += 512) m1 = fmaxf(m1, fabsf(w1[i]));
-    for (int i = tid; i < F * F; i += 512) m2 = fmaxf(m2, fabsf(w2[i]));
+    for (int i = tid; i < F * G; i += FFH_THREADS) m1 = fmaxf(m1, fabsf(w1[i]));
+    for (int i = tid; i < F * F; i += FFH_THREADS) m2 = fmaxf(m2, fabsf(w2[i]));
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
       m1 = fmaxf(m1, __shfl_xor(m1, o));
@@ -290,18 +293,18 @@ __global__ __launch_bounds__(512) void k_filter_fwd_h(const float* __restrict__ 
     }
     if (lane == 0) {
       red[wave] = m1;
-      red[8 + wave] = m2;
+      red[16 + wave] = m2;
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < FFH_THREADS / 64; ++i) {
       m1 = fmaxf(m1, red[i]);
-      m2 = fmaxf(m2, red[8 + i]);
+      m2 = fmaxf(m2, red[16 + i]);
     }
     int e1, e2;
     s1 = pow2_scale_to_2p14(m1, e1);
     s2 = pow2_scale_to_2p14(m2, e2);
-    for (int i = tid; i < NMB * K2S * 64; i += 512) {
+    for (int i = tid; i < NMB * K2S * 64; i += FFH_THREADS) {
       const int ln = i & 63, ks = (i >> 6) % K2S, mb = i / (64 * K2S);
       // contraction-index permutation kperm (split.h): elements 0..3 <- features 4kh.., 4..7 <- features 8+4kh..
       const float* row = w2 + (size_t)(32 * mb + (ln & 31)) * F + 16 * ks + 4 * (ln >> 5);
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(512) void k_filter_fwd_h(const float* __restrict__ 
       dst[0] = f.h;
       dst[64] = f.l;
     }
-    for (int i = tid; i < NMB * K1S * 64; i += 512) {
+    for (int i = tid; i < NMB * K1S * 64; i += FFH_THREADS) {
       const int ln = i & 63, ks = (i >> 6) % K1S, mb = i / (64 * K1S);
       const float* row = w1 + (size_t)(32 * mb + (ln & 31)) * G;
       float v[8];
@@ -326,17 +329,17 @@ __global__ __launch_bounds__(512) void k_filter_fwd_h(const float* __restrict__ 
       dst[0] = f.h;
       dst[64] = f.l;
     }
-    for (int i = tid; i < F; i += 512) {
+    for (int i = tid; i < F; i += FFH_THREADS) {
       b1s[i] = w.b1[l][i];
       b2s[i] = w.b2[l][i];
     }
-    for (int i = tid; i < 16 * K1S; i += 512) offs[i] = i < G ? offset[i] : 0.0f;
+    for (int i = tid; i < 16 * K1S; i += FFH_THREADS) offs[i] = i < G ? offset[i] : 0.0f;
   }
   __syncthreads();
   const float inv1 = 1.0f / (s1 * 16384.0f), inv2 = 1.0f / s2;  // powers of two: exact
   const size_t lbase = (size_t)l * P;
   const int nrb = (P + 31) / 32;
-  for (int rb = blockIdx.x + gridDim.x * wave; rb < nrb; rb += gridDim.x * 8) {
+  for (int rb = blockIdx.x + gridDim.x * wave; rb < nrb; rb += gridDim.x * (FFH_THREADS / 64)) {
     const int row = 32 * rb + j;
     const bool live = row < P;
     const float d = live ? pair_d[row] : 0.0f;
@@ -485,9 +488,9 @@ extern "C" int geossl_cfconv_filter_fwd(const float* pair_d, const float* pair_c
   static const bool bf16x3 = getenv("GEOSSL_FILTER_FWD_BF16X3") != nullptr;
 #define LAUNCH_H(NMB, K1S)                                                                                      \
   do {                                                                                                          \
-    const size_t lds = (size_t)(NMB * (2 * NMB) + NMB * K1S) * 2 * 1024 + (2 * 32 * NMB + 16 * K1S + 16) * 4;   \
+    const size_t lds = (size_t)(NMB * (2 * NMB) + NMB * K1S) * 2 * 1024 + (2 * 32 * NMB + 16 * K1S + 32) * 4;   \
     allow_big_lds(&k_filter_fwd_h<NMB, K1S>);                                                                   \
-    hipLaunchKernelGGL((k_filter_fwd_h<NMB, K1S>), grid, dim3(512), lds, stream, pair_d, pair_c, (int)P, *w, G, \
+    hipLaunchKernelGGL((k_filter_fwd_h<NMB, K1S>), grid, dim3(FFH_THREADS), lds, stream, pair_d, pair_c, (int)P, *w, G, \
                        offset, coeff, T, Wf);                                                                   \
   } while (0)
 #define LAUNCH_HF(NMB)                    \
