@@ -41,14 +41,20 @@ __global__ __launch_bounds__(256) void k_chain_prepare(GeosslPrepareBatch batch,
   const int i = blockIdx.x * 256 + threadIdx.x;
   float sw = 1.0f;
   if constexpr (KS == 8) {
-    // F = 128 (weight-stationary kernel): two fp16 pieces of W * 2^(14 - eW), eW = exponent of the largest |W| (split.h).
-    // Every block finds the largest magnitude of its (L2-resident) matrix itself.
+    // F = 128 (weight-stationary kernel): two fp16 pieces of W * 2^(14 - eW) per 32-column output block (one wave of the
+    // chain kernel owns one block), eW = exponent of the block's largest |W| (split.h).  A block of this kernel formats
+    // half of one output block (512 items each) and finds that block's largest magnitude itself (4096 values).
     __shared__ float red[4];
     float mw = 0.0f;
-    const f32x4* W4 = reinterpret_cast<const f32x4*>(W);
-    for (int q = threadIdx.x; q < K * NO / 4; q += 256) {
-      const f32x4 a = W4[q];
-      mw = fmaxf(fmaxf(mw, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+    const int mb_blk = (blockIdx.x * 256) / (64 * KS);
+    if (transB) {  // rows 32 mb .. 32 mb + 31 of W [NO][K]: contiguous
+      const f32x4* W4 = reinterpret_cast<const f32x4*>(W + (size_t)32 * mb_blk * K);
+      for (int q = threadIdx.x; q < 32 * K / 4; q += 256) {
+        const f32x4 a = W4[q];
+        mw = fmaxf(fmaxf(mw, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+      }
+    } else {       // columns 32 mb .. 32 mb + 31 of W [K][NO]
+      for (int q = threadIdx.x; q < 32 * K; q += 256) mw = fmaxf(mw, fabsf(W[(size_t)(q >> 5) * NO + 32 * mb_blk + (q & 31)]));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
@@ -57,7 +63,7 @@ __global__ __launch_bounds__(256) void k_chain_prepare(GeosslPrepareBatch batch,
     mw = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     int eW;
     sw = pow2_scale_to_2p14(mw, eW);
-    if (i == 0) reinterpret_cast<int*>(image)[(NO / 32) * KS * 2 * 64 * 4] = eW;
+    if ((i & (64 * KS - 1)) == 0) reinterpret_cast<int*>(image)[(NO / 32) * KS * 2 * 64 * 4 + mb_blk] = eW;
   }
   if (i >= nitems) return;
   const int ln = i & 63, ks = (i >> 6) % KS, mb = i / (64 * KS);
@@ -584,7 +590,7 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
       af[ks].h = *reinterpret_cast<const u32x4*>(bk + voff);
       af[ks].l = *reinterpret_cast<const u32x4*>(bk + 1024 + voff);
     }
-    eW = reinterpret_cast<const int*>(st.image)[4 * KS * 2 * 64 * 4];
+    eW = reinterpret_cast<const int*>(st.image)[4 * KS * 2 * 64 * 4 + m];  // this wave's column block
   };
   // row maxima of this wave's 16 values per lane -> LDS (lane pair j / j + 32 holds the wave's 32 columns of row j)
   auto publish_max = [&](int i, float mx) __attribute__((always_inline)) {
