@@ -627,10 +627,34 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
   float cval = 0.0f, dd = 0.0f;
   unsigned fl_raw = 0u;
   float tc[16];
-  int ajw = 0;  // second atom of row (lane & 31) of the tile ahead: every wave takes the window decision itself
-  auto request_atoms = [&](int tt, int alo_t) {  // role B: window of x / dagg rows of tile tt; role A: its row descriptors
-    ajw = pair_j[min(tt * TR + j, P - 1)];
+  // The staged window is STICKY: it stays as long as the next tile's atoms still fall inside it (pair slots are
+  // lexicographic, so a window that starts at some atom of a molecule serves the rest of that molecule and the next one) -
+  // about nine tiles in ten of 18-atom molecules neither fetch nor store a window.  Every wave takes the decision itself
+  // from the same values: the second atoms of the tile's rows (ajn, fetched one tile before the decision) and the state
+  // wab = buffer holding the window, walo = its first atom.  The decision of a tile is taken when its requests are
+  // issued and kept (dec_*) until the tile is published one iteration later.
+  int ajn = 0;
+  int wab = 0, walo = 0;
+  bool whave = false;
+  bool dec_staged = false, dec_fresh = false;
+  int dec_alo = 0, dec_wab = 0;
+  auto decide = [&](int alo_t) {
+    const int amax = wave_max_i32(ajn + 1);
+    const bool fits = whave && alo_t >= walo && amax - walo <= ATOM_CAP;
+    dec_fresh = !fits && amax - alo_t <= ATOM_CAP;
+    if (dec_fresh) {
+      wab ^= 1;
+      walo = alo_t;
+      whave = true;
+    }
+    dec_staged = fits || dec_fresh;
+    dec_alo = walo;
+    dec_wab = wab;
+  };
+  auto request_rows = [&](int tt) { ajn = pair_j[min(tt * TR + j, P - 1)]; };
+  auto request_atoms = [&](int tt, int alo_t) {  // role B: window of x / dagg rows of tile tt (if it gets a new one); role A: its row descriptors
     if constexpr (!roleA) {
+      if (!dec_fresh) return;
       // clamped addresses, no predication (a predicated load compiles to a branch with a full wait per element);
       // slots past the window are never read back
       const int nwin = min(ATOM_CAP, N - alo_t);
@@ -664,23 +688,9 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
   };
   // publish what was requested earlier as tile tt's staging buffer: role B the atom window (and its largest magnitudes),
   // the first role-A wave the row descriptors (role B is the longer path of the phase)
-  // The staged window is STICKY: it stays as long as the next tile's atoms still fall inside it (pair slots are
-  // lexicographic, so a window that starts at some atom of a molecule serves the rest of that molecule and the next one) -
-  // about nine tiles in ten of 18-atom molecules skip the staging stores.  Every wave takes the decision from the same
-  // values (wab = buffer holding the window, walo = its first atom).
-  int wab = 0, walo = 0;
-  bool whave = false;
-  auto publish = [&](int tt, int alo_t) {
-    const int amax = wave_max_i32(ajw + 1);
-    const bool fits = whave && alo_t >= walo && amax - walo <= ATOM_CAP;
-    const bool fresh = !fits && amax - alo_t <= ATOM_CAP;
-    if (fresh) {
-      wab ^= 1;
-      walo = alo_t;
-      whave = true;
-    }
-    const bool staged0 = fits || fresh;
-    alo_t = walo;  // descriptors are relative to the window in use
+  auto publish = [&](int tt) {
+    const bool staged0 = dec_staged, fresh = dec_fresh;
+    const int alo_t = dec_alo;  // descriptors are relative to the window in use
     if constexpr (roleA) {
       const int bsel = tt & 1, rr0 = tt * TR;
       if (wave == 0) {
@@ -693,12 +703,12 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
         }
         if (lane == 0) {
           L.flag(bsel)[0] = staged0 ? 1 : 0;
-          L.flag(bsel)[1] = wab;
+          L.flag(bsel)[1] = dec_wab;
           L.et[CB] = 0;
         }
       }
     } else if (fresh) {
-      const int bsel = wab;
+      const int bsel = dec_wab;
       const int nwin = min(ATOM_CAP, N - alo_t);
       FB3(0);
       FB3(1);
@@ -740,13 +750,20 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
   for (int cb = 0; cb < CB; ++cb) ETs[cb] = -126;
   if (t_begin < t_end) {
     alo_a = pair_i[t_begin * TR];
+    request_rows(t_begin);
+    decide(alo_a);
     request_atoms(t_begin, alo_a);
     request_t(t_begin);
-    publish(t_begin, alo_a);
+    publish(t_begin);
     if (t_begin + 1 < t_end) {
       alo_a = pair_i[(t_begin + 1) * TR];
+      request_rows(t_begin + 1);
+      decide(alo_a);
       request_atoms(t_begin + 1, alo_a);
-      if (t_begin + 2 < t_end) alo_b = pair_i[(t_begin + 2) * TR];
+      if (t_begin + 2 < t_end) {
+        alo_b = pair_i[(t_begin + 2) * TR];
+        request_rows(t_begin + 2);
+      }
     }
   }
   for (int t = t_begin; t < t_end; ++t) {
@@ -879,12 +896,16 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
       if (blockIdx.x == 3 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == NW) && t - t_begin < 64)
         fb_dbg2[(wave == 0 ? 0 : 1) * 64 + (t - t_begin)] = clock64();
 #endif
-      publish(t + 1, alo_a);
+      publish(t + 1);
       FBH_MARK(7);
       if (t + 2 < t_end) {
         alo_a = alo_b;
+        decide(alo_a);  // tile t + 2: its rows' second atoms were fetched one iteration ago
         request_atoms(t + 2, alo_a);
-        if (t + 3 < t_end) alo_b = pair_i[(t + 3) * TR];
+        if (t + 3 < t_end) {
+          alo_b = pair_i[(t + 3) * TR];
+          request_rows(t + 3);
+        }
       }
       request_t(t + 1);
     }
