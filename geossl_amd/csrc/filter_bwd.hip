@@ -863,10 +863,15 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
         dst[64] = f.l;
       }
     }
-    // Gaussian fragments: one builder wave per SIMD - role-A waves 0 .. NW/2-1 and role-B waves NW/2 .. NW-1 (the two
-    // roles' build phases are then about equally long)
+    // Gaussian fragments: by the role-B waves (role A also splits its saved activations in this phase; with the sticky
+    // window role B has the shorter build)
+#ifndef FBH_RBF_BY_A
+    if (!roleA) {
+      for (int it = 64 * hs + lane; it < 2 * 2 * 64; it += 64 * NW) {  // rbf: B[k = row = 16ks + kperm(e, kh)][n = g]
+#else
     if (NW == 1 ? roleA : (roleA ? hs < NW / 2 : hs >= NW / 2)) {
-      for (int it = 64 * hs + lane; it < 2 * 2 * 64; it += 64 * (NW == 1 ? 1 : NW)) {  // rbf: B[k = row = 16ks + kperm(e, kh)][n = g]
+      for (int it = 64 * hs + lane; it < 2 * 2 * 64; it += 64 * (NW == 1 ? 1 : NW)) {
+#endif
         const int ln = it & 63, ks = (it >> 6) & 1, gb = it >> 7;
         const int gg = 32 * gb + (ln & 31);
         const float off = gg < G ? offset[gg] : 0.0f;
