@@ -582,7 +582,7 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
       l1 = fmaxf(l1, __shfl_xor(l1, o, 64));
     }
     const float s2 = pow2_scale_to_2p14(wm, e2);
-    eL = __builtin_amdgcn_frexp_expf(l1);
+    eL = max(__builtin_amdgcn_frexp_expf(l1), -12);  // (a floor: 2^(14 - EO - eL) must stay finite for EO >= -100)
 #pragma unroll
     for (int ks = 0; ks < KC; ++ks) {
       float v[8];

@@ -130,7 +130,7 @@ __device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, const
 }
 // power-of-two scale that brings a magnitude m into [2^13, 2^14) (1 for m = 0), and the exponent it used
 __device__ __forceinline__ float pow2_scale_to_2p14(float m, int& e) {
-  e = __builtin_amdgcn_frexp_expf(m);  // m = f * 2^e, f in [0.5, 1); 0 for m = 0
+  e = max(__builtin_amdgcn_frexp_expf(m), -100);  // m = f * 2^e, f in [0.5, 1); 0 for m = 0; the clamp keeps 2^(14-e) finite
   return __builtin_amdgcn_ldexpf(1.0f, 14 - e);
 }
 
