@@ -805,12 +805,13 @@ def _check_filter_grads(got, ref, tol, what):
             assert err < tol, (what, l, name, err)
 
 
-def test_filter_backward_direct_vs_fp64_and_operand_scale_paths():
+@pytest.mark.parametrize("F, G", [(128, 51), (64, 20), (32, 8)])
+def test_filter_backward_direct_vs_fp64_and_operand_scale_paths(F, G):
     """geossl_cfconv_filter_bwd through the C ABI against fp64.  The kernel runs on two fp16 pieces per operand with
     running power-of-two block scales (csrc/split.h, filter_bwd.hip): upstream gradients of ordinary size, tiny (1e-12),
     large (1e+6), and with magnitudes that RISE and FALL by 2^30 along the atoms (so tiles late in a block's range raise
     the running scale and the accumulators are rescaled) must all keep the accuracy of an fp32 GEMM chain."""
-    lay, daggs, run, ref64 = _filter_problem(nmol=300, seed=11)
+    lay, daggs, run, ref64 = _filter_problem(nmol=300 if F == 128 else 150, seed=11, F=F, G=G)
     N = lay.N
     ramp = torch.exp2(torch.linspace(-20.0, 10.0, N, device=DEV).round())
     cases = {"plain": daggs, "tiny": [d * 1e-12 for d in daggs], "large": [d * 1e6 for d in daggs],
