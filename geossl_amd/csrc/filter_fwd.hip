@@ -260,10 +260,10 @@ __global__ __launch_bounds__(512) void k_filter_fwd(const float* __restrict__ pa
 // two, exact): A1 and A2 by their largest magnitude (once per block), the Gaussians by 2^14 (they are <= 1), the hidden
 // row of a pair by ITS largest magnitude (per lane pair: the row of pair j lives in lanes j and j + 32).  The biases
 // are added to the unscaled fp32 results (one FMA each), so the accumulators start from 0.
-template <int NMB, int K1S>
 #ifndef FFH_THREADS
-#define FFH_THREADS 512
+#define FFH_THREADS 512  // 8 waves per CU; 768 / 1024 were slower inside the step
 #endif
+template <int NMB, int K1S>
 __global__ __launch_bounds__(FFH_THREADS) void k_filter_fwd_h(const float* __restrict__ pair_d,
                                                       const float* __restrict__ pair_c, int P,
                                                       GeosslFilterWeights w, int G,
