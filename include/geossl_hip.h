@@ -191,7 +191,9 @@ int geossl_linear_prepared(const float* X, int ldx, const uint32_t* image, const
  * GEOSSL_EPI_SSP; tprev != NULL: * ssp'(tprev); res != NULL: + res) and Y_s stored to `out` when it is not NULL
  * (row stride ld, shared with res / tprev).  Every stage is F -> F, F in {32, 64, 128}.  `image`: operand image of the
  * stage's weight from geossl_chain_prepare (transB as in geossl_linear: 1 = W is [NO][K] (forward), 0 = W is [K][NO]
- * (dX = dY W)), geossl_chain_image_words(F) 32-bit words each.                                                    */
+ * (dX = dY W)), geossl_chain_image_words(F) 32-bit words each.  The image is opaque: MFMA operand fragments of W split
+ * into 16-bit pieces (F = 128: two fp16 pieces of W scaled by a power of two per 32-column output block, the four
+ * exponents stored behind the fragments; F = 64 / 32: three bf16 pieces); results carry fp32-GEMM accuracy.        */
 #define GEOSSL_CHAIN_MAX 3
 typedef struct {
   const uint32_t* image;
