@@ -1,8 +1,11 @@
-# per-phase clock64 marks of the filter forward (debug build with -DFF_TIMING): waves 0 and 4 (one SIMD) of block (3, 0)
-#   python tools/filter_fwd_timing.py /path/variant.so
+# per-phase clock64 marks of the filter forward (debug build with -DFF_TIMING): waves 0 and 4 (one SIMD) of block (3, 0), and the
+# shader clock during the kernel (s_memtime against the 100 MHz wall clock).  The marks sit in the three-bf16-piece kernel
+# (GEOSSL_FILTER_FWD_BF16X3, set below); the two-piece kernel has the same phase structure with half the MFMAs.
+#   tools/build_variant.sh filter_fwd.hip /path/variant.so -DFF_TIMING;  python tools/filter_fwd_timing.py /path/variant.so
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["GEOSSL_HIP_LIB"] = sys.argv[1]
+os.environ["GEOSSL_FILTER_FWD_BF16X3"] = "1"
 import numpy as np, torch
 from geossl_amd import _lib
 from geossl_amd import pretrain_GeoSSL as pg
