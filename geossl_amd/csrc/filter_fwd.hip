@@ -276,7 +276,7 @@ __global__ __launch_bounds__(FFH_THREADS) void k_filter_fwd_h(const float* __res
   float* b1s = reinterpret_cast<float*>(W1f + NMB * K1S * 2 * 64);  // [F]
   float* b2s = b1s + F;                                     // [F]
   float* offs = b2s + F;                                    // [16*K1S] Gaussian centres, zero padded
-  float* red = offs + 16 * K1S;                             // [32] block reduction of the two weight maxima
+  float* red = offs + 16 * K1S;                             // [32] block reduction of the two weight maxima, [32]: row-block counter
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
   const int l = blockIdx.y;
   float s1, s2;
@@ -335,15 +335,31 @@ __global__ __launch_bounds__(FFH_THREADS) void k_filter_fwd_h(const float* __res
     }
     for (int i = tid; i < 16 * K1S; i += FFH_THREADS) offs[i] = i < G ? offset[i] : 0.0f;
   }
+  int* next_rb = reinterpret_cast<int*>(red + 32);  // the block's row-block counter
+  if (tid == 0) *next_rb = 0;
   __syncthreads();
   const float inv1 = 1.0f / (s1 * 16384.0f), inv2 = 1.0f / s2;  // powers of two: exact
   const size_t lbase = (size_t)l * P;
   const int nrb = (P + 31) / 32;
-  for (int rb = blockIdx.x + gridDim.x * wave; rb < nrb; rb += gridDim.x * (FFH_THREADS / 64)) {
+  // Row blocks blockIdx.x + gridDim.x t of the layer are handed out on demand: of the two waves of a SIMD the older one
+  // wins the issue arbitration (in-kernel marks: 23k against 32k cycles per row block while both run), so equal shares
+  // would leave the younger wave to finish alone.  The next block's index and its two scalars per row are fetched one
+  // row block ahead.
+  auto take = [&]() {
+    int t = 0;
+    if (lane == 0) t = atomicAdd(next_rb, 1);
+    return (int)blockIdx.x + (int)gridDim.x * __builtin_amdgcn_readfirstlane(t);
+  };
+  int rb = take();
+  float d_n = pair_d[min(32 * rb + j, P - 1)], cw_n = pair_c[min(32 * rb + j, P - 1)];
+  while (rb < nrb) {
     const int row = 32 * rb + j;
     const bool live = row < P;
-    const float d = live ? pair_d[row] : 0.0f;
-    const float cw = live ? pair_c[row] : 0.0f;
+    const float d = d_n;
+    const float cw = live ? cw_n : 0.0f;
+    const int rb_next = take();
+    d_n = pair_d[min(32 * rb_next + j, P - 1)];
+    cw_n = pair_c[min(32 * rb_next + j, P - 1)];
     // every LDS read of the loop is tile-invariant: an opaque zero in the addresses keeps the compiler from hoisting
     // (and then spilling) fragments, biases and centres across the tile loop
     int z = 0;
@@ -447,6 +463,7 @@ __global__ __launch_bounds__(FFH_THREADS) void k_filter_fwd_h(const float* __res
           if (live) *reinterpret_cast<float4*>(orow + 32 * (mb0 + u) + 8 * q) = o;
         }
     }
+    rb = rb_next;
   }
 }
 
@@ -488,7 +505,7 @@ extern "C" int geossl_cfconv_filter_fwd(const float* pair_d, const float* pair_c
   static const bool bf16x3 = getenv("GEOSSL_FILTER_FWD_BF16X3") != nullptr;
 #define LAUNCH_H(NMB, K1S)                                                                                      \
   do {                                                                                                          \
-    const size_t lds = (size_t)(NMB * (2 * NMB) + NMB * K1S) * 2 * 1024 + (2 * 32 * NMB + 16 * K1S + 32) * 4;   \
+    const size_t lds = (size_t)(NMB * (2 * NMB) + NMB * K1S) * 2 * 1024 + (2 * 32 * NMB + 16 * K1S + 36) * 4;   \
     allow_big_lds(&k_filter_fwd_h<NMB, K1S>);                                                                   \
     hipLaunchKernelGGL((k_filter_fwd_h<NMB, K1S>), grid, dim3(FFH_THREADS), lds, stream, pair_d, pair_c, (int)P, *w, G, \
                        offset, coeff, T, Wf);                                                                   \
