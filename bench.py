@@ -41,6 +41,9 @@ PAINN_L, PAINN_R = 3, 20  # config.py:118-121 defaults of the reference's PaiNN 
 
 
 # entry point -> prefix of the device kernels it launches (for the PMC traffic lookup)
+PAINN_KERNELS = {"geossl_painn_interaction_fwd_mol": "k_painn_interaction_fwd_mol",
+                 "geossl_painn_interaction_bwd_mol": "k_painn_interaction_bwd_mol",
+                 "geossl_painn_interaction_fwd": "k_painn_interaction_fwd", "geossl_painn_interaction_bwd": "k_painn_interaction_bwd"}
 ENTRY_KERNELS = {"geossl_cfconv_filter_fwd": "k_filter_fwd", "geossl_cfconv_filter_bwd": "k_filter_bwd",
                  "geossl_ddm_loss_fwd": "k_ncsn_fwd", "geossl_ddm_loss_bwd_rows": "k_ncsn_bwd_rows",
                  "geossl_linear_wgrad": "geossl::k_wgrad_split<4, 4, geossl::PlainOps"}
@@ -141,9 +144,9 @@ def cpu_baseline_painn(seed, n_mols=256, timed=3, max_threads=32):
                       % (n_mols, timed, cores, os.cpu_count() or 1, max_threads, med)}
 
 
-def cpu_baseline(seed, n_mols=512, timed=3, max_threads=32):
+def cpu_baseline(seed, n_mols=1024, timed=2, max_threads=32):
     """The CPU oracle (pure-torch restatement pinned to the reference by golden vectors) on a bounded
-    sample of the same workload: DDM step fwd+bwd + Adam on `n_mols` of the 1024 molecules of a bench batch,
+    sample of the same workload: DDM step fwd+bwd + Adam on a full bench batch (`n_mols` = 1024 molecules),
     1 warm-up + `timed` timed steps (SURVEY 8(d) / BASELINE.md 3).  Threads: every host core up to `max_threads` - the
     step is ~150 small ATen ops, and beyond a few dozen threads torch's CPU backend only adds fork/join time (all
     cores of a 100+-core GPU host made the step several times SLOWER than 16 threads); the count used is reported."""
@@ -211,21 +214,343 @@ def workload_id(model, mols, molset, cutoff):
     return "%s/ddm-step/mols=%d/set=%s/cutoff=%g" % (model, mols, molset, cutoff)
 
 
+def cpu_baseline_forward(seed, n_mols=1024, timed=3, max_threads=32):
+    """The CPU oracle's SchNet forward (no autograd) on one bench batch: the baseline of the forward-only line."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+    from geossl_amd.synthetic import make_batch
+    from helpers import schnet_oracle_params, t
+    from oracle import nets
+    cores = min(os.cpu_count() or 1, max_threads)
+    torch.set_num_threads(cores)
+    cfg = dict(hidden_channels=F, num_filters=F, num_interactions=L, num_gaussians=G, cutoff=CUTOFF, node_class=9,
+               readout="mean")
+    Pm = schnet_oracle_params(cfg, requires_grad=False)
+    b = make_batch(n_mols, seed=seed, mode="A")
+    times = []
+    with torch.no_grad():
+        for it in range(1 + timed):
+            t0 = time.perf_counter()
+            nets.schnet_forward(Pm, t(b["x"])[:, 0], t(b["positions"]), t(b["batch"]), CUTOFF, L, "mean")
+            times.append(time.perf_counter() - t0)
+    med = float(np.median(times[1:]))
+    return {"value": n_mols / med, "unit": "molecules/s", "cores": cores, "kind": "port",
+            "sample": "oracle SchNet forward (no autograd) on %d molecules of the bench shape (n=18, %g A), 1 warm-up + %d "
+                      "timed passes on %d torch threads (host has %d cores; capped at %d), median %.2f s/pass"
+                      % (n_mols, CUTOFF, timed, cores, os.cpu_count() or 1, max_threads, med)}
+
+
+ARITHMETIC = ("fp32 inputs, outputs and accumulators; every Linear product on the 16-bit matrix pipe as split-operand MFMAs "
+              "(csrc/split.h): filter network, atom-row chains and weight gradients as 3 fp16 MFMAs over a two-piece fp16 "
+              "split of both operands (22 significant bits per product, power-of-two operand scales), the NCSN heads as 6 "
+              "bf16 MFMAs over a three-piece bf16 split (24 bits); element-wise work, reductions and the aggregation in fp32")
+
+
+class Workload:
+    """One configuration of the DDM step on this rank: models, pre-collated device-resident batches, the step function
+    of the chosen API, and a timer.
+
+    api = "trainer":   geossl_amd.pretrain_GeoSSL.DDMTrainer.step (flat parameter buffer, fused Adam, one all-reduce).
+    api = "reference": the loop body of the reference's train() verbatim (examples/pretrain_GeoSSL.py:248-260) on the
+                       product modules - do_DDM, loss.detach().item(), optimizer.zero_grad(), loss.backward(),
+                       optimizer.step() with stock torch.optim.Adam over the reference's three parameter groups (:332-343)
+                       - i.e. what a maintainer gets who only changes the import lines of INTEGRATION.md."""
+
+    def __init__(self, dev, rank, world, model="schnet", mols=1024, molset="A", cutoff=5.0, api="trainer", graph=True,
+                 n_batches=1, seed_base=1000):
+        from geossl_amd import pretrain_GeoSSL as pg
+        from geossl_amd.Geom3D.models import PaiNN, SchNet
+        from geossl_amd.NCSN import NCSN_version_03
+        from geossl_amd.synthetic import make_batch
+        self.pg, self.dev, self.rank, self.world = pg, dev, rank, world
+        self.model_name, self.mols, self.molset, self.cutoff, self.api, self.graph = model, mols, molset, cutoff, api, graph
+        torch.manual_seed(1234)  # identical initial weights on every rank
+        if model == "schnet":
+            self.model = SchNet(hidden_channels=F, num_filters=F, num_interactions=L, num_gaussians=G, cutoff=cutoff,
+                                node_class=9, readout="mean").to(dev)
+        else:  # pretrain_GeoSSL.py:33-42 with config.py:118-121 defaults
+            self.model = PaiNN(n_atom_basis=F, n_interactions=3, n_rbf=20, cutoff=5.0, max_z=9, n_out=1,
+                               readout="add").to(dev)
+        self.n1 = NCSN_version_03(F, 10.0, 0.01, K_LEVELS, "symmetry", 2).to(dev)
+        self.n2 = NCSN_version_03(F, 10.0, 0.01, K_LEVELS, "symmetry", 2).to(dev)
+        self.trainer = None
+        if api == "trainer":
+            self.trainer = pg.DDMTrainer(self.model, self.n1, self.n2, lr=5e-4, mu=0.0, sigma=0.3, device_noise=True,
+                                         model_3d=model, use_graph=graph)
+        else:
+            if world > 1:
+                raise SystemExit("--api reference is the reference's single-process loop (it has no data parallelism)")
+            import types
+            self.args = types.SimpleNamespace(model_3d=model, GeoSSL_option="DDM", GeoSSL_mu=0.0, GeoSSL_sigma=0.3,
+                                              lr=5e-4, decay=0.0, normalize=False, step_graph=graph)
+            pg.NCSN_model_01, pg.NCSN_model_02 = self.n1, self.n2  # the reference's module globals (:207-208)
+            group = [{"params": self.model.parameters(), "lr": self.args.lr}, {"params": self.n1.parameters()},
+                     {"params": self.n2.parameters()}]             # :332-341
+            self.optimizer = torch.optim.Adam(group, lr=self.args.lr, weight_decay=self.args.decay)  # :343
+            self.criterion = torch.nn.BCEWithLogitsLoss()          # :344 (unused by DDM, passed like the reference does)
+            self.accum_loss, self.accum_acc = 0.0, 0
+        # pre-collated, device-resident batches (SURVEY 8d): each rank owns its own molecules (weak scaling)
+        self.batches, self.sizes0 = [], None
+        for i in range(n_batches):
+            b = make_batch(mols, seed=seed_base * (rank + 1) + i, mode=molset)
+            bt = pg.Batch.from_numpy(b, dev)
+            bt.num_graphs  # cached python int
+            if model == "painn":  # precomputed on the clean geometry, like MoleculeDataset3DRadius (datasets_3D_Radius.py:120)
+                from geossl_amd import ops as _ops
+                bt.radius_edge_index = _ops.radius_graph(bt.positions, 5.0, bt.batch)
+            self.batches.append(bt)
+            if i == 0:
+                self.sizes0 = list(b["sizes"])
+        torch.cuda.manual_seed(777 + rank)  # the step's own noise draws: a different stream on every rank
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(777 + rank)
+
+    @property
+    def n_batches(self):
+        return len(self.batches)
+
+    def shared_structure(self):
+        """True when all batches have one index structure (set A with SchNet): one captured graph serves them all."""
+        return self.molset == "A" and self.model_name == "schnet"
+
+    def step(self, i):
+        bt = self.batches[i % self.n_batches]
+        if self.api == "trainer":
+            return self.trainer.step(bt, None)  # the trainer draws the step's noise on the device itself
+        # ---- examples/pretrain_GeoSSL.py:248-260, the DDM branch
+        args, model, optimizer = self.args, self.model, self.optimizer
+        batch = bt.to(self.dev)
+        loss, acc = self.pg.do_DDM(args, batch, model, criterion=self.criterion, mu=args.GeoSSL_mu, sigma=args.GeoSSL_sigma)
+        self.accum_loss += loss.detach().item()
+        self.accum_acc += acc
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        return loss.detach()
+
+    def n_graphs(self):
+        if self.trainer is not None:
+            return len(self.trainer._graphs)
+        eng = self.model.__dict__.get("_geossl_autograd_step")
+        return sum(len(sg) for sg in eng.graphs.values()) if eng is not None else 0
+
+    def uses_graph(self):
+        return (self.trainer.use_graph if self.trainer is not None else self.graph) and self.n_graphs() > 0
+
+    def prime(self):
+        """Untimed: builds the cached index structures and captures the HIP graph(s) - one step when all batches share
+        a structure, else one or two passes over the batches (the first epochs of a real run: the reference-API path
+        captures a structure on its second sighting) - so that even --warmup 0 times steady-state steps."""
+        passes = 1 if self.api == "trainer" else 2
+        loss = None
+        for _ in range(passes):
+            for i in range(1 if self.shared_structure() else self.n_batches):
+                loss = self.step(i)
+        return loss
+
+    def run(self, warmup, steps):
+        """-> (elapsed seconds (max over ranks), per-step device ms, last loss)."""
+        import torch.distributed as dist
+        loss = self.prime()
+        for i in range(warmup):
+            loss = self.step(i)
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        # per-step device time for the percentiles SURVEY 8(d) asks for: one event per step boundary on the compute
+        # stream (recording does not synchronise; `value` comes from the wall clock around the whole region)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(steps):
+            loss = self.step(warmup + i)
+            marks[i + 1].record()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+        if self.world > 1:
+            tt = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, step_ms, float(loss)
+
+    def draw(self, bt):
+        S, B, dev, gen = bt.super_edge_index.size(1), bt.num_graphs, self.dev, self.gen
+        return {"noise_level_1": torch.randint(0, K_LEVELS, (B,), device=dev, generator=gen),
+                "dist_noise_1": torch.randn(S, 1, device=dev, generator=gen),
+                "noise_level_2": torch.randint(0, K_LEVELS, (B,), device=dev, generator=gen),
+                "dist_noise_2": torch.randn(S, 1, device=dev, generator=gen),
+                "pos_noise": torch.empty_like(bt.positions).normal_(0.0, 0.3, generator=gen)}
+
+    def eager_kernel_times(self, prof_steps):
+        """HIP events around every launch of the TIMED entry points over eager forward+backward passes of the same step
+        (a graph replay has no host-side launch boundaries to bracket; rocprofv3 sees the kernels of both) and the
+        number of C-ABI calls one such pass makes."""
+        from geossl_amd import _lib
+
+        def eager_fwd_bwd(i):  # rank-local: no all-reduce, no Adam (neither is a timed entry point)
+            bt = self.batches[i % self.n_batches]
+            if self.trainer is not None:
+                self.trainer._fwd_bwd(bt, self.draw(bt))
+            else:
+                self.optimizer.zero_grad()
+                loss, _ = self.pg.do_DDM(self.args, bt, self.model, noise=self.draw(bt), graph=False)
+                loss.backward()
+
+        for i in range(2):
+            eager_fwd_bwd(i)
+        torch.cuda.synchronize()
+        _lib.TIMERS = {k: [] for k in TIMED}
+        _lib.CALLS = 0
+        for i in range(prof_steps):
+            eager_fwd_bwd(2 + i)
+        torch.cuda.synchronize()
+        timers, _lib.TIMERS = _lib.TIMERS, None
+        calls, _lib.CALLS = _lib.CALLS / prof_steps, None
+        return timers, calls
+
+    def describe(self):
+        if self.model_name == "schnet":
+            m = "SchNet F=128 L=6 G=51 cutoff=%gA" % self.cutoff
+        else:
+            m = "PaiNN F=128 L=3 rbf=20 cutoff=5A (BASELINE config 5)"
+        return ("pretrain_GeoSSL.py --GeoSSL_option=DDM step, %s, bs=%d molecules/GPU x %s atoms, %d pre-collated "
+                "device-resident batch%s/GPU" % (m, self.mols, "n=18" if self.molset == "A" else "n~clip(N(18,4),2,33) (set B)",
+                                                 self.n_batches, "" if self.n_batches == 1 else "es (visited in a fixed order)"))
+
+    def execution(self):
+        g = self.n_graphs()
+        if self.api == "trainer":
+            if not self.uses_graph():
+                return "DDMTrainer.step, eager launches"
+            return ("DDMTrainer.step: x / positions copied and the five noise draws made on the device into the graph's "
+                    "inputs, HIP graph replay of fwd+bwd (%d graph%s in one memory pool, found by the batch's structure "
+                    "fingerprint), eager all-reduce + fused Adam" % (g, "" if g == 1 else "s"))
+        return ("the reference's loop body (pretrain_GeoSSL.py:248-260): do_DDM -> loss.detach().item() -> "
+                "optimizer.zero_grad() -> loss.backward() -> torch.optim.Adam(3 groups).step(); position noise drawn on the "
+                "host like the reference (:72); do_DDM %s"
+                % (("replays a captured HIP graph of fwd+bwd (%d graph%s) and returns the loss behind an autograd node that "
+                    "hands the replayed gradients to autograd" % (g, "" if g == 1 else "s")) if self.uses_graph()
+                   else "runs eager launches"))
+
+
+def secondary_line(dev, rank, world, steps, warmup, **kw):
+    """A secondary configuration timed inside the default run, so that it is observed by the driver: value, ms/step."""
+    n_batches = kw.pop("n_batches", 1)
+    try:
+        wl = Workload(dev, rank, world, n_batches=n_batches, **kw)
+        elapsed, step_ms, loss = wl.run(warmup, steps)
+    except Exception as e:  # a secondary line must not take the headline down with it
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    out = {"value": world * wl.mols * steps / elapsed, "unit": "molecules/s", "ms_per_step": 1e3 * elapsed / steps,
+           "steps": steps, "warmup": warmup, "workload": wl.describe(), "execution": wl.execution(), "final_loss": loss,
+           "p50_ms": float(np.percentile(step_ms, 50))}
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
+def forward_only(args, dev, rank, world):
+    """BASELINE configs[1]: SchNet.forward(z, pos, batch) on a 1024-molecule batch, inference (no saved activations);
+    --forces adds pred_force = -grad(pred_energy, positions) (finetune_md17.py:46,99)."""
+    import torch.distributed as dist
+    from geossl_amd import _lib, ops
+    wl = Workload(dev, rank, world, model="schnet", mols=args.mols, molset=args.molset, cutoff=CUTOFF, api="trainer",
+                  graph=False, n_batches=max(1, min(args.max_batches, args.warmup + args.steps)))
+    model, batches, n_batches = wl.model, wl.batches, wl.n_batches
+    if args.forces:
+        for p_ in model.parameters():
+            p_.requires_grad_(False)
+        wvec = torch.cos(torch.arange(F, dtype=torch.float32, device=dev))
+
+    def fwd(i):
+        bt = batches[i % n_batches]
+        if args.forces:
+            pos = bt.positions.detach().requires_grad_(True)
+            energy = (model(bt.x[:, 0], pos, bt.batch) * wvec).sum(dim=1)
+            return -torch.autograd.grad(energy, pos, torch.ones_like(energy))[0]
+        with torch.no_grad():
+            return model(bt.x[:, 0], bt.positions, bt.batch)
+
+    for i in range(args.warmup):
+        out = fwd(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    _lib.TIMERS = {k: [] for k in TIMED}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = fwd(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    timers, _lib.TIMERS = _lib.TIMERS, None
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        return
+    roof = None
+    evs = timers.get("geossl_cfconv_filter_fwd") or []
+    if evs:
+        # the dominant kernel of a forward pass: the continuous-filter network of one view (no T store at inference)
+        ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        P1 = sum(int(n) * (int(n) - 1) // 2 for n in wl.sizes0)  # pair slots of one view
+        exe = P1 * L * (2 * 64 * F + 2 * F * F) * 3
+        bt = batches[0]
+        E = int(ops.radius_graph(bt.positions, CUTOFF, bt.batch).size(1))
+        fl, by = E * L * (2 * G * F + 2 * F * F), E * L * (4 * G + 4 + 4 * F)
+        roof = {"kernel": "geossl_cfconv_filter_fwd", "bound": "mfma", "unit": "TFLOP/s", "traffic": None,
+                "avg_launch_ms": ms, "launches_per_step": len(evs) / args.steps,
+                "timing": "HIP events around every launch of the timed region",
+                "achieved": exe / (ms * 1e-3) / 1e12, "peak": BF16_PEAK / 1e12, "frac": exe / (ms * 1e-3) / BF16_PEAK,
+                "mfma_per_fp32_product": 3, "algorithmic_TFLOPs": fl / (ms * 1e-3) / 1e12,
+                "algorithmic_GBps": by / (ms * 1e-3) / 1e9,
+                "peak_note": "executed 16-bit MFMA flops (3 per fp32 product, one filter evaluation per undirected pair slot, "
+                             "G padded to 64) over the 2.5 PFLOP/s dense peak"}
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline and not args.forces:
+        cpu = cpu_baseline_forward(seed=1000)
+    print(json.dumps({
+        "metric": ("molecules/s/GPU SchNet energy + forces (QM9-sized, bs=1024) [SURVEY 8(f) N3]" if args.forces
+                   else "molecules/s/GPU SchNet forward-only (QM9-sized, bs=1024) [BASELINE config 1]"),
+        "value": world * args.mols * args.steps / elapsed, "unit": "molecules/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "SchNet.forward%s F=128 L=6 G=51 cutoff=%gA, bs=%d molecules/GPU x %s atoms, eager "
+                               "launches (HBM-resident batches)"
+                               % (" + d/dpos" if args.forces else "", CUTOFF, args.mols,
+                                  "n=18" if args.molset == "A" else "n~clip(N(18,4),2,33) (set B)"),
+                   "parallelism": "dp%d" % world, "arithmetic": ARITHMETIC},
+        "roofline": roof, "cpu_baseline": cpu, "out_checksum": float(out.double().sum())}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--mols", type=int, default=1024, help="molecules per GPU per step")
+    ap.add_argument("--mols", type=int, default=1024,
+                    help="molecules per GPU per step (1024 = the configuration the metric is quoted on; 128 = the batch "
+                         "size of the reference's own scripts, config.py:91)")
     ap.add_argument("--dataset-mols", type=int, default=100000, help="synthetic dataset size (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary configurations the default 1-GPU run times after the headline")
     ap.add_argument("--max-batches", type=int, default=97, help="distinct pre-collated batches per GPU (config 3: 97)")
     ap.add_argument("--cutoff", type=float, default=5.0,
                     help="SchNet radius: 5 A = BASELINE's bench configuration, 10 A = the reference's default (config.py:114)")
     ap.add_argument("--set", default="A", choices=["A", "B"], dest="molset",
                     help="synthetic molecule sizes (SURVEY 8d): A = 18 atoms each (the headline), B = ragged 2..33 atoms "
-                         "(every batch its own index structure: one captured graph per batch)")
+                         "(every batch its own index structure: one captured graph per batch, visited in a fixed order)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture forward+backward into a HIP graph")
+    ap.add_argument("--api", default="trainer", choices=["trainer", "reference"],
+                    help="trainer = DDMTrainer.step (the headline); reference = the reference's own loop body "
+                         "(pretrain_GeoSSL.py:248-260: do_DDM, loss.item(), zero_grad, backward, stock torch.optim.Adam)")
     ap.add_argument("--forward-only", action="store_true",
                     help="BASELINE config 1 (secondary line): SchNet forward only, one view, no autograd")
     ap.add_argument("--forces", action="store_true",
@@ -238,11 +563,7 @@ def main():
     CUTOFF = args.cutoff
 
     from geossl_amd import _lib
-    from geossl_amd import pretrain_GeoSSL as pg
-    from geossl_amd.Geom3D.models import SchNet
-    from geossl_amd.NCSN import NCSN_version_03
     from geossl_amd.parallel import init_distributed, local_device
-    from geossl_amd.synthetic import make_batch
     import torch.distributed as dist
 
     rank, local_rank, world = init_distributed()
@@ -252,162 +573,31 @@ def main():
     torch.cuda.set_device(dev)
     _lib.load()
 
-    torch.manual_seed(1234)  # identical initial weights on every rank
-    if args.model == "schnet":
-        model = SchNet(hidden_channels=F, num_filters=F, num_interactions=L, num_gaussians=G, cutoff=CUTOFF,
-                       node_class=9, readout="mean").to(dev)
-    else:  # pretrain_GeoSSL.py:33-42 with config.py:118-121 defaults
-        from geossl_amd.Geom3D.models import PaiNN
-        model = PaiNN(n_atom_basis=F, n_interactions=3, n_rbf=20, cutoff=5.0, max_z=9, n_out=1, readout="add").to(dev)
-    n1 = NCSN_version_03(F, 10.0, 0.01, K_LEVELS, "symmetry", 2).to(dev)
-    n2 = NCSN_version_03(F, 10.0, 0.01, K_LEVELS, "symmetry", 2).to(dev)
-    trainer = pg.DDMTrainer(model, n1, n2, lr=5e-4, mu=0.0, sigma=0.3, device_noise=True, model_3d=args.model,
-                            use_graph=not args.no_graph)
-
-    # pre-collated, device-resident batches: each rank owns its own molecules (weak scaling)
-    total_steps = args.warmup + args.steps
-    n_batches = max(1, min(args.dataset_mols // (args.mols * world), total_steps, args.max_batches))
-    batches, shapes = [], []
-    for i in range(n_batches):
-        b = make_batch(args.mols, seed=1000 * (rank + 1) + i, mode=args.molset)
-        bt = pg.Batch.from_numpy(b, dev)
-        bt.num_graphs  # cached python int
-        if args.model == "painn":  # precomputed on the clean geometry, like MoleculeDataset3DRadius (datasets_3D_Radius.py:120)
-            from geossl_amd import ops as _ops
-            bt.radius_edge_index = _ops.radius_graph(bt.positions, 5.0, bt.batch)
-        batches.append(bt)
-        if i == 0:
-            sizes0 = list(b["sizes"])
-    # build the per-batch index structures once (part of collation, not of the step)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(777 + rank)
-    torch.cuda.manual_seed(777 + rank)  # the trainer's own noise draws: a different stream on every rank
-
-    def draw(bt, step):
-        S, B = bt.super_edge_index.size(1), bt.num_graphs
-        return {
-            "noise_level_1": torch.randint(0, K_LEVELS, (B,), device=dev, generator=gen),
-            "dist_noise_1": torch.randn(S, 1, device=dev, generator=gen),
-            "noise_level_2": torch.randint(0, K_LEVELS, (B,), device=dev, generator=gen),
-            "dist_noise_2": torch.randn(S, 1, device=dev, generator=gen),
-            "pos_noise": torch.empty_like(bt.positions).normal_(0.0, 0.3, generator=gen),
-        }
-
-    if args.forces:
-        for p_ in model.parameters():
-            p_.requires_grad_(False)
-        wvec = torch.cos(torch.arange(F, dtype=torch.float32, device=dev))
     if args.forward_only or args.forces:
-        # BASELINE configs[1]: SchNet.forward(z, pos, batch) on a 1024-molecule batch, inference (no saved activations);
-        # --forces adds pred_force = -grad(pred_energy, positions) (finetune_md17.py:46,99)
-        def fwd(i):
-            bt = batches[i % n_batches]
-            if args.forces:
-                pos = bt.positions.detach().requires_grad_(True)
-                energy = (model(bt.x[:, 0], pos, bt.batch) * wvec).sum(dim=1)
-                return -torch.autograd.grad(energy, pos, torch.ones_like(energy))[0]
-            with torch.no_grad():
-                return model(bt.x[:, 0], bt.positions, bt.batch)
-        for i in range(args.warmup):
-            out = fwd(i)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = fwd(args.warmup + i)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
-        if rank == 0:
-            print(json.dumps({
-                "metric": ("molecules/s/GPU SchNet energy + forces (QM9-sized, bs=1024) [SURVEY 8(f) N3]" if args.forces
-                           else "molecules/s/GPU SchNet forward-only (QM9-sized, bs=1024) [BASELINE config 1]"),
-                "value": world * args.mols * args.steps / elapsed, "unit": "molecules/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "SchNet.forward%s F=128 L=6 G=51 cutoff=%gA, bs=%d molecules/GPU x %s atoms, eager "
-                                       "launches (HBM-resident batches)"
-                                       % (" + d/dpos" if args.forces else "", CUTOFF, args.mols,
-                                          "n=18" if args.molset == "A" else "n~clip(N(18,4),2,33) (set B)"),
-                           "parallelism": "dp%d" % world},
-                "roofline": None, "cpu_baseline": None, "out_checksum": float(out.double().sum())}))
+        forward_only(args, dev, rank, world)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    def one_step(i):
-        bt = batches[i % n_batches]
-        # set A: every batch has the same index structure (1024 x 18 atoms) -> one captured graph serves all
-        # set B / PaiNN: every batch has its own index structure (ragged sizes; PaiNN's precomputed radius_edge_index)
-        # -> one captured graph per batch, all in one memory pool, captured once and replayed every epoch
-        shared = args.molset == "A" and args.model == "schnet"
-        key = ("setA", args.mols, 18) if shared else (args.molset, args.model, i % n_batches)
-        return trainer.step(bt, None, structure_key=key)  # the trainer draws the step's noise on the device itself
-
-    # untimed priming ahead of the W warm-up steps: builds the cached index structures and captures the HIP graph(s)
-    # (one step when all batches share a structure, one pass over the batches otherwise - the first epoch of a real
-    # run), so that even --warmup 0 times steady-state steps
-    loss = one_step(0)
-    if trainer.use_graph and not (args.molset == "A" and args.model == "schnet"):
-        for i in range(1, n_batches):
-            loss = one_step(i)
-    for i in range(args.warmup):
-        loss = one_step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    _lib.TIMERS = {k: [] for k in TIMED}
-    torch.cuda.synchronize()
-    # per-step device time for the percentiles SURVEY 8(d) asks for: one event per step boundary on the compute
-    # stream (recording does not synchronise; `value` comes from the wall clock around the whole region)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        loss = one_step(args.warmup + i)
-        marks[i + 1].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
-    timers, _lib.TIMERS = _lib.TIMERS, None
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    final_loss = float(loss)
-    timing_mode = "HIP events around every launch of the timed region"
-    if trainer.use_graph and rank == 0:
-        # a graph replay has no host-side launch boundaries to bracket: time the same entry points with HIP events
-        # over an eager pass of the same step right after the timed region (rocprofv3 sees the kernels of both)
-        prof_steps = min(args.steps, 10)
-        def eager_fwd_bwd(i):  # rank-local: no all-reduce, no Adam (neither is a timed entry point)
-            bt = batches[i % n_batches]
-            trainer._fwd_bwd(bt, draw(bt, i))
-
-        for i in range(2):
-            eager_fwd_bwd(total_steps + i)
-        torch.cuda.synchronize()
-        _lib.TIMERS = {k: [] for k in TIMED}
-        for i in range(prof_steps):
-            eager_fwd_bwd(total_steps + 2 + i)
-        torch.cuda.synchronize()
-        timers, _lib.TIMERS = _lib.TIMERS, None
-        timing_mode = "HIP events around every launch of %d eager steps run after the graph-replayed timed region" % prof_steps
-    else:
-        prof_steps = args.steps
+    total_steps = args.warmup + args.steps
+    n_batches = max(1, min(args.dataset_mols // (args.mols * world), total_steps, args.max_batches))
+    wl = Workload(dev, rank, world, model=args.model, mols=args.mols, molset=args.molset, cutoff=CUTOFF, api=args.api,
+                  graph=not args.no_graph, n_batches=n_batches)
+    elapsed, step_ms, final_loss = wl.run(args.warmup, args.steps)
+    if os.environ.get("GEOSSL_BENCH_RANK_LOSS"):  # tests: every rank's last loss (ranks own different molecules and noise)
+        with open(os.path.join(os.environ["GEOSSL_BENCH_RANK_LOSS"], "loss_rank%d.txt" % rank), "w") as fh:
+            fh.write(repr(final_loss))
+    timers, calls_per_step, prof_steps = None, None, min(args.steps, 10)
+    if rank == 0:
+        # a graph replay has no host-side launch boundaries to bracket: the entry points are timed with HIP events over
+        # eager forward+backward passes of the same step right after the timed region (rocprofv3 sees the kernels of both)
+        timers, calls_per_step = wl.eager_kernel_times(prof_steps)
+    timing_mode = "HIP events around every launch of %d eager steps run after the timed region" % prof_steps
 
     if rank == 0:
         from geossl_amd import ops
-        bt = batches[0]
+        bt = wl.batches[0]
         E = int(ops.radius_graph(bt.positions, CUTOFF, bt.batch).size(1))
         N, S = bt.positions.size(0), bt.super_edge_index.size(1)
         if args.model == "painn":
@@ -420,11 +610,10 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * args.mols * args.steps / elapsed
         kern = {}
-        for name, evs in timers.items():
+        for name, evs in (timers or {}).items():
             if evs:
                 ms = [a.elapsed_time(b) for a, b in evs]
-                calls_per_step = len(ms) / prof_steps
-                kern[name] = (float(np.mean(ms)), calls_per_step)
+                kern[name] = (float(np.mean(ms)), len(ms) / prof_steps)
         kern = {k: v for k, v in kern.items() if k in per_kernel}
         dom = max(kern, key=lambda k: kern[k][0] * kern[k][1]) if kern else None
         roof = None
@@ -452,12 +641,23 @@ def main():
                     "algorithmic_GBps": ach_b / 1e9, "hbm_frac": ach_b / HBM_PEAK}
             if dom.startswith("geossl_painn"):
                 # PaiNN's interaction kernels are fp32 vector code over gathered rows (no matrix pipe): priced against
-                # HBM with the algorithmic bytes above, the fp32 vector fraction beside it
-                roof.update({"bound": "hbm", "unit": "GB/s", "achieved": ach_b / 1e9, "peak": HBM_PEAK / 1e9,
-                             "frac": ach_b / HBM_PEAK, "fp32_vector_frac": ach_f / FP32_PEAK,
-                             "peak_note": "algorithmic bytes of the launch over the 8 TB/s HBM3E spec"})
+                # HBM - with the MEASURED bytes of the launch when a PMC summary of this workload is committed, else
+                # with the per-edge algorithmic bytes above (an upper bound: the molecule-staged kernels read a row once
+                # per molecule) - the fp32 vector fraction beside it
+                pk = None
+                if pm is not None:
+                    ks = [v for k, v in pm["kernels"].items() if k.startswith(PAINN_KERNELS.get(dom, "\0"))]
+                    if ks:
+                        pk = sum(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for v in ks)
+                used = pk if pk is not None else by
+                roof.update({"bound": "hbm", "unit": "GB/s", "achieved": used / dur / 1e9, "peak": HBM_PEAK / 1e9,
+                             "frac": used / dur / HBM_PEAK, "fp32_vector_frac": ach_f / FP32_PEAK, "traffic": pk,
+                             "traffic_from": ("%s @ %s" % (pm_src, pm.get("git_head"))) if pk is not None else None,
+                             "frac_from": "measured HBM bytes of the launch (PMC)" if pk is not None
+                                          else "per-edge algorithmic bytes (upper bound; no PMC summary of this workload)",
+                             "peak_note": "bytes of the launch over the 8 TB/s HBM3E spec"})
             elif dom in ("geossl_cfconv_filter_fwd", "geossl_cfconv_filter_bwd"):
-                P2 = 2 * sum(int(n) * (int(n) - 1) // 2 for n in sizes0)  # pair slots, both views
+                P2 = 2 * sum(int(n) * (int(n) - 1) // 2 for n in wl.sizes0)  # pair slots, both views
                 per_row = (2 * 64 * F + (2 if dom.endswith("fwd") else 4) * F * F)
                 exe = P2 * L * per_row * SPLIT_PRODUCTS
             else:  # other entry points issue their algorithmic flops, SPLIT MFMAs per product
@@ -468,33 +668,47 @@ def main():
                              "peak_note": "executed 16-bit MFMA flops (%d per fp32 product) over the 2.5 PFLOP/s dense peak at 2.4 GHz; "
                                           "under this load the shader clock settles at 1.6-1.9 GHz (tools/filter_fwd_timing.py)" % SPLIT_PRODUCTS})
         per_gpu = value / world
+        measured = measured_step_traffic(pm, pm_src, per_gpu)
         out = {
             "metric": ("molecules/s/GPU SchNet+DDM fwd+bwd (QM9-sized, bs=1024); % HBM roofline" if args.model == "schnet"
                        else "molecules/s/GPU PaiNN+DDM fwd+bwd (QM9-sized, bs=1024) [BASELINE config 5]"),
             "value": value, "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("pretrain_GeoSSL.py --GeoSSL_option=DDM step, %s, "
-                                    "bs=%d molecules/GPU x %s atoms, %d pre-collated device-resident batches/GPU"
-                                    % ("SchNet F=128 L=6 G=51 cutoff=%gA" % CUTOFF if args.model == "schnet"
-                                       else "PaiNN F=128 L=3 rbf=20 cutoff=5A (BASELINE config 5)", args.mols,
-                                       "n=18" if args.molset == "A" else "n~clip(N(18,4),2,33) (set B)", n_batches)),
+            "config": {"workload": wl.describe(), "api": args.api,
                        "molecules_per_gpu_per_step": args.mols, "atoms": N, "directed_edges": E, "super_edges": S,
-                       "parallelism": "dp%d" % world,
-                       "execution": ("per step: x / positions copied and the five noise draws made on the device into the graph's inputs, HIP graph replay of fwd+bwd (%d graph%s in one memory pool), eager all-reduce + Adam"
-                                     % (len(trainer._graphs), "" if len(trainer._graphs) == 1 else "s"))
-                       if trainer.use_graph else "eager"},
+                       "parallelism": "dp%d" % world, "arithmetic": ARITHMETIC, "execution": wl.execution()},
             "roofline": roof,
-            "step_roofline": {"hbm_frac": step_bytes * (per_gpu / args.mols) / HBM_PEAK,
-                              **measured_step_traffic(pm, pm_src, per_gpu),
-                              "fp32_frac": step_flops * (per_gpu / args.mols) / FP32_PEAK,
+            # what the step really moves through HBM (PMC) leads; the SURVEY 8(d) model fractions price the reference's
+            # unfused formulation and exceed 1 once fusion and the exact i<j symmetry are in (they stay for continuity)
+            "step_roofline": {**measured,
+                              "model_hbm_frac": step_bytes * (per_gpu / args.mols) / HBM_PEAK,
+                              "model_fp32_frac": step_flops * (per_gpu / args.mols) / FP32_PEAK,
                               "alg_MB_per_mol": step_bytes / args.mols / 1e6,
                               "alg_MFLOP_per_mol": step_flops / args.mols / 1e6},
             "step_ms_percentiles": {"p10": float(np.percentile(step_ms, 10)), "p50": float(np.percentile(step_ms, 50)),
                                     "p90": float(np.percentile(step_ms, 90))},
             "kernel_ms": {k: {"avg_ms": v[0], "per_step": v[1]} for k, v in kern.items()},
+            "c_abi_calls_per_step": calls_per_step,
             "final_loss": final_loss,
         }
+        headline = (args.model == "schnet" and args.mols == 1024 and args.molset == "A" and args.api == "trainer"
+                    and CUTOFF == 5.0 and not args.no_graph)
+        if world == 1 and headline and not args.no_secondary:
+            # Secondary configurations, timed here so that the driver observes them (20 steps each, a few seconds in all):
+            # the reference's own loop and batch size, ragged molecules, the second backbone.
+            del wl
+            torch.cuda.empty_cache()
+            sec = {}
+            sec["reference_api/mols=1024"] = secondary_line(dev, rank, world, 20, 5, api="reference", mols=1024)
+            sec["trainer/mols=128"] = secondary_line(dev, rank, world, 40, 10, api="trainer", mols=128)
+            sec["reference_api/mols=128"] = secondary_line(dev, rank, world, 40, 10, api="reference", mols=128)
+            sec["trainer/set=B"] = secondary_line(dev, rank, world, 20, 4, api="trainer", molset="B", n_batches=4)
+            sec["trainer/painn"] = secondary_line(dev, rank, world, 20, 4, api="trainer", model="painn", n_batches=4)
+            ref = sec["reference_api/mols=1024"]
+            if "value" in ref:
+                ref["vs_trainer"] = ref["value"] / value
+            out["secondary"] = sec
         out["cpu_baseline"] = None  # timed on rank 0 at N=1 only
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seed=1000) if args.model == "schnet" else cpu_baseline_painn(seed=1000)

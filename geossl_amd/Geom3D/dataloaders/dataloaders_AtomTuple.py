@@ -107,6 +107,9 @@ class AtomTupleExtractor:
         if torch.is_tensor(data):
             return self._from_batch_vector(data)
         data.super_edge_index = self._one(len(data.x))
+        # the full enumeration is a function of the atom count: collated batches of such molecules can share step graphs
+        # (pretrain_GeoSSL.structure_fingerprint); a sampled subset (ratio < 1) is not
+        data._sei_canonical = self.option if self.ratio >= 1 else None
         return data
 
     def _from_batch_vector(self, batch):
@@ -139,6 +142,7 @@ class BatchAtomTuple(Data):
         super().__init__(**kwargs)
         self.batch = batch
         self._sizes = None       # atoms per molecule (host integers) when the collation knows them
+        self._canonical = None   # the AtomTupleExtractor option when super_edge_index is its full enumeration
         self._num_graphs = None
 
     @staticmethod
@@ -167,6 +171,8 @@ class BatchAtomTuple(Data):
         out.batch = torch.cat(bvec, dim=-1)
         out._sizes = sizes
         out._num_graphs = len(sizes)
+        marks = {getattr(data, "_sei_canonical", None) for data in data_list}
+        out._canonical = marks.pop() if len(marks) == 1 else None
         return out.contiguous()
 
     @classmethod
@@ -184,6 +190,7 @@ class BatchAtomTuple(Data):
             from ... import ops
             out.radius_edge_index = ops.radius_graph(positions, radius, batch)
         out._sizes, out._num_graphs = host_sizes, B
+        out._canonical = option if host_sizes is not None else None
         out._prepare(option == "combination")
         return out
 

@@ -266,10 +266,14 @@ def module_status(module, device, message):
 # Optional per-entry-point HIP-event timing (bench.py): {entry point name: [(start_event, end_event), ...]}.
 # Events are recorded on the stream the kernels are launched on (torch's current stream).
 TIMERS = None
+CALLS = None  # bench.py: set to 0 to count the C-ABI calls (an int, else None)
 
 
 def call(name, *args):
+    global CALLS
     lib = load()
+    if CALLS is not None:
+        CALLS += 1
     timers = TIMERS
     if timers is not None and name in timers:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -5,7 +5,17 @@
 (``NCSN_model_01/02``, :207-208); here they are module attributes with the same names, or can be
 passed with ``NCSN_models=``.  ``DDMTrainer`` is the training-loop body (:234-260) with all
 parameters in one flat buffer: one fused Adam launch and one RCCL all-reduce per step.
+
+Forward + backward of a step are captured into HIP graphs keyed on a FINGERPRINT of the batch's index structure
+(``structure_fingerprint``) and replayed - by ``DDMTrainer`` and, for a caller that keeps the reference's own loop
+(``loss, acc = do_DDM(...); optimizer.zero_grad(); loss.backward(); optimizer.step()``, :249-260), by ``do_DDM``
+itself: the loss it returns is the output of an autograd node whose backward hands the replayed gradients to autograd.
 """
+import os
+import warnings
+from collections import OrderedDict
+
+import numpy as np
 import torch
 
 from . import _lib, ops
@@ -73,18 +83,33 @@ def _two_view_edges(batch_vec, edge_index, num_graphs):
 
 
 def do_DDM(args, batch, model, criterion=None, mu=0.0, sigma=0.3, num_neg=1, NCSN_models=None, noise=None,
-           fuse_views=True, device_noise=False):
+           fuse_views=True, device_noise=False, graph=None):
     """pretrain_GeoSSL.py:179-212 -> (loss, 0).
 
     noise: optional dict with pos_noise [N,3], noise_level_1/2 [B] int64, dist_noise_1/2 [S,1] —
     the five random draws of the step; anything missing is drawn like the reference does.
     fuse_views: run the clean and the perturbed view through the backbone as one 2B-molecule batch
     (molecules never interact, so every row sees the same arithmetic as in two separate calls).
+    graph: replay a captured HIP graph of forward + backward (see ``_AutogradStep``) when gradients are wanted and the
+    batch's index structure has a fingerprint; default: ``args.step_graph`` if present, else on unless
+    ``GEOSSL_NO_STEP_GRAPH`` is set.  The draws, the loss and the gradients are those of the eager path, bit for bit.
     """
-    noise = noise or {}
     n1, n2 = NCSN_models if NCSN_models is not None else (NCSN_model_01, NCSN_model_02)
     if n1 is None or n2 is None:
         raise RuntimeError("set geossl_amd.pretrain_GeoSSL.NCSN_model_01/02 or pass NCSN_models=(m1, m2)")
+    if graph is None:
+        graph = getattr(args, "step_graph", os.environ.get("GEOSSL_NO_STEP_GRAPH") is None)
+    if graph and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing() and fuse_views:
+        loss = _autograd_step(model, n1, n2).run(args, batch, mu, sigma, noise, device_noise)
+        if loss is not None:
+            return loss, 0
+    return _do_ddm_eager(args, batch, model, mu, sigma, (n1, n2), noise, fuse_views, device_noise)
+
+
+def _do_ddm_eager(args, batch, model, mu, sigma, heads, noise, fuse_views, device_noise):
+    """The step as eager launches behind autograd's own nodes (one per backbone / head)."""
+    noise = noise or {}
+    n1, n2 = heads
     positions = batch.positions
     x_01 = batch.x[:, 0]
     positions_01 = positions
@@ -135,10 +160,15 @@ class Batch:
     """Device-resident collated batch with the attributes do_DDM / NCSN_version_03 read
     (BatchAtomTuple, dataloaders_AtomTuple.py:40-78)."""
 
-    def __init__(self, x, positions, batch, super_edge_index, radius_edge_index=None, num_graphs=None):
+    def __init__(self, x, positions, batch, super_edge_index, radius_edge_index=None, num_graphs=None, sizes=None,
+                 canonical=None):
         self.x, self.positions, self.batch, self.super_edge_index = x, positions, batch, super_edge_index
         self.radius_edge_index = radius_edge_index
         self._num_graphs = num_graphs
+        # host-side knowledge of the collation (structure_fingerprint): atoms per molecule, and the AtomTupleExtractor
+        # option when super_edge_index is its full enumeration in batch order
+        self._sizes = None if sizes is None else [int(n) for n in sizes]
+        self._canonical = canonical
 
     @property
     def num_graphs(self):
@@ -148,11 +178,12 @@ class Batch:
 
     @classmethod
     def from_numpy(cls, d, device):
-        import numpy as np
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         rei = t(d["radius_edge_index"]) if "radius_edge_index" in d else None
         ng = int(len(d["sizes"])) if "sizes" in d else None
-        out = cls(t(d["x"]), t(d["positions"]), t(d["batch"]), t(d["super_edge_index"]), rei, ng)
+        canonical = canonical_option(d["sizes"], d["super_edge_index"]) if "sizes" in d else None
+        out = cls(t(d["x"]), t(d["positions"]), t(d["batch"]), t(d["super_edge_index"]), rei, ng, d.get("sizes"),
+                  canonical)
         if "sizes" in d:  # collation knows the molecule sizes on the host: index structures without a device read-back
             from .layout import prepare_batch
             prepare_batch(out.batch, out.super_edge_index, d["sizes"])
@@ -161,7 +192,61 @@ class Batch:
     def to(self, device):
         mv = lambda a: None if a is None else a.to(device)
         return Batch(mv(self.x), mv(self.positions), mv(self.batch), mv(self.super_edge_index),
-                     mv(self.radius_edge_index), self._num_graphs)
+                     mv(self.radius_edge_index), self._num_graphs, self._sizes, self._canonical)
+
+
+_PAIR_CACHE = {}
+
+
+def canonical_option(sizes, super_edge_index):
+    """"combination" / "permutation" when the HOST array super_edge_index [2, S] is exactly AtomTupleExtractor's full
+    enumeration (dataloaders_AtomTuple.py:19-24, ratio = 1) of molecules with these sizes, collated in batch order with
+    node offsets (:64-65); None otherwise.  Such index tensors are a function of the sizes alone."""
+    from .synthetic import combination_pairs, permutation_pairs
+    sizes = np.asarray(sizes, dtype=np.int64)
+    sei = np.asarray(super_edge_index)
+    S = sei.shape[1] if sei.ndim == 2 else -1
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    for option, count, pairs in (("combination", sizes * (sizes - 1) // 2, combination_pairs),
+                                 ("permutation", sizes * (sizes - 1), permutation_pairs)):
+        if int(count.sum()) != S or S == 0:
+            continue
+        parts = []
+        for m, n in enumerate(sizes.tolist()):
+            if (option, n) not in _PAIR_CACHE:
+                _PAIR_CACHE[(option, n)] = pairs(n)
+            parts.append(_PAIR_CACHE[(option, n)] + off[m])
+        if np.array_equal(np.concatenate(parts, axis=1), sei):
+            return option
+    return None
+
+
+def structure_fingerprint(batch, model_3d="schnet"):
+    """Hashable identity of everything a captured step binds besides x, positions and the noise: the batch vector,
+    super_edge_index and (PaiNN) radius_edge_index with the index structures derived from them.
+
+    * A batch that carries its molecule sizes on the host AND whose super_edge_index is known to be the extractor's
+      full enumeration (``_sizes`` / ``_canonical``: set by ``Batch.from_numpy``, ``BatchAtomTuple.from_sizes`` and by
+      ``BatchAtomTuple.from_data_list`` over molecules that went through ``AtomTupleExtractor(ratio=1)``) has index
+      tensors that are a function of the sizes: the fingerprint is the sizes, so every batch of a shuffled loader with
+      the same molecule sizes in the same order shares a graph - and no other batch does.
+    * Anything else (sampled tuples, PaiNN's geometry-dependent edge list, batches built by hand) is identified by
+      the tensor OBJECTS and their versions: a graph is replayed only for the very tensors it was captured on (a
+      device-resident, pre-collated batch that comes back every epoch)."""
+    tag = lambda t_: None if t_ is None else (id(t_), t_._version, tuple(t_.shape))
+    rei = getattr(batch, "radius_edge_index", None) if model_3d == "painn" else None
+    tags = (tag(batch.batch), tag(batch.super_edge_index), tag(rei))
+    cached = batch.__dict__.get("_geossl_fp")
+    if cached is not None and cached[0] == tags:
+        return cached[1]
+    sizes, canon = getattr(batch, "_sizes", None), getattr(batch, "_canonical", None)
+    if sizes is not None and canon is not None and rei is None and model_3d != "painn":
+        fp = ("sizes", canon, int(batch.batch.numel()), int(batch.super_edge_index.size(1)),
+              np.asarray(sizes, dtype=np.int32).tobytes())
+    else:
+        fp = ("tensors",) + tags
+    batch.__dict__["_geossl_fp"] = (tags, fp)
+    return fp
 
 
 class Args:
@@ -172,19 +257,258 @@ class Args:
         self.normalize = normalize
 
 
+_NOISE_KEYS = ("pos_noise", "noise_level_1", "dist_noise_1", "noise_level_2", "dist_noise_2")
+
+
+class StepGraphs:
+    """HIP graphs of forward + backward of the DDM step, one per ``structure_fingerprint``; all in ONE memory pool
+    (their activations are dead between steps, so N graphs cost the device memory of the largest plus the static
+    inputs and the loss of each).  ``fwd_bwd(batch, noise) -> loss`` is the owner's eager step; it must leave the
+    gradients in buffers that are the same for every call (the graph binds their addresses).  Least-recently-used
+    graphs are dropped beyond ``max_graphs``."""
+
+    def __init__(self, fwd_bwd, model_3d, max_graphs=256):
+        self.fwd_bwd, self.model_3d, self.max_graphs = fwd_bwd, model_3d, max_graphs
+        self.graphs, self.pool = OrderedDict(), None
+        self.enabled = True
+        self.captures = 0
+        self._warned = False
+        self._seen = OrderedDict()
+
+    def __len__(self):
+        return len(self.graphs)
+
+    def lookup(self, batch):
+        """The graph captured for this batch's index structure (None: not captured yet)."""
+        fp = structure_fingerprint(batch, self.model_3d)
+        g = self.graphs.get(fp)
+        if g is not None:
+            self.graphs.move_to_end(fp)
+        return g
+
+    def seen_before(self, batch):
+        """True from the second call on for one fingerprint (a bounded memory of hashes: a collision or a forgotten
+        entry only moves the moment of a capture)."""
+        h = hash(structure_fingerprint(batch, self.model_3d))
+        seen = h in self._seen
+        self._seen[h] = True
+        self._seen.move_to_end(h)
+        while len(self._seen) > 8192:
+            self._seen.popitem(last=False)
+        return seen
+
+    def capture(self, batch, noise):
+        """Capture fwd_bwd on clones of x / positions / the five noise tensors (the graph's static inputs); the index
+        tensors of `batch` are bound as they are (and kept alive by the entry).  None when the capture failed: the
+        owner runs eagerly from then on."""
+        fp = structure_fingerprint(batch, self.model_3d)
+        while len(self.graphs) >= self.max_graphs:
+            if not self._warned:
+                warnings.warn("more than %d distinct batch structures: the least recently used step graphs are dropped "
+                              "and captured again when they come back (raise max_graphs, or run without graphs)"
+                              % self.max_graphs)
+                self._warned = True
+            self.graphs.popitem(last=False)
+        sb = Batch(batch.x.clone(), batch.positions.clone(), batch.batch, batch.super_edge_index,
+                   getattr(batch, "radius_edge_index", None), batch.num_graphs, getattr(batch, "_sizes", None),
+                   getattr(batch, "_canonical", None))
+        sn = {k: noise[k].clone() for k in _NOISE_KEYS}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up off the capture: builds the cached layouts, sets kernel attributes
+            for _ in range(2 if not self.graphs else 1):
+                self.fwd_bwd(sb, sn)
+        torch.cuda.current_stream().wait_stream(side)
+        # nothing may be pending on the device when the capture starts (in a multi-rank job the collective's
+        # watchdog thread polls events of earlier all-reduces), and calls of other threads must not invalidate it
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, pool=self.pool, capture_error_mode="thread_local"):
+                loss = self.fwd_bwd(sb, sn)
+        except Exception as e:  # capture is an optimisation: fall back to eager execution, loudly
+            warnings.warn("HIP-graph capture of the DDM step failed (%s: %s); running eagerly" % (type(e).__name__, e))
+            torch.cuda.synchronize()
+            self.enabled = False
+            return None
+        if self.pool is None:
+            self.pool = graph.pool()
+        self.captures += 1
+        g = self.graphs[fp] = dict(graph=graph, batch=sb, noise=sn, loss=loss)
+        return g
+
+    @staticmethod
+    def refresh(g, batch, noise=None):
+        """x, positions and (if given) the five noise tensors of this step into the graph's static inputs."""
+        g["batch"].x.copy_(batch.x)
+        g["batch"].positions.copy_(batch.positions)
+        if noise is not None:
+            for k in _NOISE_KEYS:
+                g["noise"][k].copy_(noise[k])
+
+
+def draw_step_noise(batch, n1, n2, mu, sigma, device_noise, given=None, into=None):
+    """The five random draws of a step in the order the eager path makes them: perturb (pretrain_GeoSSL.py:72: a
+    host draw copied to the device, or a device draw with device_noise), then per head the noise level (NCSN.py:190)
+    and the distance noise (:194).  Entries of `given` are used instead of drawing; with `into` the results are written
+    into those tensors (the static inputs of a graph) instead of new ones."""
+    given = given or {}
+    dev = batch.positions.device
+    S, B = batch.super_edge_index.size(1), batch.num_graphs
+    out = {}
+
+    def put(key, make, fill):
+        if given.get(key) is not None:
+            if into is not None:
+                into[key].copy_(given[key].view_as(into[key]))
+            out[key] = into[key] if into is not None else given[key]
+        elif into is not None:
+            fill(into[key])
+            out[key] = into[key]
+        else:
+            out[key] = make()
+
+    if device_noise:
+        put("pos_noise", lambda: torch.empty_like(batch.positions).normal_(mu, sigma), lambda t_: t_.normal_(mu, sigma))
+    else:  # the reference's own draw (:72): CPU generator, then the copy
+        put("pos_noise", lambda: torch.normal(mu, sigma, size=batch.positions.size()).to(dev),
+            lambda t_: t_.copy_(torch.normal(mu, sigma, size=batch.positions.size())))
+    for k, head in (("1", n1), ("2", n2)):
+        K = head.sigmas.size(0)
+        put("noise_level_" + k, lambda: torch.randint(0, K, (B,), device=dev), lambda t_: t_.random_(0, K))
+        put("dist_noise_" + k, lambda: torch.randn(S, 1, device=dev), lambda t_: t_.normal_())
+    return out
+
+
+class _ReplayedLoss(torch.autograd.Function):
+    """The loss of a replayed step as a differentiable function of the parameters: forward returns the loss the graph
+    computed, backward hands autograd the gradients the same replay left in the static buffer (a snapshot taken at
+    forward time, so that two steps may be in flight before the first backward), scaled by the upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, loss, gflat, shapes, *params):
+        ctx.gflat, ctx.shapes = gflat, shapes
+        return loss.view_as(loss)
+
+    @staticmethod
+    def backward(ctx, gout):
+        g = ctx.gflat * gout  # one launch; every parameter's gradient is a view of it
+        outs, off = [], 0
+        for shape, numel, wanted in ctx.shapes:
+            outs.append(g[off:off + numel].view(shape) if wanted else None)
+            off += numel
+        return (None, None, None) + tuple(outs)
+
+
+class _AutogradStep:
+    """do_DDM's graph path for a caller that owns its optimizer (the reference loop, pretrain_GeoSSL.py:249-260).
+
+    Forward AND backward of the step are captured as one graph per index structure; the backward's gradients land in a
+    flat static buffer (the parameters' .grad point into it only while the step is captured or run).  ``run`` draws the
+    step's noise like the eager path (same generators, same order), refreshes the graph's inputs, replays, and returns
+    ``_ReplayedLoss``: ``loss.backward()`` then costs one multiply, and AccumulateGrad adopts the views."""
+
+    def __init__(self, model, n1, n2):
+        from .NCSN import _head_params
+        self.model, self.n1, self.n2 = model, n1, n2
+        # the parameters the step reaches (a parameter outside it - an atomref table, PaiNN's output layers - gets no
+        # gradient at all, like in the eager path, not a zero one)
+        backbone = model._params() if hasattr(model, "_params") else _schnet_step_params(model)
+        seen, self.params = set(), []
+        for p in list(backbone) + _head_params(n1) + _head_params(n2):
+            if id(p) not in seen and p.requires_grad:
+                seen.add(id(p))
+                self.params.append(p)
+        dev = self.params[0].device
+        self.gflat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.gflat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.shapes = tuple((tuple(p.shape), p.numel(), True) for p in self.params)
+        self.signature = self._signature()
+        self.graphs = {}   # (model_3d, normalize) -> StepGraphs
+        self._cfg = None
+
+    def _signature(self):
+        return tuple((id(p), p.data_ptr(), p.requires_grad) for m in (self.model, self.n1, self.n2)
+                     for p in m.parameters())
+
+    def _fwd_bwd(self, batch, noise):
+        args, mu, sigma = self._cfg
+        held = [p.grad for p in self.params]
+        self.gflat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        try:
+            loss = _do_ddm_eager(args, batch, self.model, mu, sigma, (self.n1, self.n2), noise, True, True)
+            with _lib.direct_grads():  # kernels accumulate straight into the static buffer
+                loss.backward()
+            for p, v in zip(self.params, self.views):  # anything autograd replaced goes back into the buffer
+                if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+        finally:
+            for p, h in zip(self.params, held):
+                p.grad = h
+        return loss.detach()
+
+    def run(self, args, batch, mu, sigma, noise, device_noise):
+        if not batch.positions.is_cuda or batch.positions.requires_grad:
+            return None
+        key = (args.model_3d, bool(getattr(args, "normalize", False)))
+        sg = self.graphs.get(key)
+        if sg is None:
+            sg = self.graphs[key] = StepGraphs(self._fwd_bwd, args.model_3d)
+        if not sg.enabled:
+            return None
+        self._cfg = (Args(args.model_3d, key[1]), mu, sigma)
+        g = sg.lookup(batch)
+        if g is None and not sg.seen_before(batch):
+            # first sighting of this index structure: eager.  A loader whose batches never repeat a structure (ragged
+            # molecules in shuffled order, sampled tuples, PaiNN edge lists collated anew every epoch) then never pays
+            # for a capture; a structure that comes back is captured on its second step.
+            return None
+        if g is None:
+            drawn = draw_step_noise(batch, self.n1, self.n2, mu, sigma, device_noise, noise)
+            g = sg.capture(batch, drawn)
+            if g is None:
+                return None
+            sg.refresh(g, batch, drawn)
+        else:
+            sg.refresh(g, batch)
+            draw_step_noise(batch, self.n1, self.n2, mu, sigma, device_noise, noise, into=g["noise"])
+        g["graph"].replay()
+        return _ReplayedLoss.apply(g["loss"].clone(), self.gflat.clone(), self.shapes, *self.params)
+
+
+def _schnet_step_params(model):
+    from .Geom3D.models.schnet import _core_params
+    return _core_params(model)
+
+
+def _autograd_step(model, n1, n2):
+    """The _AutogradStep of a (backbone, head, head) triple, kept on the backbone module; rebuilt when a parameter was
+    replaced, moved or frozen since (the graphs bind parameter addresses)."""
+    eng = model.__dict__.get("_geossl_autograd_step")
+    if eng is None or eng.n1 is not n1 or eng.n2 is not n2 or eng.signature != eng._signature():
+        eng = _AutogradStep(model, n1, n2)
+        model.__dict__["_geossl_autograd_step"] = eng
+    return eng
+
+
 class DDMTrainer:
     """The body of ``train()`` (pretrain_GeoSSL.py:234-260) for the DDM option: forward of both
     views + both heads, backward, gradient all-reduce, Adam — flat parameter buffer, no host sync
     inside ``step`` (the reference's per-step ``loss.item()`` at :255 is logging, call
     ``float(loss)`` outside the timed region if wanted).
 
-    ``use_graph=True``: forward + backward of batches that share one index structure (same
-    ``batch`` / ``super_edge_index`` contents, identified by the caller's ``structure_key``) are
-    captured once into a HIP graph and replayed; positions, atom types and the five noise tensors
-    are copied into the graph's static buffers before each replay (with ``noise=None`` and ``device_noise=True`` the
-    trainer makes the five draws itself, straight into those buffers).  A loader with ragged molecules
-    passes one key per batch (e.g. its index in the epoch): up to ``max_graphs`` graphs are kept,
-    all in one shared memory pool.  The all-reduce and the Adam launch stay outside the graph."""
+    ``use_graph=True``: forward + backward are captured once per index structure into a HIP graph and replayed;
+    positions, atom types and the five noise tensors are copied into the graph's static buffers before each replay
+    (with ``noise=None`` and ``device_noise=True`` the trainer makes the five draws itself, straight into those
+    buffers).  Which graph a batch gets is decided by ``structure_fingerprint`` - the molecule sizes for batches whose
+    index tensors are a function of them, the tensor objects otherwise - never by the caller: a shuffled loader with
+    ragged molecules captures one graph per distinct size sequence (up to ``max_graphs``, least recently used dropped,
+    all in one shared memory pool).  The all-reduce and the Adam launch stay outside the graph."""
 
     def __init__(self, model, ncsn_01, ncsn_02, lr=5e-4, weight_decay=0.0, mu=0.0, sigma=0.3, model_3d="schnet",
                  device_noise=True, use_graph=False, overlap_heads=True, max_graphs=256):
@@ -201,14 +525,18 @@ class DDMTrainer:
         # two-pass NCSN backward only (GEOSSL_NCSN_SPLIT_BWD): its weight-gradient kernels on a side stream, concurrent
         # with the backbone's backward; the default one-pass backward has nothing to overlap
         self.overlap_heads = overlap_heads
-        self._graphs, self._pool, self.max_graphs = {}, None, max_graphs
+        self.step_graphs = StepGraphs(self._fwd_bwd, model_3d, max_graphs)
         self._side = None
+
+    @property
+    def _graphs(self):
+        return self.step_graphs.graphs
 
     def _fwd_bwd(self, batch, noise):
         from . import NCSN as _ncsn
         self.flat.zero_grad()
-        loss, _ = do_DDM(self.args, batch, self.model, None, self.mu, self.sigma, NCSN_models=(self.n1, self.n2),
-                         noise=noise, device_noise=self.device_noise)
+        loss = _do_ddm_eager(self.args, batch, self.model, self.mu, self.sigma, (self.n1, self.n2), noise, True,
+                             self.device_noise)
         if self._side is None and self.overlap_heads:
             self._side = torch.cuda.Stream()
         _ncsn.set_side_stream(self._side)  # head weight gradients overlap the backbone's backward
@@ -221,91 +549,38 @@ class DDMTrainer:
         self.flat.rebind_grads()
         return loss.detach()
 
-    _NOISE_KEYS = ("pos_noise", "noise_level_1", "dist_noise_1", "noise_level_2", "dist_noise_2")
+    _NOISE_KEYS = _NOISE_KEYS
 
-    def _graph_fwd_bwd(self, batch, noise, key):
-        # The captured graph binds every index structure of the capture batch (batch vector, super_edge_index, and for
-        # PaiNN the precomputed radius_edge_index with its incidence lists, which differ from batch to batch even when
-        # the molecule sizes agree): only x, positions and the noise tensors are refreshed before a replay.  The
-        # caller's structure_key vouches for batch / super_edge_index; radius_edge_index is identified here by tensor
-        # object and version, so a different edge list gets its own capture instead of silently replaying the old one.
-        rei = batch.radius_edge_index if self.args.model_3d == "painn" else None
-        if rei is not None:
-            key = (key, id(rei), rei._version, int(rei.size(1)))
-        g = self._graphs.get(key)
+    def _graph_fwd_bwd(self, batch, noise):
+        sg = self.step_graphs
+        g = sg.lookup(batch)
         own_noise = noise is None
         if g is None:
             if own_noise:
                 noise = self._draw_noise(batch)  # this step's draws (the capture needs tensors to clone)
-            g = self._capture(batch, noise, key)
+            g = sg.capture(batch, noise)
             if g is None:  # capture failed: eager from now on
+                self.use_graph = False
                 return self._fwd_bwd(batch, noise)
             own_noise = False  # already drawn: copied below like a caller's
-        g["batch"].x.copy_(batch.x)
-        g["batch"].positions.copy_(batch.positions)
+        sg.refresh(g, batch, None if own_noise else noise)
         if own_noise:  # the step's own draws go straight into the graph's static inputs (no staging copies)
             self._draw_noise(batch, into=g["noise"])
-        else:
-            for k in self._NOISE_KEYS:
-                g["noise"][k].copy_(noise[k])
         g["graph"].replay()
-        return g["loss"]
+        # (a clone: the static scalar is overwritten by the next replay, and freed with its graph when that is dropped)
+        return g["loss"].clone()
 
     def _draw_noise(self, batch, into=None):
-        """The five random draws of a step (perturb: pretrain_GeoSSL.py:72 with the draw made on the device; the heads:
-        NCSN.py:190,194), as tensors - new ones, or in place into `into`."""
-        dev = batch.positions.device
-        if into is None:
-            S, B = batch.super_edge_index.size(1), batch.num_graphs
-            into = {"pos_noise": torch.empty_like(batch.positions),
-                    "noise_level_1": torch.empty(B, dtype=torch.long, device=dev),
-                    "noise_level_2": torch.empty(B, dtype=torch.long, device=dev),
-                    "dist_noise_1": torch.empty(S, 1, dtype=torch.float32, device=dev),
-                    "dist_noise_2": torch.empty(S, 1, dtype=torch.float32, device=dev)}
-        into["pos_noise"].normal_(self.mu, self.sigma)
-        into["noise_level_1"].random_(0, self.n1.sigmas.size(0))
-        into["dist_noise_1"].normal_()
-        into["noise_level_2"].random_(0, self.n2.sigmas.size(0))
-        into["dist_noise_2"].normal_()
-        return into
-
-    def _capture(self, batch, noise, key):
-        """One HIP graph per structure key.  Ragged batches (every batch its own index structure) get one graph each -
-        captured once, replayed every epoch; all graphs share ONE memory pool (their activations are dead between
-        steps), so the device memory of N graphs is that of the largest, plus the static inputs and the loss of each."""
-        while len(self._graphs) >= self.max_graphs:
-            self._graphs.pop(next(iter(self._graphs)))
-        sb = Batch(batch.x.clone(), batch.positions.clone(), batch.batch, batch.super_edge_index,
-                   batch.radius_edge_index, batch.num_graphs)
-        sn = {k: noise[k].clone() for k in self._NOISE_KEYS}
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # warm-up off the capture: builds the cached layouts, sets kernel attributes
-            for _ in range(2 if not self._graphs else 1):
-                self._fwd_bwd(sb, sn)
-        torch.cuda.current_stream().wait_stream(side)
-        # nothing may be pending on the device when the capture starts (in a multi-rank job the collective's
-        # watchdog thread polls events of earlier all-reduces), and calls of other threads must not invalidate it
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        try:
-            with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
-                loss = self._fwd_bwd(sb, sn)
-        except Exception as e:  # capture is an optimisation: fall back to eager execution, loudly
-            import warnings
-            warnings.warn("HIP-graph capture of the DDM step failed (%s: %s); running eagerly" % (type(e).__name__, e))
-            torch.cuda.synchronize()
-            self.use_graph = False
-            return None
-        if self._pool is None:
-            self._pool = graph.pool()
-        g = self._graphs[key] = dict(graph=graph, batch=sb, noise=sn, loss=loss)
-        return g
+        """The five random draws of a step on the device (perturb: pretrain_GeoSSL.py:72; the heads: NCSN.py:190,194),
+        as tensors - new ones, or in place into `into`."""
+        return draw_step_noise(batch, self.n1, self.n2, self.mu, self.sigma, True, None, into)
 
     def step(self, batch, noise=None, structure_key=None):
-        if self.use_graph and structure_key is not None and (
-                (noise is None and self.device_noise) or (noise is not None and all(k in noise for k in self._NOISE_KEYS))):
-            loss = self._graph_fwd_bwd(batch, noise, structure_key)
+        """One training step.  ``structure_key`` is accepted for compatibility and ignored: graphs are found by the
+        batch's own fingerprint."""
+        if self.use_graph and ((noise is None and self.device_noise)
+                               or (noise is not None and all(k in noise for k in _NOISE_KEYS))):
+            loss = self._graph_fwd_bwd(batch, noise)
         else:
             loss = self._fwd_bwd(batch, noise)
         st = self.model.__dict__.get("_geossl_status")

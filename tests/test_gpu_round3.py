@@ -1,0 +1,211 @@
+"""GPU tests added in round 3: step graphs found by a content-derived fingerprint, the reference's own loop on the
+graph path of do_DDM, bench.py's N > 1 branch on one GPU."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import product_ncsn, product_schnet, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FULL = dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=5.0, node_class=9,
+            readout="mean")
+SMALL = dict(hidden_channels=128, num_filters=128, num_interactions=2, num_gaussians=51, cutoff=5.0, node_class=9,
+             readout="mean")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded():
+    from geossl_amd import _lib
+    _lib.load()
+
+
+def _reference_loop(graph, steps, batches, cfg=SMALL, seed=11):
+    """examples/pretrain_GeoSSL.py:248-260 + :332-343 on the product modules; returns losses and final parameters."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed(seed)
+    model = product_schnet(cfg, DEV)
+    n1, n2 = product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9)
+    pg.NCSN_model_01, pg.NCSN_model_02 = n1, n2
+    args = types.SimpleNamespace(model_3d="schnet", GeoSSL_mu=0.0, GeoSSL_sigma=0.3, lr=5e-4, decay=0.0,
+                                 step_graph=graph)
+    group = [{"params": model.parameters(), "lr": args.lr}, {"params": n1.parameters()}, {"params": n2.parameters()}]
+    optimizer = torch.optim.Adam(group, lr=args.lr, weight_decay=args.decay)
+    losses = []
+    try:
+        for step in range(steps):
+            batch = batches[step % len(batches)]
+            loss, acc = pg.do_DDM(args, batch, model, criterion=None, mu=args.GeoSSL_mu, sigma=args.GeoSSL_sigma)
+            losses.append(loss.detach().item())
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+    finally:
+        pg.NCSN_model_01 = pg.NCSN_model_02 = None
+    eng = model.__dict__.get("_geossl_autograd_step")
+    captures = sum(sg.captures for sg in eng.graphs.values()) if eng is not None else 0
+    params = torch.cat([p.detach().reshape(-1) for m in (model, n1, n2) for p in m.parameters()]).cpu()
+    return losses, params, captures
+
+
+def test_reference_loop_on_the_graph_path_is_the_eager_loop_bit_for_bit():
+    """The reference's loop body, unchanged, with do_DDM replaying a captured forward+backward from the second sighting
+    of a batch structure on: same seeds -> the same five draws per step (host position noise, device head noise), the same
+    losses and, through stock torch.optim.Adam over the reference's three groups, the same parameters as eager launches.
+    Fresh tensor objects every step (a loader's collation): the graph is found by the molecule sizes."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import make_batch
+    out = {}
+    for graph in (False, True):
+        batches = [pg.Batch.from_numpy(make_batch(48, seed=40 + i), DEV) for i in range(5)]
+        out[graph] = _reference_loop(graph, 5, batches)
+    assert out[True][2] == 1 and out[False][2] == 0, "one capture, at the second step"
+    assert out[True][0] == out[False][0], (out[True][0], out[False][0])
+    assert torch.equal(out[True][1], out[False][1])
+    assert len(set(out[True][0])) == 5
+
+
+def test_graph_path_keeps_autograds_contract():
+    """The loss do_DDM returns from a replay is an ordinary differentiable scalar: torch.autograd.grad over a subset of
+    parameters, a scaled loss, gradient accumulation over two steps in flight and parameter hooks all see what the
+    eager path gives them."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    b = make_batch(32, seed=7)
+    batch = pg.Batch.from_numpy(b, DEV)
+    nz = [{k: t(v, DEV) for k, v in draw_noise(b, seed=70 + i).items()} for i in range(2)]
+    torch.manual_seed(3)
+    model = product_schnet(SMALL, DEV)
+    heads = (product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9))
+    args = pg.Args("schnet")
+    params = [p for m in (model,) + heads for p in m.parameters() if p.requires_grad]
+
+    def grads(graph):
+        for p in params:
+            p.grad = None
+        l0, _ = pg.do_DDM(args, batch, model, NCSN_models=heads, noise=nz[0], graph=graph)
+        l1, _ = pg.do_DDM(args, batch, model, NCSN_models=heads, noise=nz[1], graph=graph)
+        (0.5 * l0 + 2.0 * l1).backward()      # two steps in flight, scaled
+        return float(l0), float(l1), [None if p.grad is None else p.grad.clone() for p in params]
+
+    pg.do_DDM(args, batch, model, NCSN_models=heads, noise=nz[0], graph=True)   # first sighting (eager)
+    seen = []
+    hook = params[3].register_hook(lambda g: seen.append(g.clone()))
+    e0, e1, ge = grads(False)
+    g0, g1, gg = grads(True)
+    hook.remove()
+    assert (e0, e1) == (g0, g1)
+    assert [x is None for x in ge] == [x is None for x in gg]
+    for a, c in zip(ge, gg):
+        if a is not None:
+            assert float((a - c).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-30   # 0.5 g0 + 2 g1: one rounding apart
+    assert len(seen) == 2 and torch.allclose(seen[0], seen[1], rtol=1e-5, atol=0)
+    sub = [params[0], params[5]]
+    l, _ = pg.do_DDM(args, batch, model, NCSN_models=heads, noise=nz[0], graph=True)
+    ga = torch.autograd.grad(l, sub)
+    l, _ = pg.do_DDM(args, batch, model, NCSN_models=heads, noise=nz[0], graph=False)
+    gb = torch.autograd.grad(l, sub)
+    assert all(torch.equal(x, y) for x, y in zip(ga, gb))
+    with torch.no_grad():                                  # no gradients wanted: plain forward, no replay
+        l2, _ = pg.do_DDM(args, batch, model, NCSN_models=heads, noise=nz[0], graph=True)
+    assert not l2.requires_grad and float(l2) == e0
+
+
+def test_trainer_graphs_follow_the_batch_structure_not_a_callers_key():
+    """two ragged batches with the same N and S but different molecule sizes, stepped under ONE
+    caller key, must not replay each other's index structures; batches with equal sizes share a graph whatever tensor
+    objects they arrive as."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    specs = [[10, 20, 14], [20, 10, 14], [10, 20, 14], [14, 20, 10]]
+    raw = [make_batch(3, seed=80 + i, sizes=s) for i, s in enumerate(specs)]
+    assert len({b["x"].shape[0] for b in raw}) == 1 and len({b["super_edge_index"].shape[1] for b in raw}) == 1
+    losses, n_graphs = {}, None
+    for use_graph in (False, True):
+        tr = pg.DDMTrainer(product_schnet(SMALL, DEV), product_ncsn(128, 50, 2, DEV),
+                           product_ncsn(128, 50, 2, DEV, scale=0.9), lr=5e-4, use_graph=use_graph)
+        out = []
+        for step in range(8):
+            b = raw[step % 4]
+            noise = {k: t(v, DEV) for k, v in draw_noise(b, seed=300 + step).items()}
+            out.append(float(tr.step(pg.Batch.from_numpy(b, DEV), noise, structure_key="same-key-for-everything")))
+        losses[use_graph] = out
+        if use_graph:
+            assert tr.use_graph, "capture fell back to eager"
+            n_graphs = len(tr._graphs)
+    assert losses[True] == losses[False], losses
+    assert n_graphs == 3      # [10,20,14] twice -> one graph
+
+
+def test_trainer_graph_cache_is_lru_and_losses_survive_eviction():
+    """beyond max_graphs the least recently used graph is dropped (with a warning), a loss returned
+    earlier stays valid (it is a copy, not the graph's static scalar), and a structure that comes back is captured again
+    with the right result."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    raw = [make_batch(3, seed=90 + i, sizes=s) for i, s in enumerate([[6, 9, 12], [9, 6, 12], [12, 9, 6]])]
+
+    def run(use_graph):
+        tr = pg.DDMTrainer(product_schnet(SMALL, DEV), product_ncsn(128, 50, 2, DEV),
+                           product_ncsn(128, 50, 2, DEV, scale=0.9), lr=5e-4, use_graph=use_graph, max_graphs=2)
+        kept = []
+        for step in range(7):
+            b = raw[step % 3]
+            noise = {k: t(v, DEV) for k, v in draw_noise(b, seed=500 + step).items()}
+            kept.append(tr.step(pg.Batch.from_numpy(b, DEV), noise))
+        return [float(x) for x in kept], tr
+
+    eager, _ = run(False)
+    with pytest.warns(UserWarning, match="least recently used"):
+        replayed, tr = run(True)
+    assert replayed == eager
+    assert len(tr._graphs) == 2 and tr.step_graphs.captures == 7
+
+
+def _free_port():
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def test_bench_two_ranks_share_one_gpu(tmp_path):
+    """bench.py's own N > 1 branch (init_distributed, per-rank molecules and noise streams, barrier + max-over-ranks
+    timing, all-reduce + Adam, the JSON line of rank 0) as the driver launches it, with two ranks on the one GPU of the
+    box over gloo (fresh child processes; nothing that touched the GPU is re-executed)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2",
+               GEOSSL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", GEOSSL_BENCH_RANK_LOSS=str(tmp_path))
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--mols", "256"]
+    logs = [open(tmp_path / ("rank%d.log" % r), "w") for r in range(2)]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=logs[r],
+                              stderr=subprocess.STDOUT, cwd=REPO) for r in range(2)]
+    try:
+        codes = [p.wait(timeout=300) for p in procs]
+    except subprocess.TimeoutExpired:
+        codes = None
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+        for f in logs:
+            f.close()
+    texts = [open(tmp_path / ("rank%d.log" % r)).read() for r in range(2)]
+    assert codes == [0, 0], "\n".join(x[-1500:] for x in texts)
+    lines = [ln for ln in texts[0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not any(ln.startswith("{") for ln in texts[1].splitlines())
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["parallelism"] == "dp2"
+    assert np.isfinite(out["value"]) and out["value"] > 0 and out["cpu_baseline"] is None
+    assert abs(out["value"] - 2 * 256 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    l0, l1 = (float(open(tmp_path / ("loss_rank%d.txt" % r)).read()) for r in range(2))
+    assert np.isfinite(l0) and np.isfinite(l1) and l0 != l1      # each rank has its own molecules and noise stream

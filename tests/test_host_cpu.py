@@ -258,3 +258,134 @@ def test_dataloader_atom_tuple_batches_like_the_reference():
     # second batch renumbers from 0 (node offsets restart per batch, :57-66)
     assert int(batches[1].batch.min()) == 0 and int(batches[1].super_edge_index.min()) == 0
     assert isinstance(DataLoaderAtomTuple(dataset).sampler, torch.utils.data.RandomSampler)  # shuffle=True default
+
+
+# ------------------------------------------------------------------------------------ step-graph fingerprints (round 3)
+def _cpu_batch(b, canonical="auto"):
+    from geossl_amd import pretrain_GeoSSL as pg
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    canon = pg.canonical_option(b["sizes"], b["super_edge_index"]) if canonical == "auto" else canonical
+    return pg.Batch(tt(b["x"]), tt(b["positions"]), tt(b["batch"]), tt(b["super_edge_index"]), None, len(b["sizes"]),
+                    b["sizes"], canon)
+
+
+def test_canonical_option_recognises_the_extractors_enumerations():
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import make_batch
+    for option in ("combination", "permutation"):
+        b = make_batch(6, seed=3, mode="B", option=option)
+        assert pg.canonical_option(b["sizes"], b["super_edge_index"]) == option
+        sei = b["super_edge_index"].copy()
+        sei[:, [0, 1]] = sei[:, [1, 0]]                      # the same tuples in another order
+        assert pg.canonical_option(b["sizes"], sei) is None
+        assert pg.canonical_option(b["sizes"], b["super_edge_index"][:, :-1]) is None   # a sampled subset
+        assert pg.canonical_option(b["sizes"][::-1], b["super_edge_index"]) in (None, option)
+
+
+def test_structure_fingerprint_is_content_derived():
+    """The graph a batch replays is chosen by what the graph binds: equal molecule sizes in equal order ->
+    one fingerprint whatever the tensor objects; the same atoms split differently -> another one, although N and S
+    agree; index tensors that are not a function of the sizes -> identified by the tensor objects themselves."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import make_batch
+    b1 = make_batch(2, seed=1, sizes=[10, 20])
+    b2 = make_batch(2, seed=2, sizes=[10, 20])
+    b3 = make_batch(2, seed=1, sizes=[20, 10])
+    assert b1["x"].shape == b3["x"].shape and b1["super_edge_index"].shape == b3["super_edge_index"].shape
+    f1, f2, f3 = (pg.structure_fingerprint(_cpu_batch(b)) for b in (b1, b2, b3))
+    assert f1 == f2 and f1 != f3 and f1[0] == "sizes"
+    # no canonical marker (e.g. tuples sampled with ratio < 1): tensor identity, two collations never share a graph
+    n1, n2 = _cpu_batch(b1, canonical=None), _cpu_batch(b1, canonical=None)
+    g1, g2 = pg.structure_fingerprint(n1), pg.structure_fingerprint(n2)
+    assert g1[0] == "tensors" and g1 != g2 and pg.structure_fingerprint(n1) == g1
+    n1.super_edge_index.add_(0)                               # an in-place edit bumps the version: a new structure
+    assert pg.structure_fingerprint(n1) != g1
+    # PaiNN's edge list depends on the geometry: always by identity
+    assert pg.structure_fingerprint(_cpu_batch(b1), "painn")[0] == "tensors"
+
+
+def test_loader_marks_canonical_batches():
+    """AtomTupleExtractor(ratio=1) marks its molecules, from_data_list carries the mark (and the host sizes) into the
+    batch; a sampled extractor, or a mix of options, leaves no mark."""
+    from geossl_amd.Geom3D.dataloaders import AtomTupleExtractor, BatchAtomTuple
+    g = load_golden("g11_loader")
+    full = [AtomTupleExtractor(ratio=1, option="combination")(d) for d in _loader_molecules(g)]
+    bt = BatchAtomTuple.from_data_list(full)
+    assert bt._canonical == "combination" and bt._sizes == g["sizes"].tolist()
+    assert "_sei_canonical" not in bt.keys and "_canonical" not in bt.keys
+    np.random.seed(0)
+    half = [AtomTupleExtractor(ratio=0.5, option="combination")(d) for d in _loader_molecules(g)]
+    assert BatchAtomTuple.from_data_list(half)._canonical is None
+    mixed = full[:2] + [AtomTupleExtractor(ratio=1, option="permutation")(d) for d in _loader_molecules(g)[2:]]
+    assert BatchAtomTuple.from_data_list(mixed)._canonical is None
+
+
+def test_shard_batch_numpy_keeps_painn_edges_with_their_molecules():
+    """Data parallelism for PaiNN (BASELINE config 4/5): the precomputed radius_edge_index is sharded with the molecules
+    it belongs to and renumbered from 0, so the shards of two ranks are exactly the collations of their own molecules."""
+    from geossl_amd.parallel import shard_batch_numpy
+    from geossl_amd.synthetic import make_batch
+    from oracle import graph
+    full = make_batch(6, seed=9, mode="B")
+    off = np.concatenate([[0], np.cumsum(full["sizes"])])
+    mols = [(full["x"][off[m]:off[m + 1]], full["positions"][off[m]:off[m + 1]]) for m in range(6)]
+    full["radius_edge_index"] = graph.collate_np(mols, radius=5.0)["radius_edge_index"]
+    for rank in range(2):
+        mine = shard_batch_numpy(full, rank, 2)
+        own = graph.collate_np(mols[3 * rank:3 * rank + 3], radius=5.0)
+        for k in ("x", "positions", "batch", "super_edge_index", "radius_edge_index"):
+            assert np.array_equal(mine[k], own[k]), (rank, k)
+        assert mine["sizes"].tolist() == full["sizes"][3 * rank:3 * rank + 3].tolist()
+
+
+_PAINN_WORKER = r"""
+import os, sys
+sys.path.insert(0, {repo!r}); sys.path.insert(0, {golden!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from geossl_amd.parallel import init_distributed, shard_batch_numpy, GradAllReduce
+from geossl_amd.synthetic import make_batch, draw_noise
+from helpers import ncsn_oracle_params, t
+from oracle import graph, nets
+from test_oracle_golden import painn_params
+torch.set_num_threads(2)
+rank, _, world = init_distributed("gloo")
+cfg = dict(n_atom_basis=32, n_interactions=2, n_rbf=8, cutoff=5.0, max_z=9)
+full = make_batch(8, seed=6, mode="B")
+off = np.concatenate([[0], np.cumsum(full["sizes"])])
+mols = [(full["x"][off[m]:off[m + 1]], full["positions"][off[m]:off[m + 1]]) for m in range(8)]
+full["radius_edge_index"] = graph.collate_np(mols, radius=5.0)["radius_edge_index"]
+mine = shard_batch_numpy(full, rank, world)
+own = graph.collate_np(mols[4 * rank:4 * rank + 4], radius=5.0)
+for k in ("x", "positions", "batch", "super_edge_index", "radius_edge_index"):
+    assert np.array_equal(mine[k], own[k]), k          # the shard IS the collation of this rank's molecules
+nz = draw_noise(mine, 100 + rank)
+Pm, P1, P2 = painn_params(cfg), ncsn_oracle_params(32, 50), ncsn_oracle_params(32, 50, 0.9)
+loss = nets.do_ddm_painn(Pm, P1, P2, t(mine["x"]), t(mine["positions"]), t(mine["batch"]), t(mine["radius_edge_index"]),
+    t(mine["super_edge_index"]), t(nz["pos_noise"]), t(nz["noise_level_1"]), t(nz["dist_noise_1"]), t(nz["noise_level_2"]),
+    t(nz["dist_noise_2"]), 32, 2, 5.0, 2, "add")
+loss.backward()
+flat = torch.cat([p.grad.reshape(-1) for P in (Pm, P1, P2) for k, p in sorted(P.items()) if p.requires_grad and p.grad is not None])
+local = flat.clone()
+scale = GradAllReduce(flat)()
+torch.save(dict(local=local, reduced=flat * scale), os.path.join({out!r}, "rank%d.pt" % rank))
+dist.barrier()
+"""
+
+
+def test_painn_shards_world2_gloo(tmp_path):
+    """BASELINE config 4 with the second backbone, on CPU: two gloo ranks shard a ragged batch WITH its precomputed
+    radius_edge_index (each shard equals the collation of the rank's own molecules), run the oracle's PaiNN DDM step
+    and all-reduce the flat gradient: both hold the mean of the two local gradients."""
+    script = tmp_path / "worker.py"
+    script.write_text(_PAINN_WORKER.format(repo=REPO, golden=GOLDEN, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=False)
+    assert torch.equal(r0["reduced"], r1["reduced"])
+    want = (r0["local"] + r1["local"]) / 2
+    assert float((r0["reduced"] - want).abs().max() / want.abs().max()) < 1e-6
+    assert not torch.equal(r0["local"], r1["local"])
