@@ -140,7 +140,9 @@ class _NcsnLoss(torch.autograd.Function):
         g = _lib.NcsnGrads(*[ptr(t) for t in grads])
         lib = _lib.load()
         acc = 1 if direct else 0
-        split = os.environ.get("GEOSSL_NCSN_SPLIT_BWD") is not None  # the two-pass form (row pass, then column GEMMs)
+        # the two-pass form (row pass, then column GEMMs): on request, and for tensors of 4 GiB and more, which the
+        # one-pass kernel's 32-bit byte offsets cannot address
+        split = os.environ.get("GEOSSL_NCSN_SPLIT_BWD") is not None or max(S, N) * Fd * 4 >= 2 ** 32
         if not split:
             # one pass over the rows: dfeat / demb / grow and every weight gradient of the head (ncsn_bwd.hip)
             ws1 = torch.empty(int(lib.geossl_ddm_loss_bwd_fused_workspace_floats(S, Fd)), dtype=torch.float32, device=dev)

@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
   auto row_scale = [&](int i) __attribute__((always_inline)) {
     const float* r = rmax + (i * 4) * 32 + j;
     const float mx = fmaxf(fmaxf(r[0], r[32]), fmaxf(r[64], r[96]));
-    const int e = max(__builtin_amdgcn_frexp_expf(mx), -100);
+    const int e = mag_exponent(mx);
     krow[i] = __builtin_amdgcn_ldexpf(1.0f, e - 14);
     return __builtin_amdgcn_ldexpf(1.0f, 14 - e);
   };

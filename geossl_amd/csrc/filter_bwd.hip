@@ -818,7 +818,7 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
       bound = __uint_as_float(*reinterpret_cast<volatile unsigned*>(L.et + CB));
     }
     {
-      const int e_t = __builtin_amdgcn_readfirstlane(max(__builtin_amdgcn_frexp_expf(bound), -100));
+      const int e_t = __builtin_amdgcn_readfirstlane(mag_exponent(bound));
       if (e_t > EO) {
         const float f = __builtin_amdgcn_ldexpf(1.0f, EO - e_t);
         if constexpr (roleA) {
@@ -849,7 +849,7 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
 #pragma unroll
       for (int r = 0; r < 16; ++r) tm = fmaxf(tm, fabsf(tc[r]));
       tm = wave_max(tm);
-      ET = max(ET, __builtin_amdgcn_readfirstlane(max(__builtin_amdgcn_frexp_expf(tm), -100)));
+      ET = max(ET, __builtin_amdgcn_readfirstlane(mag_exponent(tm)));
       const float sT = __builtin_amdgcn_ldexpf(1.0f, 14 - ET);
       if (lane == 0) L.et[hs] = ET;
 #pragma unroll

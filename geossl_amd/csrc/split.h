@@ -128,9 +128,15 @@ __device__ __forceinline__ Frag2 split8h(const float (&v)[8]) {
 __device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-// power-of-two scale that brings a magnitude m into [2^13, 2^14) (1 for m = 0), and the exponent it used
+// exponent e of a magnitude m = f * 2^e, f in [0.5, 1), floored at -100 (keeps 2^(14-e) finite).  frexp gives 0 for
+// m = 0; an all-zero tile must not look like a tile of magnitude one - a RUNNING exponent that starts from it would
+// push later operands of size 1e-8 into fp16's subnormals - so zero maps to the floor as well.
+__device__ __forceinline__ int mag_exponent(float m) {
+  return m > 0.0f ? max(__builtin_amdgcn_frexp_expf(m), -100) : -100;
+}
+// power-of-two scale that brings a magnitude m into [2^13, 2^14) (2^114 for m = 0), and the exponent it used
 __device__ __forceinline__ float pow2_scale_to_2p14(float m, int& e) {
-  e = max(__builtin_amdgcn_frexp_expf(m), -100);  // m = f * 2^e, f in [0.5, 1); 0 for m = 0; the clamp keeps 2^(14-e) finite
+  e = mag_exponent(m);
   return __builtin_amdgcn_ldexpf(1.0f, 14 - e);
 }
 

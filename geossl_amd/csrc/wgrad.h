@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
 #pragma unroll
       for (int q = 0; q < 8; ++q) mx = fmaxf(mx, fabsf(v[ks][q]));
     mx = wave_max(mx);
-    e_run = max(e_run, __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_expf(mx)));
+    e_run = max(e_run, __builtin_amdgcn_readfirstlane(mag_exponent(mx)));
     return __builtin_amdgcn_ldexpf(1.0f, 14 - e_run);
   };
   // operand requests run PF row tiles ahead of their use (register sets in rotation); the block barriers are LDS-only,

@@ -252,6 +252,7 @@ class SchNetGradNode(torch.autograd.Function):
         fctx, mask = ctx.fctx, ctx.mask
         dhout, pos, *params = ctx.saved_tensors
         need = ctx.needs_input_grad[2:]  # (dhout, pos, *params)
+        higher = torch.is_grad_enabled()  # read OUTSIDE the block below: a third-order graph only if the caller wants one
         with torch.enable_grad():
             dh = dhout.detach().requires_grad_(need[0])
             ps = [p.detach().requires_grad_(True) for p in params]
@@ -268,7 +269,7 @@ class SchNetGradNode(torch.autograd.Function):
             if s is None or not ins:
                 second = [None] * len(ins)
             else:
-                second = torch.autograd.grad(s, ins, allow_unused=True, create_graph=torch.is_grad_enabled())
+                second = torch.autograd.grad(s, ins, allow_unused=True, create_graph=higher)
         it = iter(second)
         out = [next(it) if n else None for n in need]
         return (None, None) + tuple(out)

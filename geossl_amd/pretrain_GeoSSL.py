@@ -103,7 +103,7 @@ def do_DDM(args, batch, model, criterion=None, mu=0.0, sigma=0.3, num_neg=1, NCS
         loss = _autograd_step(model, n1, n2).run(args, batch, mu, sigma, noise, device_noise)
         if loss is not None:
             return loss, 0
-    return _do_ddm_eager(args, batch, model, mu, sigma, (n1, n2), noise, fuse_views, device_noise)
+    return _do_ddm_eager(args, batch, model, mu, sigma, (n1, n2), noise, fuse_views, device_noise), 0
 
 
 def _do_ddm_eager(args, batch, model, mu, sigma, heads, noise, fuse_views, device_noise):
@@ -152,8 +152,7 @@ def _do_ddm_eager(args, batch, model, mu, sigma, heads, noise, fuse_views, devic
                  distance_noise=noise.get("dist_noise_1"), out_scale=0.5)
     loss_02 = n2(batch, molecule_3D_repr_02, distance_01, noise_level=noise.get("noise_level_2"),
                  distance_noise=noise.get("dist_noise_2"), out_scale=0.5)
-    loss = loss_01 + loss_02
-    return loss, 0
+    return loss_01 + loss_02
 
 
 class Batch:
