@@ -436,6 +436,15 @@ class _AutogradStep:
     def _fwd_bwd(self, batch, noise):
         args, mu, sigma = self._cfg
         held = [p.grad for p in self.params]
+        # tensor hooks of the caller (gradient clipping, logging, reducers) belong to ITS backward, which runs later on
+        # the node `run` returns; the passes in here are internal - and in direct mode the nodes hand autograd no
+        # gradients at all, so a hook would be called with None
+        hooks = []
+        for p in self.params:
+            h = getattr(p, "_backward_hooks", None)
+            if h:
+                hooks.append((h, list(h.items())))
+                h.clear()
         self.gflat.zero_()
         for p, v in zip(self.params, self.views):
             p.grad = v
@@ -449,6 +458,8 @@ class _AutogradStep:
         finally:
             for p, h in zip(self.params, held):
                 p.grad = h
+            for h, items in hooks:
+                h.update(items)
         return loss.detach()
 
     def run(self, args, batch, mu, sigma, noise, device_noise):
