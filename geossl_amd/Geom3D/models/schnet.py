@@ -148,18 +148,9 @@ class _SchNetCore(torch.autograd.Function):
         fw = _lib.FilterWeights()
         for l, lp in enumerate(layers):
             fw.w1[l], fw.b1[l], fw.w2[l], fw.b2[l] = ptr(lp[0]), ptr(lp[1]), ptr(lp[2]), ptr(lp[3])
-        # GEOSSL_FUSED (A/B switch): "fwd" = filter network + aggregation of a block as ONE launch in the forward pass
-        # (geossl_cfconv_fused; Wf still stored for the backward's aggregation), "full" = Wf never stored, the backward's
-        # aggregation rebuilds it from the saved t.  Not with a position gradient (filter_dpos reads Wf).
-        fused = cfg["fused"] if (cfg["chain"] and P > 0 and lay.max_n <= 34 and not ctx.needs_input_grad[1]) else ""
-        images = ops.cfconv_fused_prepare(fw, L, F, G, cfg["offset"], dev) if fused else None
-        if images is None:
-            fused = ""
+        Wf = torch.empty(L, P, F, dtype=torch.float32, device=dev)
         T = torch.empty(L, P, F, dtype=torch.float32, device=dev) if training else None
-        Wf = None
-        if not fused or (fused == "fwd" and training):
-            Wf = torch.empty(L, P, F, dtype=torch.float32, device=dev)
-        if P > 0 and not fused:
+        if P > 0:
             call("geossl_cfconv_filter_fwd", ptr(pair_d), ptr(pair_c), P, C.byref(fw), L, F, G, ptr(cfg["offset"]),
                  cfg["coeff"], ptr(T), ptr(Wf), st)
         hs, xs, aggs, ts = [], [], [], []
@@ -180,11 +171,7 @@ class _SchNetCore(torch.autograd.Function):
                 rows = lambda t_: t_[a0:a1]
                 ops.linear_chain(rows(hs[0]), [dict(image=i_lin1[0], out=rows(xs[0]))])              # conv.lin1   :189
                 for l, lp in enumerate(layers):
-                    if fused:   # mlp + propagate in one launch   :187,190
-                        ops.cfconv_fused(xs[l], images[l], pair_d, pair_c, pair_flag, lay, cfg["coeff"], aggs[l],
-                                         T_l=T[l] if T is not None else None, Wf_l=Wf[l] if Wf is not None else None)
-                    else:
-                        ops.aggregate(xs[l], Wf[l], pair_flag, lay, out=aggs[l], mols=mols)   # propagate   :190
+                    ops.aggregate(xs[l], Wf[l], pair_flag, lay, out=aggs[l], mols=mols)   # propagate   :190
                     stages = [dict(image=i_lin2[l], bias=lp[6], flags=_lib.EPI_SSP, out=rows(ts[l])),  # conv.lin2 + act
                               dict(image=i_lin[l], bias=lp[8], res=rows(hs[l]), out=rows(hs[l + 1]))]  # lin + residual
                     if l + 1 < L:
@@ -223,7 +210,7 @@ class _SchNetCore(torch.autograd.Function):
             ctx.ps = ps
             ctx.params = params
             ctx.saved = dict(pair_d=pair_d, pair_c=pair_c, pair_flag=pair_flag, Wf=Wf, T=T, hs=hs, xs=xs, aggs=aggs,
-                             ts=ts, h_last=h, u=u, images=images)
+                             ts=ts, h_last=h, u=u)
         return hout
 
     @staticmethod
@@ -279,12 +266,8 @@ class _SchNetCore(torch.autograd.Function):
                 ops.linear_chain(rows(dhs[L]), [dict(image=i_lin[L - 1], tprev=rows(sv["ts"][L - 1]), out=rows(dys[L - 1])),
                                                 dict(image=i_lin2[L - 1], out=rows(daggs[L - 1]))])
                 for l in reversed(range(L)):
-                    if sv["Wf"] is None:  # the filter rows rebuilt from the saved t inside the aggregation
-                        ops.cfconv_fused(daggs[l], sv["images"][l], sv["pair_d"], sv["pair_c"], sv["pair_flag"], lay,
-                                         cfg["coeff"], dxs[l], T_l=sv["T"][l], from_t=True, swap=True)
-                    else:
-                        ops.aggregate(daggs[l], sv["Wf"][l], sv["pair_flag"], lay, swap=True, out=dxs[l],
-                                      mols=mols)                                    # transposed graph
+                    ops.aggregate(daggs[l], sv["Wf"][l], sv["pair_flag"], lay, swap=True, out=dxs[l],
+                                  mols=mols)                                        # transposed graph
                     stages = [dict(image=i_lin1[l], res=rows(dhs[l + 1]), out=rows(dhs[l]))]      # conv.lin1 + residual
                     if l > 0:
                         stages += [dict(image=i_lin[l - 1], tprev=rows(sv["ts"][l - 1]), out=rows(dys[l - 1])),
@@ -474,8 +457,7 @@ class SchNet(torch.nn.Module):
         cfg = dict(L=self.num_interactions, F=self.hidden_channels, G=self.num_gaussians, cutoff=float(self.cutoff),
                    offset=self.distance_expansion.offset, coeff=float(self.distance_expansion.coeff),
                    debug=bool(os.environ.get("GEOSSL_DEBUG")), status=status,
-                   chain=self.num_interactions >= 1 and not os.environ.get("GEOSSL_NO_CHAIN"),
-                   fused=os.environ.get("GEOSSL_FUSED", ""))
+                   chain=self.num_interactions >= 1 and not os.environ.get("GEOSSL_NO_CHAIN"))
         if pos.dtype != torch.float32:
             raise TypeError("positions must be float32")
         h = _SchNetCore.apply(z, pos.contiguous(), lay, cfg, *_core_params(self))

@@ -88,9 +88,6 @@ PROTOTYPES = {
     "geossl_cfconv_aggregate": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]),
     "geossl_aggregate_parts": (i32, [i32]),
     "geossl_cfconv_aggregate_work": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]),
-    "geossl_cfconv_fused_image_bytes": (i64, [i32, i32, i32]),
-    "geossl_cfconv_fused_prepare": (i32, [P(FilterWeights), i32, i32, i32, vp, vp, vp]),
-    "geossl_cfconv_fused": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, f32, vp, vp, vp, i32, vp, i32, vp]),
     "geossl_pair_product": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]),
     "geossl_linear": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]),
     "geossl_tn_plan": (None, [i64, i32, P(i32), P(i32)]),

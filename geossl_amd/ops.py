@@ -233,27 +233,6 @@ def aggregate(x, Wf_l, pair_flag, layout, swap=False, out=None, mols=None):
     return out
 
 
-def cfconv_fused_prepare(fw, L, F, G, offset, device):
-    """Operand images of the filter networks of all L blocks for `cfconv_fused` (one launch); None when the shape has
-    no fused path (F != 128, G > 64)."""
-    nb = int(_lib.load().geossl_cfconv_fused_image_bytes(L, F, G))
-    if nb == 0:
-        return None
-    images = torch.empty(L, nb // L, dtype=torch.uint8, device=device)
-    call("geossl_cfconv_fused_prepare", C.byref(fw), L, F, G, ptr(offset), ptr(images), stream())
-    return images
-
-
-def cfconv_fused(x, image_l, pair_d, pair_c, pair_flag, layout, coeff, out, T_l=None, from_t=False, Wf_l=None, swap=False):
-    """CFConv of one block in one launch (geossl_cfconv_fused): out[i] = sum_j x[j] * Wf_l(d_ij), the filter rows built
-    on the fly from the distances (T_l, Wf_l: optional outputs) or, from_t, from the saved hidden activation T_l."""
-    N, F = x.shape
-    call("geossl_cfconv_fused", ptr(pair_d), ptr(pair_c), ptr(pair_flag), ptr(layout.pair_i), ptr(layout.pair_j),
-         ptr(layout.mol_ptr), ptr(layout.pair_ptr), ptr(layout.order), layout.B, layout.max_n, F, ptr(image_l),
-         float(coeff), ptr(x), ptr(out), ptr(T_l), 1 if from_t else 0, ptr(Wf_l), 1 if swap else 0, stream())
-    return out
-
-
 def pair_product(a, b, layout, pair_flag, swap=False):
     """d aggregate / d filter rows as a tensor [P, F]: f0 a[i] b[j] + f1 a[j] b[i] per pair slot."""
     N, F = a.shape

@@ -266,8 +266,11 @@ class StepGraphs:
     gradients in buffers that are the same for every call (the graph binds their addresses).  Least-recently-used
     graphs are dropped beyond ``max_graphs``."""
 
-    def __init__(self, fwd_bwd, model_3d, max_graphs=256):
-        self.fwd_bwd, self.model_3d, self.max_graphs = fwd_bwd, model_3d, max_graphs
+    def __init__(self, fwd_bwd, model_3d, max_graphs=256, split=None):
+        # split = (fwd(batch, noise) -> loss with its autograd graph, bwd(loss)): forward and backward captured as TWO
+        # graphs (same pool, same capture stream; replayed in this order) - the forward's loss is then on the device
+        # before the backward runs, and the backward can run on a side stream while the host goes on (_AutogradStep)
+        self.fwd_bwd, self.model_3d, self.max_graphs, self.split = fwd_bwd, model_3d, max_graphs, split
         self.graphs, self.pool = OrderedDict(), None
         self.enabled = True
         self.captures = 0
@@ -321,19 +324,31 @@ class StepGraphs:
         # nothing may be pending on the device when the capture starts (in a multi-rank job the collective's
         # watchdog thread polls events of earlier all-reduces), and calls of other threads must not invalidate it
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
+        graph, graph_bwd = torch.cuda.CUDAGraph(), None
         try:
-            with torch.cuda.graph(graph, pool=self.pool, capture_error_mode="thread_local"):
-                loss = self.fwd_bwd(sb, sn)
+            if self.split is None:
+                with torch.cuda.graph(graph, pool=self.pool, capture_error_mode="thread_local"):
+                    loss = self.fwd_bwd(sb, sn)
+                if self.pool is None:
+                    self.pool = graph.pool()
+            else:
+                cap = torch.cuda.Stream()  # both captures on ONE stream: autograd runs a node's backward where its forward ran
+                with torch.cuda.graph(graph, pool=self.pool, stream=cap, capture_error_mode="thread_local"):
+                    live = self.split[0](sb, sn)
+                if self.pool is None:
+                    self.pool = graph.pool()
+                graph_bwd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_bwd, pool=self.pool, stream=cap, capture_error_mode="thread_local"):
+                    self.split[1](live)
+                loss = live.detach()
+                del live
         except Exception as e:  # capture is an optimisation: fall back to eager execution, loudly
             warnings.warn("HIP-graph capture of the DDM step failed (%s: %s); running eagerly" % (type(e).__name__, e))
             torch.cuda.synchronize()
             self.enabled = False
             return None
-        if self.pool is None:
-            self.pool = graph.pool()
         self.captures += 1
-        g = self.graphs[fp] = dict(graph=graph, batch=sb, noise=sn, loss=loss)
+        g = self.graphs[fp] = dict(graph=graph, graph_bwd=graph_bwd, batch=sb, noise=sn, loss=loss)
         return g
 
     @staticmethod
@@ -380,21 +395,22 @@ def draw_step_noise(batch, n1, n2, mu, sigma, device_noise, given=None, into=Non
 
 
 class _ReplayedLoss(torch.autograd.Function):
-    """The loss of a replayed step as a differentiable function of the parameters: forward returns the loss the graph
-    computed, backward hands autograd the gradients the same replay left in the static buffer (a snapshot taken at
-    forward time, so that two steps may be in flight before the first backward), scaled by the upstream gradient."""
+    """The loss of a replayed step as a differentiable function of the parameters: forward returns the loss the forward
+    graph computed, backward waits for the backward graph (replayed on the engine's side stream right behind the forward)
+    and hands autograd its gradients, scaled by the upstream gradient - one launch; every parameter's gradient is a view
+    of the product."""
 
     @staticmethod
-    def forward(ctx, loss, gflat, shapes, *params):
-        ctx.gflat, ctx.shapes = gflat, shapes
+    def forward(ctx, loss, engine, ticket, *params):
+        ctx.engine, ctx.ticket = engine, ticket
         return loss.view_as(loss)
 
     @staticmethod
     def backward(ctx, gout):
-        g = ctx.gflat * gout  # one launch; every parameter's gradient is a view of it
+        g = ctx.engine.collect(ctx.ticket) * gout
         outs, off = [], 0
-        for shape, numel, wanted in ctx.shapes:
-            outs.append(g[off:off + numel].view(shape) if wanted else None)
+        for shape, numel in ctx.engine.shapes:
+            outs.append(g[off:off + numel].view(shape))
             off += numel
         return (None, None, None) + tuple(outs)
 
@@ -402,10 +418,14 @@ class _ReplayedLoss(torch.autograd.Function):
 class _AutogradStep:
     """do_DDM's graph path for a caller that owns its optimizer (the reference loop, pretrain_GeoSSL.py:249-260).
 
-    Forward AND backward of the step are captured as one graph per index structure; the backward's gradients land in a
-    flat static buffer (the parameters' .grad point into it only while the step is captured or run).  ``run`` draws the
-    step's noise like the eager path (same generators, same order), refreshes the graph's inputs, replays, and returns
-    ``_ReplayedLoss``: ``loss.backward()`` then costs one multiply, and AccumulateGrad adopts the views."""
+    Forward and backward of the step are captured as TWO graphs per index structure (one memory pool, one capture
+    stream).  ``run`` draws the step's noise like the eager path (same generators, same order), refreshes the graph
+    inputs, replays the forward on the caller's stream and the backward on a side stream right behind it, and returns
+    the loss behind ``_ReplayedLoss``.  The reference's ``loss.detach().item()`` (:255) therefore waits for the forward
+    only; ``optimizer.zero_grad()``, ``loss.backward()`` (one wait + one multiply; AccumulateGrad adopts the views) and
+    the launches of ``optimizer.step()`` are issued by the host WHILE the backward graph runs.  The backward's gradients
+    land in a flat static buffer (the parameters' .grad point into it only while a step is captured); a step whose
+    backward() has not been called when the next step arrives keeps a snapshot of them."""
 
     def __init__(self, model, n1, n2):
         from .NCSN import _head_params
@@ -424,17 +444,24 @@ class _AutogradStep:
         for p in self.params:
             self.views.append(self.gflat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        self.shapes = tuple((tuple(p.shape), p.numel(), True) for p in self.params)
+        self.shapes = tuple((tuple(p.shape), p.numel()) for p in self.params)
         self.signature = self._signature()
         self.graphs = {}   # (model_3d, normalize) -> StepGraphs
         self._cfg = None
+        self._side = torch.cuda.Stream(device=dev)   # the backward graphs replay here
+        self._bwd_done = None                        # event behind the last backward replay
+        self._ticket = None                          # the step whose gradients are in gflat: {"serial", "event", "g"}
+        self._serial = 0
 
     def _signature(self):
         return tuple((id(p), p.data_ptr(), p.requires_grad) for m in (self.model, self.n1, self.n2)
                      for p in m.parameters())
 
-    def _fwd_bwd(self, batch, noise):
+    def _fwd(self, batch, noise):
         args, mu, sigma = self._cfg
+        return _do_ddm_eager(args, batch, self.model, mu, sigma, (self.n1, self.n2), noise, True, True)
+
+    def _bwd(self, loss):
         held = [p.grad for p in self.params]
         # tensor hooks of the caller (gradient clipping, logging, reducers) belong to ITS backward, which runs later on
         # the node `run` returns; the passes in here are internal - and in direct mode the nodes hand autograd no
@@ -449,7 +476,6 @@ class _AutogradStep:
         for p, v in zip(self.params, self.views):
             p.grad = v
         try:
-            loss = _do_ddm_eager(args, batch, self.model, mu, sigma, (self.n1, self.n2), noise, True, True)
             with _lib.direct_grads():  # kernels accumulate straight into the static buffer
                 loss.backward()
             for p, v in zip(self.params, self.views):  # anything autograd replaced goes back into the buffer
@@ -460,7 +486,23 @@ class _AutogradStep:
                 p.grad = h
             for h, items in hooks:
                 h.update(items)
+
+    def _fwd_bwd(self, batch, noise):
+        loss = self._fwd(batch, noise)
+        self._bwd(loss)
         return loss.detach()
+
+    def collect(self, ticket):
+        """The gradients of the step `ticket` stands for (unscaled, read-only): the snapshot taken when a later step was
+        about to overwrite them, else the static buffer itself once its backward replay is complete."""
+        if ticket["g"] is not None:
+            return ticket["g"]
+        if ticket["serial"] != self._serial:
+            raise RuntimeError("the gradients of this do_DDM step are gone (a later step replaced them after this step's "
+                               "backward had already run once); call backward(retain_graph=...) before the next do_DDM")
+        torch.cuda.current_stream().wait_event(ticket["event"])
+        ticket["used"] = True
+        return self.gflat
 
     def run(self, args, batch, mu, sigma, noise, device_noise):
         if not batch.positions.is_cuda or batch.positions.requires_grad:
@@ -468,7 +510,7 @@ class _AutogradStep:
         key = (args.model_3d, bool(getattr(args, "normalize", False)))
         sg = self.graphs.get(key)
         if sg is None:
-            sg = self.graphs[key] = StepGraphs(self._fwd_bwd, args.model_3d)
+            sg = self.graphs[key] = StepGraphs(self._fwd_bwd, args.model_3d, split=(self._fwd, self._bwd))
         if not sg.enabled:
             return None
         self._cfg = (Args(args.model_3d, key[1]), mu, sigma)
@@ -478,6 +520,13 @@ class _AutogradStep:
             # molecules in shuffled order, sampled tuples, PaiNN edge lists collated anew every epoch) then never pays
             # for a capture; a structure that comes back is captured on its second step.
             return None
+        main = torch.cuda.current_stream()
+        if self._bwd_done is not None:
+            # the last backward replay reads the activations and writes the gradient buffer this step is about to reuse
+            main.wait_event(self._bwd_done)
+            t = self._ticket
+            if t is not None and t["g"] is None and not t.get("used"):
+                t["g"] = self.gflat.clone()  # a step still waiting for its backward() keeps its gradients
         if g is None:
             drawn = draw_step_noise(batch, self.n1, self.n2, mu, sigma, device_noise, noise)
             g = sg.capture(batch, drawn)
@@ -487,8 +536,18 @@ class _AutogradStep:
         else:
             sg.refresh(g, batch)
             draw_step_noise(batch, self.n1, self.n2, mu, sigma, device_noise, noise, into=g["noise"])
-        g["graph"].replay()
-        return _ReplayedLoss.apply(g["loss"].clone(), self.gflat.clone(), self.shapes, *self.params)
+        g["graph"].replay()            # forward: the loss is on the device when this is done
+        loss = g["loss"].clone()
+        fwd_done = torch.cuda.Event()
+        fwd_done.record(main)
+        self._side.wait_event(fwd_done)
+        with torch.cuda.stream(self._side):  # backward: behind the forward, beside whatever the host queues next
+            g["graph_bwd"].replay()
+            self._bwd_done = torch.cuda.Event()
+            self._bwd_done.record(self._side)
+        self._serial += 1
+        self._ticket = {"serial": self._serial, "event": self._bwd_done, "g": None}
+        return _ReplayedLoss.apply(loss, self, self._ticket, *self.params)
 
 
 def _schnet_step_params(model):

@@ -154,26 +154,6 @@ int geossl_cfconv_aggregate_work(const float* x, const float* Wf, const uint8_t*
                                  const int32_t* pair_ptr, const int32_t* work, int64_t nwork, int max_n, int F,
                                  int swap, float* out, hipStream_t stream);
 
-/* ---- CFConv of ONE interaction block in one launch: filter network + aggregation, the filter rows never stored
- * (CFConv.forward, schnet.py:185-195 with InteractionBlock.mlp :141-145 and GaussianSmearing :205-207):
- *     out[i] = sum_{j in N(i)} x[j] * Wf_l(d_ij)         (swap = 1: the transposed graph, i.e. the backward's dx)
- * replaces geossl_cfconv_filter_fwd (one layer of it) + geossl_cfconv_aggregate.  F = 128, G <= 64, molecules of at
- * most 34 atoms.  Operand images of all layers come from ONE geossl_cfconv_fused_prepare launch per pass
- * (geossl_cfconv_fused_image_bytes(L, F, G) bytes; layer l starts at l * bytes / L; 0 = shape not supported).
- *   T     : from_t = 0: the hidden activation t_l [P][F] is WRITTEN there when not null (saved for the backward);
- *           from_t = 1: it is READ and the first GEMM skipped (backward: the filter rebuilt from the saved t)
- *   Wf    : when not null (from_t = 0 only) the filter rows are also stored, as geossl_cfconv_filter_fwd would
- *   order : molecules in the sequence they are dealt to the teams (largest first), or null
- * Products are the reference's (fl(fl(w C) x)); a target's sum is formed in a fixed order that is NOT the order of a
- * sequential index_add (bit-reproducible; within 1e-6 of geossl_cfconv_aggregate).                                 */
-int64_t geossl_cfconv_fused_image_bytes(int L, int F, int G);
-int geossl_cfconv_fused_prepare(const GeosslFilterWeights* w, int L, int F, int G, const float* offset, void* images,
-                                hipStream_t stream);
-int geossl_cfconv_fused(const float* pair_d, const float* pair_c, const uint8_t* pair_flag, const int32_t* pair_i,
-                        const int32_t* pair_j, const int32_t* mol_ptr, const int32_t* pair_ptr, const int32_t* order,
-                        int64_t B, int max_n, int F, const void* image, float coeff, const float* x, float* out,
-                        float* T, int from_t, float* Wf, int swap, hipStream_t stream);
-
 /* Gradient of geossl_cfconv_aggregate with respect to the filter rows, as a tensor:
  * out[p][c] = f0 a[i][c] b[j][c] + f1 a[j][c] b[i][c] for pair slot p = (i < j) with edge flags f0 (j -> i), f1 (i -> j)
  * (exchanged when swap = 1).  The first-order path never materialises it (geossl_cfconv_filter_bwd); the second-order

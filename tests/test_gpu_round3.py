@@ -209,105 +209,3 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert abs(out["value"] - 2 * 256 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
     l0, l1 = (float(open(tmp_path / ("loss_rank%d.txt" % r)).read()) for r in range(2))
     assert np.isfinite(l0) and np.isfinite(l1) and l0 != l1      # each rank has its own molecules and noise stream
-
-
-# ------------------------------------------------------------------------------ fused filter network + aggregation
-def _fused_case(sizes, seed, L=2, swap=False):
-    """Inputs of one interaction block on a synthetic batch + the unfused kernels' results."""
-    import ctypes as C
-    from geossl_amd import _lib, ops
-    from geossl_amd import pretrain_GeoSSL as pg
-    from geossl_amd.layout import MolLayout
-    from geossl_amd.synthetic import make_batch
-    b = make_batch(len(sizes), seed=seed, sizes=sizes)
-    bt = pg.Batch.from_numpy(b, DEV)
-    lay = MolLayout(bt.batch, len(sizes), sizes=list(sizes))
-    Fd, G = 128, 51
-    gen = torch.Generator(device=DEV)
-    gen.manual_seed(seed)
-    rnd = lambda *s, scale=1.0: (torch.randn(*s, device=DEV, generator=gen) * scale).contiguous()
-    ws = [(rnd(Fd, G, scale=0.3), rnd(Fd, scale=0.1), rnd(Fd, Fd, scale=0.15), rnd(Fd, scale=0.1)) for _ in range(L)]
-    fw = _lib.FilterWeights()
-    for l, (w1, b1, w2, b2) in enumerate(ws):
-        fw.w1[l], fw.b1[l], fw.w2[l], fw.b2[l] = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
-    offset = torch.linspace(0.0, 5.0, G, device=DEV)
-    coeff = -0.5 / float(offset[1] - offset[0]) ** 2
-    pair_d, pair_c, pair_flag = ops.pair_geometry(bt.positions, lay, 5.0)
-    P, N = lay.P, bt.positions.size(0)
-    T = torch.empty(L, P, Fd, device=DEV)
-    Wf = torch.empty(L, P, Fd, device=DEV)
-    _lib.call("geossl_cfconv_filter_fwd", pair_d.data_ptr(), pair_c.data_ptr(), P, C.byref(fw), L, Fd, G,
-              offset.data_ptr(), coeff, T.data_ptr(), Wf.data_ptr(), _lib.stream())
-    x = rnd(N, Fd)
-    ref = [ops.aggregate(x, Wf[l], pair_flag, lay, swap=swap) for l in range(L)]
-    images = ops.cfconv_fused_prepare(fw, L, Fd, G, offset, DEV)
-    keep = (ws, offset)
-    return dict(lay=lay, pair_d=pair_d, pair_c=pair_c, pair_flag=pair_flag, T=T, Wf=Wf, x=x, ref=ref, images=images,
-                coeff=coeff, L=L, N=N, P=P, keep=keep)
-
-
-def _scale_err(a, b):
-    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
-
-
-@pytest.mark.parametrize("sizes", [[18] * 40, [2, 33, 1, 7, 18, 34, 1, 12, 25, 3, 30, 9], [34, 34, 2, 2, 2, 1, 1, 20]],
-                         ids=["setA", "ragged", "extremes"])
-def test_cfconv_fused_matches_filter_fwd_plus_aggregate(sizes):
-    """geossl_cfconv_fused (filter network + aggregation of one block in one launch, the filter rows never stored)
-    against geossl_cfconv_filter_fwd + geossl_cfconv_aggregate on the same inputs: the saved hidden activation t bit for
-    bit (same products, same order), the aggregate and the optionally stored filter rows within 2e-6 of the tensor scale
-    (the second GEMM runs with swapped operands and one t scale per layer; a target's sum is formed in another order);
-    two launches agree bit for bit; the from_t form (backward: transposed graph, filter rebuilt from t) likewise."""
-    from geossl_amd import ops
-    c = _fused_case(sizes, seed=5)
-    lay, L, N, P = c["lay"], c["L"], c["N"], c["P"]
-    for l in range(L):
-        out = torch.full((N, 128), float("nan"), device=DEV)
-        T = torch.full((P, 128), float("nan"), device=DEV)
-        Wf = torch.full((P, 128), float("nan"), device=DEV)
-        ops.cfconv_fused(c["x"], c["images"][l], c["pair_d"], c["pair_c"], c["pair_flag"], lay, c["coeff"], out, T_l=T,
-                         Wf_l=Wf)
-        assert torch.isfinite(out).all() and torch.isfinite(T).all() and torch.isfinite(Wf).all()
-        assert torch.equal(T, c["T"][l])
-        assert _scale_err(Wf, c["Wf"][l]) < 2e-6
-        assert _scale_err(out, c["ref"][l]) < 2e-6, _scale_err(out, c["ref"][l])
-        out2 = torch.empty_like(out)
-        ops.cfconv_fused(c["x"], c["images"][l], c["pair_d"], c["pair_c"], c["pair_flag"], lay, c["coeff"], out2)  # no stores
-        assert torch.equal(out, out2)
-        dx_ref = ops.aggregate(c["x"], c["Wf"][l], c["pair_flag"], lay, swap=True)
-        dx = torch.full((N, 128), float("nan"), device=DEV)
-        ops.cfconv_fused(c["x"], c["images"][l], c["pair_d"], c["pair_c"], c["pair_flag"], lay, c["coeff"], dx,
-                         T_l=c["T"][l], from_t=True, swap=True)
-        assert _scale_err(dx, dx_ref) < 2e-6, _scale_err(dx, dx_ref)
-
-
-@pytest.mark.parametrize("mode", ["fwd", "full"])
-def test_schnet_ddm_step_with_fused_cfconv_matches_the_unfused_path(mode, monkeypatch):
-    """GEOSSL_FUSED: the whole DDM step (loss, every parameter gradient) with the fused CFConv in the forward pass
-    ("fwd") and also in the backward's transposed aggregation ("full") against the default kernels: loss 1e-6,
-    gradients 1e-5 relative."""
-    from geossl_amd import pretrain_GeoSSL as pg
-    from geossl_amd.synthetic import draw_noise, make_batch
-    b = make_batch(96, seed=21, mode="B")
-    batch = pg.Batch.from_numpy(b, DEV)
-    nz = {k: t(v, DEV) for k, v in draw_noise(b, seed=22).items()}
-    torch.manual_seed(5)
-    model = product_schnet(FULL, DEV)
-    heads = (product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9))
-    params = [p for m in (model,) + heads for p in m.parameters() if p.requires_grad]
-
-    def run():
-        for p in params:
-            p.grad = None
-        loss, _ = pg.do_DDM(pg.Args("schnet"), batch, model, NCSN_models=heads, noise=nz, graph=False)
-        loss.backward()
-        return float(loss), [None if p.grad is None else p.grad.clone() for p in params]
-
-    monkeypatch.delenv("GEOSSL_FUSED", raising=False)
-    l0, g0 = run()
-    monkeypatch.setenv("GEOSSL_FUSED", mode)
-    l1, g1 = run()
-    assert abs(l1 - l0) <= 1e-6 * abs(l0), (l0, l1)
-    for a, c in zip(g0, g1):
-        if a is not None:
-            assert float((a - c).norm() / a.norm().clamp_min(1e-30)) < 1e-5

@@ -225,6 +225,8 @@ __global__ __launch_bounds__(256, MAXN <= 18 ? 2 : 1) void k_cfconv_fused(FusedA
   for (int i = 0; i < (MAXN + 1) / 2; ++i) xr[i] = 0.0f;
   float d2 = 0.0f;           // distance of this lane's row of the tile in stage 2
   f32x4 tn[FROM_T ? 4 : 1];  // FROM_T: the saved t pieces of the tile in stage 2
+#pragma unroll
+  for (int q = 0; q < (FROM_T ? 4 : 1); ++q) tn[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   auto request_stage2 = [&]() {
     const int row = row_of(S2);
     if constexpr (FROM_T) {
@@ -236,7 +238,9 @@ __global__ __launch_bounds__(256, MAXN <= 18 ? 2 : 1) void k_cfconv_fused(FusedA
     }
   };
   request_stage2();
-  f32x4 t1[FROM_T ? 4 : 1];  // FROM_T: the pieces of the tile in stage 1
+  f32x4 t1[FROM_T ? 4 : 1];  // FROM_T: the pieces of the tile in stage 1 (zero while the pipeline fills: dummy tiles stay finite)
+#pragma unroll
+  for (int q = 0; q < (FROM_T ? 4 : 1); ++q) t1[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   int phase = 0;
   while (S0.valid | S1.valid | S2.valid) {
     const int pb = phase & 1;  // buffers written in this phase; the other pair was written in the last one
@@ -330,35 +334,86 @@ __global__ __launch_bounds__(256, MAXN <= 18 ? 2 : 1) void k_cfconv_fused(FusedA
 #pragma unroll
         for (int e = 0; e < 4; ++e) tv[4 * q + e] = t1[q][e];
     }
-    // ---- stage 0, part 2: messages of tile S0 onto the molecule's atom rows
+    // ---- stage 0, part 2: messages of tile S0 onto the molecule's atom rows.  Eight slots at a time: all table and x
+    // reads of the batch first, then the arithmetic, then the sixteen ds_add_f32 - LDS operations of a wave complete in
+    // order and the compiler keeps reads behind earlier atomics (they may alias), so a slot-by-slot loop pays two LDS
+    // round trips per slot.
     {
       const uint8_t* xs_l = reinterpret_cast<const uint8_t*>(xs) + 4 * j;
       uint8_t* acc_l = reinterpret_cast<uint8_t*>(acc) + kh * (MAXN * 128) + 4 * j;
       float* wrow = nullptr;
       if constexpr (STORE_WF) wrow = A.Wf + (size_t)(S0.base + 32 * S0.tile) * F + 32 * wave + j;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 c1 = *reinterpret_cast<const f32x4*>(tab + 8 * q + 4 * kh);
-        const f32x4 c2 = *reinterpret_cast<const f32x4*>(tab + 32 + 8 * q + 4 * kh);
-        const f32x4 cw = *reinterpret_cast<const f32x4*>(tab + 64 + 8 * q + 4 * kh);
-        const int4 io = *reinterpret_cast<const int4*>(tab + 96 + 8 * q + 4 * kh);
-        const int4 jo = *reinterpret_cast<const int4*>(tab + 128 + 8 * q + 4 * kh);
-        const int ioa[4] = {io.x, io.y, io.z, io.w}, joa[4] = {jo.x, jo.y, jo.z, jo.w};
+      for (int hb = 0; hb < 2; ++hb) {
+        int ioa[8], joa[8];
+        float c1a[8], c2a[8], cwa[8], xi[8], xj[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float wv = fmaf(acc2[4 * q + e], k2, b2f);  // (A2 t + b2)[row][feature]
-          const float xi = *reinterpret_cast<const float*>(xs_l + ioa[e]);
-          const float xj = *reinterpret_cast<const float*>(xs_l + joa[e]);
-          const float mi = mul_rn(mul_rn(wv, c1[e]), xj);    // x[j] * (Wf' * C), schnet.py:187,194
-          const float mj = mul_rn(mul_rn(wv, c2[e]), xi);
-          __hip_atomic_fetch_add(reinterpret_cast<float*>(acc_l + ioa[e]), mi, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(reinterpret_cast<float*>(acc_l + joa[e]), mj, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int qq = 0; qq < 2; ++qq) {
+          const int q = 2 * hb + qq;
+          const f32x4 c1 = *reinterpret_cast<const f32x4*>(tab + 8 * q + 4 * kh);
+          const f32x4 c2 = *reinterpret_cast<const f32x4*>(tab + 32 + 8 * q + 4 * kh);
+          const int4 io = *reinterpret_cast<const int4*>(tab + 96 + 8 * q + 4 * kh);
+          const int4 jo = *reinterpret_cast<const int4*>(tab + 128 + 8 * q + 4 * kh);
           if constexpr (STORE_WF) {
-            const int rl = 8 * q + 4 * kh + e;
-            if (S0.valid && 32 * S0.tile + rl < S0.np) wrow[(size_t)rl * F] = mul_rn(wv, cw[e]);
+            const f32x4 cw = *reinterpret_cast<const f32x4*>(tab + 64 + 8 * q + 4 * kh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cwa[4 * qq + e] = cw[e];
           }
+          const int iov[4] = {io.x, io.y, io.z, io.w}, jov[4] = {jo.x, jo.y, jo.z, jo.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            ioa[4 * qq + e] = iov[e];
+            joa[4 * qq + e] = jov[e];
+            c1a[4 * qq + e] = c1[e];
+            c2a[4 * qq + e] = c2[e];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          xi[u] = *reinterpret_cast<const float*>(xs_l + ioa[u]);
+          xj[u] = *reinterpret_cast<const float*>(xs_l + joa[u]);
+        }
+        float mi[8], mj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float wv = fmaf(acc2[8 * hb + u], k2, b2f);   // (A2 t + b2)[row][feature]
+          mi[u] = mul_rn(mul_rn(wv, c1a[u]), xj[u]);           // x[j] * (Wf' * C), schnet.py:187,194
+          mj[u] = mul_rn(mul_rn(wv, c2a[u]), xi[u]);
+          if constexpr (STORE_WF) {
+            const int rl = 8 * (2 * hb + (u >> 2)) + 4 * kh + (u & 3);
+            if (S0.valid && 32 * S0.tile + rl < S0.np) wrow[(size_t)rl * F] = mul_rn(wv, cwa[u]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#if !defined(FU_PROBE) || FU_PROBE == 0
+          __hip_atomic_fetch_add(reinterpret_cast<float*>(acc_l + ioa[u]), mi[u], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(reinterpret_cast<float*>(acc_l + joa[u]), mj[u], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+#elif FU_PROBE == 1  // timing probe: integer atomics (wrong sums)
+          __hip_atomic_fetch_add(reinterpret_cast<int*>(acc_l + ioa[u]), __float_as_int(mi[u]), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(reinterpret_cast<int*>(acc_l + joa[u]), __float_as_int(mj[u]), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+#elif FU_PROBE == 2  // timing probe: plain stores (wrong sums)
+          *reinterpret_cast<volatile float*>(acc_l + ioa[u]) = mi[u];
+          *reinterpret_cast<volatile float*>(acc_l + joa[u]) = mj[u];
+#elif FU_PROBE == 4  // fixed point: m * 2^sx = q_hi + q_lo 2^-24, two integer atomics (timing of the conversion; scale fixed)
+          {
+            const float ti = mi[u] * 1048576.0f, tj = mj[u] * 1048576.0f;
+            const float fi = floorf(ti), fj = floorf(tj);
+            __hip_atomic_fetch_add(reinterpret_cast<int*>(acc_l + ioa[u]), (int)fi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(reinterpret_cast<int*>(acc_l + joa[u]), (int)fj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(acc_l + MAXN * 128 * (1 - 2 * kh) + ioa[u]),
+                                   (unsigned)((ti - fi) * 16777216.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(acc_l + MAXN * 128 * (1 - 2 * kh) + joa[u]),
+                                   (unsigned)((tj - fj) * 16777216.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+#elif FU_PROBE == 3  // timing probe: no scatter at all
+          asm volatile("" ::"v"(mi[u]), "v"(mj[u]));
+#endif
         }
       }
     }
