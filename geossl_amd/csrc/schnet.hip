@@ -234,10 +234,25 @@ __device__ __forceinline__ void aggregate_reg_body(const float* __restrict__ x, 
     xr[i] = *reinterpret_cast<const V*>(x + (size_t)(a0 + min(i, n - 1)) * F + f);
     acc[i] = V(0.0f);
   }
-  auto slot_of = [&](int a, int b) { return b < n ? a * n - a * (a + 1) / 2 + b - a - 1 : 0; };
-  auto load_row = [&](int slot) {
-    const float* rowp = wbase + (size_t)__builtin_amdgcn_readfirstlane(slot) * F;  // uniform
+  // Filter row of position (a, b) of the request stream: slot = (first slot of row a) + b - a - 1, the row's first slot
+  // carried along in a scalar register and advanced when the stream moves to the next row.  The opaque statement keeps
+  // this arithmetic AT the request: left free, the compiler evaluated the closed form a*n - a(a+1)/2 + ... of all
+  // NMAX(NMAX-1)/2 positions ahead of the walk and spilled them (134 scalar spills at NMAX = 18, thousands in the kernel
+  // that holds every size class).
+  const int nu = __builtin_amdgcn_readfirstlane(n);
+  int rs_req = 0;
+  auto load_row = [&](int a, int b) {
+    asm volatile("" : "+s"(rs_req));
+    const int slot = b < nu ? rs_req + (b - a - 1) : 0;
+    const float* rowp = wbase + (size_t)slot * F;  // uniform
     return __builtin_nontemporal_load(reinterpret_cast<const V*>(rowp + f));
+  };
+  auto next_pos = [&](int& a, int& b) {  // advance the request stream by one position
+    if (++b == NMAX) {
+      rs_req += nu - a - 1;
+      ++a;
+      b = a + 1;
+    }
   };
   // Flags of every row atom, requested before anything else: lane b holds the flag byte of slot (a, b).  A flag load
   // inside the walk is the YOUNGEST request of the wave when its ballot needs it, and requests complete in order: it
@@ -249,18 +264,12 @@ __device__ __forceinline__ void aggregate_reg_body(const float* __restrict__ x, 
     const bool mine = lane > a && lane < n;  // (clamped address + select below: a predicated load would become a branch)
     flr[a] = pair_flag[base + (mine ? a * n - a * (a + 1) / 2 + lane - a - 1 : 0)];
   }
-  {  // prologue: the first RING positions
-    int ap = 0, bp = 1;
-#pragma unroll
-    for (int q = 0; q < RING && q < NPOS; ++q) {
-      ring[q] = load_row(slot_of(ap, bp));
-      if (++bp == NMAX) { ++ap; bp = ap + 1; }
-    }
-  }
   int q = 0, ap = 0, bp = 1;
 #pragma unroll
-  for (int k = 0; k < RING && k < NPOS; ++k)
-    if (++bp == NMAX) { ++ap; bp = ap + 1; }              // (ap, bp) = position q + RING
+  for (int k = 0; k < RING && k < NPOS; ++k) {  // prologue: the first RING positions; then (ap, bp) = position q + RING
+    ring[k] = load_row(ap, bp);
+    next_pos(ap, bp);
+  }
 #pragma unroll
   for (int a = 0; a < NMAX - 1; ++a) {
     // flags of row atom a as two ballot masks over the partner index b (the loaded value pinned: with control flow in
@@ -278,8 +287,8 @@ __device__ __forceinline__ void aggregate_reg_body(const float* __restrict__ x, 
     for (int b = a + 1; b < NMAX; ++b, ++q) {
       const V w = ring[q % RING];
       if (q + RING < NPOS) {
-        ring[q % RING] = load_row(slot_of(ap, bp));
-        if (++bp == NMAX) { ++ap; bp = ap + 1; }
+        ring[q % RING] = load_row(ap, bp);
+        next_pos(ap, bp);
       }
       const V t0 = xr[b] * w;
       const V s0 = acc_a + t0;
@@ -327,9 +336,13 @@ __device__ __forceinline__ void aggregate_reg_part(const float* __restrict__ x, 
   for (int i = 0; i < NMAX; ++i) xr[i] = *reinterpret_cast<const V*>(x + (size_t)(a0 + min(i, n - 1)) * F + f);
 #pragma unroll
   for (int i = 0; i < NG; ++i) acc[i] = V(0.0f);
-  auto slot_of = [&](int a, int b) { return b < n ? a * n - a * (a + 1) / 2 + b - a - 1 : 0; };
-  auto load_row = [&](int slot) {
-    const float* rowp = wbase + (size_t)__builtin_amdgcn_readfirstlane(slot) * F;  // uniform
+  // (request stream as in aggregate_reg_body: the first slot of the stream's row in a scalar register)
+  const int nu = __builtin_amdgcn_readfirstlane(n);
+  int rs_req = 0;
+  auto load_row = [&](int a, int b) {
+    asm volatile("" : "+s"(rs_req));
+    const int slot = b < nu ? rs_req + (b - a - 1) : 0;
+    const float* rowp = wbase + (size_t)slot * F;  // uniform
     return __builtin_nontemporal_load(reinterpret_cast<const V*>(rowp + f));
   };
   unsigned flr[AEND];  // flags of every row atom of this part, requested first (see aggregate_reg_body)
@@ -338,18 +351,19 @@ __device__ __forceinline__ void aggregate_reg_part(const float* __restrict__ x, 
     const bool mine = lane > a && lane < n;
     flr[a] = pair_flag[base + (mine ? a * n - a * (a + 1) / 2 + lane - a - 1 : 0)];
   }
-  {  // prologue: the first RING positions
-    int ap = 0, bp = AGG_BS(0);
-#pragma unroll
-    for (int q = 0; q < RING && q < NPOS; ++q) {
-      ring[q] = load_row(slot_of(ap, bp));
-      if (++bp == AGG_BE(ap)) { ++ap; bp = AGG_BS(ap); }
+  auto next_pos = [&](int& a, int& b) {
+    if (++b == AGG_BE(a)) {
+      rs_req += nu - a - 1;
+      ++a;
+      b = AGG_BS(a);
     }
-  }
+  };
   int q = 0, ap = 0, bp = AGG_BS(0);
 #pragma unroll
-  for (int k = 0; k < RING && k < NPOS; ++k)
-    if (++bp == AGG_BE(ap)) { ++ap; bp = AGG_BS(ap); }    // (ap, bp) = position q + RING
+  for (int k = 0; k < RING && k < NPOS; ++k) {  // prologue: the first RING positions; then (ap, bp) = position q + RING
+    ring[k] = load_row(ap, bp);
+    next_pos(ap, bp);
+  }
   // flags of row atom a as two ballot masks over the partner index b (as in aggregate_reg_body)
   auto row_flags = [&](int a, unsigned long long& m0, unsigned long long& m1) {
     const bool mine = lane > a && lane < n;
@@ -363,8 +377,8 @@ __device__ __forceinline__ void aggregate_reg_part(const float* __restrict__ x, 
   auto next_row = [&]() {  // filter row of position q, and the request for position q + RING
     const V w = ring[q % RING];
     if (q + RING < NPOS) {
-      ring[q % RING] = load_row(slot_of(ap, bp));
-      if (++bp == AGG_BE(ap)) { ++ap; bp = AGG_BS(ap); }
+      ring[q % RING] = load_row(ap, bp);
+      next_pos(ap, bp);
     }
     ++q;
     return w;

@@ -361,6 +361,28 @@ class StepGraphs:
                 g["noise"][k].copy_(noise[k])
 
 
+_PINNED = {}  # (shape) -> ring of two pinned staging tensors with the event behind their last copy
+
+
+def _host_normal_into(dst, mu, sigma):
+    """torch.normal(mu, sigma, size) on the HOST generator (the reference's draw, pretrain_GeoSSL.py:72: same stream, same
+    values) into the device tensor `dst` without stalling the host: the draw is made straight into pinned memory and
+    copied asynchronously (a pageable source makes the copy wait for everything queued on the stream before it - in the
+    reference loop that is the whole previous backward)."""
+    key = tuple(dst.shape)
+    ring = _PINNED.get(key)
+    if ring is None:
+        ring = _PINNED[key] = {"i": 0, "slots": [[torch.empty(key, dtype=torch.float32).pin_memory(), None] for _ in range(2)]}
+    slot = ring["slots"][ring["i"]]
+    ring["i"] ^= 1
+    if slot[1] is not None:
+        slot[1].synchronize()  # the copy that last read this staging tensor (two steps ago)
+    torch.normal(mu, sigma, size=key, out=slot[0])
+    dst.copy_(slot[0], non_blocking=True)
+    slot[1] = torch.cuda.Event()
+    slot[1].record()
+
+
 def draw_step_noise(batch, n1, n2, mu, sigma, device_noise, given=None, into=None):
     """The five random draws of a step in the order the eager path makes them: perturb (pretrain_GeoSSL.py:72: a
     host draw copied to the device, or a device draw with device_noise), then per head the noise level (NCSN.py:190)
@@ -386,7 +408,7 @@ def draw_step_noise(batch, n1, n2, mu, sigma, device_noise, given=None, into=Non
         put("pos_noise", lambda: torch.empty_like(batch.positions).normal_(mu, sigma), lambda t_: t_.normal_(mu, sigma))
     else:  # the reference's own draw (:72): CPU generator, then the copy
         put("pos_noise", lambda: torch.normal(mu, sigma, size=batch.positions.size()).to(dev),
-            lambda t_: t_.copy_(torch.normal(mu, sigma, size=batch.positions.size())))
+            lambda t_: _host_normal_into(t_, mu, sigma))
     for k, head in (("1", n1), ("2", n2)):
         K = head.sigmas.size(0)
         put("noise_level_" + k, lambda: torch.randint(0, K, (B,), device=dev), lambda t_: t_.random_(0, K))
