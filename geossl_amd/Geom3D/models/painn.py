@@ -181,7 +181,8 @@ class PaiNN(nn.Module):
         cfg = dict(F=self.n_atom_basis, L=self.n_interactions, R=self.radial_basis.n_rbf, cutoff=float(self.cutoff),
                    offsets=self.radial_basis.offsets, widths=self.radial_basis.widths,
                    eps=float(self.mixing[0].epsilon), status=status, debug=bool(os.environ.get("GEOSSL_DEBUG")),
-                   lay=lay)
+                   lay=lay, mma=(self.n_atom_basis == 128 and self.radial_basis.n_rbf in (8, 16, 20)
+                                 and not os.environ.get("GEOSSL_PAINN_VECTOR")))
         q = _PaiNNCore.apply(atomic_numbers, positions.contiguous(), el, cfg, *self._params())
         status.arm()
         from .schnet import _SegmentReduce
@@ -259,9 +260,17 @@ class _PaiNNCore(torch.autograd.Function):
                     _split3(xc, F_))                                         # Dense(F, 3F)
             q2, mu2 = torch.empty_like(q), torch.empty_like(mu)
             lay = cfg["lay"]  # one block per molecule: the rows its edges read are staged in LDS once
-            call("geossl_painn_interaction_fwd_mol", ptr(q), ptr(mu), ptr(xc), ptr(el.idx_j), ptr(inc_ptr), ptr(inc_idx),
-                 ptr(phi), ptr(fcut), ptr(dirv), ptr(fw[l * 3 * F_:(l + 1) * 3 * F_]), ptr(fb[l * 3 * F_:(l + 1) * 3 * F_]),
-                 ptr(lay.mol_ptr), lay.B, lay.max_n, N, F_, R, ptr(q2), ptr(mu2), st)   # :54-64
+            if cfg["mma"] and lay.max_n <= 44 and E > 0:  # filter on the matrix pipe (painn_mma.hip); LDS: 3.5 KB per atom + 3 KB
+                row_edge, grp_atom, _, mol_grp = el.groups("i", lay.mol_ptr)
+                call("geossl_painn_interaction_fwd_mma", ptr(q), ptr(mu), ptr(xc), ptr(el.idx_j), ptr(row_edge),
+                     ptr(grp_atom), ptr(mol_grp), ptr(phi), ptr(fcut), ptr(dirv), ptr(fw[l * 3 * F_:(l + 1) * 3 * F_]),
+                     ptr(fb[l * 3 * F_:(l + 1) * 3 * F_]), ptr(lay.mol_ptr), lay.B, lay.max_n, N, F_, R, ptr(q2), ptr(mu2),
+                     st)                                                        # :54-64
+            else:
+                call("geossl_painn_interaction_fwd_mol", ptr(q), ptr(mu), ptr(xc), ptr(el.idx_j), ptr(inc_ptr),
+                     ptr(inc_idx), ptr(phi), ptr(fcut), ptr(dirv), ptr(fw[l * 3 * F_:(l + 1) * 3 * F_]),
+                     ptr(fb[l * 3 * F_:(l + 1) * 3 * F_]), ptr(lay.mol_ptr), lay.B, lay.max_n, N, F_, R, ptr(q2), ptr(mu2),
+                     st)                                                        # :54-64
             i0w, i0b, i1w, i1b, mw = mix[l]
             mm = torch.empty(3 * N, 2 * F_, **f32)                           # mu_channel_mix        :100
             lin_fan(mu2.view(3 * N, F_), [k0 + 4, k0 + 5], [None, None], [mm[:, :F_], mm[:, F_:]])

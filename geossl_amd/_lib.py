@@ -131,6 +131,8 @@ PROTOTYPES = {
     "geossl_painn_interaction_bwd_workspace_floats": (i64, [i64, i32, i32]),
     "geossl_painn_interaction_fwd_mol": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i64, i32, i32, vp,
                                                vp, vp]),
+    "geossl_painn_interaction_fwd_mma": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i64, i32, i32,
+                                               vp, vp, vp]),
     "geossl_painn_interaction_bwd_mol_workspace_floats": (i64, [i64, i64, i32, i32]),
     "geossl_painn_interaction_bwd_mol": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i64, i32, i32,
                                                vp, vp, vp, vp, vp, i32, vp]),

@@ -186,6 +186,46 @@ class EdgeLayout:
             raise ValueError("radius_edge_index must be grouped by molecule in batch order with both ends in the "
                              "same molecule (collated MoleculeDataset3DRadius output is)")
         self._versions = (batch._version, edge_index._version)
+        self._groups = {}
+
+    def groups(self, side, mol_ptr=None):
+        """Row layout of the matrix-pipe interaction kernels (painn_mma.hip) for the incidence list `side` ("i":
+        edges by target, forward; "j": edges by source, backward): the edges of an atom in incidence order, padded to a
+        multiple of four rows ("groups" - the rows of a group share their atom; an atom without edges has one group of
+        padding).  -> (row_edge int32 [4 G'], -1 =
+        padding; grp_atom int32 [G'] = 2 * atom + (last group of its atom), -1 = unused; grp_ptr int64 [N + 1] first group of
+        an atom).  G' = E/4 + N + 1 bounds the
+        number of groups, so nothing is read back from the device."""
+        got = self._groups.get(side)
+        if got is None:
+            iptr, idx = self.inc[side]
+            dev, N, E = iptr.device, self.N, self.E
+            deg = iptr[1:] - iptr[:-1]
+            grp_ptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+            # (an atom without edges gets one group of padding rows: it takes the same path as every other atom)
+            torch.cumsum(torch.clamp((deg + 3) // 4, min=1), 0, out=grp_ptr[1:])
+            cap = E // 4 + N + 1
+            row_edge = torch.full((4 * cap,), -1, dtype=torch.int32, device=dev)
+            grp_atom = torch.full((cap,), -1, dtype=torch.int32, device=dev)
+            if E > 0:
+                owner = torch.repeat_interleave(torch.arange(N, dtype=torch.int64, device=dev), deg, output_size=E)
+                pos = 4 * grp_ptr[owner] + (torch.arange(E, dtype=torch.int64, device=dev) - iptr[owner])
+                row_edge[pos] = idx[:E]
+                # group code: atom * 2 + (the group is the last one of its atom)
+                grp = pos // 4
+                grp_atom[grp] = (2 * owner + (grp + 1 == grp_ptr[owner + 1]).to(torch.int64)).to(torch.int32)
+            # the first group of EVERY atom (so that atoms without edges have their code too, without a data-dependent
+            # index list, which would be a read-back): last group of its atom iff the atom has one group
+            ng = grp_ptr[1:] - grp_ptr[:-1]
+            grp_atom[grp_ptr[:-1]] = (2 * torch.arange(N, dtype=torch.int64, device=dev) + (ng == 1).to(torch.int64)).to(torch.int32)
+            got = self._groups[side] = (row_edge, grp_atom, grp_ptr)
+        if mol_ptr is None:
+            return got
+        # first group of every molecule (int32 [B + 1]), for the kernels' walk over molecules
+        mg = self._groups.get((side, "mol"))
+        if mg is None or mg[0] is not mol_ptr:
+            mg = self._groups[(side, "mol")] = (mol_ptr, got[2][mol_ptr.long()].to(torch.int32))
+        return got + (mg[1],)
 
 
 def get_edge_layout(batch, edge_index, num_graphs):

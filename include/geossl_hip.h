@@ -349,6 +349,17 @@ int geossl_painn_interaction_bwd(const float* dq_out, const float* dmu_out, cons
                                  const float* fcut, const float* dir, const float* Wf, const float* bf, int64_t N, int F,
                                  int R, float* dxc, float* dmu_in, float* dWf, float* dbf, float* workspace,
                                  int accumulate, hipStream_t stream);
+/* The forward pass with the filter on the matrix pipe (F = 128, n_rbf in {8, 16, 20}): W = phi' Wf'^T as one small GEMM
+ * per tile of 32 edge rows (bias and cutoff inside the contraction), the message arithmetic on the vector unit, a team
+ * of four waves per molecule.  Rows are laid out in groups of four that share their target atom (the edges of an atom
+ * in incidence order, padded to a multiple of four): row_edge [4 G] int32 (-1 = padding), grp_atom [G] int32 =
+ * 2 * atom + (the group is the last one of its atom), mol_grp [B + 1] int32 = first group of a molecule; an atom
+ * without edges has one group of padding rows.  Same sums as geossl_painn_interaction_fwd in another (fixed) order. */
+int geossl_painn_interaction_fwd_mma(const float* q, const float* mu, const float* xc, const int64_t* idx_j,
+                                     const int32_t* row_edge, const int32_t* grp_atom, const int32_t* mol_grp,
+                                     const float* phi, const float* fcut, const float* dir, const float* Wf,
+                                     const float* bf, const int32_t* mol_ptr, int64_t B, int max_n, int64_t N, int F, int R,
+                                     float* q_out, float* mu_out, hipStream_t stream);
 /* The same two passes with the molecule layout (mol_ptr [B+1] int32, max_n atoms in the largest molecule): one block
  * per molecule, the rows every edge of the molecule reads staged in LDS once (results identical bit for bit; falls back
  * to the per-atom kernels when F is not 64 / 128 or a molecule's rows do not fit the LDS).                      */

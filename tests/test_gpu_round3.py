@@ -209,3 +209,61 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert abs(out["value"] - 2 * 256 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
     l0, l1 = (float(open(tmp_path / ("loss_rank%d.txt" % r)).read()) for r in range(2))
     assert np.isfinite(l0) and np.isfinite(l1) and l0 != l1      # each rank has its own molecules and noise stream
+
+
+# --------------------------------------------------------------------------- PaiNN interaction on the matrix pipe
+def _painn_edge_case(sizes, seed, R=20):
+    from geossl_amd import _lib, ops
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.layout import MolLayout, get_edge_layout
+    from geossl_amd.synthetic import make_batch
+    b = make_batch(len(sizes), seed=seed, sizes=sizes)
+    bt = pg.Batch.from_numpy(b, DEV)
+    lay = MolLayout(bt.batch, len(sizes), sizes=list(sizes))
+    rei = ops.radius_graph(bt.positions, 5.0, bt.batch)
+    el = get_edge_layout(bt.batch, rei, lay.B)
+    E, N, Fd = el.E, bt.positions.size(0), 128
+    f32 = dict(dtype=torch.float32, device=DEV)
+    dirv, fcut, phi = torch.empty(max(E, 1), 3, **f32), torch.empty(max(E, 1), **f32), torch.empty(max(E, 1), R, **f32)
+    offsets = torch.linspace(0.0, 5.0, R, device=DEV)
+    widths = torch.abs(offsets[1] - offsets[0]) * torch.ones_like(offsets)
+    _lib.call("geossl_painn_edge_geom", bt.positions.data_ptr(), el.idx_i.data_ptr(), el.idx_j.data_ptr(), E, 5.0,
+              offsets.data_ptr(), widths.data_ptr(), R, dirv.data_ptr(), fcut.data_ptr(), phi.data_ptr(), _lib.stream())
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(seed)
+    rnd = lambda *s, scale=1.0: (torch.randn(*s, device=DEV, generator=gen) * scale).contiguous()
+    return dict(lay=lay, el=el, N=N, E=E, R=R, dirv=dirv, fcut=fcut, phi=phi, Wf=rnd(3 * Fd, R, scale=0.3),
+                bf=rnd(3 * Fd, scale=0.2), q=rnd(N, Fd), mu=rnd(N, 3, Fd), xc=rnd(N, 3 * Fd))
+
+
+@pytest.mark.parametrize("sizes", [[18] * 24, [2, 26, 1, 7, 18, 1, 12, 25, 3, 20, 9, 33], [1, 1, 2]], ids=["setA", "ragged", "tiny"])
+@pytest.mark.parametrize("R", [20, 8])
+def test_painn_interaction_forward_on_the_matrix_pipe_matches_the_vector_kernel(sizes, R):
+    """geossl_painn_interaction_fwd_mma (filter as a GEMM per tile of 32 edge rows, groups of four rows per target atom)
+    against geossl_painn_interaction_fwd_mol on the same inputs: q_out / mu_out within 2e-6 of the tensor scale (another
+    summation order, two-piece fp16 products), atoms without edges and single-atom molecules included; bit-reproducible."""
+    from geossl_amd import _lib
+    c = _painn_edge_case(sizes, seed=3, R=R)
+    lay, el, N, Fd = c["lay"], c["el"], c["N"], 128
+    st = _lib.stream()
+    inc_ptr, inc_idx = el.inc["i"]
+    q_ref, mu_ref = torch.empty_like(c["q"]), torch.empty_like(c["mu"])
+    _lib.call("geossl_painn_interaction_fwd_mol", c["q"].data_ptr(), c["mu"].data_ptr(), c["xc"].data_ptr(),
+              el.idx_j.data_ptr(), inc_ptr.data_ptr(), inc_idx.data_ptr(), c["phi"].data_ptr(), c["fcut"].data_ptr(),
+              c["dirv"].data_ptr(), c["Wf"].data_ptr(), c["bf"].data_ptr(), lay.mol_ptr.data_ptr(), lay.B, lay.max_n, N, Fd,
+              R, q_ref.data_ptr(), mu_ref.data_ptr(), st)
+    row_edge, grp_atom, grp_ptr, mol_grp = el.groups("i", lay.mol_ptr)
+    outs = []
+    for _ in range(2):
+        q_out = torch.full_like(c["q"], float("nan"))
+        mu_out = torch.full_like(c["mu"], float("nan"))
+        _lib.call("geossl_painn_interaction_fwd_mma", c["q"].data_ptr(), c["mu"].data_ptr(), c["xc"].data_ptr(),
+                  el.idx_j.data_ptr(), row_edge.data_ptr(), grp_atom.data_ptr(), mol_grp.data_ptr(), c["phi"].data_ptr(),
+                  c["fcut"].data_ptr(), c["dirv"].data_ptr(), c["Wf"].data_ptr(), c["bf"].data_ptr(), lay.mol_ptr.data_ptr(),
+                  lay.B, lay.max_n, N, Fd, R, q_out.data_ptr(), mu_out.data_ptr(), st)
+        outs.append((q_out, mu_out))
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    scale = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    assert scale(outs[0][0], q_ref) < 2e-6, scale(outs[0][0], q_ref)
+    assert scale(outs[0][1], mu_ref) < 2e-6, scale(outs[0][1], mu_ref)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
