@@ -99,6 +99,9 @@ struct EdgeRow {
   // stage 2: requests for the data of edge `ec` (clamped: always a valid edge)
   __device__ __forceinline__ void request(const PainnMmaArgs& A, int ec, int kh) {
     static_assert(R % 4 == 0 && R + 1 <= 32, "R: a multiple of 4, at most 28");
+#if defined(PM_PROBE) && PM_PROBE == 4  // timing probe: every row reads edge 0 (cache hits)
+    ec = 0;
+#endif
     const float* row = A.phi + (size_t)ec * R;
 #pragma unroll
     for (int h = 0; h < 3; ++h) {
@@ -317,9 +320,23 @@ __global__ __launch_bounds__(256, 2) void k_painn_fwd_mma(PainnMmaArgs A) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) acc[c] = mfma_f16(ah[ks], wh[c][ks], acc[c]);
     }
+#ifdef PM_DEBUG
+    if (A.pw != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (T0.gb + (c_row(r, lane) >> 2) < T0.g1)
+          A.pw[(size_t)(4 * T0.gb + c_row(r, lane)) * F + f] = acc[0][r] * tab[128 + c_row(r, lane)];
+    }
+#endif
     PM_MARK(4);
     // ---- messages, summed over the four rows of a group (the lane's groups are 2q + kh)
     float gs[4][4];
+#if defined(PM_PROBE) && PM_PROBE == 1  // timing probe: no message arithmetic at all
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) gs[q4][c] = acc[c % 3][4 * q4 + c];
+#else
     const uint8_t* xs_l = reinterpret_cast<const uint8_t*>(xs) + 4 * f;
     const uint8_t* ms_l = reinterpret_cast<const uint8_t*>(ms) + 4 * f;
 #pragma unroll
@@ -335,8 +352,13 @@ __global__ __launch_bounds__(256, 2) void k_painn_fwd_mma(PainnMmaArgs A) {
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
+#if defined(PM_PROBE) && PM_PROBE == 2  // timing probe: no gathers
+          xv[e][c] = __int_as_float(jov[e] + c);
+          mv[e][c] = __int_as_float(jov[e] - c);
+#else
           xv[e][c] = *reinterpret_cast<const float*>(xs_l + jov[e] + c * F * 4);
           mv[e][c] = *reinterpret_cast<const float*>(ms_l + jov[e] + c * F * 4);
+#endif
         }
       float sq = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -354,6 +376,7 @@ __global__ __launch_bounds__(256, 2) void k_painn_fwd_mma(PainnMmaArgs A) {
       gs[q4][2] = s1;
       gs[q4][3] = s2;
     }
+#endif
     PM_MARK(5);
     // ---- the halves exchange: half kh keeps components 2 kh, 2 kh + 1 of all eight groups
     float V[8][2];
@@ -390,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void k_painn_fwd_mma(PainnMmaArgs A) {
       const bool fin = ga[g] >= 0 && glast[g];  // uniform
       constexpr uint32_t OOR = 0xFFFFFF00u;     // beyond every buffer: the store is dropped
       const uint32_t oq = (uint32_t)(ga[g] * F + f) * 4u, om = (uint32_t)(ga[g] * 3 * F + f) * 4u;
+#if !defined(PM_PROBE) || PM_PROBE != 3
       if (kh == 0) {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, res0[g] + t0), rs_q, fin ? oq : OOR, 0, 0);  // :63
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, res1[g] + t1), rs_m, fin ? om : OOR, 0, 0);  // :64, x
@@ -397,6 +421,9 @@ __global__ __launch_bounds__(256, 2) void k_painn_fwd_mma(PainnMmaArgs A) {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, res0[g] + t0), rs_m, fin ? om + F * 4u : OOR, 0, 0);      // y
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, res1[g] + t1), rs_m, fin ? om + 2 * F * 4u : OOR, 0, 0);  // z
       }
+#else
+      asm volatile("" ::"v"(t0), "v"(t1), "v"(oq), "v"(om));
+#endif
       t0 = fin ? 0.0f : t0;
       t1 = fin ? 0.0f : t1;
     }
@@ -410,6 +437,327 @@ __global__ __launch_bounds__(256, 2) void k_painn_fwd_mma(PainnMmaArgs A) {
     e2 = e3;
     r0 = r1;
     gc0 = gc1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// Rows are grouped by SOURCE atom j here (incidence list of idx_j).  Per row (edge e = i <- j) and feature f, with the
+// upstream gradients gq = dq_out[i], gm = dmu_out[i] gathered from LDS and the source atom's own x[j], mu[j]:
+//     s1 = gm . dir_e,  s2 = gm . mu[j]
+//     dx[j]  += (gq W0, s1 W1, s2 W2)                 dmu[j] += gm * (W2 x2[j])              (sums over the rows of j)
+//     dWf'[c F + f][k] += u_c phi'_e[k],  u = (gq x0[j], s1 x1[j], s2 x2[j]) * fcut_e       (a sum over ALL rows)
+// W comes from the same small GEMM as in the forward kernel; the filter gradient is a second one per tile with the ROWS
+// on the contraction index: A = u^T (the C layout a lane holds its 16 rows in IS the A-fragment layout under kperm),
+// B = phi' with the row on the contraction index (transposed through a wave-private LDS copy of the tile's rows).  The
+// u fragments are scaled per tile by a power of two from the wave's largest magnitude; the tile's product is added to
+// the fp32 accumulators (lane = k, registers = this wave's 32 columns) outside the matrix pipe.
+template <int R>
+__global__ __launch_bounds__(256, 2) void k_painn_bwd_mma(PainnMmaArgs A) {
+  constexpr int F = PM_F;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, m = tid >> 6, j = lane & 31, kh = lane >> 5;
+  float* gqs = reinterpret_cast<float*>(smem);              // [max_n][F]   dq_out rows of the molecule
+  float* gms = gqs + (size_t)A.max_n * F;                   // [max_n][3F]  dmu_out rows
+  float* wpriv = gms + (size_t)A.max_n * 3 * F + m * (160 + 32 * 32);
+  float* tab = wpriv;                                       // [5][32]: target row offsets (gq / gm), dir x, y, z, kk * fcut
+  float* phis = wpriv + 160;                                // [32 rows][32 k] phi' of the tile (fp32, unscaled)
+  float* red = gms + (size_t)A.max_n * 3 * F + 4 * (160 + 32 * 32);  // [4]
+  const float wmax = filter_max<R>(A.Wf, A.bf, red);
+  int eW;
+  const float sW = pow2_scale_to_2p14(wmax, eW);
+  const float kk = __builtin_amdgcn_ldexpf(1.0f, eW - 28);
+  u32x4 wh[3][2], wl[3][2];
+  load_filter_fragments<R>(A.Wf, A.bf, m, lane, sW, wh, wl);
+  for (int i = lane; i < 32 * 32; i += 64) phis[i] = 0.0f;  // columns past the bias column stay zero
+  const int f = 32 * m + j;
+  const int stride = gridDim.x;
+  auto enter = [&](TilePos& t) {
+    for (;;) {
+      if (t.mol >= A.B) {
+        t = TilePos{t.mol, 0, 0, 0, 0, 0};
+        return;
+      }
+      const int a0 = A.mol_ptr[t.mol], n = A.mol_ptr[t.mol + 1] - a0;
+      const int g0 = A.mol_grp[t.mol], g1 = A.mol_grp[t.mol + 1];
+      if (g1 > g0) {
+        t = TilePos{t.mol, a0, n, g1, g0, 1};
+        return;
+      }
+      t.mol += stride;
+    }
+  };
+  auto advance = [&](TilePos& t) {
+    if (!t.valid) return;
+    t.gb += 8;
+    if (t.gb >= t.g1) {
+      t.mol += stride;
+      enter(t);
+    }
+  };
+  auto edge_of = [&](const TilePos& t) {
+    const int grow = t.gb + (j >> 2);
+    return t.valid && grow < t.g1 ? A.row_edge[4 * t.gb + j] : -1;
+  };
+  auto codes_of = [&](const TilePos& t) {
+    const int g = lane & 7;
+    return t.valid && t.gb + g < t.g1 ? A.grp_atom[t.gb + g] : -1;
+  };
+  TilePos T0{(int)blockIdx.x, 0, 0, 0, 0, 0};
+  enter(T0);
+  TilePos T1 = T0;
+  advance(T1);
+  TilePos T2 = T1;
+  advance(T2);
+  EdgeRow<R> r0, r1;
+  int e0 = edge_of(T0), e1 = edge_of(T1), e2 = edge_of(T2);
+  r0.request(A, max(e0, 0), kh);
+  int gc0 = codes_of(T0), gc1 = gc0;
+  int cur_mol = -1;
+  float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;  // running sums of the current source atom: dx (kh = 0) or dmu (kh = 1)
+  f32x16 accW[3];                           // filter gradient: lane = k, register r = column c F + 32 m + c_row(r)
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accW[c][r] = 0.0f;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(A.out0, 0, (uint32_t)A.N * 3 * F * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(A.out1, 0, (uint32_t)A.N * 3 * F * 4u, 0x00020000);
+  while (T0.valid) {
+    if (T0.mol != cur_mol) {  // a new molecule: the upstream gradients of its atoms into LDS
+      cur_mol = T0.mol;
+      __syncthreads();
+      const f32x4* qg = reinterpret_cast<const f32x4*>(A.q + (size_t)T0.a0 * F);
+      const f32x4* mg = reinterpret_cast<const f32x4*>(A.mu + (size_t)T0.a0 * 3 * F);
+      const int cnt = T0.n * 3 * F / 4, cntq = T0.n * F / 4;
+      for (int base = 0, baseq = 0; base < cnt; base += 8 * 256, baseq += 3 * 256) {
+        f32x4 bm[8], bq[3];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bm[k] = mg[min(base + k * 256 + tid, cnt - 1)];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) bq[k] = qg[min(baseq + k * 256 + tid, cntq - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int u = base + k * 256 + tid;
+          if (u < cnt) reinterpret_cast<f32x4*>(gms)[u] = bm[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int u = baseq + k * 256 + tid;
+          if (u < cntq) reinterpret_cast<f32x4*>(gqs)[u] = bq[k];
+        }
+      }
+      __syncthreads();
+    }
+    // ---- requests one and two tiles ahead
+    r1.request(A, max(e1, 0), kh);
+    gc1 = codes_of(T1);
+    TilePos T3 = T2;
+    advance(T3);
+    const int e3 = edge_of(T3);
+    // ---- group codes (uniform) and the source atoms' own rows for this lane's four groups (2 q + kh)
+    int ga[8], glast[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int code = __builtin_amdgcn_readlane(gc0, g);
+      ga[g] = code < 0 ? -1 : code >> 1;
+      glast[g] = code & 1;
+    }
+    float xsrc[4][3], msrc[4][3];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int a = max(kh ? ga[2 * q4 + 1] : ga[2 * q4], 0);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        xsrc[q4][c] = A.xc[(size_t)a * 3 * F + c * F + f];
+        msrc[q4][c] = A.mu_src[(size_t)a * 3 * F + c * F + f];
+      }
+    }
+    // ---- this tile: A fragments, row table, the tile's phi' rows (for the transposed operand)
+    const bool valid = e0 >= 0;
+    u32x4 ah[2], al[2];
+    r0.fragments(kh, valid, ah, al);
+    if (kh == 0) {
+      const int il = valid ? r0.other - T0.a0 : 0;
+      reinterpret_cast<int*>(tab)[j] = il;
+      tab[32 + j] = r0.d0;
+      tab[64 + j] = r0.d1;
+      tab[96 + j] = r0.d2;
+      tab[128 + j] = valid ? kk * r0.fc : 0.0f;
+    }
+    {  // phi' row j: k = 8 kh .. + 7, 16 .. 19 (kh = 0), the bias column R; zero rows for padding
+      const float one = valid ? 1.0f : 0.0f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kg = 8 * kh + 4 * h;
+        if (kg < R) *reinterpret_cast<f32x4*>(phis + j * 32 + kg) = r0.p[h] * one;
+      }
+      if (kh == 0 && R > 16) *reinterpret_cast<f32x4*>(phis + j * 32 + 16) = r0.p[2] * one;
+      if (kh == 1) phis[j * 32 + R] = one;
+    }
+    // ---- filter of the 32 rows (as in the forward kernel)
+    f32x16 acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] = mfma_f16(al[ks], wh[c][ks], acc[c]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] = mfma_f16(ah[ks], wl[c][ks], acc[c]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] = mfma_f16(ah[ks], wh[c][ks], acc[c]);
+    }
+    // ---- per row: gradients of the source atom (summed per group) and the rows of u
+    float gs[4][6];
+    float u[3][16];
+    const uint8_t* gq_l = reinterpret_cast<const uint8_t*>(gqs) + 4 * f;
+    const uint8_t* gm_l = reinterpret_cast<const uint8_t*>(gms) + 4 * f;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int4 io = *reinterpret_cast<const int4*>(tab + 8 * q4 + 4 * kh);
+      const f32x4 d0 = *reinterpret_cast<const f32x4*>(tab + 32 + 8 * q4 + 4 * kh);
+      const f32x4 d1 = *reinterpret_cast<const f32x4*>(tab + 64 + 8 * q4 + 4 * kh);
+      const f32x4 d2 = *reinterpret_cast<const f32x4*>(tab + 96 + 8 * q4 + 4 * kh);
+      const f32x4 kf = *reinterpret_cast<const f32x4*>(tab + 128 + 8 * q4 + 4 * kh);
+      const int iov[4] = {io.x, io.y, io.z, io.w};
+      float gq[4], gm[4][3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        gq[e] = *reinterpret_cast<const float*>(gq_l + iov[e] * (F * 4));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gm[e][c] = *reinterpret_cast<const float*>(gm_l + iov[e] * (3 * F * 4) + c * F * 4);
+      }
+      float dx0 = 0.0f, dx1 = 0.0f, dx2 = 0.0f, dm0 = 0.0f, dm1 = 0.0f, dm2 = 0.0f;
+      const float x0 = xsrc[q4][0], x1 = xsrc[q4][1], x2 = xsrc[q4][2];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * q4 + e;
+        const float W0 = acc[0][r] * kf[e], W1 = acc[1][r] * kf[e], W2 = acc[2][r] * kf[e];
+        const float s1 = gm[e][0] * d0[e] + gm[e][1] * d1[e] + gm[e][2] * d2[e];
+        const float s2 = gm[e][0] * msrc[q4][0] + gm[e][1] * msrc[q4][1] + gm[e][2] * msrc[q4][2];
+        dx0 = fmaf(gq[e], W0, dx0);
+        dx1 = fmaf(s1, W1, dx1);
+        dx2 = fmaf(s2, W2, dx2);
+        const float w2x = W2 * x2;
+        dm0 = fmaf(gm[e][0], w2x, dm0);
+        dm1 = fmaf(gm[e][1], w2x, dm1);
+        dm2 = fmaf(gm[e][2], w2x, dm2);
+        // W_c = fcut * sum_k phi'_k Wf'_ck: d/dWf'_ck = u_c phi'_k with u_c = dL/dW_c * fcut  (kf = kk * fcut)
+        u[0][r] = gq[e] * x0 * kf[e];
+        u[1][r] = s1 * x1 * kf[e];
+        u[2][r] = s2 * x2 * kf[e];
+      }
+      gs[q4][0] = dx0; gs[q4][1] = dx1; gs[q4][2] = dx2;
+      gs[q4][3] = dm0; gs[q4][4] = dm1; gs[q4][5] = dm2;
+    }
+    // ---- filter gradient of the tile: (u^T)(phi') with the rows on the contraction index
+    {
+      float mx = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(u[c][r]));
+      mx = wave_max(mx);
+      int eu;
+      const float su = pow2_scale_to_2p14(mx, eu);
+      // B fragments: lane (k = j, half kh) holds phi'[row 16 ks + kperm(e, kh)][k] (scaled by 2^14)
+      u32x4 bh[2], bl[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = phis[(16 * ks + kperm(e, kh)) * 32 + j] * 16384.0f;
+        const Frag2 fb = split8h(v);
+        bh[ks] = fb.h;
+        bl[ks] = fb.l;
+      }
+      const float ku = __builtin_amdgcn_ldexpf(1.0f, eu - 28) / kk;  // undoes su, the 2^14 of phi' and the kk inside kf
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        f32x16 tp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tp[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = u[c][8 * ks + e] * su;
+          const Frag2 fa = split8h(v);
+          tp = mfma_f16(fa.l, bh[ks], tp);
+          tp = mfma_f16(fa.h, bl[ks], tp);
+          tp = mfma_f16(fa.h, bh[ks], tp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW[c][r] = fmaf(tp[r], ku, accW[c][r]);
+      }
+    }
+    // ---- the halves exchange: half 0 keeps dx (components 0..2), half 1 dmu (3..5) of all eight groups
+    float V[8][3];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+      for (int c3 = 0; c3 < 3; ++c3) {
+        const float mine = kh ? gs[q4][3 + c3] : gs[q4][c3];
+        const float send = kh ? gs[q4][c3] : gs[q4][3 + c3];
+        const float got = swap_halves(send);
+        V[2 * q4][c3] = kh ? got : mine;
+        V[2 * q4 + 1][c3] = kh ? mine : got;
+      }
+    // ---- runs of groups with one source atom; a run that ends its atom is written out (see the forward kernel)
+    float res[8][3];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const bool fin = ga[g] >= 0 && glast[g];
+      const int al_ = fin ? ga[g] - T0.a0 : 0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) res[g][c] = kh ? gms[(size_t)al_ * 3 * F + c * F + f] : 0.0f;  // mu_out = mu + dmu: + dmu_out[j]
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      t0 += V[g][0];
+      t1 += V[g][1];
+      t2 += V[g][2];
+      const bool fin = ga[g] >= 0 && glast[g];
+      constexpr uint32_t OOR = 0xFFFFFF00u;
+      const uint32_t o = (uint32_t)(ga[g] * 3 * F + f) * 4u;
+      if (kh == 0) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, t0), rs_x, fin ? o : OOR, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, t1), rs_x, fin ? o + F * 4u : OOR, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, t2), rs_x, fin ? o + 2 * F * 4u : OOR, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, res[g][0] + t0), rs_m, fin ? o : OOR, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, res[g][1] + t1), rs_m, fin ? o + F * 4u : OOR, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, res[g][2] + t2), rs_m, fin ? o + 2 * F * 4u : OOR, 0, 0);
+      }
+      t0 = fin ? 0.0f : t0;
+      t1 = fin ? 0.0f : t1;
+      t2 = fin ? 0.0f : t2;
+    }
+    // ---- rotate the pipeline
+    T0 = T1;
+    T1 = T2;
+    T2 = T3;
+    e0 = e1;
+    e1 = e2;
+    e2 = e3;
+    r0 = r1;
+    gc0 = gc1;
+  }
+  // ---- one partial per block: dWf [3F][R] and dbf [3F] (the bias column of dWf')
+  {
+    float* pw = A.pw + (size_t)blockIdx.x * 3 * F * R;
+    float* pb = A.pb + (size_t)blockIdx.x * 3 * F;
+    if (kh == 0) {  // (the two halves hold different columns: register r <-> column c_row(r, lane))
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int col = c * F + 32 * m + c_row(r, lane);
+        if (j < R) pw[(size_t)col * R + j] = accW[c][r];
+        if (j == R) pb[col] = accW[c][r];
+      }
   }
 }
 
@@ -439,6 +787,9 @@ extern "C" int geossl_painn_interaction_fwd_mma(const float* q, const float* mu,
   a.q = q; a.mu = mu; a.xc = xc; a.idx_other = idx_j; a.row_edge = row_edge; a.grp_atom = grp_atom; a.mol_grp = mol_grp;
   a.phi = phi; a.fcut = fcut; a.dir = dir; a.Wf = Wf; a.bf = bf; a.mol_ptr = mol_ptr; a.B = (int)B; a.max_n = max_n; a.N = (int)N;
   a.out0 = q_out; a.out1 = mu_out;
+#ifdef PM_DEBUG
+  a.pw = mu_out + (size_t)N * 3 * F;  // debug: W0 of every row behind mu_out (the caller allocates the room)
+#endif
   const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
   const int nb = (int)(B < 256 * per_cu ? B : 256 * per_cu);
 #define LAUNCH_FWD_MMA(RV)                                                                              \
@@ -448,6 +799,50 @@ extern "C" int geossl_painn_interaction_fwd_mma(const float* q, const float* mu,
   } while (0)
   if (R == 20) LAUNCH_FWD_MMA(20); else if (R == 16) LAUNCH_FWD_MMA(16); else LAUNCH_FWD_MMA(8);
 #undef LAUNCH_FWD_MMA
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int64_t geossl_painn_interaction_bwd_mma_workspace_floats(int64_t B, int F, int R) {
+  const int64_t nb = B < 512 ? B : 512;
+  return nb * (3 * (int64_t)F * R + 3 * F);
+}
+
+extern "C" int geossl_painn_interaction_bwd_mma(const float* dq_out, const float* dmu_out, const float* mu, const float* xc,
+                                                const int64_t* idx_i, const int32_t* row_edge, const int32_t* grp_atom,
+                                                const int32_t* mol_grp, const float* phi, const float* fcut,
+                                                const float* dir, const float* Wf, const float* bf,
+                                                const int32_t* mol_ptr, int64_t B, int max_n, int64_t N, int F, int R,
+                                                float* dxc, float* dmu_in, float* dWf, float* dbf, float* workspace,
+                                                int accumulate, hipStream_t stream) {
+  if (N <= 0 || B <= 0) return 0;
+  const size_t lds = ((size_t)max_n * 4 * PM_F + 4 * (160 + 32 * 32) + 8) * sizeof(float);
+  if (F != PM_F || lds > 160 * 1024 || (R != 8 && R != 16 && R != 20) || N * 3 * PM_F * 4 >= ((int64_t)1 << 32))
+    return (int)hipErrorInvalidValue;
+  PainnMmaArgs a{};
+  a.q = dq_out; a.mu = dmu_out; a.xc = xc; a.mu_src = mu; a.idx_other = idx_i; a.row_edge = row_edge; a.grp_atom = grp_atom;
+  a.mol_grp = mol_grp; a.phi = phi; a.fcut = fcut; a.dir = dir; a.Wf = Wf; a.bf = bf; a.mol_ptr = mol_ptr; a.B = (int)B;
+  a.max_n = max_n; a.N = (int)N; a.out0 = dxc; a.out1 = dmu_in;
+  const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+  const int nb = (int)(B < 256 * per_cu ? B : 256 * per_cu);
+  a.pw = workspace;
+  a.pb = workspace + (size_t)nb * 3 * F * R;
+#define LAUNCH_BWD_MMA(RV)                                                                              \
+  do {                                                                                                  \
+    allow_big_lds(&k_painn_bwd_mma<RV>);                                                                \
+    hipLaunchKernelGGL((k_painn_bwd_mma<RV>), dim3((unsigned)nb), dim3(256), lds, stream, a);           \
+  } while (0)
+  if (R == 20) LAUNCH_BWD_MMA(20); else if (R == 16) LAUNCH_BWD_MMA(16); else LAUNCH_BWD_MMA(8);
+#undef LAUNCH_BWD_MMA
+  GEOSSL_CHECK_LAUNCH();
+  GeosslReduceBatch rb;
+  for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = nullptr;
+  rb.out[0] = dWf;
+  hipLaunchKernelGGL(geossl::k_reduce_partials, dim3((3 * F * R + 63) / 64, 1), dim3(256), 0, stream, rb, a.pw, nb, 3 * F * R,
+                     3 * F * R, 3 * F * R, 1, accumulate);
+  rb.out[0] = dbf;
+  hipLaunchKernelGGL(geossl::k_reduce_partials, dim3((3 * F + 63) / 64, 1), dim3(256), 0, stream, rb, a.pb, nb, 3 * F, 3 * F,
+                     3 * F, 1, accumulate);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
