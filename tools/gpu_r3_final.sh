@@ -20,3 +20,5 @@ for extra in "--model painn --max-batches 8:painn" "--set B --max-batches 24:set
   python bench.py $flags --steps 50 --warmup 10 --no-secondary 2>> $out/bench.err | tail -1 > profiles/r03_bench_${name}_${tag}.json
 done
 ls -la profiles | grep r03; tail -3 $out/refresh.log
+# only gpurun_out/ travels back from the GPU box: the profile files written above go there as well
+mkdir -p $out/profiles; cp profiles/r03_*_${tag}*.json profiles/r03_*_${tag}*.txt profiles/r03_hbm_traffic_pmc.json profiles/r03_painn_hbm_traffic_pmc.json $out/profiles/ 2>/dev/null

@@ -10,8 +10,8 @@ round=${1:-r02}; tag=${2:-vX}; head=${3:-unknown}
 out=gpurun_out/refresh_$tag
 mkdir -p "$out" profiles
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d "$out/trace" -o t -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
-{ echo "# rocprofv3 --kernel-trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline, summarised by tools/rocpd_stats.py"
+rocprofv3 --kernel-trace -d "$out/trace" -o t -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+{ echo "# rocprofv3 --kernel-trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary, summarised by tools/rocpd_stats.py"
   python tools/rocpd_stats.py "$(ls "$out"/trace/*.db | head -1)" 60; } > profiles/${round}_bench_${tag}_kernel_stats.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_f" -o f -- python3 tools/prof_step.py 4 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_w" -o w -- python3 tools/prof_step.py 4 > /dev/null 2>&1
