@@ -350,7 +350,8 @@ int geossl_painn_interaction_bwd(const float* dq_out, const float* dmu_out, cons
                                  int R, float* dxc, float* dmu_in, float* dWf, float* dbf, float* workspace,
                                  int accumulate, hipStream_t stream);
 /* The forward pass with the filter on the matrix pipe (F = 128, n_rbf in {8, 16, 20}): W = phi' Wf'^T as one small GEMM
- * per tile of 32 edge rows (bias and cutoff inside the contraction), the message arithmetic on the vector unit, a team
+ * per tile of 32 edge rows (the bias as a column of the contraction, the cutoff applied to the product as in the
+ * reference, Geom3D/models/painn.py:54-58), the message arithmetic (:59-64) on the vector unit, a team
  * of four waves per molecule.  Rows are laid out in groups of four that share their target atom (the edges of an atom
  * in incidence order, padded to a multiple of four): row_edge [4 G] int32 (-1 = padding), grp_atom [G] int32 =
  * 2 * atom + (the group is the last one of its atom), mol_grp [B + 1] int32 = first group of a molecule; an atom
