@@ -636,11 +636,11 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
     for (int i = 0; i < RB; ++i) {
       if (i < nloc) {
         const float sr = row_scale(i);
-        const float lo[8] = {raw[i][0].x * sr, raw[i][0].y * sr, raw[i][0].z * sr, raw[i][0].w * sr,
-                             raw[i][1].x * sr, raw[i][1].y * sr, raw[i][1].z * sr, raw[i][1].w * sr};
-        const float hi[8] = {raw[i][2].x * sr, raw[i][2].y * sr, raw[i][2].z * sr, raw[i][2].w * sr,
-                             raw[i][3].x * sr, raw[i][3].y * sr, raw[i][3].z * sr, raw[i][3].w * sr};
-        const Frag2 f0 = split8h(lo), f1 = split8h(hi);
+        const float lo[8] = {raw[i][0].x, raw[i][0].y, raw[i][0].z, raw[i][0].w,
+                             raw[i][1].x, raw[i][1].y, raw[i][1].z, raw[i][1].w};
+        const float hi[8] = {raw[i][2].x, raw[i][2].y, raw[i][2].z, raw[i][2].w,
+                             raw[i][3].x, raw[i][3].y, raw[i][3].z, raw[i][3].w};
+        const Frag2 f0 = split8h_scaled(lo, sr), f1 = split8h_scaled(hi, sr);
         u32x4* xd = xbuf + (size_t)i * RBF + (size_t)(2 * m * 2) * 64 + lane;
         xd[0] = f0.h; xd[64] = f0.l;
         xd[128] = f1.h; xd[192] = f1.l;
@@ -781,10 +781,10 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
           float lo[8], hi[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            lo[e] = vout[i][e] * sr;
-            hi[e] = vout[i][8 + e] * sr;
+            lo[e] = vout[i][e];
+            hi[e] = vout[i][8 + e];
           }
-          const Frag2 f0 = split8h(lo), f1 = split8h(hi);
+          const Frag2 f0 = split8h_scaled(lo, sr), f1 = split8h_scaled(hi, sr);
           u32x4* xd = xbuf + (size_t)i * RBF + (size_t)(2 * m * 2) * 64 + lane;
           xd[0] = f0.h; xd[64] = f0.l;
           xd[128] = f1.h; xd[192] = f1.l;

@@ -835,9 +835,7 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
         EO = e_t;
       }
       const float sO = __builtin_amdgcn_ldexpf(1.0f, 14 - EO);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= sO;
-      const Frag2 f = split8h(v);
+      const Frag2 f = split8h_scaled(v, sO);
       u32x4* dst = L.dOr + (size_t)(r_ks * 2) * 64 + (r_row + 32 * r_kh);
       dst[0] = f.h;
       dst[64] = f.l;
@@ -856,8 +854,8 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
       for (int s2 = 0; s2 < 2; ++s2) {
         float u8[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) u8[e] = tc[8 * s2 + e] * sT;
-        const Frag2 f = split8h(u8);
+        for (int e = 0; e < 8; ++e) u8[e] = tc[8 * s2 + e];
+        const Frag2 f = split8h_scaled(u8, sT);
         u32x4* dst = L.tf + (size_t)((hs * 2 + s2) * 2) * 64 + lane;
         dst[0] = f.h;
         dst[64] = f.l;
@@ -879,9 +877,9 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float diff = L.tdd(bsel)[16 * ks + kperm(e, ln >> 5)] - off;
-          u8[e] = gg < G ? exp_neg(coeff * (diff * diff)) * 16384.0f : 0.0f;  // Gaussians are <= 1: fixed scale 2^14
+          u8[e] = gg < G ? exp_neg(coeff * (diff * diff)) : 0.0f;
         }
-        const Frag2 f = split8h(u8);
+        const Frag2 f = split8h_scaled(u8, 16384.0f);  // Gaussians are <= 1: fixed scale 2^14
         u32x4* dst = L.rbf + (size_t)((gb * 2 + ks) * 2) * 64 + ln;
         dst[0] = f.h;
         dst[64] = f.l;
@@ -955,9 +953,9 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
         for (int e = 0; e < 8; ++e) {
           const float dU = (acc0[8 * s + e] * kdt) * dssp_from_out(tcur[8 * s + e]);
           bsum1 += dU;
-          u8[e] = dU * sU;
+          u8[e] = dU;
         }
-        du[s] = split8h(u8);
+        du[s] = split8h_scaled(u8, sU);
       }
       FBH_MARK(6);
       // dW1[h][g] += sum_rows dU[row][h] * rbf(d_row)[g]

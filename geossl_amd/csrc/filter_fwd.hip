@@ -376,9 +376,9 @@ __global__ __launch_bounds__(FFH_THREADS) void k_filter_fwd_h(const float* __res
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float diff = d - o[e];
-        v[e] = exp_neg(coeff * (diff * diff)) * 16384.0f;  // schnet.py:206-207 (padded centres meet zero weights)
+        v[e] = exp_neg(coeff * (diff * diff));  // schnet.py:206-207 (padded centres meet zero weights)
       }
-      bfr[ks] = split8h(v);
+      bfr[ks] = split8h_scaled(v, 16384.0f);
     }
     // first GEMM, transposed: acc1[mb] = (s1 A1)(2^14 rbf^T)[32mb.., rows]
     f32x16 acc1[NMB];
@@ -424,8 +424,8 @@ __global__ __launch_bounds__(FFH_THREADS) void k_filter_fwd_h(const float* __res
     for (int ks = 0; ks < K2S; ++ks) {
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = acc1[ks >> 1][8 * (ks & 1) + e] * st;
-      tb[ks] = split8h(v);
+      for (int e = 0; e < 8; ++e) v[e] = acc1[ks >> 1][8 * (ks & 1) + e];
+      tb[ks] = split8h_scaled(v, st);
     }
     // second GEMM, transposed, two 32-feature output blocks at a time
     constexpr int MP = NMB >= 2 ? 2 : 1;

@@ -108,11 +108,36 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 struct Frag2 {
   u32x4 h, l;
 };
-__device__ __forceinline__ void split2h(float v0, float v1, uint32_t& h, uint32_t& l) {
+// The split of a pair of values, plain form (7 vector instructions per value once the compiler has had its way with it:
+// it converts each value twice).  Kept as the definition the fused forms below are tested against
+// (tools/probes/split_probe.hip).
+__device__ __forceinline__ void split2h_plain(float v0, float v1, uint32_t& h, uint32_t& l) {
   const f16x2 p = {(_Float16)v0, (_Float16)v1};  // v_cvt_pk_f16_f32, round to nearest even
   h = __builtin_bit_cast(uint32_t, p);
   const f16x2 q = {(_Float16)(v0 - (float)p[0]), (_Float16)(v1 - (float)p[1])};
   l = __builtin_bit_cast(uint32_t, q);
+}
+__device__ __forceinline__ Frag2 split8h_plain(const float (&v)[8]) {
+  Frag2 f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t h, l;
+    split2h_plain(v[2 * q], v[2 * q + 1], h, l);
+    f.h[q] = h;
+    f.l[q] = l;
+  }
+  return f;
+}
+// The same two pieces in 3 instructions per PAIR: v - h is exact in fp32 (h is the nearest fp16 of v), so the mixed-
+// precision fused multiply-add h * (-1) + v, rounded once to fp16 into the low / high half of the destination
+// (v_fma_mixlo_f16 / v_fma_mixhi_f16), gives the bits of "convert back, subtract, convert".  The operands enter the
+// instruction as registers: whatever arithmetic produced v has been rounded to fp32 before - a compiler contraction
+// cannot reach into one of the two conversions and not the other (painn_mma.hip's note on inexact products).
+__device__ __forceinline__ void split2h(float v0, float v1, uint32_t& h, uint32_t& l) {
+  const f16x2 p = {(_Float16)v0, (_Float16)v1};
+  h = __builtin_bit_cast(uint32_t, p);
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(v0));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(v1));
 }
 __device__ __forceinline__ Frag2 split8h(const float (&v)[8]) {
   Frag2 f;
@@ -120,6 +145,26 @@ __device__ __forceinline__ Frag2 split8h(const float (&v)[8]) {
   for (int q = 0; q < 4; ++q) {
     uint32_t h, l;
     split2h(v[2 * q], v[2 * q + 1], h, l);
+    f.h[q] = h;
+    f.l[q] = l;
+  }
+  return f;
+}
+// Pieces of v * s for a power of two s (the operand scales of the two-piece kernels), the multiplication inside the
+// instructions: h = fp16(v s), l = fp16(v s - h) - 4 instructions per pair, scale included.  (For any other s the
+// pieces would be those of the EXACT product, not of its fp32 rounding.)
+__device__ __forceinline__ void split2h_scaled(float v0, float v1, float s, uint32_t& h, uint32_t& l) {
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h) : "v"(v0), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(v1), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v0), "v"(s), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v1), "v"(s), "v"(h));
+}
+__device__ __forceinline__ Frag2 split8h_scaled(const float (&v)[8], float s) {
+  Frag2 f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t h, l;
+    split2h_scaled(v[2 * q], v[2 * q + 1], s, h, l);
     f.h[q] = h;
     f.l[q] = l;
   }

@@ -123,9 +123,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
       if (lane == 0) eblk[blk] = ea[u];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[ks][q] *= sc;
-        const Frag2 f = split8h(v[ks]);
+        const Frag2 f = split8h_scaled(v[ks], sc);
         u32x4* dst = Fr + (size_t)((blk * 2 + ks) * 2) * 64 + lane;
         dst[0] = f.h;
         dst[64] = f.l;
@@ -148,9 +146,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
       if (lane == 0) eblk[NCM + blk] = eb[u];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[ks][q] *= sc;
-        const Frag2 f = split8h(v[ks]);
+        const Frag2 f = split8h_scaled(v[ks], sc);
         u32x4* dst = Fr + (size_t)(((NCM + blk) * 2 + ks) * 2) * 64 + lane;
         dst[0] = f.h;
         dst[64] = f.l;
