@@ -1,6 +1,7 @@
 // Backward of the denoising-distance-matching head NCSN_version_03 (NCSN.py:168-220) in ONE pass over the super-edge
 // rows: the row gradients (ncsn_rows.hip: k_ncsn_bwd_rows computes the same quantities) AND the weight gradients of
-// the two dense layers of output_mlp, on the bf16 matrix pipe (split.h).  Nothing per-row is re-read: the separate
+// the two dense layers of output_mlp, on the 16-bit matrix pipe as products of two fp16 pieces per operand (split.h:
+// three MFMAs per product; operand scales below).  Nothing per-row is re-read: the separate
 // weight-gradient launches (wgrad.h with NcsnW1Ops / NcsnW2Ops) fetched a1, a2, dz1 and the gathered h_u + h_v a
 // second time from HBM with 4-byte column requests (0.36 ms per step for the two heads against 0.15 ms of row pass).
 //
@@ -16,8 +17,8 @@
 //       unit on the lane and the rows in the registers (kperm order) - exactly the A-fragment layout of dW1's
 //       contraction over rows, and a1 is requested in that layout (16 4-byte loads of a column) for the mask;
 //       dW1[its units][all features] against the (h_u + h_v)^T fragments the B waves publish; the emb column and db1
-//       from the same registers; the pieces of dz1 go through the matrix pipe against a selection matrix (6 MFMAs,
-//       exact: a bf16 piece times 1.0) and land with the row on the lane - the B fragments of the next product - and
+//       from the same registers; the pieces of dz1 go through the matrix pipe against a selection matrix (4 MFMAs,
+//       exact: an fp16 piece times 1.0) and land with the row on the lane - the B fragments of the next product - and
 //       are published; dW2[all units of layer 2][its columns] against its own a1 fragments (phase 2).
 //   wave B_k (features [32k, 32k+32) of layer 0's input):
 //       dfeat for its features (its o1_w^T slice x the published dz1 fragments, rows on N: 16-byte row-piece stores);
@@ -25,9 +26,21 @@
 //       atom rows from L2: a half-wave reads 128 contiguous bytes of one atom) and - B_0, B_1 - dz2^T through the
 //       selection-matrix product, with db2.
 // Two barriers per tile (LDS-only: s_waitcnt lgkmcnt(0) + s_barrier, global requests stay in flight across them):
-// phase 1 is MFMA work of the A waves (78 per tile at F = 128) while the B waves build the next tile, phase 2 is
-// MFMA work of the B waves (48) and the A waves' dW2 (24).  Per SIMD and tile 156 MFMAs, the same as the two separate
-// passes together - but one read of a1 / a2 and no dz1 in HBM at all.
+// phase 1 is MFMA work of the A waves (40 per tile at F = 128) while the B waves build the next tile, phase 2 is
+// MFMA work of the B waves (36: dfeat and dW2).  One read of a1 / a2 and no dz1 in HBM at all.
+//
+// Operand scales (fp16 has five exponent bits; every scale is a power of two, exact, and undone on the fp32 side):
+//   * the upstream row gradient g spans orders of magnitude between molecules (sigma^anneal_power, NCSN.py:215-218):
+//     wave A_0 keeps EG, the RUNNING exponent of the largest |g| of the block's tiles so far, and publishes it with the
+//     row scalars of a tile.  dz2 = g w3 [a2 > 0] is scaled by 2^(14 - EG - e3) (e3: exponent of max |w3|);
+//   * dz1 is never measured: |dz1[row][m]| <= |g| sum_k |w3[k] o2_w[k][m]| < 2^(EG + eC) with eC the exponent of the
+//     largest such column sum (a weight-only constant, block-uniform), so dz1 in units of 2^(EG + eC - 14) stays
+//     below 2^14 and comes out of the dz1 accumulator by ONE constant factor.  A value 2^17 below its bound still
+//     has all 22 bits; below that the absolute error is 2^-39 of the bound;
+//   * the forward activations (a1^T by the A waves, (h_u + h_v)^T by the B waves) are measured per wave and tile and
+//     scaled by running exponents EA / EF, published next to the fragments;
+//   * a weight-gradient accumulator holds its sum in units of 2^(EG + E* - 28 + const): when one of the two running
+//     exponents rises (rare after the first tiles) the wave multiplies the accumulator by the power of two in between.
 // The narrow gradients (output_mlp.layers.2 and the 1 -> F -> 1 distance embedding) are per-unit sums over the rows of
 // quantities the tile already holds (g, demb, the perturbed distance): VALU work of the A waves in phase 2, where they
 // have no MFMAs; layers.2.weight accumulates in the B waves where they turn a2 into the dz2 fragments.
@@ -63,29 +76,37 @@ __device__ long long nb_dbg[2 * 32 * 8];
 template <int NW>
 struct NbLds {
   static constexpr int F = 32 * NW, H = F / 2, KHS = (H + 15) / 16, HMB = (H + 31) / 32, KS = F / 16;
-  u32x4* zb;    // [2][KHS][3][64]      dz2 as A fragments (lane = row, 8 consecutive units), double buffered
-  u32x4* dz2T;  // [HMB][2][3][64]      dz2^T as A fragments (lane = unit of layer 2, rows in kperm order)
-  u32x4* fT;    // [2][NW][2][3][64]    (h_u + h_v)^T as B fragments (lane = feature, rows in kperm order)
-  u32x4* dz1r;  // [KS][3][64]          dz1 as B fragments (lane = row, units in kperm order)
-  u32x4* abT;   // [NW][2][3][64]       a1^T as B fragments (lane = unit of layer 1, rows in kperm order)
+  u32x4* zb;    // [2][KHS][2][64]      dz2 as A fragments (lane = row, 8 consecutive units), double buffered
+  u32x4* dz2T;  // [HMB][2][2][64]      dz2^T as A fragments (lane = unit of layer 2, rows in kperm order)
+  u32x4* fT;    // [2][NW][2][2][64]    (h_u + h_v)^T as B fragments (lane = feature, rows in kperm order)
+  u32x4* dz1r;  // [KS][2][64]          dz1 as B fragments (lane = row, units in kperm order)
+  u32x4* abT;   // [NW][2][2][64]       a1^T as B fragments (lane = unit of layer 1, rows in kperm order)
   int4* scal;   // [3][TR]              {u, v, g, emb} of a tile's rows, ring of three tiles
   float* pdv;   // [3][TR]              perturbed distance of the rows, same ring
   float* dep;   // [TR][NW]             demb partial of every A wave
   float* wls;   // [F]                  o1_w[:, F]
+  int* eg;      // [4]                  running exponent of |g| with the scalars of a tile (ring of three)
+  int* ef;      // [2][NW]              running exponent of a B wave's (h_u + h_v)^T fragments, double buffered
+  int* ea;      // [NW]                 running exponent of an A wave's a1^T fragments
+  int* ec;      // [NW]                 prologue: exponent of the largest column sum of |w3 o2_w| per A wave
   __device__ explicit NbLds(uint8_t* smem) {
     zb = reinterpret_cast<u32x4*>(smem);
-    dz2T = zb + 2 * KHS * 3 * 64;
-    fT = dz2T + HMB * 2 * 3 * 64;
-    dz1r = fT + 2 * NW * 2 * 3 * 64;
-    abT = dz1r + KS * 3 * 64;
-    scal = reinterpret_cast<int4*>(abT + NW * 2 * 3 * 64);
+    dz2T = zb + 2 * KHS * 2 * 64;
+    fT = dz2T + HMB * 2 * 2 * 64;
+    dz1r = fT + 2 * NW * 2 * 2 * 64;
+    abT = dz1r + KS * 2 * 64;
+    scal = reinterpret_cast<int4*>(abT + NW * 2 * 2 * 64);
     pdv = reinterpret_cast<float*>(scal + 3 * TR);
     dep = pdv + 3 * TR;
     wls = dep + NW * TR;
+    eg = reinterpret_cast<int*>(wls + F);
+    ef = eg + 4;
+    ea = ef + 2 * NW;
+    ec = ea + NW;
   }
   static size_t bytes() {
-    return (size_t)(2 * KHS * 3 + HMB * 6 + 2 * NW * 6 + KS * 3 + NW * 6) * 1024 + 3 * TR * sizeof(int4) +
-           (size_t)(3 * TR + NW * TR + F) * sizeof(float);
+    return (size_t)(2 * KHS * 2 + HMB * 4 + 2 * NW * 4 + KS * 2 + NW * 4) * 1024 + 3 * TR * sizeof(int4) +
+           (size_t)(3 * TR + NW * TR + F) * sizeof(float) + (size_t)(4 + 4 * NW) * sizeof(int);
   }
 };
 
@@ -122,13 +143,22 @@ __device__ __forceinline__ int opaque(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
+// eight values that ARE fp16 numbers (a piece that went through the matrix pipe against 1.0) back into a fragment
 __device__ __forceinline__ u32x4 pack8(const f32x16& t, int s) {
   u32x4 w;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) w[q] = pk_bf16(t[8 * s + 2 * q], t[8 * s + 2 * q + 1]);
+  for (int q = 0; q < 4; ++q) {
+    const f16x2 p = {(_Float16)t[8 * s + 2 * q], (_Float16)t[8 * s + 2 * q + 1]};
+    w[q] = __builtin_bit_cast(uint32_t, p);
+  }
   return w;
 }
-__device__ __forceinline__ const u32x4& piece(const Frag3& f, int pc) { return pc == 0 ? f.h : (pc == 1 ? f.m : f.l); }
+__device__ __forceinline__ const u32x4& piece(const Frag2& f, int pc) { return pc == 0 ? f.h : f.l; }
+// exponent of a magnitude for the operand scales, floored: 2^(14 - e) and the products of two such scales stay finite
+// for all-zero operands (an untrained bias, a tile past the block's range)
+__device__ __forceinline__ int scale_exponent(float m) { return max(mag_exponent(m), -40); }
+__device__ __forceinline__ float pow2(int e) { return __builtin_amdgcn_ldexpf(1.0f, e); }
+constexpr int E_NONE = -100000;  // "no tile yet": the first rescale multiplies a zero accumulator by 2^-inf = 0
 
 template <int NW, bool ROLE_A>
 __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
@@ -147,51 +177,78 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
   const uint32_t col = 32 * nb + j;  // this lane's feature
 
   // ---------------------------------------------------------------- per-role constant state
-  Frag3 wreg[ROLE_A ? KHS : KS];  // A: o2_w[:, col] as B fragments (k = unit of layer 2, natural order)
-                                   // B: o1_w[:, col] as A fragments (k = unit of layer 1, kperm order)
-  f32x16 accw1[ROLE_A ? NW : 1];   // A: dW1[32nb + reg][32kb + lane]
-  f32x16 accw2[ROLE_A ? 1 : HMB];  // B: dW2[32mb + reg][32nb + lane]
+  Frag2 wreg[ROLE_A ? KHS : KS];  // A: o2_w[:, col] as B fragments (k = unit of layer 2, natural order), scale 2^(14-e2)
+                                   // B: o1_w[:, col] as A fragments (k = unit of layer 1, kperm order), scale 2^(14-e1)
+  f32x16 accw1[ROLE_A ? NW : 1];   // A: dW1[32nb + reg][32kb + lane] in units of 2^(E1[kb] + eC - 28)
+  f32x16 accw2[ROLE_A ? 1 : HMB];  // B: dW2[32mb + reg][32nb + lane] in units of 2^(E2 + e3 - 28)
+  int E1[ROLE_A ? NW : 1];         // A: EG + EF[kb] the accumulator is held at
+  int E2 = E_NONE;                 // B: EG + EA[nb]
+  int ew = 0;                      // A: e2, B: e1 (exponent of the wave's weight slice)
   float bsum = 0.0f, dsum = 0.0f;  // A: db1 / emb column of its unit;  B: db2 of its unit
-  u32x4 ident[2];                  // selection matrices of the matrix-pipe transpositions (B operand)
+  u32x4 ident[2];                  // selection matrices of the matrix-pipe transpositions (B operand, fp16 ones)
   float w3r[8];
   // A: the narrow gradients of this lane's unit of the 1 -> F -> 1 distance embedding (NCSN.py:197); wave A_0 also sums
   // g and demb over the rows (layers.2.bias, input_distance_mlp bias 2)
   float s_w2 = 0.0f, s_w1 = 0.0f, s_b1 = 0.0f, s_g = 0.0f, s_d = 0.0f;
   float iw1 = 0.0f, ib1 = 0.0f, iw2 = 0.0f;
+  // e3: exponent of the largest |layers.2.weight| (every wave evaluates it for itself)
+  int e3;
+  {
+    float m3 = 0.0f;
+    for (int i = lane; i < H; i += 64) m3 = fmaxf(m3, fabsf(a.w.o3_w[i]));
+    e3 = scale_exponent(wave_max(m3));
+  }
   if constexpr (ROLE_A) {
     iw1 = a.w.in_w1[col];
     ib1 = a.w.in_b1[col];
     iw2 = a.w.in_w2[col];
+    float raw[KHS][8];
+    float wm = 0.0f, csum = 0.0f;
 #pragma unroll
-    for (int ks = 0; ks < KHS; ++ks) {
-      float v[8];
+    for (int ks = 0; ks < KHS; ++ks)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int m = 16 * ks + 8 * kh + e;
-        v[e] = m < H ? a.w.o2_w[(size_t)m * F + col] : 0.0f;
+        const float v = m < H ? a.w.o2_w[(size_t)m * F + col] : 0.0f;
+        raw[ks][e] = v;
+        wm = fmaxf(wm, fabsf(v));
+        csum = fmaf(fabsf(v), m < H ? fabsf(a.w.o3_w[m]) : 0.0f, csum);
       }
-      wreg[ks] = split8(v);
-    }
+    ew = scale_exponent(wave_max(wm));
+    const float sw = pow2(14 - ew);
 #pragma unroll
-    for (int kb = 0; kb < NW; ++kb)
+    for (int ks = 0; ks < KHS; ++ks) wreg[ks] = split8h_scaled(raw[ks], sw);
+    csum += __shfl_xor(csum, 32, 64);  // the two halves of a column
+    const int ecw = max(mag_exponent(wave_max(csum)), -80);
+    if (lane == 0) L.ec[nb] = ecw;
+#pragma unroll
+    for (int kb = 0; kb < NW; ++kb) {
+      E1[kb] = E_NONE;
 #pragma unroll
       for (int r = 0; r < 16; ++r) accw1[kb][r] = 0.0f;
+    }
     // dz1^T (lane = unit, k = row 16s + kperm(e, kh)) -> row on the lane: B[k][n = row'] = [16s + kperm(e, kh) == row']
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int k0 = 16 * s + kperm(2 * q, kh), k1 = 16 * s + kperm(2 * q + 1, kh);
-        ident[s][q] = (k0 == j ? 0x3F80u : 0u) | (k1 == j ? 0x3F800000u : 0u);
+        ident[s][q] = (k0 == j ? 0x3C00u : 0u) | (k1 == j ? 0x3C000000u : 0u);
       }
   } else {
+    float raw[KS][8];
+    float wm = 0.0f;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      float v[8];
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = a.w.o1_w[(size_t)(16 * ks + kperm(e, kh)) * (F + 1) + col];
-      wreg[ks] = split8(v);
-    }
+      for (int e = 0; e < 8; ++e) {
+        raw[ks][e] = a.w.o1_w[(size_t)(16 * ks + kperm(e, kh)) * (F + 1) + col];
+        wm = fmaxf(wm, fabsf(raw[ks][e]));
+      }
+    ew = scale_exponent(wave_max(wm));
+    const float sw = pow2(14 - ew);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wreg[ks] = split8h_scaled(raw[ks], sw);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int m = 16 * nb + 8 * kh + e;  // k-step nb of the dz2 fragments is built by this wave
@@ -207,15 +264,16 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int k0 = 16 * q2 + 8 * kh + 2 * q;
-        ident[q2][q] = (k0 == j ? 0x3F80u : 0u) | (k0 + 1 == j ? 0x3F800000u : 0u);
+        ident[q2][q] = (k0 == j ? 0x3C00u : 0u) | (k0 + 1 == j ? 0x3C000000u : 0u);
       }
   }
   for (int i = tid; i < F; i += NT) L.wls[i] = a.w.o1_w[(size_t)i * (F + 1) + F];
 
   // ---------------------------------------------------------------- request / build steps (see the header)
-  // A wave 0, lanes 0..31: the row scalars of tile tt
+  // A wave 0, lanes 0..31: the row scalars of tile tt; EG: running exponent of |g| over the tiles published so far
   int sc_u = 0, sc_v = 0;
   float sc_g = 0.0f, sc_e = 0.0f, sc_p = 0.0f;
+  int EG = -60;
   auto load_scal = [&](int tt) {
     if constexpr (ROLE_A) {
       if (wave == 0) {
@@ -230,13 +288,17 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
   };
   auto put_scal = [&](int tt) {
     if constexpr (ROLE_A) {
-      if (wave == 0 && lane < TR) {
+      if (wave == 0) {
         const int row = TR * tt + lane;
-        const bool valid = row < S && tt < t_end;
+        const bool valid = lane < TR && row < S && tt < t_end;
         const float gr = valid ? pin(sc_g) * scale : 0.0f;
-        L.scal[(tt % 3) * TR + lane] = make_int4(sc_u, sc_v, __float_as_int(gr), __float_as_int(sc_e));
-        L.pdv[(tt % 3) * TR + lane] = sc_p;
-        if (valid) a.grow[row] = gr;
+        EG = max(EG, mag_exponent(wave_max(fabsf(gr))));
+        if (lane < TR) {
+          L.scal[(tt % 3) * TR + lane] = make_int4(sc_u, sc_v, __float_as_int(gr), __float_as_int(sc_e));
+          L.pdv[(tt % 3) * TR + lane] = sc_p;
+          if (valid) a.grow[row] = gr;
+        }
+        if (lane == 0) L.eg[tt % 3] = EG;
       }
     }
   };
@@ -278,6 +340,7 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
     if constexpr (!ROLE_A) {
       if (nb < KHS) {
         const float gr = __int_as_float(L.scal[(tt % 3) * TR + j].z);
+        const float sz = pow2(14 - e3 - __builtin_amdgcn_readfirstlane(L.eg[tt % 3]));
         const float av[8] = {a2raw[0].x, a2raw[0].y, a2raw[0].z, a2raw[0].w, a2raw[1].x, a2raw[1].y, a2raw[1].z, a2raw[1].w};
         float v[8];
 #pragma unroll
@@ -286,46 +349,62 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
           v[e] = a2v > 0.0f ? gr * w3r[e] : 0.0f;
           o3acc[e] = fmaf(gr, a2v, o3acc[e]);  // layers.2.weight gradient of unit 16nb + 8kh + e, this lane's rows
         }
-        const Frag3 f = split8(v);
-        u32x4* dst = L.zb + (size_t)(((tt & 1) * KHS + nb) * 3) * 64 + lane;
+        const Frag2 f = split8h_scaled(v, sz);
+        u32x4* dst = L.zb + (size_t)(((tt & 1) * KHS + nb) * 2) * 64 + lane;
         dst[0] = f.h;
-        dst[64] = f.m;
-        dst[128] = f.l;
+        dst[64] = f.l;
       }
     }
   };
+  int EF = -40;  // B: running exponent of this wave's (h_u + h_v)^T fragments
   auto build_fT = [&](int tt) {
     if constexpr (!ROLE_A) {
+      float v[16];
+      float m = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        v[r] = pin(hu[r]) + pin(hv[r]);  // NCSN.py:201-203
+        m = fmaxf(m, fabsf(v[r]));
+      }
+      EF = max(EF, mag_exponent(wave_max(m)));
+      const float sf = pow2(14 - EF);
+      if (lane == 0) L.ef[(tt & 1) * NW + nb] = EF;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        float v[8];
+        float vv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = pin(hu[8 * s + e]) + pin(hv[8 * s + e]);  // NCSN.py:201-203
-        const Frag3 f = split8(v);
-        u32x4* dst = L.fT + (size_t)((((tt & 1) * NW + nb) * 2 + s) * 3) * 64 + lane;
+        for (int e = 0; e < 8; ++e) vv[e] = v[8 * s + e];
+        const Frag2 f = split8h_scaled(vv, sf);
+        u32x4* dst = L.fT + (size_t)((((tt & 1) * NW + nb) * 2 + s) * 2) * 64 + lane;
         dst[0] = f.h;
-        dst[64] = f.m;
-        dst[128] = f.l;
+        dst[64] = f.l;
       }
     }
   };
 
   // ---------------------------------------------------------------- prologue
+  load_scal(t_begin);
+  put_scal(t_begin);
+  load_scal(t_begin + 1);
+  put_scal(t_begin + 1);
+  load_scal(t_begin + 2);  // written in phase 1 of the first tile
   if (t_begin < t_end) {
-    load_scal(t_begin);
-    put_scal(t_begin);
-    load_scal(t_begin + 1);
-    put_scal(t_begin + 1);
-    load_scal(t_begin + 2);  // written in phase 1 of the first tile
     request_a1(t_begin, 4 * kh);
     request_a2(t_begin);
-    __syncthreads();
+  }
+  __syncthreads();
+  int eC = -80;  // block-uniform exponent of the largest column sum of |w3 o2_w|: |dz1| < 2^(EG + eC)
+#pragma unroll
+  for (int i = 0; i < NW; ++i) eC = max(eC, __builtin_amdgcn_readfirstlane(L.ec[i]));
+  if (t_begin < t_end) {
     request_gather(t_begin, 4 * kh);
     build_zb(t_begin);
     build_fT(t_begin);
     request_a2(t_begin + 1);
     request_gather(t_begin + 1, 4 * kh);
   }
+  int EA = -40;  // A: running exponent of this wave's a1^T fragments
+  const float kA = pow2(e3 + ew - eC - 14);  // A: dz1 accumulator -> dz1 in units of 2^(EG + eC - 14)
   for (int t = t_begin; t < t_end; ++t) {
     const int buf = t & 1;
     int k4 = opaque(4 * kh);
@@ -333,24 +412,26 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
     lds_barrier();  // X(t): fragments and scalars of tile t published; everything of tile t-1 consumed
     // =============================================================== phase 1
     NB_MARK(1);
+    const int EGt = __builtin_amdgcn_readfirstlane(L.eg[t % 3]);
     if constexpr (ROLE_A) {
       put_scal(t + 2);
+      const float kT = pow2(EGt + eC - 14);  // one unit of this tile's scaled dz1
       // ---- dz1^T for this wave's units: rows on M
       f32x16 acc0, acc1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
       {
-        const u32x4* zs = L.zb + (size_t)(buf * KHS * 3) * 64 + lane;
-        Frag3 a0, an;
-        a0.h = zs[0]; a0.m = zs[64]; a0.l = zs[128];
+        const u32x4* zs = L.zb + (size_t)(buf * KHS * 2) * 64 + lane;
+        Frag2 a0, an;
+        a0.h = zs[0]; a0.l = zs[64];
 #pragma unroll
         for (int ks = 0; ks < KHS; ++ks) {
           if (ks + 1 < KHS) {
-            const u32x4* s0 = zs + (size_t)((ks + 1) * 3) * 64;
-            an.h = s0[0]; an.m = s0[64]; an.l = s0[128];
+            const u32x4* s0 = zs + (size_t)((ks + 1) * 2) * 64;
+            an.h = s0[0]; an.l = s0[64];
           }
           __builtin_amdgcn_sched_barrier(0);
-          mma6x2(acc0, acc1, a0, wreg[ks]);
+          mma3x2(acc0, acc1, a0, wreg[ks]);
           __builtin_amdgcn_sched_barrier(0);
           if (ks + 1 < KHS) a0 = an;
         }
@@ -359,34 +440,42 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
       float v[16];
       {
         const int4* sc = L.scal + (t % 3) * TR;
+        float tb = 0.0f, td = 0.0f, am = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           a1raw[r] = pin(a1raw[r]);
-          v[r] = a1raw[r] > 0.0f ? acc0[r] + acc1[r] : 0.0f;  // rows past S: dz2 = 0 there
-          bsum += v[r];
-          dsum = fmaf(v[r], __int_as_float(sc[crow4(r, k4)].w), dsum);
+          v[r] = a1raw[r] > 0.0f ? (acc0[r] + acc1[r]) * kA : 0.0f;  // rows past S: dz2 = 0 there
+          tb += v[r];
+          td = fmaf(v[r], __int_as_float(sc[crow4(r, k4)].w), td);
+          am = fmaxf(am, fabsf(a1raw[r]));
         }
+        bsum = fmaf(tb, kT, bsum);
+        dsum = fmaf(td, kT, dsum);
+        EA = max(EA, mag_exponent(wave_max(am)));
       }
       // a1^T of this wave's units as B fragments of dW2's contraction over rows (multiplied by the B wave that owns
       // these columns of dW2); the registers are then free for the next tile's request
+      {
+        const float sa = pow2(14 - EA);
+        if (lane == 0) L.ea[nb] = EA;
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        float vv[8];
+        for (int s = 0; s < 2; ++s) {
+          float vv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) vv[e] = a1raw[8 * s + e];
-        const Frag3 f = split8(vv);
-        u32x4* dst = L.abT + (size_t)((nb * 2 + s) * 3) * 64 + lane;
-        dst[0] = f.h;
-        dst[64] = f.m;
-        dst[128] = f.l;
+          for (int e = 0; e < 8; ++e) vv[e] = a1raw[8 * s + e];
+          const Frag2 f = split8h_scaled(vv, sa);
+          u32x4* dst = L.abT + (size_t)((nb * 2 + s) * 2) * 64 + lane;
+          dst[0] = f.h;
+          dst[64] = f.l;
+        }
       }
-      Frag3 da[2];
+      Frag2 da[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         float vv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) vv[e] = v[8 * s + e];
-        da[s] = split8(vv);
+        da[s] = split8h(vv);
       }
       // ---- the pieces of dz1 with the row on the lane (exact), published as B fragments; demb partial
       {
@@ -395,52 +484,62 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
         for (int r = 0; r < 16; ++r) wl[r] = L.wls[32 * nb + crow4(r, k4)];
         float de = 0.0f;
 #pragma unroll
-        for (int pc = 2; pc >= 0; --pc) {  // smallest piece first
+        for (int pc = 1; pc >= 0; --pc) {  // smallest piece first
           f32x16 tp;
 #pragma unroll
           for (int r = 0; r < 16; ++r) tp[r] = 0.0f;
-          tp = mfma_bf16(piece(da[0], pc), ident[0], tp);
-          tp = mfma_bf16(piece(da[1], pc), ident[1], tp);
+          tp = mfma_f16(piece(da[0], pc), ident[0], tp);
+          tp = mfma_f16(piece(da[1], pc), ident[1], tp);
 #pragma unroll
           for (int r = 0; r < 16; ++r) de = fmaf(tp[r], wl[r], de);
 #pragma unroll
           for (int half = 0; half < 2; ++half)
-            L.dz1r[(size_t)((2 * nb + half) * 3 + pc) * 64 + lane] = pack8(tp, half);
+            L.dz1r[(size_t)((2 * nb + half) * 2 + pc) * 64 + lane] = pack8(tp, half);
         }
         de += __shfl_xor(de, 32, 64);
-        if (kh == 0) L.dep[j * NW + nb] = de;
+        if (kh == 0) L.dep[j * NW + nb] = de * kT;
       }
       NB_MARK(6);
       // ---- dW1[this wave's units][all features] += dz1^T (h_u + h_v)
 #pragma unroll
-      for (int kb = 0; kb < NW; ++kb)
+      for (int kb = 0; kb < NW; ++kb) {
+        const int En = EGt + __builtin_amdgcn_readfirstlane(L.ef[buf * NW + kb]);
+        if (En != E1[kb]) {  // a running exponent rose: the sum so far in the new unit
+          const float f = pow2(max(E1[kb] - En, -200));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accw1[kb][r] *= f;
+          E1[kb] = En;
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const u32x4* s0 = L.fT + (size_t)(((buf * NW + kb) * 2 + s) * 3) * 64 + lane;
-          Frag3 bf;
-          bf.h = s0[0]; bf.m = s0[64]; bf.l = s0[128];
-          mma6(accw1[kb], da[s], bf);
+          const u32x4* s0 = L.fT + (size_t)(((buf * NW + kb) * 2 + s) * 2) * 64 + lane;
+          Frag2 bf;
+          bf.h = s0[0]; bf.l = s0[64];
+          mma3(accw1[kb], da[s], bf);
         }
+      }
     } else {
       // ---- dz2^T for unit block nb of layer 2 through the selection matrix; db2
       if (nb < HMB) {
+        float tb = 0.0f;
 #pragma unroll
-        for (int pc = 2; pc >= 0; --pc) {
+        for (int pc = 1; pc >= 0; --pc) {
           f32x16 tp;
 #pragma unroll
           for (int r = 0; r < 16; ++r) tp[r] = 0.0f;
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             if (2 * nb + q < KHS) {
-              const u32x4* s0 = L.zb + (size_t)((buf * KHS + 2 * nb + q) * 3 + pc) * 64 + lane;
-              tp = mfma_bf16(s0[0], ident[q], tp);
+              const u32x4* s0 = L.zb + (size_t)((buf * KHS + 2 * nb + q) * 2 + pc) * 64 + lane;
+              tp = mfma_f16(s0[0], ident[q], tp);
             }
           }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) bsum += tp[r];
+          for (int r = 0; r < 16; ++r) tb += tp[r];
 #pragma unroll
-          for (int s = 0; s < 2; ++s) L.dz2T[(size_t)((nb * 2 + s) * 3 + pc) * 64 + lane] = pack8(tp, s);
+          for (int s = 0; s < 2; ++s) L.dz2T[(size_t)((nb * 2 + s) * 2 + pc) * 64 + lane] = pack8(tp, s);
         }
+        bsum = fmaf(tb, pow2(EGt + e3 - 14), bsum);
       }
       NB_MARK(5);
       // ---- next tile's fragments (their requests have been in flight since phase 2 of the previous tile)
@@ -489,23 +588,24 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
       for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
       {
         const u32x4* zs = L.dz1r + lane;
-        Frag3 b0, bn;
-        b0.h = zs[0]; b0.m = zs[64]; b0.l = zs[128];
+        Frag2 b0, bn;
+        b0.h = zs[0]; b0.l = zs[64];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           if (ks + 1 < KS) {
-            const u32x4* s0 = zs + (size_t)((ks + 1) * 3) * 64;
-            bn.h = s0[0]; bn.m = s0[64]; bn.l = s0[128];
+            const u32x4* s0 = zs + (size_t)((ks + 1) * 2) * 64;
+            bn.h = s0[0]; bn.l = s0[64];
           }
           __builtin_amdgcn_sched_barrier(0);
-          mma6x2(acc0, acc1, wreg[ks], b0);
+          mma3x2(acc0, acc1, wreg[ks], b0);
           __builtin_amdgcn_sched_barrier(0);
           if (ks + 1 < KS) b0 = bn;
         }
       }
+      const float kD = pow2(EGt + eC + ew - 28);
       f32x16 outp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) outp[r] = acc0[r] + acc1[r];
+      for (int r = 0; r < 16; ++r) outp[r] = (acc0[r] + acc1[r]) * kD;
       const int row = TR * t + j;
       if (row < S) {
         const uint32_t off = ((uint32_t)row * (uint32_t)F + 32 * nb + 4 * kh) * 4u;
@@ -521,17 +621,28 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
         }
       }
       // ---- dW2[all units of layer 2][this wave's columns] += dz2^T a1
+      {
+        const int En = EGt + __builtin_amdgcn_readfirstlane(L.ea[nb]);
+        if (En != E2) {
+          const float f = pow2(max(E2 - En, -200));
+#pragma unroll
+          for (int mb = 0; mb < HMB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accw2[mb][r] *= f;
+          E2 = En;
+        }
+      }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const u32x4* sb = L.abT + (size_t)((nb * 2 + s) * 3) * 64 + lane;
-        Frag3 bf;
-        bf.h = sb[0]; bf.m = sb[64]; bf.l = sb[128];
+        const u32x4* sb = L.abT + (size_t)((nb * 2 + s) * 2) * 64 + lane;
+        Frag2 bf;
+        bf.h = sb[0]; bf.l = sb[64];
 #pragma unroll
         for (int mb = 0; mb < HMB; ++mb) {
-          const u32x4* s0 = L.dz2T + (size_t)((mb * 2 + s) * 3) * 64 + lane;
-          Frag3 af;
-          af.h = s0[0]; af.m = s0[64]; af.l = s0[128];
-          mma6(accw2[mb], af, bf);
+          const u32x4* s0 = L.dz2T + (size_t)((mb * 2 + s) * 2) * 64 + lane;
+          Frag2 af;
+          af.h = s0[0]; af.l = s0[64];
+          mma3(accw2[mb], af, bf);
         }
       }
     }
@@ -542,9 +653,11 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
   if constexpr (ROLE_A) {
     float* P1 = a.pw1 + pb * F * F;
 #pragma unroll
-    for (int kb = 0; kb < NW; ++kb)
+    for (int kb = 0; kb < NW; ++kb) {
+      const float f = pow2(max(E1[kb] + eC - 28, -200));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) P1[(size_t)(32 * nb + c_row(r, lane)) * F + 32 * kb + j] = accw1[kb][r];
+      for (int r = 0; r < 16; ++r) P1[(size_t)(32 * nb + c_row(r, lane)) * F + 32 * kb + j] = accw1[kb][r] * f;
+    }
     const float sb = bsum + __shfl_xor(bsum, 32, 64), sd = dsum + __shfl_xor(dsum, 32, 64);
     if (kh == 0) {
       a.pb1[pb * F + col] = sb;
@@ -567,12 +680,13 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
     }
   } else {
     float* P2 = a.pw2 + pb * H * F;
+    const float f = pow2(max(E2 + e3 - 28, -200));
 #pragma unroll
     for (int mb = 0; mb < HMB; ++mb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = 32 * mb + c_row(r, lane);
-        if (m < H) P2[(size_t)m * F + col] = accw2[mb][r];
+        if (m < H) P2[(size_t)m * F + col] = accw2[mb][r] * f;
       }
     const float sb = bsum + __shfl_xor(bsum, 32, 64);
     if (nb < HMB && kh == 0 && (int)col < H) a.pb2[pb * H + col] = sb;

@@ -173,6 +173,18 @@ __device__ __forceinline__ Frag2 split8h_scaled(const float (&v)[8], float s) {
 __device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+// acc += A * B from two-piece fragments (the dropped l * l is <= 2^-22 of the product), smallest products first
+__device__ __forceinline__ void mma3(f32x16& acc, const Frag2& a, const Frag2& b) {
+  acc = mfma_f16(a.l, b.h, acc);
+  acc = mfma_f16(a.h, b.l, acc);
+  acc = mfma_f16(a.h, b.h, acc);
+}
+// the same on two accumulators (see mma6x2); caller adds acc_lo + acc_hi
+__device__ __forceinline__ void mma3x2(f32x16& acc_lo, f32x16& acc_hi, const Frag2& a, const Frag2& b) {
+  acc_lo = mfma_f16(a.l, b.h, acc_lo);
+  acc_hi = mfma_f16(a.h, b.h, acc_hi);
+  acc_lo = mfma_f16(a.h, b.l, acc_lo);
+}
 // exponent e of a magnitude m = f * 2^e, f in [0.5, 1), floored at -100 (keeps 2^(14-e) finite).  frexp gives 0 for
 // m = 0; an all-zero tile must not look like a tile of magnitude one - a RUNNING exponent that starts from it would
 // push later operands of size 1e-8 into fp16's subnormals - so zero maps to the floor as well.
