@@ -97,6 +97,7 @@ class _NcsnLoss(torch.autograd.Function):
         for name, p in zip(_FIELDS, ps):
             setattr(w, name, ptr(p))
         w.sigmas = ptr(sigmas)
+        ctx.grad_slot = getattr(h, "_geossl_grad_slot", None)  # pretrain_GeoSSL.split_views: where dh may be written
         h = h.detach().contiguous()
         loss_e = torch.empty(S, dtype=torch.float32, device=dev)
         sv = None
@@ -115,8 +116,8 @@ class _NcsnLoss(torch.autograd.Function):
              ptr(distance.contiguous()), ptr(noise_level.contiguous()), ptr(distance_noise.contiguous()), C.byref(w),
              Fd, float(anneal_power), ptr(loss_e), C.byref(sv) if sv is not None else None, ptr(ws), st)
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        ws2 = torch.empty(256, dtype=torch.float32, device=dev)
-        call("geossl_loss_reduce", ptr(loss_e), S, ptr(sel.stats), float(out_scale), ptr(loss), ptr(ws2), 0, st)
+        # the row pass left one partial sum per block in its workspace: the mean is one small launch (NCSN.py:210-212)
+        call("geossl_loss_reduce_partials", ptr(ws), ptr(sel.stats), float(out_scale), ptr(loss), 0, st)
         if training:
             ctx.sel, ctx.ps, ctx.w, ctx.saved, ctx.h = sel, ps, w, saved, h
             ctx.params = params
@@ -155,7 +156,10 @@ class _NcsnLoss(torch.autograd.Function):
                  ptr(dz1), ptr(dfeat), ptr(demb), ptr(grow), st)
         dh = None
         if ctx.needs_input_grad[0]:  # first: the backbone's backward waits for nothing else
-            dh = torch.empty(N, Fd, dtype=torch.float32, device=dev)
+            slot = ctx.grad_slot
+            dh = slot.rows(N, Fd, torch.float32, dev) if slot is not None else None
+            if dh is None:
+                dh = torch.empty(N, Fd, dtype=torch.float32, device=dev)
             call("geossl_incidence_gather", ptr(dfeat), ptr(sel.inc_ptr), ptr(sel.inc_idx), N, Fd, ptr(dh), 0, st)
         if split:
             nfl = lib.geossl_ddm_loss_bwd_workspace_floats(S, Fd)

@@ -292,6 +292,14 @@ extern "C" int geossl_loss_reduce(const float* loss_e, int64_t S, const int64_t*
   return 0;
 }
 
+extern "C" int geossl_loss_reduce_partials(const float* partial, const int64_t* stats_divisor, float out_scale,
+                                           float* loss, int accumulate, hipStream_t stream) {
+  hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, stream, partial, GEOSSL_LOSS_PARTIALS, stats_divisor, out_scale,
+                     loss, accumulate);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
 static inline void small_plan(int64_t S, int* chunk, int* nblk) {
   int64_t c = (S + 2047) / 2048;  // eight blocks per CU: the row loop of a thread is a chain of dependent batches
   if (c < 64) c = 64;

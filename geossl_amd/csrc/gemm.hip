@@ -444,30 +444,7 @@ namespace geossl {
 // several reductions in one launch (tn.h: ReduceMulti); same arithmetic and order as k_reduce_partials
 __global__ __launch_bounds__(256) void k_reduce_multi(ReduceMulti m, int nblk, int accumulate) {
   __shared__ float red[4][64];
-  int g = 0;
-  while (g + 1 < m.nseg && (int)blockIdx.x >= m.xoff[g + 1]) ++g;
-  const ReduceSeg& sg = m.seg[g];
-  const int z = blockIdx.y;
-  float* out = sg.out[z];
-  if (out == nullptr) return;
-  const int len = sg.len;
-  const float* p = sg.partial + (size_t)z * nblk * len;
-  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int i = ((int)blockIdx.x - m.xoff[g]) * 64 + lane;
-  const int per = (nblk + 3) / 4, b0 = slice * per, b1 = min(nblk, b0 + per);
-  float s = 0.0f;
-  if (i < len) s = kahan_sum_strided(p + i, b0, b1, len);
-  red[slice][lane] = s;
-  __syncthreads();
-  if (slice == 0 && i < len) {
-    const size_t o = (size_t)(i / sg.ncols) * sg.ld + (size_t)(i % sg.ncols) * sg.cstride;
-    float v = accumulate ? out[o] : 0.0f;
-    v += red[0][lane];
-    v += red[1][lane];
-    v += red[2][lane];
-    v += red[3][lane];
-    out[o] = v;
-  }
+  reduce_multi_block(m, nblk, accumulate, red);
 }
 // block = 64 outputs x 4 slices of the partial list; the four slice sums are combined in slice order.
 __global__ __launch_bounds__(256) void k_reduce_partials(GeosslReduceBatch batch, const float* __restrict__ partial,

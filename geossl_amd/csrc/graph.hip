@@ -254,6 +254,38 @@ __global__ void k_pair_distance(const float* __restrict__ pos, const int64_t* __
   }
 }
 
+// The two views of a DDM step in one launch (pretrain_GeoSSL.py:68-74,199-205): pos2 = [pos ; pos + noise] (the fused
+// batch of both views) and the super-edge lengths in either view.  Same arithmetic as k_axpy (alpha = 1) followed by
+// k_pair_distance on each half: the perturbed coordinates are rounded to fp32 before the differences are taken.
+__global__ void k_ddm_views(const float* __restrict__ pos, const float* __restrict__ noise,
+                            const int64_t* __restrict__ sei0, const int64_t* __restrict__ sei1, int64_t n3, int S,
+                            float* __restrict__ pos2, float* __restrict__ d01, float* __restrict__ d02) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = t; i < n3; i += nt) {
+    const float a = pos[i];
+    pos2[i] = a;
+    pos2[n3 + i] = add_rn(a, noise[i]);
+  }
+  for (int64_t s = t; s < S; s += nt) {
+    const int64_t u = sei0[s], v = sei1[s];
+    const float ux = pos[3 * u], uy = pos[3 * u + 1], uz = pos[3 * u + 2];
+    const float vx = pos[3 * v], vy = pos[3 * v + 1], vz = pos[3 * v + 2];
+    d01[s] = sqrtf(norm2_rn(ux - vx, uy - vy, uz - vz));
+    const float px = add_rn(ux, noise[3 * u]), py = add_rn(uy, noise[3 * u + 1]), pz = add_rn(uz, noise[3 * u + 2]);
+    const float qx = add_rn(vx, noise[3 * v]), qy = add_rn(vy, noise[3 * v + 1]), qz = add_rn(vz, noise[3 * v + 2]);
+    d02[s] = sqrtf(norm2_rn(px - qx, py - qy, pz - qz));
+  }
+}
+
+// two device-to-device copies in one launch (the per-step refresh of a replayed graph's inputs: atom types and
+// positions); sizes in bytes, multiples of 4, buffers 4-byte aligned
+__global__ void k_copy2(uint32_t* __restrict__ d0, const uint32_t* __restrict__ s0, int64_t n0,
+                        uint32_t* __restrict__ d1, const uint32_t* __restrict__ s1, int64_t n1) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = t; i < n0; i += nt) d0[i] = s0[i];
+  for (int64_t i = t; i < n1; i += nt) d1[i] = s1[i];
+}
+
 __global__ void k_axpy(const float* __restrict__ a, const float* __restrict__ b, float alpha, int64_t n,
                        float* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -355,6 +387,28 @@ extern "C" int geossl_pair_distance(const float* pos, const int64_t* sei0, const
                                     hipStream_t stream) {
   if (S <= 0) return 0;
   hipLaunchKernelGGL(k_pair_distance, dim3(grid1d(S, 256)), dim3(256), 0, stream, pos, sei0, sei1, (int)S, out);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_ddm_views(const float* pos, const float* noise, const int64_t* sei0, const int64_t* sei1, int64_t N,
+                                int64_t S, float* pos2, float* d01, float* d02, hipStream_t stream) {
+  if (N <= 0) return 0;
+  const int64_t work = 3 * N > S ? 3 * N : S;
+  hipLaunchKernelGGL(k_ddm_views, dim3(grid1d(work, 256)), dim3(256), 0, stream, pos, noise, sei0, sei1, 3 * N, (int)S,
+                     pos2, d01, d02);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_copy2(void* dst0, const void* src0, int64_t bytes0, void* dst1, const void* src1, int64_t bytes1,
+                            hipStream_t stream) {
+  if ((bytes0 | bytes1) & 3) return (int)hipErrorInvalidValue;
+  if (((uintptr_t)dst0 | (uintptr_t)src0 | (uintptr_t)dst1 | (uintptr_t)src1) & 3) return (int)hipErrorInvalidValue;
+  const int64_t n0 = bytes0 / 4, n1 = bytes1 / 4, work = n0 > n1 ? n0 : n1;
+  if (work <= 0) return 0;
+  hipLaunchKernelGGL(k_copy2, dim3(grid1d(work, 256)), dim3(256), 0, stream, (uint32_t*)dst0, (const uint32_t*)src0, n0,
+                     (uint32_t*)dst1, (const uint32_t*)src1, n1);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

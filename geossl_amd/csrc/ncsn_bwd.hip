@@ -52,12 +52,6 @@
 
 using namespace geossl;
 
-namespace geossl {
-// ddm.hip: sums the [nblk][H + 3F + 2] partials of the narrow gradients into o3_w, in_w2, in_w1, in_b1, o3_b, in_b2
-int launch_ncsn_small_reduce(const float* partial, int nblk, int F, const GeosslNcsnGrads& g, int accumulate,
-                             hipStream_t stream);
-}
-
 namespace {
 
 constexpr int TR = 32;  // rows per tile
@@ -712,6 +706,35 @@ __global__ __launch_bounds__(128 * NW) void k_ncsn_bwd_fused(NcsnFusedArgs a) {
   else ncsn_bwd_body<NW, false>(a);
 }
 
+// The five fixed-order reductions of the block partials (k_reduce_multi's arithmetic) and, in the blocks behind them, the
+// narrow gradients (k_ncsn_small_reduce's: one wave per output scalar, lanes stride over the blocks, fixed butterfly) -
+// one launch per head instead of two.
+__global__ __launch_bounds__(256) void k_ncsn_reduce_all(ReduceMulti m, int nblk, int accumulate,
+                                                         const float* __restrict__ psm, int F, GeosslNcsnGrads g) {
+  __shared__ float red[4][64];
+  const int mb = m.xoff[m.nseg];
+  if ((int)blockIdx.x < mb) {
+    reduce_multi_block(m, nblk, accumulate, red);
+    return;
+  }
+  const int H = F / 2, len = H + 3 * F + 2;
+  const int i = ((int)blockIdx.x - mb) * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= len) return;
+  float s = 0.0f;
+  for (int b = lane; b < nblk; b += 64) s += psm[(size_t)b * len + i];
+  s = wave_sum(s);
+  if (lane == 0) {
+    float* dst;
+    if (i < H) dst = g.o3_w + i;
+    else if (i < H + F) dst = g.in_w2 + (i - H);
+    else if (i < H + 2 * F) dst = g.in_w1 + (i - H - F);
+    else if (i < H + 3 * F) dst = g.in_b1 + (i - H - 2 * F);
+    else if (i == H + 3 * F) dst = g.o3_b;
+    else dst = g.in_b2;
+    *dst = accumulate ? *dst + s : s;
+  }
+}
+
 inline int fused_blocks(int64_t S) {
   const int64_t ntiles = (S + TR - 1) / TR;
   return (int)(ntiles < 256 ? ntiles : 256);  // one block per CU
@@ -768,7 +791,8 @@ extern "C" int geossl_ddm_loss_bwd_fused(const float* h, const int64_t* sei0, co
   rm.add(a.pb1, F, F, F, 1, o1b, 1);
   rm.add(a.pw2, H * F, F, F, 1, o2w, 1);
   rm.add(a.pb2, H, H, H, 1, o2b, 1);
-  hipLaunchKernelGGL(k_reduce_multi, dim3(rm.blocks(), 1), dim3(256), 0, stream, rm, nb, accumulate);
+  hipLaunchKernelGGL(k_ncsn_reduce_all, dim3(rm.blocks() + (H + 3 * F + 2 + 3) / 4, 1), dim3(256), 0, stream, rm, nb,
+                     accumulate, a.psm, F, *grads);
   GEOSSL_CHECK_LAUNCH();
-  return launch_ncsn_small_reduce(a.psm, nb, F, *grads, accumulate, stream);
+  return 0;
 }

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(512) void k_ncsn_fwd(const float* __restrict__ h, c
                                                   const int64_t* __restrict__ noise_level,
                                                   const float* __restrict__ dist_noise, GeosslNcsnWeights w,
                                                   float anneal_power, float* __restrict__ loss_e,
-                                                  GeosslNcsnSaved sv) {
+                                                  GeosslNcsnSaved sv, float* __restrict__ loss_part) {
   constexpr int F = 32 * NMB, H = F / 2, HMB = (H + 31) / 32, HP = 32 * HMB, KS = F / 16;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
   u32x4* W1f = reinterpret_cast<u32x4*>(smem_raw);  // [NMB][KS][3][64]: A[m = n][k], k = 16ks + 8kh + e
@@ -43,8 +43,10 @@ __global__ __launch_bounds__(512) void k_ncsn_fwd(const float* __restrict__ h, c
   float* iw1 = w3s + HP;   // [F]
   float* ib1 = iw1 + F;    // [F]
   float* iw2 = ib1 + F;    // [F]
+  float* lred = iw2 + F;   // [8]  loss sums of the block's waves
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
   const int nrb = (S + 31) / 32;
+  float lsum = 0.0f;       // loss of this lane's rows (lanes of the lower half-wave)
   auto load_row = [&](int rb) {
     RowIn r;
     const int rowc = min(32 * rb + j, S - 1);
@@ -245,13 +247,28 @@ __global__ __launch_bounds__(512) void k_ncsn_fwd(const float* __restrict__ h, c
     const float diff = score - target;
     const float pw = powf(in.sigma, anneal_power);
     if (valid && kh == 0) {
-      loss_e[row] = (0.5f * (diff * diff)) * pw;  // :209
+      const float le = (0.5f * (diff * diff)) * pw;  // :209
+      loss_e[row] = le;
+      lsum += le;
       if (sv.pd != nullptr) {
         sv.pd[row] = pd;
         sv.emb[row] = emb;
         sv.gscale[row] = diff * pw * inv_sigma;  // d loss_e / d out
       }
     }
+  }
+  // one loss partial per block (geossl_loss_reduce_partials sums them in block order): waves in order, fixed butterfly
+  if (loss_part != nullptr) {
+    lsum = wave_sum(lsum);
+    if (lane == 0) lred[wave] = lsum;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.0f;
+      for (int i = 0; i < 8; ++i) t += lred[i];
+      loss_part[blockIdx.x] = t;
+    }
+    if (blockIdx.x == 0)
+      for (int i = (int)gridDim.x + tid; i < GEOSSL_LOSS_PARTIALS; i += 512) loss_part[i] = 0.0f;
   }
 }
 
@@ -461,25 +478,24 @@ inline int row_blocks_grid(int64_t S) {
 
 }  // namespace
 
-extern "C" int64_t geossl_ddm_loss_fwd_workspace_floats(int F) { return 0; }
+extern "C" int64_t geossl_ddm_loss_fwd_workspace_floats(int F) { return GEOSSL_LOSS_PARTIALS; }
 
 extern "C" int geossl_ddm_loss_fwd(const float* h, const int64_t* batch, const int64_t* sei0, const int64_t* sei1,
                                    int64_t S, const float* distance, const int64_t* noise_level,
                                    const float* distance_noise, const GeosslNcsnWeights* w, int F, float anneal_power,
                                    float* loss_e, const GeosslNcsnSaved* saved, float* workspace, hipStream_t stream) {
-  (void)workspace;
   if (S <= 0) return 0;
   if (F != 32 && F != 64 && F != 128) return (int)hipErrorInvalidValue;
   GeosslNcsnSaved sv = {nullptr, nullptr, nullptr, nullptr, nullptr};
   if (saved != nullptr) sv = *saved;
   const int NMB = F / 32, H = F / 2, HMB = (H + 31) / 32, KS = F / 16;
-  const size_t lds = (size_t)(NMB + HMB) * KS * 3 * 1024 + (size_t)(5 * F + 2 * 32 * HMB) * sizeof(float);
+  const size_t lds = (size_t)(NMB + HMB) * KS * 3 * 1024 + (size_t)(5 * F + 2 * 32 * HMB + 8) * sizeof(float);
   dim3 grid(row_blocks_grid(S));
 #define LAUNCH(NMBV)                                                                                              \
   do {                                                                                                            \
     allow_big_lds(&k_ncsn_fwd<NMBV>);                                                                             \
     hipLaunchKernelGGL((k_ncsn_fwd<NMBV>), grid, dim3(512), lds, stream, h, batch, sei0, sei1, (int)S, distance,  \
-                       noise_level, distance_noise, *w, anneal_power, loss_e, sv);                                \
+                       noise_level, distance_noise, *w, anneal_power, loss_e, sv, workspace);                     \
   } while (0)
   if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
 #undef LAUNCH

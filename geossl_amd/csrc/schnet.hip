@@ -541,15 +541,18 @@ __global__ void k_embedding_fwd(const int64_t* __restrict__ z, int64_t zs, const
 
 #define GEOSSL_EMB_CHUNKS 512
 // block = one chunk of rows, thread f owns feature column f of a [classes][F] accumulator table in LDS (thread-private
-// columns: no barriers, rows added in row order); every row of dh is read once, sixteen rows in flight
+// columns: no barriers, rows added in row order); every row of dh is read once, sixteen rows in flight.  Only the
+// classes [cmin, cmax] a chunk has met leave the block (QM9 uses 5 of the 119 rows of the table: a chunk's whole table
+// is 60 KB, its occupied band 4.5 KB), the band is recorded behind the partial tables for the second stage.
 __global__ void k_embedding_bwd_partial(const int64_t* __restrict__ z, int64_t zs, const float* __restrict__ dh,
-                                        int64_t N, int F, int C, float* __restrict__ partial) {
+                                        int64_t N, int F, int C, float* __restrict__ partial, int2* __restrict__ band) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int chunk = blockIdx.x, f = threadIdx.x;
   const int64_t per = (N + GEOSSL_EMB_CHUNKS - 1) / GEOSSL_EMB_CHUNKS;
   const int64_t lo = chunk * per, hi = min((int64_t)N, lo + per);
   if (f >= F) return;
   for (int c = 0; c < C; ++c) smem[c * F + f] = 0.0f;
+  int cmin = C, cmax = -1;  // the same in every thread
   constexpr int U = 16;
   for (int64_t a0 = lo; a0 < hi; a0 += U) {
     float v[U];
@@ -562,9 +565,61 @@ __global__ void k_embedding_bwd_partial(const int64_t* __restrict__ z, int64_t z
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (a0 + u < hi && cls[u] >= 0 && cls[u] < C) smem[cls[u] * F + f] += v[u];
+      if (a0 + u < hi && cls[u] >= 0 && cls[u] < C) {
+        smem[cls[u] * F + f] += v[u];
+        cmin = min(cmin, cls[u]);
+        cmax = max(cmax, cls[u]);
+      }
   }
-  for (int c = 0; c < C; ++c) partial[((size_t)chunk * C + c) * F + f] = smem[c * F + f];
+  for (int c = cmin; c <= cmax; ++c) partial[((size_t)chunk * C + c) * F + f] = smem[c * F + f];
+  if (f == 0) band[chunk] = make_int2(cmin, cmax);
+}
+// dtable[c][f] (+)= sum over the chunks whose band holds c, in chunk order: block = (class, 64 columns) x 4 slices of the
+// chunk list (one wave each).  A wave first lists the chunks of its slice that hold the class (ballot over the bands,
+// ascending), then sums their rows compensated like kahan_sum_strided; the four slice sums are combined in slice order.
+__global__ __launch_bounds__(256) void k_embedding_bwd_reduce(const float* __restrict__ partial,
+                                                              const int2* __restrict__ band, int C, int F,
+                                                              float* __restrict__ dtable, int accumulate) {
+  constexpr int PER = GEOSSL_EMB_CHUNKS / 4;
+  static_assert(PER == 128, "two chunks per lane");
+  __shared__ float red[4][64];
+  __shared__ int hits[4][PER];
+  const int c = blockIdx.y, lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + lane;
+  int n = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int b = slice * PER + 64 * h + lane;
+    const int2 r = band[b];
+    const bool hit = c >= r.x && c <= r.y;
+    const unsigned long long m = __ballot(hit);
+    if (hit) hits[slice][n + __popcll(m & ((1ull << lane) - 1ull))] = b;
+    n += __popcll(m);
+  }
+  __builtin_amdgcn_wave_barrier();
+  float s = 0.0f;
+  if (f < F) {
+#pragma clang fp reassociate(off) contract(off)
+    float k = 0.0f;
+    const float* p = partial + (size_t)c * F + f;
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) {
+      const float y = p[(size_t)hits[slice][i] * C * F] - k;
+      const float t = s + y;
+      k = (t - s) - y;
+      s = t;
+    }
+  }
+  red[slice][lane] = s;
+  __syncthreads();
+  if (slice == 0 && f < F) {
+    float v = accumulate ? dtable[(size_t)c * F + f] : 0.0f;
+    v += red[0][lane];
+    v += red[1][lane];
+    v += red[2][lane];
+    v += red[3][lane];
+    dtable[(size_t)c * F + f] = v;
+  }
 }
 // ----------------------------------------------------------------------------------------------- readout
 __global__ void k_segment_reduce_fwd(const float* __restrict__ h, const int32_t* __restrict__ mol_ptr, int B, int F,
@@ -748,24 +803,20 @@ extern "C" int geossl_embedding_fwd(const int64_t* z, int64_t z_stride, const fl
 }
 
 extern "C" int64_t geossl_embedding_bwd_workspace_floats(int num_classes, int F) {
-  return (int64_t)GEOSSL_EMB_CHUNKS * num_classes * F;
+  return (int64_t)GEOSSL_EMB_CHUNKS * num_classes * F + 2 * GEOSSL_EMB_CHUNKS;  // partial tables, then the class bands
 }
 
 extern "C" int geossl_embedding_bwd(const int64_t* z, int64_t z_stride, const float* dh, int num_classes, int64_t N,
                                     int F, float* dtable, float* workspace, int accumulate, hipStream_t stream) {
   if (num_classes <= 0) return 0;
   if (F > 256 || (size_t)num_classes * F * sizeof(float) > 160 * 1024) return (int)hipErrorInvalidValue;
+  int2* band = reinterpret_cast<int2*>(workspace + (size_t)GEOSSL_EMB_CHUNKS * num_classes * F);
   allow_big_lds(&k_embedding_bwd_partial);
   hipLaunchKernelGGL(k_embedding_bwd_partial, dim3(GEOSSL_EMB_CHUNKS), dim3((F + 63) / 64 * 64),
-                     (size_t)num_classes * F * sizeof(float), stream, z, z_stride, dh, N, F, num_classes, workspace);
+                     (size_t)num_classes * F * sizeof(float), stream, z, z_stride, dh, N, F, num_classes, workspace, band);
   GEOSSL_CHECK_LAUNCH();
-  // fixed-order sum of the per-chunk tables: 64 outputs x 4 slices of the chunk list per block, compensated (tn.h)
-  const int len = num_classes * F;
-  GeosslReduceBatch rb;
-  for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = nullptr;
-  rb.out[0] = dtable;
-  hipLaunchKernelGGL(geossl::k_reduce_partials, dim3((len + 63) / 64, 1), dim3(256), 0, stream, rb, workspace,
-                     GEOSSL_EMB_CHUNKS, len, len, len, 1, accumulate);
+  hipLaunchKernelGGL(k_embedding_bwd_reduce, dim3((F + 63) / 64, num_classes), dim3(256), 0, stream, workspace, band,
+                     num_classes, F, dtable, accumulate);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

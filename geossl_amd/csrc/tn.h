@@ -37,6 +37,34 @@ struct ReduceMulti {
   int blocks() const { return xoff[nseg]; }
 };
 __global__ void k_reduce_multi(ReduceMulti m, int nblk, int accumulate);
+// the work of one 256-thread block of k_reduce_multi (64 outputs x 4 slices of the partial list, compensated; the four
+// slice sums are combined in slice order); kernels that append reductions of their own to the batch call it
+__device__ __forceinline__ void reduce_multi_block(const ReduceMulti& m, int nblk, int accumulate, float (*red)[64]) {
+  int g = 0;
+  while (g + 1 < m.nseg && (int)blockIdx.x >= m.xoff[g + 1]) ++g;
+  const ReduceSeg& sg = m.seg[g];
+  const int z = blockIdx.y;
+  float* out = sg.out[z];
+  if (out == nullptr) return;
+  const int len = sg.len;
+  const float* p = sg.partial + (size_t)z * nblk * len;
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int i = ((int)blockIdx.x - m.xoff[g]) * 64 + lane;
+  const int per = (nblk + 3) / 4, b0 = slice * per, b1 = min(nblk, b0 + per);
+  float s = 0.0f;
+  if (i < len) s = kahan_sum_strided(p + i, b0, b1, len);
+  red[slice][lane] = s;
+  __syncthreads();
+  if (slice == 0 && i < len) {
+    const size_t o = (size_t)(i / sg.ncols) * sg.ld + (size_t)(i % sg.ncols) * sg.cstride;
+    float v = accumulate ? out[o] : 0.0f;
+    v += red[0][lane];
+    v += red[1][lane];
+    v += red[2][lane];
+    v += red[3][lane];
+    out[o] = v;
+  }
+}
 
 inline int64_t tn_workspace_floats(int64_t R, int M, int N, int nprob) {
   int chunk, nblk;

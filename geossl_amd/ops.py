@@ -259,6 +259,18 @@ def pair_distance(pos, sei0, sei1):
     return out
 
 
+def ddm_views(pos, noise, sei0, sei1):
+    """Both views of a DDM step in one launch (pretrain_GeoSSL.py:68-74,199-205): ([pos ; pos + noise] as one [2N, 3]
+    tensor, super-edge lengths of the clean view [S, 1], of the perturbed view [S, 1])."""
+    pos, noise = _f32(pos), _f32(noise)
+    N, S = pos.size(0), sei0.numel()
+    pos2 = torch.empty(2 * N, 3, dtype=torch.float32, device=pos.device)
+    d01 = torch.empty(S, 1, dtype=torch.float32, device=pos.device)
+    d02 = torch.empty(S, 1, dtype=torch.float32, device=pos.device)
+    call("geossl_ddm_views", ptr(pos), ptr(noise), ptr(sei0), ptr(sei1), N, S, ptr(pos2), ptr(d01), ptr(d02), stream())
+    return pos2, d01, d02
+
+
 def add_scaled(a, b, alpha=1.0):
     a, b = _f32(a), _f32(b)
     out = torch.empty_like(a)

@@ -44,7 +44,10 @@ def perturb(x, positions, mu, sigma, noise=None, device_noise=False, generator=N
 class _SplitViews(torch.autograd.Function):
     """h of the fused (clean ‖ perturbed) batch -> the two per-view halves.  Plain slicing would make autograd pad each
     half's gradient to the full shape and add the two (two fills, two copies and an add over 2N x F); the backward
-    here is one concatenation."""
+    here is one concatenation - or nothing at all when the two gradients already lie behind one another in one buffer,
+    which is where the heads put them when the halves carry a `GradSlot` (`split_views`)."""
+
+    STATS = {"adjacent": 0, "cat": 0}  # how the backward joined the halves (tests)
 
     @staticmethod
     def forward(ctx, h, n):
@@ -53,7 +56,44 @@ class _SplitViews(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g1, g2):
+        if (g1.is_contiguous() and g2.is_contiguous() and g1.dtype == g2.dtype and g1.dim() == 2
+                and g1.untyped_storage().data_ptr() == g2.untyped_storage().data_ptr()
+                and g2.storage_offset() == g1.storage_offset() + g1.numel()):
+            _SplitViews.STATS["adjacent"] += 1
+            return g1.new_empty(0).set_(g1.untyped_storage(), g1.storage_offset(),
+                                        (g1.size(0) + g2.size(0), g1.size(1)), (g1.size(1), 1)), None
+        _SplitViews.STATS["cat"] += 1
         return torch.cat([g1, g2]), None
+
+
+class GradSlot:
+    """Where a consumer of one half of a split tensor may put that half's gradient: rows [lo, hi) of a buffer the two
+    halves share (allocated by whoever asks first).  A head that finds the slot on its input (`_geossl_grad_slot`,
+    NCSN._NcsnLoss) writes its gradient there and returns that view; anything else ignores it and `_SplitViews.backward`
+    concatenates as before."""
+
+    def __init__(self, pair, lo, hi, total):
+        self.pair, self.lo, self.hi, self.total = pair, lo, hi, total
+
+    def rows(self, n, width, dtype, device):
+        if n != self.hi - self.lo:
+            return None
+        buf, given = self.pair.get("buf"), self.pair.setdefault("given", set())
+        if (buf is None or self.lo in given  # a second backward through the same graph: never into a buffer handed out
+                or buf.shape != (self.total, width) or buf.dtype != dtype or buf.device != device):
+            buf = torch.empty(self.total, width, dtype=dtype, device=device)
+            self.pair["buf"] = buf
+            given.clear()
+        given.add(self.lo)
+        return buf[self.lo:self.hi]
+
+
+def split_views(h, n):
+    a, b = _SplitViews.apply(h, n)
+    pair = {}
+    a._geossl_grad_slot = GradSlot(pair, 0, n, h.size(0))
+    b._geossl_grad_slot = GradSlot(pair, n, h.size(0), h.size(0))
+    return a, b
 
 
 def _two_view_batch(batch_vec, num_graphs):
@@ -113,39 +153,43 @@ def _do_ddm_eager(args, batch, model, mu, sigma, heads, noise, fuse_views, devic
     positions = batch.positions
     x_01 = batch.x[:, 0]
     positions_01 = positions
-    x_02, positions_02 = perturb(x_01, positions, mu, sigma, noise=noise.get("pos_noise"), device_noise=device_noise)
-
-    if args.model_3d == "schnet":
-        if fuse_views:
-            num_graphs = batch.num_graphs
-            b2, lay2 = _two_view_batch(batch.batch, num_graphs)
-            N = positions.size(0)
+    super_edge_index = batch.super_edge_index
+    if args.model_3d not in ("schnet", "painn"):
+        raise Exception("3D model {} not included.".format(args.model_3d))
+    if fuse_views:
+        # perturb (:68-74), the concatenation of the two views and both sets of super-edge lengths (:199-205) in one
+        # launch; the draw itself is perturb's (same generator, same place in the order of draws)
+        pos_noise = noise.get("pos_noise")
+        if pos_noise is None:
+            if device_noise:
+                pos_noise = torch.empty_like(positions).normal_(mu, sigma)
+            else:
+                pos_noise = torch.normal(mu, sigma, size=positions.size()).to(positions.device)
+        N = positions.size(0)
+        pos2, distance_01, distance_02 = ops.ddm_views(positions, pos_noise, super_edge_index[0], super_edge_index[1])
+        x2 = torch.cat([x_01, x_01])
+        if args.model_3d == "schnet":
+            b2, lay2 = _two_view_batch(batch.batch, batch.num_graphs)
             # the readout is dead compute in this step (`_` at pretrain_GeoSSL.py:187): not evaluated
-            _, h = model(torch.cat([x_01, x_02]), torch.cat([positions_01, positions_02]), b2, return_latent=True,
-                         layout=lay2, latent_only=True)
-            molecule_3D_repr_01, molecule_3D_repr_02 = _SplitViews.apply(h, N)
+            _, h = model(x2, pos2, b2, return_latent=True, layout=lay2, latent_only=True)
         else:
+            b2, e2 = _two_view_edges(batch.batch, batch.radius_edge_index, batch.num_graphs)
+            _, h = model(x2, pos2, e2, b2, return_latent=True)
+        molecule_3D_repr_01, molecule_3D_repr_02 = split_views(h, N)
+    else:
+        x_02, positions_02 = perturb(x_01, positions, mu, sigma, noise=noise.get("pos_noise"), device_noise=device_noise)
+        if args.model_3d == "schnet":
             _, molecule_3D_repr_01 = model(x_01, positions_01, batch.batch, return_latent=True)
             _, molecule_3D_repr_02 = model(x_02, positions_02, batch.batch, return_latent=True)
-    elif args.model_3d == "painn":
-        if fuse_views:
-            b2, e2 = _two_view_edges(batch.batch, batch.radius_edge_index, batch.num_graphs)
-            N = positions.size(0)
-            _, h = model(torch.cat([x_01, x_02]), torch.cat([positions_01, positions_02]), e2, b2, return_latent=True)
-            molecule_3D_repr_01, molecule_3D_repr_02 = _SplitViews.apply(h, N)
         else:
             _, molecule_3D_repr_01 = model(x_01, positions_01, batch.radius_edge_index, batch.batch, return_latent=True)
             _, molecule_3D_repr_02 = model(x_02, positions_02, batch.radius_edge_index, batch.batch, return_latent=True)
-    else:
-        raise Exception("3D model {} not included.".format(args.model_3d))
+        distance_01 = ops.pair_distance(positions_01, super_edge_index[0], super_edge_index[1])  # :199-201
+        distance_02 = ops.pair_distance(positions_02, super_edge_index[0], super_edge_index[1])  # :203-205
 
     if getattr(args, "normalize", False):  # :193-195
         molecule_3D_repr_01 = ops.row_normalize(molecule_3D_repr_01)
         molecule_3D_repr_02 = ops.row_normalize(molecule_3D_repr_02)
-
-    super_edge_index = batch.super_edge_index
-    distance_01 = ops.pair_distance(positions_01, super_edge_index[0], super_edge_index[1])  # :199-201
-    distance_02 = ops.pair_distance(positions_02, super_edge_index[0], super_edge_index[1])  # :203-205
 
     # cross-view pairing (:207-208); each head returns 0.5 * its loss so the sum is (l1 + l2) / 2 (:210)
     loss_01 = n1(batch, molecule_3D_repr_01, distance_02, noise_level=noise.get("noise_level_1"),
@@ -354,8 +398,14 @@ class StepGraphs:
     @staticmethod
     def refresh(g, batch, noise=None):
         """x, positions and (if given) the five noise tensors of this step into the graph's static inputs."""
-        g["batch"].x.copy_(batch.x)
-        g["batch"].positions.copy_(batch.positions)
+        dx, dp, sx, sp = g["batch"].x, g["batch"].positions, batch.x, batch.positions
+        if (sx.is_cuda and sp.is_cuda and sx.dtype == dx.dtype and sp.dtype == dp.dtype and sx.shape == dx.shape
+                and sp.shape == dp.shape and all(t_.is_contiguous() for t_ in (dx, dp, sx, sp))):
+            call("geossl_copy2", ptr(dx), ptr(sx), dx.numel() * dx.element_size(), ptr(dp), ptr(sp),
+                 dp.numel() * dp.element_size(), stream())  # one launch instead of two copies
+        else:
+            dx.copy_(sx)
+            dp.copy_(sp)
         if noise is not None:
             for k in _NOISE_KEYS:
                 g["noise"][k].copy_(noise[k])
@@ -677,7 +727,7 @@ class DDMTrainer:
         st = self.model.__dict__.get("_geossl_status")
         if st is not None:  # deferred index check of the backbone (a replayed graph cannot queue the host copy itself)
             st.poll()
-            st.arm()
+            st.arm(every=8)  # an out-of-range atom type surfaces up to eight steps late
         scale = self.reduce()
         self.opt.step(grad_scale=scale)
         return loss

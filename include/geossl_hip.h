@@ -27,6 +27,7 @@ extern "C" {
 #define GEOSSL_ABI_VERSION 1
 #define GEOSSL_MAX_L 12 /* max interaction blocks handled by the batched-by-layer kernels */
 #define GEOSSL_TN_MAX 32 /* max problems in one batched weight-gradient launch */
+#define GEOSSL_LOSS_PARTIALS 256 /* block partials of the per-row loss that geossl_ddm_loss_fwd leaves in its workspace */
 
 /* epilogue flags of geossl_linear */
 #define GEOSSL_EPI_BIAS 1      /* + bias[n] */
@@ -257,6 +258,15 @@ int geossl_axpy(const float* a, const float* b, float alpha, int64_t n, float* o
 /* super-edge length (:199-205): out[s] = sqrt(sum((pos[u]-pos[v])^2)) */
 int geossl_pair_distance(const float* pos, const int64_t* sei0, const int64_t* sei1, int64_t S, float* out,
                          hipStream_t stream);
+/* batch.to(device)-side plumbing of a replayed step (:248): two device-to-device copies (atom types and positions of
+ * the next batch into a captured graph's input buffers) as one launch; byte counts, multiples of 4 */
+int geossl_copy2(void* dst0, const void* src0, int64_t bytes0, void* dst1, const void* src1, int64_t bytes1,
+                 hipStream_t stream);
+/* both views at once (:68-74 and :199-205 for a fused two-view batch): pos2 [2N][3] = [pos ; pos + noise], d01 / d02 [S] =
+ * super-edge lengths in the clean / perturbed view - geossl_axpy, the concatenation and two geossl_pair_distance calls
+ * in one launch, same arithmetic */
+int geossl_ddm_views(const float* pos, const float* noise, const int64_t* sei0, const int64_t* sei1, int64_t N, int64_t S,
+                     float* pos2, float* d01, float* d02, hipStream_t stream);
 /* per-batch bookkeeping for the NCSN head: se_ptr[B+1] = first super-edge of every molecule (needs
  * batch[sei0] non-decreasing and both ends in one molecule: true for collated batches),
  * stats = {max(edge2graph)+1 (the divisor of NCSN.py:212), 1 if the ordering assumption fails}; and the
@@ -294,6 +304,8 @@ typedef struct {
 } GeosslNcsnSaved;
 /* K5 forward: loss_e[S] (NCSN.py:209) from node features h [N][F], distances d[S], the two random draws
  * noise_level[B] (i64, :190) and distance_noise[S] (:194) given as inputs.                                   */
+/* workspace (GEOSSL_LOSS_PARTIALS floats, may be NULL): receives one partial sum of loss_e per block of the launch, zeros
+ * behind them - geossl_loss_reduce_partials finishes the sum without another pass over loss_e */
 int64_t geossl_ddm_loss_fwd_workspace_floats(int F);
 int geossl_ddm_loss_fwd(const float* h, const int64_t* batch, const int64_t* sei0, const int64_t* sei1, int64_t S,
                         const float* distance, const int64_t* noise_level, const float* distance_noise,
@@ -304,6 +316,9 @@ int geossl_ddm_loss_fwd(const float* h, const int64_t* batch, const int64_t* sei
 int64_t geossl_loss_reduce_workspace_floats(int64_t S);
 int geossl_loss_reduce(const float* loss_e, int64_t S, const int64_t* stats_divisor, float out_scale, float* loss,
                        float* workspace, int accumulate, hipStream_t stream);
+/* the same loss from the block partials geossl_ddm_loss_fwd left in its workspace (fixed order: blocks in sequence) */
+int geossl_loss_reduce_partials(const float* partial, const int64_t* stats_divisor, float out_scale, float* loss,
+                                int accumulate, hipStream_t stream);
 /* K5 backward.  gout = upstream gradient of the head's scalar loss (device scalar, may be NULL = 1),
  * row pass: dz1 [S][F] (grad at output_mlp hidden 1 pre-activation), dfeat [S][F] (grad w.r.t. h_u + h_v),
  * demb[S]; then weight gradients; then dh[a] (+)= sum of dfeat over incident super-edges (fixed order).      */
