@@ -150,7 +150,9 @@ class PaiNN(nn.Module):
             ps += [n[0].weight, n[0].bias, n[1].weight, n[1].bias, blk.mu_channel_mix.weight]
         return ps
 
-    def forward(self, x, positions, radius_edge_index, batch, return_latent=False):
+    def forward(self, x, positions, radius_edge_index, batch, return_latent=False, latent_only=False):
+        """painn.py:216-269.  `latent_only` (with return_latent): the readout is not evaluated and None is returned in
+        its place - the DDM step drops it (pretrain_GeoSSL.py:187)."""
         _lib.require_cuda(x, positions, radius_edge_index, batch)
         if self.share_filters or (self.n_interactions > 1 and self.interactions[0] is self.interactions[1]):
             raise NotImplementedError("shared_filters / shared_interactions are off the GeoSSL path")
@@ -185,6 +187,8 @@ class PaiNN(nn.Module):
                                  and not os.environ.get("GEOSSL_PAINN_VECTOR")))
         q = _PaiNNCore.apply(atomic_numbers, positions.contiguous(), el, cfg, *self._params())
         status.arm()
+        if return_latent and latent_only:
+            return None, q
         from .schnet import _SegmentReduce
         h = _SegmentReduce.apply(q, lay, self.readout)  # painn.py:266
         if return_latent:
@@ -231,9 +235,11 @@ class _PaiNNCore(torch.autograd.Function):
             c0w, c0b, c1w, c1b = inter[l]
             i0w, i0b, i1w, i1b, mw = mix[l]
             blocks += [c0w] + [c1w[c * F_:(c + 1) * F_] for c in range(3)] + [mw[:F_], mw[F_:]] + \
-                      [i0w[:, :F_].contiguous(), i0w[:, F_:].contiguous()] + [i1w[c * F_:(c + 1) * F_] for c in range(3)]
+                      [i0w[:, :F_], i0w[:, F_:]] + [i1w[c * F_:(c + 1) * F_] for c in range(3)]
         img = ops.prepare_chain(blocks, transB=True) if not os.environ.get("GEOSSL_PAINN_NO_CHAIN") else None
         NB = 11  # blocks per layer, in the order above
+        # silu inside the chained launches (F = 128): GEOSSL_PAINN_SILU_KERNELS keeps the separate silu launches (A/B runs)
+        fused = img is not None and F_ == 128 and not os.environ.get("GEOSSL_PAINN_SILU_KERNELS")
 
         def lin_fan(x, ks, biases, outs):
             """several F x F blocks of one wide Dense applied to the same rows: one launch (F = 128), else one each"""
@@ -246,18 +252,24 @@ class _PaiNNCore(torch.autograd.Function):
 
         def lin(x, w, k, bias=None, res=None, out=None):
             if img is None:
-                return ops.linear(x, blocks[k], bias=bias, res=res, out=out)
+                return ops.linear(x, blocks[k].contiguous(), bias=bias, res=res, out=out)
             return ops.linear_chain(x, [dict(image=img[k], bias=bias, res=res, out=out)])[0]
 
         for l in range(L):
             c0w, c0b, c1w, c1b = inter[l]
             k0 = NB * l
-            u = lin(q, c0w, k0, bias=c0b)                                    # Dense(F, F, silu)      :27-30,53
-            s = torch.empty_like(u)
-            call("geossl_silu_fwd", ptr(u), u.numel(), ptr(s), st)
             xc = torch.empty(N, 3 * F_, **f32)
-            lin_fan(s, [k0 + 1 + c for c in range(3)], [c1b[c * F_:(c + 1) * F_] for c in range(3)],
-                    _split3(xc, F_))                                         # Dense(F, 3F)
+            if fused:  # Dense(F, F, silu) and Dense(F, 3F) (:27-30,53) in one launch: u and silu(u) are both kept
+                u, s = torch.empty(N, F_, **f32), torch.empty(N, F_, **f32)
+                ops.linear_chain(q, [dict(image=img[k0], bias=c0b, out=u, out_act=s, flags=_lib.EPI_SILU)] +
+                                 [dict(image=img[k0 + 1 + c], bias=c1b[c * F_:(c + 1) * F_], out=o_, same_input=(c > 0))
+                                  for c, o_ in enumerate(_split3(xc, F_))])
+            else:
+                u = lin(q, c0w, k0, bias=c0b)                                # Dense(F, F, silu)      :27-30,53
+                s = torch.empty_like(u)
+                call("geossl_silu_fwd", ptr(u), u.numel(), ptr(s), st)
+                lin_fan(s, [k0 + 1 + c for c in range(3)], [c1b[c * F_:(c + 1) * F_] for c in range(3)],
+                        _split3(xc, F_))                                     # Dense(F, 3F)
             q2, mu2 = torch.empty_like(q), torch.empty_like(mu)
             lay = cfg["lay"]  # one block per molecule: the rows its edges read are staged in LDS once
             if cfg["mma"] and lay.max_n <= 44 and E > 0:  # filter on the matrix pipe (painn_mma.hip); LDS: 3.5 KB per atom + 3 KB
@@ -278,18 +290,25 @@ class _PaiNNCore(torch.autograd.Function):
             call("geossl_painn_mix_pre_fwd", ptr(q2), ptr(mm), N, F_, cfg["eps"], ptr(cx), ptr(dot), st)  # :101-104
             # Dense(2F, F, silu) :105 - a contraction over 2F columns is two passes of the F-wide row GEMM (the split
             # kernel holds one K <= 128 weight image in LDS): the second adds onto the first through the residual operand
-            i0a, i0c = i0w[:, :F_].contiguous(), i0w[:, F_:].contiguous()
-            if img is not None and F_ == 128:   # both F-wide passes in one launch (the second brings its own input)
-                u1 = ops.linear_chain(cx[:, :F_], [dict(image=img[k0 + 6], bias=i0b, store=False),
-                                                   dict(image=img[k0 + 7], x=cx[:, F_:], add_prev=True)])[1]
-            else:
-                u1 = lin(cx[:, :F_], i0a, k0 + 6, bias=i0b)
-                lin(cx[:, F_:], i0c, k0 + 7, res=u1, out=u1)
-            s1 = torch.empty_like(u1)
-            call("geossl_silu_fwd", ptr(u1), u1.numel(), ptr(s1), st)
             xx = torch.empty(N, 3 * F_, **f32)
-            lin_fan(s1, [k0 + 8 + c for c in range(3)], [i1b[c * F_:(c + 1) * F_] for c in range(3)],
-                    _split3(xx, F_))                                         # Dense(F, 3F)
+            if fused:  # both F-wide passes of Dense(2F, F, silu), then Dense(F, 3F) on silu of it: one launch
+                u1, s1 = torch.empty(N, F_, **f32), torch.empty(N, F_, **f32)
+                ops.linear_chain(cx[:, :F_], [dict(image=img[k0 + 6], bias=i0b, store=False),
+                                              dict(image=img[k0 + 7], x=cx[:, F_:], add_prev=True, out=u1, out_act=s1,
+                                                   flags=_lib.EPI_SILU)] +
+                                 [dict(image=img[k0 + 8 + c], bias=i1b[c * F_:(c + 1) * F_], out=o_, same_input=(c > 0))
+                                  for c, o_ in enumerate(_split3(xx, F_))])
+            else:
+                if img is not None and F_ == 128:   # both F-wide passes in one launch (the second brings its own input)
+                    u1 = ops.linear_chain(cx[:, :F_], [dict(image=img[k0 + 6], bias=i0b, store=False),
+                                                       dict(image=img[k0 + 7], x=cx[:, F_:], add_prev=True)])[1]
+                else:
+                    u1 = lin(cx[:, :F_], None, k0 + 6, bias=i0b)
+                    lin(cx[:, F_:], None, k0 + 7, res=u1, out=u1)
+                s1 = torch.empty_like(u1)
+                call("geossl_silu_fwd", ptr(u1), u1.numel(), ptr(s1), st)
+                lin_fan(s1, [k0 + 8 + c for c in range(3)], [i1b[c * F_:(c + 1) * F_] for c in range(3)],
+                        _split3(xx, F_))                                     # Dense(F, 3F)
             q3, mu3 = torch.empty_like(q), torch.empty_like(mu)
             call("geossl_painn_mix_post_fwd", ptr(q2), ptr(mu2), ptr(mm), ptr(xx), ptr(dot), N, F_, ptr(q3), ptr(mu3), st)
             if training:
@@ -330,13 +349,14 @@ class _PaiNNCore(torch.autograd.Function):
             c0w, c0b, c1w, c1b = inter[l]
             i0w, i0b, i1w, i1b, mw = mix[l]
             blocks += [c0w] + [c1w[c * F_:(c + 1) * F_] for c in range(3)] + [mw[:F_], mw[F_:]] + \
-                      [i0w[:, :F_].contiguous(), i0w[:, F_:].contiguous()] + [i1w[c * F_:(c + 1) * F_] for c in range(3)]
+                      [i0w[:, :F_], i0w[:, F_:]] + [i1w[c * F_:(c + 1) * F_] for c in range(3)]
         img = ops.prepare_chain(blocks, transB=False) if not os.environ.get("GEOSSL_PAINN_NO_CHAIN") else None
         NB = 11
+        fused = img is not None and F_ == 128 and not os.environ.get("GEOSSL_PAINN_SILU_KERNELS")
 
         def lin_t(x, w, k, res=None, out=None):  # x @ w (the transposed use of a forward weight block)
             if img is None:
-                return ops.linear(x, blocks[k], transB=False, res=res, out=out)
+                return ops.linear(x, blocks[k].contiguous(), transB=False, res=res, out=out)
             return ops.linear_chain(x, [dict(image=img[k], res=res, out=out)])[0]
 
         lay = cfg["lay"]
@@ -377,18 +397,28 @@ class _PaiNNCore(torch.autograd.Function):
             dxx, dmm = torch.empty(N, 3 * F_, **f32), torch.empty(3 * N, 2 * F_, **f32)
             call("geossl_painn_mix_post_bwd", ptr(dq_cur), ptr(dmu_cur), ptr(sv["mm"]), ptr(sv["xx"]), ptr(sv["dot"]), N,
                  F_, ptr(dxx), ptr(dmm), st)
-            ds1 = lin_t_sum(_split3(dxx, F_), [k0 + 8 + c for c in range(3)])
             for c, xs_ in enumerate(_split3(dxx, F_)):
                 add(N, 3 * F_, F_, F_, xs_, sv["s1"], gi1w[c * F_:(c + 1) * F_], gi1b[c * F_:(c + 1) * F_])
-            du1 = torch.empty_like(ds1)
-            call("geossl_silu_bwd", ptr(sv["u1"]), ptr(ds1), ds1.numel(), ptr(du1), st)
             dctx = torch.empty(N, 2 * F_, **f32)                           # [N][2F] = du1 @ i0w
-            if img is not None and F_ == 128:
-                ops.linear_chain(du1, [dict(image=img[k0 + 6], out=dctx[:, :F_]),
-                                       dict(image=img[k0 + 7], out=dctx[:, F_:], same_input=True)])
+            if fused:  # (sum_c dxx_c W_c) * silu'(u1) = du1, then du1 @ i0w: one launch
+                du1 = torch.empty(N, F_, **f32)
+                x3 = _split3(dxx, F_)
+                ops.linear_chain(x3[0], [dict(image=img[k0 + 8], store=False),
+                                         dict(image=img[k0 + 9], x=x3[1], add_prev=True, store=False),
+                                         dict(image=img[k0 + 10], x=x3[2], add_prev=True, tprev=sv["u1"], out=du1,
+                                              flags=_lib.EPI_MUL_DSILU),
+                                         dict(image=img[k0 + 6], out=dctx[:, :F_]),
+                                         dict(image=img[k0 + 7], out=dctx[:, F_:], same_input=True)])
             else:
-                for c in range(2):
-                    lin_t(du1, i0w[:, c * F_:(c + 1) * F_], k0 + 6 + c, out=dctx[:, c * F_:(c + 1) * F_])
+                ds1 = lin_t_sum(_split3(dxx, F_), [k0 + 8 + c for c in range(3)])
+                du1 = torch.empty_like(ds1)
+                call("geossl_silu_bwd", ptr(sv["u1"]), ptr(ds1), ds1.numel(), ptr(du1), st)
+                if img is not None and F_ == 128:
+                    ops.linear_chain(du1, [dict(image=img[k0 + 6], out=dctx[:, :F_]),
+                                           dict(image=img[k0 + 7], out=dctx[:, F_:], same_input=True)])
+                else:
+                    for c in range(2):
+                        lin_t(du1, i0w[:, c * F_:(c + 1) * F_], k0 + 6 + c, out=dctx[:, c * F_:(c + 1) * F_])
             for c in range(2):
                 add(N, F_, 2 * F_, 2 * F_, du1, sv["cx"][:, c * F_:(c + 1) * F_], gi0w[:, c * F_:(c + 1) * F_],
                     gi0b if c == 0 else None)
@@ -406,12 +436,21 @@ class _PaiNNCore(torch.autograd.Function):
                  ptr(inc_ptr), ptr(inc_idx), ptr(phi), ptr(fcut), ptr(dirv), ptr(ps[1][l * 3 * F_:(l + 1) * 3 * F_]),
                  ptr(ps[2][l * 3 * F_:(l + 1) * 3 * F_]), ptr(lay.mol_ptr), lay.B, lay.max_n, N, F_, R, ptr(dxc), ptr(dmu_in),
                  ptr(g_fw[l * 3 * F_:(l + 1) * 3 * F_]), ptr(g_fb[l * 3 * F_:(l + 1) * 3 * F_]), ptr(ws), acc, st)
-            ds = lin_t_sum(_split3(dxc, F_), [k0 + 1 + c for c in range(3)])
             for c, xs_ in enumerate(_split3(dxc, F_)):
                 add(N, 3 * F_, F_, F_, xs_, sv["s"], gc1w[c * F_:(c + 1) * F_], gc1b[c * F_:(c + 1) * F_])
-            du = torch.empty_like(ds)
-            call("geossl_silu_bwd", ptr(sv["u"]), ptr(ds), ds.numel(), ptr(du), st)
-            dq_in = lin_t(du, c0w, k0, res=dq2)                              # residual q2 = q + dq
+            if fused:  # (sum_c dxc_c W_c) * silu'(u) = du, then du @ c0w + dq2 (residual q2 = q + dq): one launch
+                du, dq_in = torch.empty(N, F_, **f32), torch.empty(N, F_, **f32)
+                x3 = _split3(dxc, F_)
+                ops.linear_chain(x3[0], [dict(image=img[k0 + 1], store=False),
+                                         dict(image=img[k0 + 2], x=x3[1], add_prev=True, store=False),
+                                         dict(image=img[k0 + 3], x=x3[2], add_prev=True, tprev=sv["u"], out=du,
+                                              flags=_lib.EPI_MUL_DSILU),
+                                         dict(image=img[k0], res=dq2, out=dq_in)])
+            else:
+                ds = lin_t_sum(_split3(dxc, F_), [k0 + 1 + c for c in range(3)])
+                du = torch.empty_like(ds)
+                call("geossl_silu_bwd", ptr(sv["u"]), ptr(ds), ds.numel(), ptr(du), st)
+                dq_in = lin_t(du, c0w, k0, res=dq2)                          # residual q2 = q + dq
             add(N, F_, F_, F_, du, sv["q"], gc0w, gc0b)
             keep += [dxx, dmm, du1, dxc, du, dq2, dmu2]
             dq_cur, dmu_cur = dq_in, dmu_in

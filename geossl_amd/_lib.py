@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libgeossl_hip.so")
 MAX_L = 12
 TN_MAX = 32
 EPI_BIAS, EPI_SSP, EPI_RESIDUAL, EPI_MUL_DSSP, CHAIN_SAME_INPUT, CHAIN_NEW_INPUT, CHAIN_ADD_PREV = 1, 2, 4, 8, 16, 32, 64
+EPI_SILU, EPI_MUL_DSILU = 128, 256
 
 vp = C.c_void_p
 i64 = C.c_int64
@@ -26,15 +27,15 @@ class FilterWeights(C.Structure):
 
 
 class PrepareBatch(C.Structure):
-    _fields_ = [("W", vp * TN_MAX), ("image", vp * TN_MAX)]
+    _fields_ = [("W", vp * TN_MAX), ("image", vp * TN_MAX), ("ldw", i32 * TN_MAX)]
 
 
-CHAIN_MAX = 3
+CHAIN_MAX = 5
 
 
 class ChainStage(C.Structure):
     _fields_ = [("image", vp), ("bias", vp), ("res", vp), ("tprev", vp), ("out", vp), ("ld", i32), ("flags", i32),
-                ("xin", vp), ("ldxin", i32), ("pad_", i32)]
+                ("xin", vp), ("ldxin", i32), ("pad_", i32), ("out_act", vp)]
 
 
 class Chain(C.Structure):

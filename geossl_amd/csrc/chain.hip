@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void k_chain_prepare(GeosslPrepareBatch batch,
   const int z = blockIdx.y;
   const float* __restrict__ W = batch.W[z];
   u32x4* __restrict__ image = reinterpret_cast<u32x4*>(batch.image[z]);
+  const int ldw = batch.ldw[z] != 0 ? batch.ldw[z] : (transB ? K : NO);  // row stride of W
   const int nitems = (NO / 32) * KS * 64;
   const int i = blockIdx.x * 256 + threadIdx.x;
   float sw = 1.0f;
@@ -47,14 +48,13 @@ __global__ __launch_bounds__(256) void k_chain_prepare(GeosslPrepareBatch batch,
     __shared__ float red[4];
     float mw = 0.0f;
     const int mb_blk = (blockIdx.x * 256) / (64 * KS);
-    if (transB) {  // rows 32 mb .. 32 mb + 31 of W [NO][K]: contiguous
-      const f32x4* W4 = reinterpret_cast<const f32x4*>(W + (size_t)32 * mb_blk * K);
+    if (transB) {  // rows 32 mb .. 32 mb + 31 of W [NO][K]
       for (int q = threadIdx.x; q < 32 * K / 4; q += 256) {
-        const f32x4 a = W4[q];
+        const f32x4 a = *reinterpret_cast<const f32x4*>(W + (size_t)(32 * mb_blk + q / (K / 4)) * ldw + 4 * (q % (K / 4)));
         mw = fmaxf(fmaxf(mw, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
       }
     } else {       // columns 32 mb .. 32 mb + 31 of W [K][NO]
-      for (int q = threadIdx.x; q < 32 * K; q += 256) mw = fmaxf(mw, fabsf(W[(size_t)(q >> 5) * NO + 32 * mb_blk + (q & 31)]));
+      for (int q = threadIdx.x; q < 32 * K; q += 256) mw = fmaxf(mw, fabsf(W[(size_t)(q >> 5) * ldw + 32 * mb_blk + (q & 31)]));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
@@ -70,13 +70,13 @@ __global__ __launch_bounds__(256) void k_chain_prepare(GeosslPrepareBatch batch,
   const int n = 32 * mb + (ln & 31), kh = ln >> 5;
   float v[8];
   if (transB) {  // W [NO][K]: B[k][n] = W[n][k]
-    const f32x4 lo = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + 16 * ks + 4 * kh);
-    const f32x4 hi = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + 16 * ks + 8 + 4 * kh);
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(W + (size_t)n * ldw + 16 * ks + 4 * kh);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(W + (size_t)n * ldw + 16 * ks + 8 + 4 * kh);
     v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
     v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
   } else {       // W [K][NO]: B[k][n] = W[k][n]
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = W[(size_t)(16 * ks + kperm(e, kh)) * NO + n];
+    for (int e = 0; e < 8; ++e) v[e] = W[(size_t)(16 * ks + kperm(e, kh)) * ldw + n];
   }
   if constexpr (KS == 8) {
 #pragma unroll
@@ -555,7 +555,14 @@ __global__ __launch_bounds__(512, 2) void k_row_chain8(GeosslChain ch, const flo
 // before them.  WPS = 2: two such blocks per CU (RB = 3: 72 KB of LDS, 256 registers) that run out of step - the
 // memory phases of one fall into the arithmetic of the other; WPS = 1: one block per CU with RB = 5 and 512 registers
 // (epilogue operands requested one row block ahead).
-template <int NS, int RB, int WPS>
+// SILU: the instantiation that knows GEOSSL_EPI_SILU / GEOSSL_EPI_MUL_DSILU and the second output (PaiNN's Dense layers);
+// the other one carries none of it.
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }                    // k_silu_fwd
+__device__ __forceinline__ float dsilu_f(float x) {                                                    // k_silu_bwd
+  const float sg = 1.0f / (1.0f + expf(-x));
+  return sg * (1.0f + x * (1.0f - sg));
+}
+template <int NS, int RB, int WPS, bool SILU>
 __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const float* __restrict__ X, int ldx, int R) {
   constexpr int KS = 8, F = 128;
   constexpr int RBF = KS * 2 * 64;      // u32x4 per row block of fragments (two fp16 pieces, split.h)
@@ -663,6 +670,8 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
     const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st.tprev), 0, st.tprev != nullptr ? nbytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st.res), 0, st.res != nullptr ? nbytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(st.out, 0, st.out != nullptr ? nbytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(st.out_act, 0, (SILU && st.out_act != nullptr) ? nbytes : 0u, 0x00020000);
+    const bool act_silu = SILU && (st.flags & GEOSSL_EPI_SILU) != 0;
     auto row_off = [&](int i) __attribute__((always_inline)) {
       const int row = 32 * (rb0 + i) + j;
       return row < R ? (uint32_t)row * (uint32_t)st.ld * 4u + 128u * m + 16u * kh : 0xFFFFFF00u;  // out of range (also + 96): dropped
@@ -681,6 +690,16 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
         __builtin_amdgcn_raw_buffer_store_b128(
             __builtin_bit_cast(u32x4, f32x4{vout[i][4 * q], vout[i][4 * q + 1], vout[i][4 * q + 2], vout[i][4 * q + 3]}), rs_o,
             ro + 32 * q, 0, 0);
+      if constexpr (SILU) {  // the activated copy (issued unconditionally like every request of the loop: a null
+                             // destination is a zero-sized buffer)
+        float av[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) av[e] = act_silu ? silu_f(vout[i][e]) : vout[i][e];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          __builtin_amdgcn_raw_buffer_store_b128(
+              __builtin_bit_cast(u32x4, f32x4{av[4 * q], av[4 * q + 1], av[4 * q + 2], av[4 * q + 3]}), rs_a, ro + 32 * q, 0, 0);
+      }
     };
     if (NEB == 2) request_epi(0, tp[0], rs[0]);
 #pragma unroll
@@ -737,7 +756,15 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
 #pragma unroll
           for (int e = 0; e < 16; ++e) vout[i][e] = ssp(vout[i][e]);
         }
-        if (st.tprev != nullptr) {
+        if (SILU && st.tprev != nullptr && (st.flags & GEOSSL_EPI_MUL_DSILU)) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            vout[i][4 * q] *= dsilu_f(t[q].x);
+            vout[i][4 * q + 1] *= dsilu_f(t[q].y);
+            vout[i][4 * q + 2] *= dsilu_f(t[q].z);
+            vout[i][4 * q + 3] *= dsilu_f(t[q].w);
+          }
+        } else if (st.tprev != nullptr) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             vout[i][4 * q] *= dssp_from_out(t[q].x);
@@ -784,6 +811,15 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
             lo[e] = vout[i][e];
             hi[e] = vout[i][8 + e];
           }
+          if constexpr (SILU) {
+            if (st.flags & GEOSSL_EPI_SILU) {  // the next stage reads silu(Y); |silu(y)| <= |y|: the row scale holds
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                lo[e] = silu_f(lo[e]);
+                hi[e] = silu_f(hi[e]);
+              }
+            }
+          }
           const Frag2 f0 = split8h_scaled(lo, sr), f1 = split8h_scaled(hi, sr);
           u32x4* xd = xbuf + (size_t)i * RBF + (size_t)(2 * m * 2) * 64 + lane;
           xd[0] = f0.h; xd[64] = f0.l;
@@ -805,7 +841,10 @@ int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipS
   // weight-stationary form: F = 128 (its images are in the two-fp16-piece format: no other kernel reads them); every
   // row-piece offset must fit the 32-bit range of a buffer descriptor: longer inputs run as two launches of half the rows
   const bool cu_form = KS == 8;
-  bool same_input = false;
+  bool same_input = false, silu = false;
+  for (int s2 = 0; s2 < ch.nstage; ++s2) silu |= (ch.st[s2].flags & (GEOSSL_EPI_SILU | GEOSSL_EPI_MUL_DSILU)) != 0;
+  if (ch.nstage > 3) silu = true;  // chains of four and five stages are instantiated in that form only
+  if (silu && !cu_form) return (int)hipErrorInvalidValue;  // silu epilogues, long chains: weight-stationary form only
   for (int s2 = 0; s2 < ch.nstage; ++s2) {
     if (cu_form && ((int64_t)R * ch.st[s2].ld * 4 >= (int64_t)0xFFFFFF00u || (int64_t)R * ldx * 4 >= (int64_t)0xFFFFFF00u)) {
       const int64_t r0 = ((R / 2 + 31) / 32) * 32;
@@ -813,6 +852,7 @@ int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipS
       for (int s3 = 0; s3 < ch.nstage; ++s3) {
         GeosslChainStage& st = hi.st[s3];
         if (st.out != nullptr) st.out += r0 * st.ld;
+        if (st.out_act != nullptr) st.out_act += r0 * st.ld;
         if (st.res != nullptr) st.res += r0 * st.ld;
         if (st.tprev != nullptr) st.tprev += r0 * st.ld;
         if (st.xin != nullptr) st.xin += r0 * st.ldxin;
@@ -829,28 +869,40 @@ int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipS
   if (same_input && (!cu_form || (ch.st[0].flags & (GEOSSL_CHAIN_SAME_INPUT | GEOSSL_CHAIN_NEW_INPUT | GEOSSL_CHAIN_ADD_PREV))))
     return (int)hipErrorInvalidValue;
   if (cu_form) {
-    static const bool one_per_cu = getenv("GEOSSL_CHAIN_CU1") != nullptr;  // 512-register form, one block per CU
+    static const bool one_per_cu_env = getenv("GEOSSL_CHAIN_CU1") != nullptr;  // 512-register form, one block per CU
+    const bool one_per_cu = one_per_cu_env && !silu;
     const int RBV = one_per_cu ? 5 : 3, slots = one_per_cu ? 256 : 512;
     const int need = (nrb + RBV - 1) / RBV;                       // blocks so that none takes more than RB row blocks
     const int fill = nrb < slots ? nrb : slots;                   // blocks so that every slot of the chip has work
     const int grid = need > fill ? need : fill;
     const size_t lds = (size_t)RBV * KS * 2 * 1024 + (size_t)ch.nstage * 16 * KS * sizeof(float) + (size_t)RBV * 128 * sizeof(float);
-#define LAUNCH_CU(NSV)                                                                                           \
-  do {                                                                                                           \
-    if (one_per_cu) {                                                                                            \
-      allow_big_lds(&k_row_chain_cu<NSV, 5, 1>);                                                                 \
-      hipLaunchKernelGGL((k_row_chain_cu<NSV, 5, 1>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R);   \
-    } else {                                                                                                     \
-      allow_big_lds(&k_row_chain_cu<NSV, 3, 2>);                                                                 \
-      hipLaunchKernelGGL((k_row_chain_cu<NSV, 3, 2>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R);   \
-    }                                                                                                            \
+#define LAUNCH_CU(NSV)                                                                                                 \
+  do {                                                                                                                 \
+    if (silu) {                                                                                                        \
+      allow_big_lds(&k_row_chain_cu<NSV, 3, 2, true>);                                                                 \
+      hipLaunchKernelGGL((k_row_chain_cu<NSV, 3, 2, true>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R);   \
+    } else if (one_per_cu) {                                                                                           \
+      allow_big_lds(&k_row_chain_cu<NSV, 5, 1, false>);                                                                \
+      hipLaunchKernelGGL((k_row_chain_cu<NSV, 5, 1, false>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R);  \
+    } else {                                                                                                           \
+      allow_big_lds(&k_row_chain_cu<NSV, 3, 2, false>);                                                                \
+      hipLaunchKernelGGL((k_row_chain_cu<NSV, 3, 2, false>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R);  \
+    }                                                                                                                  \
+  } while (0)
+#define LAUNCH_CU_LONG(NSV)                                                                                            \
+  do {                                                                                                                 \
+    allow_big_lds(&k_row_chain_cu<NSV, 3, 2, true>);                                                                   \
+    hipLaunchKernelGGL((k_row_chain_cu<NSV, 3, 2, true>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R);     \
   } while (0)
     switch (ch.nstage) {
       case 1: LAUNCH_CU(1); break;
       case 2: LAUNCH_CU(2); break;
       case 3: LAUNCH_CU(3); break;
+      case 4: LAUNCH_CU_LONG(4); break;
+      case 5: LAUNCH_CU_LONG(5); break;
       default: return (int)hipErrorInvalidValue;
     }
+#undef LAUNCH_CU_LONG
 #undef LAUNCH_CU
   } else if (four_waves) {
     const int grid = ngroups < 2048 ? ngroups : 2048;  // two blocks per CU are resident (72 KB of LDS, <= 256 registers)
@@ -905,6 +957,9 @@ extern "C" int64_t geossl_chain_image_words(int F) {
 extern "C" int geossl_chain_prepare(const GeosslPrepareBatch* batch, int nprob, int F, int transB, hipStream_t stream) {
   if (nprob <= 0) return 0;
   if (nprob > GEOSSL_TN_MAX || geossl_chain_image_words(F) == 0) return (int)hipErrorInvalidValue;
+  for (int z = 0; z < nprob; ++z)
+    if (batch->ldw[z] != 0 && (batch->ldw[z] < F || (batch->ldw[z] & 3) || ((uintptr_t)batch->W[z] & 15)))
+      return (int)hipErrorInvalidValue;
   const int KS = F / 16, nitems = (F / 32) * KS * 64;
   dim3 grid((nitems + 255) / 256, nprob);
   if (KS == 8) hipLaunchKernelGGL((k_chain_prepare<8>), grid, dim3(256), 0, stream, *batch, F, transB);
@@ -923,7 +978,7 @@ extern "C" int geossl_linear_chain(const float* X, int ldx, const GeosslChain* c
   for (int s = 0; s < chain->nstage; ++s) {
     const GeosslChainStage& st = chain->st[s];
     if (st.image == nullptr) return (int)hipErrorInvalidValue;
-    if ((st.out != nullptr || st.res != nullptr || st.tprev != nullptr) && (st.ld < F || (st.ld & 3)))
+    if ((st.out != nullptr || st.res != nullptr || st.tprev != nullptr || st.out_act != nullptr) && (st.ld < F || (st.ld & 3)))
       return (int)hipErrorInvalidValue;
   }
   if (F == 128) return launch_chain<8>(*chain, X, ldx, R, stream);

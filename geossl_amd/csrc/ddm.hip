@@ -218,7 +218,13 @@ __global__ __launch_bounds__(256) void k_incidence_gather(const float* __restric
                                                           const int64_t* __restrict__ inc_ptr,
                                                           const int32_t* __restrict__ inc_idx, int N, int F,
                                                           float* __restrict__ dh, int accumulate) {
-  const int a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // A super-edge row is read twice, by its two atoms - atoms of ONE molecule, i.e. of neighbouring groups of four.
+  // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): consecutive groups on consecutive
+  // workgroups would fetch a molecule's rows into several L2s, from HBM every time.  Group g = (block mod 8) * per +
+  // block / 8 keeps neighbouring groups on one XCD and close in time: the second read is an L2 hit.
+  const int per = ((int)gridDim.x + 7) / 8;
+  const int grp = ((int)blockIdx.x % 8) * per + (int)blockIdx.x / 8;
+  const int a = grp * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (a >= N) return;
   const int64_t p0 = inc_ptr[a], p1 = inc_ptr[a + 1];
   float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // F <= 256
@@ -361,7 +367,8 @@ int launch_ncsn_small_reduce(const float* partial, int nblk, int F, const Geossl
 extern "C" int geossl_incidence_gather(const float* dfeat, const int64_t* inc_ptr, const int32_t* inc_idx, int64_t N,
                                        int F, float* dh, int accumulate, hipStream_t stream) {
   if (N <= 0) return 0;
-  hipLaunchKernelGGL(k_incidence_gather, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, dfeat, inc_ptr, inc_idx,
+  const unsigned groups = (unsigned)((N + 3) / 4);
+  hipLaunchKernelGGL(k_incidence_gather, dim3((groups + 7) / 8 * 8), dim3(256), 0, stream, dfeat, inc_ptr, inc_idx,
                      (int)N, F, dh, accumulate);
   GEOSSL_CHECK_LAUNCH();
   return 0;

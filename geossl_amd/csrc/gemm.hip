@@ -386,6 +386,8 @@ extern "C" int geossl_linear_prepare(const GeosslPrepareBatch* batch, int nprob,
                                      hipStream_t stream) {
   if (nprob <= 0) return 0;
   if (nprob > GEOSSL_TN_MAX || geossl_linear_image_words(K, NO) == 0) return (int)hipErrorInvalidValue;
+  for (int z = 0; z < nprob; ++z)
+    if (batch->ldw[z] != 0 && batch->ldw[z] != (transB ? K : NO)) return (int)hipErrorInvalidValue;  // dense weights only
   const int KS = K / 16, nitems = ((NO + 31) / 32) * KS * 64;
   dim3 grid((nitems + 255) / 256, nprob);
   if (KS == 8) hipLaunchKernelGGL((k_linear_prepare<8>), grid, dim3(256), 0, stream, *batch, NO, transB);

@@ -583,14 +583,12 @@ extern "C" int geossl_painn_interaction_bwd(const float* dq_out, const float* dm
                           idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, (int)N, F, dxc, dmu_in, pw, pb);
   GEOSSL_CHECK_LAUNCH();
   // fixed-order two-stage sums of the per-block partials (64 outputs x 4 slices of the block list per reduction block)
-  GeosslReduceBatch rb;
-  for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = nullptr;
-  rb.out[0] = dWf;
-  hipLaunchKernelGGL(geossl::k_reduce_partials, dim3((3 * F * R + 63) / 64, 1), dim3(256), 0, stream, rb, pw, nb, 3 * F * R,
-                     3 * F * R, 3 * F * R, 1, accumulate);
-  rb.out[0] = dbf;
-  hipLaunchKernelGGL(geossl::k_reduce_partials, dim3((3 * F + 63) / 64, 1), dim3(256), 0, stream, rb, pb, nb, 3 * F, 3 * F,
-                     3 * F, 1, accumulate);
+  ReduceMulti rm;  // both fixed-order sums over the block partials in one launch (k_reduce_partials' arithmetic)
+  float* ow[1] = {dWf};
+  float* ob[1] = {dbf};
+  rm.add(pw, 3 * F * R, 3 * F * R, 3 * F * R, 1, ow, 1);
+  rm.add(pb, 3 * F, 3 * F, 3 * F, 1, ob, 1);
+  hipLaunchKernelGGL(geossl::k_reduce_multi, dim3(rm.blocks(), 1), dim3(256), 0, stream, rm, nb, accumulate);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
@@ -662,14 +660,12 @@ extern "C" int geossl_painn_interaction_bwd_mol(const float* dq_out, const float
   else if (R == 32) LAUNCH_BWD_MOL(32); else return (int)hipErrorInvalidValue;
 #undef LAUNCH_BWD_MOL
   GEOSSL_CHECK_LAUNCH();
-  GeosslReduceBatch rb;
-  for (int z = 0; z < GEOSSL_TN_MAX; ++z) rb.out[z] = nullptr;
-  rb.out[0] = dWf;
-  hipLaunchKernelGGL(geossl::k_reduce_partials, dim3((3 * F * R + 63) / 64, 1), dim3(256), 0, stream, rb, pw, nb, 3 * F * R,
-                     3 * F * R, 3 * F * R, 1, accumulate);
-  rb.out[0] = dbf;
-  hipLaunchKernelGGL(geossl::k_reduce_partials, dim3((3 * F + 63) / 64, 1), dim3(256), 0, stream, rb, pb, nb, 3 * F, 3 * F,
-                     3 * F, 1, accumulate);
+  ReduceMulti rm;  // both fixed-order sums over the block partials in one launch (k_reduce_partials' arithmetic)
+  float* ow[1] = {dWf};
+  float* ob[1] = {dbf};
+  rm.add(pw, 3 * F * R, 3 * F * R, 3 * F * R, 1, ow, 1);
+  rm.add(pb, 3 * F, 3 * F, 3 * F, 1, ob, 1);
+  hipLaunchKernelGGL(geossl::k_reduce_multi, dim3(rm.blocks(), 1), dim3(256), 0, stream, rm, nb, accumulate);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

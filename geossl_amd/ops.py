@@ -96,8 +96,9 @@ def prepare_linear(weights, transB=True):
         images = torch.empty(len(chunk), words, dtype=torch.int32, device=w0.device)
         pb = _lib.PrepareBatch()
         for i, w in enumerate(chunk):
-            assert w.shape == w0.shape and w.is_contiguous()
+            assert w.shape == w0.shape and w.stride(1) == 1
             pb.W[i], pb.image[i] = ptr(w), ptr(images[i])
+            pb.ldw[i] = 0 if w.is_contiguous() else w.stride(0)
         call("geossl_linear_prepare", C.byref(pb), len(chunk), K, NO, 1 if transB else 0, stream())
         out += [PreparedWeight(images[i], K, NO) for i in range(len(chunk))]
     return out
@@ -135,7 +136,9 @@ def linear(x, w, bias=None, res=None, tprev=None, transB=True, flags=0, out=None
 
 def prepare_chain(weights, transB=True):
     """Operand images (geossl_chain_prepare) of square F x F Linear weights for `linear_chain`, one launch per
-    GEOSSL_TN_MAX weights.  transB as in `linear`.  Returns a list of int32 tensors, or None if F has no chain path."""
+    GEOSSL_TN_MAX weights.  transB as in `linear`.  A weight may be a column block of a wider matrix (unit column
+    stride, row stride a multiple of 4, 16-byte aligned): it is converted where it lies.  Returns a list of int32
+    tensors, or None if F has no chain path."""
     w0 = weights[0]
     F = w0.size(0)
     words = int(_lib.load().geossl_chain_image_words(F)) if w0.size(1) == F else 0
@@ -147,8 +150,9 @@ def prepare_chain(weights, transB=True):
         images = torch.empty(len(chunk), words, dtype=torch.int32, device=w0.device)
         pb = _lib.PrepareBatch()
         for i, w in enumerate(chunk):
-            assert w.shape == w0.shape and w.is_contiguous()
+            assert w.shape == w0.shape and w.stride(1) == 1
             pb.W[i], pb.image[i] = ptr(w), ptr(images[i])
+            pb.ldw[i] = 0 if w.is_contiguous() else w.stride(0)
         call("geossl_chain_prepare", C.byref(pb), len(chunk), F, 1 if transB else 0, stream())
         out += [images[i] for i in range(len(chunk))]
     return out
@@ -159,8 +163,10 @@ def linear_chain(x, stages):
     stages: list of dicts with `image` (from prepare_chain) and optional `bias`, `res`, `tprev`, `flags`, `store`,
     `same_input` (F = 128 only: the stage reads the input of the stage before it, not its result), `x` (F = 128 only:
     the stage reads its own input rows) with `add_prev` (and adds the result of the stage before it)
-    (default True: the stage's result is written to a new [R, F] tensor).  Returns the list of stored results
-    (None where store is False)."""
+    (default True: the stage's result is written to a new [R, F] tensor).  F = 128 only: flags EPI_SILU (the stage
+    stores its result as it is, hands silu of it to the next stage and writes that to `out_act` if given) and
+    EPI_MUL_DSILU (tprev is a saved pre-activation: * silu'(tprev)); up to five stages.  Returns the list of stored
+    results (None where store is False)."""
     R, F = x.shape  # (x may be a column slice: its row stride is passed)
     assert x.stride(1) == 1 and 1 <= len(stages) <= _lib.CHAIN_MAX
     ch = _lib.Chain()
@@ -172,12 +178,13 @@ def linear_chain(x, stages):
         if o is None and sd.get("store", True):  # ... or a new tensor, unless the stage is not stored at all
             o = torch.empty(R, F, dtype=torch.float32, device=x.device)
         # out / res / tprev of a stage share one row stride (they may be column slices of wider row-major tensors)
-        rows_ = [a for a in (o, sd.get("res"), sd.get("tprev")) if a is not None]
+        rows_ = [a for a in (o, sd.get("res"), sd.get("tprev"), sd.get("out_act")) if a is not None]
         ld = rows_[0].stride(0) if rows_ else F
         for a in rows_:
             assert a.stride(0) == ld and a.stride(1) == 1 and a.size(0) == R and a.size(1) == F
         st.image, st.bias, st.res, st.tprev, st.out = (ptr(sd["image"]), ptr(sd.get("bias")), ptr(sd.get("res")),
                                                        ptr(sd.get("tprev")), ptr(o))
+        st.out_act = ptr(sd.get("out_act"))
         st.ld, st.flags = ld, int(sd.get("flags", 0)) | (_lib.CHAIN_SAME_INPUT if sd.get("same_input") else 0)
         xin = sd.get("x")  # the stage's own input rows (F = 128): one of several F-wide passes over a wide input
         if xin is not None:

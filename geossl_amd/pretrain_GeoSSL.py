@@ -174,7 +174,7 @@ def _do_ddm_eager(args, batch, model, mu, sigma, heads, noise, fuse_views, devic
             _, h = model(x2, pos2, b2, return_latent=True, layout=lay2, latent_only=True)
         else:
             b2, e2 = _two_view_edges(batch.batch, batch.radius_edge_index, batch.num_graphs)
-            _, h = model(x2, pos2, e2, b2, return_latent=True)
+            _, h = model(x2, pos2, e2, b2, return_latent=True, latent_only=True)
         molecule_3D_repr_01, molecule_3D_repr_02 = split_views(h, N)
     else:
         x_02, positions_02 = perturb(x_01, positions, mu, sigma, noise=noise.get("pos_noise"), device_noise=device_noise)

@@ -37,6 +37,10 @@ extern "C" {
 #define GEOSSL_CHAIN_NEW_INPUT 32  /* geossl_linear_chain, F = 128: the stage reads its own input `xin` (a Linear over a
                                       wide input = several F-wide passes in one launch) */
 #define GEOSSL_CHAIN_ADD_PREV 64   /* ... and adds the result of the stage before it (kept in registers) */
+#define GEOSSL_EPI_SILU 128       /* geossl_linear_chain, F = 128: Y = X W^T + b goes to `out` as it is (the backward needs the
+                                    pre-activation), silu(Y) to `out_act` (may be NULL) and into the next stage -
+                                    Dense(F, F, silu) + the Dense behind it, painn_utils.py:27-35 */
+#define GEOSSL_EPI_MUL_DSILU 256  /* ... with tprev: * silu'(tprev), tprev = the saved PRE-activation (backward) */
 #define GEOSSL_CHAIN_SAME_INPUT 16 /* geossl_linear_chain, F = 128: the stage takes the input of the stage before it
                                       (several F -> F blocks of one wide Linear in one launch) instead of its result */
 
@@ -178,6 +182,8 @@ int geossl_linear(const float* X, int ldx, const float* W, const float* bias, co
 typedef struct {
   const float* W[GEOSSL_TN_MAX];
   uint32_t* image[GEOSSL_TN_MAX];
+  int ldw[GEOSSL_TN_MAX]; /* row stride of W in floats (a multiple of 4), 0 = dense; geossl_chain_prepare only: a column
+                             block of a wider weight (PaiNN's Dense(2F, F), painn.py:87) is converted where it lies */
 } GeosslPrepareBatch;
 int64_t geossl_linear_image_words(int K, int NO);
 int geossl_linear_prepare(const GeosslPrepareBatch* batch, int nprob, int K, int NO, int transB, hipStream_t stream);
@@ -195,7 +201,7 @@ int geossl_linear_prepared(const float* X, int ldx, const uint32_t* image, const
  * (dX = dY W)), geossl_chain_image_words(F) 32-bit words each.  The image is opaque: MFMA operand fragments of W split
  * into 16-bit pieces (F = 128: two fp16 pieces of W scaled by a power of two per 32-column output block, the four
  * exponents stored behind the fragments; F = 64 / 32: three bf16 pieces); results carry fp32-GEMM accuracy.        */
-#define GEOSSL_CHAIN_MAX 3
+#define GEOSSL_CHAIN_MAX 5 /* F = 128; the F = 64 / 32 forms take up to 3 stages */
 typedef struct {
   const uint32_t* image;
   const float* bias;  /* may be NULL */
@@ -207,6 +213,7 @@ typedef struct {
   const float* xin;   /* GEOSSL_CHAIN_NEW_INPUT: the stage's own input rows [R][F] (row stride ldxin), else NULL */
   int ldxin;
   int pad_;
+  float* out_act;     /* GEOSSL_EPI_SILU: silu of the stage's result (row stride ld), may be NULL */
 } GeosslChainStage;
 typedef struct {
   int nstage;

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import rel_err
 from helpers import product_ncsn, product_schnet, t
 
 pytestmark = pytest.mark.gpu
@@ -309,3 +310,70 @@ def test_head_gradients_meet_in_one_buffer_without_a_concatenation():
     assert stats["adjacent"] == a0 + 2 and stats["cat"] == c0 + 1
     assert l_cat == l_adj
     assert all(torch.equal(x, y) for x, y in zip(g_cat, g_adj))
+
+
+def test_ddm_views_is_perturb_concatenation_and_both_distance_sets_bit_for_bit():
+    """geossl_ddm_views (one launch) against the launches it replaces: geossl_axpy, the concatenation and two
+    geossl_pair_distance calls (pretrain_GeoSSL.py:68-74,199-205)."""
+    from geossl_amd import ops
+    g = torch.Generator().manual_seed(3)
+    N, S = 1000, 7777
+    pos = (torch.randn(N, 3, generator=g) * 3).to(DEV)
+    noise = (torch.randn(N, 3, generator=g) * 0.3).to(DEV)
+    sei = torch.randint(0, N, (2, S), generator=g).to(DEV)
+    pos2, d01, d02 = ops.ddm_views(pos, noise, sei[0], sei[1])
+    p2 = ops.add_scaled(pos, noise, 1.0)
+    assert torch.equal(pos2, torch.cat([pos, p2]))
+    assert torch.equal(d01, ops.pair_distance(pos, sei[0], sei[1]))
+    assert torch.equal(d02, ops.pair_distance(p2, sei[0], sei[1]))
+
+
+@pytest.mark.parametrize("rows", [37, 5000])
+def test_chain_silu_epilogues_match_separate_silu_launches(rows):
+    """Dense(F, F, silu) -> Dense(F, 3F) as one five-stage launch with GEOSSL_EPI_SILU (pre-activation and silu of it both
+    stored), and the backward form (sum of three passes) * silu'(u) -> next Dense with GEOSSL_EPI_MUL_DSILU, against the
+    same layers with geossl_silu_fwd / geossl_silu_bwd launched between the chains (painn_utils.py:27-35)."""
+    from geossl_amd import ops, _lib
+    from geossl_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(rows)
+    F = 128
+    W = [(torch.randn(F, F, generator=g) / 11).to(DEV) for _ in range(5)]
+    b = [(torch.randn(F, generator=g) * 0.1).to(DEV) for _ in range(4)]
+    x = torch.randn(rows, F, generator=g).to(DEV)
+    x2 = torch.randn(rows, F, generator=g).to(DEV)
+    img = ops.prepare_chain(W, transB=True)
+    # forward: [W0 x + b0 (no store), + W1 x2 -> u, silu(u) -> s, then three fan-out layers on s]
+    u, s = torch.empty(rows, F, device=DEV), torch.empty(rows, F, device=DEV)
+    outs = [torch.empty(rows, F, device=DEV) for _ in range(3)]
+    ops.linear_chain(x, [dict(image=img[0], bias=b[0], store=False),
+                         dict(image=img[1], x=x2, add_prev=True, out=u, out_act=s, flags=_lib.EPI_SILU)] +
+                     [dict(image=img[2 + c], bias=b[1 + c], out=outs[c], same_input=(c > 0)) for c in range(3)])
+    u_ref = ops.linear_chain(x, [dict(image=img[0], bias=b[0], store=False), dict(image=img[1], x=x2, add_prev=True)])[1]
+    s_ref = torch.empty_like(u_ref)
+    call("geossl_silu_fwd", ptr(u_ref), u_ref.numel(), ptr(s_ref), stream())
+    outs_ref = ops.linear_chain(s_ref, [dict(image=img[2 + c], bias=b[1 + c], same_input=(c > 0)) for c in range(3)])
+    assert torch.equal(u, u_ref)
+    assert rel_err(s, s_ref) < 1e-6
+    for a, r in zip(outs, outs_ref):
+        assert rel_err(a, r) < 2e-6
+    # against fp64
+    u64 = x.double() @ W[0].double().T + b[0].double() + x2.double() @ W[1].double().T
+    s64 = u64 * torch.sigmoid(u64)
+    assert rel_err(outs[1], (s64 @ W[3].double().T + b[2].double()).float()) < 3e-6
+    # backward form: (x W0^T + x2 W1^T) * silu'(u) -> d, then d W2^T
+    d = torch.empty(rows, F, device=DEV)
+    y = ops.linear_chain(x, [dict(image=img[0], store=False),
+                             dict(image=img[1], x=x2, add_prev=True, tprev=u, out=d, flags=_lib.EPI_MUL_DSILU),
+                             dict(image=img[2])])[2]
+    pre = ops.linear_chain(x, [dict(image=img[0], store=False), dict(image=img[1], x=x2, add_prev=True)])[1]
+    d_ref = torch.empty_like(pre)
+    call("geossl_silu_bwd", ptr(u), ptr(pre), pre.numel(), ptr(d_ref), stream())
+    y_ref = ops.linear_chain(d_ref, [dict(image=img[2])])[0]
+    assert rel_err(d, d_ref) < 1e-6 and rel_err(y, y_ref) < 2e-6
+    # a strided weight block (column half of a [F, 2F] matrix) gives the image of its contiguous copy
+    wide = torch.randn(F, 2 * F, generator=g).to(DEV)
+    for tb in (True, False):
+        a = ops.prepare_chain([wide[:, F:]], transB=tb)[0]
+        c = ops.prepare_chain([wide[:, F:].contiguous()], transB=tb)[0]
+        used = 4 * 8 * 2 * 64 * 4 + 4  # two fp16 pieces of every fragment + the four block exponents (the rest is unused)
+        assert torch.equal(a[:used], c[:used])
