@@ -9,11 +9,11 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(k_[a-z0-9_]+|[A-Za-z_]+Functor[A-Za-z_]*|CatArray\w*|distribution\w*|copyBuffer|radixSort\w*|\w*scan\w*)", name)
+    m = re.search(r"(k_[a-z0-9_]+|multi_tensor_apply_kernel\w*|[A-Za-z_]+Functor[A-Za-z_]*|CatArray\w*|distribution\w*|copyBuffer|radixSort\w*|\w*scan\w*)", name)
     return m.group(1) if m else name[:40]
 
 
-def main(path, back=2):
+def main(path, back=2, marker="k_adam"):
     c = sqlite3.connect(path)
     tables = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tables if t.startswith("rocpd_kernel_dispatch")][0]
@@ -22,7 +22,9 @@ def main(path, back=2):
     name_col = "kernel_name" if "kernel_name" in scols else "display_name"
     rows = list(c.execute("select s.%s, d.start, d.end from %s d join %s s on d.kernel_id = s.id order by d.start"
                           % (name_col, kd, ks)))
-    ends = [i for i, r in enumerate(rows) if "k_adam" in r[0]]
+    ends = [i for i, r in enumerate(rows) if marker in r[0]]
+    # a marker kernel that is launched several times in a row (multi-tensor optimiser kernels): the last of each run
+    ends = [i for n_, i in enumerate(ends) if n_ + 1 == len(ends) or ends[n_ + 1] - i > 8]
     lo, hi = ends[-back - 1] + 1, ends[-back] + 1
     step = rows[lo:hi]
     t0 = step[0][1]
@@ -42,4 +44,4 @@ def main(path, back=2):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 2)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 2, sys.argv[3] if len(sys.argv) > 3 else "k_adam")
