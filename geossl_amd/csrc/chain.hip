@@ -868,7 +868,7 @@ int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipS
   // the stage-input flags exist in the weight-stationary form only, and not on the first stage
   if (same_input && (!cu_form || (ch.st[0].flags & (GEOSSL_CHAIN_SAME_INPUT | GEOSSL_CHAIN_NEW_INPUT | GEOSSL_CHAIN_ADD_PREV))))
     return (int)hipErrorInvalidValue;
-  if (cu_form) {
+  if constexpr (KS == 8) {
     static const bool one_per_cu_env = getenv("GEOSSL_CHAIN_CU1") != nullptr;  // 512-register form, one block per CU
     const bool one_per_cu = one_per_cu_env && !silu;
     const int RBV = one_per_cu ? 5 : 3, slots = one_per_cu ? 256 : 512;
@@ -904,7 +904,7 @@ int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipS
     }
 #undef LAUNCH_CU_LONG
 #undef LAUNCH_CU
-  } else if (four_waves) {
+  } else if (four_waves) {  // (F = 64 / 32 only: the streaming forms are not instantiated for F = 128, whose images they cannot read)
     const int grid = ngroups < 2048 ? ngroups : 2048;  // two blocks per CU are resident (72 KB of LDS, <= 256 registers)
     const size_t lds = (size_t)nslot * CHUNK_BYTES + (size_t)ch.nstage * 16 * KS * sizeof(float);
 #define LAUNCH_NS(NSV)                                                                                           \

@@ -271,19 +271,28 @@ __global__ __launch_bounds__(512) void k_linear_split(const float* __restrict__ 
     // epilogue operands in the coalesced layout, requested one column block ahead of their use (before the MFMAs of
     // the previous block), clamped addresses
     f32x4 e0[4], e1[4], e0n[4], e1n[4];
-    auto request_e = [&](int mb, f32x4 (&a)[4], f32x4 (&b)[4]) {
+    // LATE_RES (K = 128 with both operands): the residual is requested behind the block's MFMAs, not ahead of them
+    constexpr bool LATE_RES = KS == 8 && E0 && E1;
+    auto request_e = [&](int mb, f32x4 (&a)[4], f32x4 (&b)[4], bool want_a, bool want_b) {
       const int cc = min(n0 + 32 * mb + c4, NO - 4);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const size_t oc = (size_t)min(32 * rb + 8 * u + cr, R - 1) * ldy + cc;
-        if (E0) a[u] = *reinterpret_cast<const f32x4*>(tprev + oc);
-        if (E1) b[u] = *reinterpret_cast<const f32x4*>(res + oc);
+        if (E0 && want_a) a[u] = *reinterpret_cast<const f32x4*>(tprev + oc);
+        if (E1 && want_b) b[u] = *reinterpret_cast<const f32x4*>(res + oc);
       }
     };
-    if (E0 || E1) request_e(mb_begin, e0, e1);
+    // (K = 128: the eight X fragments alone are 96 registers - the operands of a column block are requested at its own
+    // start, ahead of its MFMAs, not one block earlier: no second set of buffers, no spilled registers)
+    constexpr bool AHEAD = KS < 8;
+    if ((E0 || E1) && AHEAD) request_e(mb_begin, e0, e1, true, true);
     for (int mb = mb_begin; mb < mb_end; ++mb) {
       const int cb = n0 + 32 * mb;
-      if ((E0 || E1) && mb + 1 < mb_end) request_e(mb + 1, e0n, e1n);
+      if constexpr (AHEAD) {
+        if ((E0 || E1) && mb + 1 < mb_end) request_e(mb + 1, e0n, e1n, true, true);
+      } else {
+        if (E0 || E1) request_e(mb, e0, e1, true, !LATE_RES);
+      }
       f32x16 acc;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -300,15 +309,23 @@ __global__ __launch_bounds__(512) void k_linear_split(const float* __restrict__ 
       }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) {
+        if (AHEAD && ks + 1 < KS) {
           const u32x4* src = Wf + ((size_t)(mb * KS + ks + 1) * 3) * 64 + lane;
           an.h = src[0]; an.m = src[64]; an.l = src[128];
         }
         __builtin_amdgcn_sched_barrier(0);
         mma6(acc, af, xf[ks]);
         __builtin_amdgcn_sched_barrier(0);
-        if (ks + 1 < KS) af = an;
+        if (ks + 1 < KS) {
+          if constexpr (AHEAD) {
+            af = an;
+          } else {  // (K = 128: one set of weight fragments in flight)
+            const u32x4* src = Wf + ((size_t)(mb * KS + ks + 1) * 3) * 64 + lane;
+            af.h = src[0]; af.m = src[64]; af.l = src[128];
+          }
+        }
       }
+      if constexpr (LATE_RES) request_e(mb, e0, e1, false, true);
       // C layout (lane = row j, columns 8q + 4kh + {0..3}) -> stage -> coalesced layout
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -326,11 +343,13 @@ __global__ __launch_bounds__(512) void k_linear_split(const float* __restrict__ 
         const int row = 32 * rb + 8 * u + cr;
         if (row < R && cb + c4 < NO) *reinterpret_cast<f32x4*>(Y + (size_t)row * ldy + cb + c4) = v;
       }
-      if (E0 || E1) {
+      if constexpr (AHEAD) {
+        if (E0 || E1) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          e0[u] = e0n[u];
-          e1[u] = e1n[u];
+          for (int u = 0; u < 4; ++u) {
+            e0[u] = e0n[u];
+            e1[u] = e1n[u];
+          }
         }
       }
     }

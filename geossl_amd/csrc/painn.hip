@@ -641,7 +641,8 @@ extern "C" int geossl_painn_interaction_bwd_mol(const float* dq_out, const float
                                                 int accumulate, hipStream_t stream) {
   if (N <= 0 || B <= 0) return 0;
   size_t stage = (size_t)max_n * 4 * F, red = (size_t)3 * F * (R + 1);
-  if (!painn_mol_ok(F, max_n, (size_t)4 * F) || red * sizeof(float) > 150 * 1024)
+  // (n_rbf = 32: the molecule-staged backward would hold 32 filter rows per thread and spill; the per-atom form runs)
+  if (!painn_mol_ok(F, max_n, (size_t)4 * F) || red * sizeof(float) > 150 * 1024 || R == 32)
     return geossl_painn_interaction_bwd(dq_out, dmu_out, mu, xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, N, F, R,
                                         dxc, dmu_in, dWf, dbf, workspace, accumulate, stream);
   const int nb = (int)(B < GEOSSL_PAINN_BWD_MOL_BLOCKS ? B : GEOSSL_PAINN_BWD_MOL_BLOCKS);
@@ -657,7 +658,7 @@ extern "C" int geossl_painn_interaction_bwd_mol(const float* dq_out, const float
                        pw, pb);                                                                                     \
   } while (0)
   if (R == 20) LAUNCH_BWD_MOL(20); else if (R == 16) LAUNCH_BWD_MOL(16); else if (R == 8) LAUNCH_BWD_MOL(8);
-  else if (R == 32) LAUNCH_BWD_MOL(32); else return (int)hipErrorInvalidValue;
+  else return (int)hipErrorInvalidValue;
 #undef LAUNCH_BWD_MOL
   GEOSSL_CHECK_LAUNCH();
   ReduceMulti rm;  // both fixed-order sums over the block partials in one launch (k_reduce_partials' arithmetic)
