@@ -167,21 +167,40 @@ class _SchNetCore(torch.autograd.Function):
                 [full() for _ in range(L)]
             u, hout = full(), full()
 
-            def run_rows(a0, a1, mols):
+            def run_rows(a0, a1, mols, todo=None):
+                """the operations of the layer loop: launched one by one, or collected in `todo`"""
                 rows = lambda t_: t_[a0:a1]
-                ops.linear_chain(rows(hs[0]), [dict(image=i_lin1[0], out=rows(xs[0]))])              # conv.lin1   :189
+
+                def chain(x_, stages):
+                    if todo is not None:
+                        todo.append(("chain", x_, stages))
+                    else:
+                        ops.linear_chain(x_, stages)
+
+                chain(rows(hs[0]), [dict(image=i_lin1[0], out=rows(xs[0]))])                           # conv.lin1   :189
                 for l, lp in enumerate(layers):
-                    ops.aggregate(xs[l], Wf[l], pair_flag, lay, out=aggs[l], mols=mols)   # propagate   :190
+                    if todo is not None:
+                        todo.append(("agg", xs[l], Wf[l], aggs[l], False))
+                    else:
+                        ops.aggregate(xs[l], Wf[l], pair_flag, lay, out=aggs[l], mols=mols)            # propagate   :190
                     stages = [dict(image=i_lin2[l], bias=lp[6], flags=_lib.EPI_SSP, out=rows(ts[l])),  # conv.lin2 + act
                               dict(image=i_lin[l], bias=lp[8], res=rows(hs[l]), out=rows(hs[l + 1]))]  # lin + residual
                     if l + 1 < L:
                         stages.append(dict(image=i_lin1[l + 1], out=rows(xs[l + 1])))                  # next conv.lin1
                     else:
                         stages.append(dict(image=img[3 * L], bias=head[1], flags=_lib.EPI_SSP, out=rows(u)))  # :99-100
-                    ops.linear_chain(rows(aggs[l]), stages)
-                ops.linear_chain(rows(u), [dict(image=img[3 * L + 1], bias=head[3], out=rows(hout))])  # lin2        :101
+                    chain(rows(aggs[l]), stages)
+                chain(rows(u), [dict(image=img[3 * L + 1], bias=head[3], out=rows(hout))])             # lin2        :101
 
-            run_rows(0, N, None)
+            # One launch for the whole loop where the shape allows (every block carries its molecules through all
+            # operations, ops.layer_loop), else 14 launches
+            todo = [] if (cfg["loop"] and P > 0 and 2 * L + 2 <= _lib.LOOP_MAX_OPS) else None
+            if todo is not None:
+                run_rows(0, N, None, todo)
+                if not ops.layer_loop(todo, lay, pair_flag, N, F, stagger=cfg["loop_stagger"]):
+                    todo = None
+            if todo is None:
+                run_rows(0, N, None)
             h = hs[L]
             hs = hs[:L]
             if not training:
@@ -259,22 +278,38 @@ class _SchNetCore(torch.autograd.Function):
             dys, dxs = [full() for _ in range(L)], [full() for _ in range(L)]
             daggs = [full() for _ in range(L)]
 
-            def run_rows(a0, a1, mols):
+            def run_rows(a0, a1, mols, todo=None):
                 rows = lambda t_: t_[a0:a1]
-                ops.linear_chain(rows(dh_out), [dict(image=img[3 * L + 1], tprev=rows(sv["u"]), out=rows(du)),
-                                                dict(image=img[3 * L], out=rows(dhs[L]))])
-                ops.linear_chain(rows(dhs[L]), [dict(image=i_lin[L - 1], tprev=rows(sv["ts"][L - 1]), out=rows(dys[L - 1])),
-                                                dict(image=i_lin2[L - 1], out=rows(daggs[L - 1]))])
+
+                def chain(x_, stages):
+                    if todo is not None:
+                        todo.append(("chain", x_, stages))
+                    else:
+                        ops.linear_chain(x_, stages)
+
+                chain(rows(dh_out), [dict(image=img[3 * L + 1], tprev=rows(sv["u"]), out=rows(du)),
+                                     dict(image=img[3 * L], out=rows(dhs[L]))])
+                chain(rows(dhs[L]), [dict(image=i_lin[L - 1], tprev=rows(sv["ts"][L - 1]), out=rows(dys[L - 1])),
+                                     dict(image=i_lin2[L - 1], out=rows(daggs[L - 1]))])
                 for l in reversed(range(L)):
-                    ops.aggregate(daggs[l], sv["Wf"][l], sv["pair_flag"], lay, swap=True, out=dxs[l],
-                                  mols=mols)                                        # transposed graph
+                    if todo is not None:
+                        todo.append(("agg", daggs[l], sv["Wf"][l], dxs[l], True))
+                    else:
+                        ops.aggregate(daggs[l], sv["Wf"][l], sv["pair_flag"], lay, swap=True, out=dxs[l],
+                                      mols=mols)                                    # transposed graph
                     stages = [dict(image=i_lin1[l], res=rows(dhs[l + 1]), out=rows(dhs[l]))]      # conv.lin1 + residual
                     if l > 0:
                         stages += [dict(image=i_lin[l - 1], tprev=rows(sv["ts"][l - 1]), out=rows(dys[l - 1])),
                                    dict(image=i_lin2[l - 1], out=rows(daggs[l - 1]))]
-                    ops.linear_chain(rows(dxs[l]), stages)
+                    chain(rows(dxs[l]), stages)
 
-            run_rows(0, N, None)
+            todo = [] if (cfg["loop"] and lay.P > 0 and 2 * L + 2 <= _lib.LOOP_MAX_OPS) else None
+            if todo is not None:
+                run_rows(0, N, None, todo)
+                if not ops.layer_loop(todo, lay, sv["pair_flag"], N, F, stagger=cfg["loop_stagger"]):
+                    todo = None
+            if todo is None:
+                run_rows(0, N, None)
             probs.append((dh_out, sv["u"], g_head[2], g_head[3]))
             probs.append((du, sv["h_last"], g_head[0], g_head[1]))
             for l in reversed(range(L)):
@@ -457,7 +492,11 @@ class SchNet(torch.nn.Module):
         cfg = dict(L=self.num_interactions, F=self.hidden_channels, G=self.num_gaussians, cutoff=float(self.cutoff),
                    offset=self.distance_expansion.offset, coeff=float(self.distance_expansion.coeff),
                    debug=bool(os.environ.get("GEOSSL_DEBUG")), status=status,
-                   chain=self.num_interactions >= 1 and not os.environ.get("GEOSSL_NO_CHAIN"))
+                   chain=self.num_interactions >= 1 and not os.environ.get("GEOSSL_NO_CHAIN"),
+                   # the layer loop (chains and aggregations between the filter network and the heads) as ONE launch
+                   # per pass, ops.layer_loop; GEOSSL_NO_LAYER_LOOP: the 26 separate launches (A/B runs)
+                   loop=not os.environ.get("GEOSSL_NO_LAYER_LOOP"),
+                   loop_stagger=int(os.environ.get("GEOSSL_LAYER_LOOP_STAGGER") or 0))
         if pos.dtype != torch.float32:
             raise TypeError("positions must be float32")
         h = _SchNetCore.apply(z, pos.contiguous(), lay, cfg, *_core_params(self))

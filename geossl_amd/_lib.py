@@ -42,6 +42,13 @@ class Chain(C.Structure):
     _fields_ = [("nstage", i32), ("st", ChainStage * CHAIN_MAX)]
 
 
+LOOP_MAX_OPS = 14
+
+
+class LoopOp(C.Structure):
+    _fields_ = [("kind", i32), ("swap", i32), ("X", vp), ("Wf", vp), ("out", vp), ("chain", Chain)]
+
+
 class FilterGradIn(C.Structure):
     _fields_ = [("x", vp * MAX_L), ("dagg", vp * MAX_L)]
 
@@ -115,6 +122,7 @@ PROTOTYPES = {
     "geossl_incidence_fill": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp]),
     "geossl_ddm_loss_fwd_workspace_floats": (i64, [i32]),
     "geossl_ddm_loss_fwd": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, P(NcsnWeights), i32, f32, vp, P(NcsnSaved), vp, vp]),
+    "geossl_schnet_layer_loop": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, i64, i32, i32, vp]),
     "geossl_copy2": (i32, [vp, vp, i64, vp, vp, i64, vp]),
     "geossl_ddm_views": (i32, [vp, vp, vp, vp, i64, i64, vp, vp, vp, vp]),
     "geossl_loss_reduce_partials": (i32, [vp, vp, f32, vp, i32, vp]),

@@ -22,6 +22,7 @@
 #include "common.h"
 #include "geossl_hip.h"
 #include "split.h"
+#include "aggregate_reg.h"
 
 #include <cstdlib>
 
@@ -562,8 +563,11 @@ __device__ __forceinline__ float dsilu_f(float x) {                             
   const float sg = 1.0f / (1.0f + expf(-x));
   return sg * (1.0f + x * (1.0f - sg));
 }
-template <int NS, int RB, int WPS, bool SILU>
-__global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const float* __restrict__ X, int ldx, int R) {
+// The body works on rows row0 + 32 i + j, i < nloc <= RB, that lie below row_end (k_row_chain_cu: a run of whole row
+// blocks of the launch; k_layer_loop: the atoms of a block's molecules); R = rows of the tensors (buffer ranges).
+template <int NS, int RB, int WPS, bool SILU, typename ChainT>
+__device__ __forceinline__ void chain_cu_body(const ChainT& ch, const float* __restrict__ X, int ldx, int R,
+                                              int row0, int row_end, int nloc) {
   constexpr int KS = 8, F = 128;
   constexpr int RBF = KS * 2 * 64;      // u32x4 per row block of fragments (two fp16 pieces, split.h)
 #ifndef CHAIN_CU_NEB2
@@ -578,17 +582,11 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
   float* rmax = bias_s + NS * F;                                          // [RB][4][32] largest |value| of a row in a wave's columns
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
   const int m = __builtin_amdgcn_readfirstlane(tid >> 6);                  // this wave's column block
-  const int nrb = (R + 31) / 32;
-  // contiguous runs of row blocks: the first `extra` blocks take one more (they are the first to be placed on a CU, so
-  // a CU that holds two blocks holds at most one long one)
-  const int nblk = (int)gridDim.x, base = nrb / nblk, extra = nrb - base * nblk, b = (int)blockIdx.x;
-  const int rb0 = b * base + min(b, extra);
-  const int nloc = base + (b < extra ? 1 : 0);                             // <= RB, uniform
   const uint32_t voff = (uint32_t)lane * 16u;
   Frag2 af[KS];
   int eW = 0;            // exponent of the stage's weight scale (stored behind the image by k_chain_prepare)
   float krow[RB];        // 2^(e_row - 14) of the rows whose fragments sit in xbuf: undoes their scale
-  auto request_weights = [&](const GeosslChainStage& st) __attribute__((always_inline)) {
+  auto request_weights = [&](const auto& st) __attribute__((always_inline)) {
     const char* img = reinterpret_cast<const char*>(st.image) + (size_t)(m * KS) * 2 * 1024;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -623,7 +621,7 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
     const char* xb = reinterpret_cast<const char*>(Xp) + 128 * m;
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      const uint32_t rowc = (uint32_t)min(32 * (rb0 + min(i, nloc - 1)) + j, R - 1);
+      const uint32_t rowc = (uint32_t)min(row0 + 32 * min(i, nloc - 1) + j, row_end - 1);
       const uint32_t xo = rowc * (uint32_t)ldxp * 4u + 16u * kh;
 #pragma unroll
       for (int q = 0; q < 4; ++q) raw[i][q] = *reinterpret_cast<const f32x4*>(xb + 32 * q + xo);
@@ -659,7 +657,7 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
   float vout[RB][16];  // a stage's results (this wave's column block of every row block)
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const GeosslChainStage st = ch.st[s];
+    const auto st = ch.st[s];
     const int eWs = eW;
     f32x4 tp[NEB][4], rs[NEB][4];
     // Every vector-memory instruction of the stage loop is issued unconditionally (buffer addressing: a null operand
@@ -673,8 +671,8 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(st.out_act, 0, (SILU && st.out_act != nullptr) ? nbytes : 0u, 0x00020000);
     const bool act_silu = SILU && (st.flags & GEOSSL_EPI_SILU) != 0;
     auto row_off = [&](int i) __attribute__((always_inline)) {
-      const int row = 32 * (rb0 + i) + j;
-      return row < R ? (uint32_t)row * (uint32_t)st.ld * 4u + 128u * m + 16u * kh : 0xFFFFFF00u;  // out of range (also + 96): dropped
+      const int row = row0 + 32 * i + j;
+      return row < row_end ? (uint32_t)row * (uint32_t)st.ld * 4u + 128u * m + 16u * kh : 0xFFFFFF00u;  // out of range (also + 96): dropped
     };
     auto request_epi = [&](int i, f32x4 (&t)[4], f32x4 (&r)[4]) __attribute__((always_inline)) {
       const uint32_t ro = row_off(i);
@@ -831,6 +829,89 @@ __global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const
   }
 }
 
+template <int NS, int RB, int WPS, bool SILU>
+__global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const float* __restrict__ X, int ldx, int R) {
+  const int nrb = (R + 31) / 32;
+  // contiguous runs of row blocks: the first `extra` blocks take one more (they are the first to be placed on a CU, so
+  // a CU that holds two blocks holds at most one long one)
+  const int nblk = (int)gridDim.x, base = nrb / nblk, extra = nrb - base * nblk, b = (int)blockIdx.x;
+  const int rb0 = b * base + min(b, extra);
+  const int nloc = base + (b < extra ? 1 : 0);                             // <= RB, uniform
+  chain_cu_body<NS, RB, WPS, SILU>(ch, X, ldx, R, 32 * rb0, R, nloc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The layer loop of the SchNet backbone in ONE launch (geossl_schnet_layer_loop).  Everything between the filter
+// network and the heads is local to a molecule: the row-local Linear chains (this file) and the neighbour aggregation
+// (aggregate_reg.h) alternate, and neither ever reads a row of another molecule.  A block of four waves therefore owns a
+// few molecules (<= 96 atom rows, <= RB row blocks) through ALL operations: chain of stages over its rows (wave m =
+// column block m, as in k_row_chain_cu), block barrier, aggregation of its molecules (wave w = every fourth molecule,
+// as in k_aggregate_reg), barrier, next chain ...  No grid-wide dependency exists, so 12 + 14 launches of a step become
+// two - and the blocks need not be in the same phase: the second half of the grid starts `stagger` sleeps late, so that
+// one half is in its (latency-bound, HBM idle) chain while the other half streams filter rows at full HBM speed.
+struct LoopStage {  // a stage of GeosslChain with what the loop does not use fixed at compile time
+  const uint32_t* image;
+  const float* bias;
+  const float* res;
+  const float* tprev;
+  float* out;
+  int flags, pad;
+  static constexpr int ld = 128, ldxin = 0;
+  static constexpr const float* xin = nullptr;
+  static constexpr float* out_act = nullptr;
+};
+struct LoopOp {
+  const float* X;   // chain: input rows; aggregation: x
+  const float* Wf;  // aggregation: filter rows of the block
+  float* out;       // aggregation: destination rows
+  int kind, nstage, swap, pad;
+  LoopStage st[3];  // (chain_cu_body reads ch.st[s]: the operation is its own chain)
+};
+constexpr int LOOP_MAX_OPS = 14;
+struct LoopArgs {
+  LoopOp op[LOOP_MAX_OPS];
+  const int4* plan;  // per block: first row, end row, first molecule, end molecule
+  const int32_t* mol_ptr;
+  const int32_t* pair_ptr;
+  const uint8_t* pair_flag;
+  int nops, R, stagger, pad;
+};
+
+template <int NMAX>
+__global__ __launch_bounds__(256, 2) void k_layer_loop(LoopArgs a) {
+  constexpr int F = 128;
+  const int4 pl = a.plan[blockIdx.x];
+  const int nloc = (pl.y - pl.x + 31) / 32;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if ((int)blockIdx.x >= ((int)gridDim.x + 1) / 2)
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  for (int o = 0; o < a.nops; ++o) {
+    const LoopOp& op = a.op[o];
+    if (op.kind == 0) {
+      if (op.nstage == 1) chain_cu_body<1, 3, 2, false>(op, op.X, F, a.R, pl.x, pl.y, nloc);
+      else if (op.nstage == 2) chain_cu_body<2, 3, 2, false>(op, op.X, F, a.R, pl.x, pl.y, nloc);
+      else chain_cu_body<3, 3, 2, false>(op, op.X, F, a.R, pl.x, pl.y, nloc);
+    } else {
+      for (int mm = pl.z + wave; mm < pl.w; mm += 4) {
+        const int a0 = a.mol_ptr[mm], n = a.mol_ptr[mm + 1] - a0, base = a.pair_ptr[mm];
+        if constexpr (NMAX > 0) {
+          aggregate_reg_body<NMAX>(op.X, op.Wf, a.pair_flag, a0, n, base, lane, 2 * lane, F, op.swap, op.out);
+        } else {  // ragged batch: every wave takes the unrolled walk of its molecule's size class (k_aggregate_reg_ragged)
+          const int nu = __builtin_amdgcn_readfirstlane(n);
+          // (ring of filter-row requests of the largest classes: 12 instead of 24 - this kernel also holds the chain's state)
+#define LOOP_CLASS(NM, RING) if (nu <= NM) aggregate_reg_body<NM, RING>(op.X, op.Wf, a.pair_flag, a0, n, base, lane, 2 * lane, F, op.swap, op.out); else
+          LOOP_CLASS(8, 0) LOOP_CLASS(12, 0) LOOP_CLASS(16, 0) LOOP_CLASS(18, 0) LOOP_CLASS(20, 0) LOOP_CLASS(22, 0)
+          LOOP_CLASS(24, 0) LOOP_CLASS(26, 0) LOOP_CLASS(28, 12) LOOP_CLASS(30, 12) LOOP_CLASS(33, 12) {}
+#undef LOOP_CLASS
+        }
+      }
+    }
+    // the next operation reads what this one wrote (rows of the block's own molecules, through L2), and reuses the LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
 template <int KS>
 int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipStream_t stream) {
   constexpr int NMB = KS / 2, CHUNK_BYTES = KS * 3 * 1024;
@@ -871,7 +952,8 @@ int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipS
   if constexpr (KS == 8) {
     static const bool one_per_cu_env = getenv("GEOSSL_CHAIN_CU1") != nullptr;  // 512-register form, one block per CU
     const bool one_per_cu = one_per_cu_env && !silu;
-    const int RBV = one_per_cu ? 5 : 3, slots = one_per_cu ? 256 : 512;
+    static const int slots_env = getenv("GEOSSL_CHAIN_SLOTS") != nullptr ? atoi(getenv("GEOSSL_CHAIN_SLOTS")) : 0;  // experiments
+    const int RBV = one_per_cu ? 5 : 3, slots = slots_env > 0 ? slots_env : (one_per_cu ? 256 : 512);
     const int need = (nrb + RBV - 1) / RBV;                       // blocks so that none takes more than RB row blocks
     const int fill = nrb < slots ? nrb : slots;                   // blocks so that every slot of the chip has work
     const int grid = need > fill ? need : fill;
@@ -984,4 +1066,58 @@ extern "C" int geossl_linear_chain(const float* X, int ldx, const GeosslChain* c
   if (F == 128) return launch_chain<8>(*chain, X, ldx, R, stream);
   if (F == 64) return launch_chain<4>(*chain, X, ldx, R, stream);
   return launch_chain<2>(*chain, X, ldx, R, stream);
+}
+
+extern "C" int geossl_schnet_layer_loop(const GeosslLoopOp* ops, int nops, const int32_t* plan, int nblocks,
+                                        const int32_t* mol_ptr, const int32_t* pair_ptr, const uint8_t* pair_flag,
+                                        int max_n, int uniform, int64_t N, int F, int stagger, hipStream_t stream) {
+  if (nops <= 0 || nblocks <= 0) return 0;
+  if (ops == nullptr || plan == nullptr || nops > LOOP_MAX_OPS || F != 128 || max_n > 33 || N <= 0) return (int)hipErrorInvalidValue;
+  if (N * (int64_t)F * 4 >= (int64_t)0xFFFFFF00u) return (int)hipErrorInvalidValue;  // 32-bit buffer offsets
+  LoopArgs a;
+  for (int o = 0; o < nops; ++o) {
+    const GeosslLoopOp& src = ops[o];
+    LoopOp& d = a.op[o];
+    d.kind = src.kind; d.swap = src.swap; d.X = src.X; d.Wf = src.Wf; d.out = src.out; d.pad = 0;
+    d.nstage = src.kind == 0 ? src.chain.nstage : 0;
+    if (src.X == nullptr) return (int)hipErrorInvalidValue;
+    if (src.kind == 0) {
+      if (src.chain.nstage < 1 || src.chain.nstage > 3) return (int)hipErrorInvalidValue;
+      for (int s2 = 0; s2 < 3; ++s2) {
+        LoopStage& ls = d.st[s2];
+        if (s2 < src.chain.nstage) {
+          const GeosslChainStage& st = src.chain.st[s2];
+          // plain stages only: dense [N][F] operands, no stage-input flags, no silu forms
+          if (st.image == nullptr || (st.flags & ~(GEOSSL_EPI_BIAS | GEOSSL_EPI_SSP | GEOSSL_EPI_RESIDUAL | GEOSSL_EPI_MUL_DSSP)) ||
+              ((st.out != nullptr || st.res != nullptr || st.tprev != nullptr) && st.ld != F) || st.xin != nullptr ||
+              st.out_act != nullptr)
+            return (int)hipErrorInvalidValue;
+          ls.image = st.image; ls.bias = st.bias; ls.res = st.res; ls.tprev = st.tprev; ls.out = st.out; ls.flags = st.flags;
+        } else {
+          ls.image = nullptr; ls.bias = nullptr; ls.res = nullptr; ls.tprev = nullptr; ls.out = nullptr; ls.flags = 0;
+        }
+        ls.pad = 0;
+      }
+    } else if (src.kind == 1) {
+      if (src.Wf == nullptr || src.out == nullptr) return (int)hipErrorInvalidValue;
+      for (int s2 = 0; s2 < 3; ++s2) d.st[s2] = LoopStage{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    } else {
+      return (int)hipErrorInvalidValue;
+    }
+  }
+  a.plan = reinterpret_cast<const int4*>(plan);
+  a.mol_ptr = mol_ptr; a.pair_ptr = pair_ptr; a.pair_flag = pair_flag;
+  a.nops = nops; a.R = (int)N; a.stagger = stagger; a.pad = 0;
+  const size_t lds = (size_t)3 * 8 * 2 * 1024 + (size_t)3 * 128 * sizeof(float) + (size_t)3 * 128 * sizeof(float);
+  // uniform == every molecule has max_n atoms (the caller knows): the walk of that class alone; else the kernel that
+  // holds every class
+  if (uniform && max_n == 18) {
+    allow_big_lds(&k_layer_loop<18>);
+    hipLaunchKernelGGL((k_layer_loop<18>), dim3(nblocks), dim3(256), lds, stream, a);
+  } else {
+    allow_big_lds(&k_layer_loop<0>);
+    hipLaunchKernelGGL((k_layer_loop<0>), dim3(nblocks), dim3(256), lds, stream, a);
+  }
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
 }

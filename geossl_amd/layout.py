@@ -81,6 +81,38 @@ class MolLayout:
             self.agg_work = torch.from_numpy((mol | (part << 28)).astype(np.int32)).to(dev)
         self.device = dev
         self._batch_version = batch._version
+        self._sizes_host = sizes
+        self._loop_plan = None
+        self.uniform = False
+
+    def loop_plan(self, max_rows=96, max_mols=None):
+        """Blocks of the layer loop (geossl_schnet_layer_loop): consecutive molecules packed into blocks of at most
+        `max_rows` atom rows and `max_mols` molecules -> (int32 tensor [nblocks, 4] = first row, end row, first molecule,
+        end molecule; nblocks), or None when a molecule does not fit a block.  From host sizes when the layout was built
+        from them, else from one read-back of mol_ptr (cached)."""
+        if self._loop_plan is None:
+            sizes = self._sizes_host
+            if sizes is None:
+                mp = self.mol_ptr.cpu().numpy()
+                sizes = (mp[1:] - mp[:-1]).tolist()
+            plan, row, m = [], 0, 0
+            B = len(sizes)
+            if max_mols is None:  # one molecule per wave of a block, fewer when the batch would not fill the chip's 512 slots
+                max_mols = min(4, max(1, -(-B // 512)))
+            if any(n > max_rows for n in sizes) or B == 0:
+                self._loop_plan = (None, 0)
+                return self._loop_plan
+            while m < B:
+                r0, m0, rows = row, m, 0
+                while m < B and m - m0 < max_mols and rows + sizes[m] <= max_rows:
+                    rows += sizes[m]
+                    m += 1
+                row += rows
+                plan.append((r0, row, m0, m))
+            t_ = torch.tensor(plan, dtype=torch.int32).to(self.device)
+            self.uniform = len(set(sizes)) == 1
+            self._loop_plan = (t_, len(plan))
+        return self._loop_plan
 
 
 def get_layout(batch):

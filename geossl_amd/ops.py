@@ -198,6 +198,48 @@ def linear_chain(x, stages):
     return outs
 
 
+def _fill_chain(ch, stages, R, F):
+    """stage dicts (image / bias / res / tprev / out / flags, all operands dense [R, F]) -> a _lib.Chain"""
+    ch.nstage = len(stages)
+    for s, sd in enumerate(stages):
+        st = ch.st[s]
+        for a in (sd.get("out"), sd.get("res"), sd.get("tprev")):
+            assert a is None or (a.shape == (R, F) and a.is_contiguous())
+        st.image, st.bias, st.res, st.tprev, st.out = (ptr(sd["image"]), ptr(sd.get("bias")), ptr(sd.get("res")),
+                                                       ptr(sd.get("tprev")), ptr(sd.get("out")))
+        st.ld, st.flags = F, int(sd.get("flags", 0))
+        st.xin, st.ldxin, st.out_act = None, 0, None
+
+
+def layer_loop(ops_list, layout, pair_flag, N, F, stagger=0):
+    """The operations of `ops_list` - ("chain", x, stages) / ("agg", x, Wf_l, out, swap) - as ONE launch in which every
+    block carries its own molecules through all of them (geossl_schnet_layer_loop).  Returns False when the shape has no
+    such path (the caller then launches them one by one)."""
+    plan, nblk = layout.loop_plan()
+    if plan is None or F != 128 or layout.max_n > 33 or len(ops_list) > _lib.LOOP_MAX_OPS:
+        return False
+    if not layout.uniform and layout.max_n > 20:
+        # ragged batch with large molecules: a block's aggregation lasts as long as the walk of its largest molecule
+        # (n^2 positions on ONE wave), and that block sets the duration of the whole launch; the separate launches
+        # share such molecules between two or four waves (MolLayout.agg_work) - measured 352 k against 337 k (set B)
+        return False
+    arr = (_lib.LoopOp * len(ops_list))()
+    for i, op in enumerate(ops_list):
+        o = arr[i]
+        if op[0] == "chain":
+            _, x, stages = op
+            assert x.shape == (N, F) and x.is_contiguous() and len(stages) <= 3
+            o.kind, o.swap, o.X, o.Wf, o.out = 0, 0, ptr(x), None, None
+            _fill_chain(o.chain, stages, N, F)
+        else:
+            _, x, Wf_l, out, swap = op
+            o.kind, o.swap, o.X, o.Wf, o.out = 1, 1 if swap else 0, ptr(x), ptr(Wf_l), ptr(out)
+            o.chain.nstage = 0
+    call("geossl_schnet_layer_loop", C.byref(arr), len(ops_list), ptr(plan), nblk, ptr(layout.mol_ptr), ptr(layout.pair_ptr),
+         ptr(pair_flag), layout.max_n, 1 if layout.uniform else 0, N, F, int(stagger), stream())
+    return True
+
+
 def linear_wgrad(problems, R, M, N, accumulate=False, lda=None, ldb=None, ldw=None):
     """Batched weight gradients.  problems: list of (A [R,M], B [R,N], dW [M,N], db [M] or None); lda/ldb/ldw are
     the row strides when A / B / dW are column slices of wider tensors."""

@@ -223,6 +223,28 @@ int64_t geossl_chain_image_words(int F);
 int geossl_chain_prepare(const GeosslPrepareBatch* batch, int nprob, int F, int transB, hipStream_t stream);
 int geossl_linear_chain(const float* X, int ldx, const GeosslChain* chain, int64_t R, int F, hipStream_t stream);
 
+/* The layer loop of the SchNet backbone in one launch (schnet.py:95-101 between the filter network and the heads, and
+ * its backward): a list of operations that each block of the launch applies, in order, to the rows of the molecules it
+ * owns - kind 0: the chain of geossl_linear_chain over those rows (plain stages: dense [N][F] operands, at most three),
+ * kind 1: geossl_cfconv_aggregate for those molecules (x = X, filter rows Wf, destination out; swap as there).  `plan`
+ * [nblocks][4] int32 = {first row, end row, first molecule, end molecule} of a block (at most 96 rows; consecutive
+ * blocks cover the batch).  uniform != 0: every molecule has max_n atoms.  stagger: the second half of the grid starts
+ * that many sleeps late (0 = in step; for experiments).  F = 128, molecules of at most 33 atoms; anything else returns
+ * hipErrorInvalidValue and the caller launches the operations one by one.  Same arithmetic as the separate launches:
+ * results bit-identical. */
+#define GEOSSL_LOOP_MAX_OPS 14
+typedef struct {
+  int kind; /* 0 = chain, 1 = aggregation */
+  int swap;
+  const float* X;
+  const float* Wf;
+  float* out;
+  GeosslChain chain;
+} GeosslLoopOp;
+int geossl_schnet_layer_loop(const GeosslLoopOp* ops, int nops, const int32_t* plan, int nblocks, const int32_t* mol_ptr,
+                             const int32_t* pair_ptr, const uint8_t* pair_flag, int max_n, int uniform, int64_t N, int F,
+                             int stagger, hipStream_t stream);
+
 /* batched weight gradients: dW_z[m][n] (+)= sum_r A_z[r][m]*B_z[r][n], db_z[m] (+)= sum_r A_z[r][m];
  * lda / ldb / ldw: row strides of A_z, B_z, dW_z (M, N <= 128 per problem: wider layers are tiled by the caller)  */
 typedef struct {
