@@ -377,3 +377,43 @@ def test_chain_silu_epilogues_match_separate_silu_launches(rows):
         c = ops.prepare_chain([wide[:, F:].contiguous()], transB=tb)[0]
         used = 4 * 8 * 2 * 64 * 4 + 4  # two fp16 pieces of every fragment + the four block exponents (the rest is unused)
         assert torch.equal(a[:used], c[:used])
+
+
+@pytest.mark.parametrize("sizes", [[18] * 40, [5, 9, 18, 20, 2, 1, 13, 17, 20, 11, 3, 16] * 3, [18] * 7 + [30] + [12] * 5])
+def test_layer_loop_is_the_separate_launches_bit_for_bit(sizes, monkeypatch):
+    """geossl_schnet_layer_loop (every chain and aggregation of the backbone between the filter network and the heads as
+    ONE launch per pass, a block carrying its molecules through all of them) against the 26 separate launches: atom
+    features, and every parameter gradient, bit for bit - uniform molecules (the single-class kernel), ragged ones up to
+    20 atoms (the kernel that holds every class), and a batch with a 30-atom molecule (falls back to separate launches)."""
+    from geossl_amd import _lib
+    from geossl_amd.Geom3D.dataloaders.dataloaders_AtomTuple import BatchAtomTuple
+    g = torch.Generator().manual_seed(len(sizes))
+    N = sum(sizes)
+    x = torch.randint(0, 9, (N, 1), generator=g).to(DEV)
+    pos = (torch.randn(N, 3, generator=g) * 2).to(DEV)
+    data = BatchAtomTuple.from_sizes(x, pos, sizes, option="combination")
+    torch.manual_seed(1)
+    model = product_schnet(FULL, DEV)
+    w = torch.randn(N, 128, generator=g).to(DEV)
+
+    def run(loop):
+        if loop:
+            monkeypatch.delenv("GEOSSL_NO_LAYER_LOOP", raising=False)
+        else:
+            monkeypatch.setenv("GEOSSL_NO_LAYER_LOOP", "1")
+        for p in model.parameters():
+            p.grad = None
+        _lib.CALLS = 0
+        _, h = model(x[:, 0], pos, data.batch, return_latent=True)
+        (h * w).sum().backward()
+        calls, _lib.CALLS = _lib.CALLS, None
+        return h.detach().clone(), [p.grad.clone() for p in model.parameters() if p.grad is not None], calls
+
+    h0, g0, c0 = run(False)
+    h1, g1, c1 = run(True)
+    assert torch.equal(h0, h1)
+    assert len(g0) == len(g1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+    if max(sizes) <= 20:
+        assert c1 == c0 - 2 * (2 * 6 + 2) + 2      # 14 launches per pass became one
+    else:
+        assert c1 == c0                              # large ragged molecules: the separate launches
