@@ -84,17 +84,24 @@ class MolLayout:
         self._sizes_host = sizes
         self._loop_plan = None
         self.uniform = False
+        if sizes is not None:
+            self.loop_plan()  # now, from the host sizes: its small upload must not fall into a graph capture
 
     def loop_plan(self, max_rows=96, max_mols=None):
         """Blocks of the layer loop (geossl_schnet_layer_loop): consecutive molecules packed into blocks of at most
         `max_rows` atom rows and `max_mols` molecules -> (int32 tensor [nblocks, 4] = first row, end row, first molecule,
-        end molecule; nblocks), or None when a molecule does not fit a block.  From host sizes when the layout was built
-        from them, else from one read-back of mol_ptr (cached)."""
+        end molecule; nblocks), or (None, 0) when a molecule does not fit a block or the layout was not built from host
+        sizes (a loader that knows them passes them: prepare_batch, BatchAtomTuple.from_sizes / from_data_list)."""
         if self._loop_plan is None:
             sizes = self._sizes_host
+            if sizes is not None and torch.cuda.is_current_stream_capturing():
+                return (None, 0)  # (no upload inside a capture; not remembered)
             if sizes is None:
-                mp = self.mol_ptr.cpu().numpy()
-                sizes = (mp[1:] - mp[:-1]).tolist()
+                # a layout built from the batch vector alone: the sizes are on the device only, and reading them back
+                # would drain the stream once per new batch (0.3 ms measured on the forward-only line) - no plan, the
+                # caller launches the operations one by one
+                self._loop_plan = (None, 0)
+                return self._loop_plan
             plan, row, m = [], 0, 0
             B = len(sizes)
             if max_mols is None:  # one molecule per wave of a block, fewer when the batch would not fill the chip's 512 slots
@@ -119,9 +126,15 @@ def get_layout(batch):
     """Layout cached on the batch tensor object itself (the same object is passed for both views
     and both heads of a DDM step)."""
     lay = getattr(batch, "_geossl_layout", None)
+    hs = getattr(batch, "_geossl_sizes", None)  # (host sizes, tensor version) left by prepare_batch
+    sizes = hs[0] if hs is not None and hs[1] == batch._version and sum(hs[0]) == batch.numel() else None
     if lay is None or lay._batch_version != batch._version or lay.N != batch.numel():
-        lay = MolLayout(batch)
+        lay = MolLayout(batch, sizes=sizes)
         batch._geossl_layout = lay
+    elif sizes is not None and lay._sizes_host is None and len(sizes) == lay.B:
+        lay._sizes_host, lay._loop_plan = sizes, None  # a layout built before the collation's sizes were attached
+        if not torch.cuda.is_current_stream_capturing():
+            lay.loop_plan()
     return lay
 
 
@@ -179,6 +192,7 @@ def prepare_batch(batch_vec, super_edge_index, sizes):
     b2 = torch.cat([batch_vec, batch_vec + B])
     lay2 = MolLayout(b2, 2 * B, sizes=sizes + sizes)
     batch_vec._geossl_two_view = (b2, lay2, batch_vec._version)
+    batch_vec._geossl_sizes = (sizes, batch_vec._version)  # a one-view layout (get_layout), if one is asked for, is built from them too
     if super_edge_index is not None:
         # the caller built super_edge_index from the same sizes (AtomTupleExtractor): its grouping needs no check
         get_super_edge_layout(batch_vec, super_edge_index, B, validate=False)

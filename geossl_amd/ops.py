@@ -3,6 +3,7 @@ stream).  Every function takes/returns CUDA tensors; nothing here computes on th
 import ctypes as C
 import math
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -198,23 +199,20 @@ def linear_chain(x, stages):
     return outs
 
 
-def _fill_chain(ch, stages, R, F):
-    """stage dicts (image / bias / res / tprev / out / flags, all operands dense [R, F]) -> a _lib.Chain"""
-    ch.nstage = len(stages)
-    for s, sd in enumerate(stages):
-        st = ch.st[s]
-        for a in (sd.get("out"), sd.get("res"), sd.get("tprev")):
-            assert a is None or (a.shape == (R, F) and a.is_contiguous())
-        st.image, st.bias, st.res, st.tprev, st.out = (ptr(sd["image"]), ptr(sd.get("bias")), ptr(sd.get("res")),
-                                                       ptr(sd.get("tprev")), ptr(sd.get("out")))
-        st.ld, st.flags = F, int(sd.get("flags", 0))
-        st.xin, st.ldxin, st.out_act = None, 0, None
+# GeosslLoopOp as 64-bit words (include/geossl_hip.h; checked against the ctypes layout when the module is imported):
+# word 0 = kind | swap << 32, 1 = X, 2 = Wf, 3 = out, 4 = chain.nstage, then 9 words per stage: image, bias, res, tprev,
+# out, ld | flags << 32, xin, ldxin, out_act
+_LOOP_WORDS, _LOOP_STAGE0, _LOOP_STAGE_WORDS = 50, 5, 9
+assert C.sizeof(_lib.LoopOp) == 8 * _LOOP_WORDS and _lib.LoopOp.chain.offset == 32 and _lib.Chain.st.offset == 8 \
+    and C.sizeof(_lib.ChainStage) == 8 * _LOOP_STAGE_WORDS and _lib.ChainStage.ld.offset == 40 \
+    and _lib.ChainStage.out_act.offset == 64
 
 
 def layer_loop(ops_list, layout, pair_flag, N, F, stagger=0):
     """The operations of `ops_list` - ("chain", x, stages) / ("agg", x, Wf_l, out, swap) - as ONE launch in which every
     block carries its own molecules through all of them (geossl_schnet_layer_loop).  Returns False when the shape has no
-    such path (the caller then launches them one by one)."""
+    such path (the caller then launches them one by one).  The operation list is written as plain 64-bit words (a
+    field-by-field ctypes fill of 14 operations cost more host time than the 14 calls it replaces)."""
     plan, nblk = layout.loop_plan()
     if plan is None or F != 128 or layout.max_n > 33 or len(ops_list) > _lib.LOOP_MAX_OPS:
         return False
@@ -223,20 +221,29 @@ def layer_loop(ops_list, layout, pair_flag, N, F, stagger=0):
         # (n^2 positions on ONE wave), and that block sets the duration of the whole launch; the separate launches
         # share such molecules between two or four waves (MolLayout.agg_work) - measured 352 k against 337 k (set B)
         return False
-    arr = (_lib.LoopOp * len(ops_list))()
+    words = [0] * (_LOOP_WORDS * len(ops_list))
+    dp = lambda t_: 0 if t_ is None else t_.data_ptr()
     for i, op in enumerate(ops_list):
-        o = arr[i]
+        b = _LOOP_WORDS * i
         if op[0] == "chain":
             _, x, stages = op
             assert x.shape == (N, F) and x.is_contiguous() and len(stages) <= 3
-            o.kind, o.swap, o.X, o.Wf, o.out = 0, 0, ptr(x), None, None
-            _fill_chain(o.chain, stages, N, F)
+            words[b + 1], words[b + 4] = x.data_ptr(), len(stages)
+            for s, sd in enumerate(stages):
+                w = b + _LOOP_STAGE0 + _LOOP_STAGE_WORDS * s
+                o, r, tp = sd.get("out"), sd.get("res"), sd.get("tprev")
+                for a in (o, r, tp):
+                    assert a is None or (a.shape == (N, F) and a.is_contiguous())
+                words[w], words[w + 1], words[w + 2], words[w + 3], words[w + 4] = (
+                    sd["image"].data_ptr(), dp(sd.get("bias")), dp(r), dp(tp), dp(o))
+                words[w + 5] = F | (int(sd.get("flags", 0)) << 32)
         else:
             _, x, Wf_l, out, swap = op
-            o.kind, o.swap, o.X, o.Wf, o.out = 1, 1 if swap else 0, ptr(x), ptr(Wf_l), ptr(out)
-            o.chain.nstage = 0
-    call("geossl_schnet_layer_loop", C.byref(arr), len(ops_list), ptr(plan), nblk, ptr(layout.mol_ptr), ptr(layout.pair_ptr),
-         ptr(pair_flag), layout.max_n, 1 if layout.uniform else 0, N, F, int(stagger), stream())
+            words[b], words[b + 1], words[b + 2], words[b + 3] = 1 | ((1 if swap else 0) << 32), x.data_ptr(), \
+                Wf_l.data_ptr(), out.data_ptr()
+    arr = np.array(words, dtype=np.uint64)
+    call("geossl_schnet_layer_loop", arr.ctypes.data, len(ops_list), ptr(plan), nblk, ptr(layout.mol_ptr),
+         ptr(layout.pair_ptr), ptr(pair_flag), layout.max_n, 1 if layout.uniform else 0, N, F, int(stagger), stream())
     return True
 
 

@@ -397,10 +397,7 @@ def test_layer_loop_is_the_separate_launches_bit_for_bit(sizes, monkeypatch):
     w = torch.randn(N, 128, generator=g).to(DEV)
 
     def run(loop):
-        if loop:
-            monkeypatch.delenv("GEOSSL_NO_LAYER_LOOP", raising=False)
-        else:
-            monkeypatch.setenv("GEOSSL_NO_LAYER_LOOP", "1")
+        monkeypatch.setenv("GEOSSL_LAYER_LOOP", "1" if loop else "0")  # (by default: only while a graph is captured)
         for p in model.parameters():
             p.grad = None
         _lib.CALLS = 0
