@@ -122,4 +122,127 @@ __device__ __forceinline__ void aggregate_reg_body(const float* __restrict__ x, 
     if (i < n && has_cols) *reinterpret_cast<V*>(out + (size_t)(a0 + i) * F + f) = acc[i];
 }
 
+// One TARGET GROUP of a large molecule: the walk of aggregate_reg_body restricted to the positions that touch a target
+// atom in [G0, G1) = part P of K equal parts of the size class - rows a < G0 only at their partners b in the group
+// (edge a -> b), rows a in the group at all their partners.  Every sum of a target is still formed by one wave in
+// the order of the full walk (positions are dropped, never reordered): results stay bit-identical.  K waves then share
+// a molecule whose single walk would outlast the launch (ragged batches: the 26..33-atom molecules), each with
+// 1 - (1 - 1/K)^2 of its filter rows (0.75 for K = 2, 0.44 for K = 4); with fewer accumulators the ring is deeper.
+template <int NMAX, int K, int P>
+__device__ __forceinline__ void aggregate_reg_part(const float* __restrict__ x, const float* __restrict__ Wf,
+                                                   const uint8_t* __restrict__ pair_flag, int a0, int n, int base,
+                                                   int lane, int f, int F, int swap, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  typedef f32x2 V;
+  constexpr int G0 = (P * NMAX) / K, G1 = ((P + 1) * NMAX) / K, NG = G1 - G0;
+  constexpr int AEND = G1 < NMAX - 1 ? G1 : NMAX - 1;     // rows a in [0, AEND) have positions
+  constexpr int RING = 40;
+  // positions of row a: partners b in [bs(a), be(a))
+#define AGG_BS(a) ((a) < G0 ? G0 : (a) + 1)
+#define AGG_BE(a) ((a) < G0 ? G1 : NMAX)
+  constexpr int NPOS = G0 * NG + (AEND - G0) * NMAX - ((AEND * (AEND + 1)) / 2 - (G0 * (G0 + 1)) / 2);
+  const bool has_cols = f >= 0;  // (as in aggregate_reg_body)
+  f = has_cols ? f : 0;
+  const float* __restrict__ wbase = Wf + (size_t)base * F;
+  V xr[NMAX], acc[NG], ring[RING];
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i) xr[i] = *reinterpret_cast<const V*>(x + (size_t)(a0 + min(i, n - 1)) * F + f);
+#pragma unroll
+  for (int i = 0; i < NG; ++i) acc[i] = V(0.0f);
+  // (request stream as in aggregate_reg_body: the first slot of the stream's row in a scalar register)
+  const int nu = __builtin_amdgcn_readfirstlane(n);
+  int rs_req = 0;
+  auto load_row = [&](int a, int b) {
+    asm volatile("" : "+s"(rs_req));
+    const int slot = b < nu ? rs_req + (b - a - 1) : 0;
+    const float* rowp = wbase + (size_t)slot * F;  // uniform
+    return __builtin_nontemporal_load(reinterpret_cast<const V*>(rowp + f));
+  };
+  unsigned flr[AEND];  // flags of every row atom of this part, requested first (see aggregate_reg_body)
+#pragma unroll
+  for (int a = 0; a < AEND; ++a) {
+    const bool mine = lane > a && lane < n;
+    flr[a] = pair_flag[base + (mine ? a * n - a * (a + 1) / 2 + lane - a - 1 : 0)];
+  }
+  auto next_pos = [&](int& a, int& b) {
+    if (++b == AGG_BE(a)) {
+      rs_req += nu - a - 1;
+      ++a;
+      b = AGG_BS(a);
+    }
+  };
+  int q = 0, ap = 0, bp = AGG_BS(0);
+#pragma unroll
+  for (int k = 0; k < RING && k < NPOS; ++k) {  // prologue: the first RING positions; then (ap, bp) = position q + RING
+    ring[k] = load_row(ap, bp);
+    next_pos(ap, bp);
+  }
+  // flags of row atom a as two ballot masks over the partner index b (as in aggregate_reg_body)
+  auto row_flags = [&](int a, unsigned long long& m0, unsigned long long& m1) {
+    const bool mine = lane > a && lane < n;
+    unsigned fl = flr[a];
+    asm volatile("" : "+v"(fl));
+    fl = mine ? fl : 0u;
+    if (swap) fl = ((fl & 1u) << 1) | ((fl >> 1) & 1u);
+    m0 = __builtin_amdgcn_ballot_w64((fl & 1u) != 0u);  // edge b -> a
+    m1 = __builtin_amdgcn_ballot_w64((fl & 2u) != 0u);  // edge a -> b
+  };
+  auto next_row = [&]() {  // filter row of position q, and the request for position q + RING
+    const V w = ring[q % RING];
+    if (q + RING < NPOS) {
+      ring[q % RING] = load_row(ap, bp);
+      next_pos(ap, bp);
+    }
+    ++q;
+    return w;
+  };
+  // (two loop nests with plain bounds: the unroller needs the trip counts)
+  // ---- rows before the group: only the edges a -> b into the group's targets
+#pragma unroll
+  for (int a = 0; a < G0; ++a) {
+    unsigned long long m0, m1;
+    row_flags(a, m0, m1);
+    const V xa = xr[a];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int b = G0 + i;
+      const V w = next_row();
+      const V t1 = xa * w;
+      const V s1 = acc[i] + t1;
+      acc[i] = ((m1 >> b) & 1ull) ? s1 : acc[i];
+      asm volatile("" : "+v"(acc[i].x), "+v"(acc[i].y) : : "memory");  // keep the schedule as written (see above)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- rows of the group: target a from every partner b, and target b while b is in the group
+#pragma unroll
+  for (int a = G0; a < AEND; ++a) {
+    unsigned long long m0, m1;
+    row_flags(a, m0, m1);
+    V acc_a = acc[a - G0];
+    const V xa = xr[a];
+#pragma unroll
+    for (int b = a + 1; b < NMAX; ++b) {
+      const V w = next_row();
+      const V t0 = xr[b] * w;
+      const V s0 = acc_a + t0;
+      acc_a = ((m0 >> b) & 1ull) ? s0 : acc_a;
+      if (b < G1) {
+        const V t1 = xa * w;
+        const V s1 = acc[b - G0] + t1;
+        acc[b - G0] = ((m1 >> b) & 1ull) ? s1 : acc[b - G0];
+        asm volatile("" : "+v"(acc[b - G0].x), "+v"(acc[b - G0].y) : : "memory");
+      }
+      asm volatile("" : "+v"(acc_a.x), "+v"(acc_a.y) : : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    acc[a - G0] = acc_a;
+  }
+#undef AGG_BS
+#undef AGG_BE
+#pragma unroll
+  for (int i = 0; i < NG; ++i)
+    if (G0 + i < n && has_cols) *reinterpret_cast<V*>(out + (size_t)(a0 + G0 + i) * F + f) = acc[i];
+}
+
 }  // namespace geossl

@@ -894,16 +894,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_loop(LoopArgs a) {
     } else {
       for (int mm = pl.z + wave; mm < pl.w; mm += 4) {
         const int a0 = a.mol_ptr[mm], n = a.mol_ptr[mm + 1] - a0, base = a.pair_ptr[mm];
-        if constexpr (NMAX > 0) {
-          aggregate_reg_body<NMAX>(op.X, op.Wf, a.pair_flag, a0, n, base, lane, 2 * lane, F, op.swap, op.out);
-        } else {  // ragged batch: every wave takes the unrolled walk of its molecule's size class (k_aggregate_reg_ragged)
-          const int nu = __builtin_amdgcn_readfirstlane(n);
-          // (ring of filter-row requests of the largest classes: 12 instead of 24 - this kernel also holds the chain's state)
-#define LOOP_CLASS(NM, RING) if (nu <= NM) aggregate_reg_body<NM, RING>(op.X, op.Wf, a.pair_flag, a0, n, base, lane, 2 * lane, F, op.swap, op.out); else
-          LOOP_CLASS(8, 0) LOOP_CLASS(12, 0) LOOP_CLASS(16, 0) LOOP_CLASS(18, 0) LOOP_CLASS(20, 0) LOOP_CLASS(22, 0)
-          LOOP_CLASS(24, 0) LOOP_CLASS(26, 0) LOOP_CLASS(28, 12) LOOP_CLASS(30, 12) LOOP_CLASS(33, 12) {}
-#undef LOOP_CLASS
-        }
+        aggregate_reg_body<NMAX>(op.X, op.Wf, a.pair_flag, a0, n, base, lane, 2 * lane, F, op.swap, op.out);
       }
     }
     // the next operation reads what this one wrote (rows of the block's own molecules, through L2), and reuses the LDS
@@ -1072,7 +1063,8 @@ extern "C" int geossl_schnet_layer_loop(const GeosslLoopOp* ops, int nops, const
                                         const int32_t* mol_ptr, const int32_t* pair_ptr, const uint8_t* pair_flag,
                                         int max_n, int uniform, int64_t N, int F, int stagger, hipStream_t stream) {
   if (nops <= 0 || nblocks <= 0) return 0;
-  if (ops == nullptr || plan == nullptr || nops > LOOP_MAX_OPS || F != 128 || max_n > 33 || N <= 0) return (int)hipErrorInvalidValue;
+  if (ops == nullptr || plan == nullptr || nops > LOOP_MAX_OPS || F != 128 || !uniform || max_n > 20 || N <= 0)
+    return (int)hipErrorInvalidValue;
   if (N * (int64_t)F * 4 >= (int64_t)0xFFFFFF00u) return (int)hipErrorInvalidValue;  // 32-bit buffer offsets
   LoopArgs a;
   for (int o = 0; o < nops; ++o) {
@@ -1109,14 +1101,15 @@ extern "C" int geossl_schnet_layer_loop(const GeosslLoopOp* ops, int nops, const
   a.mol_ptr = mol_ptr; a.pair_ptr = pair_ptr; a.pair_flag = pair_flag;
   a.nops = nops; a.R = (int)N; a.stagger = stagger; a.pad = 0;
   const size_t lds = (size_t)3 * 8 * 2 * 1024 + (size_t)3 * 128 * sizeof(float) + (size_t)3 * 128 * sizeof(float);
-  // uniform == every molecule has max_n atoms (the caller knows): the walk of that class alone; else the kernel that
-  // holds every class
-  if (uniform && max_n == 18) {
+  // uniform batches only (every molecule has max_n atoms, says the caller): the walk of one size class.  A form that
+  // holds every class (waves of a block on different walks, molecules of 27 atoms and more shared by two or four waves)
+  // was built and measured on set B: 650-670 us per pass against 470 us as separate launches - removed.
+  if (max_n <= 18) {
     allow_big_lds(&k_layer_loop<18>);
     hipLaunchKernelGGL((k_layer_loop<18>), dim3(nblocks), dim3(256), lds, stream, a);
   } else {
-    allow_big_lds(&k_layer_loop<0>);
-    hipLaunchKernelGGL((k_layer_loop<0>), dim3(nblocks), dim3(256), lds, stream, a);
+    allow_big_lds(&k_layer_loop<20>);
+    hipLaunchKernelGGL((k_layer_loop<20>), dim3(nblocks), dim3(256), lds, stream, a);
   }
   GEOSSL_CHECK_LAUNCH();
   return 0;

@@ -84,14 +84,12 @@ class MolLayout:
         self._sizes_host = sizes
         self._loop_plan = None
         self.uniform = False
-        if sizes is not None:
-            self.loop_plan()  # now, from the host sizes: its small upload must not fall into a graph capture
 
     def loop_plan(self, max_rows=96, max_mols=None):
-        """Blocks of the layer loop (geossl_schnet_layer_loop): consecutive molecules packed into blocks of at most
-        `max_rows` atom rows and `max_mols` molecules -> (int32 tensor [nblocks, 4] = first row, end row, first molecule,
-        end molecule; nblocks), or (None, 0) when a molecule does not fit a block or the layout was not built from host
-        sizes (a loader that knows them passes them: prepare_batch, BatchAtomTuple.from_sizes / from_data_list)."""
+        """Blocks of the layer loop (geossl_schnet_layer_loop): consecutive molecules of a uniform batch in blocks of at
+        most `max_rows` atom rows -> (int32 tensor [nblocks, 4] = first row, end row, first molecule, end molecule;
+        nblocks), or (None, 0) when the batch has no such plan or the layout was not built from host sizes (a loader that
+        knows them passes them: prepare_batch, BatchAtomTuple.from_sizes / from_data_list)."""
         if self._loop_plan is None:
             sizes = self._sizes_host
             if sizes is not None and torch.cuda.is_current_stream_capturing():
@@ -102,22 +100,27 @@ class MolLayout:
                 # caller launches the operations one by one
                 self._loop_plan = (None, 0)
                 return self._loop_plan
-            plan, row, m = [], 0, 0
             B = len(sizes)
-            if max_mols is None:  # one molecule per wave of a block, fewer when the batch would not fill the chip's 512 slots
-                max_mols = min(4, max(1, -(-B // 512)))
-            if any(n > max_rows for n in sizes) or B == 0:
+            self.uniform = B > 0 and len(set(sizes)) == 1
+            # Uniform batches only (ops.layer_loop).  ONE round of blocks: the blocks of a second round would start when
+            # the first round ends, and a block runs for the whole pass - 515 blocks on the chip's 512 slots (two blocks
+            # of four waves per CU) would double the launch.  So: the fewest molecules per block (one per wave is the
+            # target, fewer for a small batch) with which the batch fits 512 blocks of at most max_rows rows; no plan if
+            # there is none (the caller launches the operations one by one).
+            if not self.uniform or max(sizes) > max_rows:
                 self._loop_plan = (None, 0)
                 return self._loop_plan
-            while m < B:
-                r0, m0, rows = row, m, 0
-                while m < B and m - m0 < max_mols and rows + sizes[m] <= max_rows:
-                    rows += sizes[m]
-                    m += 1
-                row += rows
-                plan.append((r0, row, m0, m))
-            t_ = torch.tensor(plan, dtype=torch.int32).to(self.device)
-            self.uniform = len(set(sizes)) == 1
+            n = sizes[0]
+            if max_mols is None:
+                max_mols = max(1, -(-B // 512))
+            if max_mols * n > max_rows:
+                self._loop_plan = (None, 0)
+                return self._loop_plan
+            ptr_ = np.arange(B + 1, dtype=np.int64) * n
+            m0s = np.arange(0, B, max_mols, dtype=np.int64)
+            m1s = np.minimum(m0s + max_mols, B)
+            plan = np.stack([ptr_[m0s], ptr_[m1s], m0s, m1s], axis=1).astype(np.int32)
+            t_ = torch.from_numpy(np.ascontiguousarray(plan)).to(self.device)
             self._loop_plan = (t_, len(plan))
         return self._loop_plan
 
@@ -133,8 +136,6 @@ def get_layout(batch):
         batch._geossl_layout = lay
     elif sizes is not None and lay._sizes_host is None and len(sizes) == lay.B:
         lay._sizes_host, lay._loop_plan = sizes, None  # a layout built before the collation's sizes were attached
-        if not torch.cuda.is_current_stream_capturing():
-            lay.loop_plan()
     return lay
 
 
@@ -191,6 +192,7 @@ def prepare_batch(batch_vec, super_edge_index, sizes):
     B = len(sizes)
     b2 = torch.cat([batch_vec, batch_vec + B])
     lay2 = MolLayout(b2, 2 * B, sizes=sizes + sizes)
+    lay2.loop_plan()  # the block plan of the layer loop, now: its small upload must not fall into a graph capture
     batch_vec._geossl_two_view = (b2, lay2, batch_vec._version)
     batch_vec._geossl_sizes = (sizes, batch_vec._version)  # a one-view layout (get_layout), if one is asked for, is built from them too
     if super_edge_index is not None:

@@ -214,12 +214,9 @@ def layer_loop(ops_list, layout, pair_flag, N, F, stagger=0):
     such path (the caller then launches them one by one).  The operation list is written as plain 64-bit words (a
     field-by-field ctypes fill of 14 operations cost more host time than the 14 calls it replaces)."""
     plan, nblk = layout.loop_plan()
-    if plan is None or F != 128 or layout.max_n > 33 or len(ops_list) > _lib.LOOP_MAX_OPS:
-        return False
-    if not layout.uniform and layout.max_n > 20:
-        # ragged batch with large molecules: a block's aggregation lasts as long as the walk of its largest molecule
-        # (n^2 positions on ONE wave), and that block sets the duration of the whole launch; the separate launches
-        # share such molecules between two or four waves (MolLayout.agg_work) - measured 352 k against 337 k (set B)
+    if plan is None or F != 128 or not layout.uniform or layout.max_n > 20 or len(ops_list) > _lib.LOOP_MAX_OPS:
+        # (ragged batches: a kernel that holds every size class - waves of a block on different walks, large molecules
+        # shared by two or four waves - was measured at 650-670 us per pass against 470 us as separate launches)
         return False
     words = [0] * (_LOOP_WORDS * len(ops_list))
     dp = lambda t_: 0 if t_ is None else t_.data_ptr()

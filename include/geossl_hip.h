@@ -229,9 +229,9 @@ int geossl_linear_chain(const float* X, int ldx, const GeosslChain* chain, int64
  * kind 1: geossl_cfconv_aggregate for those molecules (x = X, filter rows Wf, destination out; swap as there).  `plan`
  * [nblocks][4] int32 = {first row, end row, first molecule, end molecule} of a block (at most 96 rows; consecutive
  * blocks cover the batch).  uniform != 0: every molecule has max_n atoms.  stagger: the second half of the grid starts
- * that many sleeps late (0 = in step; for experiments).  F = 128, molecules of at most 33 atoms; anything else returns
- * hipErrorInvalidValue and the caller launches the operations one by one.  Same arithmetic as the separate launches:
- * results bit-identical. */
+ * that many sleeps late (0 = in step; for experiments).  F = 128 and uniform batches of at most 20 atoms per molecule;
+ * anything else returns hipErrorInvalidValue and the caller launches the operations one by one.  Same arithmetic as
+ * the separate launches: results bit-identical. */
 #define GEOSSL_LOOP_MAX_OPS 14
 typedef struct {
   int kind; /* 0 = chain, 1 = aggregation */
