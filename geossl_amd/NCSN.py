@@ -185,6 +185,132 @@ class _NcsnLoss(torch.autograd.Function):
         return (dh, None, None, None, None, None, None, None) + tuple(grads)
 
 
+class _NcsnLossPair(torch.autograd.Function):
+    """Both heads of a DDM step (pretrain_GeoSSL.py:207-210) as ONE autograd node: loss = scale * (l1 + l2), the row
+    passes, the one-pass backwards and the incidence gathers of the two heads in the same launches
+    (geossl_ddm_loss_fwd2 / _bwd_fused2: 4 launches per step where two _NcsnLoss nodes make 12).  Same arithmetic per
+    head; at the reference's batch size a head's row pass fills a quarter of the chip, the pair half of it."""
+
+    @staticmethod
+    def forward(ctx, h1, h2, d1, d2, nl1, dn1, nl2, dn2, sel, sigmas, powers, out_scale, npar, *params):
+        dev = h1.device
+        S, Fd, N = sel.S, h1.size(1), h1.size(0)
+        training = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or any(ctx.needs_input_grad[13:])
+        ps = [p.detach().contiguous() for p in params]
+        pss = (ps[:npar], ps[npar:])
+        hs = (h1.detach().contiguous(), h2.detach().contiguous())
+        ctx.grad_slots = (getattr(h1, "_geossl_grad_slot", None), getattr(h2, "_geossl_grad_slot", None))
+        heads = (_lib.NcsnHeadFwd * 2)()
+        keep, saved, ws = [], [], []
+        for k, (h, d, nl, dn) in enumerate(((hs[0], d1, nl1, dn1), (hs[1], d2, nl2, dn2))):
+            hd = heads[k]
+            d, nl, dn = d.contiguous(), nl.contiguous(), dn.contiguous()
+            keep += [d, nl, dn]
+            for name, p in zip(_FIELDS, pss[k]):
+                setattr(hd.w, name, ptr(p))
+            hd.w.sigmas = ptr(sigmas[k])
+            hd.h, hd.distance, hd.noise_level, hd.distance_noise = ptr(h), ptr(d), ptr(nl), ptr(dn)
+            hd.anneal_power = float(powers[k])
+            loss_e = torch.empty(S, dtype=torch.float32, device=dev)
+            sv = {}
+            if training:
+                sv = dict(a1=torch.empty(S, Fd, dtype=torch.float32, device=dev),
+                          a2=torch.empty(S, Fd // 2, dtype=torch.float32, device=dev),
+                          pd=torch.empty(S, dtype=torch.float32, device=dev),
+                          emb=torch.empty(S, dtype=torch.float32, device=dev),
+                          gscale=torch.empty(S, dtype=torch.float32, device=dev))
+                for name in ("a1", "a2", "pd", "emb", "gscale"):
+                    setattr(hd.saved, name, ptr(sv[name]))
+            w_ = torch.empty(256, dtype=torch.float32, device=dev)
+            hd.loss_e, hd.workspace = ptr(loss_e), ptr(w_)
+            keep.append(loss_e)
+            saved.append(sv)
+            ws.append(w_)
+        st = stream()
+        call("geossl_ddm_loss_fwd2", C.byref(heads), ptr(sel.batch), ptr(sel.sei0), ptr(sel.sei1), S, Fd, st)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        call("geossl_loss_reduce_partials2", ptr(ws[0]), ptr(ws[1]), ptr(sel.stats), float(out_scale), float(out_scale),
+             ptr(loss), st)
+        if training:
+            ctx.sel, ctx.pss, ctx.saved, ctx.hs, ctx.sigmas = sel, pss, saved, hs, sigmas
+            ctx.params, ctx.npar, ctx.out_scale = params, npar, float(out_scale)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        sel, pss, saved, hs = ctx.sel, ctx.pss, ctx.saved, ctx.hs
+        dev = hs[0].device
+        S, Fd, N = sel.S, hs[0].size(1), hs[0].size(0)
+        st = stream()
+        gout = gout.contiguous().to(torch.float32)
+        direct = _lib.direct_grads_enabled(ctx.params)  # opt-in (DDMTrainer); otherwise gradients go through autograd
+        grads = [p.grad for p in ctx.params] if direct else [torch.empty_like(p) for p in pss[0] + pss[1]]
+        gs = (grads[:ctx.npar], grads[ctx.npar:])
+        lib = _lib.load()
+        heads = (_lib.NcsnHeadBwd * 2)()
+        keep, dhs = [], []
+        nws = int(lib.geossl_ddm_loss_bwd_fused_workspace_floats(S, Fd))
+        for k in range(2):
+            hd = heads[k]
+            for name, p in zip(_FIELDS, pss[k]):
+                setattr(hd.w, name, ptr(p))
+            hd.w.sigmas = ptr(ctx.sigmas[k])
+            for name in ("a1", "a2", "pd", "emb", "gscale"):
+                setattr(hd.saved, name, ptr(saved[k][name]))
+            for name, t_ in zip(_FIELDS, gs[k]):
+                setattr(hd.grads, name, ptr(t_))
+            dfeat = torch.empty(S, Fd, dtype=torch.float32, device=dev)
+            demb = torch.empty(S, dtype=torch.float32, device=dev)
+            grow = torch.empty(S, dtype=torch.float32, device=dev)
+            ws1 = torch.empty(nws, dtype=torch.float32, device=dev)
+            slot = ctx.grad_slots[k]
+            dh = slot.rows(N, Fd, torch.float32, dev) if slot is not None else None
+            if dh is None:
+                dh = torch.empty(N, Fd, dtype=torch.float32, device=dev)
+            hd.h, hd.out_scale, hd.dfeat, hd.demb, hd.grow, hd.workspace, hd.dh = (
+                ptr(hs[k]), ctx.out_scale, ptr(dfeat), ptr(demb), ptr(grow), ptr(ws1), ptr(dh))
+            keep += [dfeat, demb, grow, ws1]
+            dhs.append(dh)
+        call("geossl_ddm_loss_bwd_fused2", C.byref(heads), ptr(sel.sei0), ptr(sel.sei1), S, N, Fd, ptr(sel.stats),
+             ptr(gout), ptr(sel.inc_ptr), ptr(sel.inc_idx), 1 if direct else 0, st)
+        head = (dhs[0], dhs[1]) + (None,) * 11
+        if direct:
+            return head + (None,) * len(grads)
+        return head + tuple(grads)
+
+
+def ddm_heads_loss(n1, n2, data, h1, distance_1, h2, distance_2, noise_level_1=None, distance_noise_1=None,
+                   noise_level_2=None, distance_noise_2=None, out_scale=0.5):
+    """out_scale * (NCSN_model_01(data, h1, distance_1) + NCSN_model_02(data, h2, distance_2)) - the loss of
+    pretrain_GeoSSL.py:207-210 - with both heads in the same launches (_NcsnLossPair) when they allow it, else as two
+    calls.  The random draws are the ones the two forward() calls make, in their order."""
+    ok = (isinstance(n1, NCSN_version_03) and isinstance(n2, NCSN_version_03) and n1.emb_dim == n2.emb_dim
+          and n1.emb_dim in (32, 64, 128) and not os.environ.get("GEOSSL_NCSN_SPLIT_BWD")
+          and not os.environ.get("GEOSSL_NCSN_SEPARATE_HEADS")
+          and h1.shape == h2.shape and not distance_1.requires_grad and not distance_2.requires_grad)
+    if ok:
+        S_, N_, Fd = data.super_edge_index.size(1), h1.size(0), h1.size(1)
+        ok = S_ > 0 and max(S_, N_) * Fd * 4 < 2 ** 32
+    if not ok:
+        return (n1(data, h1, distance_1, noise_level=noise_level_1, distance_noise=distance_noise_1, out_scale=out_scale) +
+                n2(data, h2, distance_2, noise_level=noise_level_2, distance_noise=distance_noise_2, out_scale=out_scale))
+    _lib.require_cuda(h1, h2, distance_1, distance_2, n1.sigmas, n2.sigmas)
+    n1.device = n2.device = n1.sigmas.device
+    num_graphs = data.num_graphs
+    sel = get_super_edge_layout(data.batch, data.super_edge_index, num_graphs)
+    draws = []
+    for n_, nl, dn, d in ((n1, noise_level_1, distance_noise_1, distance_1), (n2, noise_level_2, distance_noise_2, distance_2)):
+        if nl is None:  # NCSN.py:190
+            nl = torch.randint(0, n_.sigmas.size(0), (num_graphs,), device=n_.sigmas.device)
+        if dn is None:  # NCSN.py:194
+            dn = torch.randn_like(d)
+        draws.append((nl, dn))
+    p1, p2 = _head_params(n1), _head_params(n2)
+    return _NcsnLossPair.apply(h1, h2, distance_1.view(-1), distance_2.view(-1), draws[0][0], draws[0][1].view(-1),
+                               draws[1][0], draws[1][1].view(-1), sel, (n1.sigmas.detach(), n2.sigmas.detach()),
+                               (n1.anneal_power, n2.anneal_power), out_scale, len(p1), *p1, *p2)
+
+
 class NCSN_version_03(torch.nn.Module):
     def __init__(self, emb_dim, sigma_begin, sigma_end, num_noise_level, noise_type, anneal_power):
         super().__init__()

@@ -74,6 +74,16 @@ class NcsnSaved(C.Structure):
     _fields_ = [(k, vp) for k in ("a1", "a2", "pd", "emb", "gscale")]
 
 
+class NcsnHeadFwd(C.Structure):
+    _fields_ = [("h", vp), ("distance", vp), ("noise_level", vp), ("distance_noise", vp), ("w", NcsnWeights),
+                ("saved", NcsnSaved), ("anneal_power", f32), ("pad_", f32), ("loss_e", vp), ("workspace", vp)]
+
+
+class NcsnHeadBwd(C.Structure):
+    _fields_ = [("h", vp), ("w", NcsnWeights), ("saved", NcsnSaved), ("out_scale", f32), ("pad_", f32), ("dfeat", vp),
+                ("demb", vp), ("grow", vp), ("grads", NcsnGrads), ("workspace", vp), ("dh", vp)]
+
+
 P = C.POINTER
 # name -> (restype, argtypes); mirrors include/geossl_hip.h one to one
 PROTOTYPES = {
@@ -126,6 +136,9 @@ PROTOTYPES = {
     "geossl_copy2": (i32, [vp, vp, i64, vp, vp, i64, vp]),
     "geossl_ddm_views": (i32, [vp, vp, vp, vp, i64, i64, vp, vp, vp, vp]),
     "geossl_loss_reduce_partials": (i32, [vp, vp, f32, vp, i32, vp]),
+    "geossl_ddm_loss_fwd2": (i32, [vp, vp, vp, vp, i64, i32, vp]),
+    "geossl_loss_reduce_partials2": (i32, [vp, vp, vp, f32, f32, vp, vp]),
+    "geossl_ddm_loss_bwd_fused2": (i32, [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, i32, vp]),
     "geossl_loss_reduce_workspace_floats": (i64, [i64]),
     "geossl_loss_reduce": (i32, [vp, i64, vp, f32, vp, vp, i32, vp]),
     "geossl_ddm_loss_bwd_rows": (i32, [P(NcsnWeights), P(NcsnSaved), i64, i32, vp, f32, vp, vp, vp, vp, vp, vp]),

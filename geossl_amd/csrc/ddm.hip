@@ -48,6 +48,22 @@ __global__ void k_loss_final(const float* __restrict__ partial, int nblk, const 
   const float v = (s / (float)divisor[0]) * out_scale;  // loss.mean() over max(edge2graph)+1 graphs, NCSN.py:210-212
   loss[0] = accumulate ? loss[0] + v : v;
 }
+// the two heads' means and their sum in one launch: loss = scale0 * sum(p0) / divisor + scale1 * sum(p1) / divisor, each
+// sum in k_loss_final's order, then added (as loss_01 + loss_02 is, pretrain_GeoSSL.py:210)
+__global__ void k_loss_final2(const float* __restrict__ p0, const float* __restrict__ p1, int nblk,
+                              const int64_t* __restrict__ divisor, float scale0, float scale1, float* __restrict__ loss) {
+  if (blockIdx.x != 0) return;
+  float s0 = 0.0f, s1 = 0.0f;
+  for (int b = threadIdx.x; b < nblk; b += 64) {
+    s0 += p0[b];
+    s1 += p1[b];
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if (threadIdx.x != 0) return;
+  const float v0 = (s0 / (float)divisor[0]) * scale0, v1 = (s1 / (float)divisor[0]) * scale1;
+  loss[0] = v0 + v1;
+}
 #define GEOSSL_LOSS_BLOCKS 256
 
 // ---------------------------------------------------------------------------------------------- backward
@@ -214,10 +230,14 @@ __global__ __launch_bounds__(64) void k_ncsn_small_reduce(const float* __restric
 }
 
 // dh[a] (+)= sum over incident super-edges (fixed order) of dfeat[s]; one wave per atom
-__global__ __launch_bounds__(256) void k_incidence_gather(const float* __restrict__ dfeat,
+__global__ __launch_bounds__(256) void k_incidence_gather(const float* __restrict__ dfeat0,
                                                           const int64_t* __restrict__ inc_ptr,
                                                           const int32_t* __restrict__ inc_idx, int N, int F,
-                                                          float* __restrict__ dh, int accumulate) {
+                                                          float* __restrict__ dh0, int accumulate,
+                                                          const float* __restrict__ dfeat1, float* __restrict__ dh1) {
+  // (blockIdx.y = 1: the second head of a two-head launch - same incidence lists, its own rows)
+  const float* __restrict__ dfeat = blockIdx.y == 0 ? dfeat0 : dfeat1;
+  float* __restrict__ dh = blockIdx.y == 0 ? dh0 : dh1;
   // A super-edge row is read twice, by its two atoms - atoms of ONE molecule, i.e. of neighbouring groups of four.
   // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): consecutive groups on consecutive
   // workgroups would fetch a molecule's rows into several L2s, from HBM every time.  Group g = (block mod 8) * per +
@@ -306,6 +326,14 @@ extern "C" int geossl_loss_reduce_partials(const float* partial, const int64_t* 
   return 0;
 }
 
+extern "C" int geossl_loss_reduce_partials2(const float* partial0, const float* partial1, const int64_t* stats_divisor,
+                                            float scale0, float scale1, float* loss, hipStream_t stream) {
+  hipLaunchKernelGGL(k_loss_final2, dim3(1), dim3(64), 0, stream, partial0, partial1, GEOSSL_LOSS_PARTIALS, stats_divisor,
+                     scale0, scale1, loss);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
 static inline void small_plan(int64_t S, int* chunk, int* nblk) {
   int64_t c = (S + 2047) / 2048;  // eight blocks per CU: the row loop of a thread is a chain of dependent batches
   if (c < 64) c = 64;
@@ -369,10 +397,23 @@ extern "C" int geossl_incidence_gather(const float* dfeat, const int64_t* inc_pt
   if (N <= 0) return 0;
   const unsigned groups = (unsigned)((N + 3) / 4);
   hipLaunchKernelGGL(k_incidence_gather, dim3((groups + 7) / 8 * 8), dim3(256), 0, stream, dfeat, inc_ptr, inc_idx,
-                     (int)N, F, dh, accumulate);
+                     (int)N, F, dh, accumulate, (const float*)nullptr, (float*)nullptr);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
+
+namespace geossl {
+// dh of both heads in one launch (geossl_ddm_loss_bwd_fused2, ncsn_bwd.hip)
+int launch_incidence_gather2(const float* dfeat0, const float* dfeat1, const int64_t* inc_ptr, const int32_t* inc_idx,
+                             int64_t N, int F, float* dh0, float* dh1, hipStream_t stream) {
+  if (N <= 0) return 0;
+  const unsigned groups = (unsigned)((N + 3) / 4);
+  hipLaunchKernelGGL(k_incidence_gather, dim3((groups + 7) / 8 * 8, 2), dim3(256), 0, stream, dfeat0, inc_ptr, inc_idx,
+                     (int)N, F, dh0, 0, dfeat1, dh1);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+}  // namespace geossl
 
 extern "C" int geossl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                                 float beta1, float beta2, float eps, float weight_decay, int64_t step_count,

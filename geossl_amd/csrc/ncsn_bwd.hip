@@ -705,6 +705,13 @@ __global__ __launch_bounds__(128 * NW) void k_ncsn_bwd_fused(NcsnFusedArgs a) {
   if ((int)(threadIdx.x >> 6) < NW) ncsn_bwd_body<NW, true>(a);
   else ncsn_bwd_body<NW, false>(a);
 }
+// both heads of a DDM step in one launch: blockIdx.y = head
+template <int NW>
+__global__ __launch_bounds__(128 * NW) void k_ncsn_bwd_fused2(NcsnFusedArgs a0, NcsnFusedArgs a1) {
+  const NcsnFusedArgs& a = blockIdx.y == 0 ? a0 : a1;
+  if ((int)(threadIdx.x >> 6) < NW) ncsn_bwd_body<NW, true>(a);
+  else ncsn_bwd_body<NW, false>(a);
+}
 
 // The five fixed-order reductions of the block partials (k_reduce_multi's arithmetic) and, in the blocks behind them, the
 // narrow gradients (k_ncsn_small_reduce's: one wave per output scalar, lanes stride over the blocks, fixed butterfly) -
@@ -794,5 +801,62 @@ extern "C" int geossl_ddm_loss_bwd_fused(const float* h, const int64_t* sei0, co
   hipLaunchKernelGGL(k_ncsn_reduce_all, dim3(rm.blocks() + (H + 3 * F + 2 + 3) / 4, 1), dim3(256), 0, stream, rm, nb,
                      accumulate, a.psm, F, *grads);
   GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+namespace geossl {
+int launch_incidence_gather2(const float* dfeat0, const float* dfeat1, const int64_t* inc_ptr, const int32_t* inc_idx,
+                             int64_t N, int F, float* dh0, float* dh1, hipStream_t stream);
+}
+
+extern "C" int geossl_ddm_loss_bwd_fused2(const GeosslNcsnHeadBwd* heads, const int64_t* sei0, const int64_t* sei1,
+                                          int64_t S, int64_t N, int F, const int64_t* stats_divisor, const float* gout,
+                                          const int64_t* inc_ptr, const int32_t* inc_idx, int accumulate,
+                                          hipStream_t stream) {
+  if (S <= 0) return 0;
+  if (heads == nullptr || (F != 32 && F != 64 && F != 128)) return (int)hipErrorInvalidValue;
+  if (S * (int64_t)F * 4 >= ((int64_t)1 << 32) || N * (int64_t)F * 4 >= ((int64_t)1 << 32)) return (int)hipErrorInvalidValue;
+  const int nb = fused_blocks(S), H = F / 2;
+  NcsnFusedArgs a[2];
+  for (int k = 0; k < 2; ++k) {
+    const GeosslNcsnHeadBwd& hd = heads[k];
+    if (hd.h == nullptr || hd.dfeat == nullptr || hd.workspace == nullptr) return (int)hipErrorInvalidValue;
+    NcsnFusedArgs& x = a[k];
+    x.h = hd.h; x.sei0 = sei0; x.sei1 = sei1; x.S = (int)S; x.w = hd.w; x.sv = hd.saved; x.divisor = stats_divisor;
+    x.out_scale = hd.out_scale; x.gout = gout; x.dfeat = hd.dfeat; x.demb = hd.demb; x.grow = hd.grow;
+    x.pw1 = hd.workspace;
+    x.pd1 = x.pw1 + (size_t)nb * F * F;
+    x.pb1 = x.pd1 + (size_t)nb * F;
+    x.pw2 = x.pb1 + (size_t)nb * F;
+    x.pb2 = x.pw2 + (size_t)nb * H * F;
+    x.psm = x.pb2 + (size_t)nb * H;
+  }
+#define LAUNCH2(NWV)                                                                                                \
+  do {                                                                                                              \
+    allow_big_lds(&k_ncsn_bwd_fused2<NWV>);                                                                         \
+    hipLaunchKernelGGL((k_ncsn_bwd_fused2<NWV>), dim3(nb, 2), dim3(128 * NWV), NbLds<NWV>::bytes(), stream, a[0], a[1]); \
+  } while (0)
+  if (F == 128) LAUNCH2(4); else if (F == 64) LAUNCH2(2); else LAUNCH2(1);
+#undef LAUNCH2
+  GEOSSL_CHECK_LAUNCH();
+  for (int k = 0; k < 2; ++k) {  // the fixed-order reductions of a head: one launch each (the argument block is 1.8 KB)
+    const GeosslNcsnGrads* grads = &heads[k].grads;
+    ReduceMulti rm;
+    float* o1w[1] = {grads->o1_w};
+    float* o1c[1] = {grads->o1_w + F};
+    float* o1b[1] = {grads->o1_b};
+    float* o2w[1] = {grads->o2_w};
+    float* o2b[1] = {grads->o2_b};
+    rm.add(a[k].pw1, F * F, F, F + 1, 1, o1w, 1);
+    rm.add(a[k].pd1, F, F, F, F + 1, o1c, 1);
+    rm.add(a[k].pb1, F, F, F, 1, o1b, 1);
+    rm.add(a[k].pw2, H * F, F, F, 1, o2w, 1);
+    rm.add(a[k].pb2, H, H, H, 1, o2b, 1);
+    hipLaunchKernelGGL(k_ncsn_reduce_all, dim3(rm.blocks() + (H + 3 * F + 2 + 3) / 4, 1), dim3(256), 0, stream, rm, nb,
+                       accumulate, a[k].psm, F, *grads);
+    GEOSSL_CHECK_LAUNCH();
+  }
+  if (heads[0].dh != nullptr && heads[1].dh != nullptr)
+    return launch_incidence_gather2(heads[0].dfeat, heads[1].dfeat, inc_ptr, inc_idx, N, F, heads[0].dh, heads[1].dh, stream);
   return 0;
 }

@@ -25,13 +25,13 @@ struct RowIn {
 
 // NMB = F/32
 template <int NMB>
-__global__ __launch_bounds__(512) void k_ncsn_fwd(const float* __restrict__ h, const int64_t* __restrict__ batch,
-                                                  const int64_t* __restrict__ sei0, const int64_t* __restrict__ sei1,
-                                                  int S, const float* __restrict__ distance,
-                                                  const int64_t* __restrict__ noise_level,
-                                                  const float* __restrict__ dist_noise, GeosslNcsnWeights w,
-                                                  float anneal_power, float* __restrict__ loss_e,
-                                                  GeosslNcsnSaved sv, float* __restrict__ loss_part) {
+__device__ __forceinline__ void ncsn_fwd_body(const float* __restrict__ h, const int64_t* __restrict__ batch,
+                                              const int64_t* __restrict__ sei0, const int64_t* __restrict__ sei1,
+                                              int S, const float* __restrict__ distance,
+                                              const int64_t* __restrict__ noise_level,
+                                              const float* __restrict__ dist_noise, const GeosslNcsnWeights& w,
+                                              float anneal_power, float* __restrict__ loss_e,
+                                              const GeosslNcsnSaved& sv, float* __restrict__ loss_part) {
   constexpr int F = 32 * NMB, H = F / 2, HMB = (H + 31) / 32, HP = 32 * HMB, KS = F / 16;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
   u32x4* W1f = reinterpret_cast<u32x4*>(smem_raw);  // [NMB][KS][3][64]: A[m = n][k], k = 16ks + 8kh + e
@@ -273,6 +273,37 @@ __global__ __launch_bounds__(512) void k_ncsn_fwd(const float* __restrict__ h, c
 }
 
 template <int NMB>
+__global__ __launch_bounds__(512) void k_ncsn_fwd(const float* __restrict__ h, const int64_t* __restrict__ batch,
+                                                  const int64_t* __restrict__ sei0, const int64_t* __restrict__ sei1,
+                                                  int S, const float* __restrict__ distance,
+                                                  const int64_t* __restrict__ noise_level,
+                                                  const float* __restrict__ dist_noise, GeosslNcsnWeights w,
+                                                  float anneal_power, float* __restrict__ loss_e,
+                                                  GeosslNcsnSaved sv, float* __restrict__ loss_part) {
+  ncsn_fwd_body<NMB>(h, batch, sei0, sei1, S, distance, noise_level, dist_noise, w, anneal_power, loss_e, sv, loss_part);
+}
+// both heads of a DDM step in one launch: blockIdx.y = head (same super-edges, each head its own view, weights, noise)
+struct NcsnFwdHead {
+  const float* h;
+  const float* distance;
+  const int64_t* noise_level;
+  const float* dist_noise;
+  GeosslNcsnWeights w;
+  GeosslNcsnSaved sv;
+  float anneal_power;
+  float* loss_e;
+  float* loss_part;
+};
+template <int NMB>
+__global__ __launch_bounds__(512) void k_ncsn_fwd2(NcsnFwdHead a0, NcsnFwdHead a1, const int64_t* __restrict__ batch,
+                                                   const int64_t* __restrict__ sei0, const int64_t* __restrict__ sei1,
+                                                   int S) {
+  const NcsnFwdHead& a = blockIdx.y == 0 ? a0 : a1;
+  ncsn_fwd_body<NMB>(a.h, batch, sei0, sei1, S, a.distance, a.noise_level, a.dist_noise, a.w, a.anneal_power, a.loss_e,
+                     a.sv, a.loss_part);
+}
+
+template <int NMB>
 __global__ __launch_bounds__(512) void k_ncsn_bwd_rows(GeosslNcsnWeights w, GeosslNcsnSaved sv, int S,
                                                        const int64_t* __restrict__ divisor, float out_scale,
                                                        const float* __restrict__ gout, float* __restrict__ dz1,
@@ -496,6 +527,32 @@ extern "C" int geossl_ddm_loss_fwd(const float* h, const int64_t* batch, const i
     allow_big_lds(&k_ncsn_fwd<NMBV>);                                                                             \
     hipLaunchKernelGGL((k_ncsn_fwd<NMBV>), grid, dim3(512), lds, stream, h, batch, sei0, sei1, (int)S, distance,  \
                        noise_level, distance_noise, *w, anneal_power, loss_e, sv, workspace);                     \
+  } while (0)
+  if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
+#undef LAUNCH
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_ddm_loss_fwd2(const GeosslNcsnHeadFwd* heads, const int64_t* batch, const int64_t* sei0,
+                                    const int64_t* sei1, int64_t S, int F, hipStream_t stream) {
+  if (S <= 0) return 0;
+  if (heads == nullptr || (F != 32 && F != 64 && F != 128)) return (int)hipErrorInvalidValue;
+  NcsnFwdHead a[2];
+  for (int k = 0; k < 2; ++k) {
+    const GeosslNcsnHeadFwd& hd = heads[k];
+    if (hd.h == nullptr || hd.loss_e == nullptr) return (int)hipErrorInvalidValue;
+    a[k].h = hd.h; a[k].distance = hd.distance; a[k].noise_level = hd.noise_level; a[k].dist_noise = hd.distance_noise;
+    a[k].w = hd.w; a[k].sv = hd.saved; a[k].anneal_power = hd.anneal_power; a[k].loss_e = hd.loss_e;
+    a[k].loss_part = hd.workspace;
+  }
+  const int NMB = F / 32, H = F / 2, HMB = (H + 31) / 32, KS = F / 16;
+  const size_t lds = (size_t)(NMB + HMB) * KS * 3 * 1024 + (size_t)(5 * F + 2 * 32 * HMB + 8) * sizeof(float);
+  dim3 grid(row_blocks_grid(S), 2);
+#define LAUNCH(NMBV)                                                                                              \
+  do {                                                                                                            \
+    allow_big_lds(&k_ncsn_fwd2<NMBV>);                                                                            \
+    hipLaunchKernelGGL((k_ncsn_fwd2<NMBV>), grid, dim3(512), lds, stream, a[0], a[1], batch, sei0, sei1, (int)S);  \
   } while (0)
   if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
 #undef LAUNCH

@@ -192,11 +192,12 @@ def _do_ddm_eager(args, batch, model, mu, sigma, heads, noise, fuse_views, devic
         molecule_3D_repr_02 = ops.row_normalize(molecule_3D_repr_02)
 
     # cross-view pairing (:207-208); each head returns 0.5 * its loss so the sum is (l1 + l2) / 2 (:210)
-    loss_01 = n1(batch, molecule_3D_repr_01, distance_02, noise_level=noise.get("noise_level_1"),
-                 distance_noise=noise.get("dist_noise_1"), out_scale=0.5)
-    loss_02 = n2(batch, molecule_3D_repr_02, distance_01, noise_level=noise.get("noise_level_2"),
-                 distance_noise=noise.get("dist_noise_2"), out_scale=0.5)
-    return loss_01 + loss_02
+    # (both heads in the same launches where they allow it: NCSN.ddm_heads_loss)
+    from .NCSN import ddm_heads_loss
+    return ddm_heads_loss(n1, n2, batch, molecule_3D_repr_01, distance_02, molecule_3D_repr_02, distance_01,
+                          noise_level_1=noise.get("noise_level_1"), distance_noise_1=noise.get("dist_noise_1"),
+                          noise_level_2=noise.get("noise_level_2"), distance_noise_2=noise.get("dist_noise_2"),
+                          out_scale=0.5)
 
 
 class Batch:

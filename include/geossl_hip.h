@@ -345,6 +345,43 @@ int geossl_ddm_loss_fwd(const float* h, const int64_t* batch, const int64_t* sei
 int64_t geossl_loss_reduce_workspace_floats(int64_t S);
 int geossl_loss_reduce(const float* loss_e, int64_t S, const int64_t* stats_divisor, float out_scale, float* loss,
                        float* workspace, int accumulate, hipStream_t stream);
+/* The two heads of a DDM step (pretrain_GeoSSL.py:207-208: same super-edges, each head its own view, weights and noise)
+ * in the SAME launches - at the reference's batch size one head's row pass fills a quarter of the chip.
+ * geossl_ddm_loss_fwd2: both row passes (workspace as in geossl_ddm_loss_fwd); geossl_loss_reduce_partials2: loss =
+ * scale0 * mean_0 + scale1 * mean_1 from the two workspaces; geossl_ddm_loss_bwd_fused2: both one-pass backwards, their
+ * reductions, and dh of both heads (geossl_incidence_gather) - 3 launches where the single-head calls make 8. */
+typedef struct {
+  const float* h;              /* [N][F] node features of the head's view */
+  const float* distance;       /* [S] */
+  const int64_t* noise_level;  /* [B] */
+  const float* distance_noise; /* [S] */
+  GeosslNcsnWeights w;
+  GeosslNcsnSaved saved;       /* all NULL: nothing kept for a backward */
+  float anneal_power;
+  float pad_;
+  float* loss_e;               /* [S] */
+  float* workspace;            /* GEOSSL_LOSS_PARTIALS floats */
+} GeosslNcsnHeadFwd;
+typedef struct {
+  const float* h;
+  GeosslNcsnWeights w;
+  GeosslNcsnSaved saved;
+  float out_scale;
+  float pad_;
+  float* dfeat;                /* [S][F] */
+  float* demb;                 /* [S] */
+  float* grow;                 /* [S] */
+  GeosslNcsnGrads grads;
+  float* workspace;            /* geossl_ddm_loss_bwd_fused_workspace_floats(S, F) */
+  float* dh;                   /* [N][F], may be NULL */
+} GeosslNcsnHeadBwd;
+int geossl_ddm_loss_fwd2(const GeosslNcsnHeadFwd* heads, const int64_t* batch, const int64_t* sei0, const int64_t* sei1,
+                         int64_t S, int F, hipStream_t stream);
+int geossl_loss_reduce_partials2(const float* partial0, const float* partial1, const int64_t* stats_divisor, float scale0,
+                                 float scale1, float* loss, hipStream_t stream);
+int geossl_ddm_loss_bwd_fused2(const GeosslNcsnHeadBwd* heads, const int64_t* sei0, const int64_t* sei1, int64_t S,
+                               int64_t N, int F, const int64_t* stats_divisor, const float* gout, const int64_t* inc_ptr,
+                               const int32_t* inc_idx, int accumulate, hipStream_t stream);
 /* the same loss from the block partials geossl_ddm_loss_fwd left in its workspace (fixed order: blocks in sequence) */
 int geossl_loss_reduce_partials(const float* partial, const int64_t* stats_divisor, float out_scale, float* loss,
                                 int accumulate, hipStream_t stream);

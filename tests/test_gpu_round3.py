@@ -414,3 +414,38 @@ def test_layer_loop_is_the_separate_launches_bit_for_bit(sizes, monkeypatch):
         assert c1 == c0 - 2 * (2 * 6 + 2) + 2      # 14 launches per pass became one
     else:
         assert c1 == c0                              # ragged batches: the separate launches
+
+
+def test_two_heads_in_the_same_launches_are_the_two_single_head_calls(monkeypatch):
+    """NCSN.ddm_heads_loss (both heads of pretrain_GeoSSL.py:207-210 as one autograd node on geossl_ddm_loss_fwd2 /
+    _bwd_fused2) against NCSN_model_01(...) + NCSN_model_02(...): loss and every gradient bit for bit, with the heads'
+    own draws (same generator calls in the same order) as well as injected noise."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    b = make_batch(40, seed=21, mode="B")
+    batch = pg.Batch.from_numpy(b, DEV)
+    torch.manual_seed(9)
+    model = product_schnet(SMALL, DEV)
+    heads = (product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 5, DEV, scale=0.9))
+    args = pg.Args("schnet")
+    params = [p for m in (model,) + heads for p in m.parameters() if p.requires_grad]
+    full = {k: t(v, DEV) for k, v in draw_noise(b, seed=22).items()}
+
+    def run(separate, noise):
+        if separate:
+            monkeypatch.setenv("GEOSSL_NCSN_SEPARATE_HEADS", "1")
+        else:
+            monkeypatch.delenv("GEOSSL_NCSN_SEPARATE_HEADS", raising=False)
+        for p in params:
+            p.grad = None
+        torch.manual_seed(77)
+        torch.cuda.manual_seed(77)
+        loss, _ = pg.do_DDM(args, batch, model, NCSN_models=heads, noise=noise, graph=False)
+        loss.backward()
+        return float(loss), [p.grad.clone() for p in params if p.grad is not None]
+
+    for noise in (full, {"pos_noise": full["pos_noise"]}):   # (second: the heads draw their own levels and distance noise)
+        l0, g0 = run(True, noise)
+        l1, g1 = run(False, noise)
+        assert np.isfinite(l0) and l0 == l1
+        assert len(g0) == len(g1) and all(torch.equal(x, y) for x, y in zip(g0, g1))
