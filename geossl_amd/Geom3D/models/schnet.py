@@ -160,7 +160,11 @@ class _SchNetCore(torch.autograd.Function):
             # lin + residual and the next block's conv.lin1 (after the last block: the head).  Operand images of all
             # 3L + 2 square weights from one launch.  (Running the two views of a DDM step as two parallel graph branches
             # - lock-step or staggered by one aggregation - was measured and gave nothing: DESIGN.md section 7.)
-            img = ops.prepare_chain([lp[k] for lp in layers for k in (4, 5, 7)] + [head[0], head[2]], transB=True)
+            chain_w = [lp[k] for lp in layers for k in (4, 5, 7)] + [head[0], head[2]]
+            if want_params and 2 * len(chain_w) <= _lib.PREPARE_MAX:  # the backward's images from the same launch
+                img, img_bwd = ops.prepare_chain(chain_w, both=True)
+            else:
+                img, img_bwd = ops.prepare_chain(chain_w, transB=True), None
             i_lin1, i_lin2, i_lin = img[0:3 * L:3], img[1:3 * L:3], img[2:3 * L:3]
             full = lambda: torch.empty(N, F, dtype=torch.float32, device=dev)
             hs, xs, aggs, ts = [h] + [full() for _ in range(L)], [full() for _ in range(L)], [full() for _ in range(L)], \
@@ -229,7 +233,7 @@ class _SchNetCore(torch.autograd.Function):
             ctx.ps = ps
             ctx.params = params
             ctx.saved = dict(pair_d=pair_d, pair_c=pair_c, pair_flag=pair_flag, Wf=Wf, T=T, hs=hs, xs=xs, aggs=aggs,
-                             ts=ts, h_last=h, u=u)
+                             ts=ts, h_last=h, u=u, img_bwd=img_bwd if cfg["chain"] else None)
         return hout
 
     @staticmethod
@@ -270,7 +274,9 @@ class _SchNetCore(torch.autograd.Function):
         if cfg["chain"]:
             # the same chains walked backwards: [head.lin2 + act', head.lin1], [lin_{L-1} + act', conv.lin2_{L-1}], then per
             # block  dX through conv.lin1_l (+ the residual branch), lin_{l-1} + act', conv.lin2_{l-1}
-            img = ops.prepare_chain([lp[k] for lp in layers for k in (4, 5, 7)] + [head[0], head[2]], transB=False)
+            img = sv.get("img_bwd")  # converted with the forward's images (the weights have not changed since)
+            if img is None:
+                img = ops.prepare_chain([lp[k] for lp in layers for k in (4, 5, 7)] + [head[0], head[2]], transB=False)
             i_lin1, i_lin2, i_lin = img[0:3 * L:3], img[1:3 * L:3], img[2:3 * L:3]
             full = lambda: torch.empty(N, F, dtype=torch.float32, device=dev)
             du = full()

@@ -26,8 +26,11 @@ class FilterWeights(C.Structure):
     _fields_ = [("w1", vp * MAX_L), ("b1", vp * MAX_L), ("w2", vp * MAX_L), ("b2", vp * MAX_L)]
 
 
+PREPARE_MAX = 64
+
+
 class PrepareBatch(C.Structure):
-    _fields_ = [("W", vp * TN_MAX), ("image", vp * TN_MAX), ("ldw", i32 * TN_MAX)]
+    _fields_ = [("W", vp * PREPARE_MAX), ("image", vp * PREPARE_MAX), ("ldw", i32 * PREPARE_MAX), ("tb", i32 * PREPARE_MAX)]
 
 
 CHAIN_MAX = 5
@@ -134,7 +137,7 @@ PROTOTYPES = {
     "geossl_ddm_loss_fwd": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, P(NcsnWeights), i32, f32, vp, P(NcsnSaved), vp, vp]),
     "geossl_schnet_layer_loop": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, i64, i32, i32, vp]),
     "geossl_copy2": (i32, [vp, vp, i64, vp, vp, i64, vp]),
-    "geossl_ddm_views": (i32, [vp, vp, vp, vp, i64, i64, vp, vp, vp, vp]),
+    "geossl_ddm_views": (i32, [vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, i64, vp, vp]),
     "geossl_loss_reduce_partials": (i32, [vp, vp, f32, vp, i32, vp]),
     "geossl_ddm_loss_fwd2": (i32, [vp, vp, vp, vp, i64, i32, vp]),
     "geossl_loss_reduce_partials2": (i32, [vp, vp, vp, f32, f32, vp, vp]),

@@ -33,9 +33,10 @@ namespace {
 // image_z[mb][ks][piece][lane] (u32x4) with the contraction index of every k-step in kperm order:
 //   lane (n = lane & 31, kh = lane >> 5), element e  <->  B[k = 16 ks + kperm(e, kh)][n]
 template <int KS>
-__global__ __launch_bounds__(256) void k_chain_prepare(GeosslPrepareBatch batch, int NO, int transB) {
+__global__ __launch_bounds__(256) void k_chain_prepare(GeosslPrepareBatch batch, int NO, int transB_call) {
   constexpr int K = 16 * KS;
   const int z = blockIdx.y;
+  const int transB = batch.tb[z] == 0 ? transB_call : (batch.tb[z] == 1 ? 1 : 0);
   const float* __restrict__ W = batch.W[z];
   u32x4* __restrict__ image = reinterpret_cast<u32x4*>(batch.image[z]);
   const int ldw = batch.ldw[z] != 0 ? batch.ldw[z] : (transB ? K : NO);  // row stride of W
@@ -1029,7 +1030,7 @@ extern "C" int64_t geossl_chain_image_words(int F) {
 
 extern "C" int geossl_chain_prepare(const GeosslPrepareBatch* batch, int nprob, int F, int transB, hipStream_t stream) {
   if (nprob <= 0) return 0;
-  if (nprob > GEOSSL_TN_MAX || geossl_chain_image_words(F) == 0) return (int)hipErrorInvalidValue;
+  if (nprob > GEOSSL_PREPARE_MAX || geossl_chain_image_words(F) == 0) return (int)hipErrorInvalidValue;
   for (int z = 0; z < nprob; ++z)
     if (batch->ldw[z] != 0 && (batch->ldw[z] < F || (batch->ldw[z] & 3) || ((uintptr_t)batch->W[z] & 15)))
       return (int)hipErrorInvalidValue;

@@ -404,7 +404,7 @@ extern "C" int64_t geossl_linear_image_words(int K, int NO) {
 extern "C" int geossl_linear_prepare(const GeosslPrepareBatch* batch, int nprob, int K, int NO, int transB,
                                      hipStream_t stream) {
   if (nprob <= 0) return 0;
-  if (nprob > GEOSSL_TN_MAX || geossl_linear_image_words(K, NO) == 0) return (int)hipErrorInvalidValue;
+  if (nprob > GEOSSL_PREPARE_MAX || geossl_linear_image_words(K, NO) == 0) return (int)hipErrorInvalidValue;
   for (int z = 0; z < nprob; ++z)
     if (batch->ldw[z] != 0 && batch->ldw[z] != (transB ? K : NO)) return (int)hipErrorInvalidValue;  // dense weights only
   const int KS = K / 16, nitems = ((NO + 31) / 32) * KS * 64;
@@ -465,7 +465,7 @@ namespace geossl {
 // several reductions in one launch (tn.h: ReduceMulti); same arithmetic and order as k_reduce_partials
 __global__ __launch_bounds__(256) void k_reduce_multi(ReduceMulti m, int nblk, int accumulate) {
   __shared__ float red[4][64];
-  reduce_multi_block(m, nblk, accumulate, red);
+  reduce_multi_block(m, nblk, accumulate, red, (int)blockIdx.y);
 }
 // block = 64 outputs x 4 slices of the partial list; the four slice sums are combined in slice order.
 __global__ __launch_bounds__(256) void k_reduce_partials(GeosslReduceBatch batch, const float* __restrict__ partial,

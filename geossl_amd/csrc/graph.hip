@@ -259,8 +259,15 @@ __global__ void k_pair_distance(const float* __restrict__ pos, const int64_t* __
 // k_pair_distance on each half: the perturbed coordinates are rounded to fp32 before the differences are taken.
 __global__ void k_ddm_views(const float* __restrict__ pos, const float* __restrict__ noise,
                             const int64_t* __restrict__ sei0, const int64_t* __restrict__ sei1, int64_t n3, int S,
-                            float* __restrict__ pos2, float* __restrict__ d01, float* __restrict__ d02) {
+                            float* __restrict__ pos2, float* __restrict__ d01, float* __restrict__ d02,
+                            const int64_t* __restrict__ z, int64_t zs, int64_t* __restrict__ z2) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+  if (z2 != nullptr)  // atom types of the two-view batch: the column z[:, 0] twice
+    for (int64_t i = t; i < n3 / 3; i += nt) {
+      const int64_t v = z[i * zs];
+      z2[i] = v;
+      z2[n3 / 3 + i] = v;
+    }
   for (int64_t i = t; i < n3; i += nt) {
     const float a = pos[i];
     pos2[i] = a;
@@ -392,11 +399,12 @@ extern "C" int geossl_pair_distance(const float* pos, const int64_t* sei0, const
 }
 
 extern "C" int geossl_ddm_views(const float* pos, const float* noise, const int64_t* sei0, const int64_t* sei1, int64_t N,
-                                int64_t S, float* pos2, float* d01, float* d02, hipStream_t stream) {
+                                int64_t S, float* pos2, float* d01, float* d02, const int64_t* z, int64_t z_stride,
+                                int64_t* z2, hipStream_t stream) {
   if (N <= 0) return 0;
   const int64_t work = 3 * N > S ? 3 * N : S;
   hipLaunchKernelGGL(k_ddm_views, dim3(grid1d(work, 256)), dim3(256), 0, stream, pos, noise, sei0, sei1, 3 * N, (int)S,
-                     pos2, d01, d02);
+                     pos2, d01, d02, z, z_stride, z2);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

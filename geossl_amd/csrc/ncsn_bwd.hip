@@ -716,12 +716,12 @@ __global__ __launch_bounds__(128 * NW) void k_ncsn_bwd_fused2(NcsnFusedArgs a0, 
 // The five fixed-order reductions of the block partials (k_reduce_multi's arithmetic) and, in the blocks behind them, the
 // narrow gradients (k_ncsn_small_reduce's: one wave per output scalar, lanes stride over the blocks, fixed butterfly) -
 // one launch per head instead of two.
-__global__ __launch_bounds__(256) void k_ncsn_reduce_all(ReduceMulti m, int nblk, int accumulate,
-                                                         const float* __restrict__ psm, int F, GeosslNcsnGrads g) {
-  __shared__ float red[4][64];
+__device__ __forceinline__ void ncsn_reduce_all_block(const ReduceMulti& m, int nblk, int accumulate,
+                                                      const float* __restrict__ psm, int F, const GeosslNcsnGrads& g,
+                                                      float (*red)[64]) {
   const int mb = m.xoff[m.nseg];
   if ((int)blockIdx.x < mb) {
-    reduce_multi_block(m, nblk, accumulate, red);
+    reduce_multi_block(m, nblk, accumulate, red, 0);
     return;
   }
   const int H = F / 2, len = H + 3 * F + 2;
@@ -740,6 +740,20 @@ __global__ __launch_bounds__(256) void k_ncsn_reduce_all(ReduceMulti m, int nblk
     else dst = g.in_b2;
     *dst = accumulate ? *dst + s : s;
   }
+}
+__global__ __launch_bounds__(256) void k_ncsn_reduce_all(ReduceMulti m, int nblk, int accumulate,
+                                                         const float* __restrict__ psm, int F, GeosslNcsnGrads g) {
+  __shared__ float red[4][64];
+  ncsn_reduce_all_block(m, nblk, accumulate, psm, F, g, red);
+}
+// both heads of a two-head launch: blockIdx.y = head
+__global__ __launch_bounds__(256) void k_ncsn_reduce_all2(ReduceMulti m0, ReduceMulti m1, int nblk, int accumulate,
+                                                          const float* __restrict__ psm0,
+                                                          const float* __restrict__ psm1, int F, GeosslNcsnGrads g0,
+                                                          GeosslNcsnGrads g1) {
+  __shared__ float red[4][64];
+  if (blockIdx.y == 0) ncsn_reduce_all_block(m0, nblk, accumulate, psm0, F, g0, red);
+  else ncsn_reduce_all_block(m1, nblk, accumulate, psm1, F, g1, red);
 }
 
 inline int fused_blocks(int64_t S) {
@@ -839,23 +853,23 @@ extern "C" int geossl_ddm_loss_bwd_fused2(const GeosslNcsnHeadBwd* heads, const 
   if (F == 128) LAUNCH2(4); else if (F == 64) LAUNCH2(2); else LAUNCH2(1);
 #undef LAUNCH2
   GEOSSL_CHECK_LAUNCH();
-  for (int k = 0; k < 2; ++k) {  // the fixed-order reductions of a head: one launch each (the argument block is 1.8 KB)
+  ReduceMulti rm[2];  // the fixed-order reductions of both heads in one launch
+  for (int k = 0; k < 2; ++k) {
     const GeosslNcsnGrads* grads = &heads[k].grads;
-    ReduceMulti rm;
     float* o1w[1] = {grads->o1_w};
     float* o1c[1] = {grads->o1_w + F};
     float* o1b[1] = {grads->o1_b};
     float* o2w[1] = {grads->o2_w};
     float* o2b[1] = {grads->o2_b};
-    rm.add(a[k].pw1, F * F, F, F + 1, 1, o1w, 1);
-    rm.add(a[k].pd1, F, F, F, F + 1, o1c, 1);
-    rm.add(a[k].pb1, F, F, F, 1, o1b, 1);
-    rm.add(a[k].pw2, H * F, F, F, 1, o2w, 1);
-    rm.add(a[k].pb2, H, H, H, 1, o2b, 1);
-    hipLaunchKernelGGL(k_ncsn_reduce_all, dim3(rm.blocks() + (H + 3 * F + 2 + 3) / 4, 1), dim3(256), 0, stream, rm, nb,
-                       accumulate, a[k].psm, F, *grads);
-    GEOSSL_CHECK_LAUNCH();
+    rm[k].add(a[k].pw1, F * F, F, F + 1, 1, o1w, 1);
+    rm[k].add(a[k].pd1, F, F, F, F + 1, o1c, 1);
+    rm[k].add(a[k].pb1, F, F, F, 1, o1b, 1);
+    rm[k].add(a[k].pw2, H * F, F, F, 1, o2w, 1);
+    rm[k].add(a[k].pb2, H, H, H, 1, o2b, 1);
   }
+  hipLaunchKernelGGL(k_ncsn_reduce_all2, dim3(rm[0].blocks() + (H + 3 * F + 2 + 3) / 4, 2), dim3(256), 0, stream, rm[0],
+                     rm[1], nb, accumulate, a[0].psm, a[1].psm, F, heads[0].grads, heads[1].grads);
+  GEOSSL_CHECK_LAUNCH();
   if (heads[0].dh != nullptr && heads[1].dh != nullptr)
     return launch_incidence_gather2(heads[0].dfeat, heads[1].dfeat, inc_ptr, inc_idx, N, F, heads[0].dh, heads[1].dh, stream);
   return 0;

@@ -311,7 +311,7 @@ __global__ void k_embedding_bwd_partial(const int64_t* __restrict__ z, int64_t z
                                         int64_t N, int F, int C, float* __restrict__ partial, int2* __restrict__ band) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int chunk = blockIdx.x, f = threadIdx.x;
-  const int64_t per = (N + GEOSSL_EMB_CHUNKS - 1) / GEOSSL_EMB_CHUNKS;
+  const int64_t per = (N + (int64_t)gridDim.x - 1) / (int64_t)gridDim.x;
   const int64_t lo = chunk * per, hi = min((int64_t)N, lo + per);
   if (f >= F) return;
   for (int c = 0; c < C; ++c) smem[c * F + f] = 0.0f;
@@ -341,19 +341,20 @@ __global__ void k_embedding_bwd_partial(const int64_t* __restrict__ z, int64_t z
 // chunk list (one wave each).  A wave first lists the chunks of its slice that hold the class (ballot over the bands,
 // ascending), then sums their rows compensated like kahan_sum_strided; the four slice sums are combined in slice order.
 __global__ __launch_bounds__(256) void k_embedding_bwd_reduce(const float* __restrict__ partial,
-                                                              const int2* __restrict__ band, int C, int F,
+                                                              const int2* __restrict__ band, int nchunks, int C, int F,
                                                               float* __restrict__ dtable, int accumulate) {
-  constexpr int PER = GEOSSL_EMB_CHUNKS / 4;
-  static_assert(PER == 128, "two chunks per lane");
+  constexpr int PERMAX = GEOSSL_EMB_CHUNKS / 4;
+  static_assert(PERMAX == 128, "two chunks per lane");
+  const int PER = nchunks / 4;  // chunks per slice (nchunks: a multiple of 4, at most GEOSSL_EMB_CHUNKS)
   __shared__ float red[4][64];
-  __shared__ int hits[4][PER];
+  __shared__ int hits[4][PERMAX];
   const int c = blockIdx.y, lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int f = blockIdx.x * 64 + lane;
   int n = 0;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int b = slice * PER + 64 * h + lane;
-    const int2 r = band[b];
+    const int2 r = 64 * h + lane < PER ? band[b] : make_int2(1, 0);
     const bool hit = c >= r.x && c <= r.y;
     const unsigned long long m = __ballot(hit);
     if (hit) hits[slice][n + __popcll(m & ((1ull << lane) - 1ull))] = b;
@@ -574,12 +575,15 @@ extern "C" int geossl_embedding_bwd(const int64_t* z, int64_t z_stride, const fl
   if (num_classes <= 0) return 0;
   if (F > 256 || (size_t)num_classes * F * sizeof(float) > 160 * 1024) return (int)hipErrorInvalidValue;
   int2* band = reinterpret_cast<int2*>(workspace + (size_t)GEOSSL_EMB_CHUNKS * num_classes * F);
+  // chunks of at least 64 rows (a small batch: fewer chunks, a shorter list for the second stage), a multiple of 4
+  int nchunks = (int)((N + 63) / 64);
+  nchunks = nchunks < 16 ? 16 : (nchunks > GEOSSL_EMB_CHUNKS ? GEOSSL_EMB_CHUNKS : (nchunks + 3) / 4 * 4);
   allow_big_lds(&k_embedding_bwd_partial);
-  hipLaunchKernelGGL(k_embedding_bwd_partial, dim3(GEOSSL_EMB_CHUNKS), dim3((F + 63) / 64 * 64),
+  hipLaunchKernelGGL(k_embedding_bwd_partial, dim3(nchunks), dim3((F + 63) / 64 * 64),
                      (size_t)num_classes * F * sizeof(float), stream, z, z_stride, dh, N, F, num_classes, workspace, band);
   GEOSSL_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_embedding_bwd_reduce, dim3((F + 63) / 64, num_classes), dim3(256), 0, stream, workspace, band,
-                     num_classes, F, dtable, accumulate);
+                     nchunks, num_classes, F, dtable, accumulate);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

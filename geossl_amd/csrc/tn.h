@@ -39,11 +39,11 @@ struct ReduceMulti {
 __global__ void k_reduce_multi(ReduceMulti m, int nblk, int accumulate);
 // the work of one 256-thread block of k_reduce_multi (64 outputs x 4 slices of the partial list, compensated; the four
 // slice sums are combined in slice order); kernels that append reductions of their own to the batch call it
-__device__ __forceinline__ void reduce_multi_block(const ReduceMulti& m, int nblk, int accumulate, float (*red)[64]) {
+__device__ __forceinline__ void reduce_multi_block(const ReduceMulti& m, int nblk, int accumulate, float (*red)[64],
+                                                   int z) {
   int g = 0;
   while (g + 1 < m.nseg && (int)blockIdx.x >= m.xoff[g + 1]) ++g;
   const ReduceSeg& sg = m.seg[g];
-  const int z = blockIdx.y;
   float* out = sg.out[z];
   if (out == nullptr) return;
   const int len = sg.len;

@@ -135,28 +135,31 @@ def linear(x, w, bias=None, res=None, tprev=None, transB=True, flags=0, out=None
     return out
 
 
-def prepare_chain(weights, transB=True):
+def prepare_chain(weights, transB=True, both=False):
     """Operand images (geossl_chain_prepare) of square F x F Linear weights for `linear_chain`, one launch per
-    GEOSSL_TN_MAX weights.  transB as in `linear`.  A weight may be a column block of a wider matrix (unit column
+    GEOSSL_PREPARE_MAX images.  transB as in `linear`.  A weight may be a column block of a wider matrix (unit column
     stride, row stride a multiple of 4, 16-byte aligned): it is converted where it lies.  Returns a list of int32
-    tensors, or None if F has no chain path."""
+    tensors, or None if F has no chain path; `both`: (forward images (transB=True), backward images (transB=False)) of
+    every weight from the same launch."""
     w0 = weights[0]
     F = w0.size(0)
     words = int(_lib.load().geossl_chain_image_words(F)) if w0.size(1) == F else 0
     if words == 0:
-        return None
+        return (None, None) if both else None
+    jobs = [(w, 1) for w in weights] + [(w, 2) for w in weights] if both else [(w, 0) for w in weights]
     out = []
-    for lo in range(0, len(weights), _lib.TN_MAX):
-        chunk = weights[lo:lo + _lib.TN_MAX]
+    for lo in range(0, len(jobs), _lib.PREPARE_MAX):
+        chunk = jobs[lo:lo + _lib.PREPARE_MAX]
         images = torch.empty(len(chunk), words, dtype=torch.int32, device=w0.device)
         pb = _lib.PrepareBatch()
-        for i, w in enumerate(chunk):
+        for i, (w, tb) in enumerate(chunk):
             assert w.shape == w0.shape and w.stride(1) == 1
             pb.W[i], pb.image[i] = ptr(w), ptr(images[i])
             pb.ldw[i] = 0 if w.is_contiguous() else w.stride(0)
+            pb.tb[i] = tb
         call("geossl_chain_prepare", C.byref(pb), len(chunk), F, 1 if transB else 0, stream())
         out += [images[i] for i in range(len(chunk))]
-    return out
+    return (out[:len(weights)], out[len(weights):]) if both else out
 
 
 def linear_chain(x, stages):
@@ -312,16 +315,22 @@ def pair_distance(pos, sei0, sei1):
     return out
 
 
-def ddm_views(pos, noise, sei0, sei1):
+def ddm_views(pos, noise, sei0, sei1, z=None):
     """Both views of a DDM step in one launch (pretrain_GeoSSL.py:68-74,199-205): ([pos ; pos + noise] as one [2N, 3]
-    tensor, super-edge lengths of the clean view [S, 1], of the perturbed view [S, 1])."""
+    tensor, super-edge lengths of the clean view [S, 1], of the perturbed view [S, 1]); with the atom types `z` [N]
+    (any stride) also [z ; z]."""
     pos, noise = _f32(pos), _f32(noise)
     N, S = pos.size(0), sei0.numel()
     pos2 = torch.empty(2 * N, 3, dtype=torch.float32, device=pos.device)
     d01 = torch.empty(S, 1, dtype=torch.float32, device=pos.device)
     d02 = torch.empty(S, 1, dtype=torch.float32, device=pos.device)
-    call("geossl_ddm_views", ptr(pos), ptr(noise), ptr(sei0), ptr(sei1), N, S, ptr(pos2), ptr(d01), ptr(d02), stream())
-    return pos2, d01, d02
+    z2 = None
+    if z is not None:
+        assert z.dim() == 1 and z.dtype == torch.long and z.numel() == N
+        z2 = torch.empty(2 * N, dtype=torch.long, device=pos.device)
+    call("geossl_ddm_views", ptr(pos), ptr(noise), ptr(sei0), ptr(sei1), N, S, ptr(pos2), ptr(d01), ptr(d02), ptr(z),
+         z.stride(0) if z is not None and N > 0 else 1, ptr(z2), stream())
+    return (pos2, d01, d02) if z is None else (pos2, d01, d02, z2)
 
 
 def add_scaled(a, b, alpha=1.0):

@@ -166,8 +166,8 @@ def _do_ddm_eager(args, batch, model, mu, sigma, heads, noise, fuse_views, devic
             else:
                 pos_noise = torch.normal(mu, sigma, size=positions.size()).to(positions.device)
         N = positions.size(0)
-        pos2, distance_01, distance_02 = ops.ddm_views(positions, pos_noise, super_edge_index[0], super_edge_index[1])
-        x2 = torch.cat([x_01, x_01])
+        pos2, distance_01, distance_02, x2 = ops.ddm_views(positions, pos_noise, super_edge_index[0], super_edge_index[1],
+                                                           z=x_01)
         if args.model_3d == "schnet":
             b2, lay2 = _two_view_batch(batch.batch, batch.num_graphs)
             # the readout is dead compute in this step (`_` at pretrain_GeoSSL.py:187): not evaluated

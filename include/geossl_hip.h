@@ -175,15 +175,18 @@ int geossl_linear(const float* X, int ldx, const float* W, const float* bias, co
 
 /* Prepared weights.  geossl_linear re-shapes W into its MFMA operand image (bf16 pieces in fragment order) in every
  * block of every launch; a weight that is used by several launches between two optimiser steps (forward, backward,
- * both views) can be converted once instead: geossl_linear_prepare builds the images of up to GEOSSL_TN_MAX
+ * both views) can be converted once instead: geossl_linear_prepare builds the images of up to GEOSSL_PREPARE_MAX
  * weights of one shape in a single launch, geossl_linear_prepared is geossl_linear reading such an image
  * (same arithmetic, bit-identical results).  geossl_linear_image_words: size of one image in 32-bit words, 0 if the
  * shape has no prepared path (K not in {32, 64, 128}).                                                       */
+#define GEOSSL_PREPARE_MAX 64 /* weights in one geossl_linear_prepare / geossl_chain_prepare launch */
 typedef struct {
-  const float* W[GEOSSL_TN_MAX];
-  uint32_t* image[GEOSSL_TN_MAX];
-  int ldw[GEOSSL_TN_MAX]; /* row stride of W in floats (a multiple of 4), 0 = dense; geossl_chain_prepare only: a column
+  const float* W[GEOSSL_PREPARE_MAX];
+  uint32_t* image[GEOSSL_PREPARE_MAX];
+  int ldw[GEOSSL_PREPARE_MAX]; /* row stride of W in floats (a multiple of 4), 0 = dense; geossl_chain_prepare only: a column
                              block of a wider weight (PaiNN's Dense(2F, F), painn.py:87) is converted where it lies */
+  int tb[GEOSSL_PREPARE_MAX];  /* geossl_chain_prepare only: 0 = the call's transB, 1 = transB 1, 2 = transB 0 for this weight
+                                  (the forward and the backward image of a weight from one launch) */
 } GeosslPrepareBatch;
 int64_t geossl_linear_image_words(int K, int NO);
 int geossl_linear_prepare(const GeosslPrepareBatch* batch, int nprob, int K, int NO, int transB, hipStream_t stream);
@@ -293,9 +296,10 @@ int geossl_copy2(void* dst0, const void* src0, int64_t bytes0, void* dst1, const
                  hipStream_t stream);
 /* both views at once (:68-74 and :199-205 for a fused two-view batch): pos2 [2N][3] = [pos ; pos + noise], d01 / d02 [S] =
  * super-edge lengths in the clean / perturbed view - geossl_axpy, the concatenation and two geossl_pair_distance calls
- * in one launch, same arithmetic */
+ * in one launch, same arithmetic; z2 != NULL: also z2 [2N] = the atom types z[i * z_stride] of the N atoms, twice */
 int geossl_ddm_views(const float* pos, const float* noise, const int64_t* sei0, const int64_t* sei1, int64_t N, int64_t S,
-                     float* pos2, float* d01, float* d02, hipStream_t stream);
+                     float* pos2, float* d01, float* d02, const int64_t* z, int64_t z_stride, int64_t* z2,
+                     hipStream_t stream);
 /* per-batch bookkeeping for the NCSN head: se_ptr[B+1] = first super-edge of every molecule (needs
  * batch[sei0] non-decreasing and both ends in one molecule: true for collated batches),
  * stats = {max(edge2graph)+1 (the divisor of NCSN.py:212), 1 if the ordering assumption fails}; and the
