@@ -830,7 +830,9 @@ extern "C" int geossl_ddm_loss_bwd_fused2(const GeosslNcsnHeadBwd* heads, const 
   if (S <= 0) return 0;
   if (heads == nullptr || (F != 32 && F != 64 && F != 128)) return (int)hipErrorInvalidValue;
   if (S * (int64_t)F * 4 >= ((int64_t)1 << 32) || N * (int64_t)F * 4 >= ((int64_t)1 << 32)) return (int)hipErrorInvalidValue;
-  const int nb = fused_blocks(S), H = F / 2;
+  // half of the chip per head: the two heads' blocks are resident together (one block of 8 x 256 registers per CU), and
+  // a block's fixed costs - formatting its weight slices, 100 KB of partial sums - are paid by half as many blocks
+  const int nb = (fused_blocks(S) + 1) / 2, H = F / 2;
   NcsnFusedArgs a[2];
   for (int k = 0; k < 2; ++k) {
     const GeosslNcsnHeadBwd& hd = heads[k];

@@ -548,7 +548,7 @@ extern "C" int geossl_ddm_loss_fwd2(const GeosslNcsnHeadFwd* heads, const int64_
   }
   const int NMB = F / 32, H = F / 2, HMB = (H + 31) / 32, KS = F / 16;
   const size_t lds = (size_t)(NMB + HMB) * KS * 3 * 1024 + (size_t)(5 * F + 2 * 32 * HMB + 8) * sizeof(float);
-  dim3 grid(row_blocks_grid(S), 2);
+  dim3 grid((row_blocks_grid(S) + 1) / 2, 2);  // half of the chip per head: both heads' blocks resident together
 #define LAUNCH(NMBV)                                                                                              \
   do {                                                                                                            \
     allow_big_lds(&k_ncsn_fwd2<NMBV>);                                                                            \
