@@ -100,29 +100,37 @@ class MolLayout:
                 # caller launches the operations one by one
                 self._loop_plan = (None, 0)
                 return self._loop_plan
-            B = len(sizes)
-            self.uniform = B > 0 and len(set(sizes)) == 1
-            # Uniform batches only (ops.layer_loop).  ONE round of blocks: the blocks of a second round would start when
-            # the first round ends, and a block runs for the whole pass - 515 blocks on the chip's 512 slots (two blocks
-            # of four waves per CU) would double the launch.  So: the fewest molecules per block (one per wave is the
-            # target, fewer for a small batch) with which the batch fits 512 blocks of at most max_rows rows; no plan if
-            # there is none (the caller launches the operations one by one).
-            if not self.uniform or max(sizes) > max_rows:
+            self.uniform = len(sizes) > 0 and len(set(sizes)) == 1
+            plan = loop_block_plan(sizes, max_rows, max_mols)
+            if plan is None:
                 self._loop_plan = (None, 0)
                 return self._loop_plan
-            n = sizes[0]
-            if max_mols is None:
-                max_mols = max(1, -(-B // 512))
-            if max_mols * n > max_rows:
-                self._loop_plan = (None, 0)
-                return self._loop_plan
-            ptr_ = np.arange(B + 1, dtype=np.int64) * n
-            m0s = np.arange(0, B, max_mols, dtype=np.int64)
-            m1s = np.minimum(m0s + max_mols, B)
-            plan = np.stack([ptr_[m0s], ptr_[m1s], m0s, m1s], axis=1).astype(np.int32)
             t_ = torch.from_numpy(np.ascontiguousarray(plan)).to(self.device)
             self._loop_plan = (t_, len(plan))
         return self._loop_plan
+
+
+def loop_block_plan(sizes, max_rows=96, max_mols=None, slots=512):
+    """Block plan of the layer loop (geossl_schnet_layer_loop) for molecules of `sizes` atoms: int32 array [nblocks, 4] =
+    (first row, end row, first molecule, end molecule), or None when the batch has no plan.
+
+    Uniform batches only (ops.layer_loop).  ONE round of blocks: the blocks of a second round would start when the first
+    round ends, and a block runs for the whole pass - 515 blocks on the chip's 512 slots (two blocks of four waves per
+    CU) would double the launch.  So: the fewest molecules per block (one per wave is the target, fewer for a small batch)
+    with which the batch fits `slots` blocks of at most `max_rows` rows; None if there is none (the caller launches the
+    operations one by one)."""
+    B = len(sizes)
+    if B == 0 or len(set(sizes)) != 1 or sizes[0] > max_rows or sizes[0] < 1:
+        return None
+    n = int(sizes[0])
+    if max_mols is None:
+        max_mols = max(1, -(-B // slots))
+    if max_mols * n > max_rows:
+        return None
+    ptr_ = np.arange(B + 1, dtype=np.int64) * n
+    m0s = np.arange(0, B, max_mols, dtype=np.int64)
+    m1s = np.minimum(m0s + max_mols, B)
+    return np.stack([ptr_[m0s], ptr_[m1s], m0s, m1s], axis=1).astype(np.int32)
 
 
 def get_layout(batch):

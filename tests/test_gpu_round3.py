@@ -452,3 +452,46 @@ def test_two_heads_in_the_same_launches_are_the_two_single_head_calls(monkeypatc
         assert len(g0) == len(g1)
         for x, y in zip(g0, g1):
             assert float((x - y).abs().max()) <= 2e-6 * float(y.abs().max()) + 1e-30
+
+
+def test_small_entry_points_of_round_3_through_the_c_abi():
+    """geossl_copy2 (two copies, one launch), geossl_loss_reduce_partials (the mean from the row pass's block partials)
+    against geossl_loss_reduce over the per-edge losses, and geossl_schnet_layer_loop's refusal of shapes it does not
+    take (the caller then launches the operations one by one)."""
+    import ctypes as C
+    from geossl_amd import _lib
+    from geossl_amd._lib import ptr, stream
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(0, 100, (1000, 2), generator=g).to(DEV)
+    b = torch.randn(1000, 3, generator=g).to(DEV)
+    da, db = torch.zeros_like(a), torch.zeros_like(b)
+    assert lib.geossl_copy2(ptr(da), ptr(a), a.numel() * 8, ptr(db), ptr(b), b.numel() * 4, stream()) == 0
+    assert torch.equal(da, a) and torch.equal(db, b)
+    assert lib.geossl_copy2(ptr(da), ptr(a), 6, ptr(db), ptr(b), 4, stream()) != 0           # not a multiple of 4
+    # loss from block partials == loss from the per-edge values (same total, other partial sums: 1e-6)
+    S = 50_000
+    le = torch.rand(S, generator=g).to(DEV)
+    stats = torch.tensor([40, 0], dtype=torch.int64, device=DEV)
+    part = torch.zeros(256, device=DEV)
+    part[:200] = le.view(200, 250).sum(1)
+    l1, l2, ws = torch.zeros((), device=DEV), torch.zeros((), device=DEV), torch.empty(256, device=DEV)
+    assert lib.geossl_loss_reduce(ptr(le), S, ptr(stats), 0.5, ptr(l1), ptr(ws), 0, stream()) == 0
+    assert lib.geossl_loss_reduce_partials(ptr(part), ptr(stats), 0.5, ptr(l2), 0, stream()) == 0
+    ref = float(le.double().sum() / 40 * 0.5)
+    assert abs(float(l1) - ref) <= 1e-6 * ref and abs(float(l2) - ref) <= 1e-6 * ref
+    l3 = torch.zeros((), device=DEV)
+    assert lib.geossl_loss_reduce_partials2(ptr(part), ptr(part), ptr(stats), 0.5, 0.25, ptr(l3), stream()) == 0
+    assert abs(float(l3) - 1.5 * ref) <= 1e-6 * ref
+    # the layer loop refuses ragged batches, other widths, too many operations
+    ops_ = (_lib.LoopOp * 1)()
+    plan = torch.tensor([[0, 18, 0, 1]], dtype=torch.int32, device=DEV)
+    x = torch.zeros(18, 128, device=DEV)
+    ops_[0].kind, ops_[0].X, ops_[0].Wf, ops_[0].out = 1, ptr(x), ptr(x), ptr(x)
+    args = (C.byref(ops_), 1, ptr(plan), 1, ptr(plan), ptr(plan), ptr(plan))
+    assert lib.geossl_schnet_layer_loop(*args, 18, 0, 18, 128, 0, stream()) != 0     # not uniform
+    assert lib.geossl_schnet_layer_loop(*args, 18, 1, 18, 64, 0, stream()) != 0      # F = 64
+    assert lib.geossl_schnet_layer_loop(*args, 21, 1, 18, 128, 0, stream()) != 0     # molecules above 20 atoms
+    assert lib.geossl_schnet_layer_loop(C.byref(ops_), 15, ptr(plan), 1, ptr(plan), ptr(plan), ptr(plan), 18, 1, 18, 128, 0,
+                                        stream()) != 0                               # more than 14 operations
+    torch.cuda.synchronize()

@@ -389,3 +389,23 @@ def test_painn_shards_world2_gloo(tmp_path):
     want = (r0["local"] + r1["local"]) / 2
     assert float((r0["reduced"] - want).abs().max() / want.abs().max()) < 1e-6
     assert not torch.equal(r0["local"], r1["local"])
+
+
+def test_layer_loop_block_plan():
+    """layout.loop_block_plan: one round of at most 512 blocks, the fewest molecules per block that fit it, at most 96
+    rows per block; uniform batches only."""
+    from geossl_amd.layout import loop_block_plan
+    p = loop_block_plan([18] * 2048)                       # the bench batch (two views of 1024 molecules)
+    assert p.shape == (512, 4) and p[0].tolist() == [0, 72, 0, 4] and p[-1].tolist() == [36792, 36864, 2044, 2048]
+    p = loop_block_plan([18] * 256)                        # bs = 128: one molecule per block (fills 256 of the slots)
+    assert p.shape == (256, 4) and p[3].tolist() == [54, 72, 3, 4]
+    p = loop_block_plan([18] * 2060)                       # 515 blocks of four would need a second round: five per block
+    assert p.shape == (412, 4) and p[-1].tolist() == [18 * 2055, 18 * 2060, 2055, 2060]
+    assert (p[:, 1] - p[:, 0]).max() <= 96 and p[:, 0].tolist() == sorted(p[:, 0].tolist())
+    assert (p[1:, 0] == p[:-1, 1]).all() and (p[1:, 2] == p[:-1, 3]).all()      # consecutive blocks cover the batch
+    assert loop_block_plan([18] * 3000) is None            # six per block would be 108 rows
+    assert loop_block_plan([18] * 10 + [17]) is None       # ragged: no plan
+    assert loop_block_plan([120] * 4) is None              # a molecule larger than a block
+    assert loop_block_plan([]) is None
+    p = loop_block_plan([7] * 6000)                        # small molecules: 12 per block = 84 rows, 500 blocks
+    assert p.shape == (500, 4) and int((p[:, 1] - p[:, 0]).max()) == 84
