@@ -293,6 +293,69 @@ __global__ void k_copy2(uint32_t* __restrict__ d0, const uint32_t* __restrict__ 
   for (int64_t i = t; i < n1; i += nt) d1[i] = s1[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The five random draws of a DDM step in ONE launch (perturb pretrain_GeoSSL.py:72: N(mu, sigma) per coordinate; per
+// head a noise level per molecule NCSN.py:190 and N(0, 1) per super-edge :194) for a caller that owns its random
+// stream (DDMTrainer with device noise): counter-based Philox4x32-10 keyed by a 64-bit seed read from the device (the
+// caller draws it from torch's generator, so torch.cuda.manual_seed governs the stream), counter = (group of four
+// outputs, segment); normals by Box-Muller.  Not the values torch's own calls would give - the reference's loop keeps
+// those (do_DDM).
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+__device__ __forceinline__ void normal4(uint4 r, float (&z)[4]) {
+  const float u0 = ((float)(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f), u1 = (float)(r.y >> 8) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(r.z >> 8) + 1.0f) * (1.0f / 16777216.0f), u3 = (float)(r.w >> 8) * (1.0f / 16777216.0f);
+  const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+  float sa, ca, sb, cb;
+  sincosf(6.283185307179586f * u1, &sa, &ca);
+  sincosf(6.283185307179586f * u3, &sb, &cb);
+  z[0] = ra * ca; z[1] = ra * sa; z[2] = rb * cb; z[3] = rb * sb;
+}
+__global__ void k_ddm_noise(const int64_t* __restrict__ seed, float mu, float sigma, int64_t n_pos, int64_t S, int64_t B,
+                            int K1, int K2, float* __restrict__ pos_noise, int64_t* __restrict__ nl1,
+                            float* __restrict__ dn1, int64_t* __restrict__ nl2, float* __restrict__ dn2) {
+  const uint64_t sd = (uint64_t)seed[0];
+  const uint2 key = make_uint2((uint32_t)sd, (uint32_t)(sd >> 32));
+  const int64_t g_pos = (n_pos + 3) / 4, g_s = (S + 3) / 4, g_b = (B + 3) / 4;
+  const int64_t total = g_pos + 2 * g_s + 2 * g_b;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int seg;
+    int64_t g = t;
+    if (g < g_pos) seg = 0;
+    else if ((g -= g_pos) < g_s) seg = 1;
+    else if ((g -= g_s) < g_s) seg = 2;
+    else if ((g -= g_s) < g_b) seg = 3;
+    else { g -= g_b; seg = 4; }
+    const uint4 r = philox4x32_10(make_uint4((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)seg, 0u), key);
+    if (seg <= 2) {
+      float z[4];
+      normal4(r, z);
+      float* dst = seg == 0 ? pos_noise : (seg == 1 ? dn1 : dn2);
+      const int64_t n = seg == 0 ? n_pos : S;
+      const float m = seg == 0 ? mu : 0.0f, sg = seg == 0 ? sigma : 1.0f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * g + e < n) dst[4 * g + e] = add_rn(mul_rn(z[e], sg), m);
+    } else {
+      int64_t* dst = seg == 3 ? nl1 : nl2;
+      const uint32_t K = (uint32_t)(seg == 3 ? K1 : K2);
+      const uint32_t v[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * g + e < B) dst[4 * g + e] = (int64_t)(v[e] % K);
+    }
+  }
+}
+
 __global__ void k_axpy(const float* __restrict__ a, const float* __restrict__ b, float alpha, int64_t n,
                        float* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -417,6 +480,18 @@ extern "C" int geossl_copy2(void* dst0, const void* src0, int64_t bytes0, void* 
   if (work <= 0) return 0;
   hipLaunchKernelGGL(k_copy2, dim3(grid1d(work, 256)), dim3(256), 0, stream, (uint32_t*)dst0, (const uint32_t*)src0, n0,
                      (uint32_t*)dst1, (const uint32_t*)src1, n1);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int geossl_ddm_noise(const int64_t* seed, float mu, float sigma, int64_t n_pos, int64_t S, int64_t B, int K1,
+                                int K2, float* pos_noise, int64_t* noise_level_1, float* distance_noise_1,
+                                int64_t* noise_level_2, float* distance_noise_2, hipStream_t stream) {
+  if (seed == nullptr || K1 < 1 || K2 < 1) return (int)hipErrorInvalidValue;
+  const int64_t total = (n_pos + 3) / 4 + 2 * ((S + 3) / 4) + 2 * ((B + 3) / 4);
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(k_ddm_noise, dim3(grid1d(total, 256)), dim3(256), 0, stream, seed, mu, sigma, n_pos, S, B, K1, K2,
+                     pos_noise, noise_level_1, distance_noise_1, noise_level_2, distance_noise_2);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

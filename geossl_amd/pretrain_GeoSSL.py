@@ -467,6 +467,28 @@ def draw_step_noise(batch, n1, n2, mu, sigma, device_noise, given=None, into=Non
     return out
 
 
+def draw_step_noise_fused(batch, n1, n2, mu, sigma, into=None):
+    """The five draws of a step for a caller that owns its random stream (DDMTrainer with device noise): ONE 64-bit seed
+    from torch's CUDA generator (so torch.cuda.manual_seed governs the stream), then one launch that fills all five
+    tensors (geossl_ddm_noise: Philox keyed by the seed) - two launches where the torch calls are five.  New tensors, or
+    in place into `into` (the static inputs of a graph)."""
+    dev = batch.positions.device
+    N, S, B = batch.positions.size(0), batch.super_edge_index.size(1), batch.num_graphs
+    if into is None:
+        into = {"pos_noise": torch.empty(N, 3, dtype=torch.float32, device=dev),
+                "noise_level_1": torch.empty(B, dtype=torch.long, device=dev),
+                "dist_noise_1": torch.empty(S, 1, dtype=torch.float32, device=dev),
+                "noise_level_2": torch.empty(B, dtype=torch.long, device=dev),
+                "dist_noise_2": torch.empty(S, 1, dtype=torch.float32, device=dev)}
+    for k in _NOISE_KEYS:
+        assert into[k].is_contiguous()
+    seed = torch.empty(1, dtype=torch.long, device=dev).random_()
+    call("geossl_ddm_noise", ptr(seed), float(mu), float(sigma), 3 * N, S, B, n1.sigmas.size(0), n2.sigmas.size(0),
+         ptr(into["pos_noise"]), ptr(into["noise_level_1"]), ptr(into["dist_noise_1"]), ptr(into["noise_level_2"]),
+         ptr(into["dist_noise_2"]), stream())
+    return into
+
+
 class _ReplayedLoss(torch.autograd.Function):
     """The loss of a replayed step as a differentiable function of the parameters: forward returns the loss the forward
     graph computed, backward waits for the backward graph (replayed on the engine's side stream right behind the forward)
@@ -678,6 +700,8 @@ class DDMTrainer:
     def _fwd_bwd(self, batch, noise):
         from . import NCSN as _ncsn
         self.flat.zero_grad()
+        if noise is None and self.device_noise:
+            noise = self._draw_noise(batch)  # the trainer's own stream, eager launches or replayed graph alike
         loss = _do_ddm_eager(self.args, batch, self.model, self.mu, self.sigma, (self.n1, self.n2), noise, True,
                              self.device_noise)
         if self._side is None and self.overlap_heads:
@@ -716,7 +740,9 @@ class DDMTrainer:
     def _draw_noise(self, batch, into=None):
         """The five random draws of a step on the device (perturb: pretrain_GeoSSL.py:72; the heads: NCSN.py:190,194),
         as tensors - new ones, or in place into `into`."""
-        return draw_step_noise(batch, self.n1, self.n2, self.mu, self.sigma, True, None, into)
+        if os.environ.get("GEOSSL_TORCH_DRAWS"):  # the five torch calls (the form before geossl_ddm_noise)
+            return draw_step_noise(batch, self.n1, self.n2, self.mu, self.sigma, True, None, into)
+        return draw_step_noise_fused(batch, self.n1, self.n2, self.mu, self.sigma, into)
 
     def step(self, batch, noise=None, structure_key=None):
         """One training step.  ``structure_key`` is accepted for compatibility and ignored: graphs are found by the

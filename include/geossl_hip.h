@@ -294,6 +294,13 @@ int geossl_pair_distance(const float* pos, const int64_t* sei0, const int64_t* s
  * the next batch into a captured graph's input buffers) as one launch; byte counts, multiples of 4 */
 int geossl_copy2(void* dst0, const void* src0, int64_t bytes0, void* dst1, const void* src1, int64_t bytes1,
                  hipStream_t stream);
+/* The five random draws of a DDM step (perturb :72: N(mu, sigma) per coordinate, n_pos = 3 N values; per head a noise
+ * level in [0, K) per molecule NCSN.py:190 and N(0, 1) per super-edge :194) in one launch, for a caller that owns its
+ * random stream (DDMTrainer with device noise): Philox4x32-10 keyed by the 64-bit *seed on the device.  The reference's
+ * own loop keeps torch's calls (do_DDM: same generator, same values). */
+int geossl_ddm_noise(const int64_t* seed, float mu, float sigma, int64_t n_pos, int64_t S, int64_t B, int K1, int K2,
+                     float* pos_noise, int64_t* noise_level_1, float* distance_noise_1, int64_t* noise_level_2,
+                     float* distance_noise_2, hipStream_t stream);
 /* both views at once (:68-74 and :199-205 for a fused two-view batch): pos2 [2N][3] = [pos ; pos + noise], d01 / d02 [S] =
  * super-edge lengths in the clean / perturbed view - geossl_axpy, the concatenation and two geossl_pair_distance calls
  * in one launch, same arithmetic; z2 != NULL: also z2 [2N] = the atom types z[i * z_stride] of the N atoms, twice */

@@ -544,3 +544,40 @@ def test_two_piece_ncsn_backward_follows_the_scale_of_the_row_gradient(power, up
         assert errs[k] < tol, (k, errs[k])
     zero = run(False, 0.0)
     assert all(float(v.abs().max()) == 0.0 for v in zero.values())
+
+
+def test_one_launch_noise_of_the_trainer():
+    """geossl_ddm_noise (the trainer's five draws in one launch, Philox keyed by a seed from torch's generator): the same
+    seed gives the same tensors, another seed others; positions noise ~ N(mu, sigma), distance noise ~ N(0, 1), levels
+    uniform on [0, K); nothing is written past the tensors."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import make_batch
+    b = make_batch(700, seed=2)
+    batch = pg.Batch.from_numpy(b, DEV)
+    n1, n2 = product_ncsn(128, 50, 2, DEV), product_ncsn(128, 30, 2, DEV)
+
+    def draw(seed):
+        torch.cuda.manual_seed(seed)
+        return {k: v.clone() for k, v in pg.draw_step_noise_fused(batch, n1, n2, 0.25, 0.3).items()}
+
+    a, a2, c = draw(5), draw(5), draw(6)
+    assert all(torch.equal(a[k], a2[k]) for k in a) and not any(torch.equal(a[k], c[k]) for k in a)
+    pn = a["pos_noise"].double()
+    assert pn.shape == batch.positions.shape and abs(float(pn.mean()) - 0.25) < 5e-3 and abs(float(pn.std()) - 0.3) < 5e-3
+    for k in ("dist_noise_1", "dist_noise_2"):
+        d = a[k].double().view(-1)
+        assert d.numel() == batch.super_edge_index.size(1)
+        assert abs(float(d.mean())) < 1e-2 and abs(float(d.std()) - 1.0) < 1e-2
+        assert abs(float((d ** 3).mean())) < 3e-2 and abs(float((d ** 4).mean()) - 3.0) < 0.1      # skewness, kurtosis
+        assert float(d.abs().max()) > 3.5
+    assert float((a["dist_noise_1"] * a["dist_noise_2"]).double().mean().abs()) < 1e-2                  # independent streams
+    for k, K in (("noise_level_1", 50), ("noise_level_2", 30)):
+        lv = a[k]
+        assert lv.dtype == torch.long and lv.numel() == 700 and int(lv.min()) >= 0 and int(lv.max()) < K
+        assert len(torch.unique(lv)) >= K - 3
+    # in place into a graph's static inputs, with guard elements behind them
+    into = {k: torch.full((v.numel() + 8,), 7, dtype=v.dtype, device=DEV) for k, v in a.items()}
+    views = {k: into[k][:a[k].numel()].view(a[k].shape) for k in a}
+    torch.cuda.manual_seed(5)
+    pg.draw_step_noise_fused(batch, n1, n2, 0.25, 0.3, into=views)
+    assert all(torch.equal(views[k], a[k]) for k in a) and all(bool((into[k][-8:] == 7).all()) for k in a)
