@@ -198,7 +198,8 @@ class BatchAtomTuple(Data):
         """Index structures of the DDM step from the host-side molecule sizes (layout.prepare_batch)."""
         if self._sizes is not None and self.batch is not None and self.batch.is_cuda and grouped:
             from ...layout import prepare_batch
-            prepare_batch(self.batch, getattr(self, "super_edge_index", None), self._sizes)
+            # lazy: a step that replays a capacity-bucket graph builds these structures in the bucket's own buffers
+            prepare_batch(self.batch, getattr(self, "super_edge_index", None), self._sizes, lazy=True)
 
     def to(self, device, **kw):
         super().to(device, **kw)

@@ -137,8 +137,14 @@ class _SchNetCore(torch.autograd.Function):
         # an atom type outside the table raises in the reference (Embedding); here the kernel flags it in the model's
         # status word, which forward() polls without draining the stream (synchronously under GEOSSL_DEBUG)
         status = cfg["status"]
-        call("geossl_embedding_fwd", ptr(z), z.stride(0) if z.numel() else 1, ptr(emb_w), emb_w.size(0), N, F, ptr(h),
-             ptr(status.word), st)
+        # a layout of a capacity bucket (geossl_amd/bucket.py) carries the device addresses of the batch's real counts:
+        # N, P are then capacities and every row-count-driven launch below is told where the real count lives
+        dyn = getattr(lay, "dyn", None)
+        dN2, dP2 = (dyn.n_atoms2, dyn.n_pairs2) if dyn is not None else (None, None)
+        if dyn is not None and (ctx.needs_input_grad[1] or F != 128 or not cfg["chain"]):
+            raise _lib.GeosslHipError("a capacity-bucket layout serves the F = 128 chain path without position gradients")
+        call("geossl_embedding_fwd_dyn", ptr(z), z.stride(0) if z.numel() else 1, ptr(emb_w), emb_w.size(0), N, F, ptr(h),
+             ptr(status.word), dN2, st)
         if cfg["debug"]:
             status.check()
         # radius graph + edge length + envelope (schnet.py:91-93,186)
@@ -151,8 +157,8 @@ class _SchNetCore(torch.autograd.Function):
         Wf = torch.empty(L, P, F, dtype=torch.float32, device=dev)
         T = torch.empty(L, P, F, dtype=torch.float32, device=dev) if training else None
         if P > 0:
-            call("geossl_cfconv_filter_fwd", ptr(pair_d), ptr(pair_c), P, C.byref(fw), L, F, G, ptr(cfg["offset"]),
-                 cfg["coeff"], ptr(T), ptr(Wf), st)
+            call("geossl_cfconv_filter_fwd_dyn", ptr(pair_d), ptr(pair_c), P, C.byref(fw), L, F, G, ptr(cfg["offset"]),
+                 cfg["coeff"], ptr(T), ptr(Wf), dP2, st)
         hs, xs, aggs, ts = [], [], [], []
         heads = None
         if cfg["chain"]:
@@ -179,7 +185,7 @@ class _SchNetCore(torch.autograd.Function):
                     if todo is not None:
                         todo.append(("chain", x_, stages))
                     else:
-                        ops.linear_chain(x_, stages)
+                        ops.linear_chain(x_, stages, dyn_rows=dN2)
 
                 chain(rows(hs[0]), [dict(image=i_lin1[0], out=rows(xs[0]))])                           # conv.lin1   :189
                 for l, lp in enumerate(layers):
@@ -198,7 +204,7 @@ class _SchNetCore(torch.autograd.Function):
 
             # One launch for the whole loop where the shape allows (every block carries its molecules through all
             # operations, ops.layer_loop), else 14 launches
-            todo = [] if (cfg["loop"] and P > 0 and 2 * L + 2 <= _lib.LOOP_MAX_OPS) else None
+            todo = [] if (cfg["loop"] and P > 0 and 2 * L + 2 <= _lib.LOOP_MAX_OPS and dyn is None) else None
             if todo is not None:
                 run_rows(0, N, None, todo)
                 if not ops.layer_loop(todo, lay, pair_flag, N, F, stagger=cfg["loop_stagger"]):
@@ -269,6 +275,8 @@ class _SchNetCore(torch.autograd.Function):
         g_emb, g_head = grads[0], grads[1 + 9 * L:]
         g_layers = [grads[1 + 9 * l: 1 + 9 * (l + 1)] for l in range(L)]
         dh_out = dhout.contiguous()
+        dyn = getattr(lay, "dyn", None)
+        dN2, dP2 = (dyn.n_atoms2, dyn.n_pairs2) if dyn is not None else (None, None)
         probs = []  # (A = dY, B = X, dW, db)
         daggs = [None] * L
         if cfg["chain"]:
@@ -291,7 +299,7 @@ class _SchNetCore(torch.autograd.Function):
                     if todo is not None:
                         todo.append(("chain", x_, stages))
                     else:
-                        ops.linear_chain(x_, stages)
+                        ops.linear_chain(x_, stages, dyn_rows=dN2)
 
                 chain(rows(dh_out), [dict(image=img[3 * L + 1], tprev=rows(sv["u"]), out=rows(du)),
                                      dict(image=img[3 * L], out=rows(dhs[L]))])
@@ -309,7 +317,7 @@ class _SchNetCore(torch.autograd.Function):
                                    dict(image=i_lin2[l - 1], out=rows(daggs[l - 1]))]
                     chain(rows(dxs[l]), stages)
 
-            todo = [] if (cfg["loop"] and lay.P > 0 and 2 * L + 2 <= _lib.LOOP_MAX_OPS) else None
+            todo = [] if (cfg["loop"] and lay.P > 0 and 2 * L + 2 <= _lib.LOOP_MAX_OPS and dyn is None) else None
             if todo is not None:
                 run_rows(0, N, None, todo)
                 if not ops.layer_loop(todo, lay, sv["pair_flag"], N, F, stagger=cfg["loop_stagger"]):
@@ -351,13 +359,13 @@ class _SchNetCore(torch.autograd.Function):
             gin.x[l], gin.dagg[l] = ptr(sv["xs"][l]), ptr(daggs[l])
         if want_params:
             # every atom-row weight gradient in one batched launch
-            ops.linear_wgrad(probs, N, F, F, accumulate=bool(accum))
+            ops.linear_wgrad(probs, N, F, F, accumulate=bool(accum), dyn_rows=dN2)
             # embedding table
             nfl = _lib.load().geossl_embedding_bwd_workspace_floats(emb_w.size(0), F)
             ws = torch.empty(nfl, dtype=torch.float32, device=dev)
             z = ctx.z
-            call("geossl_embedding_bwd", ptr(z), z.stride(0) if z.numel() else 1, ptr(dh), emb_w.size(0), N, F,
-                 ptr(g_emb), ptr(ws), accum, st)
+            call("geossl_embedding_bwd_dyn", ptr(z), z.stride(0) if z.numel() else 1, ptr(dh), emb_w.size(0), N, F,
+                 ptr(g_emb), ptr(ws), accum, dN2, st)
             # continuous-filter network weights, all blocks at once
             if P > 0:
                 gout = _lib.FilterGradOut()
@@ -365,9 +373,9 @@ class _SchNetCore(torch.autograd.Function):
                     gout.dw1[l], gout.db1[l], gout.dw2[l], gout.db2[l] = ptr(gl[0]), ptr(gl[1]), ptr(gl[2]), ptr(gl[3])
                 nfl = _lib.load().geossl_cfconv_filter_bwd_workspace_floats(P, L, F, G)
                 ws2 = torch.empty(nfl, dtype=torch.float32, device=dev)
-                call("geossl_cfconv_filter_bwd", ptr(sv["pair_d"]), ptr(sv["pair_c"]), ptr(sv["pair_flag"]),
+                call("geossl_cfconv_filter_bwd_dyn", ptr(sv["pair_d"]), ptr(sv["pair_c"]), ptr(sv["pair_flag"]),
                      ptr(lay.pair_i), ptr(lay.pair_j), P, N, C.byref(fw), C.byref(gin), L, F, G, ptr(cfg["offset"]),
-                     cfg["coeff"], ptr(sv["T"]), C.byref(gout), ptr(ws2), accum, st)
+                     cfg["coeff"], ptr(sv["T"]), C.byref(gout), ptr(ws2), accum, dP2, dN2, st)
             elif not direct:
                 for gl in g_layers:
                     for k in range(4):

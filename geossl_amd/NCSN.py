@@ -110,7 +110,9 @@ class _NcsnLoss(torch.autograd.Function):
                          gscale=torch.empty(S, dtype=torch.float32, device=dev))
             sv = _lib.NcsnSaved(*[ptr(saved[k]) for k in ("a1", "a2", "pd", "emb", "gscale")])
         lib = _lib.load()
-        ws = torch.empty(max(int(lib.geossl_ddm_loss_fwd_workspace_floats(Fd)), 256), dtype=torch.float32, device=dev)
+        nws = max(int(lib.geossl_ddm_loss_fwd_workspace_floats(Fd)), 256)
+        # (no super-edges: the row pass returns before it writes its block partials - the mean below then sums zeros)
+        ws = (torch.empty if S > 0 else torch.zeros)(nws, dtype=torch.float32, device=dev)
         st = stream()
         call("geossl_ddm_loss_fwd", ptr(h), ptr(sel.batch), ptr(sel.sei0), ptr(sel.sei1), S,
              ptr(distance.contiguous()), ptr(noise_level.contiguous()), ptr(distance_noise.contiguous()), C.byref(w),
@@ -198,8 +200,17 @@ class _NcsnLossPair(torch.autograd.Function):
         training = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or any(ctx.needs_input_grad[13:])
         ps = [p.detach().contiguous() for p in params]
         pss = (ps[:npar], ps[npar:])
-        hs = (h1.detach().contiguous(), h2.detach().contiguous())
-        ctx.grad_slots = (getattr(h1, "_geossl_grad_slot", None), getattr(h2, "_geossl_grad_slot", None))
+        # capacity bucket (geossl_amd/bucket.py): h1 is the whole [view 0 ; view 1 ; unused] feature tensor and h2 is
+        # None - both heads get its base address, head 1's rows start at the real atom count the kernels read from the
+        # device (dyn_view); S is the capacity of the super-edge buffers, the real count is read the same way
+        dyn = getattr(sel, "dyn", None)
+        ctx.dyn = dyn
+        if dyn is not None:
+            hs = (h1.detach().contiguous(),) * 2
+            ctx.grad_slots = (None, None)
+        else:
+            hs = (h1.detach().contiguous(), h2.detach().contiguous())
+            ctx.grad_slots = (getattr(h1, "_geossl_grad_slot", None), getattr(h2, "_geossl_grad_slot", None))
         heads = (_lib.NcsnHeadFwd * 2)()
         keep, saved, ws = [], [], []
         for k, (h, d, nl, dn) in enumerate(((hs[0], d1, nl1, dn1), (hs[1], d2, nl2, dn2))):
@@ -227,7 +238,8 @@ class _NcsnLossPair(torch.autograd.Function):
             saved.append(sv)
             ws.append(w_)
         st = stream()
-        call("geossl_ddm_loss_fwd2", C.byref(heads), ptr(sel.batch), ptr(sel.sei0), ptr(sel.sei1), S, Fd, st)
+        call("geossl_ddm_loss_fwd2_dyn", C.byref(heads), ptr(sel.batch), ptr(sel.sei0), ptr(sel.sei1), S, Fd,
+             None if dyn is None else dyn.n_super, None if dyn is None else dyn.n_atoms, st)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         call("geossl_loss_reduce_partials2", ptr(ws[0]), ptr(ws[1]), ptr(sel.stats), float(out_scale), float(out_scale),
              ptr(loss), st)
@@ -250,6 +262,8 @@ class _NcsnLossPair(torch.autograd.Function):
         heads = (_lib.NcsnHeadBwd * 2)()
         keep, dhs = [], []
         nws = int(lib.geossl_ddm_loss_bwd_fused_workspace_floats(S, Fd))
+        dyn = ctx.dyn
+        dh_all = torch.empty(N, Fd, dtype=torch.float32, device=dev) if dyn is not None else None  # both views' rows
         for k in range(2):
             hd = heads[k]
             for name, p in zip(_FIELDS, pss[k]):
@@ -264,16 +278,18 @@ class _NcsnLossPair(torch.autograd.Function):
             grow = torch.empty(S, dtype=torch.float32, device=dev)
             ws1 = torch.empty(nws, dtype=torch.float32, device=dev)
             slot = ctx.grad_slots[k]
-            dh = slot.rows(N, Fd, torch.float32, dev) if slot is not None else None
+            dh = dh_all if dyn is not None else (slot.rows(N, Fd, torch.float32, dev) if slot is not None else None)
             if dh is None:
                 dh = torch.empty(N, Fd, dtype=torch.float32, device=dev)
             hd.h, hd.out_scale, hd.dfeat, hd.demb, hd.grow, hd.workspace, hd.dh = (
                 ptr(hs[k]), ctx.out_scale, ptr(dfeat), ptr(demb), ptr(grow), ptr(ws1), ptr(dh))
             keep += [dfeat, demb, grow, ws1]
             dhs.append(dh)
-        call("geossl_ddm_loss_bwd_fused2", C.byref(heads), ptr(sel.sei0), ptr(sel.sei1), S, N, Fd, ptr(sel.stats),
-             ptr(gout), ptr(sel.inc_ptr), ptr(sel.inc_idx), 1 if direct else 0, st)
-        head = (dhs[0], dhs[1]) + (None,) * 11
+        # (bucket: N = rows of the fused tensor bounds the byte offsets; the gather walks the real atoms of a view)
+        call("geossl_ddm_loss_bwd_fused2_dyn", C.byref(heads), ptr(sel.sei0), ptr(sel.sei1), S, sel.N if dyn is not None else N,
+             Fd, ptr(sel.stats), ptr(gout), ptr(sel.inc_ptr), ptr(sel.inc_idx), 1 if direct else 0,
+             None if dyn is None else dyn.n_super, None if dyn is None else dyn.n_atoms, st)
+        head = ((dh_all, None) if dyn is not None else (dhs[0], dhs[1])) + (None,) * 11
         if direct:
             return head + (None,) * len(grads)
         return head + tuple(grads)
@@ -287,17 +303,23 @@ def ddm_heads_loss(n1, n2, data, h1, distance_1, h2, distance_2, noise_level_1=N
     ok = (isinstance(n1, NCSN_version_03) and isinstance(n2, NCSN_version_03) and n1.emb_dim == n2.emb_dim
           and n1.emb_dim in (32, 64, 128) and not os.environ.get("GEOSSL_NCSN_SPLIT_BWD")
           and not os.environ.get("GEOSSL_NCSN_SEPARATE_HEADS")
-          and h1.shape == h2.shape and not distance_1.requires_grad and not distance_2.requires_grad)
+          and (h2 is None or h1.shape == h2.shape) and not distance_1.requires_grad and not distance_2.requires_grad
+          # the paired kernels write the two heads' gradients from different blocks of ONE launch: the heads must not
+          # share a parameter (the same module passed twice, tied weights) - such a pair takes the two single-head calls
+          and n1 is not n2 and not ({id(p) for p in _head_params(n1)} & {id(p) for p in _head_params(n2)}))
     if ok:
         S_, N_, Fd = data.super_edge_index.size(1), h1.size(0), h1.size(1)
         ok = S_ > 0 and max(S_, N_) * Fd * 4 < 2 ** 32
+    bucket = getattr(data, "_bucket", None)
+    if bucket is not None and (not ok or h2 is not None):
+        raise _lib.GeosslHipError("a capacity-bucket batch needs the paired NCSN heads on one fused feature tensor")
     if not ok:
         return (n1(data, h1, distance_1, noise_level=noise_level_1, distance_noise=distance_noise_1, out_scale=out_scale) +
                 n2(data, h2, distance_2, noise_level=noise_level_2, distance_noise=distance_noise_2, out_scale=out_scale))
     _lib.require_cuda(h1, h2, distance_1, distance_2, n1.sigmas, n2.sigmas)
     n1.device = n2.device = n1.sigmas.device
     num_graphs = data.num_graphs
-    sel = get_super_edge_layout(data.batch, data.super_edge_index, num_graphs)
+    sel = bucket.sel if bucket is not None else get_super_edge_layout(data.batch, data.super_edge_index, num_graphs)
     draws = []
     for n_, nl, dn, d in ((n1, noise_level_1, distance_noise_1, distance_1), (n2, noise_level_2, distance_noise_2, distance_2)):
         if nl is None:  # NCSN.py:190

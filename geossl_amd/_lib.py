@@ -87,6 +87,13 @@ class NcsnHeadBwd(C.Structure):
                 ("demb", vp), ("grow", vp), ("grads", NcsnGrads), ("workspace", vp), ("dh", vp)]
 
 
+COPY_MAX = 8
+
+
+class CopyBatch(C.Structure):
+    _fields_ = [("dst", vp * COPY_MAX), ("src", vp * COPY_MAX), ("bytes", i64 * COPY_MAX)]
+
+
 P = C.POINTER
 # name -> (restype, argtypes); mirrors include/geossl_hip.h one to one
 PROTOTYPES = {
@@ -173,6 +180,19 @@ PROTOTYPES = {
     "geossl_painn_mix_pre_bwd": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp]),
     "geossl_add": (i32, [vp, vp, i64, vp, vp]),
     "geossl_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, vp]),
+    # capacity launches: the namesake's arguments + device-side row count(s) before the stream
+    "geossl_copy_n": (i32, [P(CopyBatch), i32, vp]),
+    "geossl_ddm_views_dyn": (i32, [vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
+    "geossl_embedding_fwd_dyn": (i32, [vp, i64, vp, i32, i64, i32, vp, vp, vp, vp]),
+    "geossl_embedding_bwd_dyn": (i32, [vp, i64, vp, i32, i64, i32, vp, vp, i32, vp, vp]),
+    "geossl_cfconv_filter_fwd_dyn": (i32, [vp, vp, i64, P(FilterWeights), i32, i32, i32, vp, f32, vp, vp, vp, vp]),
+    "geossl_cfconv_filter_bwd_dyn": (i32, [vp, vp, vp, vp, vp, i64, i64, P(FilterWeights), P(FilterGradIn), i32, i32, i32,
+                                           vp, f32, vp, P(FilterGradOut), vp, i32, vp, vp, vp]),
+    "geossl_cfconv_aggregate_work_dyn": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp]),
+    "geossl_linear_chain_dyn": (i32, [vp, i32, P(Chain), i64, i32, vp, vp]),
+    "geossl_linear_wgrad_dyn": (i32, [P(TnBatch), i32, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
+    "geossl_ddm_loss_fwd2_dyn": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp]),
+    "geossl_ddm_loss_bwd_fused2_dyn": (i32, [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp]),
 }
 
 _lib = None
@@ -266,6 +286,12 @@ class StatusWord:
         self.event = None
         self.message = message
 
+    def __deepcopy__(self, memo):  # (lives in module.__dict__: a copied / pickled module makes its own on first use)
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
     def poll(self):
         if self.event is None or torch.cuda.is_current_stream_capturing():  # no event queries inside a capture
             return
@@ -311,12 +337,13 @@ def call(name, *args):
     if CALLS is not None:
         CALLS += 1
     timers = TIMERS
-    if timers is not None and name in timers:
+    key = name[:-4] if name.endswith("_dyn") else name  # (a `_dyn` entry point is timed under its namesake)
+    if timers is not None and key in timers:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = getattr(lib, name)(*args)
         e1.record()
-        timers[name].append((e0, e1))
+        timers[key].append((e0, e1))
     else:
         rc = getattr(lib, name)(*args)
     check(rc, name)

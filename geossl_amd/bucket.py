@@ -1,0 +1,261 @@
+"""Capacity buckets: the static inputs and index structures behind a step graph that is replayed on batches of ANY
+size sequence.
+
+The reference's loader is ``DataLoaderAtomTuple(dataset, batch_size, shuffle=True)`` over ragged molecules
+(examples/pretrain_GeoSSL.py:301, Geom3D/dataloaders/dataloaders_AtomTuple.py:81-88; with BFS masking the sizes are
+re-drawn every epoch, Geom3D/datasets/datasets_3D.py:24-67): no two batches share a size sequence, so a graph keyed by
+the sequence (``pretrain_GeoSSL.structure_fingerprint``) is never replayed there.  A ``Bucket`` fixes what a captured
+graph binds - addresses, grids, by-value counts - at a CAPACITY (atoms, pair slots, super-edges, work items of the
+aggregation; the number of molecules is the loader's batch size) and turns everything else into device DATA:
+
+* every index structure of the step (``mol_ptr`` / ``pair_ptr`` of the two-view batch, the pair-slot atoms, the
+  aggregation's work list, ``se_ptr``, the divisor of NCSN.py:210-212, the incidence lists) lives in static buffers that
+  ``fill`` rewrites before a replay: the pointer arrays and the work list are computed on the host from the molecule
+  sizes the collation knows (a few cumulative sums over B integers) and go up in ONE pinned copy, the per-slot arrays are
+  produced on the device by the layout kernels launched eagerly with the batch's exact counts;
+* the real counts sit in ``dims`` (int32, device); the kernels of the captured step are the ``_dyn`` entry points of
+  include/geossl_hip.h, which take their grid from the capacity and their row count from ``dims``: rows past the real
+  count are never read or written.
+
+Layout of the fused two-view batch in a bucket: ``[view 0 atoms | view 1 atoms | unused]`` - view 1 starts right behind
+the REAL atoms of view 0 (``dims[N]``), so the molecule CSR stays contiguous.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+MAX_N = 33          # largest molecule a bucket takes (the register-form aggregation's largest size class)
+D_N, D_N2, D_P2, D_S, D_W, D_B = 0, 1, 2, 3, 4, 5   # words of `dims`
+
+
+class DynDims:
+    """Device addresses of a bucket's real counts, as the ``dyn_*`` arguments of the ``_dyn`` entry points."""
+
+    def __init__(self, dims):
+        base = dims.data_ptr()
+        self.tensor = dims
+        self.n_atoms = base + 4 * D_N       # atoms of one view (= the row offset of view 1)
+        self.n_atoms2 = base + 4 * D_N2     # atoms of the two-view batch
+        self.n_pairs2 = base + 4 * D_P2     # pair slots of the two-view batch
+        self.n_super = base + 4 * D_S       # super-edges of one view
+        self.n_work = base + 4 * D_W        # work items of the aggregation
+
+
+class _Layout:
+    """Duck type of layout.MolLayout for the two-view batch of a bucket (capacity shapes, static buffers)."""
+
+    uniform = False
+    order = None
+    _sizes_host = None
+
+    def loop_plan(self, *a, **k):
+        return (None, 0)   # (the layer loop is a plan for uniform batches: they keep their per-structure graph)
+
+
+class _SuperEdges:
+    """Duck type of layout.SuperEdgeLayout for a bucket."""
+
+
+def _parts_table():
+    lib = _lib.load()
+    return np.array([lib.geossl_aggregate_parts(k) for k in range(MAX_N + 1)], dtype=np.int64)
+
+
+_PARTS = None
+
+
+def batch_counts(sizes, option):
+    """(atoms N, pair slots P, super-edges S, aggregation work items W of the two-view batch) of molecules `sizes`."""
+    global _PARTS
+    if _PARTS is None:
+        _PARTS = _parts_table()
+    n = np.asarray(sizes, dtype=np.int64)
+    P = int((n * (n - 1) // 2).sum())
+    S = P if option == "combination" else 2 * P
+    W = 2 * int(_PARTS[n].sum())
+    return int(n.sum()), P, S, W
+
+
+def eligible(batch, model_3d, normalize=False):
+    """Can this batch go through a bucket graph?  SchNet backbone, molecule sizes known on the host (1 .. 33 atoms, at
+    least one molecule with a pair), super_edge_index the extractor's full enumeration - every index tensor of the step
+    is then a function of the sizes."""
+    sizes, canon = getattr(batch, "_sizes", None), getattr(batch, "_canonical", None)
+    if model_3d != "schnet" or normalize or sizes is None or canon not in ("combination", "permutation") or not sizes:
+        return False
+    lo, hi = min(sizes), max(sizes)
+    if lo < 1 or hi > MAX_N or hi < 2:
+        return False
+    return batch.positions.is_cuda and batch.positions.dtype == torch.float32 and batch.x.dim() == 2
+
+
+def modules_ok(model, n1, n2):
+    """The step of these modules can run on a bucket: the F = 128 chain path of SchNet (the chained row kernel is the one
+    that takes a device-side row count) and the paired NCSN heads (two different modules of width 128)."""
+    import os
+    from .Geom3D.models.schnet import SchNet
+    from .NCSN import NCSN_version_03, _head_params
+    if os.environ.get("GEOSSL_NO_CHAIN") or os.environ.get("GEOSSL_NCSN_SPLIT_BWD") or os.environ.get("GEOSSL_NCSN_SEPARATE_HEADS"):
+        return False
+    if not isinstance(model, SchNet) or model.hidden_channels != 128 or model.num_filters != 128 \
+            or model.num_interactions < 1 or model.dipole or model.atomref is not None or model.mean is not None:
+        return False
+    if not (isinstance(n1, NCSN_version_03) and isinstance(n2, NCSN_version_03)) or n1 is n2 \
+            or n1.emb_dim != 128 or n2.emb_dim != 128:
+        return False
+    return not ({id(p) for p in _head_params(n1)} & {id(p) for p in _head_params(n2)})
+
+
+def is_uniform(batch):
+    sizes = getattr(batch, "_sizes", None)
+    return sizes is not None and len(sizes) > 0 and min(sizes) == max(sizes)
+
+
+def _round_up(v, g):
+    return int(-(-int(v) // g) * g)
+
+
+def capacities(N, P, S, W, B, prev=None):
+    """Capacities for a batch with these counts: a slack that covers the spread of a shuffled loader's batch sums
+    (relative spread ~ 1 / sqrt(B)), rounded to the kernels' tile sizes; never below a previous bucket's."""
+    slack = min(0.25, max(0.03, 1.5 / np.sqrt(max(B, 1))))
+    cap = lambda v, g: _round_up(v * (1.0 + slack) + g, g)
+    out = [cap(N, 32), cap(P, 64), cap(S, 64), cap(W, 64)]
+    if prev is not None:
+        out = [max(a, b) for a, b in zip(out, prev)]
+    return tuple(out)
+
+
+class Bucket:
+    def __init__(self, device, B, caps, option, x_cols=2):
+        from .pretrain_GeoSSL import Batch
+        self.device, self.B, self.option = device, int(B), option
+        self.N_cap, self.P_cap, self.S_cap, self.W_cap = (int(c) for c in caps)
+        B, Nc, Pc, Sc, Wc = self.B, self.N_cap, self.P_cap, self.S_cap, self.W_cap
+        i32 = dict(dtype=torch.int32, device=device)
+        i64 = dict(dtype=torch.int64, device=device)
+        # ---- the blob: everything the host computes, uploaded in one copy (int32 words; int64 parts 8-byte aligned)
+        o = {"dims": 0}
+        o["mol_ptr"] = 8
+        o["pair_ptr"] = o["mol_ptr"] + 2 * B + 1
+        o["se_ptr"] = o["pair_ptr"] + 2 * B + 1
+        o["work"] = o["se_ptr"] + B + 1
+        o["stats"] = _round_up(o["work"] + Wc, 2)
+        o["inc_ptr"] = o["stats"] + 4
+        self.words = o["inc_ptr"] + 2 * (Nc + 1)
+        self.off = o
+        self.blob = torch.zeros(self.words, **i32)
+        self.dims = self.blob[0:8]
+        self.dyn = DynDims(self.dims)
+        self._host = [[torch.zeros(self.words, dtype=torch.int32).pin_memory(), None] for _ in range(3)]
+        self._slot = 0
+        # ---- static inputs of the step
+        self.x = torch.zeros(Nc, x_cols, **i64)
+        self.positions = torch.zeros(Nc, 3, dtype=torch.float32, device=device)
+        self.batch_vec = torch.zeros(Nc, **i64)
+        self.sei = torch.zeros(2, Sc, **i64)
+        self.b2 = torch.zeros(2 * Nc, **i64)   # placeholder for SchNet.forward's `batch` argument (the layout is passed)
+        # ---- two-view molecule layout
+        lay = _Layout()
+        lay.N, lay.B, lay.P, lay.max_n = 2 * Nc, 2 * B, 2 * Pc, MAX_N
+        lay.mol_ptr = self.blob[o["mol_ptr"]:o["mol_ptr"] + 2 * B + 1]
+        lay.pair_ptr = self.blob[o["pair_ptr"]:o["pair_ptr"] + 2 * B + 1]
+        lay.pair_i = torch.zeros(2 * Pc, **i32)
+        lay.pair_j = torch.zeros(2 * Pc, **i32)
+        lay.agg_work = self.blob[o["work"]:o["work"] + Wc]
+        lay.device, lay.dyn = device, self.dyn
+        lay._batch_version = self.b2._version
+        self.lay2 = lay
+        # ---- super-edge bookkeeping of the heads
+        sel = _SuperEdges()
+        sel.sei0, sel.sei1, sel.batch = self.sei[0], self.sei[1], self.batch_vec
+        sel.S, sel.N, sel.B = Sc, Nc, B
+        sel.se_ptr = self.blob[o["se_ptr"]:o["se_ptr"] + B + 1]
+        sel.stats = self.blob[o["stats"]:o["stats"] + 4].view(torch.int64)
+        sel.inc_ptr = self.blob[o["inc_ptr"]:o["inc_ptr"] + 2 * (Nc + 1)].view(torch.int64)
+        sel.inc_idx = torch.zeros(2 * Sc, **i32)
+        sel.dyn = self.dyn
+        sel._versions = (self.batch_vec._version, self.sei._version)
+        self.sel = sel
+        # ---- the batch object the captured step sees
+        self.batch = Batch(self.x, self.positions, self.batch_vec, self.sei, None, B, None, option)
+        self.batch._bucket = self
+        self.real = None  # (N, P, S, W) of the batch last filled in
+
+    def caps(self):
+        return (self.N_cap, self.P_cap, self.S_cap, self.W_cap)
+
+    def fits(self, counts):
+        return all(c <= cap for c, cap in zip(counts, self.caps()))
+
+    def fill(self, batch, counts=None):
+        """The batch's atom types, positions, index tensors and derived structures into the static buffers."""
+        global _PARTS
+        if _PARTS is None:
+            _PARTS = _parts_table()
+        B, o = self.B, self.off
+        n = np.asarray(batch._sizes, dtype=np.int64)
+        if n.shape[0] != B:
+            raise ValueError("bucket of %d molecules got a batch of %d" % (B, n.shape[0]))
+        N, P, S, W = counts if counts is not None else batch_counts(n, self.option)
+        if not self.fits((N, P, S, W)) or P < 1:
+            raise ValueError("batch exceeds the bucket's capacity")
+        slot = self._host[self._slot]
+        self._slot = (self._slot + 1) % len(self._host)
+        if slot[1] is not None:
+            slot[1].synchronize()   # the upload that last read this staging buffer (three steps ago)
+        h = slot[0].numpy()
+        h[0:8] = (N, 2 * N, 2 * P, S, W, B, 0, 0)
+        mp = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(n, out=mp[1:])
+        npair = n * (n - 1) // 2
+        pp = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(npair, out=pp[1:])
+        h[o["mol_ptr"]:o["mol_ptr"] + B + 1] = mp
+        h[o["mol_ptr"] + B + 1:o["mol_ptr"] + 2 * B + 1] = mp[1:] + N
+        h[o["pair_ptr"]:o["pair_ptr"] + B + 1] = pp
+        h[o["pair_ptr"] + B + 1:o["pair_ptr"] + 2 * B + 1] = pp[1:] + P
+        mult = 1 if self.option == "combination" else 2
+        h[o["se_ptr"]:o["se_ptr"] + B + 1] = pp * mult
+        # work list of the aggregation over the 2B molecules of both views: largest first (stable), the 27..33-atom
+        # molecules as 2 or 4 items (layout.MolLayout.agg_work)
+        n2 = np.concatenate([n, n])
+        idx = np.argsort(-n2, kind="stable")
+        parts = _PARTS[n2][idx]
+        mol = np.repeat(idx, parts)
+        ends = np.cumsum(parts)
+        part = np.arange(int(ends[-1]), dtype=np.int64) - np.repeat(ends - parts, parts)
+        h[o["work"]:o["work"] + W] = (mol | (part << 28)).astype(np.int32)
+        # NCSN.py:210-212: loss.mean() divides by max(edge2graph) + 1 = the last molecule with a super-edge, + 1
+        has = np.nonzero(npair > 0)[0]
+        st = h[o["stats"]:o["stats"] + 4].view(np.int64)
+        st[0], st[1] = int(has[-1]) + 1, 0
+        ip = h[o["inc_ptr"]:o["inc_ptr"] + 2 * (N + 1)].view(np.int64)
+        ip[0] = 0
+        np.cumsum(np.repeat((n - 1) * mult, n), out=ip[1:])
+        self.blob.copy_(slot[0], non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        # ---- device side: the five input tensors in one launch, then the per-slot index arrays
+        sei = batch.super_edge_index
+        if sei.stride(1) != 1 or not batch.positions.is_contiguous() or not batch.x.is_contiguous() \
+                or not batch.batch.is_contiguous() or batch.x.size(1) != self.x.size(1):
+            raise ValueError("bucket fill expects contiguous collated tensors")
+        cb = _lib.CopyBatch()
+        for k, (dst, src, nbytes) in enumerate((
+                (self.x, batch.x, N * self.x.size(1) * 8), (self.positions, batch.positions, N * 12),
+                (self.batch_vec, batch.batch, N * 8), (self.sei[0], sei[0], S * 8), (self.sei[1], sei[1], S * 8))):
+            cb.dst[k], cb.src[k], cb.bytes[k] = ptr(dst), ptr(src), nbytes
+        st_ = stream()
+        call("geossl_copy_n", C.byref(cb), 5, st_)
+        lay = self.lay2
+        call("geossl_pair_index_fill", ptr(lay.mol_ptr), ptr(lay.pair_ptr), 2 * B, ptr(lay.pair_i), ptr(lay.pair_j), st_)
+        sel = self.sel
+        call("geossl_incidence_fill", ptr(sel.batch), ptr(sel.sei0), ptr(sel.sei1), ptr(sel.se_ptr), N, 3,
+             ptr(sel.inc_ptr), ptr(sel.inc_idx), st_)
+        self.real = (N, P, S, W)
+        return self.real

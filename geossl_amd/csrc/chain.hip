@@ -831,13 +831,16 @@ __device__ __forceinline__ void chain_cu_body(const ChainT& ch, const float* __r
 }
 
 template <int NS, int RB, int WPS, bool SILU>
-__global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const float* __restrict__ X, int ldx, int R) {
+__global__ __launch_bounds__(256, WPS) void k_row_chain_cu(GeosslChain ch, const float* __restrict__ X, int ldx, int R,
+                                                           const int32_t* __restrict__ dyn_R) {
+  R = dyn_count(R, dyn_R);  // (a grid sized for more rows only makes the runs of row blocks shorter: nloc <= RB holds)
   const int nrb = (R + 31) / 32;
   // contiguous runs of row blocks: the first `extra` blocks take one more (they are the first to be placed on a CU, so
   // a CU that holds two blocks holds at most one long one)
   const int nblk = (int)gridDim.x, base = nrb / nblk, extra = nrb - base * nblk, b = (int)blockIdx.x;
   const int rb0 = b * base + min(b, extra);
   const int nloc = base + (b < extra ? 1 : 0);                             // <= RB, uniform
+  if (nloc == 0) return;  // (only with a device-side row count below the grid's: block-uniform, before any barrier)
   chain_cu_body<NS, RB, WPS, SILU>(ch, X, ldx, R, 32 * rb0, R, nloc);
 }
 
@@ -905,8 +908,10 @@ __global__ __launch_bounds__(256, 2) void k_layer_loop(LoopArgs a) {
 }
 
 template <int KS>
-int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipStream_t stream) {
+int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipStream_t stream,
+                 const int32_t* dyn_R = nullptr) {
   constexpr int NMB = KS / 2, CHUNK_BYTES = KS * 3 * 1024;
+  if (dyn_R != nullptr && KS != 8) return (int)hipErrorInvalidValue;  // device-side row counts: weight-stationary form only
   const int nrb = (int)((R + 31) / 32), ngroups = (nrb + 3) / 4;
   const int nslot = chain_slots(ch.nstage * NMB);
   static const bool four_waves = getenv("GEOSSL_CHAIN4") != nullptr;  // the four-wave form, kept for A/B runs
@@ -920,6 +925,7 @@ int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipS
   if (silu && !cu_form) return (int)hipErrorInvalidValue;  // silu epilogues, long chains: weight-stationary form only
   for (int s2 = 0; s2 < ch.nstage; ++s2) {
     if (cu_form && ((int64_t)R * ch.st[s2].ld * 4 >= (int64_t)0xFFFFFF00u || (int64_t)R * ldx * 4 >= (int64_t)0xFFFFFF00u)) {
+      if (dyn_R != nullptr) return (int)hipErrorInvalidValue;  // (two launches of half the rows: by-value counts only)
       const int64_t r0 = ((R / 2 + 31) / 32) * 32;
       GeosslChain hi = ch;
       for (int s3 = 0; s3 < ch.nstage; ++s3) {
@@ -954,19 +960,19 @@ int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipS
   do {                                                                                                                 \
     if (silu) {                                                                                                        \
       allow_big_lds(&k_row_chain_cu<NSV, 3, 2, true>);                                                                 \
-      hipLaunchKernelGGL((k_row_chain_cu<NSV, 3, 2, true>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R);   \
+      hipLaunchKernelGGL((k_row_chain_cu<NSV, 3, 2, true>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R, dyn_R);   \
     } else if (one_per_cu) {                                                                                           \
       allow_big_lds(&k_row_chain_cu<NSV, 5, 1, false>);                                                                \
-      hipLaunchKernelGGL((k_row_chain_cu<NSV, 5, 1, false>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R);  \
+      hipLaunchKernelGGL((k_row_chain_cu<NSV, 5, 1, false>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R, dyn_R);  \
     } else {                                                                                                           \
       allow_big_lds(&k_row_chain_cu<NSV, 3, 2, false>);                                                                \
-      hipLaunchKernelGGL((k_row_chain_cu<NSV, 3, 2, false>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R);  \
+      hipLaunchKernelGGL((k_row_chain_cu<NSV, 3, 2, false>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R, dyn_R);  \
     }                                                                                                                  \
   } while (0)
 #define LAUNCH_CU_LONG(NSV)                                                                                            \
   do {                                                                                                                 \
     allow_big_lds(&k_row_chain_cu<NSV, 3, 2, true>);                                                                   \
-    hipLaunchKernelGGL((k_row_chain_cu<NSV, 3, 2, true>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R);     \
+    hipLaunchKernelGGL((k_row_chain_cu<NSV, 3, 2, true>), dim3(grid), dim3(256), lds, stream, ch, X, ldx, (int)R, dyn_R);     \
   } while (0)
     switch (ch.nstage) {
       case 1: LAUNCH_CU(1); break;
@@ -1045,6 +1051,11 @@ extern "C" int geossl_chain_prepare(const GeosslPrepareBatch* batch, int nprob, 
 
 extern "C" int geossl_linear_chain(const float* X, int ldx, const GeosslChain* chain, int64_t R, int F,
                                    hipStream_t stream) {
+  return geossl_linear_chain_dyn(X, ldx, chain, R, F, nullptr, stream);
+}
+
+extern "C" int geossl_linear_chain_dyn(const float* X, int ldx, const GeosslChain* chain, int64_t R, int F,
+                                       const int32_t* dyn_R, hipStream_t stream) {
   if (R <= 0) return 0;
   if (chain == nullptr || chain->nstage < 1 || chain->nstage > GEOSSL_CHAIN_MAX || geossl_chain_image_words(F) == 0)
     return (int)hipErrorInvalidValue;
@@ -1055,9 +1066,9 @@ extern "C" int geossl_linear_chain(const float* X, int ldx, const GeosslChain* c
     if ((st.out != nullptr || st.res != nullptr || st.tprev != nullptr || st.out_act != nullptr) && (st.ld < F || (st.ld & 3)))
       return (int)hipErrorInvalidValue;
   }
-  if (F == 128) return launch_chain<8>(*chain, X, ldx, R, stream);
-  if (F == 64) return launch_chain<4>(*chain, X, ldx, R, stream);
-  return launch_chain<2>(*chain, X, ldx, R, stream);
+  if (F == 128) return launch_chain<8>(*chain, X, ldx, R, stream, dyn_R);
+  if (F == 64) return launch_chain<4>(*chain, X, ldx, R, stream, dyn_R);
+  return launch_chain<2>(*chain, X, ldx, R, stream, dyn_R);
 }
 
 extern "C" int geossl_schnet_layer_loop(const GeosslLoopOp* ops, int nops, const int32_t* plan, int nblocks,

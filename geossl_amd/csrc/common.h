@@ -178,6 +178,14 @@ __device__ __forceinline__ float kahan_sum_strided(const float* __restrict__ p, 
   return s;
 }
 
+// Row count of a launch whose grid and buffers were sized for a CAPACITY (a captured HIP graph replayed on batches of
+// different sizes, pretrain_GeoSSL.StepGraphs): `cap` is the by-value count the launch was built with, `dyn` (nullable)
+// points at the batch's real count in device memory.  Rows at and past the real count do not exist: never read, never
+// written, their blocks leave zero partial sums.
+__device__ __forceinline__ int dyn_count(int cap, const int32_t* __restrict__ dyn) {
+  return dyn != nullptr ? min(cap, *dyn) : cap;  // (uniform address: a scalar load)
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

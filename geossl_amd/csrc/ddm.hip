@@ -234,10 +234,15 @@ __global__ __launch_bounds__(256) void k_incidence_gather(const float* __restric
                                                           const int64_t* __restrict__ inc_ptr,
                                                           const int32_t* __restrict__ inc_idx, int N, int F,
                                                           float* __restrict__ dh0, int accumulate,
-                                                          const float* __restrict__ dfeat1, float* __restrict__ dh1) {
+                                                          const float* __restrict__ dfeat1, float* __restrict__ dh1,
+                                                          const int32_t* __restrict__ dyn_view) {
   // (blockIdx.y = 1: the second head of a two-head launch - same incidence lists, its own rows)
   const float* __restrict__ dfeat = blockIdx.y == 0 ? dfeat0 : dfeat1;
   float* __restrict__ dh = blockIdx.y == 0 ? dh0 : dh1;
+  // capacity launch: *dyn_view = real atoms of a view; both heads were handed the base of ONE [view 0 ; view 1] gradient
+  // tensor, head 1 writes its rows behind head 0's
+  N = dyn_count(N, dyn_view);
+  if (dyn_view != nullptr && blockIdx.y == 1) dh += (size_t)N * F;
   // A super-edge row is read twice, by its two atoms - atoms of ONE molecule, i.e. of neighbouring groups of four.
   // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): consecutive groups on consecutive
   // workgroups would fetch a molecule's rows into several L2s, from HBM every time.  Group g = (block mod 8) * per +
@@ -397,7 +402,7 @@ extern "C" int geossl_incidence_gather(const float* dfeat, const int64_t* inc_pt
   if (N <= 0) return 0;
   const unsigned groups = (unsigned)((N + 3) / 4);
   hipLaunchKernelGGL(k_incidence_gather, dim3((groups + 7) / 8 * 8), dim3(256), 0, stream, dfeat, inc_ptr, inc_idx,
-                     (int)N, F, dh, accumulate, (const float*)nullptr, (float*)nullptr);
+                     (int)N, F, dh, accumulate, (const float*)nullptr, (float*)nullptr, (const int32_t*)nullptr);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
@@ -405,11 +410,11 @@ extern "C" int geossl_incidence_gather(const float* dfeat, const int64_t* inc_pt
 namespace geossl {
 // dh of both heads in one launch (geossl_ddm_loss_bwd_fused2, ncsn_bwd.hip)
 int launch_incidence_gather2(const float* dfeat0, const float* dfeat1, const int64_t* inc_ptr, const int32_t* inc_idx,
-                             int64_t N, int F, float* dh0, float* dh1, hipStream_t stream) {
+                             int64_t N, int F, float* dh0, float* dh1, hipStream_t stream, const int32_t* dyn_view) {
   if (N <= 0) return 0;
   const unsigned groups = (unsigned)((N + 3) / 4);
   hipLaunchKernelGGL(k_incidence_gather, dim3((groups + 7) / 8 * 8, 2), dim3(256), 0, stream, dfeat0, inc_ptr, inc_idx,
-                     (int)N, F, dh0, 0, dfeat1, dh1);
+                     (int)N, F, dh0, 0, dfeat1, dh1, dyn_view);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

@@ -91,7 +91,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
                                                 const float* __restrict__ offset, float coeff,
                                                 const float* __restrict__ T, float* __restrict__ partial_w1,
                                                 float* __restrict__ partial_b1, float* __restrict__ partial_w2,
-                                                float* __restrict__ partial_b2) {
+                                                float* __restrict__ partial_b2, int Pstride) {
   constexpr int F = 32 * NW, NT = 128 * NW, KC = F / 16, CB = F / 32, AS = BwdLds<F>::AS, Q = F / 4;
   static_assert(TR * (F / 8) == NT, "one dOr fragment lane per thread");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
@@ -102,7 +102,7 @@ __device__ __forceinline__ void filter_bwd_body(const float* __restrict__ pair_d
   const int l = blockIdx.y;
   const float* __restrict__ x = g.x[l];
   const float* __restrict__ dagg = g.dagg[l];
-  const size_t lbase = (size_t)l * P;
+  const size_t lbase = (size_t)l * Pstride;  // (layer stride of T: the capacity the launch was built for; P: real rows)
   const float* __restrict__ Tl = T + lbase * F;   // uniform base: the per-lane part stays a 32-bit offset
   const uint32_t tcol = 32 * hs + j;               // this lane's hidden unit
 
@@ -487,13 +487,18 @@ __global__ __launch_bounds__(128 * NW) void k_filter_bwd(const float* __restrict
                                                          float* __restrict__ partial_w1,
                                                          float* __restrict__ partial_b1,
                                                          float* __restrict__ partial_w2,
-                                                         float* __restrict__ partial_b2) {
+                                                         float* __restrict__ partial_b2,
+                                                         const int32_t* __restrict__ dyn_P,
+                                                         const int32_t* __restrict__ dyn_N) {
+  const int Pstride = P;
+  P = dyn_count(P, dyn_P);
+  N = dyn_count(N, dyn_N);
   if ((int)(threadIdx.x >> 6) < NW)
     filter_bwd_body<NW, true>(pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, w, g, G, offset, coeff, T, partial_w1,
-                              partial_b1, partial_w2, partial_b2);
+                              partial_b1, partial_w2, partial_b2, Pstride);
   else
     filter_bwd_body<NW, false>(pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, w, g, G, offset, coeff, T, partial_w1,
-                               partial_b1, partial_w2, partial_b2);
+                               partial_b1, partial_w2, partial_b2, Pstride);
 }
 
 // =====================================================================================================================
@@ -543,7 +548,7 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
                                                 const float* __restrict__ offset, float coeff,
                                                 const float* __restrict__ T, float* __restrict__ partial_w1,
                                                 float* __restrict__ partial_b1, float* __restrict__ partial_w2,
-                                                float* __restrict__ partial_b2) {
+                                                float* __restrict__ partial_b2, int Pstride) {
   constexpr int F = 32 * NW, NT = 128 * NW, KC = F / 16, CB = F / 32, AS = BwdLdsH<F>::AS, Q = F / 4;
   static_assert(TR * (F / 8) == NT, "one dOr fragment lane per thread");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
@@ -554,7 +559,7 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
   const int l = blockIdx.y;
   const float* __restrict__ x = g.x[l];
   const float* __restrict__ dagg = g.dagg[l];
-  const size_t lbase = (size_t)l * P;
+  const size_t lbase = (size_t)l * Pstride;  // (layer stride of T: the capacity the launch was built for; P: real rows)
   const float* __restrict__ Tl = T + lbase * F;   // uniform base: the per-lane part stays a 32-bit offset
   const uint32_t tcol = 32 * hs + j;               // this lane's hidden unit
 
@@ -1083,13 +1088,18 @@ __global__ __launch_bounds__(128 * NW) void k_filter_bwd_h(const float* __restri
                                                          float* __restrict__ partial_w1,
                                                          float* __restrict__ partial_b1,
                                                          float* __restrict__ partial_w2,
-                                                         float* __restrict__ partial_b2) {
+                                                         float* __restrict__ partial_b2,
+                                                         const int32_t* __restrict__ dyn_P,
+                                                         const int32_t* __restrict__ dyn_N) {
+  const int Pstride = P;
+  P = dyn_count(P, dyn_P);
+  N = dyn_count(N, dyn_N);
   if ((int)(threadIdx.x >> 6) < NW)
     filter_bwd_body_h<NW, true>(pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, w, g, G, offset, coeff, T, partial_w1,
-                              partial_b1, partial_w2, partial_b2);
+                              partial_b1, partial_w2, partial_b2, Pstride);
   else
     filter_bwd_body_h<NW, false>(pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, w, g, G, offset, coeff, T, partial_w1,
-                               partial_b1, partial_w2, partial_b2);
+                               partial_b1, partial_w2, partial_b2, Pstride);
 }
 
 inline int blocks_per_layer(int L, int ntiles) {
@@ -1125,6 +1135,16 @@ extern "C" int geossl_cfconv_filter_bwd(const float* pair_d, const float* pair_c
                                         const float* offset, float coeff, const float* T,
                                         const GeosslFilterGradOut* out, float* workspace, int accumulate,
                                         hipStream_t stream) {
+  return geossl_cfconv_filter_bwd_dyn(pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, w, g, L, F, G, offset, coeff, T, out,
+                                      workspace, accumulate, nullptr, nullptr, stream);
+}
+
+extern "C" int geossl_cfconv_filter_bwd_dyn(const float* pair_d, const float* pair_c, const uint8_t* pair_flag,
+                                            const int32_t* pair_i, const int32_t* pair_j, int64_t P, int64_t N,
+                                            const GeosslFilterWeights* w, const GeosslFilterGradIn* g, int L, int F,
+                                            int G, const float* offset, float coeff, const float* T,
+                                            const GeosslFilterGradOut* out, float* workspace, int accumulate,
+                                            const int32_t* dyn_P, const int32_t* dyn_N, hipStream_t stream) {
   if (P <= 0 || L <= 0) return 0;
   if (L > GEOSSL_MAX_L || (F != 32 && F != 64 && F != 128) || G > 64) return (int)hipErrorInvalidValue;
   const int ntiles = (int)((P + TR - 1) / TR);
@@ -1139,16 +1159,16 @@ extern "C" int geossl_cfconv_filter_bwd(const float* pair_d, const float* pair_c
     const size_t lds = BwdLds<32 * NW>::bytes();                                                                   \
     allow_big_lds(&k_filter_bwd<NW>);                                                                              \
     hipLaunchKernelGGL((k_filter_bwd<NW>), grid, dim3(128 * NW), lds, stream, pair_d, pair_c, pair_flag, pair_i,   \
-                       pair_j, (int)P, (int)N, *w, *g, G, offset, coeff, T, pw1, pb1, pw2, pb2);                   \
+                       pair_j, (int)P, (int)N, *w, *g, G, offset, coeff, T, pw1, pb1, pw2, pb2, dyn_P, dyn_N);     \
   } while (0)
 #define LAUNCH_H(NW)                                                                                               \
   do {                                                                                                             \
     const size_t lds = BwdLdsH<32 * NW>::bytes();                                                                  \
     allow_big_lds(&k_filter_bwd_h<NW>);                                                                            \
     hipLaunchKernelGGL((k_filter_bwd_h<NW>), grid, dim3(128 * NW), lds, stream, pair_d, pair_c, pair_flag, pair_i, \
-                       pair_j, (int)P, (int)N, *w, *g, G, offset, coeff, T, pw1, pb1, pw2, pb2);                   \
+                       pair_j, (int)P, (int)N, *w, *g, G, offset, coeff, T, pw1, pb1, pw2, pb2, dyn_P, dyn_N);     \
   } while (0)
-  static const bool bf16x3 = getenv("GEOSSL_FILTER_BWD_BF16X3") != nullptr;
+  const bool bf16x3 = getenv("GEOSSL_FILTER_BWD_BF16X3") != nullptr;  // (read per call: bench.py times both forms in one process)
   if (!bf16x3) {
     if (F == 128) LAUNCH_H(4); else if (F == 64) LAUNCH_H(2); else LAUNCH_H(1);
   } else {

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(512) void k_filter_fwd(const float* __restrict__ pa
                                                     const float* __restrict__ pair_c, int P,
                                                     GeosslFilterWeights w, int G,
                                                     const float* __restrict__ offset, float coeff,
-                                                    float* __restrict__ Tout, float* __restrict__ Wf) {
+                                                    float* __restrict__ Tout, float* __restrict__ Wf,
+                                                    const int32_t* __restrict__ dyn_P) {
   constexpr int F = 32 * NMB, K2S = F / 16;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
   u32x4* W2f = reinterpret_cast<u32x4*>(smem_raw);          // [NMB][K2S][3][64] A fragments of A2
@@ -88,7 +89,9 @@ __global__ __launch_bounds__(512) void k_filter_fwd(const float* __restrict__ pa
     for (int i = tid; i < 16 * K1S; i += 512) offs[i] = i < G ? offset[i] : 0.0f;
   }
   __syncthreads();
-  const size_t lbase = (size_t)l * P;
+  const size_t lbase = (size_t)l * P;  // (the layer stride of T / Wf is the by-value - capacity - count)
+  P = dyn_count(P, dyn_P);
+  if (P <= 0) return;
   const int nrb = (P + 31) / 32;
   // ---- main loop: a wave takes 32 pair rows through both GEMMs; no block-level synchronisation
   // row blocks dealt wave-index-major: the waves that get one block more than the others are then spread one per SIMD
@@ -268,7 +271,8 @@ __global__ __launch_bounds__(FFH_THREADS) void k_filter_fwd_h(const float* __res
                                                       const float* __restrict__ pair_c, int P,
                                                       GeosslFilterWeights w, int G,
                                                       const float* __restrict__ offset, float coeff,
-                                                      float* __restrict__ Tout, float* __restrict__ Wf) {
+                                                      float* __restrict__ Tout, float* __restrict__ Wf,
+                                                    const int32_t* __restrict__ dyn_P) {
   constexpr int F = 32 * NMB, K2S = F / 16;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
   u32x4* W2f = reinterpret_cast<u32x4*>(smem_raw);          // [NMB][K2S][2][64] A fragments of A2 * s2
@@ -339,7 +343,9 @@ __global__ __launch_bounds__(FFH_THREADS) void k_filter_fwd_h(const float* __res
   if (tid == 0) *next_rb = 0;
   __syncthreads();
   const float inv1 = 1.0f / (s1 * 16384.0f), inv2 = 1.0f / s2;  // powers of two: exact
-  const size_t lbase = (size_t)l * P;
+  const size_t lbase = (size_t)l * P;  // (the layer stride of T / Wf is the by-value - capacity - count)
+  P = dyn_count(P, dyn_P);
+  if (P <= 0) return;
   const int nrb = (P + 31) / 32;
   // Row blocks blockIdx.x + gridDim.x t of the layer are handed out on demand: of the two waves of a SIMD the older one
   // wins the issue arbitration (in-kernel marks: 23k against 32k cycles per row block while both run), so equal shares
@@ -480,6 +486,13 @@ namespace {
 extern "C" int geossl_cfconv_filter_fwd(const float* pair_d, const float* pair_c, int64_t P,
                                         const GeosslFilterWeights* w, int L, int F, int G, const float* offset,
                                         float coeff, float* T, float* Wf, hipStream_t stream) {
+  return geossl_cfconv_filter_fwd_dyn(pair_d, pair_c, P, w, L, F, G, offset, coeff, T, Wf, nullptr, stream);
+}
+
+extern "C" int geossl_cfconv_filter_fwd_dyn(const float* pair_d, const float* pair_c, int64_t P,
+                                            const GeosslFilterWeights* w, int L, int F, int G, const float* offset,
+                                            float coeff, float* T, float* Wf, const int32_t* dyn_P,
+                                            hipStream_t stream) {
   if (P <= 0 || L <= 0) return 0;
   if (L > GEOSSL_MAX_L || (F != 32 && F != 64 && F != 128) || G > 64 || G < 1) return (int)hipErrorInvalidValue;
   const int nrb = (int)((P + 31) / 32);
@@ -492,7 +505,7 @@ extern "C" int geossl_cfconv_filter_fwd(const float* pair_d, const float* pair_c
     const size_t lds = (size_t)(NMB * (2 * NMB) + NMB * K1S) * 3 * 1024 + (2 * 32 * NMB + 16 * K1S) * 4;        \
     allow_big_lds(&k_filter_fwd<NMB, K1S>);                                                                     \
     hipLaunchKernelGGL((k_filter_fwd<NMB, K1S>), grid, dim3(512), lds, stream, pair_d, pair_c, (int)P, *w, G,   \
-                       offset, coeff, T, Wf);                                                                   \
+                       offset, coeff, T, Wf, dyn_P);                                                            \
   } while (0)
 #define LAUNCH_F(NMB)                   \
   do {                                  \
@@ -502,13 +515,13 @@ extern "C" int geossl_cfconv_filter_fwd(const float* pair_d, const float* pair_c
     else LAUNCH(NMB, 4);                \
   } while (0)
   // default: two fp16 pieces per operand (3 MFMAs per product); GEOSSL_FILTER_FWD_BF16X3 selects the three-bf16-piece form
-  static const bool bf16x3 = getenv("GEOSSL_FILTER_FWD_BF16X3") != nullptr;
+  const bool bf16x3 = getenv("GEOSSL_FILTER_FWD_BF16X3") != nullptr;  // (read per call: bench.py times both forms in one process)
 #define LAUNCH_H(NMB, K1S)                                                                                      \
   do {                                                                                                          \
     const size_t lds = (size_t)(NMB * (2 * NMB) + NMB * K1S) * 2 * 1024 + (2 * 32 * NMB + 16 * K1S + 36) * 4;   \
     allow_big_lds(&k_filter_fwd_h<NMB, K1S>);                                                                   \
     hipLaunchKernelGGL((k_filter_fwd_h<NMB, K1S>), grid, dim3(FFH_THREADS), lds, stream, pair_d, pair_c, (int)P, *w, G, \
-                       offset, coeff, T, Wf);                                                                   \
+                       offset, coeff, T, Wf, dyn_P);                                                            \
   } while (0)
 #define LAUNCH_HF(NMB)                    \
   do {                                    \

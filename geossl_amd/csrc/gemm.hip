@@ -515,6 +515,12 @@ extern "C" int64_t geossl_tn_workspace_floats(int64_t R, int M, int N, int nprob
 // Column GEMM (weight gradient) of plain row-major operands: k_wgrad_split<., ., PlainOps> (wgrad.h).
 extern "C" int geossl_linear_wgrad(const GeosslTnBatch* batch, int nprob, int64_t R, int M, int N, int lda, int ldb,
                                    int ldw, float* workspace, int accumulate, hipStream_t stream) {
+  return geossl_linear_wgrad_dyn(batch, nprob, R, M, N, lda, ldb, ldw, workspace, accumulate, nullptr, stream);
+}
+
+extern "C" int geossl_linear_wgrad_dyn(const GeosslTnBatch* batch, int nprob, int64_t R, int M, int N, int lda, int ldb,
+                                       int ldw, float* workspace, int accumulate, const int32_t* dyn_R,
+                                       hipStream_t stream) {
   if (lda < M || ldb < N || ldw < N || (lda & 3) || (ldb & 3) || (M & 3) || (N & 3)) return (int)hipErrorInvalidValue;
   if (nprob <= 0 || R <= 0) return 0;
   if (nprob > GEOSSL_TN_MAX) return (int)hipErrorInvalidValue;
@@ -530,7 +536,7 @@ extern "C" int geossl_linear_wgrad(const GeosslTnBatch* batch, int nprob, int64_
       out.db[z] = batch->db[z];
       out.dd[z] = nullptr;
     }
-#define WG(a, b) if (NCM == a && NCN == b) return launch_wgrad_split<a, b>(ops, nprob, R, M, N, out, ldw, 1, workspace, accumulate, stream)
+#define WG(a, b) if (NCM == a && NCN == b) return launch_wgrad_split<a, b>(ops, nprob, R, M, N, out, ldw, 1, workspace, accumulate, stream, dyn_R)
     WG(4, 4); WG(4, 2); WG(2, 4); WG(2, 2); WG(1, 1); WG(1, 2); WG(2, 1); WG(4, 1); WG(1, 4);
 #undef WG
   }

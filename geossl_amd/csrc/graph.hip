@@ -260,7 +260,11 @@ __global__ void k_pair_distance(const float* __restrict__ pos, const int64_t* __
 __global__ void k_ddm_views(const float* __restrict__ pos, const float* __restrict__ noise,
                             const int64_t* __restrict__ sei0, const int64_t* __restrict__ sei1, int64_t n3, int S,
                             float* __restrict__ pos2, float* __restrict__ d01, float* __restrict__ d02,
-                            const int64_t* __restrict__ z, int64_t zs, int64_t* __restrict__ z2) {
+                            const int64_t* __restrict__ z, int64_t zs, int64_t* __restrict__ z2,
+                            const int32_t* __restrict__ dyn_N, const int32_t* __restrict__ dyn_S) {
+  // (capacity launch: the second view starts right behind the REAL atoms of the first)
+  n3 = 3 * (int64_t)dyn_count((int)(n3 / 3), dyn_N);
+  S = dyn_count(S, dyn_S);
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
   if (z2 != nullptr)  // atom types of the two-view batch: the column z[:, 0] twice
     for (int64_t i = t; i < n3 / 3; i += nt) {
@@ -461,15 +465,22 @@ extern "C" int geossl_pair_distance(const float* pos, const int64_t* sei0, const
   return 0;
 }
 
-extern "C" int geossl_ddm_views(const float* pos, const float* noise, const int64_t* sei0, const int64_t* sei1, int64_t N,
-                                int64_t S, float* pos2, float* d01, float* d02, const int64_t* z, int64_t z_stride,
-                                int64_t* z2, hipStream_t stream) {
+extern "C" int geossl_ddm_views_dyn(const float* pos, const float* noise, const int64_t* sei0, const int64_t* sei1,
+                                    int64_t N, int64_t S, float* pos2, float* d01, float* d02, const int64_t* z,
+                                    int64_t z_stride, int64_t* z2, const int32_t* dyn_N, const int32_t* dyn_S,
+                                    hipStream_t stream) {
   if (N <= 0) return 0;
   const int64_t work = 3 * N > S ? 3 * N : S;
   hipLaunchKernelGGL(k_ddm_views, dim3(grid1d(work, 256)), dim3(256), 0, stream, pos, noise, sei0, sei1, 3 * N, (int)S,
-                     pos2, d01, d02, z, z_stride, z2);
+                     pos2, d01, d02, z, z_stride, z2, dyn_N, dyn_S);
   GEOSSL_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int geossl_ddm_views(const float* pos, const float* noise, const int64_t* sei0, const int64_t* sei1, int64_t N,
+                                int64_t S, float* pos2, float* d01, float* d02, const int64_t* z, int64_t z_stride,
+                                int64_t* z2, hipStream_t stream) {
+  return geossl_ddm_views_dyn(pos, noise, sei0, sei1, N, S, pos2, d01, d02, z, z_stride, z2, nullptr, nullptr, stream);
 }
 
 extern "C" int geossl_copy2(void* dst0, const void* src0, int64_t bytes0, void* dst1, const void* src1, int64_t bytes1,
@@ -480,6 +491,31 @@ extern "C" int geossl_copy2(void* dst0, const void* src0, int64_t bytes0, void* 
   if (work <= 0) return 0;
   hipLaunchKernelGGL(k_copy2, dim3(grid1d(work, 256)), dim3(256), 0, stream, (uint32_t*)dst0, (const uint32_t*)src0, n0,
                      (uint32_t*)dst1, (const uint32_t*)src1, n1);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+// up to GEOSSL_COPY_MAX device-to-device copies in one launch (blockIdx.y = copy): the per-step refresh of a
+// capacity-bucketed graph's inputs (atom types, positions, batch vector, both rows of super_edge_index)
+namespace {
+__global__ void k_copy_n(GeosslCopyBatch b) {
+  const uint32_t* __restrict__ s = reinterpret_cast<const uint32_t*>(b.src[blockIdx.y]);
+  uint32_t* __restrict__ d = reinterpret_cast<uint32_t*>(b.dst[blockIdx.y]);
+  const int64_t n = b.bytes[blockIdx.y] / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+}  // namespace
+
+extern "C" int geossl_copy_n(const GeosslCopyBatch* batch, int n, hipStream_t stream) {
+  if (batch == nullptr || n < 0 || n > GEOSSL_COPY_MAX) return (int)hipErrorInvalidValue;
+  int64_t work = 0;
+  for (int i = 0; i < n; ++i) {
+    if ((batch->bytes[i] & 3) || (((uintptr_t)batch->dst[i] | (uintptr_t)batch->src[i]) & 3) || batch->bytes[i] < 0)
+      return (int)hipErrorInvalidValue;
+    if (batch->bytes[i] / 4 > work) work = batch->bytes[i] / 4;
+  }
+  if (n == 0 || work <= 0) return 0;
+  hipLaunchKernelGGL(k_copy_n, dim3(grid1d(work, 256, 512), n), dim3(256), 0, stream, *batch);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

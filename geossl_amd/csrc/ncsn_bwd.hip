@@ -155,7 +155,7 @@ __device__ __forceinline__ float pow2(int e) { return __builtin_amdgcn_ldexpf(1.
 constexpr int E_NONE = -100000;  // "no tile yet": the first rescale multiplies a zero accumulator by 2^-inf = 0
 
 template <int NW, bool ROLE_A>
-__device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
+__device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a, const int S, const float* __restrict__ a_h) {
   using L_t = NbLds<NW>;
   constexpr int F = L_t::F, H = L_t::H, KHS = L_t::KHS, HMB = L_t::HMB, KS = L_t::KS, NT = 128 * NW;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
@@ -163,7 +163,6 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nb = ROLE_A ? wave : wave - NW;  // this wave's 32-wide feature block
-  const int S = a.S;
   const int ntiles = (S + TR - 1) / TR;
   const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
   const int t_begin = (int)blockIdx.x * per, t_end = min(ntiles, t_begin + per);
@@ -325,8 +324,8 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int2 uv = sc[2 * crow4(r, k4)];  // .x, .y of the int4 entry
-        hu[r] = ldg_off(a.h, ((uint32_t)uv.x * (uint32_t)F + col) * 4u);
-        hv[r] = ldg_off(a.h, ((uint32_t)uv.y * (uint32_t)F + col) * 4u);
+        hu[r] = ldg_off(a_h, ((uint32_t)uv.x * (uint32_t)F + col) * 4u);
+        hv[r] = ldg_off(a_h, ((uint32_t)uv.y * (uint32_t)F + col) * 4u);
       }
     }
   };
@@ -702,15 +701,21 @@ __device__ __forceinline__ void ncsn_bwd_body(const NcsnFusedArgs& a) {
 // both sides execute the same barriers.
 template <int NW>
 __global__ __launch_bounds__(128 * NW) void k_ncsn_bwd_fused(NcsnFusedArgs a) {
-  if ((int)(threadIdx.x >> 6) < NW) ncsn_bwd_body<NW, true>(a);
-  else ncsn_bwd_body<NW, false>(a);
+  if ((int)(threadIdx.x >> 6) < NW) ncsn_bwd_body<NW, true>(a, a.S, a.h);
+  else ncsn_bwd_body<NW, false>(a, a.S, a.h);
 }
 // both heads of a DDM step in one launch: blockIdx.y = head
 template <int NW>
-__global__ __launch_bounds__(128 * NW) void k_ncsn_bwd_fused2(NcsnFusedArgs a0, NcsnFusedArgs a1) {
+__global__ __launch_bounds__(128 * NW) void k_ncsn_bwd_fused2(NcsnFusedArgs a0, NcsnFusedArgs a1,
+                                                              const int32_t* __restrict__ dyn_S,
+                                                              const int32_t* __restrict__ dyn_view) {
   const NcsnFusedArgs& a = blockIdx.y == 0 ? a0 : a1;
-  if ((int)(threadIdx.x >> 6) < NW) ncsn_bwd_body<NW, true>(a);
-  else ncsn_bwd_body<NW, false>(a);
+  // capacity launch (see k_ncsn_fwd2): real row count; head 1's features start *dyn_view rows into the shared tensor
+  const int S = dyn_count(a.S, dyn_S);
+  const float* h = a.h;
+  if (dyn_view != nullptr && blockIdx.y == 1) h += (size_t)(*dyn_view) * (32 * NW);
+  if ((int)(threadIdx.x >> 6) < NW) ncsn_bwd_body<NW, true>(a, S, h);
+  else ncsn_bwd_body<NW, false>(a, S, h);
 }
 
 // The five fixed-order reductions of the block partials (k_reduce_multi's arithmetic) and, in the blocks behind them, the
@@ -820,13 +825,22 @@ extern "C" int geossl_ddm_loss_bwd_fused(const float* h, const int64_t* sei0, co
 
 namespace geossl {
 int launch_incidence_gather2(const float* dfeat0, const float* dfeat1, const int64_t* inc_ptr, const int32_t* inc_idx,
-                             int64_t N, int F, float* dh0, float* dh1, hipStream_t stream);
+                             int64_t N, int F, float* dh0, float* dh1, hipStream_t stream, const int32_t* dyn_view);
 }
 
 extern "C" int geossl_ddm_loss_bwd_fused2(const GeosslNcsnHeadBwd* heads, const int64_t* sei0, const int64_t* sei1,
                                           int64_t S, int64_t N, int F, const int64_t* stats_divisor, const float* gout,
                                           const int64_t* inc_ptr, const int32_t* inc_idx, int accumulate,
                                           hipStream_t stream) {
+  return geossl_ddm_loss_bwd_fused2_dyn(heads, sei0, sei1, S, N, F, stats_divisor, gout, inc_ptr, inc_idx, accumulate,
+                                        nullptr, nullptr, stream);
+}
+
+extern "C" int geossl_ddm_loss_bwd_fused2_dyn(const GeosslNcsnHeadBwd* heads, const int64_t* sei0, const int64_t* sei1,
+                                              int64_t S, int64_t N, int F, const int64_t* stats_divisor,
+                                              const float* gout, const int64_t* inc_ptr, const int32_t* inc_idx,
+                                              int accumulate, const int32_t* dyn_S, const int32_t* dyn_view,
+                                              hipStream_t stream) {
   if (S <= 0) return 0;
   if (heads == nullptr || (F != 32 && F != 64 && F != 128)) return (int)hipErrorInvalidValue;
   if (S * (int64_t)F * 4 >= ((int64_t)1 << 32) || N * (int64_t)F * 4 >= ((int64_t)1 << 32)) return (int)hipErrorInvalidValue;
@@ -850,7 +864,8 @@ extern "C" int geossl_ddm_loss_bwd_fused2(const GeosslNcsnHeadBwd* heads, const 
 #define LAUNCH2(NWV)                                                                                                \
   do {                                                                                                              \
     allow_big_lds(&k_ncsn_bwd_fused2<NWV>);                                                                         \
-    hipLaunchKernelGGL((k_ncsn_bwd_fused2<NWV>), dim3(nb, 2), dim3(128 * NWV), NbLds<NWV>::bytes(), stream, a[0], a[1]); \
+    hipLaunchKernelGGL((k_ncsn_bwd_fused2<NWV>), dim3(nb, 2), dim3(128 * NWV), NbLds<NWV>::bytes(), stream, a[0], a[1], \
+                       dyn_S, dyn_view);                                                                            \
   } while (0)
   if (F == 128) LAUNCH2(4); else if (F == 64) LAUNCH2(2); else LAUNCH2(1);
 #undef LAUNCH2
@@ -873,6 +888,7 @@ extern "C" int geossl_ddm_loss_bwd_fused2(const GeosslNcsnHeadBwd* heads, const 
                      rm[1], nb, accumulate, a[0].psm, a[1].psm, F, heads[0].grads, heads[1].grads);
   GEOSSL_CHECK_LAUNCH();
   if (heads[0].dh != nullptr && heads[1].dh != nullptr)
-    return launch_incidence_gather2(heads[0].dfeat, heads[1].dfeat, inc_ptr, inc_idx, N, F, heads[0].dh, heads[1].dh, stream);
+    return launch_incidence_gather2(heads[0].dfeat, heads[1].dfeat, inc_ptr, inc_idx, N, F, heads[0].dh, heads[1].dh, stream,
+                                    dyn_view);
   return 0;
 }

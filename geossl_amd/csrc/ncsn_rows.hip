@@ -297,10 +297,15 @@ struct NcsnFwdHead {
 template <int NMB>
 __global__ __launch_bounds__(512) void k_ncsn_fwd2(NcsnFwdHead a0, NcsnFwdHead a1, const int64_t* __restrict__ batch,
                                                    const int64_t* __restrict__ sei0, const int64_t* __restrict__ sei1,
-                                                   int S) {
+                                                   int S, const int32_t* __restrict__ dyn_S,
+                                                   const int32_t* __restrict__ dyn_view) {
   const NcsnFwdHead& a = blockIdx.y == 0 ? a0 : a1;
-  ncsn_fwd_body<NMB>(a.h, batch, sei0, sei1, S, a.distance, a.noise_level, a.dist_noise, a.w, a.anneal_power, a.loss_e,
-                     a.sv, a.loss_part);
+  // capacity launch: the real number of super-edges, and (dyn_view) both heads were handed the base of ONE
+  // [view 0 ; view 1] feature tensor - head 1's rows start *dyn_view rows in
+  const float* h = a.h;
+  if (dyn_view != nullptr && blockIdx.y == 1) h += (size_t)(*dyn_view) * (32 * NMB);
+  ncsn_fwd_body<NMB>(h, batch, sei0, sei1, dyn_count(S, dyn_S), a.distance, a.noise_level, a.dist_noise, a.w,
+                     a.anneal_power, a.loss_e, a.sv, a.loss_part);
 }
 
 template <int NMB>
@@ -536,6 +541,12 @@ extern "C" int geossl_ddm_loss_fwd(const float* h, const int64_t* batch, const i
 
 extern "C" int geossl_ddm_loss_fwd2(const GeosslNcsnHeadFwd* heads, const int64_t* batch, const int64_t* sei0,
                                     const int64_t* sei1, int64_t S, int F, hipStream_t stream) {
+  return geossl_ddm_loss_fwd2_dyn(heads, batch, sei0, sei1, S, F, nullptr, nullptr, stream);
+}
+
+extern "C" int geossl_ddm_loss_fwd2_dyn(const GeosslNcsnHeadFwd* heads, const int64_t* batch, const int64_t* sei0,
+                                        const int64_t* sei1, int64_t S, int F, const int32_t* dyn_S,
+                                        const int32_t* dyn_view, hipStream_t stream) {
   if (S <= 0) return 0;
   if (heads == nullptr || (F != 32 && F != 64 && F != 128)) return (int)hipErrorInvalidValue;
   NcsnFwdHead a[2];
@@ -552,7 +563,8 @@ extern "C" int geossl_ddm_loss_fwd2(const GeosslNcsnHeadFwd* heads, const int64_
 #define LAUNCH(NMBV)                                                                                              \
   do {                                                                                                            \
     allow_big_lds(&k_ncsn_fwd2<NMBV>);                                                                            \
-    hipLaunchKernelGGL((k_ncsn_fwd2<NMBV>), grid, dim3(512), lds, stream, a[0], a[1], batch, sei0, sei1, (int)S);  \
+    hipLaunchKernelGGL((k_ncsn_fwd2<NMBV>), grid, dim3(512), lds, stream, a[0], a[1], batch, sei0, sei1, (int)S,   \
+                       dyn_S, dyn_view);                                                                          \
   } while (0)
   if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
 #undef LAUNCH

@@ -270,8 +270,8 @@ __device__ __forceinline__ void aggregate_big(const float* __restrict__ x, const
 __global__ __launch_bounds__(64, 2) void k_aggregate_reg_work(
     const float* __restrict__ x, const float* __restrict__ Wf, const uint8_t* __restrict__ pair_flag,
     const int32_t* __restrict__ mol_ptr, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ work,
-    int nwork, int F, int swap, float* __restrict__ out) {
-  if ((int)blockIdx.x >= nwork) return;
+    int nwork, int F, int swap, float* __restrict__ out, const int32_t* __restrict__ dyn_nwork) {
+  if ((int)blockIdx.x >= dyn_count(nwork, dyn_nwork)) return;
   const int wk = work[blockIdx.x];
   const int m = wk & 0x0FFFFFFF, part = __builtin_amdgcn_readfirstlane((wk >> 28) & 7);
   const int lane = threadIdx.x, f = 2 * lane < F ? 2 * lane : -2;  // -2: no channels (see k_aggregate_reg)
@@ -288,7 +288,9 @@ __global__ __launch_bounds__(64, 2) void k_aggregate_reg_work(
 
 // --------------------------------------------------------------------------------------------- embedding
 __global__ void k_embedding_fwd(const int64_t* __restrict__ z, int64_t zs, const float* __restrict__ table, int C,
-                                int64_t N, int F, float* __restrict__ out, int32_t* __restrict__ status) {
+                                int64_t N, int F, float* __restrict__ out, int32_t* __restrict__ status,
+                                const int32_t* __restrict__ dyn_N) {
+  N = dyn_count((int)N, dyn_N);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N * F; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t a = i / F;
     const int f = (int)(i - a * F);
@@ -308,8 +310,10 @@ __global__ void k_embedding_fwd(const int64_t* __restrict__ z, int64_t zs, const
 // classes [cmin, cmax] a chunk has met leave the block (QM9 uses 5 of the 119 rows of the table: a chunk's whole table
 // is 60 KB, its occupied band 4.5 KB), the band is recorded behind the partial tables for the second stage.
 __global__ void k_embedding_bwd_partial(const int64_t* __restrict__ z, int64_t zs, const float* __restrict__ dh,
-                                        int64_t N, int F, int C, float* __restrict__ partial, int2* __restrict__ band) {
+                                        int64_t N, int F, int C, float* __restrict__ partial, int2* __restrict__ band,
+                                        const int32_t* __restrict__ dyn_N) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  N = dyn_count((int)N, dyn_N);  // (chunks past the real rows leave an empty band)
   const int chunk = blockIdx.x, f = threadIdx.x;
   const int64_t per = (N + (int64_t)gridDim.x - 1) / (int64_t)gridDim.x;
   const int64_t lo = chunk * per, hi = min((int64_t)N, lo + per);
@@ -493,15 +497,23 @@ extern "C" int geossl_aggregate_parts(int n) {  // work items of an n-atom molec
   return n < AGG_K4_MIN ? 2 : 4;
 }
 
-extern "C" int geossl_cfconv_aggregate_work(const float* x, const float* Wf, const uint8_t* pair_flag,
-                                            const int32_t* mol_ptr, const int32_t* pair_ptr, const int32_t* work,
-                                            int64_t nwork, int max_n, int F, int swap, float* out, hipStream_t stream) {
+extern "C" int geossl_cfconv_aggregate_work_dyn(const float* x, const float* Wf, const uint8_t* pair_flag,
+                                                const int32_t* mol_ptr, const int32_t* pair_ptr, const int32_t* work,
+                                                int64_t nwork, int max_n, int F, int swap, float* out,
+                                                const int32_t* dyn_nwork, hipStream_t stream) {
   if (nwork <= 0) return 0;
   if (max_n > 33 || F > 128 || F <= 32) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(k_aggregate_reg_work, dim3((unsigned)nwork), dim3(64), 0, stream, x, Wf, pair_flag, mol_ptr,
-                     pair_ptr, work, (int)nwork, F, swap, out);
+                     pair_ptr, work, (int)nwork, F, swap, out, dyn_nwork);
   GEOSSL_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int geossl_cfconv_aggregate_work(const float* x, const float* Wf, const uint8_t* pair_flag,
+                                            const int32_t* mol_ptr, const int32_t* pair_ptr, const int32_t* work,
+                                            int64_t nwork, int max_n, int F, int swap, float* out, hipStream_t stream) {
+  return geossl_cfconv_aggregate_work_dyn(x, Wf, pair_flag, mol_ptr, pair_ptr, work, nwork, max_n, F, swap, out, nullptr,
+                                          stream);
 }
 
 extern "C" int geossl_cfconv_aggregate(const float* x, const float* Wf, const uint8_t* pair_flag,
@@ -557,13 +569,20 @@ extern "C" int geossl_row_normalize_bwd(const float* g, const float* y, const fl
   return 0;
 }
 
-extern "C" int geossl_embedding_fwd(const int64_t* z, int64_t z_stride, const float* table, int num_classes, int64_t N,
-                                    int F, float* out, int32_t* status, hipStream_t stream) {
+extern "C" int geossl_embedding_fwd_dyn(const int64_t* z, int64_t z_stride, const float* table, int num_classes,
+                                        int64_t N, int F, float* out, int32_t* status, const int32_t* dyn_N,
+                                        hipStream_t stream) {
   if (N <= 0) return 0;
+  if (N > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(k_embedding_fwd, dim3(grid1d(N * F, 256)), dim3(256), 0, stream, z, z_stride, table, num_classes, N,
-                     F, out, status);
+                     F, out, status, dyn_N);
   GEOSSL_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int geossl_embedding_fwd(const int64_t* z, int64_t z_stride, const float* table, int num_classes, int64_t N,
+                                    int F, float* out, int32_t* status, hipStream_t stream) {
+  return geossl_embedding_fwd_dyn(z, z_stride, table, num_classes, N, F, out, status, nullptr, stream);
 }
 
 extern "C" int64_t geossl_embedding_bwd_workspace_floats(int num_classes, int F) {
@@ -572,7 +591,14 @@ extern "C" int64_t geossl_embedding_bwd_workspace_floats(int num_classes, int F)
 
 extern "C" int geossl_embedding_bwd(const int64_t* z, int64_t z_stride, const float* dh, int num_classes, int64_t N,
                                     int F, float* dtable, float* workspace, int accumulate, hipStream_t stream) {
+  return geossl_embedding_bwd_dyn(z, z_stride, dh, num_classes, N, F, dtable, workspace, accumulate, nullptr, stream);
+}
+
+extern "C" int geossl_embedding_bwd_dyn(const int64_t* z, int64_t z_stride, const float* dh, int num_classes, int64_t N,
+                                        int F, float* dtable, float* workspace, int accumulate, const int32_t* dyn_N,
+                                        hipStream_t stream) {
   if (num_classes <= 0) return 0;
+  if (N > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
   if (F > 256 || (size_t)num_classes * F * sizeof(float) > 160 * 1024) return (int)hipErrorInvalidValue;
   int2* band = reinterpret_cast<int2*>(workspace + (size_t)GEOSSL_EMB_CHUNKS * num_classes * F);
   // chunks of at least 64 rows (a small batch: fewer chunks, a shorter list for the second stage), a multiple of 4
@@ -580,7 +606,8 @@ extern "C" int geossl_embedding_bwd(const int64_t* z, int64_t z_stride, const fl
   nchunks = nchunks < 16 ? 16 : (nchunks > GEOSSL_EMB_CHUNKS ? GEOSSL_EMB_CHUNKS : (nchunks + 3) / 4 * 4);
   allow_big_lds(&k_embedding_bwd_partial);
   hipLaunchKernelGGL(k_embedding_bwd_partial, dim3(nchunks), dim3((F + 63) / 64 * 64),
-                     (size_t)num_classes * F * sizeof(float), stream, z, z_stride, dh, N, F, num_classes, workspace, band);
+                     (size_t)num_classes * F * sizeof(float), stream, z, z_stride, dh, N, F, num_classes, workspace, band,
+                     dyn_N);
   GEOSSL_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_embedding_bwd_reduce, dim3((F + 63) / 64, num_classes), dim3(256), 0, stream, workspace, band,
                      nchunks, num_classes, F, dtable, accumulate);

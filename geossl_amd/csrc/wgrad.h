@@ -37,7 +37,9 @@ struct WgradOut {
 template <int NCM, int NCN, class Ops>
 __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chunk, int M, int N,
                                                         float* __restrict__ partial, float* __restrict__ partial_bias,
-                                                        float* __restrict__ partial_dot) {
+                                                        float* __restrict__ partial_dot,
+                                                        const int32_t* __restrict__ dyn_R) {
+  R = dyn_count(R, dyn_R);  // (row chunks past the real rows write zero partials)
   constexpr int SA = (NCM + 3) / 4, SB = (NCN + 3) / 4;  // operand blocks converted per wave: A block wave + 4u
   constexpr int T = NCM * NCN, TPW = (T + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
 // dimension dW_ld (>= N); dd is written with stride dd_stride (e.g. the last column of a [M][N+1] weight).
 template <int NCM, int NCN, class Ops>
 int launch_wgrad_split(const Ops& ops, int nprob, int64_t R, int M, int N, const WgradOut& out, int dW_ld, int dd_stride,
-                       float* workspace, int accumulate, hipStream_t stream) {
+                       float* workspace, int accumulate, hipStream_t stream, const int32_t* dyn_R = nullptr) {
   if (nprob <= 0 || R <= 0) return 0;
   if (nprob > GEOSSL_TN_MAX) return (int)hipErrorInvalidValue;
   int chunk, nblk;
@@ -248,7 +250,7 @@ int launch_wgrad_split(const Ops& ops, int nprob, int64_t R, int M, int N, const
   const size_t lds = (size_t)(NCM + NCN) * 2 * 2 * 1024 + (size_t)(NCM + NCN) * sizeof(int);
   allow_big_lds(&k_wgrad_split<NCM, NCN, Ops>);
   hipLaunchKernelGGL((k_wgrad_split<NCM, NCN, Ops>), dim3(nblk, nprob), dim3(256), lds, stream, ops, (int)R, chunk, M,
-                     N, partial, any_b ? pbias : nullptr, any_d ? pdot : nullptr);
+                     N, partial, any_b ? pbias : nullptr, any_d ? pdot : nullptr, dyn_R);
   GEOSSL_CHECK_LAUNCH();
   ReduceMulti rm;  // dW, db and dd partial sums in one launch
   rm.add(partial, M * N, N, dW_ld, 1, out.dW, nprob);

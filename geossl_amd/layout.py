@@ -84,6 +84,7 @@ class MolLayout:
         self._sizes_host = sizes
         self._loop_plan = None
         self.uniform = False
+        self.dyn = None  # bucket.DynDims when the layout belongs to a capacity bucket (device-side row counts)
 
     def loop_plan(self, max_rows=96, max_mols=None):
         """Blocks of the layer loop (geossl_schnet_layer_loop): consecutive molecules of a uniform batch in blocks of at
@@ -180,10 +181,14 @@ class SuperEdgeLayout:
             raise ValueError("super_edge_index must be grouped by molecule in batch order with both ends in "
                              "the same molecule (collated AtomTupleExtractor output is)")
         self._versions = (batch._version, sei._version)
+        self.dyn = None
 
 
 def get_super_edge_layout(batch, super_edge_index, num_graphs, validate=True):
     lay = getattr(super_edge_index, "_geossl_layout", None)
+    # (collated AtomTupleExtractor output, marked by prepare_batch: grouped by molecule by construction - no check, no sync)
+    if getattr(super_edge_index, "_geossl_grouped", None) == (batch._version, super_edge_index._version):
+        validate = False
     if (lay is None or lay._versions != (batch._version, super_edge_index._version)
             or lay.S != super_edge_index.size(1) or lay.N != batch.numel()):
         lay = SuperEdgeLayout(batch, super_edge_index, num_graphs, validate=validate)
@@ -191,13 +196,22 @@ def get_super_edge_layout(batch, super_edge_index, num_graphs, validate=True):
     return lay
 
 
-def prepare_batch(batch_vec, super_edge_index, sizes):
+def prepare_batch(batch_vec, super_edge_index, sizes, lazy=False):
     """Collation-time construction of every position-independent index structure the DDM step reads (two-view
     molecule layout, super-edge incidence lists) from HOST molecule sizes: no read-back from the device, so a
     loader that calls this for batch k+1 does not stall behind the kernels of batch k.  The structures are cached on
-    the tensors and found by the step (get_layout / pretrain_GeoSSL._two_view_batch / get_super_edge_layout)."""
+    the tensors and found by the step (get_layout / pretrain_GeoSSL._two_view_batch / get_super_edge_layout).
+
+    lazy: only leave the sizes on the tensors; the structures are built from them by the first step that asks (still
+    without a read-back).  A step that replays a capacity-bucket graph (geossl_amd/bucket.py) never asks: it writes the
+    same structures into the bucket's static buffers, so a streaming loader does not pay for both."""
     sizes = [int(n) for n in sizes]
     B = len(sizes)
+    batch_vec._geossl_sizes = (sizes, batch_vec._version)
+    if super_edge_index is not None:
+        super_edge_index._geossl_grouped = (batch_vec._version, super_edge_index._version)
+    if lazy:
+        return
     b2 = torch.cat([batch_vec, batch_vec + B])
     lay2 = MolLayout(b2, 2 * B, sizes=sizes + sizes)
     lay2.loop_plan()  # the block plan of the layer loop, now: its small upload must not fall into a graph capture

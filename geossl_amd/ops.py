@@ -162,7 +162,13 @@ def prepare_chain(weights, transB=True, both=False):
     return (out[:len(weights)], out[len(weights):]) if both else out
 
 
-def linear_chain(x, stages):
+def _dyn(layout_or_dyn, field):
+    """Device address of a bucket's real count (bucket.DynDims), or None."""
+    d = getattr(layout_or_dyn, "dyn", layout_or_dyn)
+    return None if d is None else getattr(d, field)
+
+
+def linear_chain(x, stages, dyn_rows=None):
     """Several F -> F Linear layers applied to the rows of x back to back in one launch (geossl_linear_chain).
     stages: list of dicts with `image` (from prepare_chain) and optional `bias`, `res`, `tprev`, `flags`, `store`,
     `same_input` (F = 128 only: the stage reads the input of the stage before it, not its result), `x` (F = 128 only:
@@ -198,7 +204,8 @@ def linear_chain(x, stages):
         else:
             st.xin, st.ldxin = None, 0
         outs.append(o)
-    call("geossl_linear_chain", ptr(x), x.stride(0), C.byref(ch), R, F, stream())
+    # dyn_rows: device address of the real row count when R is a capacity (bucket.DynDims; F = 128 only)
+    call("geossl_linear_chain_dyn", ptr(x), x.stride(0), C.byref(ch), R, F, dyn_rows, stream())
     return outs
 
 
@@ -247,7 +254,7 @@ def layer_loop(ops_list, layout, pair_flag, N, F, stagger=0):
     return True
 
 
-def linear_wgrad(problems, R, M, N, accumulate=False, lda=None, ldb=None, ldw=None):
+def linear_wgrad(problems, R, M, N, accumulate=False, lda=None, ldb=None, ldw=None, dyn_rows=None):
     """Batched weight gradients.  problems: list of (A [R,M], B [R,N], dW [M,N], db [M] or None); lda/ldb/ldw are
     the row strides when A / B / dW are column slices of wider tensors."""
     dev = problems[0][0].device
@@ -259,8 +266,8 @@ def linear_wgrad(problems, R, M, N, accumulate=False, lda=None, ldb=None, ldw=No
             tb.A[i], tb.B[i], tb.dW[i], tb.db[i] = ptr(A), ptr(Bm), ptr(dW), ptr(db)
         nfl = _lib.load().geossl_tn_workspace_floats(R, M, N, len(chunk))
         ws = torch.empty(nfl, dtype=torch.float32, device=dev)
-        call("geossl_linear_wgrad", C.byref(tb), len(chunk), R, M, N, lda, ldb, ldw, ptr(ws), 1 if accumulate else 0,
-             stream())
+        call("geossl_linear_wgrad_dyn", C.byref(tb), len(chunk), R, M, N, lda, ldb, ldw, ptr(ws), 1 if accumulate else 0,
+             dyn_rows, stream())
 
 
 def aggregate(x, Wf_l, pair_flag, layout, swap=False, out=None, mols=None):
@@ -272,9 +279,12 @@ def aggregate(x, Wf_l, pair_flag, layout, swap=False, out=None, mols=None):
         out = torch.empty_like(x)
     work = getattr(layout, "agg_work", None)
     if mols is None and work is not None and 32 < F <= 128:
-        call("geossl_cfconv_aggregate_work", ptr(x), ptr(Wf_l), ptr(pair_flag), ptr(layout.mol_ptr), ptr(layout.pair_ptr),
-             ptr(work), work.numel(), layout.max_n, F, 1 if swap else 0, ptr(out), stream())
+        call("geossl_cfconv_aggregate_work_dyn", ptr(x), ptr(Wf_l), ptr(pair_flag), ptr(layout.mol_ptr),
+             ptr(layout.pair_ptr), ptr(work), work.numel(), layout.max_n, F, 1 if swap else 0, ptr(out),
+             _dyn(layout, "n_work"), stream())
         return out
+    if getattr(layout, "dyn", None) is not None:
+        raise _lib.GeosslHipError("a capacity-bucket layout needs the work-list aggregation (64 or 128 features)")
     if mols is None:
         mp, pp, order, B = ptr(layout.mol_ptr), ptr(layout.pair_ptr), layout.order, layout.B
     else:
@@ -315,7 +325,7 @@ def pair_distance(pos, sei0, sei1):
     return out
 
 
-def ddm_views(pos, noise, sei0, sei1, z=None):
+def ddm_views(pos, noise, sei0, sei1, z=None, dyn=None):
     """Both views of a DDM step in one launch (pretrain_GeoSSL.py:68-74,199-205): ([pos ; pos + noise] as one [2N, 3]
     tensor, super-edge lengths of the clean view [S, 1], of the perturbed view [S, 1]); with the atom types `z` [N]
     (any stride) also [z ; z]."""
@@ -328,8 +338,9 @@ def ddm_views(pos, noise, sei0, sei1, z=None):
     if z is not None:
         assert z.dim() == 1 and z.dtype == torch.long and z.numel() == N
         z2 = torch.empty(2 * N, dtype=torch.long, device=pos.device)
-    call("geossl_ddm_views", ptr(pos), ptr(noise), ptr(sei0), ptr(sei1), N, S, ptr(pos2), ptr(d01), ptr(d02), ptr(z),
-         z.stride(0) if z is not None and N > 0 else 1, ptr(z2), stream())
+    # dyn (bucket.DynDims): N and S are capacities, the real counts are read on the device; view 1 starts at row dims[N]
+    call("geossl_ddm_views_dyn", ptr(pos), ptr(noise), ptr(sei0), ptr(sei1), N, S, ptr(pos2), ptr(d01), ptr(d02), ptr(z),
+         z.stride(0) if z is not None and N > 0 else 1, ptr(z2), _dyn(dyn, "n_atoms"), _dyn(dyn, "n_super"), stream())
     return (pos2, d01, d02) if z is None else (pos2, d01, d02, z2)
 
 

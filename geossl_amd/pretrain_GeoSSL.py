@@ -102,7 +102,11 @@ def _two_view_batch(batch_vec, num_graphs):
     cached = getattr(batch_vec, "_geossl_two_view", None)
     if cached is None or cached[2] != batch_vec._version:
         b2 = torch.cat([batch_vec, batch_vec + num_graphs])
-        lay2 = MolLayout(b2, 2 * num_graphs)
+        hs = getattr(batch_vec, "_geossl_sizes", None)  # host sizes left by layout.prepare_batch(lazy=True)
+        sizes = hs[0] if hs is not None and hs[1] == batch_vec._version and len(hs[0]) == num_graphs else None
+        lay2 = MolLayout(b2, 2 * num_graphs, sizes=None if sizes is None else sizes + sizes)
+        if sizes is not None and not torch.cuda.is_current_stream_capturing():
+            lay2.loop_plan()
         cached = (b2, lay2, batch_vec._version)
         batch_vec._geossl_two_view = cached
     return cached[0], cached[1]
@@ -156,6 +160,23 @@ def _do_ddm_eager(args, batch, model, mu, sigma, heads, noise, fuse_views, devic
     super_edge_index = batch.super_edge_index
     if args.model_3d not in ("schnet", "painn"):
         raise Exception("3D model {} not included.".format(args.model_3d))
+    bucket = getattr(batch, "_bucket", None)
+    if bucket is not None:
+        # the static batch of a capacity bucket (geossl_amd/bucket.py): tensors have the bucket's capacity, the real counts
+        # are device data (bucket.dyn); the fused batch is [view 0 | view 1 | unused] and goes to the heads whole
+        if args.model_3d != "schnet" or not fuse_views or getattr(args, "normalize", False):
+            raise _lib.GeosslHipError("capacity buckets serve the fused SchNet step")
+        pos_noise = noise.get("pos_noise")
+        if pos_noise is None:
+            pos_noise = torch.empty_like(positions).normal_(mu, sigma)
+        pos2, distance_01, distance_02, x2 = ops.ddm_views(positions, pos_noise, super_edge_index[0], super_edge_index[1],
+                                                           z=x_01, dyn=bucket.dyn)
+        _, h = model(x2, pos2, bucket.b2, return_latent=True, layout=bucket.lay2, latent_only=True)
+        from .NCSN import ddm_heads_loss
+        return ddm_heads_loss(n1, n2, batch, h, distance_02, None, distance_01,
+                              noise_level_1=noise.get("noise_level_1"), distance_noise_1=noise.get("dist_noise_1"),
+                              noise_level_2=noise.get("noise_level_2"), distance_noise_2=noise.get("dist_noise_2"),
+                              out_scale=0.5)
     if fuse_views:
         # perturb (:68-74), the concatenation of the two views and both sets of super-edge lengths (:199-205) in one
         # launch; the draw itself is perturb's (same generator, same place in the order of draws)
@@ -221,7 +242,9 @@ class Batch:
         return self._num_graphs
 
     @classmethod
-    def from_numpy(cls, d, device):
+    def from_numpy(cls, d, device, prepare=True):
+        """prepare=False: the index structures of the step are built (from the host sizes) by the first step that needs
+        them - a step that replays a capacity-bucket graph never does."""
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         rei = t(d["radius_edge_index"]) if "radius_edge_index" in d else None
         ng = int(len(d["sizes"])) if "sizes" in d else None
@@ -230,7 +253,7 @@ class Batch:
                   canonical)
         if "sizes" in d:  # collation knows the molecule sizes on the host: index structures without a device read-back
             from .layout import prepare_batch
-            prepare_batch(out.batch, out.super_edge_index, d["sizes"])
+            prepare_batch(out.batch, out.super_edge_index, d["sizes"], lazy=not prepare)
         return out
 
     def to(self, device):
@@ -265,6 +288,23 @@ def canonical_option(sizes, super_edge_index):
     return None
 
 
+_UID = [0]
+
+
+def _tensor_uid(t_):
+    """A number that identifies the tensor OBJECT for as long as it lives and is never handed out again (id() is: CPython
+    reuses the address of a freed tensor, and a streaming loader would then look like a batch that came back)."""
+    uid = t_.__dict__.get("_geossl_uid") if hasattr(t_, "__dict__") else None
+    if uid is None:
+        _UID[0] += 1
+        uid = _UID[0]
+        try:
+            t_._geossl_uid = uid
+        except AttributeError:
+            return ("id", id(t_))
+    return uid
+
+
 def structure_fingerprint(batch, model_3d="schnet"):
     """Hashable identity of everything a captured step binds besides x, positions and the noise: the batch vector,
     super_edge_index and (PaiNN) radius_edge_index with the index structures derived from them.
@@ -277,7 +317,7 @@ def structure_fingerprint(batch, model_3d="schnet"):
     * Anything else (sampled tuples, PaiNN's geometry-dependent edge list, batches built by hand) is identified by
       the tensor OBJECTS and their versions: a graph is replayed only for the very tensors it was captured on (a
       device-resident, pre-collated batch that comes back every epoch)."""
-    tag = lambda t_: None if t_ is None else (id(t_), t_._version, tuple(t_.shape))
+    tag = lambda t_: None if t_ is None else (_tensor_uid(t_), t_._version, tuple(t_.shape))
     rei = getattr(batch, "radius_edge_index", None) if model_3d == "painn" else None
     tags = (tag(batch.batch), tag(batch.super_edge_index), tag(rei))
     cached = batch.__dict__.get("_geossl_fp")
@@ -305,33 +345,83 @@ _NOISE_KEYS = ("pos_noise", "noise_level_1", "dist_noise_1", "noise_level_2", "d
 
 
 class StepGraphs:
-    """HIP graphs of forward + backward of the DDM step, one per ``structure_fingerprint``; all in ONE memory pool
-    (their activations are dead between steps, so N graphs cost the device memory of the largest plus the static
-    inputs and the loss of each).  ``fwd_bwd(batch, noise) -> loss`` is the owner's eager step; it must leave the
-    gradients in buffers that are the same for every call (the graph binds their addresses).  Least-recently-used
-    graphs are dropped beyond ``max_graphs``."""
+    """HIP graphs of forward + backward of the DDM step; all in ONE memory pool (their activations are dead between
+    steps, so N graphs cost the device memory of the largest plus the static inputs and the loss of each).
+    ``fwd_bwd(batch, noise) -> loss`` is the owner's eager step; it must leave the gradients in buffers that are the same
+    for every call (the graph binds their addresses).  Least-recently-used graphs are dropped beyond ``max_graphs``.
 
-    def __init__(self, fwd_bwd, model_3d, max_graphs=256, split=None):
+    Which graph serves a batch (``mode="auto"``):
+
+    * a batch of EQUAL-SIZED molecules, and anything a bucket cannot take (PaiNN's geometry-dependent edge list, sampled
+      tuples, batches built by hand): one graph per ``structure_fingerprint`` - the size sequence, or the tensor objects;
+      a structure that only a fingerprint identifies is captured on its SECOND sighting (a loader that never repeats one
+      never pays for a capture);
+    * every other SchNet batch - ragged molecules in shuffled order, the reference's loader (pretrain_GeoSSL.py:301) - one
+      graph per (molecules in the batch, tuple option) at a CAPACITY (``geossl_amd/bucket.py``): the graph's kernels read
+      the batch's real atom / pair-slot / super-edge counts and every index structure from device memory, so ONE graph
+      replays on any size sequence; a batch that outgrows the capacity makes a larger bucket (its graph is captured
+      again: a handful of times at the start of a run).
+
+    ``mode="structure"``: per-structure graphs only, captured at the first sighting (pre-collated, device-resident
+    batches that come back every epoch)."""
+
+    def __init__(self, fwd_bwd, model_3d, max_graphs=256, split=None, mode="auto", normalize=False, modules=None):
         # split = (fwd(batch, noise) -> loss with its autograd graph, bwd(loss)): forward and backward captured as TWO
         # graphs (same pool, same capture stream; replayed in this order) - the forward's loss is then on the device
         # before the backward runs, and the backward can run on a side stream while the host goes on (_AutogradStep)
         self.fwd_bwd, self.model_3d, self.max_graphs, self.split = fwd_bwd, model_3d, max_graphs, split
+        self.mode, self.normalize = mode, normalize
+        self.modules = modules  # (backbone, head, head): what bucket.modules_ok looks at
         self.graphs, self.pool = OrderedDict(), None
         self.enabled = True
         self.captures = 0
         self._warned = False
         self._seen = OrderedDict()
+        self.bucket_ok = True   # cleared when a bucket capture failed: per-structure graphs from then on
 
     def __len__(self):
         return len(self.graphs)
 
+    # ---- which graph
+    def bucket_key(self, batch):
+        """("bucket", molecules, option) when the batch goes through a capacity bucket, else None."""
+        from . import bucket as bk
+        if (self.mode != "auto" or not self.bucket_ok or os.environ.get("GEOSSL_NO_BUCKETS")
+                or not bk.eligible(batch, self.model_3d, self.normalize) or bk.is_uniform(batch)
+                or self.modules is None or not bk.modules_ok(*self.modules)):
+            return None
+        return ("bucket", len(batch._sizes), batch._canonical)
+
     def lookup(self, batch):
-        """The graph captured for this batch's index structure (None: not captured yet)."""
+        """The graph that serves this batch (None: not captured yet, or its bucket is too small)."""
+        key = self.bucket_key(batch)
+        if key is not None:
+            from . import bucket as bk
+            g = self.graphs.get(key)
+            if g is None:
+                return None
+            counts = bk.batch_counts(batch._sizes, batch._canonical)
+            if not g["bucket"].fits(counts):
+                return None
+            g["counts"] = counts
+            self.graphs.move_to_end(key)
+            return g
         fp = structure_fingerprint(batch, self.model_3d)
         g = self.graphs.get(fp)
         if g is not None:
             self.graphs.move_to_end(fp)
         return g
+
+    def capture_now(self, batch):
+        """Should a batch without a graph be captured at this sighting?  Buckets and equal-sized molecules: yes (their
+        graph serves every later batch of the kind); a structure known by fingerprint only: from its second sighting on
+        (mode "structure": always)."""
+        if self.mode != "auto" or self.bucket_key(batch) is not None:
+            return True
+        from . import bucket as bk
+        if bk.is_uniform(batch) and getattr(batch, "_canonical", None) is not None and self.model_3d == "schnet":
+            return True
+        return self.seen_before(batch)
 
     def seen_before(self, batch):
         """True from the second call on for one fingerprint (a bounded memory of hashes: a collision or a forgotten
@@ -344,11 +434,8 @@ class StepGraphs:
             self._seen.popitem(last=False)
         return seen
 
-    def capture(self, batch, noise):
-        """Capture fwd_bwd on clones of x / positions / the five noise tensors (the graph's static inputs); the index
-        tensors of `batch` are bound as they are (and kept alive by the entry).  None when the capture failed: the
-        owner runs eagerly from then on."""
-        fp = structure_fingerprint(batch, self.model_3d)
+    # ---- capture
+    def _evict(self):
         while len(self.graphs) >= self.max_graphs:
             if not self._warned:
                 warnings.warn("more than %d distinct batch structures: the least recently used step graphs are dropped "
@@ -356,10 +443,61 @@ class StepGraphs:
                               % self.max_graphs)
                 self._warned = True
             self.graphs.popitem(last=False)
+
+    def capture(self, batch, noise):
+        """Capture fwd_bwd on static inputs: clones of x / positions / the five noise tensors with the batch's own index
+        tensors bound as they are (per-structure graph), or the buffers of a capacity bucket filled from the batch.  None
+        when the capture failed: the owner runs eagerly (a failed bucket: per-structure graphs) from then on."""
+        key = self.bucket_key(batch)
+        if key is not None:
+            g = self._capture_bucket(key, batch, noise)
+            if g is not None or not self.enabled:
+                return g
+            key = None  # the bucket could not be captured: this batch's own structure
+        fp = structure_fingerprint(batch, self.model_3d)
+        self._evict()
         sb = Batch(batch.x.clone(), batch.positions.clone(), batch.batch, batch.super_edge_index,
                    getattr(batch, "radius_edge_index", None), batch.num_graphs, getattr(batch, "_sizes", None),
                    getattr(batch, "_canonical", None))
         sn = {k: noise[k].clone() for k in _NOISE_KEYS}
+        g = self._capture(sb, sn)
+        if g is not None:
+            self.graphs[fp] = g
+        return g
+
+    def _capture_bucket(self, key, batch, noise):
+        from . import bucket as bk
+        old = self.graphs.pop(key, None)
+        counts = bk.batch_counts(batch._sizes, batch._canonical)
+        caps = bk.capacities(*counts, B=len(batch._sizes), prev=None if old is None else old["bucket"].caps())
+        del old  # (its graph and static buffers go before the larger ones are made)
+        self._evict()
+        dev = batch.positions.device
+        try:
+            bkt = bk.Bucket(dev, len(batch._sizes), caps, batch._canonical, x_cols=batch.x.size(1))
+            bkt.fill(batch, counts)
+        except (ValueError, RuntimeError) as e:
+            warnings.warn("capacity bucket not usable for this batch (%s); per-structure graphs from now on" % e)
+            self.bucket_ok = False
+            return None
+        N, P, S, W = counts
+        B = len(batch._sizes)
+        f32 = dict(dtype=torch.float32, device=dev)
+        sn = {"pos_noise": torch.zeros(bkt.N_cap, 3, **f32), "dist_noise_1": torch.zeros(bkt.S_cap, 1, **f32),
+              "dist_noise_2": torch.zeros(bkt.S_cap, 1, **f32),
+              "noise_level_1": torch.zeros(B, dtype=torch.long, device=dev),
+              "noise_level_2": torch.zeros(B, dtype=torch.long, device=dev)}
+        g0 = dict(bucket=bkt, noise=sn, counts=counts)
+        self.copy_noise(g0, noise)
+        g = self._capture(bkt.batch, sn)
+        if g is None:
+            self.enabled, self.bucket_ok = True, False  # (eager fallback is for a failed per-structure capture)
+            return None
+        g.update(bucket=bkt, counts=counts)
+        self.graphs[key] = g
+        return g
+
+    def _capture(self, sb, sn):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up off the capture: builds the cached layouts, sets kernel attributes
@@ -393,23 +531,46 @@ class StepGraphs:
             self.enabled = False
             return None
         self.captures += 1
-        g = self.graphs[fp] = dict(graph=graph, graph_bwd=graph_bwd, batch=sb, noise=sn, loss=loss)
-        return g
+        return dict(graph=graph, graph_bwd=graph_bwd, batch=sb, noise=sn, loss=loss)
+
+    # ---- per-step refresh of a graph's static inputs
+    @staticmethod
+    def noise_views(g, batch=None):
+        """The graph's five static noise tensors at the size of THIS batch (a bucket's are capacity-sized: the real rows
+        are the leading ones) - what a caller's draws are written into."""
+        bkt = g.get("bucket")
+        if bkt is None:
+            return g["noise"]
+        N, P, S, W = g["counts"]
+        sn = g["noise"]
+        return {"pos_noise": sn["pos_noise"][:N], "dist_noise_1": sn["dist_noise_1"][:S],
+                "dist_noise_2": sn["dist_noise_2"][:S], "noise_level_1": sn["noise_level_1"],
+                "noise_level_2": sn["noise_level_2"]}
+
+    @staticmethod
+    def copy_noise(g, noise):
+        into = StepGraphs.noise_views(g)
+        for k in _NOISE_KEYS:
+            into[k].copy_(noise[k].view_as(into[k]))
 
     @staticmethod
     def refresh(g, batch, noise=None):
-        """x, positions and (if given) the five noise tensors of this step into the graph's static inputs."""
-        dx, dp, sx, sp = g["batch"].x, g["batch"].positions, batch.x, batch.positions
-        if (sx.is_cuda and sp.is_cuda and sx.dtype == dx.dtype and sp.dtype == dp.dtype and sx.shape == dx.shape
-                and sp.shape == dp.shape and all(t_.is_contiguous() for t_ in (dx, dp, sx, sp))):
-            call("geossl_copy2", ptr(dx), ptr(sx), dx.numel() * dx.element_size(), ptr(dp), ptr(sp),
-                 dp.numel() * dp.element_size(), stream())  # one launch instead of two copies
+        """x, positions and (if given) the five noise tensors of this step into the graph's static inputs; a bucket also
+        gets the batch's index structures and real counts."""
+        bkt = g.get("bucket")
+        if bkt is not None:
+            bkt.fill(batch, g["counts"])
         else:
-            dx.copy_(sx)
-            dp.copy_(sp)
+            dx, dp, sx, sp = g["batch"].x, g["batch"].positions, batch.x, batch.positions
+            if (sx.is_cuda and sp.is_cuda and sx.dtype == dx.dtype and sp.dtype == dp.dtype and sx.shape == dx.shape
+                    and sp.shape == dp.shape and all(t_.is_contiguous() for t_ in (dx, dp, sx, sp))):
+                call("geossl_copy2", ptr(dx), ptr(sx), dx.numel() * dx.element_size(), ptr(dp), ptr(sp),
+                     dp.numel() * dp.element_size(), stream())  # one launch instead of two copies
+            else:
+                dx.copy_(sx)
+                dp.copy_(sp)
         if noise is not None:
-            for k in _NOISE_KEYS:
-                g["noise"][k].copy_(noise[k])
+            StepGraphs.copy_noise(g, noise)
 
 
 _PINNED = {}  # (shape) -> ring of two pinned staging tensors with the event behind their last copy
@@ -510,6 +671,20 @@ class _ReplayedLoss(torch.autograd.Function):
         return (None, None, None) + tuple(outs)
 
 
+class _Ticket(dict):
+    """The claim of one do_DDM step on the gradients its backward replay leaves in the engine's buffer ("serial",
+    "event", "g", "used").  The replay runs on a side stream and READS the parameters: when a loss is dropped without
+    backward() (a skipped non-finite step followed by an EMA update, load_state_dict, another loss's optimizer step) the
+    caller's stream is made to wait for the replay here, so that no later parameter write can overtake it."""
+
+    def __del__(self):
+        try:
+            if not self.get("used") and self.get("event") is not None and not self["event"].query():
+                torch.cuda.current_stream().wait_event(self["event"])
+        except Exception:  # interpreter shutdown, a destroyed context: nothing left to order
+            pass
+
+
 class _AutogradStep:
     """do_DDM's graph path for a caller that owns its optimizer (the reference loop, pretrain_GeoSSL.py:249-260).
 
@@ -552,6 +727,14 @@ class _AutogradStep:
     def _signature(self):
         return tuple((id(p), p.data_ptr(), p.requires_grad) for m in (self.model, self.n1, self.n2)
                      for p in m.parameters())
+
+    # The engine hangs on the backbone module (model.__dict__) and holds graphs, streams and events: a copy or a pickle
+    # of the model (copy.deepcopy for an EMA twin, torch.save(model)) carries None instead and builds its own on first use.
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
 
     def _fwd(self, batch, noise):
         args, mu, sigma = self._cfg
@@ -606,15 +789,18 @@ class _AutogradStep:
         key = (args.model_3d, bool(getattr(args, "normalize", False)))
         sg = self.graphs.get(key)
         if sg is None:
-            sg = self.graphs[key] = StepGraphs(self._fwd_bwd, args.model_3d, split=(self._fwd, self._bwd))
+            sg = self.graphs[key] = StepGraphs(self._fwd_bwd, args.model_3d, split=(self._fwd, self._bwd),
+                                               mode=getattr(args, "step_graph_mode", "auto"), normalize=key[1],
+                                               modules=(self.model, self.n1, self.n2))
         if not sg.enabled:
             return None
         self._cfg = (Args(args.model_3d, key[1]), mu, sigma)
         g = sg.lookup(batch)
-        if g is None and not sg.seen_before(batch):
-            # first sighting of this index structure: eager.  A loader whose batches never repeat a structure (ragged
-            # molecules in shuffled order, sampled tuples, PaiNN edge lists collated anew every epoch) then never pays
-            # for a capture; a structure that comes back is captured on its second step.
+        if g is None and not sg.capture_now(batch):
+            # first sighting of an index structure that only its own graph can serve (sampled tuples, PaiNN edge lists,
+            # batches built by hand): eager - a loader that never repeats such a structure never pays for a capture, one
+            # that comes back is captured on its second step.  Ragged SchNet batches of a loader share ONE capacity-bucket
+            # graph and equal-sized molecules one per-structure graph: those are captured right away.
             return None
         main = torch.cuda.current_stream()
         if self._bwd_done is not None:
@@ -631,7 +817,7 @@ class _AutogradStep:
             sg.refresh(g, batch, drawn)
         else:
             sg.refresh(g, batch)
-            draw_step_noise(batch, self.n1, self.n2, mu, sigma, device_noise, noise, into=g["noise"])
+            draw_step_noise(batch, self.n1, self.n2, mu, sigma, device_noise, noise, into=sg.noise_views(g))
         g["graph"].replay()            # forward: the loss is on the device when this is done
         loss = g["loss"].clone()
         fwd_done = torch.cuda.Event()
@@ -642,7 +828,14 @@ class _AutogradStep:
             self._bwd_done = torch.cuda.Event()
             self._bwd_done.record(self._side)
         self._serial += 1
-        self._ticket = {"serial": self._serial, "event": self._bwd_done, "g": None}
+        self._ticket = _Ticket(serial=self._serial, event=self._bwd_done, g=None)
+        # deferred index check of the backbone: the embedding kernel flagged an out-of-range atom type in the status
+        # word, but model.forward's own arm() does nothing while a graph is captured and a replay never reaches it -
+        # read the word here like DDMTrainer.step does (IndexError up to eight steps late, like Embedding's, not never)
+        st = self.model.__dict__.get("_geossl_status")
+        if st is not None:
+            st.poll()
+            st.arm(every=8)
         return _ReplayedLoss.apply(loss, self, self._ticket, *self.params)
 
 
@@ -676,7 +869,7 @@ class DDMTrainer:
     all in one shared memory pool).  The all-reduce and the Adam launch stay outside the graph."""
 
     def __init__(self, model, ncsn_01, ncsn_02, lr=5e-4, weight_decay=0.0, mu=0.0, sigma=0.3, model_3d="schnet",
-                 device_noise=True, use_graph=False, overlap_heads=True, max_graphs=256):
+                 device_noise=True, use_graph=False, overlap_heads=True, max_graphs=256, graph_mode="auto"):
         from .optim import FlatParams, FusedAdam
         from .parallel import GradAllReduce
         self.model, self.n1, self.n2 = model, ncsn_01, ncsn_02
@@ -690,7 +883,11 @@ class DDMTrainer:
         # two-pass NCSN backward only (GEOSSL_NCSN_SPLIT_BWD): its weight-gradient kernels on a side stream, concurrent
         # with the backbone's backward; the default one-pass backward has nothing to overlap
         self.overlap_heads = overlap_heads
-        self.step_graphs = StepGraphs(self._fwd_bwd, model_3d, max_graphs)
+        # graph_mode "auto": ragged SchNet batches share one capacity-bucket graph per batch size, equal-sized molecules
+        # one graph per size, anything else one per structure from its second sighting on; "structure": one graph per
+        # structure fingerprint, captured at first sight (StepGraphs)
+        self.step_graphs = StepGraphs(self._fwd_bwd, model_3d, max_graphs, mode=graph_mode,
+                                      modules=(model, ncsn_01, ncsn_02))
         self._side = None
 
     @property
@@ -723,6 +920,8 @@ class DDMTrainer:
         g = sg.lookup(batch)
         own_noise = noise is None
         if g is None:
+            if not sg.capture_now(batch):  # a structure only its own graph can serve, seen for the first time: eager
+                return self._fwd_bwd(batch, noise)
             if own_noise:
                 noise = self._draw_noise(batch)  # this step's draws (the capture needs tensors to clone)
             g = sg.capture(batch, noise)
@@ -732,7 +931,7 @@ class DDMTrainer:
             own_noise = False  # already drawn: copied below like a caller's
         sg.refresh(g, batch, None if own_noise else noise)
         if own_noise:  # the step's own draws go straight into the graph's static inputs (no staging copies)
-            self._draw_noise(batch, into=g["noise"])
+            self._draw_noise(g["batch"], into=g["noise"])  # (g["batch"]: a bucket's draws cover its capacity)
         g["graph"].replay()
         # (a clone: the static scalar is overwritten by the next replay, and freed with its graph when that is dropped)
         return g["loss"].clone()

@@ -81,6 +81,31 @@ def make_batch(num_mols, seed=0, mode="A", option="combination", n_fixed=18, siz
     return {"x": x, "positions": positions, "batch": batch, "super_edge_index": sei, "sizes": sizes}
 
 
+_SEI_CACHE = {}
+
+
+def collate_subset(pool, mol_ids, option="combination"):
+    """The molecules `mol_ids` of the collated pool `pool` (a make_batch dict), collated in that order - what a shuffled
+    loader over a dataset of molecules hands over (dataloaders_AtomTuple.py:46-78, 81-88): same dict layout as
+    make_batch."""
+    sizes_all = np.asarray(pool["sizes"], dtype=np.int64)
+    off_all = np.concatenate([[0], np.cumsum(sizes_all)])
+    mol_ids = np.asarray(mol_ids, dtype=np.int64)
+    sizes = sizes_all[mol_ids]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    # atom rows of the chosen molecules, in order
+    rows = np.repeat(off_all[mol_ids] - off[:-1], sizes) + np.arange(int(off[-1]), dtype=np.int64)
+    se = []
+    for m, n in enumerate(sizes.tolist()):
+        key = (option, n)
+        if key not in _SEI_CACHE:
+            _SEI_CACHE[key] = combination_pairs(n) if option == "combination" else permutation_pairs(n)
+        se.append(_SEI_CACHE[key] + off[m])
+    sei = np.concatenate(se, axis=1) if se else np.empty((2, 0), np.int64)
+    return {"x": pool["x"][rows], "positions": pool["positions"][rows],
+            "batch": np.repeat(np.arange(len(sizes), dtype=np.int64), sizes), "super_edge_index": sei, "sizes": sizes}
+
+
 def draw_noise(batch, seed, num_noise_level=50, sigma=0.3, mu=0.0):
     """The three random draws of one DDM step per view pair, as explicit tensors:
     pos_noise ~ N(mu, sigma^2) [N,3]; per NCSN head noise_level ~ U{0..K-1} [B] and

@@ -484,6 +484,62 @@ int geossl_adam_step(float* param, const float* grad, float* exp_avg, float* exp
                      float beta1, float beta2, float eps, float weight_decay, int64_t step_count, float grad_scale,
                      hipStream_t stream);
 
+/* ---- Capacity launches: the `_dyn` entry points --------------------------------------------------------------------
+ * The reference's loader is DataLoaderAtomTuple(dataset, batch_size, shuffle=True) over ragged molecules
+ * (examples/pretrain_GeoSSL.py:301, Geom3D/dataloaders/dataloaders_AtomTuple.py:81-88): the atom, pair-slot and
+ * super-edge counts of a batch change every step, while a captured HIP graph fixes every launch's grid and by-value
+ * arguments.  A `_dyn` entry point is its namesake with the row count(s) ALSO readable from device memory: the by-value
+ * count is the CAPACITY (it sizes the grid, the workspaces and the layer stride of [L][P][F] tensors), `dyn_*` (nullable;
+ * NULL = the namesake's behaviour) points at an int32 holding the batch's real count, written before the launch reaches
+ * the stream.  Rows at and past the real count do not exist: never read, never written; their blocks leave zero partial
+ * sums.  Real counts must be >= 1.  The index structures a launch walks (mol_ptr, pair_ptr, work lists, incidence lists,
+ * super_edge_index) are device data anyway.  geossl_amd.pretrain_GeoSSL.StepGraphs replays ONE graph per
+ * (molecules per batch, capacity) on batches of any size sequence this way.
+ *
+ * dyn_view (the two NCSN entry points): both heads were handed the base address of ONE [view 0 ; view 1] feature /
+ * gradient tensor; head 1's rows start *dyn_view rows (the real atom count of a view) behind head 0's.            */
+#define GEOSSL_COPY_MAX 8
+typedef struct GeosslCopyBatch {
+  void* dst[GEOSSL_COPY_MAX];
+  const void* src[GEOSSL_COPY_MAX];
+  int64_t bytes[GEOSSL_COPY_MAX]; /* multiples of 4; buffers 4-byte aligned */
+} GeosslCopyBatch;
+/* batch.to(device) into the static inputs of a replayed graph (:248): n <= GEOSSL_COPY_MAX device copies, one launch */
+int geossl_copy_n(const GeosslCopyBatch* batch, int n, hipStream_t stream);
+/* perturb + both views + both super-edge length sets (:68-74,199-205); view 1 starts at row *dyn_N of pos2 / z2 */
+int geossl_ddm_views_dyn(const float* pos, const float* noise, const int64_t* sei0, const int64_t* sei1, int64_t N,
+                         int64_t S, float* pos2, float* d01, float* d02, const int64_t* z, int64_t z_stride, int64_t* z2,
+                         const int32_t* dyn_N, const int32_t* dyn_S, hipStream_t stream);
+int geossl_embedding_fwd_dyn(const int64_t* z, int64_t z_stride, const float* table, int num_classes, int64_t N, int F,
+                             float* out, int32_t* status, const int32_t* dyn_N, hipStream_t stream);
+int geossl_embedding_bwd_dyn(const int64_t* z, int64_t z_stride, const float* dh, int num_classes, int64_t N, int F,
+                             float* dtable, float* workspace, int accumulate, const int32_t* dyn_N, hipStream_t stream);
+int geossl_cfconv_filter_fwd_dyn(const float* pair_d, const float* pair_c, int64_t P, const GeosslFilterWeights* w, int L,
+                                 int F, int G, const float* offset, float coeff, float* T, float* Wf,
+                                 const int32_t* dyn_P, hipStream_t stream);
+int geossl_cfconv_filter_bwd_dyn(const float* pair_d, const float* pair_c, const uint8_t* pair_flag,
+                                 const int32_t* pair_i, const int32_t* pair_j, int64_t P, int64_t N,
+                                 const GeosslFilterWeights* w, const GeosslFilterGradIn* g, int L, int F, int G,
+                                 const float* offset, float coeff, const float* T, const GeosslFilterGradOut* out,
+                                 float* workspace, int accumulate, const int32_t* dyn_P, const int32_t* dyn_N,
+                                 hipStream_t stream);
+/* work items [0, *dyn_nwork) of the list */
+int geossl_cfconv_aggregate_work_dyn(const float* x, const float* Wf, const uint8_t* pair_flag, const int32_t* mol_ptr,
+                                     const int32_t* pair_ptr, const int32_t* work, int64_t nwork, int max_n, int F,
+                                     int swap, float* out, const int32_t* dyn_nwork, hipStream_t stream);
+/* F = 128 (the weight-stationary chain kernel) only */
+int geossl_linear_chain_dyn(const float* X, int ldx, const GeosslChain* chain, int64_t R, int F, const int32_t* dyn_R,
+                            hipStream_t stream);
+int geossl_linear_wgrad_dyn(const GeosslTnBatch* batch, int nprob, int64_t R, int M, int N, int lda, int ldb, int ldw,
+                            float* workspace, int accumulate, const int32_t* dyn_R, hipStream_t stream);
+int geossl_ddm_loss_fwd2_dyn(const GeosslNcsnHeadFwd* heads, const int64_t* batch, const int64_t* sei0,
+                             const int64_t* sei1, int64_t S, int F, const int32_t* dyn_S, const int32_t* dyn_view,
+                             hipStream_t stream);
+int geossl_ddm_loss_bwd_fused2_dyn(const GeosslNcsnHeadBwd* heads, const int64_t* sei0, const int64_t* sei1, int64_t S,
+                                   int64_t N, int F, const int64_t* stats_divisor, const float* gout,
+                                   const int64_t* inc_ptr, const int32_t* inc_idx, int accumulate, const int32_t* dyn_S,
+                                   const int32_t* dyn_view, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

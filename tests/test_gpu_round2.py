@@ -232,13 +232,17 @@ def test_reference_loader_surface_feeds_the_ddm_step():
     (batch,) = list(loader)
     batch = batch.to(DEV)
     assert batch.batch.is_cuda and torch.equal(batch.super_edge_index.cpu(), t(g["super_edge_index"]))
-    assert getattr(batch.batch, "_geossl_two_view", None) is not None  # index structures built at .to(), from host sizes
+    # .to() leaves the collation's host sizes on the tensors; the index structures are built from them (no device
+    # read-back) by the first step that needs them - a step that replays a capacity-bucket graph never does
+    assert batch.batch._geossl_sizes[0] == sizes and getattr(batch.batch, "_geossl_two_view", None) is None
     cfg = cfg_of(g)
     model = product_schnet(cfg, DEV)
     n1, n2 = product_ncsn(32, 50, 2, DEV), product_ncsn(32, 50, 2, DEV, scale=0.9)
     noise = {k: t(g[k], DEV) for k in NOISE_KEYS}
     loss, _ = pg.do_DDM(pg.Args("schnet"), batch, model, None, 0.0, 0.3, NCSN_models=(n1, n2), noise=noise)
     assert rel_err(loss.detach().cpu(), g["loss"]) < TOL_OUT
+    lay2 = batch.batch._geossl_two_view[1]
+    assert lay2._sizes_host == sizes + sizes                          # built from the host sizes
 
 
 @pytest.mark.parametrize("option", ["combination", "permutation"])

@@ -133,7 +133,8 @@ def test_trainer_graphs_follow_the_batch_structure_not_a_callers_key():
     losses, n_graphs = {}, None
     for use_graph in (False, True):
         tr = pg.DDMTrainer(product_schnet(SMALL, DEV), product_ncsn(128, 50, 2, DEV),
-                           product_ncsn(128, 50, 2, DEV, scale=0.9), lr=5e-4, use_graph=use_graph)
+                           product_ncsn(128, 50, 2, DEV, scale=0.9), lr=5e-4, use_graph=use_graph,
+                           graph_mode="structure")  # (the default mode serves ragged batches from ONE bucket graph)
         out = []
         for step in range(8):
             b = raw[step % 4]
@@ -157,7 +158,8 @@ def test_trainer_graph_cache_is_lru_and_losses_survive_eviction():
 
     def run(use_graph):
         tr = pg.DDMTrainer(product_schnet(SMALL, DEV), product_ncsn(128, 50, 2, DEV),
-                           product_ncsn(128, 50, 2, DEV, scale=0.9), lr=5e-4, use_graph=use_graph, max_graphs=2)
+                           product_ncsn(128, 50, 2, DEV, scale=0.9), lr=5e-4, use_graph=use_graph, max_graphs=2,
+                           graph_mode="structure")
         kept = []
         for step in range(7):
             b = raw[step % 3]
@@ -179,37 +181,42 @@ def _free_port():
 
 
 def test_bench_two_ranks_share_one_gpu(tmp_path):
-    """bench.py's own N > 1 branch (init_distributed, per-rank molecules and noise streams, barrier + max-over-ranks
-    timing, all-reduce + Adam, the JSON line of rank 0) as the driver launches it, with two ranks on the one GPU of the
-    box over gloo (fresh child processes; nothing that touched the GPU is re-executed)."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2",
-               GEOSSL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", GEOSSL_BENCH_RANK_LOSS=str(tmp_path))
+    """`python bench.py --gpus 2` with no launcher around it - the command shape the driver uses: the parent (which never
+    touches the GPU) starts two fresh ranks itself; they run bench.py's N > 1 branch (init_distributed, per-rank
+    molecules and noise streams, barrier + max-over-ranks timing, all-reduce + Adam, the JSON line of rank 0) on the one
+    GPU of the box over gloo."""
+    env = dict(os.environ, GEOSSL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", GEOSSL_BENCH_RANK_LOSS=str(tmp_path))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--no-cpu-baseline", "--mols", "256"]
-    logs = [open(tmp_path / ("rank%d.log" % r), "w") for r in range(2)]
-    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=logs[r],
-                              stderr=subprocess.STDOUT, cwd=REPO) for r in range(2)]
-    try:
-        codes = [p.wait(timeout=300) for p in procs]
-    except subprocess.TimeoutExpired:
-        codes = None
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-                p.wait()
-        for f in logs:
-            f.close()
-    texts = [open(tmp_path / ("rank%d.log" % r)).read() for r in range(2)]
-    assert codes == [0, 0], "\n".join(x[-1500:] for x in texts)
-    lines = [ln for ln in texts[0].splitlines() if ln.startswith("{")]
-    assert len(lines) == 1 and not any(ln.startswith("{") for ln in texts[1].splitlines())
+    with open(tmp_path / "out.log", "w") as fo, open(tmp_path / "err.log", "w") as fe:
+        p = subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe, cwd=REPO)
+        try:
+            code = p.wait(timeout=300)
+        except subprocess.TimeoutExpired:
+            code = None
+            p.kill()
+            p.wait()
+    out_text, err_text = open(tmp_path / "out.log").read(), open(tmp_path / "err.log").read()
+    assert code == 0, out_text[-1500:] + "\n" + err_text[-1500:]
+    lines = [ln for ln in out_text.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not any(ln.startswith("{") for ln in err_text.splitlines())
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["backend"] == "gloo" and out["config"]["world_size_initialised"] == 2
     assert np.isfinite(out["value"]) and out["value"] > 0 and out["cpu_baseline"] is None
     assert abs(out["value"] - 2 * 256 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
     l0, l1 = (float(open(tmp_path / ("loss_rank%d.txt" % r)).read()) for r in range(2))
     assert np.isfinite(l0) and np.isfinite(l1) and l0 != l1      # each rank has its own molecules and noise stream
+
+
+def test_bench_gpus_flag_must_match_the_launched_world(tmp_path):
+    """--gpus N under a launcher that started another number of ranks fails loudly instead of printing n_gpus: 1."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, cwd=REPO, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
 
 
 # --------------------------------------------------------------------------- PaiNN interaction on the matrix pipe

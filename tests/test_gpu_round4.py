@@ -1,0 +1,423 @@
+"""GPU tests added in round 4: capacity-bucket step graphs (ONE graph replayed on batches of any size sequence), the
+`_dyn` entry points behind them through the C ABI, the headline shape against the oracle through the replayed trainer
+path, the deferred atom-type check on do_DDM's graph path."""
+import ctypes as C
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from helpers import ncsn_oracle_params, product_ncsn, product_schnet, schnet_oracle_params, t, unique_named_grads
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FULL = dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=5.0, node_class=9,
+            readout="mean")
+SMALL = dict(hidden_channels=128, num_filters=128, num_interactions=2, num_gaussians=51, cutoff=5.0, node_class=9,
+             readout="mean")
+TOL_OUT, TOL_GRAD = 1e-5, 1e-4
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded():
+    from geossl_amd import _lib
+    _lib.load()
+
+
+def _ragged_sizes(B, seed, lo=2, hi=33):
+    rng = np.random.default_rng(seed)
+    return np.clip(np.rint(rng.normal(18.0, 4.0, size=B)), lo, hi).astype(np.int64)
+
+
+def _trainer(cfg=SMALL, **kw):
+    from geossl_amd import pretrain_GeoSSL as pg
+    return pg.DDMTrainer(product_schnet(cfg, DEV), product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9),
+                         lr=5e-4, **kw)
+
+
+def _bucket_of(tr):
+    keys = [k for k in tr._graphs if isinstance(k, tuple) and k and k[0] == "bucket"]
+    assert len(keys) == 1, list(tr._graphs)
+    return tr._graphs[keys[0]]["bucket"]
+
+
+# ------------------------------------------------------------------------------------------------ bucket graphs
+def test_one_graph_replays_on_every_size_sequence_bit_for_bit():
+    """The reference's loader hands over ragged molecules in shuffled order (pretrain_GeoSSL.py:301): no two batches share
+    a size sequence.  DDMTrainer(use_graph=True) serves them all from ONE captured graph (a capacity bucket: the kernels
+    read the real counts and every index structure from device memory).  Five batches with five size sequences - different
+    atom, pair-slot and super-edge counts, single-atom molecules among them: one capture, losses and parameters
+    bit-identical to the SAME launches made eagerly on the same bucket, and equal to the plain eager step on the batch
+    itself within fp32 summation order."""
+    from geossl_amd import bucket as bk
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    B = 24
+    specs = [_ragged_sizes(B, 10 + i) for i in range(5)]
+    specs[2][3] = 1                       # a molecule without pairs in the middle of a batch
+    specs[3][-1] = 1                      # ... and at the end (NCSN.py:210-212: the mean's divisor drops to B - 1)
+    # (the batch with the most pair slots first: at 24 molecules per batch the counts spread by a third, more than the
+    # slack of a first capture - growth is the next test's subject)
+    specs.sort(key=lambda s: -int((s * (s - 1) // 2).sum()))
+    raw = [make_batch(B, seed=200 + i, sizes=s) for i, s in enumerate(specs)]
+    assert len({tuple(s) for s in map(tuple, specs)}) == 5
+    assert len({b["x"].shape[0] for b in raw}) > 1 and len({b["super_edge_index"].shape[1] for b in raw}) > 1
+    noise = [{k: t(v, DEV) for k, v in draw_noise(b, seed=300 + i).items()} for i, b in enumerate(raw)]
+
+    tr = _trainer(use_graph=True)
+    got = [float(tr.step(pg.Batch.from_numpy(b, DEV), nz)) for b, nz in zip(raw, noise)]
+    assert tr.use_graph and tr.step_graphs.captures == 1 and len(tr._graphs) == 1
+    bkt = _bucket_of(tr)
+    params_graph = tr.flat.flat.clone()
+
+    # the same launches, eagerly: a bucket of the same capacity, filled batch by batch
+    te = _trainer(use_graph=False)
+    eb = bk.Bucket(torch.device(DEV), B, bkt.caps(), "combination")
+    f32 = dict(dtype=torch.float32, device=DEV)
+    sn = {"pos_noise": torch.zeros(eb.N_cap, 3, **f32), "dist_noise_1": torch.zeros(eb.S_cap, 1, **f32),
+          "dist_noise_2": torch.zeros(eb.S_cap, 1, **f32), "noise_level_1": torch.zeros(B, dtype=torch.long, device=DEV),
+          "noise_level_2": torch.zeros(B, dtype=torch.long, device=DEV)}
+    eager_bucket = []
+    for b, nz in zip(raw, noise):
+        N, P, S, W = eb.fill(pg.Batch.from_numpy(b, DEV))
+        sn["pos_noise"][:N].copy_(nz["pos_noise"])
+        sn["dist_noise_1"][:S].copy_(nz["dist_noise_1"])
+        sn["dist_noise_2"][:S].copy_(nz["dist_noise_2"])
+        sn["noise_level_1"].copy_(nz["noise_level_1"])
+        sn["noise_level_2"].copy_(nz["noise_level_2"])
+        loss = te._fwd_bwd(eb.batch, sn)
+        te.opt.step(grad_scale=te.reduce())
+        eager_bucket.append(float(loss))
+    assert got == eager_bucket, (got, eager_bucket)
+    assert torch.equal(params_graph, te.flat.flat)
+
+    # the plain eager step on the batch itself (exact shapes, per-batch index structures)
+    tp = _trainer(use_graph=False)
+    plain = [float(tp.step(pg.Batch.from_numpy(b, DEV), nz)) for b, nz in zip(raw, noise)]
+    for a, c in zip(got, plain):
+        assert abs(a - c) <= 2e-6 * abs(c), (got, plain)
+    assert rel_err(params_graph, tp.flat.flat) < 1e-5
+
+
+def test_bucket_grows_when_a_batch_outgrows_it_and_keeps_one_graph():
+    """A batch larger than the bucket's capacity (small molecules first, then large ones) makes a larger bucket and a new
+    capture; the smaller batches that follow replay the larger graph.  Losses as the plain eager trainer computes them."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    B = 16
+    specs = [np.full(B, 6), _ragged_sizes(B, 3), np.full(B, 30), _ragged_sizes(B, 4), np.full(B, 6)]
+    specs[0][0], specs[2][0], specs[4][1] = 7, 29, 5      # (not uniform: uniform batches keep their per-structure graph)
+    raw = [make_batch(B, seed=400 + i, sizes=s) for i, s in enumerate(specs)]
+    noise = [{k: t(v, DEV) for k, v in draw_noise(b, seed=500 + i).items()} for i, b in enumerate(raw)]
+    tr, tp = _trainer(use_graph=True), _trainer(use_graph=False)
+    caps = []
+    for b, nz in zip(raw, noise):
+        a = float(tr.step(pg.Batch.from_numpy(b, DEV), nz))
+        c = float(tp.step(pg.Batch.from_numpy(b, DEV), nz))
+        assert abs(a - c) <= 2e-6 * abs(c), (a, c)
+        caps.append(_bucket_of(tr).caps())
+    assert len(tr._graphs) == 1 and tr.step_graphs.captures == 3          # 6-atom, ragged, 30-atom molecules
+    assert caps[0] != caps[1] != caps[2] and caps[2] == caps[3] == caps[4]
+    assert rel_err(tr.flat.flat, tp.flat.flat) < 1e-5
+
+
+def test_trainer_draws_its_own_noise_into_a_bucket():
+    """noise=None: the trainer's one-launch draws (geossl_ddm_noise) fill the bucket's capacity-sized noise buffers - the
+    value of an element depends on the seed and its index only, so the step sees the draws of the exact-sized launch."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import make_batch
+    B = 12
+    raw = [make_batch(B, seed=600 + i, sizes=_ragged_sizes(B, 60 + i)) for i in range(3)]
+    out = {}
+    for use_graph in (False, True):
+        torch.cuda.manual_seed(99)
+        tr = _trainer(use_graph=use_graph)
+        out[use_graph] = [float(tr.step(pg.Batch.from_numpy(b, DEV), None)) for b in raw]
+        if use_graph:
+            assert tr.step_graphs.captures == 1
+    for a, c in zip(out[True], out[False]):
+        assert np.isfinite(a) and abs(a - c) <= 2e-6 * abs(c), out
+
+
+def test_reference_loop_on_a_shuffled_ragged_loader_captures_once():
+    """examples/pretrain_GeoSSL.py:248-260 on the product modules over the reference's own loader surface
+    (AtomTupleExtractor transform, DataLoaderAtomTuple(shuffle=True), batch.to(device)) with ragged molecules: every batch
+    has its own size sequence, do_DDM captures ONE pair of graphs (forward, backward) at the first step and replays it
+    from then on; the draws are the eager loop's (same generators, same order, same sizes), so losses and parameters
+    follow the eager loop within fp32 summation order."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.Geom3D.dataloaders import AtomTupleExtractor, Data, DataLoaderAtomTuple
+    from geossl_amd.synthetic import make_batch
+    sizes = _ragged_sizes(96, 7)
+    b = make_batch(96, seed=77, sizes=sizes)
+    ext = AtomTupleExtractor(ratio=1, option="combination")
+    off, dataset = 0, []
+    for n in sizes.tolist():
+        dataset.append(ext(Data(x=torch.from_numpy(b["x"][off:off + n]), positions=torch.from_numpy(b["positions"][off:off + n]))))
+        off += n
+    out = {}
+    for graph in (False, True):
+        torch.manual_seed(5)
+        torch.cuda.manual_seed(5)
+        model = product_schnet(SMALL, DEV)
+        n1, n2 = product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9)
+        pg.NCSN_model_01, pg.NCSN_model_02 = n1, n2
+        args = types.SimpleNamespace(model_3d="schnet", GeoSSL_mu=0.0, GeoSSL_sigma=0.3, lr=5e-4, decay=0.0, step_graph=graph)
+        group = [{"params": model.parameters(), "lr": args.lr}, {"params": n1.parameters()}, {"params": n2.parameters()}]
+        optimizer = torch.optim.Adam(group, lr=args.lr, weight_decay=args.decay)
+        gen = torch.Generator()
+        gen.manual_seed(1)
+        loader = DataLoaderAtomTuple(dataset, batch_size=16, shuffle=True, generator=gen)
+        losses, seqs = [], set()
+        try:
+            for epoch in range(2):
+                for batch in loader:
+                    batch = batch.to(DEV)
+                    seqs.add(tuple(batch._sizes))
+                    loss, acc = pg.do_DDM(args, batch, model, criterion=None, mu=args.GeoSSL_mu, sigma=args.GeoSSL_sigma)
+                    losses.append(loss.detach().item())
+                    optimizer.zero_grad()
+                    loss.backward()
+                    optimizer.step()
+        finally:
+            pg.NCSN_model_01 = pg.NCSN_model_02 = None
+        assert len(seqs) == len(losses) == 12
+        eng = model.__dict__.get("_geossl_autograd_step")
+        caps = sum(sg.captures for sg in eng.graphs.values()) if eng is not None else 0
+        out[graph] = (losses, torch.cat([p.detach().reshape(-1) for m in (model, n1, n2) for p in m.parameters()]).cpu(), caps)
+    assert out[False][2] == 0 and 1 <= out[True][2] <= 2, out[True][2]       # (a second capture only if the bucket grew)
+    for a, c in zip(out[True][0], out[False][0]):
+        assert abs(a - c) <= 5e-6 * abs(c), (out[True][0], out[False][0])
+    assert rel_err(out[True][1], out[False][1]) < 1e-4
+
+
+def test_out_of_range_atom_type_is_reported_on_do_ddms_graph_path():
+    """the reference raises IndexError from Embedding for an atom type outside the table; a replayed
+    step never reaches model.forward's own check.  do_DDM polls the status word behind its replays like DDMTrainer.step:
+    the error surfaces a few steps late instead of never."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import make_batch
+    model = product_schnet(SMALL, DEV)
+    heads = (product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9))
+    args = pg.Args("schnet")
+    b = make_batch(8, seed=3)
+    good = pg.Batch.from_numpy(b, DEV)
+    for _ in range(3):
+        loss, _ = pg.do_DDM(args, good, model, NCSN_models=heads, graph=True)
+        loss.backward()
+    eng = model.__dict__["_geossl_autograd_step"]
+    assert sum(sg.captures for sg in eng.graphs.values()) == 1
+    b["x"][5, 0] = 17
+    bad = pg.Batch.from_numpy(b, DEV)
+    with pytest.raises(IndexError):
+        for _ in range(40):
+            loss, _ = pg.do_DDM(args, bad, model, NCSN_models=heads, graph=True)
+            loss.backward()
+            torch.cuda.synchronize()
+
+
+def test_engine_on_the_module_survives_deepcopy_and_pickle():
+    """the graph engine and the status word hang on the backbone's __dict__; copy.deepcopy (an EMA twin)
+    and pickling the module must not trip over their streams / events / graphs."""
+    import copy
+    import io
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import make_batch
+    model = product_schnet(SMALL, DEV)
+    heads = (product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9))
+    batch = pg.Batch.from_numpy(make_batch(8, seed=3), DEV)
+    loss, _ = pg.do_DDM(pg.Args("schnet"), batch, model, NCSN_models=heads, graph=True)
+    loss.backward()
+    assert model.__dict__.get("_geossl_autograd_step") is not None
+    twin = copy.deepcopy(model)
+    assert twin.__dict__.get("_geossl_autograd_step") is None
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    l2, _ = pg.do_DDM(pg.Args("schnet"), batch, twin, NCSN_models=heads, graph=True)
+    assert torch.isfinite(l2)
+
+
+def test_paired_heads_refuse_shared_parameters():
+    """the same head passed twice must not take the paired launches (two blocks of one launch would add
+    into the same gradient addresses): it takes the two single-head calls and gives their sum."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    b = make_batch(6, seed=9)
+    batch = pg.Batch.from_numpy(b, DEV)
+    nz = {k: t(v, DEV) for k, v in draw_noise(b, seed=10).items()}
+    model, n1 = product_schnet(SMALL, DEV), product_ncsn(128, 50, 2, DEV)
+    n1b = product_ncsn(128, 50, 2, DEV)
+    la, _ = pg.do_DDM(pg.Args("schnet"), batch, model, NCSN_models=(n1, n1), noise=nz, graph=False)
+    la.backward()
+    ga = n1.output_mlp.layers[0].weight.grad.clone()
+    model.zero_grad()
+    lb, _ = pg.do_DDM(pg.Args("schnet"), batch, model, NCSN_models=(n1b, product_ncsn(128, 50, 2, DEV)), noise=nz, graph=False)
+    lb.backward()
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb))
+    assert torch.isfinite(ga).all() and float(ga.abs().max()) > 0
+
+
+# ------------------------------------------------------------------------------------- the headline shape, pinned
+def test_headline_shape_through_the_replayed_trainer_vs_oracle():
+    """1024 molecules of set A with injected noise through DDMTrainer(use_graph=True) - the 512-block
+    layer loop, the paired heads and the graph replay are all on - against oracle.nets.do_ddm_schnet: loss <= 1e-5,
+    backbone gradients <= 1e-4; and the replay is the eager launch bit for bit at this size."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    from oracle import nets
+    b = make_batch(1024, seed=0, mode="A")
+    nz = draw_noise(b, seed=1)
+    batch = pg.Batch.from_numpy(b, DEV)
+    noise = {k: t(v, DEV) for k, v in nz.items()}
+    res = {}
+    for use_graph in (True, False):
+        tr = _trainer(FULL, use_graph=use_graph)
+        loss = tr._graph_fwd_bwd(batch, noise) if use_graph else tr._fwd_bwd(batch, noise)   # (no Adam: gradients stay)
+        if use_graph:
+            assert tr.use_graph and tr.step_graphs.captures == 1
+        res[use_graph] = (loss.clone(), tr.flat.grad.clone(), tr)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    Pm, P1, P2 = schnet_oracle_params(FULL), ncsn_oracle_params(128, 50), ncsn_oracle_params(128, 50, 0.9)
+    ref = nets.do_ddm_schnet(Pm, P1, P2, t(b["x"]), t(b["positions"]), t(b["batch"]), t(b["super_edge_index"]),
+                             t(nz["pos_noise"]), t(nz["noise_level_1"]), t(nz["dist_noise_1"]), t(nz["noise_level_2"]),
+                             t(nz["dist_noise_2"]), 5.0, 6, 2, "mean")
+    ref.backward()
+    assert rel_err(res[True][0].cpu(), ref.detach()) < TOL_OUT
+    g = unique_named_grads(res[True][2].model)
+    for k in ("lin2.weight", "lin1.weight", "interactions.0.mlp.0.weight", "interactions.3.mlp.2.weight",
+              "interactions.5.conv.lin1.weight", "interactions.2.conv.lin2.weight", "interactions.4.lin.weight",
+              "embedding.weight"):
+        assert rel_err(g[k].cpu(), Pm[k].grad) < TOL_GRAD, k
+
+
+def test_ragged_full_size_through_the_bucket_graph_vs_oracle():
+    """Set B (ragged, 2..33 atoms) at the bench size through the bucket graph of DDMTrainer against the oracle:
+    loss <= 1e-5, backbone gradients <= 1e-4 (512 molecules: the oracle's step stays within seconds)."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    from oracle import nets
+    b = make_batch(512, seed=5, mode="B")
+    nz = draw_noise(b, seed=6)
+    batch = pg.Batch.from_numpy(b, DEV)
+    noise = {k: t(v, DEV) for k, v in nz.items()}
+    tr = _trainer(FULL, use_graph=True)
+    loss = tr._graph_fwd_bwd(batch, noise)
+    assert tr.use_graph and tr.step_graphs.captures == 1 and _bucket_of(tr) is not None
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    Pm, P1, P2 = schnet_oracle_params(FULL), ncsn_oracle_params(128, 50), ncsn_oracle_params(128, 50, 0.9)
+    ref = nets.do_ddm_schnet(Pm, P1, P2, t(b["x"]), t(b["positions"]), t(b["batch"]), t(b["super_edge_index"]),
+                             t(nz["pos_noise"]), t(nz["noise_level_1"]), t(nz["dist_noise_1"]), t(nz["noise_level_2"]),
+                             t(nz["dist_noise_2"]), 5.0, 6, 2, "mean")
+    ref.backward()
+    assert rel_err(loss.cpu(), ref.detach()) < TOL_OUT
+    g = unique_named_grads(tr.model)
+    for k in ("lin2.weight", "interactions.0.mlp.0.weight", "interactions.5.conv.lin1.weight",
+              "interactions.2.conv.lin2.weight", "embedding.weight"):
+        assert rel_err(g[k].cpu(), Pm[k].grad) < TOL_GRAD, k
+
+
+# ------------------------------------------------------------------------------- `_dyn` entry points, C ABI level
+def _dims(*vals):
+    return torch.tensor(list(vals), dtype=torch.int32, device=DEV)
+
+
+def test_filter_forward_with_a_device_side_row_count():
+    """geossl_cfconv_filter_fwd_dyn: grid and layer stride from the capacity, rows from device memory - the real rows are
+    the plain launch's bit for bit, rows past the count are never written."""
+    from geossl_amd import _lib
+    L, F, G, P, Pc = 3, 128, 51, 1000, 1408
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, device=DEV, generator=gen) * sc).contiguous()
+    d, c = torch.rand(Pc, device=DEV, generator=gen) * 5.0, torch.rand(Pc, device=DEV, generator=gen)
+    w = [(rnd(F, G, sc=0.2), rnd(F, sc=0.1), rnd(F, F, sc=0.1), rnd(F, sc=0.1)) for _ in range(L)]
+    fw = _lib.FilterWeights()
+    for l, (a, b1, a2, b2) in enumerate(w):
+        fw.w1[l], fw.b1[l], fw.w2[l], fw.b2[l] = a.data_ptr(), b1.data_ptr(), a2.data_ptr(), b2.data_ptr()
+    offset = torch.linspace(0.0, 5.0, G, device=DEV)
+    coeff = -0.5 / float(offset[1] - offset[0]) ** 2
+    T0, W0 = torch.empty(L, P, F, device=DEV), torch.empty(L, P, F, device=DEV)
+    _lib.call("geossl_cfconv_filter_fwd", d.data_ptr(), c.data_ptr(), P, C.byref(fw), L, F, G, offset.data_ptr(), coeff,
+              T0.data_ptr(), W0.data_ptr(), _lib.stream())
+    T1, W1 = torch.full((L, Pc, F), 7.0, device=DEV), torch.full((L, Pc, F), 7.0, device=DEV)
+    dims = _dims(P)
+    _lib.call("geossl_cfconv_filter_fwd_dyn", d.data_ptr(), c.data_ptr(), Pc, C.byref(fw), L, F, G, offset.data_ptr(), coeff,
+              T1.data_ptr(), W1.data_ptr(), dims.data_ptr(), _lib.stream())
+    assert torch.equal(T1[:, :P], T0) and torch.equal(W1[:, :P], W0)
+    assert bool((T1[:, P:] == 7.0).all()) and bool((W1[:, P:] == 7.0).all())
+
+
+def test_row_kernels_with_a_device_side_row_count():
+    """geossl_linear_chain_dyn / geossl_linear_wgrad_dyn / geossl_embedding_{fwd,bwd}_dyn: the rows below the device-side
+    count are computed as by the plain launch over exactly those rows (chain, embedding: bit for bit; the reductions over
+    rows: the same sums cut at other block boundaries), the rows past it are neither read (NaN there) nor written."""
+    from geossl_amd import _lib, ops
+    F, R, Rc = 128, 700, 1024
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, device=DEV, generator=gen) * sc).contiguous()
+    X, W, bias = rnd(Rc, F), rnd(F, F, sc=0.1), rnd(F, sc=0.1)
+    X[R:] = float("nan")
+    dims = _dims(R)
+    img = ops.prepare_chain([W], transB=True)
+    y0 = ops.linear_chain(X[:R], [dict(image=img[0], bias=bias, flags=_lib.EPI_SSP)])[0]
+    out = torch.full((Rc, F), 7.0, device=DEV)
+    ops.linear_chain(X, [dict(image=img[0], bias=bias, flags=_lib.EPI_SSP, out=out)], dyn_rows=dims.data_ptr())
+    assert torch.equal(out[:R], y0) and bool((out[R:] == 7.0).all())
+    # weight gradient: dW = A^T B over the real rows
+    A, Bm = rnd(Rc, F), rnd(Rc, F)
+    A[R:], Bm[R:] = float("nan"), float("nan")
+    dW0, db0, dW1, db1 = (torch.empty(F, F, device=DEV), torch.empty(F, device=DEV), torch.empty(F, F, device=DEV),
+                          torch.empty(F, device=DEV))
+    ops.linear_wgrad([(A[:R], Bm[:R], dW0, db0)], R, F, F)
+    ops.linear_wgrad([(A, Bm, dW1, db1)], Rc, F, F, dyn_rows=dims.data_ptr())
+    ref = A[:R].double().t() @ Bm[:R].double()
+    assert rel_err(dW1, ref) < 2e-6 and rel_err(dW1, dW0) < 2e-6 and rel_err(db1, A[:R].double().sum(0)) < 2e-6
+    # embedding forward / backward
+    z = torch.randint(0, 9, (Rc, 2), device=DEV, generator=gen)
+    z[R:, 0] = 99                                       # outside the table: must not be looked at
+    table, status = rnd(9, F), torch.zeros(1, dtype=torch.int32, device=DEV)
+    h1 = torch.full((Rc, F), 7.0, device=DEV)
+    _lib.call("geossl_embedding_fwd_dyn", z.data_ptr(), 2, table.data_ptr(), 9, Rc, F, h1.data_ptr(), status.data_ptr(),
+              dims.data_ptr(), _lib.stream())
+    assert torch.equal(h1[:R], table[z[:R, 0]]) and bool((h1[R:] == 7.0).all()) and int(status) == 0
+    dh = rnd(Rc, F)
+    dh[R:] = float("nan")
+    nfl = _lib.load().geossl_embedding_bwd_workspace_floats(9, F)
+    ws, g1 = torch.empty(nfl, device=DEV), torch.empty(9, F, device=DEV)
+    _lib.call("geossl_embedding_bwd_dyn", z.data_ptr(), 2, dh.data_ptr(), 9, Rc, F, g1.data_ptr(), ws.data_ptr(), 0,
+              dims.data_ptr(), _lib.stream())
+    gref = torch.zeros(9, F, dtype=torch.float64, device=DEV).index_add_(0, z[:R, 0], dh[:R].double())
+    assert rel_err(g1, gref) < 2e-6
+
+
+def test_copy_n_and_ddm_views_with_device_side_counts():
+    from geossl_amd import _lib, ops
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    srcs = [torch.randint(0, 1000, (n,), device=DEV, generator=gen, dtype=torch.int32) for n in (5, 1000, 33, 0, 70000)]
+    dsts = [torch.full((n + 3,), -1, device=DEV, dtype=torch.int32) for n in (5, 1000, 33, 0, 70000)]
+    cb = _lib.CopyBatch()
+    for k, (d_, s_) in enumerate(zip(dsts, srcs)):
+        cb.dst[k], cb.src[k], cb.bytes[k] = d_.data_ptr(), s_.data_ptr(), 4 * s_.numel()
+    _lib.call("geossl_copy_n", C.byref(cb), 5, _lib.stream())
+    for d_, s_ in zip(dsts, srcs):
+        assert torch.equal(d_[:s_.numel()], s_) and bool((d_[s_.numel():] == -1).all())
+    # both views behind one another at the REAL atom count
+    N, Nc, S, Sc = 50, 64, 120, 160
+    pos, noise = torch.randn(Nc, 3, device=DEV, generator=gen), torch.randn(Nc, 3, device=DEV, generator=gen) * 0.3
+    x = torch.randint(0, 9, (Nc, 2), device=DEV, generator=gen)
+    sei = torch.randint(0, N, (2, Sc), device=DEV, generator=gen)
+    p0, a0, b0, z0 = ops.ddm_views(pos[:N].contiguous(), noise[:N].contiguous(), sei[0, :S].contiguous(),
+                                   sei[1, :S].contiguous(), z=x[:N, 0])
+
+    class D:
+        pass
+    dims = _dims(N, S)
+    dyn = D()
+    dyn.n_atoms, dyn.n_super = dims.data_ptr(), dims.data_ptr() + 4
+    p1, a1, b1, z1 = ops.ddm_views(pos, noise, sei[0].contiguous(), sei[1].contiguous(), z=x[:, 0], dyn=dyn)
+    assert torch.equal(p1[:2 * N], p0) and torch.equal(z1[:2 * N], z0)
+    assert torch.equal(a1[:S], a0) and torch.equal(b1[:S], b0)
