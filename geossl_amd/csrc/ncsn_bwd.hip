@@ -705,11 +705,13 @@ __global__ __launch_bounds__(128 * NW) void k_ncsn_bwd_fused(NcsnFusedArgs a) {
   else ncsn_bwd_body<NW, false>(a, a.S, a.h);
 }
 // both heads of a DDM step in one launch: blockIdx.y = head
+// (the two argument sets as ONE kernel argument indexed by blockIdx.y: a block loads its own set from the kernarg
+// segment; as two arguments with a select between them the compiler kept BOTH sets in scalar registers and spilled 64)
+struct NcsnFusedPair { NcsnFusedArgs a[2]; };
 template <int NW>
-__global__ __launch_bounds__(128 * NW) void k_ncsn_bwd_fused2(NcsnFusedArgs a0, NcsnFusedArgs a1,
-                                                              const int32_t* __restrict__ dyn_S,
+__global__ __launch_bounds__(128 * NW) void k_ncsn_bwd_fused2(NcsnFusedPair pr, const int32_t* __restrict__ dyn_S,
                                                               const int32_t* __restrict__ dyn_view) {
-  const NcsnFusedArgs& a = blockIdx.y == 0 ? a0 : a1;
+  const NcsnFusedArgs& a = pr.a[blockIdx.y];
   // capacity launch (see k_ncsn_fwd2): real row count; head 1's features start *dyn_view rows into the shared tensor
   const int S = dyn_count(a.S, dyn_S);
   const float* h = a.h;
@@ -847,7 +849,8 @@ extern "C" int geossl_ddm_loss_bwd_fused2_dyn(const GeosslNcsnHeadBwd* heads, co
   // half of the chip per head: the two heads' blocks are resident together (one block of 8 x 256 registers per CU), and
   // a block's fixed costs - formatting its weight slices, 100 KB of partial sums - are paid by half as many blocks
   const int nb = (fused_blocks(S) + 1) / 2, H = F / 2;
-  NcsnFusedArgs a[2];
+  NcsnFusedPair pr;
+  NcsnFusedArgs* a = pr.a;
   for (int k = 0; k < 2; ++k) {
     const GeosslNcsnHeadBwd& hd = heads[k];
     if (hd.h == nullptr || hd.dfeat == nullptr || hd.workspace == nullptr) return (int)hipErrorInvalidValue;
@@ -864,7 +867,7 @@ extern "C" int geossl_ddm_loss_bwd_fused2_dyn(const GeosslNcsnHeadBwd* heads, co
 #define LAUNCH2(NWV)                                                                                                \
   do {                                                                                                              \
     allow_big_lds(&k_ncsn_bwd_fused2<NWV>);                                                                         \
-    hipLaunchKernelGGL((k_ncsn_bwd_fused2<NWV>), dim3(nb, 2), dim3(128 * NWV), NbLds<NWV>::bytes(), stream, a[0], a[1], \
+    hipLaunchKernelGGL((k_ncsn_bwd_fused2<NWV>), dim3(nb, 2), dim3(128 * NWV), NbLds<NWV>::bytes(), stream, pr,         \
                        dyn_S, dyn_view);                                                                            \
   } while (0)
   if (F == 128) LAUNCH2(4); else if (F == 64) LAUNCH2(2); else LAUNCH2(1);

@@ -294,12 +294,13 @@ struct NcsnFwdHead {
   float* loss_e;
   float* loss_part;
 };
+struct NcsnFwdPair { NcsnFwdHead a[2]; };  // one kernel argument indexed by blockIdx.y (see k_ncsn_bwd_fused2)
 template <int NMB>
-__global__ __launch_bounds__(512) void k_ncsn_fwd2(NcsnFwdHead a0, NcsnFwdHead a1, const int64_t* __restrict__ batch,
+__global__ __launch_bounds__(512) void k_ncsn_fwd2(NcsnFwdPair pr, const int64_t* __restrict__ batch,
                                                    const int64_t* __restrict__ sei0, const int64_t* __restrict__ sei1,
                                                    int S, const int32_t* __restrict__ dyn_S,
                                                    const int32_t* __restrict__ dyn_view) {
-  const NcsnFwdHead& a = blockIdx.y == 0 ? a0 : a1;
+  const NcsnFwdHead& a = pr.a[blockIdx.y];
   // capacity launch: the real number of super-edges, and (dyn_view) both heads were handed the base of ONE
   // [view 0 ; view 1] feature tensor - head 1's rows start *dyn_view rows in
   const float* h = a.h;
@@ -549,7 +550,8 @@ extern "C" int geossl_ddm_loss_fwd2_dyn(const GeosslNcsnHeadFwd* heads, const in
                                         const int32_t* dyn_view, hipStream_t stream) {
   if (S <= 0) return 0;
   if (heads == nullptr || (F != 32 && F != 64 && F != 128)) return (int)hipErrorInvalidValue;
-  NcsnFwdHead a[2];
+  NcsnFwdPair pr;
+  NcsnFwdHead* a = pr.a;
   for (int k = 0; k < 2; ++k) {
     const GeosslNcsnHeadFwd& hd = heads[k];
     if (hd.h == nullptr || hd.loss_e == nullptr) return (int)hipErrorInvalidValue;
@@ -563,7 +565,7 @@ extern "C" int geossl_ddm_loss_fwd2_dyn(const GeosslNcsnHeadFwd* heads, const in
 #define LAUNCH(NMBV)                                                                                              \
   do {                                                                                                            \
     allow_big_lds(&k_ncsn_fwd2<NMBV>);                                                                            \
-    hipLaunchKernelGGL((k_ncsn_fwd2<NMBV>), grid, dim3(512), lds, stream, a[0], a[1], batch, sei0, sei1, (int)S,   \
+    hipLaunchKernelGGL((k_ncsn_fwd2<NMBV>), grid, dim3(512), lds, stream, pr, batch, sei0, sei1, (int)S,           \
                        dyn_S, dyn_view);                                                                          \
   } while (0)
   if (F == 128) LAUNCH(4); else if (F == 64) LAUNCH(2); else LAUNCH(1);
