@@ -20,6 +20,7 @@ vp = C.c_void_p
 i64 = C.c_int64
 i32 = C.c_int
 f32 = C.c_float
+f64 = C.c_double
 
 
 class FilterWeights(C.Structure):
@@ -179,7 +180,7 @@ PROTOTYPES = {
     "geossl_painn_mix_post_bwd": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp]),
     "geossl_painn_mix_pre_bwd": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp]),
     "geossl_add": (i32, [vp, vp, i64, vp, vp]),
-    "geossl_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, vp]),
+    "geossl_adam_step": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i64, f32, vp]),
     # capacity launches: the namesake's arguments + device-side row count(s) before the stream
     "geossl_copy_n": (i32, [P(CopyBatch), i32, vp]),
     "geossl_ddm_views_dyn": (i32, [vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp]),

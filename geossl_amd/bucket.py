@@ -68,12 +68,20 @@ def _parts_table():
 _PARTS = None
 
 
+def sizes_array(batch):
+    """The batch's molecule sizes as an int64 array, made once per batch object."""
+    arr = batch.__dict__.get("_geossl_sizes_np")
+    if arr is None:
+        arr = batch.__dict__["_geossl_sizes_np"] = np.asarray(batch._sizes, dtype=np.int64)
+    return arr
+
+
 def batch_counts(sizes, option):
     """(atoms N, pair slots P, super-edges S, aggregation work items W of the two-view batch) of molecules `sizes`."""
     global _PARTS
     if _PARTS is None:
         _PARTS = _parts_table()
-    n = np.asarray(sizes, dtype=np.int64)
+    n = sizes if isinstance(sizes, np.ndarray) else np.asarray(sizes, dtype=np.int64)
     P = int((n * (n - 1) // 2).sum())
     S = P if option == "combination" else 2 * P
     W = 2 * int(_PARTS[n].sum())
@@ -85,9 +93,9 @@ def eligible(batch, model_3d, normalize=False):
     least one molecule with a pair), super_edge_index the extractor's full enumeration - every index tensor of the step
     is then a function of the sizes."""
     sizes, canon = getattr(batch, "_sizes", None), getattr(batch, "_canonical", None)
-    if model_3d != "schnet" or normalize or sizes is None or canon not in ("combination", "permutation") or not sizes:
+    if model_3d != "schnet" or normalize or sizes is None or canon not in ("combination", "permutation") or not len(sizes):
         return False
-    lo, hi = min(sizes), max(sizes)
+    lo, hi = size_range(batch)
     if lo < 1 or hi > MAX_N or hi < 2:
         return False
     return batch.positions.is_cuda and batch.positions.dtype == torch.float32 and batch.x.dim() == 2
@@ -110,9 +118,20 @@ def modules_ok(model, n1, n2):
     return not ({id(p) for p in _head_params(n1)} & {id(p) for p in _head_params(n2)})
 
 
+def size_range(batch):
+    r = batch.__dict__.get("_geossl_size_range")
+    if r is None:
+        n = sizes_array(batch)
+        r = batch.__dict__["_geossl_size_range"] = (int(n.min()), int(n.max()))
+    return r
+
+
 def is_uniform(batch):
     sizes = getattr(batch, "_sizes", None)
-    return sizes is not None and len(sizes) > 0 and min(sizes) == max(sizes)
+    if sizes is None or not len(sizes):
+        return False
+    lo, hi = size_range(batch)
+    return lo == hi
 
 
 def _round_up(v, g):
@@ -198,7 +217,7 @@ class Bucket:
         if _PARTS is None:
             _PARTS = _parts_table()
         B, o = self.B, self.off
-        n = np.asarray(batch._sizes, dtype=np.int64)
+        n = sizes_array(batch)
         if n.shape[0] != B:
             raise ValueError("bucket of %d molecules got a batch of %d" % (B, n.shape[0]))
         N, P, S, W = counts if counts is not None else batch_counts(n, self.option)

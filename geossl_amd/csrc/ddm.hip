@@ -286,21 +286,27 @@ __global__ __launch_bounds__(256) void k_incidence_gather(const float* __restric
 
 // ------------------------------------------------------------------------------------------------- Adam
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                       float* __restrict__ v, int64_t n, float step_size, float beta1, float beta2, float eps,
+                       float* __restrict__ v, int64_t n, float step_size, float w1, float beta2, float w2, float eps,
                        float wd, float bc2_sqrt, float grad_scale) {
-  // torch.optim.Adam single-tensor path: exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad,
-  // value=1-beta2); denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps); param.addcdiv_(exp_avg, denom,
-  // value=-lr/bias_correction1)
+  // torch.optim.Adam's default (foreach) device path, rounding step by rounding step - found by comparing forms against
+  // it bit for bit (tools/probes/adam_probe.hip: 0 differing elements of param / exp_avg / exp_avg_sq over four steps):
+  //   exp_avg.lerp_(grad, 1 - beta1)                          = fma(w1, grad - exp_avg, exp_avg)
+  //   exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)  = fma(w2, grad * grad, exp_avg_sq * beta2)
+  //   denom = exp_avg_sq.sqrt() / bias_correction2_sqrt + eps
+  //   param.addcdiv_(exp_avg, denom, value=-lr / bc1)         = fma(-step_size, exp_avg / denom, param)
+  // with w1 = float(1 - beta1), w2 = float(1 - beta2) formed in DOUBLE on the host like torch forms them (1.0f - 0.999f
+  // is 4.7e-5 away from float(0.001): the form this kernel had until round 4)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float gi = g[i] * grad_scale;
+    float gi = mul_rn(g[i], grad_scale);
     const float pi = p[i];
     if (wd != 0.0f) gi = fmaf(wd, pi, gi);
-    const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
-    const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+    const float m0 = m[i];
+    const float mi = fmaf(w1, add_rn(gi, -m0), m0);
+    const float vi = fmaf(w2, mul_rn(gi, gi), mul_rn(v[i], beta2));
     m[i] = mi;
     v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi + (-step_size * mi) / denom;
+    const float denom = add_rn(sqrtf(vi) / bc2_sqrt, eps);
+    p[i] = fmaf(-step_size, mi / denom, pi);
   }
 }
 
@@ -420,14 +426,16 @@ int launch_incidence_gather2(const float* dfeat0, const float* dfeat1, const int
 }
 }  // namespace geossl
 
-extern "C" int geossl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                                float beta1, float beta2, float eps, float weight_decay, int64_t step_count,
+extern "C" int geossl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                                double beta1, double beta2, double eps, double weight_decay, int64_t step_count,
                                 float grad_scale, hipStream_t stream) {
   if (n <= 0) return 0;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step_count);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step_count);
+  // (hyperparameters arrive as the doubles Python holds; every derived scalar is formed in double and rounded once)
+  const double bc1 = 1.0 - pow(beta1, (double)step_count);
+  const double bc2 = 1.0 - pow(beta2, (double)step_count);
   hipLaunchKernelGGL(k_adam, dim3(grid1d(n, 256)), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, n,
-                     (float)((double)lr / bc1), beta1, beta2, eps, weight_decay, (float)sqrt(bc2), grad_scale);
+                     (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                     (float)weight_decay, (float)sqrt(bc2), grad_scale);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

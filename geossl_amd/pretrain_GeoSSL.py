@@ -257,6 +257,10 @@ class Batch:
         return out
 
     def to(self, device):
+        dev = torch.device(device)
+        if all(a is None or (a.device == dev or (dev.index is None and a.device.type == dev.type))
+               for a in (self.x, self.positions, self.batch, self.super_edge_index, self.radius_edge_index)):
+            return self  # (already there: like Tensor.to, no new object - what is cached on this one stays)
         mv = lambda a: None if a is None else a.to(device)
         return Batch(mv(self.x), mv(self.positions), mv(self.batch), mv(self.super_edge_index),
                      mv(self.radius_edge_index), self._num_graphs, self._sizes, self._canonical)
@@ -400,7 +404,7 @@ class StepGraphs:
             g = self.graphs.get(key)
             if g is None:
                 return None
-            counts = bk.batch_counts(batch._sizes, batch._canonical)
+            counts = bk.batch_counts(bk.sizes_array(batch), batch._canonical)
             if not g["bucket"].fits(counts):
                 return None
             g["counts"] = counts
@@ -468,7 +472,7 @@ class StepGraphs:
     def _capture_bucket(self, key, batch, noise):
         from . import bucket as bk
         old = self.graphs.pop(key, None)
-        counts = bk.batch_counts(batch._sizes, batch._canonical)
+        counts = bk.batch_counts(bk.sizes_array(batch), batch._canonical)
         caps = bk.capacities(*counts, B=len(batch._sizes), prev=None if old is None else old["bucket"].caps())
         del old  # (its graph and static buffers go before the larger ones are made)
         self._evict()
@@ -508,6 +512,13 @@ class StepGraphs:
         # watchdog thread polls events of earlier all-reduces), and calls of other threads must not invalidate it
         torch.cuda.synchronize()
         graph, graph_bwd = torch.cuda.CUDAGraph(), None
+        # No garbage collection while a capture is open: a collection that happens to run there finalises whatever old
+        # graphs, events and streams sit in unreachable cycles (an engine of a model that is gone), and destroying a
+        # graph or querying an event inside a capture aborts the process.
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
         try:
             if self.split is None:
                 with torch.cuda.graph(graph, pool=self.pool, capture_error_mode="thread_local"):
@@ -530,6 +541,9 @@ class StepGraphs:
             torch.cuda.synchronize()
             self.enabled = False
             return None
+        finally:
+            if gc_was_on:
+                gc.enable()
         self.captures += 1
         return dict(graph=graph, graph_bwd=graph_bwd, batch=sb, noise=sn, loss=loss)
 
@@ -573,7 +587,7 @@ class StepGraphs:
             StepGraphs.copy_noise(g, noise)
 
 
-_PINNED = {}  # (shape) -> ring of two pinned staging tensors with the event behind their last copy
+_PINNED = {"i": 0, "slots": [[None, None], [None, None]]}  # ring of two pinned staging buffers (grow-only) + copy events
 
 
 def _host_normal_into(dst, mu, sigma):
@@ -581,16 +595,18 @@ def _host_normal_into(dst, mu, sigma):
     values) into the device tensor `dst` without stalling the host: the draw is made straight into pinned memory and
     copied asynchronously (a pageable source makes the copy wait for everything queued on the stream before it - in the
     reference loop that is the whole previous backward)."""
-    key = tuple(dst.shape)
-    ring = _PINNED.get(key)
-    if ring is None:
-        ring = _PINNED[key] = {"i": 0, "slots": [[torch.empty(key, dtype=torch.float32).pin_memory(), None] for _ in range(2)]}
+    key, n = tuple(dst.shape), dst.numel()
+    ring = _PINNED
     slot = ring["slots"][ring["i"]]
     ring["i"] ^= 1
     if slot[1] is not None:
-        slot[1].synchronize()  # the copy that last read this staging tensor (two steps ago)
-    torch.normal(mu, sigma, size=key, out=slot[0])
-    dst.copy_(slot[0], non_blocking=True)
+        slot[1].synchronize()  # the copy that last read this staging buffer (two steps ago)
+    if slot[0] is None or slot[0].numel() < n:
+        # one buffer for every size (a shuffled loader's batches all differ: pinning memory per shape cost a step's time)
+        slot[0] = torch.empty(max(n + n // 4, 4096), dtype=torch.float32).pin_memory()
+    stage = slot[0][:n].view(key)
+    torch.normal(mu, sigma, size=key, out=stage)   # (the values of a fresh tensor of this size: the generator fills in order)
+    dst.copy_(stage, non_blocking=True)
     slot[1] = torch.cuda.Event()
     slot[1].record()
 
@@ -663,8 +679,17 @@ class _ReplayedLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        eng = ctx.engine
-        g = eng.collect(ctx.ticket) * gout
+        eng, ticket = ctx.engine, ctx.ticket
+        src = eng.collect(ticket)
+        pre = ticket.pop("views", None)
+        if pre is not None:
+            # the step's own output buffer and its per-parameter views were made in do_DDM, while the host was going to
+            # wait for the forward anyway; handing them out once keeps them stealable (AccumulateGrad adopts a gradient
+            # nobody else references - the list dies with this frame)
+            buf, outs = pre
+            torch.mul(src, gout, out=buf)
+            return (None, None, None) + tuple(outs)
+        g = src * gout
         # one split for all parameters, then a reshape each (two tensor operations per parameter were a third of this
         # backward's host time at 59 parameters - and the host is what bounds the loop at small batches)
         outs = [v.view(shape) for v, (shape, _) in zip(g.split_with_sizes(eng.numels), eng.shapes)]
@@ -679,7 +704,8 @@ class _Ticket(dict):
 
     def __del__(self):
         try:
-            if not self.get("used") and self.get("event") is not None and not self["event"].query():
+            if (not self.get("used") and self.get("event") is not None and not torch.cuda.is_current_stream_capturing()
+                    and not self["event"].query()):
                 torch.cuda.current_stream().wait_event(self["event"])
         except Exception:  # interpreter shutdown, a destroyed context: nothing left to order
             pass
@@ -709,6 +735,11 @@ class _AutogradStep:
                 seen.add(id(p))
                 self.params.append(p)
         dev = self.params[0].device
+        # the parameters move into ONE flat buffer (values unchanged; they stay ordinary leaves): the gradients this
+        # engine hands to autograd are views of one flat buffer at the same offsets, which lets a stock torch.optim.Adam
+        # over these parameters run as one launch (optim.ParamHome and its step hook)
+        from .optim import ParamHome
+        self.home = ParamHome.of(self.params)
         self.gflat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
         self.views, off = [], 0
         for p in self.params:
@@ -716,7 +747,18 @@ class _AutogradStep:
             off += p.numel()
         self.shapes = tuple((tuple(p.shape), p.numel()) for p in self.params)
         self.numels = [n for _, n in self.shapes]
-        self.signature = self._signature()
+        # where every parameter of the three modules hangs (submodule, name) with its object, address and grad flag:
+        # `unchanged()` compares them per call without walking the module trees
+        self._where = []
+        for m in (self.model, self.n1, self.n2):
+            seen_mod = set()
+            for sub in m.modules():
+                if id(sub) in seen_mod:
+                    continue
+                seen_mod.add(id(sub))
+                for name, p in sub._parameters.items():
+                    if p is not None:
+                        self._where.append((sub._parameters, name, p, p.data_ptr(), p.requires_grad))
         self.graphs = {}   # (model_3d, normalize) -> StepGraphs
         self._cfg = None
         self._side = torch.cuda.Stream(device=dev)   # the backward graphs replay here
@@ -724,9 +766,13 @@ class _AutogradStep:
         self._ticket = None                          # the step whose gradients are in gflat: {"serial", "event", "g"}
         self._serial = 0
 
-    def _signature(self):
-        return tuple((id(p), p.data_ptr(), p.requires_grad) for m in (self.model, self.n1, self.n2)
-                     for p in m.parameters())
+    def unchanged(self):
+        """No parameter of the three modules was replaced, moved or (un)frozen since the engine was built (its graphs bind
+        the parameters' addresses)."""
+        for d, name, p, addr, rg in self._where:
+            if d.get(name) is not p or p.data_ptr() != addr or p.requires_grad != rg:
+                return False
+        return True
 
     # The engine hangs on the backbone module (model.__dict__) and holds graphs, streams and events: a copy or a pickle
     # of the model (copy.deepcopy for an EMA twin, torch.save(model)) carries None instead and builds its own on first use.
@@ -829,6 +875,9 @@ class _AutogradStep:
             self._bwd_done.record(self._side)
         self._serial += 1
         self._ticket = _Ticket(serial=self._serial, event=self._bwd_done, g=None)
+        _single_thread_backward()
+        buf = torch.empty_like(self.gflat)   # this step's (scaled) gradients as autograd will receive them
+        self._ticket["views"] = (buf, [v.view(shape) for v, (shape, _) in zip(buf.split_with_sizes(self.numels), self.shapes)])
         # deferred index check of the backbone: the embedding kernel flagged an out-of-range atom type in the status
         # word, but model.forward's own arm() does nothing while a graph is captured and a replay never reaches it -
         # read the word here like DDMTrainer.step does (IndexError up to eight steps late, like Embedding's, not never)
@@ -837,6 +886,24 @@ class _AutogradStep:
             st.poll()
             st.arm(every=8)
         return _ReplayedLoss.apply(loss, self, self._ticket, *self.params)
+
+
+_BACKWARD_TLS = [None]
+
+
+def _single_thread_backward():
+    """The loss of a replayed step has ONE node behind it (_ReplayedLoss) and its 59 AccumulateGrads; autograd would hand
+    them to its per-device worker thread and wake the caller when it is done - a hand-over that costs 0.13 ms per
+    backward() (measured, tools/ref_loop_profile.py), a fifth of a whole step at the reference's batch size.  With
+    multithreading off the calling thread runs the backward itself.  The switch is autograd's own, thread-local
+    (torch.autograd.set_multithreading_enabled), and only matters to graphs that span several devices - which one
+    process per GPU never builds; GEOSSL_KEEP_AUTOGRAD_THREADS leaves it alone."""
+    import threading
+    tid = threading.get_ident()
+    if _BACKWARD_TLS[0] != tid:
+        _BACKWARD_TLS[0] = tid
+        if not os.environ.get("GEOSSL_KEEP_AUTOGRAD_THREADS"):
+            torch.autograd.set_multithreading_enabled(False)
 
 
 def _schnet_step_params(model):
@@ -848,7 +915,7 @@ def _autograd_step(model, n1, n2):
     """The _AutogradStep of a (backbone, head, head) triple, kept on the backbone module; rebuilt when a parameter was
     replaced, moved or frozen since (the graphs bind parameter addresses)."""
     eng = model.__dict__.get("_geossl_autograd_step")
-    if eng is None or eng.n1 is not n1 or eng.n2 is not n2 or eng.signature != eng._signature():
+    if eng is None or eng.n1 is not n1 or eng.n2 is not n2 or not eng.unchanged():
         eng = _AutogradStep(model, n1, n2)
         model.__dict__["_geossl_autograd_step"] = eng
     return eng

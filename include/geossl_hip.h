@@ -479,9 +479,12 @@ int geossl_painn_mix_pre_bwd(const float* dq_new, const float* dctx, const float
 int geossl_add(const float* a, const float* b, int64_t n, float* out, hipStream_t stream);
 
 /* ---- Adam — torch.optim.Adam step at pretrain_GeoSSL.py:258-260,343 over one flat fp32 buffer
- * (amsgrad off; weight_decay added to the gradient as torch does).  step_count is the 1-based step.        */
-int geossl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                     float beta1, float beta2, float eps, float weight_decay, int64_t step_count, float grad_scale,
+ * (amsgrad off; weight_decay added to the gradient as torch does).  step_count is the 1-based step.  The
+ * hyperparameters are the DOUBLES Python holds: torch forms 1 - beta, lr / bias_correction1 and sqrt(bias_correction2) in
+ * double and rounds once; the update is torch's default (foreach) device arithmetic bit for bit
+ * (tools/probes/adam_probe.hip).                                                                              */
+int geossl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                     double beta1, double beta2, double eps, double weight_decay, int64_t step_count, float grad_scale,
                      hipStream_t stream);
 
 /* ---- Capacity launches: the `_dyn` entry points --------------------------------------------------------------------

@@ -421,3 +421,95 @@ def test_copy_n_and_ddm_views_with_device_side_counts():
     p1, a1, b1, z1 = ops.ddm_views(pos, noise, sei[0].contiguous(), sei[1].contiguous(), z=x[:, 0], dyn=dyn)
     assert torch.equal(p1[:2 * N], p0) and torch.equal(z1[:2 * N], z0)
     assert torch.equal(a1[:S], a0) and torch.equal(b1[:S], b0)
+
+
+# --------------------------------------------------------------------------- stock torch.optim.Adam on the flat path
+def _ref_loop(graph, steps, batches, adam_kw=None, between=None, cfg=SMALL, seed=11):
+    """examples/pretrain_GeoSSL.py:248-260 + :332-343 on the product modules -> (losses, parameters, optimizer)."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed(seed)
+    model = product_schnet(cfg, DEV)
+    n1, n2 = product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9)
+    pg.NCSN_model_01, pg.NCSN_model_02 = n1, n2
+    args = types.SimpleNamespace(model_3d="schnet", GeoSSL_mu=0.0, GeoSSL_sigma=0.3, lr=5e-4, decay=0.0, step_graph=graph)
+    group = [{"params": model.parameters(), "lr": args.lr}, {"params": n1.parameters()}, {"params": n2.parameters()}]
+    optimizer = torch.optim.Adam(group, lr=args.lr, weight_decay=args.decay, **(adam_kw or {}))
+    losses = []
+    try:
+        for step in range(steps):
+            loss, acc = pg.do_DDM(args, batches[step % len(batches)], model, criterion=None, mu=0.0, sigma=0.3)
+            losses.append(loss.detach().item())
+            optimizer.zero_grad()
+            loss.backward()
+            if between is not None:
+                between(step, model, n1, n2, optimizer)
+            optimizer.step()
+    finally:
+        pg.NCSN_model_01 = pg.NCSN_model_02 = None
+    params = torch.cat([p.detach().reshape(-1) for m in (model, n1, n2) for p in m.parameters()]).cpu()
+    return losses, params, optimizer, (model, n1, n2)
+
+
+def test_stock_adam_runs_as_one_launch_on_the_graph_path_bit_for_bit():
+    """The reference's optimizer, unmodified (torch.optim.Adam over three groups, :332-343): on do_DDM's graph path its
+    step is ONE geossl_adam_step launch (the parameters and the gradients autograd received are views of flat buffers; a
+    global step hook does the update and leaves the stock step nothing to do) - with torch's foreach arithmetic bit for
+    bit: losses and parameters equal the eager loop's, the optimizer's state has torch's layout and values, the gradients
+    are back on the parameters after the step."""
+    from geossl_amd import _lib
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import make_batch
+    batches = [pg.Batch.from_numpy(make_batch(32, seed=40 + i), DEV) for i in range(4)]
+    calls = []
+    real = _lib.call
+
+    def counting(name, *a):
+        calls.append(name)
+        return real(name, *a)
+
+    eager = _ref_loop(False, 6, batches)
+    pg.call, saved = counting, pg.call
+    import geossl_amd.optim as go
+    go.call = counting
+    try:
+        graph = _ref_loop(True, 6, batches)
+    finally:
+        pg.call, go.call = saved, real
+    assert calls.count("geossl_adam_step") == 6
+    assert graph[0] == eager[0] and torch.equal(graph[1], eager[1])
+    so, se = graph[2].state_dict(), eager[2].state_dict()
+    assert so["param_groups"] == se["param_groups"] and set(so["state"]) == set(se["state"])
+    for k in se["state"]:
+        assert float(so["state"][k]["step"]) == float(se["state"][k]["step"]) == 6.0
+        assert torch.equal(so["state"][k]["exp_avg"], se["state"][k]["exp_avg"])
+        assert torch.equal(so["state"][k]["exp_avg_sq"], se["state"][k]["exp_avg_sq"])
+    model = graph[3][0]
+    assert all(p.grad is not None for p in model.parameters() if p.requires_grad)
+    # the optimizer's state survives a round trip, and the hook takes the loaded copies in again
+    graph[2].load_state_dict(graph[2].state_dict())
+
+
+def test_stock_adam_hook_steps_aside_for_what_it_does_not_know():
+    """amsgrad (a different update), a gradient replaced by a copy between backward() and step() (not a view of the flat
+    buffer any more) and in-place clipping (still the views: fused) - results as the eager loop computes them."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import make_batch
+    batches = [pg.Batch.from_numpy(make_batch(16, seed=60 + i), DEV) for i in range(2)]
+    a, b = _ref_loop(False, 4, batches, adam_kw=dict(amsgrad=True)), _ref_loop(True, 4, batches, adam_kw=dict(amsgrad=True))
+    assert a[0] == b[0] and torch.equal(a[1], b[1])
+
+    def replace_one(step, model, n1, n2, opt):
+        if step == 2:
+            model.lin2.weight.grad = model.lin2.weight.grad.clone() * 0.5
+
+    a, b = _ref_loop(False, 4, batches, between=replace_one), _ref_loop(True, 4, batches, between=replace_one)
+    assert a[0] == b[0] and torch.equal(a[1], b[1])
+
+    def clip(step, model, n1, n2, opt):
+        torch.nn.utils.clip_grad_norm_(list(model.parameters()) + list(n1.parameters()) + list(n2.parameters()), 0.5)
+
+    a, b = _ref_loop(False, 4, batches, between=clip), _ref_loop(True, 4, batches, between=clip)
+    for x, y in zip(a[0], b[0]):
+        assert abs(x - y) <= 1e-6 * abs(y)
+    assert rel_err(b[1], a[1]) < 1e-6
