@@ -840,14 +840,14 @@ def main():
             sec["trainer/set=B"] = secondary_line(dev, rank, world, 20, 4, api="trainer", molset="B", n_batches=4)
             # the loader the reference really uses (pretrain_GeoSSL.py:301: shuffle=True over ragged molecules): every
             # batch its own size sequence, visited once, nothing primed - captures fall into the timed region
-            sec["trainer/set=B/distinct"] = secondary_line(dev, rank, world, 120, 0, api="trainer", molset="B",
-                                                           n_batches=120, distinct=True)
+            sec["trainer/set=B/distinct"] = secondary_line(dev, rank, world, 240, 0, api="trainer", molset="B",
+                                                           n_batches=240, distinct=True)
             sec["trainer/set=B/mols=128"] = secondary_line(dev, rank, world, 40, 8, api="trainer", molset="B", mols=128,
                                                            n_batches=4)
-            sec["trainer/set=B/mols=128/distinct"] = secondary_line(dev, rank, world, 240, 0, api="trainer", molset="B",
-                                                                    mols=128, n_batches=240, distinct=True)
-            sec["reference_api/set=B/mols=128/distinct"] = secondary_line(dev, rank, world, 240, 0, api="reference",
-                                                                          molset="B", mols=128, n_batches=240, distinct=True)
+            sec["trainer/set=B/mols=128/distinct"] = secondary_line(dev, rank, world, 480, 0, api="trainer", molset="B",
+                                                                    mols=128, n_batches=480, distinct=True)
+            sec["reference_api/set=B/mols=128/distinct"] = secondary_line(dev, rank, world, 480, 0, api="reference",
+                                                                          molset="B", mols=128, n_batches=480, distinct=True)
             for a, b_ in (("trainer/set=B/distinct", "trainer/set=B"),
                           ("trainer/set=B/mols=128/distinct", "trainer/set=B/mols=128"),
                           ("reference_api/set=B/mols=128/distinct", "trainer/set=B/mols=128")):

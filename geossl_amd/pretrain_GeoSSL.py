@@ -502,6 +502,14 @@ class StepGraphs:
         return g
 
     def _capture(self, sb, sn):
+        import time
+        timing = [] if os.environ.get("GEOSSL_CAPTURE_TIMING") else None
+
+        def lap(name):
+            if timing is not None:
+                torch.cuda.synchronize()
+                timing.append((name, time.perf_counter()))
+        lap("start")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up off the capture: builds the cached layouts, sets kernel attributes
@@ -511,13 +519,14 @@ class StepGraphs:
         # nothing may be pending on the device when the capture starts (in a multi-rank job the collective's
         # watchdog thread polls events of earlier all-reduces), and calls of other threads must not invalidate it
         torch.cuda.synchronize()
+        lap("warm-up passes")
         graph, graph_bwd = torch.cuda.CUDAGraph(), None
         # No garbage collection while a capture is open: a collection that happens to run there finalises whatever old
         # graphs, events and streams sit in unreachable cycles (an engine of a model that is gone), and destroying a
-        # graph or querying an event inside a capture aborts the process.
+        # graph or querying an event inside a capture aborts the process.  (Not collecting up front either: a full
+        # collection of a process with torch loaded costs 45 ms, as much as the rest of the capture.)
         import gc
         gc_was_on = gc.isenabled()
-        gc.collect()
         gc.disable()
         try:
             if self.split is None:
@@ -544,6 +553,9 @@ class StepGraphs:
         finally:
             if gc_was_on:
                 gc.enable()
+        lap("capture + instantiate")
+        if timing is not None:
+            print("capture timing (ms):", ", ".join("%s %.1f" % (n, 1e3 * (t - timing[i][1])) for i, (n, t) in enumerate(timing[1:])))
         self.captures += 1
         return dict(graph=graph, graph_bwd=graph_bwd, batch=sb, noise=sn, loss=loss)
 
