@@ -155,7 +155,16 @@ class _SchNetCore(torch.autograd.Function):
         for l, lp in enumerate(layers):
             fw.w1[l], fw.b1[l], fw.w2[l], fw.b2[l] = ptr(lp[0]), ptr(lp[1]), ptr(lp[2]), ptr(lp[3])
         Wf = torch.empty(L, P, F, dtype=torch.float32, device=dev)
-        T = torch.empty(L, P, F, dtype=torch.float32, device=dev) if training else None
+        # The hidden rows T = ssp(W1 rbf + b1) of the filter network are saved for the backward (0.96 GB written and read
+        # again per step at the bench size).  They are a function of the pair's distance alone, and the weight-gradient
+        # kernel can rebuild them (GEOSSL_FILTER_RECOMPUTE_T: one K = 64 product per tile by its role-A waves; the forward
+        # then stores Wf only) - measured on two boxes: forward 0.41 -> 0.31 ms, backward 0.74 -> 0.88 ms, the step
+        # within 0.1 % either way, 21 % less HBM traffic.  Equal speed is not a win: saving stays the default, the
+        # rebuild is there for when memory is what is short.  The position gradient
+        # (geossl_cfconv_filter_dpos) and the three-bf16-piece backward read the saved rows.
+        keep_T = training and (ctx.needs_input_grad[1] or not os.environ.get("GEOSSL_FILTER_RECOMPUTE_T")
+                               or bool(os.environ.get("GEOSSL_FILTER_BWD_BF16X3")))
+        T = torch.empty(L, P, F, dtype=torch.float32, device=dev) if keep_T else None
         if P > 0:
             call("geossl_cfconv_filter_fwd_dyn", ptr(pair_d), ptr(pair_c), P, C.byref(fw), L, F, G, ptr(cfg["offset"]),
                  cfg["coeff"], ptr(T), ptr(Wf), dP2, st)
@@ -204,7 +213,7 @@ class _SchNetCore(torch.autograd.Function):
 
             # One launch for the whole loop where the shape allows (every block carries its molecules through all
             # operations, ops.layer_loop), else 14 launches
-            todo = [] if (cfg["loop"] and P > 0 and 2 * L + 2 <= _lib.LOOP_MAX_OPS and dyn is None) else None
+            todo = [] if (cfg["loop"] and P > 0 and 2 * L + 2 <= _lib.LOOP_MAX_OPS) else None
             if todo is not None:
                 run_rows(0, N, None, todo)
                 if not ops.layer_loop(todo, lay, pair_flag, N, F, stagger=cfg["loop_stagger"]):
@@ -317,7 +326,7 @@ class _SchNetCore(torch.autograd.Function):
                                    dict(image=i_lin2[l - 1], out=rows(daggs[l - 1]))]
                     chain(rows(dxs[l]), stages)
 
-            todo = [] if (cfg["loop"] and lay.P > 0 and 2 * L + 2 <= _lib.LOOP_MAX_OPS and dyn is None) else None
+            todo = [] if (cfg["loop"] and lay.P > 0 and 2 * L + 2 <= _lib.LOOP_MAX_OPS) else None
             if todo is not None:
                 run_rows(0, N, None, todo)
                 if not ops.layer_loop(todo, lay, sv["pair_flag"], N, F, stagger=cfg["loop_stagger"]):

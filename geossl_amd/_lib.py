@@ -144,6 +144,7 @@ PROTOTYPES = {
     "geossl_ddm_loss_fwd_workspace_floats": (i64, [i32]),
     "geossl_ddm_loss_fwd": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, P(NcsnWeights), i32, f32, vp, P(NcsnSaved), vp, vp]),
     "geossl_schnet_layer_loop": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, i64, i32, i32, vp]),
+    "geossl_schnet_layer_loop_ragged": (i32, [vp, i32, vp, vp, vp, i64, i32, i64, i32, vp]),
     "geossl_copy2": (i32, [vp, vp, i64, vp, vp, i64, vp]),
     "geossl_ddm_noise": (i32, [vp, f32, f32, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp]),
     "geossl_ddm_views": (i32, [vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, i64, vp, vp]),

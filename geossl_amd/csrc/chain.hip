@@ -879,12 +879,30 @@ struct LoopArgs {
   const int32_t* pair_ptr;
   const uint8_t* pair_flag;
   int nops, R, stagger, pad;
+  int nmol, mols_per_block;  // ragged form (NMAX = 0): block b owns molecules [b * mols_per_block, ...) of nmol
 };
 
+// NMAX > 0: uniform batch, blocks from the host's plan, the walk of one size class.  NMAX = 0: RAGGED molecules
+// (1 .. 33 atoms) of a small batch - block b owns `mols_per_block` (1 or 2: at most 66 atom rows = three row blocks)
+// consecutive molecules, found from mol_ptr on the device (no host plan: the loop then also serves a capacity bucket,
+// whose index structures are device data); every wave takes the unrolled walk of its molecule's size class.  At 1024
+// molecules per view this form loses to the separate launches (a block owns its molecules for a whole pass, 14
+// launches rebalance 14 times: DESIGN.md section 7); at the reference's batch size every launch of the pass is a
+// 5 .. 9 us latency and the loop is what removes them.
 template <int NMAX>
 __global__ __launch_bounds__(256, 2) void k_layer_loop(LoopArgs a) {
   constexpr int F = 128;
-  const int4 pl = a.plan[blockIdx.x];
+  int4 pl;
+  if constexpr (NMAX > 0) {
+    pl = a.plan[blockIdx.x];
+  } else {
+    pl.z = (int)blockIdx.x * a.mols_per_block;
+    pl.w = min(pl.z + a.mols_per_block, a.nmol);
+    if (pl.z >= pl.w) return;  // (block-uniform, before any barrier)
+    pl.x = a.mol_ptr[pl.z];
+    pl.y = a.mol_ptr[pl.w];
+    if (pl.x >= pl.y) return;
+  }
   const int nloc = (pl.y - pl.x + 31) / 32;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
   if ((int)blockIdx.x >= ((int)gridDim.x + 1) / 2)
@@ -898,7 +916,15 @@ __global__ __launch_bounds__(256, 2) void k_layer_loop(LoopArgs a) {
     } else {
       for (int mm = pl.z + wave; mm < pl.w; mm += 4) {
         const int a0 = a.mol_ptr[mm], n = a.mol_ptr[mm + 1] - a0, base = a.pair_ptr[mm];
-        aggregate_reg_body<NMAX>(op.X, op.Wf, a.pair_flag, a0, n, base, lane, 2 * lane, F, op.swap, op.out);
+        if constexpr (NMAX > 0) {
+          aggregate_reg_body<NMAX>(op.X, op.Wf, a.pair_flag, a0, n, base, lane, 2 * lane, F, op.swap, op.out);
+        } else {
+          const int nu = __builtin_amdgcn_readfirstlane(n);
+#define LOOP_CLASS(NM) if (nu <= NM) aggregate_reg_body<NM>(op.X, op.Wf, a.pair_flag, a0, n, base, lane, 2 * lane, F, op.swap, op.out); else
+          LOOP_CLASS(8) LOOP_CLASS(12) LOOP_CLASS(16) LOOP_CLASS(18) LOOP_CLASS(20) LOOP_CLASS(22) LOOP_CLASS(24)
+          LOOP_CLASS(26) LOOP_CLASS(28) LOOP_CLASS(30) LOOP_CLASS(33) {}
+#undef LOOP_CLASS
+        }
       }
     }
     // the next operation reads what this one wrote (rows of the block's own molecules, through L2), and reuses the LDS
@@ -1071,14 +1097,7 @@ extern "C" int geossl_linear_chain_dyn(const float* X, int ldx, const GeosslChai
   return launch_chain<2>(*chain, X, ldx, R, stream, dyn_R);
 }
 
-extern "C" int geossl_schnet_layer_loop(const GeosslLoopOp* ops, int nops, const int32_t* plan, int nblocks,
-                                        const int32_t* mol_ptr, const int32_t* pair_ptr, const uint8_t* pair_flag,
-                                        int max_n, int uniform, int64_t N, int F, int stagger, hipStream_t stream) {
-  if (nops <= 0 || nblocks <= 0) return 0;
-  if (ops == nullptr || plan == nullptr || nops > LOOP_MAX_OPS || F != 128 || !uniform || max_n > 20 || N <= 0)
-    return (int)hipErrorInvalidValue;
-  if (N * (int64_t)F * 4 >= (int64_t)0xFFFFFF00u) return (int)hipErrorInvalidValue;  // 32-bit buffer offsets
-  LoopArgs a;
+static int fill_loop_ops(const GeosslLoopOp* ops, int nops, int F, LoopArgs& a) {
   for (int o = 0; o < nops; ++o) {
     const GeosslLoopOp& src = ops[o];
     LoopOp& d = a.op[o];
@@ -1109,9 +1128,22 @@ extern "C" int geossl_schnet_layer_loop(const GeosslLoopOp* ops, int nops, const
       return (int)hipErrorInvalidValue;
     }
   }
+  return 0;
+}
+
+extern "C" int geossl_schnet_layer_loop(const GeosslLoopOp* ops, int nops, const int32_t* plan, int nblocks,
+                                        const int32_t* mol_ptr, const int32_t* pair_ptr, const uint8_t* pair_flag,
+                                        int max_n, int uniform, int64_t N, int F, int stagger, hipStream_t stream) {
+  if (nops <= 0 || nblocks <= 0) return 0;
+  if (ops == nullptr || plan == nullptr || nops > LOOP_MAX_OPS || F != 128 || !uniform || max_n > 20 || N <= 0)
+    return (int)hipErrorInvalidValue;
+  if (N * (int64_t)F * 4 >= (int64_t)0xFFFFFF00u) return (int)hipErrorInvalidValue;  // 32-bit buffer offsets
+  LoopArgs a;
+  const int rc = fill_loop_ops(ops, nops, F, a);
+  if (rc != 0) return rc;
   a.plan = reinterpret_cast<const int4*>(plan);
   a.mol_ptr = mol_ptr; a.pair_ptr = pair_ptr; a.pair_flag = pair_flag;
-  a.nops = nops; a.R = (int)N; a.stagger = stagger; a.pad = 0;
+  a.nops = nops; a.R = (int)N; a.stagger = stagger; a.pad = 0; a.nmol = 0; a.mols_per_block = 0;
   const size_t lds = (size_t)3 * 8 * 2 * 1024 + (size_t)3 * 128 * sizeof(float) + (size_t)3 * 128 * sizeof(float);
   // uniform batches only (every molecule has max_n atoms, says the caller): the walk of one size class.  A form that
   // holds every class (waves of a block on different walks, molecules of 27 atoms and more shared by two or four waves)
@@ -1123,6 +1155,33 @@ extern "C" int geossl_schnet_layer_loop(const GeosslLoopOp* ops, int nops, const
     allow_big_lds(&k_layer_loop<20>);
     hipLaunchKernelGGL((k_layer_loop<20>), dim3(nblocks), dim3(256), lds, stream, a);
   }
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+// The layer loop over RAGGED molecules of a small batch (k_layer_loop<0>): B molecules of 1 .. 33 atoms described by
+// mol_ptr / pair_ptr on the device, `mols_per_block` (1 or 2) consecutive molecules per block, one round of blocks
+// (ceil(B / mols_per_block) <= 512 * 2: two blocks of four waves per CU).  N = rows of the atom tensors (a capacity is
+// fine: no row past mol_ptr[B] is touched).
+extern "C" int geossl_schnet_layer_loop_ragged(const GeosslLoopOp* ops, int nops, const int32_t* mol_ptr,
+                                               const int32_t* pair_ptr, const uint8_t* pair_flag, int64_t B,
+                                               int mols_per_block, int64_t N, int F, hipStream_t stream) {
+  if (nops <= 0 || B <= 0) return 0;
+  if (ops == nullptr || mol_ptr == nullptr || pair_ptr == nullptr || nops > LOOP_MAX_OPS || F != 128 || N <= 0 ||
+      mols_per_block < 1 || mols_per_block > 2)
+    return (int)hipErrorInvalidValue;
+  if (N * (int64_t)F * 4 >= (int64_t)0xFFFFFF00u) return (int)hipErrorInvalidValue;  // 32-bit buffer offsets
+  const int64_t nblocks = (B + mols_per_block - 1) / mols_per_block;
+  if (nblocks > 1024) return (int)hipErrorInvalidValue;
+  LoopArgs a;
+  const int rc = fill_loop_ops(ops, nops, F, a);
+  if (rc != 0) return rc;
+  a.plan = nullptr;
+  a.mol_ptr = mol_ptr; a.pair_ptr = pair_ptr; a.pair_flag = pair_flag;
+  a.nops = nops; a.R = (int)N; a.stagger = 0; a.pad = 0; a.nmol = (int)B; a.mols_per_block = mols_per_block;
+  const size_t lds = (size_t)3 * 8 * 2 * 1024 + (size_t)3 * 128 * sizeof(float) + (size_t)3 * 128 * sizeof(float);
+  allow_big_lds(&k_layer_loop<0>);
+  hipLaunchKernelGGL((k_layer_loop<0>), dim3((unsigned)nblocks), dim3(256), lds, stream, a);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

@@ -518,6 +518,7 @@ struct BwdLdsH {
   u32x4* tf;     // [CB][2][2][64]  t fragments: hidden-unit block x k-step x piece
   u32x4* rbf;    // [2][2][2][64]
   int* et;       // [CB] running exponent of each role-A wave's t fragments; [CB] = scratch word of the unstaged path
+  float* offs;   // [64] Gaussian centres, zero padded (the role-A waves rebuild the hidden row from them when T is not saved)
   // staging arrays, double buffered (buffer t & 1 serves tile t): written during the MFMA phase of tile t-1, read
   // only by the build of tile t
   static constexpr int STAGE_FLOATS = 2 * ATOM_CAP * AS + TR + 4 * TR + 4 + 8;  // xs, ds, tdd, desc (int4), flags, window maxima
@@ -534,12 +535,18 @@ struct BwdLdsH {
     tf = dOr + KC * 2 * 64;
     rbf = tf + CB * 2 * 2 * 64;
     et = reinterpret_cast<int*>(rbf + 2 * 2 * 2 * 64);
-    stage0 = reinterpret_cast<float*>(et + 8);
+    offs = reinterpret_cast<float*>(et + 8);
+    stage0 = offs + 64;
   }
-  static size_t bytes() { return (size_t)(KC * 2 + CB * 4 + 8) * 1024 + 32 + (size_t)2 * STAGE_FLOATS * 4; }
+  static size_t bytes() { return (size_t)(KC * 2 + CB * 4 + 8) * 1024 + 32 + 256 + (size_t)2 * STAGE_FLOATS * 4; }
 };
 
-template <int NW, bool ROLE_A>
+// RECOMP: T == nullptr - the hidden row t = ssp(W1 rbf(d) + b1) is not read back from HBM (the forward did not store it:
+// 0.96 GB written and read again per step at the bench size) but rebuilt by the role-A waves from the row's distance:
+// one K = 64 product per tile against the wave's W1 slice (held as B fragments), the Gaussians as A fragments in
+// registers - the forward kernel's arithmetic with the operand roles swapped (rows on M, hidden units on N), which
+// leaves t in the C layout the rest of the tile wants (lane = hidden unit, register = pair row).
+template <int NW, bool ROLE_A, bool RECOMP>
 __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair_d, const float* __restrict__ pair_c,
                                                 const uint8_t* __restrict__ pair_flag,
                                                 const int32_t* __restrict__ pair_i,
@@ -565,6 +572,37 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
 
   // ---- role A: W2 slice as B fragments of dt = dO W2:  B[k = c = 16ks + 8kh + e][n = h] = W2[c][h]
   Frag2 bw2[roleA ? KC : 1];
+  // role A, RECOMP: W1 slice as B fragments of u = rbf W1^T:  B[k = g = 16ks + 8kh + e][n = h] = W1[h][g], scaled to 2^14
+  Frag2 bw1[(roleA && RECOMP) ? 4 : 1];
+  float inv1 = 0.0f, b1v = 0.0f;
+  if constexpr (RECOMP) {
+    for (int i = tid; i < 64; i += NT) L.offs[i] = i < G ? offset[i] : 0.0f;  // (visible after the first tile barrier)
+    if constexpr (roleA) {
+      const float* w1 = w.w1[l] + (size_t)(32 * hs + j) * G;
+      float raw[4][8];
+      float wm = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int gg = 16 * ks + 8 * kh + e;
+          raw[ks][e] = gg < G ? w1[min(gg, G - 1)] : 0.0f;
+          wm = fmaxf(wm, fabsf(raw[ks][e]));
+        }
+      wm = wave_max(wm);
+      int e1;
+      const float s1 = pow2_scale_to_2p14(wm, e1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        float v8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v8[e] = raw[ks][e] * s1;
+        bw1[ks] = split8h(v8);
+      }
+      inv1 = 1.0f / (s1 * 16384.0f);  // a power of two: exact
+      b1v = w.b1[l][32 * hs + j];
+    }
+  }
   int e2 = 0, eL = 0;          // role A: exponents of max |W2 slice| and of its largest column L1 norm (bounds dt)
   f32x16 accw1[2];             // role A: dW1 rows [32hs, +32) x gaussians [0, 64): lane = g, register = h
   f32x16 accw2[roleA ? 1 : CB];  // role B: dW2 rows c of this wave's channel block (register) x all h (lane), per h block
@@ -684,11 +722,43 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
   };
   // saved hidden activation of this lane's hidden unit: role A in C layout (register r <-> row c_row(r)), role B in
   // B-fragment layout (k-step s, element e <-> row 16s + 8kh + e); rows past P are clamped (their dO is 0)
+  float dreq = 0.0f;  // RECOMP: distance of this lane's pair row of the tile whose hidden rows are rebuilt next
   auto request_t = [&](int tt) {
-    if constexpr (roleA) {
+    if constexpr (roleA && !RECOMP) {
       const int rr0 = tt * TR;
 #pragma unroll
       for (int r = 0; r < 16; ++r) tc[r] = Tl[(uint32_t)min(rr0 + c_row(r, lane), P - 1) * (uint32_t)F + tcol];
+    }
+    if constexpr (roleA && RECOMP) dreq = pair_d[min(tt * TR + j, P - 1)];
+  };
+  // RECOMP: the hidden rows of a tile for this wave's units, u = rbf(d) W1^T + b1, t = ssp(u) (schnet.py:141-145,205-207),
+  // into tc.  A operand = the Gaussians of row j (8 per k-step and half) built in registers - every role-A wave its own
+  // copy, one per SIMD.  Runs at the END of the wave's MFMA phase for the NEXT tile: role A finishes that phase first
+  // and would wait at the barrier (in-kernel marks: 2 k of a tile's 8.7 k cycles); inside the build phase, where the
+  // hidden rows are consumed, it sat on the tile's critical path (0.85 -> 0.99 ms per launch).
+  auto rebuild_t = [&](float dj) {
+    if constexpr (roleA && RECOMP) {
+      f32x16 au;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) au[r] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const f32x4 o0 = *reinterpret_cast<const f32x4*>(L.offs + 16 * ks + 8 * kh);
+        const f32x4 o1 = *reinterpret_cast<const f32x4*>(L.offs + 16 * ks + 8 * kh + 4);
+        const float o[8] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+        float g8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float diff = dj - o[e];
+          g8[e] = exp_neg(coeff * (diff * diff));  // (padded centres meet zero weights)
+        }
+        const Frag2 a = split8h_scaled(g8, 16384.0f);
+        au = mfma_f16(a.l, bw1[ks].h, au);
+        au = mfma_f16(a.h, bw1[ks].l, au);
+        au = mfma_f16(a.h, bw1[ks].h, au);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tc[r] = ssp(fmaf(au[r], inv1, b1v));
     }
   };
   // publish what was requested earlier as tile tt's staging buffer: role B the atom window (and its largest magnitudes),
@@ -759,6 +829,10 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
     decide(alo_a);
     request_atoms(t_begin, alo_a);
     request_t(t_begin);
+    if constexpr (RECOMP) {
+      lds_barrier();  // the Gaussian centres in LDS (block-uniform branch: every wave of the block takes it)
+      rebuild_t(dreq);
+    }
     publish(t_begin);
     if (t_begin + 1 < t_end) {
       alo_a = pair_i[(t_begin + 1) * TR];
@@ -977,6 +1051,7 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
         accw1[0] = mfma_f16(du[s].h, b0.h, accw1[0]);
         accw1[1] = mfma_f16(du[s].h, b1.h, accw1[1]);
       }
+      if (t + 1 < t_end) rebuild_t(dreq);  // the next tile's hidden rows (its distances were requested above)
     } else {
       // Role B wave w owns filter output channels c in [32w, 32w+32).  Its dO^T fragments (lane = c, 8 pair rows) come
       // from the dOr fragments through the matrix pipe: D = dOr_piece * I (I = 16 x 32 selection of the channel block)
@@ -1076,7 +1151,7 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
 
 // The two roles run separate instantiations of the body (their register sets differ: W2 fragments + dW1
 // accumulators against dW2 accumulators); the branch is wave-uniform and both sides execute the same barriers.
-template <int NW>
+template <int NW, bool RECOMP>
 __global__ __launch_bounds__(128 * NW) void k_filter_bwd_h(const float* __restrict__ pair_d,
                                                          const float* __restrict__ pair_c,
                                                          const uint8_t* __restrict__ pair_flag,
@@ -1095,10 +1170,10 @@ __global__ __launch_bounds__(128 * NW) void k_filter_bwd_h(const float* __restri
   P = dyn_count(P, dyn_P);
   N = dyn_count(N, dyn_N);
   if ((int)(threadIdx.x >> 6) < NW)
-    filter_bwd_body_h<NW, true>(pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, w, g, G, offset, coeff, T, partial_w1,
+    filter_bwd_body_h<NW, true, RECOMP>(pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, w, g, G, offset, coeff, T, partial_w1,
                               partial_b1, partial_w2, partial_b2, Pstride);
   else
-    filter_bwd_body_h<NW, false>(pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, w, g, G, offset, coeff, T, partial_w1,
+    filter_bwd_body_h<NW, false, RECOMP>(pair_d, pair_c, pair_flag, pair_i, pair_j, P, N, w, g, G, offset, coeff, T, partial_w1,
                                partial_b1, partial_w2, partial_b2, Pstride);
 }
 
@@ -1164,11 +1239,20 @@ extern "C" int geossl_cfconv_filter_bwd_dyn(const float* pair_d, const float* pa
 #define LAUNCH_H(NW)                                                                                               \
   do {                                                                                                             \
     const size_t lds = BwdLdsH<32 * NW>::bytes();                                                                  \
-    allow_big_lds(&k_filter_bwd_h<NW>);                                                                            \
-    hipLaunchKernelGGL((k_filter_bwd_h<NW>), grid, dim3(128 * NW), lds, stream, pair_d, pair_c, pair_flag, pair_i, \
-                       pair_j, (int)P, (int)N, *w, *g, G, offset, coeff, T, pw1, pb1, pw2, pb2, dyn_P, dyn_N);     \
+    if (T == nullptr) {                                                                                            \
+      allow_big_lds(&k_filter_bwd_h<NW, true>);                                                                    \
+      hipLaunchKernelGGL((k_filter_bwd_h<NW, true>), grid, dim3(128 * NW), lds, stream, pair_d, pair_c, pair_flag, \
+                         pair_i, pair_j, (int)P, (int)N, *w, *g, G, offset, coeff, T, pw1, pb1, pw2, pb2, dyn_P,   \
+                         dyn_N);                                                                                   \
+    } else {                                                                                                       \
+      allow_big_lds(&k_filter_bwd_h<NW, false>);                                                                   \
+      hipLaunchKernelGGL((k_filter_bwd_h<NW, false>), grid, dim3(128 * NW), lds, stream, pair_d, pair_c, pair_flag,\
+                         pair_i, pair_j, (int)P, (int)N, *w, *g, G, offset, coeff, T, pw1, pb1, pw2, pb2, dyn_P,   \
+                         dyn_N);                                                                                   \
+    }                                                                                                              \
   } while (0)
   const bool bf16x3 = getenv("GEOSSL_FILTER_BWD_BF16X3") != nullptr;  // (read per call: bench.py times both forms in one process)
+  if (bf16x3 && T == nullptr) return (int)hipErrorInvalidValue;  // (the three-piece form reads the saved hidden rows)
   if (!bf16x3) {
     if (F == 128) LAUNCH_H(4); else if (F == 64) LAUNCH_H(2); else LAUNCH_H(1);
   } else {

@@ -2,6 +2,7 @@
 stream).  Every function takes/returns CUDA tensors; nothing here computes on the host."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -11,6 +12,10 @@ from ._lib import call, ptr, stream
 from .layout import MolLayout, get_layout
 
 PI_F32 = float(torch.tensor(math.pi, dtype=torch.float32))
+# molecules of the (two-view) batch up to which ragged batches take the layer loop.  Same-box A/B on set B (trainer, one
+# bucket graph): 128 molecules per view +3.8 % (0.871 -> 0.839 ms), 256 +2 %, 512 -4 % (1.762 -> 1.840 ms) - a block's pass
+# lasts as long as the serial walks of its largest molecule, which the separate launches pay as well but rebalance
+RAGGED_LOOP_MAX_MOLS = 512
 
 
 def _f32(t):
@@ -224,9 +229,15 @@ def layer_loop(ops_list, layout, pair_flag, N, F, stagger=0):
     such path (the caller then launches them one by one).  The operation list is written as plain 64-bit words (a
     field-by-field ctypes fill of 14 operations cost more host time than the 14 calls it replaces)."""
     plan, nblk = layout.loop_plan()
-    if plan is None or F != 128 or not layout.uniform or layout.max_n > 20 or len(ops_list) > _lib.LOOP_MAX_OPS:
-        # (ragged batches: a kernel that holds every size class - waves of a block on different walks, large molecules
-        # shared by two or four waves - was measured at 650-670 us per pass against 470 us as separate launches)
+    # RAGGED molecules of a SMALL batch (the reference's batch sizes): every launch of the pass is then a 5 .. 9 us
+    # latency and the loop removes 13 of the 14; blocks of one or two molecules found from mol_ptr on the device (a
+    # capacity bucket's index structures are device data).  Beyond RAGGED_LOOP_MAX_MOLS the ragged loop loses to the
+    # separate launches (a block owns its molecules for the whole pass: 650-670 us per pass against 470 us at 2 x 1024
+    # molecules, DESIGN.md section 7) and is not used.
+    ragged = (plan is None and F == 128 and 1 < layout.max_n <= 33 and layout.B <= RAGGED_LOOP_MAX_MOLS
+              and not os.environ.get("GEOSSL_NO_RAGGED_LOOP") and len(ops_list) <= _lib.LOOP_MAX_OPS)
+    if not ragged and (plan is None or F != 128 or not layout.uniform or layout.max_n > 20
+                       or len(ops_list) > _lib.LOOP_MAX_OPS):
         return False
     words = [0] * (_LOOP_WORDS * len(ops_list))
     dp = lambda t_: 0 if t_ is None else t_.data_ptr()
@@ -249,6 +260,10 @@ def layer_loop(ops_list, layout, pair_flag, N, F, stagger=0):
             words[b], words[b + 1], words[b + 2], words[b + 3] = 1 | ((1 if swap else 0) << 32), x.data_ptr(), \
                 Wf_l.data_ptr(), out.data_ptr()
     arr = np.array(words, dtype=np.uint64)
+    if ragged:
+        call("geossl_schnet_layer_loop_ragged", arr.ctypes.data, len(ops_list), ptr(layout.mol_ptr), ptr(layout.pair_ptr),
+             ptr(pair_flag), layout.B, 1 if layout.B <= 512 else 2, N, F, stream())
+        return True
     call("geossl_schnet_layer_loop", arr.ctypes.data, len(ops_list), ptr(plan), nblk, ptr(layout.mol_ptr),
          ptr(layout.pair_ptr), ptr(pair_flag), layout.max_n, 1 if layout.uniform else 0, N, F, int(stagger), stream())
     return True

@@ -247,6 +247,14 @@ typedef struct {
 int geossl_schnet_layer_loop(const GeosslLoopOp* ops, int nops, const int32_t* plan, int nblocks, const int32_t* mol_ptr,
                              const int32_t* pair_ptr, const uint8_t* pair_flag, int max_n, int uniform, int64_t N, int F,
                              int stagger, hipStream_t stream);
+/* The same loop over RAGGED molecules (1 .. 33 atoms each) of a SMALL batch: block b owns `mols_per_block` (1 or 2)
+ * consecutive molecules, found from mol_ptr on the device - no host plan, so the launch also serves a capacity bucket
+ * (the `_dyn` section below), whose index structures are device data; every wave takes the unrolled walk of its
+ * molecule's size class.  B molecules in at most 1024 blocks.  N = rows of the atom tensors (a capacity is fine: no row
+ * past mol_ptr[B] is touched).  Results bit-identical to the separate launches. */
+int geossl_schnet_layer_loop_ragged(const GeosslLoopOp* ops, int nops, const int32_t* mol_ptr, const int32_t* pair_ptr,
+                                    const uint8_t* pair_flag, int64_t B, int mols_per_block, int64_t N, int F,
+                                    hipStream_t stream);
 
 /* batched weight gradients: dW_z[m][n] (+)= sum_r A_z[r][m]*B_z[r][n], db_z[m] (+)= sum_r A_z[r][m];
  * lda / ldb / ldw: row strides of A_z, B_z, dW_z (M, N <= 128 per problem: wider layers are tiled by the caller)  */

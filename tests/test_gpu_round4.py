@@ -513,3 +513,26 @@ def test_stock_adam_hook_steps_aside_for_what_it_does_not_know():
     for x, y in zip(a[0], b[0]):
         assert abs(x - y) <= 1e-6 * abs(y)
     assert rel_err(b[1], a[1]) < 1e-6
+
+
+def test_filter_backward_rebuilds_the_hidden_rows_when_they_were_not_saved(monkeypatch):
+    """GEOSSL_FILTER_RECOMPUTE_T: the forward stores Wf only and geossl_cfconv_filter_bwd (T = NULL) rebuilds
+    t = ssp(W1 rbf(d) + b1) per tile - the same gradients as from the saved rows (fp32 rounding apart), on a ragged batch
+    whose tiles straddle molecules and end in a partial tile."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    b = make_batch(40, seed=21, sizes=_ragged_sizes(40, 21))
+    batch = pg.Batch.from_numpy(b, DEV)
+    noise = {k: t(v, DEV) for k, v in draw_noise(b, seed=22).items()}
+    grads = {}
+    for mode in ("saved", "rebuilt"):
+        if mode == "rebuilt":
+            monkeypatch.setenv("GEOSSL_FILTER_RECOMPUTE_T", "1")
+        model = product_schnet(FULL, DEV)
+        heads = (product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9))
+        loss, _ = pg.do_DDM(pg.Args("schnet"), batch, model, NCSN_models=heads, noise=noise, graph=False)
+        loss.backward()
+        grads[mode] = (float(loss), {k: v.clone() for k, v in unique_named_grads(model).items()})
+    assert grads["saved"][0] == grads["rebuilt"][0]                      # (the forward does not change)
+    for k, v in grads["saved"][1].items():
+        assert rel_err(grads["rebuilt"][1][k], v) < 2e-6, k
