@@ -122,6 +122,99 @@ __device__ __forceinline__ void aggregate_reg_body(const float* __restrict__ x, 
     if (i < n && has_cols) *reinterpret_cast<V*>(out + (size_t)(a0 + i) * F + f) = acc[i];
 }
 
+// ---------------------------------------------------------------------------------------- K4, block form
+// ONE molecule (1 .. 33 atoms) aggregated by the FOUR waves of a block (the layer loop over the ragged molecules of a
+// small batch, chain.hip: k_layer_loop<0>, where a block owns one molecule and three of its waves would watch the
+// fourth walk n(n-1)/2 pair slots): wave w forms the sums of the target atoms a = w, w + 4, ...; a lane owns two
+// adjacent feature columns (F = 128).  For a target the filter rows of ALL its partners b != a are requested at once
+// (at most 32: one memory round trip per target, the next target's requests issued before this one's sums) and added in
+// ascending source order with separate multiply and add - the rounding sequence of the walks above: bit-identical.
+// A filter row is read by both of its atoms' waves (through L2).  No size classes, no unrolled walks: the molecule's
+// rows of x sit in LDS (`smem`: 33 x 128 floats + 528 flag bytes; the caller's block barrier follows).
+__device__ __forceinline__ void aggregate_block_body(const float* __restrict__ x, const float* __restrict__ Wf,
+                                                     const uint8_t* __restrict__ pair_flag, int a0, int n, int base,
+                                                     int swap, float* __restrict__ out, uint8_t* smem) {
+#pragma clang fp contract(off)
+  typedef f32x2 V;
+  constexpr int F = 128, NP = 32;  // partners of a target: n - 1 <= 32
+  float* xs = reinterpret_cast<float*>(smem);   // [n][F]
+  uint8_t* fls = smem + 33 * F * sizeof(float);  // [n(n-1)/2] edge flags (exchanged when swap)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nu = __builtin_amdgcn_readfirstlane(n), np = nu * (nu - 1) / 2;
+  for (int i = tid; i < nu * (F / 4); i += 256) {
+    const int row = i >> 5, q = i & 31;
+    *reinterpret_cast<f32x4*>(xs + row * F + 4 * q) = *reinterpret_cast<const f32x4*>(x + (size_t)(a0 + row) * F + 4 * q);
+  }
+  for (int p = tid; p < np; p += 256) {
+    unsigned fl = pair_flag[base + p];
+    if (swap) fl = ((fl & 1u) << 1) | ((fl >> 1) & 1u);
+    fls[p] = (uint8_t)fl;
+  }
+  __syncthreads();
+  const float* __restrict__ wcol = Wf + (size_t)base * F + 2 * lane;
+  const float* xl = xs + 2 * lane;
+  // per target: lane u < n - 1 describes partner b = u + (u >= a): its pair slot and whether b sends to a
+  int slot_l = 0, b_l = 0;
+  unsigned long long mask = 0ull;
+  auto describe = [&](int a) {
+    const int u = lane < nu - 1 ? lane : 0;
+    const int b = u + (u >= a ? 1 : 0);
+    const int i = min(a, b), j = max(a, b);
+    slot_l = nu > 1 ? i * nu - i * (i + 1) / 2 + (j - i - 1) : 0;
+    b_l = nu > 1 ? b : 0;
+    const unsigned fl = nu > 1 ? (unsigned)fls[slot_l] : 0u;
+    const bool sends = lane < nu - 1 && ((a < b ? (fl & 1u) : (fl & 2u)) != 0u);   // pair (i < j): bit 0 = j -> i, bit 1 = i -> j
+    mask = __builtin_amdgcn_ballot_w64(sends);
+  };
+  auto request = [&](V (&w)[NP]) {
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int s = __builtin_amdgcn_readlane(slot_l, u);  // (lanes past the partner count repeat partner 0: clamped, dropped below)
+      w[u] = __builtin_nontemporal_load(reinterpret_cast<const V*>(wcol + (size_t)s * F));
+    }
+  };
+  auto reduce = [&](const V (&w)[NP], int a, unsigned long long m, int bl) {
+    V acc = V(0.0f);
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int b = __builtin_amdgcn_readlane(bl, u);
+      const V xb = *reinterpret_cast<const V*>(xl + b * F);
+      const V t = xb * w[u];
+      const V s = acc + t;
+      acc = ((m >> u) & 1ull) ? s : acc;
+    }
+    *reinterpret_cast<V*>(out + (size_t)(a0 + a) * F + 2 * lane) = acc;
+  };
+  // two targets in flight: the requests of target a + 4 are issued before the sums of target a are formed
+  V w0[NP], w1[NP];
+  int a = wave;
+  if (a < nu) {
+    describe(a);
+    request(w0);
+  }
+  while (a < nu) {
+    const unsigned long long m0 = mask;
+    const int bl0 = b_l;
+    const int an = a + 4;
+    if (an < nu) {
+      describe(an);
+      request(w1);
+    }
+    reduce(w0, a, m0, bl0);
+    if (an >= nu) break;
+    const unsigned long long m1 = mask;
+    const int bl1 = b_l;
+    const int an2 = an + 4;
+    if (an2 < nu) {
+      describe(an2);
+      request(w0);
+    }
+    reduce(w1, an, m1, bl1);
+    a = an2;
+  }
+}
+
 // One TARGET GROUP of a large molecule: the walk of aggregate_reg_body restricted to the positions that touch a target
 // atom in [G0, G1) = part P of K equal parts of the size class - rows a < G0 only at their partners b in the group
 // (edge a -> b), rows a in the group at all their partners.  Every sum of a target is still formed by one wave in

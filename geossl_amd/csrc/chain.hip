@@ -882,12 +882,12 @@ struct LoopArgs {
   int nmol, mols_per_block;  // ragged form (NMAX = 0): block b owns molecules [b * mols_per_block, ...) of nmol
 };
 
-// NMAX > 0: uniform batch, blocks from the host's plan, the walk of one size class.  NMAX = 0: RAGGED molecules
-// (1 .. 33 atoms) of a small batch - block b owns `mols_per_block` (1 or 2: at most 66 atom rows = three row blocks)
-// consecutive molecules, found from mol_ptr on the device (no host plan: the loop then also serves a capacity bucket,
-// whose index structures are device data); every wave takes the unrolled walk of its molecule's size class.  At 1024
-// molecules per view this form loses to the separate launches (a block owns its molecules for a whole pass, 14
-// launches rebalance 14 times: DESIGN.md section 7); at the reference's batch size every launch of the pass is a
+// NMAX > 0: uniform batch, blocks from the host's plan, the walk of one size class (a wave per molecule).  NMAX = 0:
+// RAGGED molecules (1 .. 33 atoms) of a small batch - block b owns `mols_per_block` (1 or 2: at most 66 atom rows =
+// three row blocks) consecutive molecules, found from mol_ptr on the device (no host plan: the loop then also serves a
+// capacity bucket, whose index structures are device data), and aggregates each with all four waves
+// (aggregate_block_body).  At 1024 molecules per view a block-owns-its-molecules loop loses to the separate launches
+// (14 launches rebalance 14 times: DESIGN.md section 7); at the reference's batch size every launch of the pass is a
 // 5 .. 9 us latency and the loop is what removes them.
 template <int NMAX>
 __global__ __launch_bounds__(256, 2) void k_layer_loop(LoopArgs a) {
@@ -916,14 +916,17 @@ __global__ __launch_bounds__(256, 2) void k_layer_loop(LoopArgs a) {
     } else {
       for (int mm = pl.z + wave; mm < pl.w; mm += 4) {
         const int a0 = a.mol_ptr[mm], n = a.mol_ptr[mm + 1] - a0, base = a.pair_ptr[mm];
-        if constexpr (NMAX > 0) {
+        if constexpr (NMAX > 0)
           aggregate_reg_body<NMAX>(op.X, op.Wf, a.pair_flag, a0, n, base, lane, 2 * lane, F, op.swap, op.out);
-        } else {
-          const int nu = __builtin_amdgcn_readfirstlane(n);
-#define LOOP_CLASS(NM) if (nu <= NM) aggregate_reg_body<NM>(op.X, op.Wf, a.pair_flag, a0, n, base, lane, 2 * lane, F, op.swap, op.out); else
-          LOOP_CLASS(8) LOOP_CLASS(12) LOOP_CLASS(16) LOOP_CLASS(18) LOOP_CLASS(20) LOOP_CLASS(22) LOOP_CLASS(24)
-          LOOP_CLASS(26) LOOP_CLASS(28) LOOP_CLASS(30) LOOP_CLASS(33) {}
-#undef LOOP_CLASS
+      }
+      if constexpr (NMAX == 0) {
+        // ragged form: the block's molecules one after the other, each by all four waves (aggregate_block_body: a wave
+        // sums the target atoms w, w + 4, ... - no wave waits for another one's serial walk)
+        extern __shared__ __attribute__((aligned(16))) uint8_t loop_smem[];
+        for (int mm = pl.z; mm < pl.w; ++mm) {
+          const int a0 = a.mol_ptr[mm], n = a.mol_ptr[mm + 1] - a0, base = a.pair_ptr[mm];
+          if (mm > pl.z) __syncthreads();  // (the staging area is reused)
+          aggregate_block_body(op.X, op.Wf, a.pair_flag, a0, n, base, op.swap, op.out, loop_smem);
         }
       }
     }

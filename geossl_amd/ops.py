@@ -13,9 +13,12 @@ from .layout import MolLayout, get_layout
 
 PI_F32 = float(torch.tensor(math.pi, dtype=torch.float32))
 # molecules of the (two-view) batch up to which ragged batches take the layer loop.  Same-box A/B on set B (trainer, one
-# bucket graph): 128 molecules per view +3.8 % (0.871 -> 0.839 ms), 256 +2 %, 512 -4 % (1.762 -> 1.840 ms) - a block's pass
-# lasts as long as the serial walks of its largest molecule, which the separate launches pay as well but rebalance
-RAGGED_LOOP_MAX_MOLS = 512
+# bucket graph), loop against separate launches: 128 molecules per view 0.865 -> 0.820 ms (+5.5 %), 256 1.18 -> 1.23 ms,
+# 512 1.75 -> 2.06 ms: with one block per molecule an operation of the loop is a 9 us chain of dependent round trips
+# (weights from L2, rows through L2 between operations) whatever the batch, and from 256 molecules per view on the
+# separate launches fill the chip better.  (First form, every wave the unrolled walk of its molecule's size class: 0.839
+# ms at 128 with 31 spilled registers; the block form above has none.)
+RAGGED_LOOP_MAX_MOLS = int(os.environ.get("GEOSSL_RAGGED_LOOP_MAX", 256))
 
 
 def _f32(t):
