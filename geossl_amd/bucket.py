@@ -149,6 +149,39 @@ def capacities(N, P, S, W, B, prev=None):
     return tuple(out)
 
 
+def host_plan(sizes, option):
+    """Everything of a batch's index structures that is a function of the molecule sizes alone, as numpy arrays - the part
+    of a bucket fill that runs on the host (and is tested without a GPU): counts (N, P, S, W); mol_ptr / pair_ptr of the
+    TWO-VIEW batch ([2B + 1], view 1 behind view 0); se_ptr [B + 1]; the aggregation's work list over the 2B molecules
+    (largest first, stable; 27 .. 33-atom molecules as 2 or 4 items: molecule | part << 28); the divisor of NCSN.py:210-212
+    (last molecule with a super-edge, + 1); inc_ptr [N + 1] (an atom of an n-atom molecule lies on n - 1 tuples of the
+    "combination" enumeration, 2 (n - 1) of "permutation")."""
+    global _PARTS
+    if _PARTS is None:
+        _PARTS = _parts_table()
+    n = sizes if isinstance(sizes, np.ndarray) else np.asarray(sizes, dtype=np.int64)
+    B = n.shape[0]
+    N, P, S, W = batch_counts(n, option)
+    mult = 1 if option == "combination" else 2
+    mp = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum(n, out=mp[1:])
+    npair = n * (n - 1) // 2
+    pp = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum(npair, out=pp[1:])
+    n2 = np.concatenate([n, n])
+    idx = np.argsort(-n2, kind="stable")
+    parts = _PARTS[n2][idx]
+    mol = np.repeat(idx, parts)
+    ends = np.cumsum(parts)
+    part = np.arange(int(ends[-1]), dtype=np.int64) - np.repeat(ends - parts, parts)
+    has = np.nonzero(npair > 0)[0]
+    ip = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(np.repeat((n - 1) * mult, n), out=ip[1:])
+    return dict(counts=(N, P, S, W), mol_ptr2=np.concatenate([mp, mp[1:] + N]), pair_ptr2=np.concatenate([pp, pp[1:] + P]),
+                se_ptr=pp * mult, work=(mol | (part << 28)).astype(np.int32), divisor=int(has[-1]) + 1 if has.size else 0,
+                inc_ptr=ip)
+
+
 class Bucket:
     def __init__(self, device, B, caps, option, x_cols=2):
         from .pretrain_GeoSSL import Batch
@@ -228,34 +261,15 @@ class Bucket:
         if slot[1] is not None:
             slot[1].synchronize()   # the upload that last read this staging buffer (three steps ago)
         h = slot[0].numpy()
+        hp = host_plan(n, self.option)
         h[0:8] = (N, 2 * N, 2 * P, S, W, B, 0, 0)
-        mp = np.zeros(B + 1, dtype=np.int64)
-        np.cumsum(n, out=mp[1:])
-        npair = n * (n - 1) // 2
-        pp = np.zeros(B + 1, dtype=np.int64)
-        np.cumsum(npair, out=pp[1:])
-        h[o["mol_ptr"]:o["mol_ptr"] + B + 1] = mp
-        h[o["mol_ptr"] + B + 1:o["mol_ptr"] + 2 * B + 1] = mp[1:] + N
-        h[o["pair_ptr"]:o["pair_ptr"] + B + 1] = pp
-        h[o["pair_ptr"] + B + 1:o["pair_ptr"] + 2 * B + 1] = pp[1:] + P
-        mult = 1 if self.option == "combination" else 2
-        h[o["se_ptr"]:o["se_ptr"] + B + 1] = pp * mult
-        # work list of the aggregation over the 2B molecules of both views: largest first (stable), the 27..33-atom
-        # molecules as 2 or 4 items (layout.MolLayout.agg_work)
-        n2 = np.concatenate([n, n])
-        idx = np.argsort(-n2, kind="stable")
-        parts = _PARTS[n2][idx]
-        mol = np.repeat(idx, parts)
-        ends = np.cumsum(parts)
-        part = np.arange(int(ends[-1]), dtype=np.int64) - np.repeat(ends - parts, parts)
-        h[o["work"]:o["work"] + W] = (mol | (part << 28)).astype(np.int32)
-        # NCSN.py:210-212: loss.mean() divides by max(edge2graph) + 1 = the last molecule with a super-edge, + 1
-        has = np.nonzero(npair > 0)[0]
+        h[o["mol_ptr"]:o["mol_ptr"] + 2 * B + 1] = hp["mol_ptr2"]
+        h[o["pair_ptr"]:o["pair_ptr"] + 2 * B + 1] = hp["pair_ptr2"]
+        h[o["se_ptr"]:o["se_ptr"] + B + 1] = hp["se_ptr"]
+        h[o["work"]:o["work"] + W] = hp["work"]
         st = h[o["stats"]:o["stats"] + 4].view(np.int64)
-        st[0], st[1] = int(has[-1]) + 1, 0
-        ip = h[o["inc_ptr"]:o["inc_ptr"] + 2 * (N + 1)].view(np.int64)
-        ip[0] = 0
-        np.cumsum(np.repeat((n - 1) * mult, n), out=ip[1:])
+        st[0], st[1] = hp["divisor"], 0
+        h[o["inc_ptr"]:o["inc_ptr"] + 2 * (N + 1)].view(np.int64)[:] = hp["inc_ptr"]
         self.blob.copy_(slot[0], non_blocking=True)
         slot[1] = torch.cuda.Event()
         slot[1].record()

@@ -409,3 +409,70 @@ def test_layer_loop_block_plan():
     assert loop_block_plan([]) is None
     p = loop_block_plan([7] * 6000)                        # small molecules: 12 per block = 84 rows, 500 blocks
     assert p.shape == (500, 4) and int((p[:, 1] - p[:, 0]).max()) == 84
+
+
+# ------------------------------------------------------------------------------------- capacity buckets, host side
+def test_bucket_host_plan_matches_the_collated_batch():
+    """bucket.host_plan: everything of a batch's index structures that is a function of the molecule sizes, against what
+    the collation itself produces (synthetic.make_batch: AtomTupleExtractor's enumeration with node offsets) and the
+    oracle's pair-slot order - pointer arrays of the two-view batch, se_ptr, the incidence counts behind inc_ptr, the
+    divisor of NCSN.py:210-212, and an aggregation work list that covers every (molecule, part) once, largest first."""
+    from geossl_amd import bucket as bk
+    from geossl_amd._lib import load
+    from geossl_amd.synthetic import make_batch
+    lib = load()
+    for option in ("combination", "permutation"):
+        sizes = np.array([5, 33, 1, 18, 27, 2, 30, 1, 9, 31, 20, 1], dtype=np.int64)   # (trailing single atom: divisor B - 1)
+        b = make_batch(len(sizes), seed=3, sizes=sizes, option=option)
+        hp = bk.host_plan(sizes, option)
+        N, P, S, W = hp["counts"]
+        B = len(sizes)
+        assert N == b["x"].shape[0] and S == b["super_edge_index"].shape[1] and P == int((sizes * (sizes - 1) // 2).sum())
+        off = np.concatenate([[0], np.cumsum(sizes)])
+        assert np.array_equal(hp["mol_ptr2"], np.concatenate([off, off[1:] + N]))
+        poff = np.concatenate([[0], np.cumsum(sizes * (sizes - 1) // 2)])
+        assert np.array_equal(hp["pair_ptr2"], np.concatenate([poff, poff[1:] + P]))
+        e2g = b["batch"][b["super_edge_index"][0]]
+        assert np.array_equal(np.diff(hp["se_ptr"]), np.bincount(e2g, minlength=B)) and hp["divisor"] == int(e2g.max()) + 1
+        deg = np.bincount(b["super_edge_index"].reshape(-1), minlength=N)
+        assert np.array_equal(np.diff(hp["inc_ptr"]), deg) and hp["inc_ptr"][0] == 0
+        mol, part = hp["work"] & 0x0FFFFFFF, (hp["work"].astype(np.int64) >> 28) & 7
+        assert len(mol) == W
+        n2 = np.concatenate([sizes, sizes])
+        want = sorted((m, k) for m in range(2 * B) for k in range(lib.geossl_aggregate_parts(int(n2[m]))))
+        assert sorted(zip(mol.tolist(), part.tolist())) == want
+        assert np.all(np.diff(n2[mol]) <= 0)                                        # largest molecules first
+
+
+def test_bucket_capacities_and_eligibility():
+    """Capacities cover the batch with slack, are multiples of the kernels' tiles and never shrink; only batches whose
+    index tensors are a function of the sizes (host sizes + the extractor's full enumeration, molecules of <= 33 atoms)
+    go through a bucket, and equal-sized molecules keep their per-structure graph."""
+    import types
+    from geossl_amd import bucket as bk
+    from geossl_amd import pretrain_GeoSSL as pg
+    caps = bk.capacities(18000, 160000, 160000, 2100, B=1024)
+    assert all(c >= v * 1.03 for c, v in zip(caps, (18000, 160000, 160000, 2100)))
+    assert caps[0] % 32 == 0 and caps[1] % 64 == 0 and caps[2] % 64 == 0
+    grown = bk.capacities(17000, 170000, 150000, 2000, B=1024, prev=caps)
+    assert all(g >= c for g, c in zip(grown, caps)) and grown[1] >= 170000 * 1.03
+    small = bk.capacities(2300, 20000, 20000, 260, B=128)
+    assert small[0] >= 2300 * 1.13                                                   # 1.5 / sqrt(128) of slack
+
+    pos = types.SimpleNamespace(is_cuda=True, dtype=torch.float32)
+    x = types.SimpleNamespace(dim=lambda: 2)
+
+    def batch(sizes, canon="combination"):
+        return types.SimpleNamespace(_sizes=sizes, _canonical=canon, positions=pos, x=x)
+
+    assert bk.eligible(batch([18, 20, 2]), "schnet") and not bk.is_uniform(batch([18, 20, 2]))
+    assert bk.is_uniform(batch([18] * 5))
+    assert not bk.eligible(batch([18, 34]), "schnet")                                # beyond the register aggregation's classes
+    assert not bk.eligible(batch([18, 20], canon=None), "schnet")                    # sampled tuples: not a function of the sizes
+    assert not bk.eligible(batch([18, 20]), "painn") and not bk.eligible(batch([18, 20]), "schnet", normalize=True)
+    assert not bk.eligible(batch([1, 1, 1]), "schnet")                               # no pair at all
+    # routing of StepGraphs without a GPU: auto mode buckets ragged batches only when the modules allow it
+    sg = pg.StepGraphs(lambda b, n: None, "schnet", modules=None)
+    assert sg.bucket_key(batch([18, 20, 2])) is None                                 # (no modules known: no bucket)
+    sg2 = pg.StepGraphs(lambda b, n: None, "schnet", mode="structure", modules=None)
+    assert sg2.capture_now(batch([18, 20, 2]))                                       # structure mode: capture at first sight
