@@ -536,3 +536,29 @@ def test_filter_backward_rebuilds_the_hidden_rows_when_they_were_not_saved(monke
     assert grads["saved"][0] == grads["rebuilt"][0]                      # (the forward does not change)
     for k, v in grads["saved"][1].items():
         assert rel_err(grads["rebuilt"][1][k], v) < 2e-6, k
+
+
+def test_bucket_graph_with_the_permutation_enumeration_and_the_switch_that_turns_buckets_off(monkeypatch):
+    """AtomTupleExtractor(option="permutation") (dataloaders_AtomTuple.py:19-20: both orders of every pair, twice the
+    super-edges and incidence entries) through a bucket graph; and GEOSSL_NO_BUCKETS, under which ragged batches go back to
+    per-structure graphs from their second sighting on."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    B = 10
+    raw = [make_batch(B, seed=700 + i, sizes=_ragged_sizes(B, 70 + i, hi=20), option="permutation") for i in range(3)]
+    raw.sort(key=lambda b: -b["super_edge_index"].shape[1])
+    noise = [{k: t(v, DEV) for k, v in draw_noise(b, seed=800 + i).items()} for i, b in enumerate(raw)]
+    tr, tp = _trainer(use_graph=True), _trainer(use_graph=False)
+    for b, nz in zip(raw, noise):
+        bt = pg.Batch.from_numpy(b, DEV)
+        assert bt._canonical == "permutation"
+        a, c = float(tr.step(bt, nz)), float(tp.step(pg.Batch.from_numpy(b, DEV), nz))
+        assert abs(a - c) <= 2e-6 * abs(c), (a, c)
+    assert tr.step_graphs.captures == 1 and _bucket_of(tr).option == "permutation"
+    assert rel_err(tr.flat.flat, tp.flat.flat) < 1e-5
+    monkeypatch.setenv("GEOSSL_NO_BUCKETS", "1")
+    tr2 = _trainer(use_graph=True)
+    for rep in range(2):
+        for b, nz in zip(raw, noise):
+            tr2.step(pg.Batch.from_numpy(b, DEV), nz)
+    assert tr2.step_graphs.captures == 3 and all(not (isinstance(k, tuple) and k[0] == "bucket") for k in tr2._graphs)
