@@ -726,8 +726,17 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
   auto request_t = [&](int tt) {
     if constexpr (roleA && !RECOMP) {
       const int rr0 = tt * TR;
+      if (rr0 + TR <= P) {
+        // a whole tile: row c_row(r) = (r & 3) + 8 (r >> 2) + 4 kh - register r is a constant number of rows behind the
+        // lane's first row, so the sixteen requests share four bases and carry their offsets as immediates (as sixteen
+        // clamped per-lane addresses they were ~50 vector instructions of a role-A wave's ~400 per tile)
+        const float* tb = Tl + (size_t)(rr0 + 4 * kh) * F + tcol;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tc[r] = Tl[(uint32_t)min(rr0 + c_row(r, lane), P - 1) * (uint32_t)F + tcol];
+        for (int r = 0; r < 16; ++r) tc[r] = tb[((r & 3) + 8 * (r >> 2)) * F];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tc[r] = Tl[(uint32_t)min(rr0 + c_row(r, lane), P - 1) * (uint32_t)F + tcol];
+      }
     }
     if constexpr (roleA && RECOMP) dreq = pair_d[min(tt * TR + j, P - 1)];
   };
@@ -952,11 +961,14 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
         const int ln = it & 63, ks = (it >> 6) & 1, gb = it >> 7;
         const int gg = 32 * gb + (ln & 31);
         const float off = gg < G ? offset[gg] : 0.0f;
+        // column 63 (free whenever G < 64) is a column of ONES: dW1[:, 63] = sum over the rows of dU = db1, formed by the
+        // matrix pipe with the rest of dW1 instead of sixteen vector adds per role-A wave and tile
+        const float pad = (gg == 63 && G < 64) ? 1.0f : 0.0f;
         float u8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float diff = L.tdd(bsel)[16 * ks + kperm(e, ln >> 5)] - off;
-          u8[e] = gg < G ? exp_neg(coeff * (diff * diff)) : 0.0f;
+          u8[e] = gg < G ? exp_neg(coeff * (diff * diff)) : pad;
         }
         const Frag2 f = split8h_scaled(u8, 16384.0f);  // Gaussians are <= 1: fixed scale 2^14
         u32x4* dst = L.rbf + (size_t)((gb * 2 + ks) * 2) * 64 + ln;
@@ -1023,18 +1035,19 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
       // dU = dt * ssp'(pre) (C layout: lane = hidden unit, register = pair row); registers 0..7 / 8..15 are the
       // elements of k-steps 0 / 1 of the contraction over pair rows
       // acc holds (2^(14-EO) dO)(2^(14-e2) W2); |dt| <= 2^EO * (largest column L1 norm of the W2 slice) < 2^(EO+eL)
-      const float kdt = __builtin_amdgcn_ldexpf(1.0f, EO + e2 - 28), sU = __builtin_amdgcn_ldexpf(1.0f, 14 - EO - eL);
+      // dU = acc kdt ssp'(.) with kdt = 2^(EO + e2 - 28); the split wants dU 2^(14 - EO - eL): both powers of two, folded
+      // into ONE scale 2^(e2 - eL - 14) of the split (exact), so the product with kdt is never formed
+      const float kdt = __builtin_amdgcn_ldexpf(1.0f, EO + e2 - 28), sUk = __builtin_amdgcn_ldexpf(1.0f, e2 - eL - 14);
       Frag2 du[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         float u8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float dU = (acc0[8 * s + e] * kdt) * dssp_from_out(tcur[8 * s + e]);
-          bsum1 += dU;
-          u8[e] = dU;
+          u8[e] = acc0[8 * s + e] * dssp_from_out(tcur[8 * s + e]);
+          if (G >= 64) bsum1 = fmaf(u8[e], kdt, bsum1);  // (no free column for the ones: the bias sum on the vector unit)
         }
-        du[s] = split8h_scaled(u8, sU);
+        du[s] = split8h_scaled(u8, sUk);
       }
       FBH_MARK(6);
       // dW1[h][g] += sum_rows dU[row][h] * rbf(d_row)[g]
@@ -1133,8 +1146,16 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
         for (int r = 0; r < 16; ++r) Pw[(size_t)(32 * hs + c_row(r, lane)) * G + gg] = accw1[gb][r] * kw1;
       }
     }
-    const float s = bsum1 + __shfl_xor(bsum1, 32, 64);
-    if (kh == 0) partial_b1[pb * F + 32 * hs + j] = s;
+    if (G < 64) {
+      // db1 = column 63 of the dW1 accumulator (the ones column of the Gaussian fragments): lane j = 31 of block 1
+      if (j == 31) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) partial_b1[pb * F + 32 * hs + c_row(r, lane)] = accw1[1][r] * kw1;
+      }
+    } else {
+      const float s = bsum1 + __shfl_xor(bsum1, 32, 64);
+      if (kh == 0) partial_b1[pb * F + 32 * hs + j] = s;
+    }
   } else {
     float* Pw = partial_w2 + pb * F * F;
 #pragma unroll
