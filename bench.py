@@ -544,16 +544,22 @@ def forward_only(args, dev, rank, world, emit=True):
                   graph=False, n_batches=max(1, min(args.max_batches, args.warmup + args.steps)))
     model, batches, n_batches = wl.model, wl.batches, wl.n_batches
     if args.forces:
-        for p_ in model.parameters():
+        # the energy head of the finetuning script (graph_pred_linear, finetune_md17.py:38-44) on the HIP GEMM; the sign
+        # of pred_force = -grad(E, positions, grad_outputs=ones) (:46) rides on grad_outputs: no arithmetic outside the
+        # library's kernels in the step
+        from geossl_amd.Geom3D.models.painn import Dense
+        torch.manual_seed(11)
+        head = Dense(F, 1).to(dev)
+        for p_ in list(model.parameters()) + list(head.parameters()):
             p_.requires_grad_(False)
-        wvec = torch.cos(torch.arange(F, dtype=torch.float32, device=dev))
+        minus_one = torch.full((args.mols, 1), -1.0, device=dev)
 
     def fwd(i):
         bt = batches[i % n_batches]
         if args.forces:
             pos = bt.positions.detach().requires_grad_(True)
-            energy = (model(bt.x[:, 0], pos, bt.batch) * wvec).sum(dim=1)
-            return -torch.autograd.grad(energy, pos, torch.ones_like(energy))[0]
+            energy = head(model(bt.x[:, 0], pos, bt.batch))
+            return torch.autograd.grad(energy, pos, minus_one)[0]
         with torch.no_grad():
             return model(bt.x[:, 0], bt.positions, bt.batch)
 

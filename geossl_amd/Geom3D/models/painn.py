@@ -38,11 +38,12 @@ class Dense(nn.Linear):
     def forward(self, input):
         """painn_utils.py:31-35 for stand-alone use (the energy head of create_output_layers(); inside PaiNN the Dense
         layers run in the fused node): the product on the HIP row GEMM, differentiable to any order."""
-        from ...higher_order import _linear_wide
+        from ...higher_order import _linear_wide, _silu
         _lib.require_cuda(input)
         lead = input.shape[:-1]
-        y = _linear_wide(input.reshape(-1, input.shape[-1]), self.weight, self.bias)
-        return self.activation(y).reshape(*lead, self.out_features)
+        y = _linear_wide(input.reshape(-1, input.shape[-1]), self.weight, self.bias)  # bias in the GEMM's epilogue
+        act = _silu if self.activation is F.silu else self.activation       # (F.silu: geossl_silu_fwd / _bwd)
+        return act(y).reshape(*lead, self.out_features)
 
 
 class GaussianRBF(nn.Module):
@@ -162,20 +163,8 @@ class PaiNN(nn.Module):
             raise NotImplementedError("HIP path implements the reference default activation F.silu")
         atomic_numbers = x[:, 0] if x.dim() == 2 else x  # painn.py:226-229
         lay = get_layout(batch)
-        if positions.requires_grad and torch.is_grad_enabled():
-            # forces / training on forces (finetune_md17.py:38-54): the fused kernels have no position gradient; the
-            # forward runs as a graph of differentiable primitives instead (Dense layers on the HIP GEMMs)
-            from ...higher_order import painn_atom_features
-            cfg = dict(F=self.n_atom_basis, L=self.n_interactions, cutoff=float(self.cutoff),
-                       offsets=self.radial_basis.offsets, widths=self.radial_basis.widths,
-                       eps=float(self.mixing[0].epsilon))
-            if positions.dtype != torch.float32:
-                raise TypeError("positions must be float32")
-            q = painn_atom_features(atomic_numbers, positions, radius_edge_index[0], radius_edge_index[1], cfg,
-                                    self._params())
-            from .schnet import _SegmentReduce
-            h = _SegmentReduce.apply(q, lay, self.readout)
-            return (h, q) if return_latent else h
+        if positions.dtype != torch.float32:
+            raise TypeError("positions must be float32")
         el = get_edge_layout(batch, radius_edge_index, lay.B)
         status = _lib.module_status(self, positions.device, "atomic number out of range for the embedding table "
                                     "(max_z=%d)" % self.embedding.num_embeddings)
@@ -208,9 +197,8 @@ class _PaiNNCore(torch.autograd.Function):
         F_, L, R = cfg["F"], cfg["L"], cfg["R"]
         dev, N, E = pos.device, pos.size(0), el.E
         st = stream()
-        if ctx.needs_input_grad[1]:
-            raise NotImplementedError("PaiNN: gradient w.r.t. positions is not built (SchNet has it, first order)")
-        training = any(ctx.needs_input_grad[4:])
+        want_params = any(ctx.needs_input_grad[4:])
+        training = want_params or ctx.needs_input_grad[1]  # positions: forces (finetune_md17.py:46)
         ps = [p.detach().contiguous() for p in params]
         emb_w, fw, fb = ps[0], ps[1], ps[2]
         inter = [ps[3 + 4 * l: 7 + 4 * l] for l in range(L)]
@@ -316,19 +304,35 @@ class _PaiNNCore(torch.autograd.Function):
             q, mu = q3, mu3
         if training:
             ctx.el, ctx.cfg, ctx.z, ctx.ps, ctx.params = el, cfg, z, ps, params
+            ctx.pos, ctx.want_params = pos, want_params
             ctx.geom = (dirv, fcut, phi)
             ctx.saved = saved
         return q
 
     @staticmethod
     def backward(ctx, dq):
+        want_pos, want_params = ctx.needs_input_grad[1], ctx.want_params
+        if torch.is_grad_enabled():
+            # a backward with grad mode ON = create_graph=True (finetune_md17.py:46,99): the gradients may be
+            # differentiated again (training on forces, :51-54).  The fused first-order kernels still compute them, as
+            # the outputs of a node that knows how to be differentiated (geossl_amd/higher_order.py)
+            from ...higher_order import PaiNNGradNode
+            dpos, grads = PaiNNGradNode.run(ctx, dq, want_pos, want_params)
+            return (None, dpos, None, None) + tuple(grads)
+        dpos, grads = _PaiNNCore.fused_backward(ctx, dq, want_pos, want_params, allow_direct=True)
+        return (None, dpos, None, None) + tuple(grads)
+
+    @staticmethod
+    def fused_backward(ctx, dq, want_pos, want_params, allow_direct):
+        """First-order gradients by the fused kernels -> (dpos or None, [one entry per parameter, None = not returned])."""
         el, cfg, ps = ctx.el, ctx.cfg, ctx.ps
         F_, L, R = cfg["F"], cfg["L"], cfg["R"]
         dirv, fcut, phi = ctx.geom
         dev, N = dq.device, dq.size(0)
         st = stream()
         f32 = dict(dtype=torch.float32, device=dev)
-        direct = _lib.direct_grads_enabled(ctx.params)  # opt-in (DDMTrainer); otherwise gradients go through autograd
+        # opt-in (DDMTrainer); otherwise gradients go through autograd
+        direct = want_params and allow_direct and _lib.direct_grads_enabled(ctx.params)
         grads = [p.grad for p in ctx.params] if direct else [torch.zeros_like(p) for p in ps]
         acc = 1 if direct else 0
         g_emb, g_fw, g_fb = grads[0], grads[1], grads[2]
@@ -386,6 +390,9 @@ class _PaiNNCore(torch.autograd.Function):
         nfl = _lib.load().geossl_painn_interaction_bwd_mol_workspace_floats(N, lay.B, F_, R)
         ws = torch.empty(max(int(nfl), 1), **f32)
         keep = []
+        E = el.E
+        if want_pos:  # dL/d(phi, fcut, dir) per edge, summed over the blocks (painn_force.hip)
+            dphi, dfc, ddir = torch.empty(max(E, 1), R, **f32), torch.empty(max(E, 1), **f32), torch.empty(max(E, 1), 3, **f32)
         for l in reversed(range(L)):
             sv = ctx.saved[l]
             c0w, c0b, c1w, c1b = inter[l]
@@ -431,6 +438,11 @@ class _PaiNNCore(torch.autograd.Function):
                 add(3 * N, 2 * F_, F_, F_, dmm[:, c * F_:(c + 1) * F_], sv["mu2"].view(3 * N, F_),
                     gmw[c * F_:(c + 1) * F_], None)
             # ---- interaction block
+            if want_pos:
+                call("geossl_painn_edge_grads", ptr(dq2), ptr(dmu2), ptr(sv["mu"]), ptr(sv["xc"]), ptr(el.idx_i),
+                     ptr(el.idx_j), ptr(phi), ptr(fcut), ptr(dirv), ptr(ps[1][l * 3 * F_:(l + 1) * 3 * F_]),
+                     ptr(ps[2][l * 3 * F_:(l + 1) * 3 * F_]), E, F_, R, ptr(dphi), ptr(dfc), ptr(ddir),
+                     0 if l == L - 1 else 1, st)
             dxc, dmu_in = torch.empty(N, 3 * F_, **f32), torch.empty(N, 3, F_, **f32)
             call("geossl_painn_interaction_bwd_mol", ptr(dq2), ptr(dmu2), ptr(sv["mu"]), ptr(sv["xc"]), ptr(el.idx_i),
                  ptr(inc_ptr), ptr(inc_idx), ptr(phi), ptr(fcut), ptr(dirv), ptr(ps[1][l * 3 * F_:(l + 1) * 3 * F_]),
@@ -454,6 +466,17 @@ class _PaiNNCore(torch.autograd.Function):
             add(N, F_, F_, F_, du, sv["q"], gc0w, gc0b)
             keep += [dxx, dmm, du1, dxc, du, dq2, dmu2]
             dq_cur, dmu_cur = dq_in, dmu_in
+        dpos = None
+        if want_pos:
+            dpos = torch.zeros(N, 3, **f32)
+            if E > 0:
+                dr = torch.empty(E, 3, **f32)
+                call("geossl_painn_edge_geom_bwd", ptr(ctx.pos), ptr(el.idx_i), ptr(el.idx_j), E, cfg["cutoff"],
+                     ptr(cfg["offsets"]), ptr(cfg["widths"]), R, ptr(dphi), ptr(dfc), ptr(ddir), ptr(dr), st)
+                (pi, ii), (pj, ij) = el.inc["i"], el.inc["j"]
+                call("geossl_painn_position_grad", ptr(dr), ptr(pi), ptr(ii), ptr(pj), ptr(ij), N, ptr(dpos), st)
+        if not want_params:  # an evaluation of the forces alone (finetune_md17.py:85-105 with frozen weights)
+            return dpos, [None] * len(grads)
         for (rows, lda, ldb, ldw), probs in groups.items():
             ops.linear_wgrad(probs, rows, F_, F_, accumulate=bool(acc), lda=lda, ldb=ldb, ldw=ldw)
         # embedding table; padding_idx = 0 keeps row 0 without gradient (painn.py:174)
@@ -466,8 +489,7 @@ class _PaiNNCore(torch.autograd.Function):
         tmp[0].zero_()
         if direct:
             g_emb.add_(tmp)
-        else:
-            g_emb.copy_(tmp)
-        if direct:
-            return (None, None, None, None) + (None,) * len(grads)
-        return (None, None, None, None) + tuple(grads)
+            return dpos, [None] * len(grads)
+        g_emb.copy_(tmp)
+        # ctx.saved stays: finetune_md17.py:46 differentiates with retain_graph=True and runs this node again
+        return dpos, [g if p.requires_grad else None for g, p in zip(grads, ctx.params)]

@@ -181,6 +181,9 @@ PROTOTYPES = {
     "geossl_painn_mix_post_bwd": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp]),
     "geossl_painn_mix_pre_bwd": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp]),
     "geossl_add": (i32, [vp, vp, i64, vp, vp]),
+    "geossl_painn_edge_grads": (i32, [vp] * 11 + [i64, i32, i32, vp, vp, vp, i32, vp]),
+    "geossl_painn_edge_geom_bwd": (i32, [vp, vp, vp, i64, f32, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "geossl_painn_position_grad": (i32, [vp, vp, vp, vp, vp, i64, vp, vp]),
     "geossl_adam_step": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i64, f32, vp]),
     # capacity launches: the namesake's arguments + device-side row count(s) before the stream
     "geossl_copy_n": (i32, [P(CopyBatch), i32, vp]),

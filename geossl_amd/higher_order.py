@@ -10,9 +10,9 @@ What runs where: every GEMM (``_MM``: the three forms X W^T, X W, A^T B are clos
 row / column GEMM kernels, the neighbour aggregation and its filter gradient (``_Agg`` / ``_PairProd``, closed as well)
 on geossl_cfconv_aggregate / geossl_pair_product, the radius graph on geossl_pair_geometry; the element-wise glue of
 this path (distance, Gaussian smearing, cosine envelope, softplus, bias adds) is plain torch on the same device -
-PyTorch's own derivative formulas carry the higher orders there.  PaiNN has no fused position-gradient kernels: with
-``positions.requires_grad`` its whole forward takes the primitive route (``painn_atom_features``).  Nothing here is on
-the DDM hot path.
+PyTorch's own derivative formulas carry the higher orders there.  PaiNN works the same way (``painn_atom_features``,
+``PaiNNGradNode``): its forward and its first-order gradients - positions included, painn_force.hip - are the fused
+kernels, and only a backward through those gradients walks the primitive graph.  Nothing here is on the DDM hot path.
 """
 import math
 
@@ -24,13 +24,13 @@ from . import ops
 SSP_SHIFT = torch.log(torch.tensor(2.0)).item()  # schnet.py:213
 
 
-def _mm_raw(a, b, mode):
+def _mm_raw(a, b, mode, bias=None):
     a, b = a.contiguous(), b.contiguous()
     if a.size(0) == 0:  # no rows (e.g. a batch without edges): the kernels are not launched
         shape = {"nt": (0, b.size(0)), "nn": (0, b.size(1)), "tn": (a.size(1), b.size(1))}[mode]
         return torch.zeros(shape, dtype=torch.float32, device=a.device)
     try:
-        return _mm_launch(a, b, mode)
+        return _mm_launch(a, b, mode, bias)
     except Exception as e:
         raise type(e)("%s [_MM %s: a %s, b %s]" % (e, mode, tuple(a.shape), tuple(b.shape))) from e
 
@@ -43,14 +43,17 @@ def _up(n, m):
     return (n + m - 1) // m * m
 
 
-def _mm_launch(a, b, mode):
+def _mm_launch(a, b, mode, bias=None):
     """Raw products on the HIP GEMMs; widths are zero-padded to what the kernels take (contraction: multiples of 8,
-    outputs: multiples of 4; column GEMM tiles of 32 / 64 / 128) and the result is cut back."""
+    outputs: multiples of 4; column GEMM tiles of 32 / 64 / 128) and the result is cut back.  `bias` ("nt" only): added
+    in the epilogue of the first contraction pass."""
     if mode in ("nt", "nn"):
         R, K = a.shape
         NO = b.size(0) if mode == "nt" else b.size(1)
         Kp, NOp = _up(K, 8), _up(NO, 4)
         a = _pad2(a, R, Kp)
+        if bias is not None:
+            bias = bias.contiguous() if NOp == NO else F.pad(bias, (0, NOp - NO))
         outs = []
         for c0 in range(0, NOp, 128):  # output slabs of <= 128 columns
             c1 = min(c0 + 128, NOp)
@@ -60,7 +63,8 @@ def _mm_launch(a, b, mode):
                 ak = a if (k0 == 0 and k1 == Kp) else a[:, k0:k1]
                 if mode == "nt":   # a [R, K] @ b[NO, K]^T
                     w = _pad2(b[c0:min(c1, NO), k0:min(k1, K)], c1 - c0, k1 - k0)
-                    y = ops.linear(ak, w.contiguous(), transB=True, res=y, K=k1 - k0, NO=c1 - c0)
+                    y = ops.linear(ak, w.contiguous(), transB=True, res=y, K=k1 - k0, NO=c1 - c0,
+                                   bias=bias[c0:c1] if (bias is not None and k0 == 0) else None)
                 else:              # a [R, K] @ b[K, NO]
                     w = _pad2(b[k0:min(k1, K), c0:min(c1, NO)], k1 - k0, c1 - c0)
                     y = ops.linear(ak, w.contiguous(), transB=False, res=y, K=k1 - k0, NO=c1 - c0)
@@ -145,9 +149,73 @@ class _PairProd(torch.autograd.Function):
         return da, db, None, None, None
 
 
+class _LinearBias(torch.autograd.Function):
+    """x @ w^T + b with the bias added in the GEMM's epilogue.  Its derivative is made of _MM forms (d b: the column
+    sums of the upstream gradient, as its product with a column of ones), so it is differentiable to any order."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return _mm_raw(x, w, "nt", bias=b.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        dx = _MM.apply(g, w, "nn") if ctx.needs_input_grad[0] else None
+        dw = _MM.apply(g, x, "tn") if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.needs_input_grad[2]:
+            ones = torch.ones(g.size(0), 1, dtype=g.dtype, device=g.device)
+            db = _MM.apply(g, ones, "tn").reshape(-1)
+        return dx, dw, db
+
+
+class _Silu(torch.autograd.Function):
+    """F.silu on geossl_silu_fwd; the derivative is a node of its own (_SiluGrad) so that forces through an activation
+    of the energy head stay on kernels under create_graph=True (finetune_md17.py:46,99)."""
+
+    @staticmethod
+    def forward(ctx, u):
+        from ._lib import call, ptr, stream
+        u = u.contiguous()
+        ctx.save_for_backward(u)
+        y = torch.empty_like(u)
+        call("geossl_silu_fwd", ptr(u), u.numel(), ptr(y), stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (u,) = ctx.saved_tensors
+        return _SiluGrad.apply(u, g)
+
+
+class _SiluGrad(torch.autograd.Function):
+    """du = g * silu'(u) on geossl_silu_bwd; differentiated (training on forces): silu'' in closed form, torch ops."""
+
+    @staticmethod
+    def forward(ctx, u, g):
+        from ._lib import call, ptr, stream
+        g = g.contiguous()
+        ctx.save_for_backward(u, g)
+        du = torch.empty_like(u)
+        call("geossl_silu_bwd", ptr(u), ptr(g), u.numel(), ptr(du), stream())
+        return du
+
+    @staticmethod
+    def backward(ctx, c):
+        u, g = ctx.saved_tensors
+        s = torch.sigmoid(u)
+        d1 = s * (1.0 + u * (1.0 - s))                      # silu'
+        d2 = s * (1.0 - s) * (2.0 + u * (1.0 - 2.0 * s))    # silu''
+        return c * g * d2, c * d1
+
+
+def _silu(x):
+    return _Silu.apply(x)
+
+
 def _linear(x, w, b=None):
-    y = _MM.apply(x, w, "nt")
-    return y if b is None else y + b
+    return _MM.apply(x, w, "nt") if b is None else _LinearBias.apply(x, w, b)
 
 
 def _ssp(x):
@@ -181,14 +249,13 @@ def schnet_atom_features(z, pos, lay, cfg, params):
 
 def _linear_wide(x, w, b=None):
     """x @ w^T + b for any widths (the padding / slabbing to the kernels' shapes happens inside _MM)."""
-    y = _MM.apply(x, w, "nt")
-    return y if b is None else y + b
+    return _linear(x, w, b)
 
 
 def painn_atom_features(z, pos, idx_i, idx_j, cfg, params):
-    """painn.py:230-255 (edge geometry .. last mixing block) as a graph of differentiable primitives - the route PaiNN
-    takes when its positions require a gradient (forces and training on forces, finetune_md17.py:38-54): every Dense
-    layer on the HIP row / column GEMMs, gathers, scatter-adds and element-wise glue in torch on the device.
+    """painn.py:230-255 (edge geometry .. last mixing block) as a graph of differentiable primitives - what
+    PaiNNGradNode differentiates twice when a force is back-propagated (training on forces, finetune_md17.py:46-54):
+    every Dense layer on the HIP row / column GEMMs, gathers, scatter-adds and element-wise glue in torch on the device.
     `params` in PaiNN._params() order."""
     Fd, L, cutoff = cfg["F"], cfg["L"], cfg["cutoff"]
     emb_w, fw, fb = params[0], params[1], params[2]
@@ -206,7 +273,7 @@ def painn_atom_features(z, pos, idx_i, idx_j, cfg, params):
     mu = torch.zeros(n_atoms, 3, Fd, dtype=q.dtype, device=q.device)              # :249
     for l in range(L):
         c0w, c0b, c1w, c1b = inter[l]
-        x = _linear_wide(F.silu(_linear_wide(q, c0w, c0b)), c1w, c1b)             # :53
+        x = _linear_wide(_silu(_linear_wide(q, c0w, c0b)), c1w, c1b)             # :53
         x = filters[:, l * 3 * Fd:(l + 1) * 3 * Fd] * x[idx_j]                    # :54,56
         dq, dmuR, dmumu = torch.split(x, Fd, dim=-1)                              # :58
         dq = torch.zeros_like(q).index_add(0, idx_i, dq)                          # :59
@@ -217,11 +284,46 @@ def painn_atom_features(z, pos, idx_i, idx_j, cfg, params):
         mu_mix = _linear_wide(mu.reshape(3 * n_atoms, Fd), mw).reshape(n_atoms, 3, 2 * Fd)   # :100
         mu_V, mu_W = torch.split(mu_mix, Fd, dim=-1)                              # :101
         mu_Vn = torch.sqrt(torch.sum(mu_V ** 2, dim=-2) + cfg["eps"])             # :102
-        x = _linear_wide(F.silu(_linear_wide(torch.cat([q, mu_Vn], dim=-1), i0w, i0b)), i1w, i1b)   # :104-105
+        x = _linear_wide(_silu(_linear_wide(torch.cat([q, mu_Vn], dim=-1), i0w, i0b)), i1w, i1b)   # :104-105
         dq_intra, dmu_intra, dqmu_intra = torch.split(x, Fd, dim=-1)              # :107
         q = q + dq_intra + dqmu_intra * torch.sum(mu_V * mu_W, dim=1)             # :110,112
         mu = mu + dmu_intra[:, None, :] * mu_W                                    # :108,113
     return q
+
+
+def _run_grad_node(node, fctx, dhout, want_pos, want_params):
+    params = list(fctx.params)
+    mask = [bool(want_pos)] + [bool(want_params and p.requires_grad) for p in params]
+    outs = node.apply(fctx, mask, dhout, fctx.pos, *params)
+    it = iter(outs)
+    vals = [next(it) if m else None for m in mask]
+    return vals[0], vals[1:]
+
+
+def _second_order(features, mask, need, cot, dhout, pos, params):
+    """The derivative of the first-order gradients (d pos, d params given d h), contracted with their cotangents `cot`:
+    the primitive restatement `features(pos, params)` differentiated twice.  `need`: which of (dhout, pos, *params) get
+    a gradient."""
+    higher = torch.is_grad_enabled()  # read OUTSIDE the block below: a third-order graph only if the caller wants one
+    with torch.enable_grad():
+        dh = dhout.detach().requires_grad_(need[0])
+        ps = [p.detach().requires_grad_(True) for p in params]
+        x = pos.detach().requires_grad_(True)
+        h = features(x, ps)
+        wrt = [t for t, m in zip([x] + ps, mask) if m]
+        first = torch.autograd.grad(h, wrt, grad_outputs=dh, create_graph=True, allow_unused=True)
+        s = None
+        for f, c in zip(first, cot):
+            if f is not None and c is not None:
+                term = (f * c).sum()
+                s = term if s is None else s + term
+        ins = [t for t, n in zip([dh, x] + ps, need) if n]
+        if s is None or not ins:
+            second = [None] * len(ins)
+        else:
+            second = torch.autograd.grad(s, ins, allow_unused=True, create_graph=higher)
+    it = iter(second)
+    return [next(it) if n else None for n in need]
 
 
 class SchNetGradNode(torch.autograd.Function):
@@ -231,12 +333,7 @@ class SchNetGradNode(torch.autograd.Function):
 
     @staticmethod
     def run(fctx, dhout, want_pos, want_params):
-        params = list(fctx.params)
-        mask = [bool(want_pos)] + [bool(want_params and p.requires_grad) for p in params]
-        outs = SchNetGradNode.apply(fctx, mask, dhout, fctx.pos, *params)
-        it = iter(outs)
-        vals = [next(it) if m else None for m in mask]
-        return vals[0], vals[1:]
+        return _run_grad_node(SchNetGradNode, fctx, dhout, want_pos, want_params)
 
     @staticmethod
     def forward(ctx, fctx, mask, dhout, pos, *params):
@@ -249,27 +346,35 @@ class SchNetGradNode(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *cot):
-        fctx, mask = ctx.fctx, ctx.mask
+        fctx = ctx.fctx
         dhout, pos, *params = ctx.saved_tensors
-        need = ctx.needs_input_grad[2:]  # (dhout, pos, *params)
-        higher = torch.is_grad_enabled()  # read OUTSIDE the block below: a third-order graph only if the caller wants one
-        with torch.enable_grad():
-            dh = dhout.detach().requires_grad_(need[0])
-            ps = [p.detach().requires_grad_(True) for p in params]
-            x = pos.detach().requires_grad_(True)
-            h = schnet_atom_features(fctx.z, x, fctx.lay, fctx.cfg, ps)
-            wrt = [t for t, m in zip([x] + ps, mask) if m]
-            first = torch.autograd.grad(h, wrt, grad_outputs=dh, create_graph=True, allow_unused=True)
-            s = None
-            for f, c in zip(first, cot):
-                if f is not None and c is not None:
-                    term = (f * c).sum()
-                    s = term if s is None else s + term
-            ins = [t for t, n in zip([dh, x] + ps, need) if n]
-            if s is None or not ins:
-                second = [None] * len(ins)
-            else:
-                second = torch.autograd.grad(s, ins, allow_unused=True, create_graph=higher)
-        it = iter(second)
-        out = [next(it) if n else None for n in need]
+        out = _second_order(lambda x, ps: schnet_atom_features(fctx.z, x, fctx.lay, fctx.cfg, ps), ctx.mask,
+                            ctx.needs_input_grad[2:], cot, dhout, pos, params)
+        return (None, None) + tuple(out)
+
+
+class PaiNNGradNode(torch.autograd.Function):
+    """The same for the fused PaiNN node: forward = its first-order kernels (painn.hip, painn_force.hip), backward =
+    painn_atom_features differentiated twice."""
+
+    @staticmethod
+    def run(fctx, dq, want_pos, want_params):
+        return _run_grad_node(PaiNNGradNode, fctx, dq, want_pos, want_params)
+
+    @staticmethod
+    def forward(ctx, fctx, mask, dq, pos, *params):
+        from .Geom3D.models.painn import _PaiNNCore
+        dpos, grads = _PaiNNCore.fused_backward(fctx, dq, mask[0], any(mask[1:]), allow_direct=False)
+        ctx.fctx, ctx.mask = fctx, mask
+        ctx.save_for_backward(dq, pos, *params)
+        vals = [dpos] + list(grads)
+        return tuple(v for v, m in zip(vals, mask) if m)
+
+    @staticmethod
+    def backward(ctx, *cot):
+        fctx = ctx.fctx
+        dq, pos, *params = ctx.saved_tensors
+        el = fctx.el
+        out = _second_order(lambda x, ps: painn_atom_features(fctx.z, x, el.idx_i, el.idx_j, fctx.cfg, ps), ctx.mask,
+                            ctx.needs_input_grad[2:], cot, dq, pos, params)
         return (None, None) + tuple(out)

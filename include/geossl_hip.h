@@ -486,6 +486,24 @@ int geossl_painn_mix_pre_bwd(const float* dq_new, const float* dctx, const float
                              float* dq_in, float* dmm, hipStream_t stream);
 int geossl_add(const float* a, const float* b, int64_t n, float* out, hipStream_t stream);
 
+/* ---- PaiNN position gradient, first order — examples/finetune_md17.py:46 (grad(energy, positions)) through
+ * Geom3D/models/painn.py:232-241,54-64.  edge_grads (one call per interaction block, in the backward's order, the first
+ * with accumulate = 0): dphi [E][R], dfcut [E], ddir [E][3] += the block's dL/d(phi, fcut, dir) given the gradient at
+ * the block's output (dq_out [N][F], dmu_out [N][3][F]), its inputs mu [N][3][F], xc [N][3F] and its filter_net rows
+ * Wf [3F][R] / bf [3F].  edge_geom_bwd: dr [E][3] = dL/d r_ij (r_ij = pos[idx_i] - pos[idx_j]).  position_grad:
+ * dpos [N][3] = sum of dr over the edges by idx_i minus the sum over the edges by idx_j (the two incidence lists of
+ * geossl_incidence_*, sides = 1 and 2), fixed order. */
+int geossl_painn_edge_grads(const float* dq_out, const float* dmu_out, const float* mu, const float* xc,
+                            const int64_t* idx_i, const int64_t* idx_j, const float* phi, const float* fcut,
+                            const float* dir, const float* Wf, const float* bf, int64_t E, int F, int R, float* dphi,
+                            float* dfcut, float* ddir, int accumulate, hipStream_t stream);
+int geossl_painn_edge_geom_bwd(const float* pos, const int64_t* idx_i, const int64_t* idx_j, int64_t E, float cutoff,
+                               const float* offsets, const float* widths, int R, const float* dphi, const float* dfcut,
+                               const float* ddir, float* dr, hipStream_t stream);
+int geossl_painn_position_grad(const float* dr, const int64_t* inc_i_ptr, const int32_t* inc_i_idx,
+                               const int64_t* inc_j_ptr, const int32_t* inc_j_idx, int64_t N, float* dpos,
+                               hipStream_t stream);
+
 /* ---- Adam — torch.optim.Adam step at pretrain_GeoSSL.py:258-260,343 over one flat fp32 buffer
  * (amsgrad off; weight_decay added to the gradient as torch does).  step_count is the 1-based step.  The
  * hyperparameters are the DOUBLES Python holds: torch forms 1 - beta, lr / bias_correction1 and sqrt(bias_correction2) in

@@ -562,3 +562,161 @@ def test_bucket_graph_with_the_permutation_enumeration_and_the_switch_that_turns
         for b, nz in zip(raw, noise):
             tr2.step(pg.Batch.from_numpy(b, DEV), nz)
     assert tr2.step_graphs.captures == 3 and all(not (isinstance(k, tuple) and k[0] == "bucket") for k in tr2._graphs)
+
+
+# ---------------------------------------------------------------- PaiNN forces on the fused kernels
+
+PAINN = dict(n_atom_basis=128, n_interactions=3, n_rbf=20, cutoff=5.0, max_z=9, n_out=1, readout="add")
+
+
+def _painn_model_and_batch(sizes, seed, cfg=PAINN):
+    from filler import fill_module_
+    from geossl_amd import ops
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.Geom3D.models import PaiNN
+    from geossl_amd.synthetic import make_batch
+    b = make_batch(0, seed=seed, sizes=sizes)
+    bt = pg.Batch.from_numpy(b, DEV)
+    bt.x[:, 0].clamp_(max=8)
+    bt.radius_edge_index = ops.radius_graph(bt.positions, cfg["cutoff"], bt.batch)
+    return fill_module_(PaiNN(**cfg)).to(DEV), bt
+
+
+@pytest.mark.parametrize("F_,R", [(128, 20), (64, 16)])
+def test_painn_forces_on_fused_kernels_vs_fp64_oracle(F_, R):
+    """finetune_md17.py:46, first order: -dE/dpos of the PaiNN backbone by the fused node (painn_force.hip: per-edge
+    gradients of the radial basis, the cutoff and the direction, then the edge-geometry derivative) against
+    oracle.nets.painn_forward differentiated in fp64; the parameter gradients of the same backward are bit-identical
+    to a backward that does not ask for the positions; the net force on every molecule vanishes."""
+    from oracle import nets
+    from test_oracle_golden import painn_params
+    cfg = dict(PAINN, n_atom_basis=F_, n_rbf=R)
+    model, bt = _painn_model_and_batch([1, 2, 3, 18, 18, 40, 9, 33, 5], seed=31, cfg=cfg)
+    wgt = torch.cos(torch.arange(F_, dtype=torch.float32, device=DEV))
+    pos = bt.positions.clone().requires_grad_(True)
+    rep = model(bt.x, pos, bt.radius_edge_index, bt.batch)
+    energy = (rep * wgt).sum(dim=1)
+    force = -torch.autograd.grad(energy, pos, torch.ones_like(energy), retain_graph=True)[0]
+    P64 = {k: v.double() for k, v in painn_params(cfg).items()}
+    p64 = bt.positions.cpu().double().requires_grad_(True)
+    rep64 = nets.painn_forward(P64, bt.x.cpu(), p64, bt.radius_edge_index.cpu(), bt.batch.cpu(), F_, 3, 5.0, "add")
+    e64 = (rep64 * wgt.cpu().double()).sum(dim=1)
+    f64 = -torch.autograd.grad(e64.sum(), p64)[0]
+    assert rel_err(energy.detach().cpu().double(), e64.detach()) < TOL_OUT
+    assert rel_err(force.cpu().double(), f64) < TOL_GRAD
+    net = torch.zeros(9, 3, dtype=torch.float64).index_add_(0, bt.batch.cpu(), force.cpu().double())
+    assert float(net.abs().max()) < 1e-4 * float(f64.abs().max())
+    model.zero_grad()
+    energy.sum().backward(inputs=[pos] + list(model.parameters()))
+    with_pos = {k: v.clone() for k, v in unique_named_grads(model).items()}
+    assert rel_err(pos.grad.cpu().double(), -f64) < TOL_GRAD
+    model.zero_grad()
+    (model(bt.x, bt.positions, bt.radius_edge_index, bt.batch) * wgt).sum().backward()
+    for k, v in unique_named_grads(model).items():
+        assert torch.equal(v, with_pos[k]), k
+
+
+def test_painn_force_evaluation_launches_the_fused_node_only(monkeypatch):
+    """The reference's evaluation loop asks for create_graph=True and detaches (finetune_md17.py:99): the PaiNN force is
+    the fused kernels' either way (bit-identical), and the primitive restatement is never built."""
+    from geossl_amd import higher_order
+
+    def never(*a, **k):
+        raise AssertionError("the primitive route ran during a first-order force evaluation")
+    monkeypatch.setattr(higher_order, "painn_atom_features", never)
+    model, bt = _painn_model_and_batch([12, 7, 21, 3], seed=8)
+    forces = []
+    for create_graph in (False, True):
+        pos = bt.positions.clone().requires_grad_(True)
+        energy = model(bt.x, pos, bt.radius_edge_index, bt.batch).sum(dim=1)
+        f = torch.autograd.grad(energy, pos, torch.ones_like(energy), create_graph=create_graph, retain_graph=True)[0]
+        assert f.requires_grad == create_graph
+        forces.append(f.detach())
+    assert torch.equal(forces[0], forces[1])
+    # frozen weights: positions only
+    for p in model.parameters():
+        p.requires_grad_(False)
+    pos = bt.positions.clone().requires_grad_(True)
+    energy = model(bt.x, pos, bt.radius_edge_index, bt.batch).sum(dim=1)
+    f = torch.autograd.grad(energy.sum(), pos)[0]
+    assert torch.equal(f, forces[0])
+
+
+def test_painn_edge_gradient_kernels_through_the_c_abi():
+    """geossl_painn_edge_grads / edge_geom_bwd / position_grad on their own (include/geossl_hip.h) against autograd of
+    the same per-edge expressions in fp64: one interaction block, accumulate = 0 then 1 (twice the gradient)."""
+    from geossl_amd._lib import call, ptr, stream
+    from geossl_amd.layout import EdgeLayout
+    torch.manual_seed(5)
+    N, F_, R, cutoff = 23, 128, 20, 5.0
+    pos = torch.randn(N, 3, device=DEV) * 1.5
+    batch = torch.zeros(N, dtype=torch.long, device=DEV)
+    d = torch.cdist(pos, pos)
+    ii, jj = torch.nonzero((d < cutoff) & ~torch.eye(N, dtype=torch.bool, device=DEV), as_tuple=True)
+    ei = torch.stack([ii, jj])
+    el = EdgeLayout(batch, ei, 1)
+    E = el.E
+    offsets = torch.linspace(0.0, cutoff, R, device=DEV)
+    widths = torch.full((R,), float(offsets[1] - offsets[0]), device=DEV)
+    Wf, bf = torch.randn(3 * F_, R, device=DEV) * 0.3, torch.randn(3 * F_, device=DEV) * 0.1
+    gq, gmu = torch.randn(N, F_, device=DEV), torch.randn(N, 3, F_, device=DEV)
+    mu, xc = torch.randn(N, 3, F_, device=DEV), torch.randn(N, 3 * F_, device=DEV)
+    f32 = dict(dtype=torch.float32, device=DEV)
+    dirv, fcut, phi = torch.empty(E, 3, **f32), torch.empty(E, **f32), torch.empty(E, R, **f32)
+    st = stream()
+    call("geossl_painn_edge_geom", ptr(pos), ptr(el.idx_i), ptr(el.idx_j), E, cutoff, ptr(offsets), ptr(widths), R,
+         ptr(dirv), ptr(fcut), ptr(phi), st)
+    dphi, dfc, ddir = torch.empty(E, R, **f32), torch.empty(E, **f32), torch.empty(E, 3, **f32)
+    for acc in (0, 1):
+        call("geossl_painn_edge_grads", ptr(gq), ptr(gmu), ptr(mu), ptr(xc), ptr(el.idx_i), ptr(el.idx_j), ptr(phi),
+             ptr(fcut), ptr(dirv), ptr(Wf), ptr(bf), E, F_, R, ptr(dphi), ptr(dfc), ptr(ddir), acc, st)
+    dr, dpos = torch.empty(E, 3, **f32), torch.empty(N, 3, **f32)
+    call("geossl_painn_edge_geom_bwd", ptr(pos), ptr(el.idx_i), ptr(el.idx_j), E, cutoff, ptr(offsets), ptr(widths), R,
+         ptr(dphi), ptr(dfc), ptr(ddir), ptr(dr), st)
+    (pi, ix), (pj, jx) = el.inc["i"], el.inc["j"]
+    call("geossl_painn_position_grad", ptr(dr), ptr(pi), ptr(ix), ptr(pj), ptr(jx), N, ptr(dpos), st)
+    # the same in fp64 by autograd (painn.py:232-241,56-61)
+    D = lambda v: v.double().cpu()
+    p64 = D(pos).requires_grad_(True)
+    i_, j_ = ii.cpu(), jj.cpu()
+    r = p64[i_] - p64[j_]
+    dist = r.norm(dim=1, keepdim=True)
+    u = r / dist
+    ph = torch.exp((-0.5 / D(widths) ** 2) * (dist - D(offsets)) ** 2)
+    fc = 0.5 * (torch.cos(dist * np.pi / cutoff) + 1.0) * (dist < cutoff)
+    W = (ph @ D(Wf).T + D(bf)) * fc
+    x = W * D(xc)[j_]
+    m0, m1, m2 = torch.split(x, F_, dim=1)
+    dmu_e = m1[:, None, :] * u[:, :, None] + m2[:, None, :] * D(mu)[j_]
+    val = (m0 * D(gq)[i_]).sum() + (dmu_e * D(gmu)[i_]).sum()
+    ref = torch.autograd.grad(val, p64)[0]
+    assert rel_err(dpos.cpu().double(), 2.0 * ref) < 1e-5
+
+
+def test_standalone_dense_and_silu_nodes_to_second_order():
+    """Dense as a module of its own (the energy head of create_output_layers(), painn_utils.py:9-35): bias in the GEMM's
+    epilogue, F.silu on geossl_silu_fwd / geossl_silu_bwd - values, first derivatives and the derivative of a
+    gradient (what training on forces differentiates, finetune_md17.py:46-54) against torch in fp64."""
+    import torch.nn.functional as Fn
+    from geossl_amd.Geom3D.models.painn import Dense
+    torch.manual_seed(9)
+    for n_in, n_out, act in ((128, 64, Fn.silu), (64, 1, None), (20, 384, None)):
+        lay = Dense(n_in, n_out, activation=act).to(DEV)
+        torch.nn.init.normal_(lay.bias, std=0.3)
+        x = torch.randn(37, n_in, device=DEV, requires_grad=True)
+        c = torch.randn(37, n_out, device=DEV)
+        y = lay(x)
+        (gx,) = torch.autograd.grad(y, x, c, create_graph=True)
+        loss = (gx ** 2).sum() + (y ** 2).sum()
+        loss.backward()
+        x64 = x.detach().double().cpu().requires_grad_(True)
+        w64, b64 = lay.weight.detach().double().cpu().requires_grad_(True), lay.bias.detach().double().cpu().requires_grad_(True)
+        y64 = Fn.linear(x64, w64, b64)
+        y64 = Fn.silu(y64) if act is not None else y64
+        (gx64,) = torch.autograd.grad(y64, x64, c.double().cpu(), create_graph=True)
+        ((gx64 ** 2).sum() + (y64 ** 2).sum()).backward()
+        assert rel_err(y.detach().cpu().double(), y64.detach()) < TOL_OUT
+        assert rel_err(gx.detach().cpu().double(), gx64.detach()) < TOL_GRAD
+        assert rel_err(x.grad.cpu().double(), x64.grad) < TOL_GRAD
+        assert rel_err(lay.weight.grad.cpu().double(), w64.grad) < TOL_GRAD
+        assert rel_err(lay.bias.grad.cpu().double(), b64.grad) < TOL_GRAD
