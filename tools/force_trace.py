@@ -26,10 +26,14 @@ else:
     head = Dense(128, 1).to(dev)
     rep_of = lambda pos: model(bt.x[:, 0], pos, bt.batch)
 minus_one = torch.full((mols, 1), -1.0, device=dev)
+import time
 for step in range(steps):
+    if step == steps // 2:  # second half timed (the first pays the one-time preparation)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
     pos = bt.positions.detach().requires_grad_(True)
     energy = head(rep_of(pos))                                   # finetune_md17.py:38-44
     # pred_force = -grad(E, pos, grad_outputs=ones) (:46): the sign rides on grad_outputs
     force = torch.autograd.grad(energy, pos, grad_outputs=minus_one, create_graph=True, retain_graph=True)[0].detach_()
 torch.cuda.synchronize()
-print(which, "force", tuple(force.shape), float(force.abs().max()))
+ms = 1e3 * (time.perf_counter() - t0) / (steps - steps // 2)
+print(which, "force", tuple(force.shape), float(force.abs().max()), "%.3f ms per evaluation = %.1f k molecules/s" % (ms, mols / ms))
