@@ -101,13 +101,16 @@ def eligible(batch, model_3d, normalize=False):
     return batch.positions.is_cuda and batch.positions.dtype == torch.float32 and batch.x.dim() == 2
 
 
+MODULE_SWITCHES = ("GEOSSL_NO_CHAIN", "GEOSSL_NCSN_SPLIT_BWD", "GEOSSL_NCSN_SEPARATE_HEADS")  # read by modules_ok
+
+
 def modules_ok(model, n1, n2):
     """The step of these modules can run on a bucket: the F = 128 chain path of SchNet (the chained row kernel is the one
     that takes a device-side row count) and the paired NCSN heads (two different modules of width 128)."""
     import os
     from .Geom3D.models.schnet import SchNet
     from .NCSN import NCSN_version_03, _head_params
-    if os.environ.get("GEOSSL_NO_CHAIN") or os.environ.get("GEOSSL_NCSN_SPLIT_BWD") or os.environ.get("GEOSSL_NCSN_SEPARATE_HEADS"):
+    if any(os.environ.get(k) for k in MODULE_SWITCHES):
         return False
     if not isinstance(model, SchNet) or model.hidden_channels != 128 or model.num_filters != 128 \
             or model.num_interactions < 1 or model.dipole or model.atomref is not None or model.mean is not None:

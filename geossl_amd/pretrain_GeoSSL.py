@@ -382,6 +382,7 @@ class StepGraphs:
         self._warned = False
         self._seen = OrderedDict()
         self.bucket_ok = True   # cleared when a bucket capture failed: per-structure graphs from then on
+        self._mod_ok = None
 
     def __len__(self):
         return len(self.graphs)
@@ -392,9 +393,18 @@ class StepGraphs:
         from . import bucket as bk
         if (self.mode != "auto" or not self.bucket_ok or os.environ.get("GEOSSL_NO_BUCKETS")
                 or not bk.eligible(batch, self.model_3d, self.normalize) or bk.is_uniform(batch)
-                or self.modules is None or not bk.modules_ok(*self.modules)):
+                or self.modules is None or not self._modules_ok()):
             return None
         return ("bucket", len(batch._sizes), batch._canonical)
+
+    def _modules_ok(self):
+        """bucket.modules_ok of this engine's modules, remembered per state of the switches it reads (the modules of a
+        StepGraphs are fixed: a replaced parameter rebuilds the engine, _AutogradStep.unchanged / DDMTrainer)."""
+        from . import bucket as bk
+        env = tuple(os.environ.get(k) for k in bk.MODULE_SWITCHES)
+        if self._mod_ok is None or self._mod_ok[0] != env:
+            self._mod_ok = (env, bk.modules_ok(*self.modules))
+        return self._mod_ok[1]
 
     def lookup(self, batch):
         """The graph that serves this batch (None: not captured yet, or its bucket is too small)."""
