@@ -21,6 +21,7 @@ i64 = C.c_int64
 i32 = C.c_int
 f32 = C.c_float
 f64 = C.c_double
+u64 = C.c_uint64
 
 
 class FilterWeights(C.Structure):
@@ -147,6 +148,7 @@ PROTOTYPES = {
     "geossl_schnet_layer_loop_ragged": (i32, [vp, i32, vp, vp, vp, i64, i32, i64, i32, vp]),
     "geossl_copy2": (i32, [vp, vp, i64, vp, vp, i64, vp]),
     "geossl_ddm_noise": (i32, [vp, f32, f32, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "geossl_ddm_noise_seeded": (i32, [u64, f32, f32, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, vp]),
     "geossl_ddm_views": (i32, [vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, i64, vp, vp]),
     "geossl_loss_reduce_partials": (i32, [vp, vp, f32, vp, i32, vp]),
     "geossl_ddm_loss_fwd2": (i32, [vp, vp, vp, vp, i64, i32, vp]),

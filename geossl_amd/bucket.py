@@ -247,8 +247,9 @@ class Bucket:
     def fits(self, counts):
         return all(c <= cap for c, cap in zip(counts, self.caps()))
 
-    def fill(self, batch, counts=None):
-        """The batch's atom types, positions, index tensors and derived structures into the static buffers."""
+    def fill(self, batch, counts=None, zero=None):
+        """The batch's atom types, positions, index tensors and derived structures into the static buffers; `zero`: a
+        float32 buffer cleared by the same launch (the owner's flat gradient buffer)."""
         global _PARTS
         if _PARTS is None:
             _PARTS = _parts_table()
@@ -282,12 +283,14 @@ class Bucket:
                 or not batch.batch.is_contiguous() or batch.x.size(1) != self.x.size(1):
             raise ValueError("bucket fill expects contiguous collated tensors")
         cb = _lib.CopyBatch()
-        for k, (dst, src, nbytes) in enumerate((
-                (self.x, batch.x, N * self.x.size(1) * 8), (self.positions, batch.positions, N * 12),
-                (self.batch_vec, batch.batch, N * 8), (self.sei[0], sei[0], S * 8), (self.sei[1], sei[1], S * 8))):
-            cb.dst[k], cb.src[k], cb.bytes[k] = ptr(dst), ptr(src), nbytes
+        jobs = [(self.x, batch.x, N * self.x.size(1) * 8), (self.positions, batch.positions, N * 12),
+                (self.batch_vec, batch.batch, N * 8), (self.sei[0], sei[0], S * 8), (self.sei[1], sei[1], S * 8)]
+        if zero is not None:
+            jobs.append((zero, None, zero.numel() * 4))  # (src NULL: a fill with zeros)
+        for k, (dst, src, nbytes) in enumerate(jobs):
+            cb.dst[k], cb.src[k], cb.bytes[k] = ptr(dst), (ptr(src) if src is not None else None), nbytes
         st_ = stream()
-        call("geossl_copy_n", C.byref(cb), 5, st_)
+        call("geossl_copy_n", C.byref(cb), len(jobs), st_)
         lay = self.lay2
         call("geossl_pair_index_fill", ptr(lay.mol_ptr), ptr(lay.pair_ptr), 2 * B, ptr(lay.pair_i), ptr(lay.pair_j), st_)
         sel = self.sel

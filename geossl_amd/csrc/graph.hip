@@ -191,6 +191,37 @@ __global__ __launch_bounds__(64) void k_radius(const float* __restrict__ pos, co
   }
 }
 
+// MODE 2 for molecules of at most `cap` atoms (the neighbour cap of torch_cluster.radius_graph, self hit included, can
+// then never cut a list: the flags are the plain threshold test, symmetric bit for bit because the squared distance is):
+// no adjacency pass, the pair slots of a molecule dealt flat to the 64 lanes of its wave - 3 rounds for 18 atoms where
+// the general kernel walks 18 + 17 dependent rows.  Same arithmetic, same outputs.
+__global__ __launch_bounds__(64) void k_pair_geometry_flat(const float* __restrict__ pos, const int32_t* __restrict__ mol_ptr,
+                                                           const int32_t* __restrict__ pair_ptr, int B, float r2,
+                                                           float cutoff, float* __restrict__ pair_d,
+                                                           float* __restrict__ pair_c, uint8_t* __restrict__ pair_flag) {
+  __shared__ float sp[3 * 64];
+  const int m = blockIdx.x, lane = threadIdx.x;
+  if (m >= B) return;
+  const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0;
+  const int base = pair_ptr[m], np = n * (n - 1) / 2;
+  for (int i = lane; i < 3 * n; i += 64) sp[i] = pos[(size_t)a0 * 3 + i];
+  __syncthreads();
+  const float tn = (float)(2 * n - 1);
+  for (int q = lane; q < np; q += 64) {
+    // slot q = a n - a (a + 1) / 2 + (b - a - 1), a < b: the row from the closed form, corrected by one either way
+    int a = (int)((tn - sqrtf(fmaxf(tn * tn - 8.0f * (float)q, 0.0f))) * 0.5f);
+    a = min(max(a, 0), n - 2);
+    if (a * n - a * (a + 1) / 2 > q) --a;
+    else if ((a + 1) * n - (a + 1) * (a + 2) / 2 <= q) ++a;
+    const int b = q - (a * n - a * (a + 1) / 2) + a + 1;
+    const float d2 = dist2_nofma(sp + 3 * a, sp + 3 * b);
+    const float d = sqrtf(d2);
+    pair_d[base + q] = d;
+    pair_c[base + q] = 0.5f * (cosf(mul_rn(d, GEOSSL_PI_F) / cutoff) + 1.0f);  // schnet.py:186, fp32 op by op
+    pair_flag[base + q] = d2 < r2 ? (uint8_t)3 : (uint8_t)0;
+  }
+}
+
 inline size_t radius_lds(int max_n) {
   const size_t words = (max_n + 63) / 64;
   return (size_t)max_n * words * 8 + (size_t)max_n * 12;
@@ -324,10 +355,11 @@ __device__ __forceinline__ void normal4(uint4 r, float (&z)[4]) {
   sincosf(6.283185307179586f * u3, &sb, &cb);
   z[0] = ra * ca; z[1] = ra * sa; z[2] = rb * cb; z[3] = rb * sb;
 }
-__global__ void k_ddm_noise(const int64_t* __restrict__ seed, float mu, float sigma, int64_t n_pos, int64_t S, int64_t B,
-                            int K1, int K2, float* __restrict__ pos_noise, int64_t* __restrict__ nl1,
-                            float* __restrict__ dn1, int64_t* __restrict__ nl2, float* __restrict__ dn2) {
-  const uint64_t sd = (uint64_t)seed[0];
+__global__ void k_ddm_noise(const int64_t* __restrict__ seed, uint64_t seed_value, float mu, float sigma, int64_t n_pos,
+                            int64_t S, int64_t B, int K1, int K2, float* __restrict__ pos_noise,
+                            int64_t* __restrict__ nl1, float* __restrict__ dn1, int64_t* __restrict__ nl2,
+                            float* __restrict__ dn2) {
+  const uint64_t sd = seed != nullptr ? (uint64_t)seed[0] : seed_value;
   const uint2 key = make_uint2((uint32_t)sd, (uint32_t)(sd >> 32));
   const int64_t g_pos = (n_pos + 3) / 4, g_s = (S + 3) / 4, g_b = (B + 3) / 4;
   const int64_t total = g_pos + 2 * g_s + 2 * g_b;
@@ -423,6 +455,12 @@ extern "C" int geossl_pair_geometry(const float* pos, const int32_t* mol_ptr, co
                                     int max_n, float r2, int cap, float cutoff, float* pair_d, float* pair_c,
                                     uint8_t* pair_flag, hipStream_t stream) {
   if (B <= 0) return 0;
+  if (max_n <= cap && max_n <= 64) {
+    hipLaunchKernelGGL(k_pair_geometry_flat, dim3((unsigned)B), dim3(64), 0, stream, pos, mol_ptr, pair_ptr, (int)B, r2,
+                       cutoff, pair_d, pair_c, pair_flag);
+    GEOSSL_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL((k_radius<2>), dim3((unsigned)B), dim3(64), radius_lds(max_n), stream, pos, mol_ptr, pair_ptr,
                      (int)B, max_n, r2, cap, nullptr, nullptr, nullptr, nullptr, nullptr, pair_d, pair_flag, cutoff, pair_c);
   GEOSSL_CHECK_LAUNCH();
@@ -502,7 +540,12 @@ __global__ void k_copy_n(GeosslCopyBatch b) {
   const uint32_t* __restrict__ s = reinterpret_cast<const uint32_t*>(b.src[blockIdx.y]);
   uint32_t* __restrict__ d = reinterpret_cast<uint32_t*>(b.dst[blockIdx.y]);
   const int64_t n = b.bytes[blockIdx.y] / 4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+  if (s == nullptr) {  // a fill with zeros (src = NULL): a gradient buffer cleared in the launch that refreshes the inputs
+    for (int64_t i = t0; i < n; i += nt) d[i] = 0u;
+    return;
+  }
+  for (int64_t i = t0; i < n; i += nt) d[i] = s[i];
 }
 }  // namespace
 
@@ -510,7 +553,8 @@ extern "C" int geossl_copy_n(const GeosslCopyBatch* batch, int n, hipStream_t st
   if (batch == nullptr || n < 0 || n > GEOSSL_COPY_MAX) return (int)hipErrorInvalidValue;
   int64_t work = 0;
   for (int i = 0; i < n; ++i) {
-    if ((batch->bytes[i] & 3) || (((uintptr_t)batch->dst[i] | (uintptr_t)batch->src[i]) & 3) || batch->bytes[i] < 0)
+    if ((batch->bytes[i] & 3) || (((uintptr_t)batch->dst[i] | (uintptr_t)batch->src[i]) & 3) || batch->bytes[i] < 0 ||
+        (batch->dst[i] == nullptr && batch->bytes[i] > 0))
       return (int)hipErrorInvalidValue;
     if (batch->bytes[i] / 4 > work) work = batch->bytes[i] / 4;
   }
@@ -520,16 +564,32 @@ extern "C" int geossl_copy_n(const GeosslCopyBatch* batch, int n, hipStream_t st
   return 0;
 }
 
+static int ddm_noise_launch(const int64_t* seed, uint64_t seed_value, float mu, float sigma, int64_t n_pos, int64_t S,
+                            int64_t B, int K1, int K2, float* pos_noise, int64_t* noise_level_1,
+                            float* distance_noise_1, int64_t* noise_level_2, float* distance_noise_2,
+                            hipStream_t stream) {
+  if (K1 < 1 || K2 < 1) return (int)hipErrorInvalidValue;
+  const int64_t total = (n_pos + 3) / 4 + 2 * ((S + 3) / 4) + 2 * ((B + 3) / 4);
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(k_ddm_noise, dim3(grid1d(total, 256)), dim3(256), 0, stream, seed, seed_value, mu, sigma, n_pos, S, B,
+                     K1, K2, pos_noise, noise_level_1, distance_noise_1, noise_level_2, distance_noise_2);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int geossl_ddm_noise(const int64_t* seed, float mu, float sigma, int64_t n_pos, int64_t S, int64_t B, int K1,
                                 int K2, float* pos_noise, int64_t* noise_level_1, float* distance_noise_1,
                                 int64_t* noise_level_2, float* distance_noise_2, hipStream_t stream) {
-  if (seed == nullptr || K1 < 1 || K2 < 1) return (int)hipErrorInvalidValue;
-  const int64_t total = (n_pos + 3) / 4 + 2 * ((S + 3) / 4) + 2 * ((B + 3) / 4);
-  if (total <= 0) return 0;
-  hipLaunchKernelGGL(k_ddm_noise, dim3(grid1d(total, 256)), dim3(256), 0, stream, seed, mu, sigma, n_pos, S, B, K1, K2,
-                     pos_noise, noise_level_1, distance_noise_1, noise_level_2, distance_noise_2);
-  GEOSSL_CHECK_LAUNCH();
-  return 0;
+  if (seed == nullptr) return (int)hipErrorInvalidValue;
+  return ddm_noise_launch(seed, 0, mu, sigma, n_pos, S, B, K1, K2, pos_noise, noise_level_1, distance_noise_1,
+                          noise_level_2, distance_noise_2, stream);
+}
+
+extern "C" int geossl_ddm_noise_seeded(uint64_t seed, float mu, float sigma, int64_t n_pos, int64_t S, int64_t B, int K1,
+                                       int K2, float* pos_noise, int64_t* noise_level_1, float* distance_noise_1,
+                                       int64_t* noise_level_2, float* distance_noise_2, hipStream_t stream) {
+  return ddm_noise_launch(nullptr, seed, mu, sigma, n_pos, S, B, K1, K2, pos_noise, noise_level_1, distance_noise_1,
+                          noise_level_2, distance_noise_2, stream);
 }
 
 extern "C" int geossl_axpy(const float* a, const float* b, float alpha, int64_t n, float* out, hipStream_t stream) {

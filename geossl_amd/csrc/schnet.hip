@@ -303,6 +303,26 @@ __global__ void k_embedding_fwd(const int64_t* __restrict__ z, int64_t zs, const
     }
   }
 }
+// the same for F = 4 << SH4 (32, 64, 128): four columns per thread, shifts instead of the 64-bit division
+template <int SH4>
+__global__ __launch_bounds__(256) void k_embedding_fwd4(const int64_t* __restrict__ z, int64_t zs,
+                                                        const float* __restrict__ table, int C, int N,
+                                                        float* __restrict__ out, int32_t* __restrict__ status,
+                                                        const int32_t* __restrict__ dyn_N) {
+  N = dyn_count(N, dyn_N);
+  const uint32_t total = (uint32_t)N << SH4;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t a = i >> SH4, f4 = i & ((1u << SH4) - 1u);
+    const int64_t c = z[(int64_t)a * zs];
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (c < 0 || c >= C) {
+      if (status != nullptr) *status = 1;
+    } else {
+      v = reinterpret_cast<const f32x4*>(table)[((uint32_t)c << SH4) + f4];
+    }
+    reinterpret_cast<f32x4*>(out)[i] = v;
+  }
+}
 
 #define GEOSSL_EMB_CHUNKS 512
 // block = one chunk of rows, thread f owns feature column f of a [classes][F] accumulator table in LDS (thread-private
@@ -574,6 +594,15 @@ extern "C" int geossl_embedding_fwd_dyn(const int64_t* z, int64_t z_stride, cons
                                         hipStream_t stream) {
   if (N <= 0) return 0;
   if (N > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
+  const bool al16 = ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (al16 && (F == 32 || F == 64 || F == 128) && N * (F / 4) < ((int64_t)1 << 31)) {
+    const dim3 grid(grid1d(N * (F / 4), 256)), block(256);
+    if (F == 128) hipLaunchKernelGGL(k_embedding_fwd4<5>, grid, block, 0, stream, z, z_stride, table, num_classes, (int)N, out, status, dyn_N);
+    else if (F == 64) hipLaunchKernelGGL(k_embedding_fwd4<4>, grid, block, 0, stream, z, z_stride, table, num_classes, (int)N, out, status, dyn_N);
+    else hipLaunchKernelGGL(k_embedding_fwd4<3>, grid, block, 0, stream, z, z_stride, table, num_classes, (int)N, out, status, dyn_N);
+    GEOSSL_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(k_embedding_fwd, dim3(grid1d(N * F, 256)), dim3(256), 0, stream, z, z_stride, table, num_classes, N,
                      F, out, status, dyn_N);
   GEOSSL_CHECK_LAUNCH();

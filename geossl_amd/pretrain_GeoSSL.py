@@ -11,6 +11,7 @@ Forward + backward of a step are captured into HIP graphs keyed on a FINGERPRINT
 (``loss, acc = do_DDM(...); optimizer.zero_grad(); loss.backward(); optimizer.step()``, :249-260), by ``do_DDM``
 itself: the loss it returns is the output of an autograd node whose backward hands the replayed gradients to autograd.
 """
+import ctypes as C
 import os
 import warnings
 from collections import OrderedDict
@@ -383,6 +384,9 @@ class StepGraphs:
         self._seen = OrderedDict()
         self.bucket_ok = True   # cleared when a bucket capture failed: per-structure graphs from then on
         self._mod_ok = None
+        # a float32 buffer the owner wants cleared before every replay (its flat gradient buffer): done by the launch that
+        # refreshes the graph's inputs instead of a fill node inside the graph (one launch less per step)
+        self.zero_with_refresh = None
 
     def __len__(self):
         return len(self.graphs)
@@ -567,7 +571,7 @@ class StepGraphs:
         if timing is not None:
             print("capture timing (ms):", ", ".join("%s %.1f" % (n, 1e3 * (t - timing[i][1])) for i, (n, t) in enumerate(timing[1:])))
         self.captures += 1
-        return dict(graph=graph, graph_bwd=graph_bwd, batch=sb, noise=sn, loss=loss)
+        return dict(graph=graph, graph_bwd=graph_bwd, batch=sb, noise=sn, loss=loss, zero=self.zero_with_refresh)
 
     # ---- per-step refresh of a graph's static inputs
     @staticmethod
@@ -593,18 +597,28 @@ class StepGraphs:
     def refresh(g, batch, noise=None):
         """x, positions and (if given) the five noise tensors of this step into the graph's static inputs; a bucket also
         gets the batch's index structures and real counts."""
-        bkt = g.get("bucket")
+        bkt, zero = g.get("bucket"), g.get("zero")
         if bkt is not None:
-            bkt.fill(batch, g["counts"])
+            bkt.fill(batch, g["counts"], zero=zero)
         else:
             dx, dp, sx, sp = g["batch"].x, g["batch"].positions, batch.x, batch.positions
             if (sx.is_cuda and sp.is_cuda and sx.dtype == dx.dtype and sp.dtype == dp.dtype and sx.shape == dx.shape
                     and sp.shape == dp.shape and all(t_.is_contiguous() for t_ in (dx, dp, sx, sp))):
-                call("geossl_copy2", ptr(dx), ptr(sx), dx.numel() * dx.element_size(), ptr(dp), ptr(sp),
-                     dp.numel() * dp.element_size(), stream())  # one launch instead of two copies
+                if zero is None:
+                    call("geossl_copy2", ptr(dx), ptr(sx), dx.numel() * dx.element_size(), ptr(dp), ptr(sp),
+                         dp.numel() * dp.element_size(), stream())  # one launch instead of two copies
+                else:
+                    cb = _lib.CopyBatch()
+                    for k, (d_, s_, nb) in enumerate(((dx, sx, dx.numel() * dx.element_size()),
+                                                      (dp, sp, dp.numel() * dp.element_size()),
+                                                      (zero, None, zero.numel() * 4))):
+                        cb.dst[k], cb.src[k], cb.bytes[k] = ptr(d_), (ptr(s_) if s_ is not None else None), nb
+                    call("geossl_copy_n", C.byref(cb), 3, stream())
             else:
                 dx.copy_(sx)
                 dp.copy_(sp)
+                if zero is not None:
+                    zero.zero_()
         if noise is not None:
             StepGraphs.copy_noise(g, noise)
 
@@ -666,10 +680,25 @@ def draw_step_noise(batch, n1, n2, mu, sigma, device_noise, given=None, into=Non
     return out
 
 
+def _next_noise_key(dev):
+    """A 64-bit Philox key from the state of torch's CUDA generator of this device, taken on the HOST (no launch): the
+    generator's seed mixed with its offset, which is then advanced like a draw of four values would - so
+    torch.cuda.manual_seed governs the stream and other torch draws in between move it, exactly as when the key was
+    drawn on the device."""
+    gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+    off = int(gen.get_offset())
+    gen.set_offset(off + 4)
+    m64 = (1 << 64) - 1
+    x = (int(gen.initial_seed()) + 0x9E3779B97F4A7C15 * (off // 4 + 1)) & m64     # splitmix64 of (seed, draw number)
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & m64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & m64
+    return x ^ (x >> 31)
+
+
 def draw_step_noise_fused(batch, n1, n2, mu, sigma, into=None):
-    """The five draws of a step for a caller that owns its random stream (DDMTrainer with device noise): ONE 64-bit seed
-    from torch's CUDA generator (so torch.cuda.manual_seed governs the stream), then one launch that fills all five
-    tensors (geossl_ddm_noise: Philox keyed by the seed) - two launches where the torch calls are five.  New tensors, or
+    """The five draws of a step for a caller that owns its random stream (DDMTrainer with device noise): ONE 64-bit key
+    derived on the host from torch's CUDA generator (so torch.cuda.manual_seed governs the stream), then one launch that
+    fills all five tensors (geossl_ddm_noise_seeded: Philox under that key) - one launch where the torch calls are five.  New tensors, or
     in place into `into` (the static inputs of a graph)."""
     dev = batch.positions.device
     N, S, B = batch.positions.size(0), batch.super_edge_index.size(1), batch.num_graphs
@@ -681,8 +710,7 @@ def draw_step_noise_fused(batch, n1, n2, mu, sigma, into=None):
                 "dist_noise_2": torch.empty(S, 1, dtype=torch.float32, device=dev)}
     for k in _NOISE_KEYS:
         assert into[k].is_contiguous()
-    seed = torch.empty(1, dtype=torch.long, device=dev).random_()
-    call("geossl_ddm_noise", ptr(seed), float(mu), float(sigma), 3 * N, S, B, n1.sigmas.size(0), n2.sigmas.size(0),
+    call("geossl_ddm_noise_seeded", _next_noise_key(dev), float(mu), float(sigma), 3 * N, S, B, n1.sigmas.size(0), n2.sigmas.size(0),
          ptr(into["pos_noise"]), ptr(into["noise_level_1"]), ptr(into["dist_noise_1"]), ptr(into["noise_level_2"]),
          ptr(into["dist_noise_2"]), stream())
     return into
@@ -763,6 +791,7 @@ class _AutogradStep:
         from .optim import ParamHome
         self.home = ParamHome.of(self.params)
         self.gflat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        self._one = torch.ones((), dtype=torch.float32, device=dev)
         self.views, off = [], 0
         for p in self.params:
             self.views.append(self.gflat[off:off + p.numel()].view_as(p))
@@ -819,12 +848,13 @@ class _AutogradStep:
             if h:
                 hooks.append((h, list(h.items())))
                 h.clear()
-        self.gflat.zero_()
+        if not torch.cuda.is_current_stream_capturing():
+            self.gflat.zero_()  # (a replayed step: cleared by the launch that refreshes the graph's inputs, StepGraphs.refresh)
         for p, v in zip(self.params, self.views):
             p.grad = v
         try:
             with _lib.direct_grads():  # kernels accumulate straight into the static buffer
-                loss.backward()
+                loss.backward(self._one)  # (a standing 1.0: backward() would fill a new one, a launch per step)
             for p, v in zip(self.params, self.views):  # anything autograd replaced goes back into the buffer
                 if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
                     v.copy_(p.grad)
@@ -860,6 +890,7 @@ class _AutogradStep:
             sg = self.graphs[key] = StepGraphs(self._fwd_bwd, args.model_3d, split=(self._fwd, self._bwd),
                                                mode=getattr(args, "step_graph_mode", "auto"), normalize=key[1],
                                                modules=(self.model, self.n1, self.n2))
+            sg.zero_with_refresh = self.gflat
         if not sg.enabled:
             return None
         self._cfg = (Args(args.model_3d, key[1]), mu, sigma)
@@ -977,6 +1008,9 @@ class DDMTrainer:
         # structure fingerprint, captured at first sight (StepGraphs)
         self.step_graphs = StepGraphs(self._fwd_bwd, model_3d, max_graphs, mode=graph_mode,
                                       modules=(model, ncsn_01, ncsn_02))
+        self.step_graphs.zero_with_refresh = self.flat.grad
+        self._zero_outside = True
+        self._one = torch.ones((), dtype=torch.float32, device=self.flat.grad.device)
         self._side = None
 
     @property
@@ -985,7 +1019,8 @@ class DDMTrainer:
 
     def _fwd_bwd(self, batch, noise):
         from . import NCSN as _ncsn
-        self.flat.zero_grad()
+        if not (self._zero_outside and torch.cuda.is_current_stream_capturing()):
+            self.flat.zero_grad()  # (a replayed step: cleared with the refresh of the graph's inputs, StepGraphs.refresh)
         if noise is None and self.device_noise:
             noise = self._draw_noise(batch)  # the trainer's own stream, eager launches or replayed graph alike
         loss = _do_ddm_eager(self.args, batch, self.model, self.mu, self.sigma, (self.n1, self.n2), noise, True,
@@ -995,7 +1030,7 @@ class DDMTrainer:
         _ncsn.set_side_stream(self._side)  # head weight gradients overlap the backbone's backward
         try:
             with _lib.direct_grads():  # every p.grad is a view of self.flat.grad: kernels accumulate into it directly
-                loss.backward()
+                loss.backward(self._one)  # (a standing 1.0: backward() would fill a new one, a launch per step)
         finally:
             _ncsn.set_side_stream(None)
             _ncsn.join_side_stream()

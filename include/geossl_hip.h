@@ -309,6 +309,11 @@ int geossl_copy2(void* dst0, const void* src0, int64_t bytes0, void* dst1, const
 int geossl_ddm_noise(const int64_t* seed, float mu, float sigma, int64_t n_pos, int64_t S, int64_t B, int K1, int K2,
                      float* pos_noise, int64_t* noise_level_1, float* distance_noise_1, int64_t* noise_level_2,
                      float* distance_noise_2, hipStream_t stream);
+/* the same with the 64-bit Philox key passed by value (a caller that derives it on the host - from torch's generator
+ * state - saves the launch that draws it on the device) */
+int geossl_ddm_noise_seeded(uint64_t seed, float mu, float sigma, int64_t n_pos, int64_t S, int64_t B, int K1, int K2,
+                            float* pos_noise, int64_t* noise_level_1, float* distance_noise_1, int64_t* noise_level_2,
+                            float* distance_noise_2, hipStream_t stream);
 /* both views at once (:68-74 and :199-205 for a fused two-view batch): pos2 [2N][3] = [pos ; pos + noise], d01 / d02 [S] =
  * super-edge lengths in the clean / perturbed view - geossl_axpy, the concatenation and two geossl_pair_distance calls
  * in one launch, same arithmetic; z2 != NULL: also z2 [2N] = the atom types z[i * z_stride] of the N atoms, twice */
@@ -531,7 +536,7 @@ int geossl_adam_step(float* param, const float* grad, float* exp_avg, float* exp
 typedef struct GeosslCopyBatch {
   void* dst[GEOSSL_COPY_MAX];
   const void* src[GEOSSL_COPY_MAX];
-  int64_t bytes[GEOSSL_COPY_MAX]; /* multiples of 4; buffers 4-byte aligned */
+  int64_t bytes[GEOSSL_COPY_MAX]; /* multiples of 4; buffers 4-byte aligned; src[i] == NULL: dst[i] is filled with zeros */
 } GeosslCopyBatch;
 /* batch.to(device) into the static inputs of a replayed graph (:248): n <= GEOSSL_COPY_MAX device copies, one launch */
 int geossl_copy_n(const GeosslCopyBatch* batch, int n, hipStream_t stream);

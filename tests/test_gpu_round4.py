@@ -720,3 +720,91 @@ def test_standalone_dense_and_silu_nodes_to_second_order():
         assert rel_err(x.grad.cpu().double(), x64.grad) < TOL_GRAD
         assert rel_err(lay.weight.grad.cpu().double(), w64.grad) < TOL_GRAD
         assert rel_err(lay.bias.grad.cpu().double(), b64.grad) < TOL_GRAD
+
+
+# ---------------------------------------------------------------- small launches of a step (round 4, second half)
+
+def test_flat_pair_geometry_is_the_general_kernel_bit_for_bit():
+    """geossl_pair_geometry on molecules of at most cap atoms takes the flat form (pair slots dealt to the lanes, no
+    adjacency pass): distances, envelope and flags bit-identical to the general kernel (forced by declaring max_n above
+    the cap), ragged sizes 1 .. 33 and a radius that cuts pairs."""
+    from geossl_amd._lib import call, ptr, stream
+    from geossl_amd.layout import MolLayout
+    from geossl_amd.synthetic import make_batch
+    b = make_batch(0, seed=17, sizes=[1, 2, 33, 18, 3, 27, 33, 5, 18, 1, 9, 31, 2])
+    pos = t(b["positions"], DEV) * 1.7   # (spread: some pairs beyond the radius)
+    lay = MolLayout(t(b["batch"], DEV), len(b["sizes"]))
+    assert lay.max_n == 33
+    outs = []
+    for max_n in (lay.max_n, 65):
+        d = torch.full((lay.P,), -1.0, device=DEV)
+        c = torch.full((lay.P,), -1.0, device=DEV)
+        fl = torch.full((lay.P,), 9, dtype=torch.uint8, device=DEV)
+        call("geossl_pair_geometry", ptr(pos), ptr(lay.mol_ptr), ptr(lay.pair_ptr), lay.B, max_n, 25.0, 33, 5.0, ptr(d),
+             ptr(c), ptr(fl), stream())
+        outs.append((d, c, fl))
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+    assert 0 < int((outs[0][2] == 0).sum()) < lay.P and set(outs[0][2].unique().tolist()) <= {0, 3}
+
+
+def test_copy_n_fills_with_zeros_where_the_source_is_null():
+    from geossl_amd import _lib
+    from geossl_amd._lib import call, ptr, stream
+    src = torch.arange(1000, dtype=torch.int32, device=DEV)
+    dst = torch.full((1008,), -1, dtype=torch.int32, device=DEV)
+    z = torch.full((5000,), 3.0, device=DEV)
+    cb = _lib.CopyBatch()
+    cb.dst[0], cb.src[0], cb.bytes[0] = ptr(dst), ptr(src), 4000
+    cb.dst[1], cb.src[1], cb.bytes[1] = ptr(z), None, 4 * 4992
+    call("geossl_copy_n", C.byref(cb), 2, stream())
+    assert torch.equal(dst[:1000], src) and bool((dst[1000:] == -1).all())
+    assert bool((z[:4992] == 0).all()) and bool((z[4992:] == 3.0).all())
+
+
+def test_noise_key_by_value_is_the_device_seed_path_and_follows_the_generator():
+    """geossl_ddm_noise_seeded(key) == geossl_ddm_noise(&key in device memory); the trainer's key follows torch's CUDA
+    generator: the same manual seed gives the same draws, a torch draw in between moves them."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd._lib import call, ptr, stream
+    from geossl_amd.synthetic import make_batch
+    key = 0x1234ABCD5678EF01
+    outs = []
+    for by_value in (False, True):
+        t_ = {"p": torch.empty(300, device=DEV), "l1": torch.empty(7, dtype=torch.long, device=DEV),
+              "d1": torch.empty(50, device=DEV), "l2": torch.empty(7, dtype=torch.long, device=DEV), "d2": torch.empty(50, device=DEV)}
+        seed = torch.tensor([key], dtype=torch.long, device=DEV)
+        call("geossl_ddm_noise_seeded" if by_value else "geossl_ddm_noise", key if by_value else ptr(seed), 0.0, 0.3, 300, 50, 7,
+             50, 30, ptr(t_["p"]), ptr(t_["l1"]), ptr(t_["d1"]), ptr(t_["l2"]), ptr(t_["d2"]), stream())
+        outs.append(t_)
+    assert all(torch.equal(outs[0][k], outs[1][k]) for k in outs[0])
+    batch = pg.Batch.from_numpy(make_batch(40, seed=2), DEV)
+    n1, n2 = product_ncsn(128, 50, 2, DEV), product_ncsn(128, 30, 2, DEV)
+
+    def draws(extra):
+        torch.cuda.manual_seed(11)
+        if extra:
+            torch.rand(4, device=DEV)
+        a = {k: v.clone() for k, v in pg.draw_step_noise_fused(batch, n1, n2, 0.0, 0.3).items()}
+        b = {k: v.clone() for k, v in pg.draw_step_noise_fused(batch, n1, n2, 0.0, 0.3).items()}
+        return a, b
+    (a0, b0), (a1, b1), (a2, _) = draws(False), draws(False), draws(True)
+    assert all(torch.equal(a0[k], a1[k]) and torch.equal(b0[k], b1[k]) for k in a0)
+    assert not torch.equal(a0["pos_noise"], b0["pos_noise"]) and not torch.equal(a0["pos_noise"], a2["pos_noise"])
+
+
+@pytest.mark.parametrize("F_", [32, 64, 128, 48])
+def test_embedding_forward_vector_form_matches_the_table(F_):
+    """geossl_embedding_fwd: four columns per thread for F in (32, 64, 128), the generic form otherwise - rows of the
+    table bit for bit, an out-of-range class flags the status word and gives a zero row."""
+    from geossl_amd._lib import call, ptr, stream
+    torch.manual_seed(1)
+    table = torch.randn(9, F_, device=DEV)
+    x = torch.randint(0, 9, (1237, 2), device=DEV)
+    x[5, 0], x[77, 0] = 9, -1
+    out = torch.full((1237, F_), 7.0, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    call("geossl_embedding_fwd", ptr(x), 2, ptr(table), 9, 1237, F_, ptr(out), ptr(status), stream())
+    want = table[x[:, 0].clamp(0, 8)]
+    want[5], want[77] = 0.0, 0.0
+    assert torch.equal(out, want) and int(status) == 1
