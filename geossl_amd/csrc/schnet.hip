@@ -325,40 +325,60 @@ __global__ __launch_bounds__(256) void k_embedding_fwd4(const int64_t* __restric
 }
 
 #define GEOSSL_EMB_CHUNKS 512
-// block = one chunk of rows, thread f owns feature column f of a [classes][F] accumulator table in LDS (thread-private
-// columns: no barriers, rows added in row order); every row of dh is read once, sixteen rows in flight.  Only the
-// classes [cmin, cmax] a chunk has met leave the block (QM9 uses 5 of the 119 rows of the table: a chunk's whole table
+// block = one chunk of rows, split over NG groups of threads (rows g, g + NG, ... of the chunk to group g); thread f of a
+// group owns feature column f of the group's [classes][F] accumulator table in LDS (thread-private columns: rows added
+// in row order, no barriers), sixteen rows in flight per group; the group tables are then summed in group order.  Only
+// the classes [cmin, cmax] a chunk has met leave the block (QM9 uses 5 of the 119 rows of the table: a chunk's whole table
 // is 60 KB, its occupied band 4.5 KB), the band is recorded behind the partial tables for the second stage.
+template <int NG>
 __global__ void k_embedding_bwd_partial(const int64_t* __restrict__ z, int64_t zs, const float* __restrict__ dh,
                                         int64_t N, int F, int C, float* __restrict__ partial, int2* __restrict__ band,
                                         const int32_t* __restrict__ dyn_N) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [NG][C][F], then NG bands
   N = dyn_count((int)N, dyn_N);  // (chunks past the real rows leave an empty band)
-  const int chunk = blockIdx.x, f = threadIdx.x;
+  const int TF = blockDim.x / NG;  // threads of a group (F rounded up to whole waves)
+  const int chunk = blockIdx.x, grp = threadIdx.x / TF, f = threadIdx.x - grp * TF;
   const int64_t per = (N + (int64_t)gridDim.x - 1) / (int64_t)gridDim.x;
   const int64_t lo = chunk * per, hi = min((int64_t)N, lo + per);
-  if (f >= F) return;
-  for (int c = 0; c < C; ++c) smem[c * F + f] = 0.0f;
-  int cmin = C, cmax = -1;  // the same in every thread
-  constexpr int U = 16;
-  for (int64_t a0 = lo; a0 < hi; a0 += U) {
-    float v[U];
-    int cls[U];
+  float* tab = smem + (size_t)grp * C * F;
+  int2* gband = reinterpret_cast<int2*>(smem + (size_t)NG * C * F);
+  int cmin = C, cmax = -1;  // the same in every thread of a group
+  if (f < F) {
+    for (int c = 0; c < C; ++c) tab[c * F + f] = 0.0f;
+    constexpr int U = 16;
+    for (int64_t a0 = lo + grp; a0 < hi; a0 += (int64_t)U * NG) {
+      float v[U];
+      int cls[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t a = min(a0 + u, hi - 1);
-      v[u] = dh[a * F + f];
-      cls[u] = (int)z[a * zs];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (a0 + u < hi && cls[u] >= 0 && cls[u] < C) {
-        smem[cls[u] * F + f] += v[u];
-        cmin = min(cmin, cls[u]);
-        cmax = max(cmax, cls[u]);
+      for (int u = 0; u < U; ++u) {
+        const int64_t a = min(a0 + (int64_t)u * NG, hi - 1);
+        v[u] = dh[a * F + f];
+        cls[u] = (int)z[a * zs];
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (a0 + (int64_t)u * NG < hi && cls[u] >= 0 && cls[u] < C) {
+          tab[cls[u] * F + f] += v[u];
+          cmin = min(cmin, cls[u]);
+          cmax = max(cmax, cls[u]);
+        }
+    }
+    if (f == 0) gband[grp] = make_int2(cmin, cmax);
   }
-  for (int c = cmin; c <= cmax; ++c) partial[((size_t)chunk * C + c) * F + f] = smem[c * F + f];
+  if (NG > 1) {
+    __syncthreads();
+    if (grp != 0) return;
+    for (int g = 0; g < NG; ++g) {
+      cmin = min(cmin, gband[g].x);
+      cmax = max(cmax, gband[g].y);
+    }
+  }
+  if (f >= F) return;
+  for (int c = cmin; c <= cmax; ++c) {
+    float sum = smem[c * F + f];
+    for (int g = 1; g < NG; ++g) sum += smem[((size_t)g * C + c) * F + f];  // group order
+    partial[((size_t)chunk * C + c) * F + f] = sum;
+  }
   if (f == 0) band[chunk] = make_int2(cmin, cmax);
 }
 // dtable[c][f] (+)= sum over the chunks whose band holds c, in chunk order: block = (class, 64 columns) x 4 slices of the
@@ -630,13 +650,21 @@ extern "C" int geossl_embedding_bwd_dyn(const int64_t* z, int64_t z_stride, cons
   if (N > 0x7FFFFFFF) return (int)hipErrorInvalidValue;
   if (F > 256 || (size_t)num_classes * F * sizeof(float) > 160 * 1024) return (int)hipErrorInvalidValue;
   int2* band = reinterpret_cast<int2*>(workspace + (size_t)GEOSSL_EMB_CHUNKS * num_classes * F);
-  // chunks of at least 64 rows (a small batch: fewer chunks, a shorter list for the second stage), a multiple of 4
-  int nchunks = (int)((N + 63) / 64);
+  // Four row groups per chunk while their tables fit 48 KB of LDS (SchNet's 9 classes: 18 KB), else one.  Chunks of at
+  // least 32 rows per group (a small batch: fewer chunks, a shorter list for the second stage), a multiple of 4.
+  const int TF = (F + 63) / 64 * 64;
+  const int ng = ((size_t)4 * num_classes * F * sizeof(float) <= 48 * 1024 && 4 * TF <= 1024) ? 4 : 1;
+  int nchunks = (int)((N + 32 * ng - 1) / (32 * ng));
   nchunks = nchunks < 16 ? 16 : (nchunks > GEOSSL_EMB_CHUNKS ? GEOSSL_EMB_CHUNKS : (nchunks + 3) / 4 * 4);
-  allow_big_lds(&k_embedding_bwd_partial);
-  hipLaunchKernelGGL(k_embedding_bwd_partial, dim3(nchunks), dim3((F + 63) / 64 * 64),
-                     (size_t)num_classes * F * sizeof(float), stream, z, z_stride, dh, N, F, num_classes, workspace, band,
-                     dyn_N);
+  const size_t lds = (size_t)ng * num_classes * F * sizeof(float) + ng * sizeof(int2);
+  if (ng == 4) {
+    hipLaunchKernelGGL(k_embedding_bwd_partial<4>, dim3(nchunks), dim3(4 * TF), lds, stream, z, z_stride, dh, N, F,
+                       num_classes, workspace, band, dyn_N);
+  } else {
+    allow_big_lds(&k_embedding_bwd_partial<1>);
+    hipLaunchKernelGGL(k_embedding_bwd_partial<1>, dim3(nchunks), dim3(TF), lds, stream, z, z_stride, dh, N, F,
+                       num_classes, workspace, band, dyn_N);
+  }
   GEOSSL_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_embedding_bwd_reduce, dim3((F + 63) / 64, num_classes), dim3(256), 0, stream, workspace, band,
                      nchunks, num_classes, F, dtable, accumulate);
