@@ -808,3 +808,49 @@ def test_embedding_forward_vector_form_matches_the_table(F_):
     want = table[x[:, 0].clamp(0, 8)]
     want[5], want[77] = 0.0, 0.0
     assert torch.equal(out, want) and int(status) == 1
+
+
+def test_painn_forces_without_edges_and_under_no_grad():
+    """Single-atom molecules (no edges): the force is zero and finite; a forward under no_grad with positions that
+    require a gradient saves nothing and matches the forward that does."""
+    model, bt = _painn_model_and_batch([1, 1, 1], seed=3)
+    assert bt.radius_edge_index.size(1) == 0
+    pos = bt.positions.clone().requires_grad_(True)
+    e = model(bt.x, pos, bt.radius_edge_index, bt.batch).sum()
+    (f,) = torch.autograd.grad(e, pos)
+    assert f.shape == pos.shape and float(f.abs().max()) == 0.0
+    model2, bt2 = _painn_model_and_batch([7, 12, 3], seed=4)
+    pos2 = bt2.positions.clone().requires_grad_(True)
+    with torch.no_grad():
+        a = model2(bt2.x, pos2, bt2.radius_edge_index, bt2.batch)
+    b = model2(bt2.x, pos2, bt2.radius_edge_index, bt2.batch)
+    assert not a.requires_grad and b.requires_grad and torch.equal(a, b.detach())
+
+
+def test_trainer_gradients_are_cleared_across_graph_kinds_and_eager_steps():
+    """The flat gradient buffer is cleared by the refresh launch of a replayed step (bucket graphs and per-structure graphs
+    alike) and by the step itself when it runs eagerly: the same batch gives the same gradient whatever ran before."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    tr = _trainer(use_graph=True)
+    ragged = [make_batch(0, seed=40 + i, sizes=_ragged_sizes(24, 40 + i)) for i in range(2)]
+    uniform = make_batch(24, seed=50)
+    probe, pn = ragged[0], draw_noise(ragged[0], seed=9)
+    seen = []
+
+    def grad_of_probe():
+        bt = pg.Batch.from_numpy(probe, DEV)
+        tr._graph_fwd_bwd(bt, {k: t(v, DEV) for k, v in pn.items()})
+        return tr.flat.grad.clone()
+    # bucket graph (captured on the probe), then another ragged batch, a uniform batch (its own graph), an eager step
+    seen.append(grad_of_probe())
+    tr._graph_fwd_bwd(pg.Batch.from_numpy(ragged[1], DEV), None)
+    seen.append(grad_of_probe())
+    tr._graph_fwd_bwd(pg.Batch.from_numpy(uniform, DEV), None)
+    seen.append(grad_of_probe())
+    tr._fwd_bwd(pg.Batch.from_numpy(ragged[1], DEV), None)
+    seen.append(grad_of_probe())
+    assert float(seen[0].abs().max()) > 0
+    for g_ in seen[1:]:
+        assert torch.equal(g_, seen[0])
+    assert tr.step_graphs.captures == 2
