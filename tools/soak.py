@@ -1,0 +1,46 @@
+# long run on never-repeating ragged batches: device memory, host RSS and step time must stay flat
+#   python tools/soak.py [steps] [mols] [trainer|reference]
+import os, resource, sys, time, types
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from geossl_amd import pretrain_GeoSSL as pg
+from geossl_amd.Geom3D.models import SchNet
+from geossl_amd.NCSN import NCSN_version_03
+from geossl_amd.synthetic import collate_subset, make_batch
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+mols = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+api = sys.argv[3] if len(sys.argv) > 3 else "trainer"
+dev = "cuda:0"
+torch.manual_seed(0)
+model = SchNet(128, 128, 6, 51, 5.0, node_class=9).to(dev)
+n1 = NCSN_version_03(128, 10.0, 0.01, 50, "symmetry", 2).to(dev)
+n2 = NCSN_version_03(128, 10.0, 0.01, 50, "symmetry", 2).to(dev)
+pool = make_batch(4096, seed=1, mode="B")
+rng = np.random.default_rng(5)
+if api == "trainer":
+    tr = pg.DDMTrainer(model, n1, n2, lr=5e-4, use_graph=True)
+else:
+    pg.NCSN_model_01, pg.NCSN_model_02 = n1, n2
+    args = types.SimpleNamespace(model_3d="schnet", lr=5e-4, decay=0.0)
+    opt = torch.optim.Adam([{"params": model.parameters(), "lr": 5e-4}, {"params": n1.parameters()}, {"params": n2.parameters()}], lr=5e-4)
+marks = []
+t0 = time.perf_counter()
+for step in range(steps):
+    bt = pg.Batch.from_numpy(collate_subset(pool, rng.permutation(4096)[:mols]), dev, prepare=False)
+    if api == "trainer":
+        loss = tr.step(bt)
+    else:
+        loss, _ = pg.do_DDM(args, bt, model, mu=0.0, sigma=0.3)
+        v = loss.detach().item()
+        opt.zero_grad(); loss.backward(); opt.step()
+    if (step + 1) % (steps // 10) == 0:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        marks.append((step + 1, 1e3 * (t1 - t0) / (steps // 10), torch.cuda.memory_allocated() / 2**20, torch.cuda.memory_reserved() / 2**20,
+                      resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024, float(loss)))
+        t0 = time.perf_counter()
+for m in marks:
+    print("step %5d  %.3f ms/step (incl. host collate)  allocated %.0f MiB  reserved %.0f MiB  max RSS %.0f MiB  loss %.4f" % m)
+caps = tr.step_graphs.captures if api == "trainer" else sum(sg.captures for sg in model.__dict__["_geossl_autograd_step"].graphs.values())
+print("captures", caps)
