@@ -98,7 +98,31 @@ def eligible(batch, model_3d, normalize=False):
     lo, hi = size_range(batch)
     if lo < 1 or hi > MAX_N or hi < 2:
         return False
-    return batch.positions.is_cuda and batch.positions.dtype == torch.float32 and batch.x.dim() == 2
+    return tensors_ok(batch)
+
+
+def tensors_ok(batch):
+    """The batch's tensors are what `Bucket.fill` copies by byte count: int64 x [N, c] / batch [N] / super_edge_index
+    [2, S], float32 positions [N, 3], all contiguous along what is copied, with N and S the counts the molecule sizes
+    give (an int32 x, or a super_edge_index altered after the extractor marked it canonical, would make the copy read past
+    the source).  Checked once per (batch object, tensor versions)."""
+    x, pos, bv, sei = batch.x, batch.positions, batch.batch, batch.super_edge_index
+    tag = tuple((id(t_), t_._version) for t_ in (x, pos, bv, sei))
+    got = batch.__dict__.get("_geossl_tensors_ok")
+    if got is not None and got[0] == tag:
+        return got[1]
+    n = sizes_array(batch)
+    N = int(n.sum())
+    P = int((n * (n - 1) // 2).sum())
+    S = P if batch._canonical == "combination" else 2 * P
+    ok = (pos.is_cuda and pos.dtype == torch.float32 and pos.dim() == 2 and pos.size(1) == 3 and pos.is_contiguous()
+          and pos.size(0) == N
+          and x.is_cuda and x.dtype == torch.long and x.dim() == 2 and x.is_contiguous() and x.size(0) == N
+          and bv.is_cuda and bv.dtype == torch.long and bv.dim() == 1 and bv.is_contiguous() and bv.numel() == N
+          and sei.is_cuda and sei.dtype == torch.long and sei.dim() == 2 and sei.size(0) == 2 and sei.size(1) == S
+          and sei.stride(1) == 1)
+    batch.__dict__["_geossl_tensors_ok"] = (tag, ok)
+    return ok
 
 
 MODULE_SWITCHES = ("GEOSSL_NO_CHAIN", "GEOSSL_NCSN_SPLIT_BWD", "GEOSSL_NCSN_SEPARATE_HEADS")  # read by modules_ok

@@ -152,6 +152,12 @@ __device__ __forceinline__ void aggregate_block_body(const float* __restrict__ x
     fls[p] = (uint8_t)fl;
   }
   __syncthreads();
+  if (nu < 2) {
+    // a single atom has no pair slot: pair_ptr[m] may equal P (the molecule is the last one), and a request for "slot 0"
+    // would read one row past the [L, P, F] filter tensor - the sum over no partners is written without any request
+    if (nu == 1 && wave == 0) *reinterpret_cast<V*>(out + (size_t)a0 * F + 2 * lane) = V(0.0f);
+    return;
+  }
   const float* __restrict__ wcol = Wf + (size_t)base * F + 2 * lane;
   const float* xl = xs + 2 * lane;
   // per target: lane u < n - 1 describes partner b = u + (u >= a): its pair slot and whether b sends to a

@@ -232,7 +232,7 @@ class _AdamPlan:
         home = self.home
         grads = [p.grad for p in home.params]
         g0 = grads[0]
-        if g0 is None or not home.intact():
+        if g0 is None or not home.intact(full=True):  # (every parameter: a re-pointed middle one must not go unnoticed)
             return False
         if g0.dtype != torch.float32:
             return False
@@ -281,7 +281,7 @@ def _adam_pre_hook(optimizer, args, kwargs):
                 or os.environ.get("GEOSSL_NO_FUSED_ADAM")):
             return None
         plan = optimizer.__dict__.get("_geossl_plan")
-        if plan is None or plan is False or not plan.home.intact():
+        if plan is None or plan is False or not plan.home.intact(full=True):
             plan = _find_plan(optimizer)
             optimizer.__dict__["_geossl_plan"] = plan
         if plan:

@@ -347,6 +347,14 @@ class Args:
 
 
 _NOISE_KEYS = ("pos_noise", "noise_level_1", "dist_noise_1", "noise_level_2", "dist_noise_2")
+_OWN_CAPTURE = [0]  # > 0 while StepGraphs._capture has a capture open
+
+
+def own_capture_open():
+    """True while a StepGraphs capture of this module is recording on the current stream: the one situation in which the
+    step's passes leave clearing the gradient buffer to StepGraphs.refresh.  A caller that captures the step in a CUDA
+    graph of ITS OWN gets the fill recorded into that graph like any other launch."""
+    return _OWN_CAPTURE[0] > 0 and torch.cuda.is_current_stream_capturing()
 
 
 class StepGraphs:
@@ -542,6 +550,7 @@ class StepGraphs:
         import gc
         gc_was_on = gc.isenabled()
         gc.disable()
+        _OWN_CAPTURE[0] += 1   # (the owner's passes leave the gradient buffer to `refresh` only inside THIS capture)
         try:
             if self.split is None:
                 with torch.cuda.graph(graph, pool=self.pool, capture_error_mode="thread_local"):
@@ -565,6 +574,7 @@ class StepGraphs:
             self.enabled = False
             return None
         finally:
+            _OWN_CAPTURE[0] -= 1
             if gc_was_on:
                 gc.enable()
         lap("capture + instantiate")
@@ -599,7 +609,11 @@ class StepGraphs:
         gets the batch's index structures and real counts."""
         bkt, zero = g.get("bucket"), g.get("zero")
         if bkt is not None:
-            bkt.fill(batch, g["counts"], zero=zero)
+            try:
+                bkt.fill(batch, g["counts"], zero=zero)
+            except ValueError as e:  # (tensors the bucket cannot copy: the caller runs this step eagerly)
+                warnings.warn("capacity bucket refused a batch (%s); the step runs eagerly" % e)
+                return False
         else:
             dx, dp, sx, sp = g["batch"].x, g["batch"].positions, batch.x, batch.positions
             if (sx.is_cuda and sp.is_cuda and sx.dtype == dx.dtype and sp.dtype == dp.dtype and sx.shape == dx.shape
@@ -621,6 +635,7 @@ class StepGraphs:
                     zero.zero_()
         if noise is not None:
             StepGraphs.copy_noise(g, noise)
+        return True
 
 
 _PINNED = {"i": 0, "slots": [[None, None], [None, None]]}  # ring of two pinned staging buffers (grow-only) + copy events
@@ -731,6 +746,7 @@ class _ReplayedLoss(torch.autograd.Function):
     def backward(ctx, gout):
         eng, ticket = ctx.engine, ctx.ticket
         src = eng.collect(ticket)
+        _restore_backward_threads(ticket)  # (takes effect from the caller's next backward on)
         pre = ticket.pop("views", None)
         if pre is not None:
             # the step's own output buffer and its per-parameter views were made in do_DDM, while the host was going to
@@ -753,6 +769,10 @@ class _Ticket(dict):
     caller's stream is made to wait for the replay here, so that no later parameter write can overtake it."""
 
     def __del__(self):
+        try:
+            _restore_backward_threads(self)
+        except Exception:
+            pass
         try:
             if (not self.get("used") and self.get("event") is not None and not torch.cuda.is_current_stream_capturing()
                     and not self["event"].query()):
@@ -848,7 +868,7 @@ class _AutogradStep:
             if h:
                 hooks.append((h, list(h.items())))
                 h.clear()
-        if not torch.cuda.is_current_stream_capturing():
+        if not own_capture_open():
             self.gflat.zero_()  # (a replayed step: cleared by the launch that refreshes the graph's inputs, StepGraphs.refresh)
         for p, v in zip(self.params, self.views):
             p.grad = v
@@ -913,9 +933,11 @@ class _AutogradStep:
             g = sg.capture(batch, drawn)
             if g is None:
                 return None
-            sg.refresh(g, batch, drawn)
+            if not sg.refresh(g, batch, drawn):
+                return None
         else:
-            sg.refresh(g, batch)
+            if not sg.refresh(g, batch):
+                return None  # (the bucket refused the batch's tensors: this step as eager launches)
             draw_step_noise(batch, self.n1, self.n2, mu, sigma, device_noise, noise, into=sg.noise_views(g))
         g["graph"].replay()            # forward: the loss is on the device when this is done
         loss = g["loss"].clone()
@@ -927,8 +949,11 @@ class _AutogradStep:
             self._bwd_done = torch.cuda.Event()
             self._bwd_done.record(self._side)
         self._serial += 1
+        prev = self._ticket
+        if prev is not None:
+            _restore_backward_threads(prev)  # (a loss that never saw its backward(): its switch goes back first)
         self._ticket = _Ticket(serial=self._serial, event=self._bwd_done, g=None)
-        _single_thread_backward()
+        _single_thread_backward(self._ticket)
         buf = torch.empty_like(self.gflat)   # this step's (scaled) gradients as autograd will receive them
         self._ticket["views"] = (buf, [v.view(shape) for v, (shape, _) in zip(buf.split_with_sizes(self.numels), self.shapes)])
         # deferred index check of the backbone: the embedding kernel flagged an out-of-range atom type in the status
@@ -941,22 +966,24 @@ class _AutogradStep:
         return _ReplayedLoss.apply(loss, self, self._ticket, *self.params)
 
 
-_BACKWARD_TLS = [None]
-
-
-def _single_thread_backward():
+def _single_thread_backward(ticket):
     """The loss of a replayed step has ONE node behind it (_ReplayedLoss) and its 59 AccumulateGrads; autograd would hand
     them to its per-device worker thread and wake the caller when it is done - a hand-over that costs 0.13 ms per
     backward() (measured, tools/ref_loop_profile.py), a fifth of a whole step at the reference's batch size.  With
     multithreading off the calling thread runs the backward itself.  The switch is autograd's own, thread-local
-    (torch.autograd.set_multithreading_enabled), and only matters to graphs that span several devices - which one
-    process per GPU never builds; GEOSSL_KEEP_AUTOGRAD_THREADS leaves it alone."""
-    import threading
-    tid = threading.get_ident()
-    if _BACKWARD_TLS[0] != tid:
-        _BACKWARD_TLS[0] = tid
-        if not os.environ.get("GEOSSL_KEEP_AUTOGRAD_THREADS"):
-            torch.autograd.set_multithreading_enabled(False)
+    (torch.autograd.set_multithreading_enabled); it is turned off when do_DDM hands out the loss and put back to what the
+    caller had when that loss's backward has run (or the loss is dropped): other autograd work of the caller - graphs
+    that span several devices - sees its own setting.  GEOSSL_KEEP_AUTOGRAD_THREADS leaves the switch alone."""
+    if os.environ.get("GEOSSL_KEEP_AUTOGRAD_THREADS"):
+        return
+    if torch.autograd.is_multithreading_enabled():
+        torch.autograd.set_multithreading_enabled(False)
+        ticket["mt_restore"] = True
+
+
+def _restore_backward_threads(ticket):
+    if ticket.pop("mt_restore", None):
+        torch.autograd.set_multithreading_enabled(True)
 
 
 def _schnet_step_params(model):
@@ -1019,7 +1046,7 @@ class DDMTrainer:
 
     def _fwd_bwd(self, batch, noise):
         from . import NCSN as _ncsn
-        if not (self._zero_outside and torch.cuda.is_current_stream_capturing()):
+        if not (self._zero_outside and own_capture_open()):
             self.flat.zero_grad()  # (a replayed step: cleared with the refresh of the graph's inputs, StepGraphs.refresh)
         if noise is None and self.device_noise:
             noise = self._draw_noise(batch)  # the trainer's own stream, eager launches or replayed graph alike
@@ -1053,7 +1080,8 @@ class DDMTrainer:
                 self.use_graph = False
                 return self._fwd_bwd(batch, noise)
             own_noise = False  # already drawn: copied below like a caller's
-        sg.refresh(g, batch, None if own_noise else noise)
+        if not sg.refresh(g, batch, None if own_noise else noise):
+            return self._fwd_bwd(batch, noise)  # (the bucket refused the batch's tensors: this step as eager launches)
         if own_noise:  # the step's own draws go straight into the graph's static inputs (no staging copies)
             self._draw_noise(g["batch"], into=g["noise"])  # (g["batch"]: a bucket's draws cover its capacity)
         g["graph"].replay()

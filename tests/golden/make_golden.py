@@ -484,8 +484,92 @@ def g12():
         save("g12_ddm_trajectory_" + tag, **arrs)
 
 
+def extract_finetune():
+    """`train` and `eval` of examples/finetune_qm9.py (:163-275, :278-384) as the reference wrote them: the file itself
+    cannot be imported (argparse at import, rdkit datasets), so the two FunctionDefs are AST-extracted and executed
+    verbatim against module globals supplied here."""
+    src = open(os.path.join(REF, "examples", "finetune_qm9.py")).read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("train", "eval")]
+    assert len(keep) == 2
+    mod = ast.Module(body=keep, type_ignores=[])
+    from sklearn.metrics import mean_absolute_error
+    ns = {"torch": torch, "F": torch.nn.functional, "mean_absolute_error": mean_absolute_error}
+    exec(compile(mod, "finetune_qm9.py[train,eval]", "exec"), ns)
+    return ns
+
+
+class FtBatch:
+    """Duck-typed PyG batch of finetune_qm9.py's loader: .x .positions .batch .y and .to(device)."""
+
+    def __init__(self, d, y):
+        self.x, self.positions, self.batch = (torch.from_numpy(np.ascontiguousarray(d[k])) for k in ("x", "positions", "batch"))
+        self.y = y
+
+    def to(self, device):
+        return self
+
+
+def g14():
+    """BASELINE config 1: examples/finetune_qm9.py with SchNet at the defaults of examples/config.py (:111-115,141:
+    emb_dim = num_filters 128, 6 interactions, 51 gaussians, cutoff 10, readout mean) - the reference's own train()
+    (:163-275: forward, graph_pred_linear, L1 on the normalised target, Adam) over one epoch of three batches of 32
+    QM9-sized molecules (<= 29 atoms), CosineAnnealingLR(T_max = 100) stepped per epoch (:500-507), one more epoch, then
+    its own eval() (:278-384, under no_grad) over two batches.  Per-step losses (the criterion is wrapped to record
+    them), parameters after the two epochs, eval predictions and MAE."""
+    ns = extract_finetune()
+    cfg = dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=10.0, node_class=9,
+               readout="mean")
+    rng = np.random.default_rng(140)
+    num_tasks_total, task_id = 12, 7
+    def mk(seed, B=32):
+        sizes = np.clip(np.rint(rng.normal(18.0, 5.0, size=B)), 3, 29).astype(np.int64)
+        d = make_batch(0, seed=seed, sizes=sizes.tolist())
+        y = torch.from_numpy(rng.normal(-1.5, 2.0, size=(B * num_tasks_total,)).astype(np.float32))  # PyG cat: [B * tasks]
+        return d, FtBatch(d, y)
+    train_set = [mk(141 + i) for i in range(3)]
+    eval_set = [mk(151 + i) for i in range(2)]
+    model = fill_module_(SchNet(**cfg))
+    head = fill_module_(torch.nn.Linear(128, 1))   # graph_pred_linear (:113)
+    losses = []
+    l1 = torch.nn.L1Loss()                          # --loss mae (:453)
+
+    def criterion(pred, y):
+        out = l1(pred, y)
+        losses.append(out.detach().clone())
+        return out
+
+    class A:
+        model_3d, verbose, lr_scheduler = "schnet", False, "CosineAnnealingLR"
+    TRAIN_mean, TRAIN_std = -1.4, 2.1
+    group = [{"params": model.parameters(), "lr": 5e-4}, {"params": head.parameters(), "lr": 5e-4}]
+    optimizer = torch.optim.Adam(group, lr=5e-4, weight_decay=0)                      # (:500-507)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, 100)
+    ns.update(model=model, graph_pred_linear=head, args=A, criterion=criterion, TRAIN_mean=TRAIN_mean,
+              TRAIN_std=TRAIN_std, task_id=task_id, lr_scheduler=sched)
+    loader = [b for _, b in train_set]
+    acc = [ns["train"](epoch, "cpu", loader, optimizer) for epoch in (1, 2)]
+    mae, y_true, y_scores = ns["eval"]("cpu", [b for _, b in eval_set])
+    arrs = dict(cfg=json.dumps(cfg), task_id=task_id, TRAIN_mean=np.float64(TRAIN_mean), TRAIN_std=np.float64(TRAIN_std),
+                losses=torch.stack(losses), loss_acc=np.asarray(acc, dtype=np.float64), lr_after=np.float64(optimizer.param_groups[0]["lr"]),
+                mae=np.float64(mae), y_true=y_true, y_scores=y_scores)
+    for tag, items in (("train", train_set), ("eval", eval_set)):
+        for i, (d, b) in enumerate(items):
+            arrs["%s/%d/x" % (tag, i)], arrs["%s/%d/positions" % (tag, i)] = d["x"], d["positions"]
+            arrs["%s/%d/batch" % (tag, i)], arrs["%s/%d/y" % (tag, i)] = d["batch"], b.y
+            arrs["%s/%d/sizes" % (tag, i)] = np.asarray(d["sizes"])
+    seen = set()
+    for name, p in model.named_parameters():
+        if id(p) in seen:
+            continue
+        seen.add(id(p))
+        arrs["psum/" + name] = grad_summary(p.detach())
+    arrs["head/weight"], arrs["head/bias"] = head.weight.detach(), head.bias.detach()
+    save("g14_finetune_qm9_schnet", **arrs)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13):
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14):
         if not only or fn.__name__ in only:
             fn()

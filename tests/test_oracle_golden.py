@@ -335,3 +335,58 @@ def test_g13_painn_force_training():
             assert rel_err(grad_summary(P[k[5:]].grad), g[k]) < 5e-5, k
     for ref_name, mine in head_ref_names.items():
         assert rel_err(dict(head.named_parameters())[mine].grad, g["head_grad/" + ref_name]) < 5e-5, ref_name
+
+
+def finetune_epochs(g, forward, params, head_w, head_b, device="cpu"):
+    """The loop of examples/finetune_qm9.py:163-275 (forward -> graph_pred_linear -> squeeze -> L1 on the normalised
+    target -> zero_grad / backward / Adam step; CosineAnnealingLR(T_max = 100) stepped per epoch, :500-507) over the
+    fixture's three training batches for two epochs, then eval() (:278-384) over its two evaluation batches:
+    `forward(x0, positions, batch) -> [B, F]`.  Returns (per-step losses, eval predictions)."""
+    tm, ts, task = float(g["TRAIN_mean"]), float(g["TRAIN_std"]), int(g["task_id"])
+    opt = torch.optim.Adam([{"params": params, "lr": 5e-4}, {"params": [head_w, head_b], "lr": 5e-4}], lr=5e-4,
+                           weight_decay=0)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 100)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    losses = []
+    for epoch in (1, 2):
+        for i in range(3):
+            x, pos, bat, y = (dev(g["train/%d/%s" % (i, k)]) for k in ("x", "positions", "batch", "y"))
+            rep = forward(x[:, 0], pos, bat)                                             # :179
+            pred = torch.nn.functional.linear(rep, head_w, head_b).squeeze()             # :250
+            B = pred.size()[0]
+            yy = (y.view(B, -1)[:, task] - tm) / ts                                      # :254-257
+            loss = torch.nn.functional.l1_loss(pred, yy)                                 # :259, --loss mae
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        sched.step()                                                                      # :270-271
+    scores = []
+    with torch.no_grad():                                                                 # :278
+        for i in range(2):
+            x, pos, bat = (dev(g["eval/%d/%s" % (i, k)]) for k in ("x", "positions", "batch"))
+            pred = torch.nn.functional.linear(forward(x[:, 0], pos, bat), head_w, head_b).squeeze()
+            scores.append(pred * ts + tm)                                                 # :374
+    return losses, torch.cat(scores).cpu(), float(opt.param_groups[0]["lr"])
+
+
+def test_g14_finetune_qm9_schnet_two_epochs_and_eval():
+    """BASELINE config 1 (examples/finetune_qm9.py, SchNet at config.py's defaults: cutoff 10, 51 gaussians, readout
+    mean, batches of 32 QM9-sized molecules) on the oracle against the reference's own train() / eval(): per-step L1
+    losses, the parameters after two epochs, the evaluation predictions and their MAE."""
+    g = load_golden("g14_finetune_qm9_schnet")
+    cfg = json.loads(str(g["cfg"]))
+    P = schnet_params(cfg)
+    hw = fill_dict({"weight": (1, 128), "bias": (1,)})
+    head_w, head_b = hw["weight"].requires_grad_(), hw["bias"].requires_grad_()
+    fwd = lambda z, pos, bat: nets.schnet_forward(P, z, pos, bat, cfg["cutoff"], cfg["num_interactions"], cfg["readout"])
+    losses, scores, lr = finetune_epochs(g, fwd, [p for p in P.values() if p.requires_grad], head_w, head_b)
+    assert rel_err(losses, g["losses"]) < 1e-5 and abs(lr - float(g["lr_after"])) < 1e-12
+    assert rel_err(scores, g["y_scores"]) < 1e-5
+    y_true = torch.cat([t(g["eval/%d/y" % i]).view(32, -1)[:, int(g["task_id"])] for i in range(2)])
+    assert torch.equal(y_true, t(g["y_true"]))
+    assert abs(float((scores - y_true).abs().mean()) - float(g["mae"])) < 1e-5 * float(g["mae"])
+    for k in g:
+        if k.startswith("psum/"):
+            assert rel_err(grad_summary(P[k[5:]].detach()), g[k]) < 1e-5, k
+    assert rel_err(head_w, g["head/weight"]) < 1e-5 and rel_err(head_b, g["head/bias"]) < 1e-5
