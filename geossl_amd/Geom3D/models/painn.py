@@ -151,9 +151,12 @@ class PaiNN(nn.Module):
             ps += [n[0].weight, n[0].bias, n[1].weight, n[1].bias, blk.mu_channel_mix.weight]
         return ps
 
-    def forward(self, x, positions, radius_edge_index, batch, return_latent=False, latent_only=False):
+    def forward(self, x, positions, radius_edge_index, batch, return_latent=False, latent_only=False, layout=None,
+                edge_layout=None):
         """painn.py:216-269.  `latent_only` (with return_latent): the readout is not evaluated and None is returned in
-        its place - the DDM step drops it (pretrain_GeoSSL.py:187)."""
+        its place - the DDM step drops it (pretrain_GeoSSL.py:187).  `layout` / `edge_layout` (extension): the molecule
+        and edge structures of the batch when the caller already has them - the static, capacity-sized structures of a
+        capacity bucket (geossl_amd/bucket.py), whose real counts are device data."""
         _lib.require_cuda(x, positions, radius_edge_index, batch)
         if self.share_filters or (self.n_interactions > 1 and self.interactions[0] is self.interactions[1]):
             raise NotImplementedError("shared_filters / shared_interactions are off the GeoSSL path")
@@ -162,10 +165,10 @@ class PaiNN(nn.Module):
         if self.activation is not F.silu:
             raise NotImplementedError("HIP path implements the reference default activation F.silu")
         atomic_numbers = x[:, 0] if x.dim() == 2 else x  # painn.py:226-229
-        lay = get_layout(batch)
+        lay = layout if layout is not None else get_layout(batch)
         if positions.dtype != torch.float32:
             raise TypeError("positions must be float32")
-        el = get_edge_layout(batch, radius_edge_index, lay.B)
+        el = edge_layout if edge_layout is not None else get_edge_layout(batch, radius_edge_index, lay.B)
         status = _lib.module_status(self, positions.device, "atomic number out of range for the embedding table "
                                     "(max_z=%d)" % self.embedding.num_embeddings)
         status.poll()  # an out-of-range atomic number seen by an earlier call raises here (IndexError, like Embedding)
@@ -204,12 +207,20 @@ class _PaiNNCore(torch.autograd.Function):
         inter = [ps[3 + 4 * l: 7 + 4 * l] for l in range(L)]
         mix = [ps[3 + 4 * L + 5 * l: 8 + 4 * L + 5 * l] for l in range(L)]
         f32 = dict(dtype=torch.float32, device=dev)
+        # the structures of a capacity bucket (geossl_amd/bucket.py) carry the device addresses of the batch's real counts:
+        # N, E are then capacities and every count-driven launch below is told where the real count lives (rows of the
+        # scalar features, rows of the vector features viewed as [3 N, F], edges)
+        dyn = getattr(el, "dyn", None)
+        dN, dN3, dE = (dyn.n_atoms2, dyn.n_atoms2x3, dyn.n_edges2) if dyn is not None else (None, None, None)
+        if dyn is not None and (ctx.needs_input_grad[1] or F_ != 128 or os.environ.get("GEOSSL_PAINN_NO_CHAIN")
+                                or os.environ.get("GEOSSL_PAINN_SILU_KERNELS")):
+            raise _lib.GeosslHipError("a capacity-bucket layout serves the F = 128 chain path without position gradients")
         dirv, fcut, phi = torch.empty(max(E, 1), 3, **f32), torch.empty(max(E, 1), **f32), torch.empty(max(E, 1), R, **f32)
-        call("geossl_painn_edge_geom", ptr(pos), ptr(el.idx_i), ptr(el.idx_j), E, cfg["cutoff"], ptr(cfg["offsets"]),
-             ptr(cfg["widths"]), R, ptr(dirv), ptr(fcut), ptr(phi), st)
+        call("geossl_painn_edge_geom_dyn", ptr(pos), ptr(el.idx_i), ptr(el.idx_j), E, cfg["cutoff"], ptr(cfg["offsets"]),
+             ptr(cfg["widths"]), R, ptr(dirv), ptr(fcut), ptr(phi), dE, st)
         q = torch.empty(N, F_, **f32)
-        call("geossl_embedding_fwd", ptr(z), z.stride(0) if z.numel() else 1, ptr(emb_w), emb_w.size(0), N, F_, ptr(q),
-             ptr(cfg["status"].word), st)                                   # painn.py:247 (row 0 is the zero padding row)
+        call("geossl_embedding_fwd_dyn", ptr(z), z.stride(0) if z.numel() else 1, ptr(emb_w), emb_w.size(0), N, F_, ptr(q),
+             ptr(cfg["status"].word), dN, st)                               # painn.py:247 (row 0 is the zero padding row)
         if cfg["debug"]:
             cfg["status"].check()
         mu = torch.zeros(N, 3, F_, **f32)                                    # :249
@@ -236,12 +247,14 @@ class _PaiNNCore(torch.autograd.Function):
                     lin(x, None, k, bias=b_, out=o_)
                 return
             ops.linear_chain(x, [dict(image=img[k], bias=b_, out=o_, same_input=(n_ > 0))
-                                 for n_, (k, b_, o_) in enumerate(zip(ks, biases, outs))])
+                                 for n_, (k, b_, o_) in enumerate(zip(ks, biases, outs))],
+                             dyn_rows=dN if x.size(0) == N else dN3)
 
         def lin(x, w, k, bias=None, res=None, out=None):
             if img is None:
                 return ops.linear(x, blocks[k].contiguous(), bias=bias, res=res, out=out)
-            return ops.linear_chain(x, [dict(image=img[k], bias=bias, res=res, out=out)])[0]
+            return ops.linear_chain(x, [dict(image=img[k], bias=bias, res=res, out=out)],
+                                    dyn_rows=dN if x.size(0) == N else dN3)[0]
 
         for l in range(L):
             c0w, c0b, c1w, c1b = inter[l]
@@ -251,7 +264,7 @@ class _PaiNNCore(torch.autograd.Function):
                 u, s = torch.empty(N, F_, **f32), torch.empty(N, F_, **f32)
                 ops.linear_chain(q, [dict(image=img[k0], bias=c0b, out=u, out_act=s, flags=_lib.EPI_SILU)] +
                                  [dict(image=img[k0 + 1 + c], bias=c1b[c * F_:(c + 1) * F_], out=o_, same_input=(c > 0))
-                                  for c, o_ in enumerate(_split3(xc, F_))])
+                                  for c, o_ in enumerate(_split3(xc, F_))], dyn_rows=dN)
             else:
                 u = lin(q, c0w, k0, bias=c0b)                                # Dense(F, F, silu)      :27-30,53
                 s = torch.empty_like(u)
@@ -262,10 +275,10 @@ class _PaiNNCore(torch.autograd.Function):
             lay = cfg["lay"]  # one block per molecule: the rows its edges read are staged in LDS once
             if cfg["mma"] and lay.max_n <= 44 and E > 0:  # filter on the matrix pipe (painn_mma.hip); LDS: 3.5 KB per atom + 3 KB
                 row_edge, grp_atom, _, mol_grp = el.groups("i", lay.mol_ptr)
-                call("geossl_painn_interaction_fwd_mma", ptr(q), ptr(mu), ptr(xc), ptr(el.idx_j), ptr(row_edge),
+                call("geossl_painn_interaction_fwd_mma_dyn", ptr(q), ptr(mu), ptr(xc), ptr(el.idx_j), ptr(row_edge),
                      ptr(grp_atom), ptr(mol_grp), ptr(phi), ptr(fcut), ptr(dirv), ptr(fw[l * 3 * F_:(l + 1) * 3 * F_]),
                      ptr(fb[l * 3 * F_:(l + 1) * 3 * F_]), ptr(lay.mol_ptr), lay.B, lay.max_n, N, F_, R, ptr(q2), ptr(mu2),
-                     st)                                                        # :54-64
+                     ptr(getattr(el, "mol_grp_end", None)), st)                 # :54-64
             else:
                 call("geossl_painn_interaction_fwd_mol", ptr(q), ptr(mu), ptr(xc), ptr(el.idx_j), ptr(inc_ptr),
                      ptr(inc_idx), ptr(phi), ptr(fcut), ptr(dirv), ptr(fw[l * 3 * F_:(l + 1) * 3 * F_]),
@@ -275,7 +288,7 @@ class _PaiNNCore(torch.autograd.Function):
             mm = torch.empty(3 * N, 2 * F_, **f32)                           # mu_channel_mix        :100
             lin_fan(mu2.view(3 * N, F_), [k0 + 4, k0 + 5], [None, None], [mm[:, :F_], mm[:, F_:]])
             cx, dot = torch.empty(N, 2 * F_, **f32), torch.empty(N, F_, **f32)
-            call("geossl_painn_mix_pre_fwd", ptr(q2), ptr(mm), N, F_, cfg["eps"], ptr(cx), ptr(dot), st)  # :101-104
+            call("geossl_painn_mix_pre_fwd_dyn", ptr(q2), ptr(mm), N, F_, cfg["eps"], ptr(cx), ptr(dot), dN, st)  # :101-104
             # Dense(2F, F, silu) :105 - a contraction over 2F columns is two passes of the F-wide row GEMM (the split
             # kernel holds one K <= 128 weight image in LDS): the second adds onto the first through the residual operand
             xx = torch.empty(N, 3 * F_, **f32)
@@ -285,7 +298,7 @@ class _PaiNNCore(torch.autograd.Function):
                                               dict(image=img[k0 + 7], x=cx[:, F_:], add_prev=True, out=u1, out_act=s1,
                                                    flags=_lib.EPI_SILU)] +
                                  [dict(image=img[k0 + 8 + c], bias=i1b[c * F_:(c + 1) * F_], out=o_, same_input=(c > 0))
-                                  for c, o_ in enumerate(_split3(xx, F_))])
+                                  for c, o_ in enumerate(_split3(xx, F_))], dyn_rows=dN)
             else:
                 if img is not None and F_ == 128:   # both F-wide passes in one launch (the second brings its own input)
                     u1 = ops.linear_chain(cx[:, :F_], [dict(image=img[k0 + 6], bias=i0b, store=False),
@@ -298,7 +311,8 @@ class _PaiNNCore(torch.autograd.Function):
                 lin_fan(s1, [k0 + 8 + c for c in range(3)], [i1b[c * F_:(c + 1) * F_] for c in range(3)],
                         _split3(xx, F_))                                     # Dense(F, 3F)
             q3, mu3 = torch.empty_like(q), torch.empty_like(mu)
-            call("geossl_painn_mix_post_fwd", ptr(q2), ptr(mu2), ptr(mm), ptr(xx), ptr(dot), N, F_, ptr(q3), ptr(mu3), st)
+            call("geossl_painn_mix_post_fwd_dyn", ptr(q2), ptr(mu2), ptr(mm), ptr(xx), ptr(dot), N, F_, ptr(q3), ptr(mu3),
+                 dN, st)
             if training:
                 saved.append(dict(q=q, mu=mu, u=u, s=s, xc=xc, q2=q2, mu2=mu2, mm=mm, cx=cx, dot=dot, u1=u1, s1=s1, xx=xx))
             q, mu = q3, mu3
@@ -341,6 +355,10 @@ class _PaiNNCore(torch.autograd.Function):
         g_inter = [grads[3 + 4 * l: 7 + 4 * l] for l in range(L)]
         g_mix = [grads[3 + 4 * L + 5 * l: 8 + 4 * L + 5 * l] for l in range(L)]
         inc_ptr, inc_idx = el.inc["j"]
+        dyn = getattr(el, "dyn", None)
+        dN, dN3 = (dyn.n_atoms2, dyn.n_atoms2x3) if dyn is not None else (None, None)
+        if dyn is not None and want_pos:
+            raise _lib.GeosslHipError("a capacity-bucket layout serves the step without position gradients")
         dq_cur = dq.contiguous()
         dmu_cur = torch.zeros(N, 3, F_, **f32)
         groups = {}  # (rows, lda, ldb, ldw) -> list of problems, all with M = N = F
@@ -361,7 +379,7 @@ class _PaiNNCore(torch.autograd.Function):
         def lin_t(x, w, k, res=None, out=None):  # x @ w (the transposed use of a forward weight block)
             if img is None:
                 return ops.linear(x, blocks[k].contiguous(), transB=False, res=res, out=out)
-            return ops.linear_chain(x, [dict(image=img[k], res=res, out=out)])[0]
+            return ops.linear_chain(x, [dict(image=img[k], res=res, out=out)], dyn_rows=dN if x.size(0) == N else dN3)[0]
 
         lay = cfg["lay"]
         def lin_t_sum(xs_list, ks, res=None):
@@ -385,7 +403,7 @@ class _PaiNNCore(torch.autograd.Function):
                 # the residual belongs to the stage that stores: move it there (the row stride must be the output's)
                 stages[0].pop("res")
                 stages[-1]["res"] = res
-            return ops.linear_chain(xs_list[0], stages)[-1]
+            return ops.linear_chain(xs_list[0], stages, dyn_rows=dN if xs_list[0].size(0) == N else dN3)[-1]
 
         nfl = _lib.load().geossl_painn_interaction_bwd_mol_workspace_floats(N, lay.B, F_, R)
         ws = torch.empty(max(int(nfl), 1), **f32)
@@ -402,8 +420,8 @@ class _PaiNNCore(torch.autograd.Function):
             k0 = NB * l
             # ---- mixing block
             dxx, dmm = torch.empty(N, 3 * F_, **f32), torch.empty(3 * N, 2 * F_, **f32)
-            call("geossl_painn_mix_post_bwd", ptr(dq_cur), ptr(dmu_cur), ptr(sv["mm"]), ptr(sv["xx"]), ptr(sv["dot"]), N,
-                 F_, ptr(dxx), ptr(dmm), st)
+            call("geossl_painn_mix_post_bwd_dyn", ptr(dq_cur), ptr(dmu_cur), ptr(sv["mm"]), ptr(sv["xx"]), ptr(sv["dot"]), N,
+                 F_, ptr(dxx), ptr(dmm), dN, st)
             for c, xs_ in enumerate(_split3(dxx, F_)):
                 add(N, 3 * F_, F_, F_, xs_, sv["s1"], gi1w[c * F_:(c + 1) * F_], gi1b[c * F_:(c + 1) * F_])
             dctx = torch.empty(N, 2 * F_, **f32)                           # [N][2F] = du1 @ i0w
@@ -415,7 +433,7 @@ class _PaiNNCore(torch.autograd.Function):
                                          dict(image=img[k0 + 10], x=x3[2], add_prev=True, tprev=sv["u1"], out=du1,
                                               flags=_lib.EPI_MUL_DSILU),
                                          dict(image=img[k0 + 6], out=dctx[:, :F_]),
-                                         dict(image=img[k0 + 7], out=dctx[:, F_:], same_input=True)])
+                                         dict(image=img[k0 + 7], out=dctx[:, F_:], same_input=True)], dyn_rows=dN)
             else:
                 ds1 = lin_t_sum(_split3(dxx, F_), [k0 + 8 + c for c in range(3)])
                 du1 = torch.empty_like(ds1)
@@ -430,8 +448,8 @@ class _PaiNNCore(torch.autograd.Function):
                 add(N, F_, 2 * F_, 2 * F_, du1, sv["cx"][:, c * F_:(c + 1) * F_], gi0w[:, c * F_:(c + 1) * F_],
                     gi0b if c == 0 else None)
             dq2 = torch.empty(N, F_, **f32)
-            call("geossl_painn_mix_pre_bwd", ptr(dq_cur), ptr(dctx), ptr(sv["cx"]), ptr(sv["mm"]), N, F_, ptr(dq2),
-                 ptr(dmm), st)
+            call("geossl_painn_mix_pre_bwd_dyn", ptr(dq_cur), ptr(dctx), ptr(sv["cx"]), ptr(sv["mm"]), N, F_, ptr(dq2),
+                 ptr(dmm), dN, st)
             # d mu (after interaction): contraction over the 2F columns of dmm in two F-wide passes
             dmu2 = lin_t_sum([dmm[:, :F_], dmm[:, F_:]], [k0 + 4, k0 + 5], res=dmu_cur.view(3 * N, F_))
             for c in range(2):
@@ -457,7 +475,7 @@ class _PaiNNCore(torch.autograd.Function):
                                          dict(image=img[k0 + 2], x=x3[1], add_prev=True, store=False),
                                          dict(image=img[k0 + 3], x=x3[2], add_prev=True, tprev=sv["u"], out=du,
                                               flags=_lib.EPI_MUL_DSILU),
-                                         dict(image=img[k0], res=dq2, out=dq_in)])
+                                         dict(image=img[k0], res=dq2, out=dq_in)], dyn_rows=dN)
             else:
                 ds = lin_t_sum(_split3(dxc, F_), [k0 + 1 + c for c in range(3)])
                 du = torch.empty_like(ds)
@@ -478,14 +496,15 @@ class _PaiNNCore(torch.autograd.Function):
         if not want_params:  # an evaluation of the forces alone (finetune_md17.py:85-105 with frozen weights)
             return dpos, [None] * len(grads)
         for (rows, lda, ldb, ldw), probs in groups.items():
-            ops.linear_wgrad(probs, rows, F_, F_, accumulate=bool(acc), lda=lda, ldb=ldb, ldw=ldw)
+            ops.linear_wgrad(probs, rows, F_, F_, accumulate=bool(acc), lda=lda, ldb=ldb, ldw=ldw,
+                             dyn_rows=dN if rows == N else dN3)
         # embedding table; padding_idx = 0 keeps row 0 without gradient (painn.py:174)
         z = ctx.z
         emb_w = ps[0]
         tmp = torch.empty_like(emb_w)
         wsf = torch.empty(int(_lib.load().geossl_embedding_bwd_workspace_floats(emb_w.size(0), F_)), **f32)
-        call("geossl_embedding_bwd", ptr(z), z.stride(0) if z.numel() else 1, ptr(dq_cur), emb_w.size(0), N, F_, ptr(tmp),
-             ptr(wsf), 0, st)
+        call("geossl_embedding_bwd_dyn", ptr(z), z.stride(0) if z.numel() else 1, ptr(dq_cur), emb_w.size(0), N, F_, ptr(tmp),
+             ptr(wsf), 0, dN, st)
         tmp[0].zero_()
         if direct:
             g_emb.add_(tmp)

@@ -200,6 +200,16 @@ PROTOTYPES = {
     "geossl_linear_wgrad_dyn": (i32, [P(TnBatch), i32, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
     "geossl_ddm_loss_fwd2_dyn": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp]),
     "geossl_ddm_loss_bwd_fused2_dyn": (i32, [vp, vp, vp, i64, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp]),
+    # PaiNN on a capacity bucket
+    "geossl_painn_group_capacity": (i64, [i64, i64]),
+    "geossl_painn_edge_layout": (i32, [vp, vp, i64, vp, i64, i64, i64] + [vp] * 12),
+    "geossl_painn_edge_geom_dyn": (i32, [vp, vp, vp, i64, f32, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "geossl_painn_interaction_fwd_mma_dyn": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i64, i32,
+                                                   i32, vp, vp, vp, vp]),
+    "geossl_painn_mix_pre_fwd_dyn": (i32, [vp, vp, i64, i32, f32, vp, vp, vp, vp]),
+    "geossl_painn_mix_post_fwd_dyn": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp]),
+    "geossl_painn_mix_post_bwd_dyn": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp]),
+    "geossl_painn_mix_pre_bwd_dyn": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp, vp]),
 }
 
 _lib = None

@@ -28,8 +28,12 @@ import torch
 from . import _lib
 from ._lib import call, ptr, stream
 
-MAX_N = 33          # largest molecule a bucket takes (the register-form aggregation's largest size class)
-D_N, D_N2, D_P2, D_S, D_W, D_B = 0, 1, 2, 3, 4, 5   # words of `dims`
+MAX_N = 255         # largest molecule a bucket takes (the limit of the aggregation's work list and of the heads)
+SMALL_N = 33        # ... and the largest one of the register-form aggregation's size classes: buckets whose molecules
+                    # all fit it keep the flat pair-geometry kernel and the ragged layer loop
+MAX_N_CLASSES = (SMALL_N, 64, 128, MAX_N)   # a bucket's bound on the molecule size (LDS of the radius-graph kernel)
+D_N, D_N2, D_P2, D_S, D_W, D_B, D_N6, D_E2 = 0, 1, 2, 3, 4, 5, 6, 7   # words of `dims`
+PAINN_MAX_N_CLASSES = (22, 33, 44, 64, 96, 128, MAX_N)   # PaiNN: the bound sizes the LDS of its per-molecule kernels
 
 
 class DynDims:
@@ -43,6 +47,8 @@ class DynDims:
         self.n_pairs2 = base + 4 * D_P2     # pair slots of the two-view batch
         self.n_super = base + 4 * D_S       # super-edges of one view
         self.n_work = base + 4 * D_W        # work items of the aggregation
+        self.n_atoms2x3 = base + 4 * D_N6   # PaiNN: rows of the vector features viewed as [3 N2, F]
+        self.n_edges2 = base + 4 * D_E2     # PaiNN: edges of the two-view batch
 
 
 class _Layout:
@@ -60,12 +66,29 @@ class _SuperEdges:
     """Duck type of layout.SuperEdgeLayout for a bucket."""
 
 
+class _Edges:
+    """Duck type of layout.EdgeLayout for the two-view batch of a PaiNN bucket: every array is a static buffer at the
+    bucket's capacity that geossl_painn_edge_layout rewrites per step; the groups of a molecule end at mol_grp_end."""
+
+    def groups(self, side, mol_ptr=None):
+        assert side == "i"
+        return (self.row_edge, self.grp_atom, None, self.mol_grp)
+
+
 def _parts_table():
-    lib = _lib.load()
-    return np.array([lib.geossl_aggregate_parts(k) for k in range(MAX_N + 1)], dtype=np.int64)
+    from .layout import parts_table
+    return parts_table()
 
 
 _PARTS = None
+
+
+def max_n_class(hi, prev=None, model_3d="schnet"):
+    """The bucket's bound on the molecule size for a batch whose largest molecule has `hi` atoms."""
+    for c in (PAINN_MAX_N_CLASSES if model_3d == "painn" else MAX_N_CLASSES):
+        if hi <= c and (prev is None or c >= prev):
+            return c
+    return MAX_N
 
 
 def sizes_array(batch):
@@ -89,15 +112,22 @@ def batch_counts(sizes, option):
 
 
 def eligible(batch, model_3d, normalize=False):
-    """Can this batch go through a bucket graph?  SchNet backbone, molecule sizes known on the host (1 .. 33 atoms, at
-    least one molecule with a pair), super_edge_index the extractor's full enumeration - every index tensor of the step
-    is then a function of the sizes."""
+    """Can this batch go through a bucket graph?  Molecule sizes known on the host (1 .. 255 atoms, at least one molecule
+    with a pair), super_edge_index the extractor's full enumeration - every index tensor of the SchNet step is then a
+    function of the sizes; PaiNN: also a collated radius_edge_index on the device (its structures are rebuilt on the
+    device per step, geossl_painn_edge_layout)."""
     sizes, canon = getattr(batch, "_sizes", None), getattr(batch, "_canonical", None)
-    if model_3d != "schnet" or normalize or sizes is None or canon not in ("combination", "permutation") or not len(sizes):
+    if (model_3d not in ("schnet", "painn") or normalize or sizes is None or canon not in ("combination", "permutation")
+            or not len(sizes)):
         return False
     lo, hi = size_range(batch)
     if lo < 1 or hi > MAX_N or hi < 2:
         return False
+    if model_3d == "painn":
+        rei = getattr(batch, "radius_edge_index", None)
+        if (rei is None or not rei.is_cuda or rei.dtype != torch.long or rei.dim() != 2 or rei.size(0) != 2
+                or rei.stride(1) != 1):
+            return False
     return tensors_ok(batch)
 
 
@@ -126,18 +156,30 @@ def tensors_ok(batch):
 
 
 MODULE_SWITCHES = ("GEOSSL_NO_CHAIN", "GEOSSL_NCSN_SPLIT_BWD", "GEOSSL_NCSN_SEPARATE_HEADS")  # read by modules_ok
+PAINN_SWITCHES = ("GEOSSL_PAINN_NO_CHAIN", "GEOSSL_PAINN_SILU_KERNELS")   # ... for a PaiNN backbone as well
 
 
 def modules_ok(model, n1, n2):
-    """The step of these modules can run on a bucket: the F = 128 chain path of SchNet (the chained row kernel is the one
-    that takes a device-side row count) and the paired NCSN heads (two different modules of width 128)."""
+    """The step of these modules can run on a bucket: the F = 128 chain path of SchNet / PaiNN (the chained row kernel is
+    the one that takes a device-side row count) and the paired NCSN heads (two different modules of width 128)."""
     import os
+    from .Geom3D.models.painn import PaiNN
     from .Geom3D.models.schnet import SchNet
     from .NCSN import NCSN_version_03, _head_params
     if any(os.environ.get(k) for k in MODULE_SWITCHES):
         return False
-    if not isinstance(model, SchNet) or model.hidden_channels != 128 or model.num_filters != 128 \
-            or model.num_interactions < 1 or model.dipole or model.atomref is not None or model.mean is not None:
+    if isinstance(model, SchNet):
+        if (model.hidden_channels != 128 or model.num_filters != 128 or model.num_interactions < 1 or model.dipole
+                or model.atomref is not None or model.mean is not None):
+            return False
+    elif isinstance(model, PaiNN):
+        import torch.nn.functional as F_
+        if (model.n_atom_basis != 128 or model.radial_basis.n_rbf not in (8, 16, 20) or model.share_filters
+                or model.n_interactions < 1 or model.activation is not F_.silu
+                or (model.n_interactions > 1 and model.interactions[0] is model.interactions[1])
+                or any(os.environ.get(k) for k in PAINN_SWITCHES)):
+            return False
+    else:
         return False
     if not (isinstance(n1, NCSN_version_03) and isinstance(n2, NCSN_version_03)) or n1 is n2 \
             or n1.emb_dim != 128 or n2.emb_dim != 128:
@@ -165,15 +207,38 @@ def _round_up(v, g):
     return int(-(-int(v) // g) * g)
 
 
-def capacities(N, P, S, W, B, prev=None):
+def _slacks(B, sizes=None):
+    """Relative head room of a capacity over the first batch's count, for (atoms, pair-slot-like counts): it has to cover
+    the spread of a shuffled loader's batch sums, ~ cv / sqrt(B) with cv the relative spread of the per-molecule count -
+    three of those standard deviations, from the sizes of the batch at hand when they are given (molecules with hydrogens
+    spread twice as much in their pair-slot counts as the 18 +- 4 atoms of set B), never below 1.5 / sqrt(B)."""
+    base = min(0.25, max(0.03, 1.5 / np.sqrt(max(B, 1))))
+    if sizes is None or len(sizes) < 2:
+        return base, base
+    n = np.asarray(sizes, dtype=np.float64)
+    p = n * (n - 1) / 2
+    cv = lambda v: float(v.std() / max(v.mean(), 1e-9))
+    f = 3.0 / np.sqrt(max(B, 1))
+    return max(base, min(0.4, f * cv(n))), max(base, min(0.4, f * cv(p)))
+
+
+def capacities(N, P, S, W, B, prev=None, sizes=None):
     """Capacities for a batch with these counts: a slack that covers the spread of a shuffled loader's batch sums
-    (relative spread ~ 1 / sqrt(B)), rounded to the kernels' tile sizes; never below a previous bucket's."""
-    slack = min(0.25, max(0.03, 1.5 / np.sqrt(max(B, 1))))
-    cap = lambda v, g: _round_up(v * (1.0 + slack) + g, g)
-    out = [cap(N, 32), cap(P, 64), cap(S, 64), cap(W, 64)]
+    (`_slacks`), rounded to the kernels' tile sizes; never below a previous bucket's."""
+    sn, sp = _slacks(B, sizes)
+    cap = lambda v, g, sl: _round_up(v * (1.0 + sl) + g, g)
+    out = [cap(N, 32, sn), cap(P, 64, sp), cap(S, 64, sp), cap(W, 64, sp)]
     if prev is not None:
         out = [max(a, b) for a, b in zip(out, prev)]
     return tuple(out)
+
+
+def edge_capacity(E, B, prev=None, sizes=None):
+    """Capacity for the edges of a PaiNN batch (one view) with E edges, with the slack of `capacities` for pair-slot-like
+    counts (the edges of a molecule lie between its atoms and its pair slots)."""
+    slack = _slacks(B, sizes)[1]
+    cap = _round_up(E * (1.0 + slack) + 64, 64)
+    return cap if prev is None else max(cap, int(prev))
 
 
 def host_plan(sizes, option):
@@ -205,15 +270,20 @@ def host_plan(sizes, option):
     ip = np.zeros(N + 1, dtype=np.int64)
     np.cumsum(np.repeat((n - 1) * mult, n), out=ip[1:])
     return dict(counts=(N, P, S, W), mol_ptr2=np.concatenate([mp, mp[1:] + N]), pair_ptr2=np.concatenate([pp, pp[1:] + P]),
-                se_ptr=pp * mult, work=(mol | (part << 28)).astype(np.int32), divisor=int(has[-1]) + 1 if has.size else 0,
-                inc_ptr=ip)
+                se_ptr=pp * mult, work=(mol | (part << 28)).astype(np.uint32).view(np.int32),
+                divisor=int(has[-1]) + 1 if has.size else 0, inc_ptr=ip)
 
 
 class Bucket:
-    def __init__(self, device, B, caps, option, x_cols=2):
+    """kind "schnet": pair-slot structures of the two-view batch (pointer arrays and work list from the host, pair-slot
+    atoms by geossl_pair_index_fill).  kind "painn": the structures of the batch's radius_edge_index for the two-view batch
+    (geossl_painn_edge_layout: one launch on the batch's own edge tensor, outputs at the edge capacity E_cap)."""
+
+    def __init__(self, device, B, caps, option, x_cols=2, max_n=SMALL_N, kind="schnet", E_cap=0):
         from .pretrain_GeoSSL import Batch
-        self.device, self.B, self.option = device, int(B), option
-        self.N_cap, self.P_cap, self.S_cap, self.W_cap = (int(c) for c in caps)
+        self.device, self.B, self.option, self.max_n = device, int(B), option, int(max_n)
+        self.kind, self.E_cap = kind, int(E_cap)
+        self.N_cap, self.P_cap, self.S_cap, self.W_cap = (int(c) for c in caps[:4])
         B, Nc, Pc, Sc, Wc = self.B, self.N_cap, self.P_cap, self.S_cap, self.W_cap
         i32 = dict(dtype=torch.int32, device=device)
         i64 = dict(dtype=torch.int64, device=device)
@@ -237,18 +307,38 @@ class Bucket:
         self.positions = torch.zeros(Nc, 3, dtype=torch.float32, device=device)
         self.batch_vec = torch.zeros(Nc, **i64)
         self.sei = torch.zeros(2, Sc, **i64)
-        self.b2 = torch.zeros(2 * Nc, **i64)   # placeholder for SchNet.forward's `batch` argument (the layout is passed)
+        self.b2 = torch.zeros(2 * Nc, **i64)   # placeholder for the backbone's `batch` argument (the layout is passed)
         # ---- two-view molecule layout
         lay = _Layout()
-        lay.N, lay.B, lay.P, lay.max_n = 2 * Nc, 2 * B, 2 * Pc, MAX_N
+        lay.N, lay.B, lay.P, lay.max_n = 2 * Nc, 2 * B, 2 * Pc, self.max_n
         lay.mol_ptr = self.blob[o["mol_ptr"]:o["mol_ptr"] + 2 * B + 1]
         lay.pair_ptr = self.blob[o["pair_ptr"]:o["pair_ptr"] + 2 * B + 1]
-        lay.pair_i = torch.zeros(2 * Pc, **i32)
-        lay.pair_j = torch.zeros(2 * Pc, **i32)
-        lay.agg_work = self.blob[o["work"]:o["work"] + Wc]
         lay.device, lay.dyn = device, self.dyn
         lay._batch_version = self.b2._version
+        lay.agg_work = None
+        if kind == "schnet":
+            lay.pair_i = torch.zeros(2 * Pc, **i32)
+            lay.pair_j = torch.zeros(2 * Pc, **i32)
+            lay.agg_work = self.blob[o["work"]:o["work"] + Wc]
         self.lay2 = lay
+        # ---- PaiNN: edge structures of the two-view batch
+        self.el = None
+        if kind == "painn":
+            Ec = self.E_cap
+            el = _Edges()
+            el.E, el.N, el.B = 2 * Ec, 2 * Nc, 2 * B
+            el.idx_i, el.idx_j = torch.zeros(2 * Ec, **i64), torch.zeros(2 * Ec, **i64)
+            el.inc = {"i": (torch.zeros(2 * Nc + 1, **i64), torch.zeros(max(2 * Ec, 1), **i32)),
+                      "j": (torch.zeros(2 * Nc + 1, **i64), torch.zeros(max(2 * Ec, 1), **i32))}
+            G = int(_lib.load().geossl_painn_group_capacity(2 * Ec, 2 * Nc))
+            el.row_edge = torch.full((4 * G,), -1, **i32)
+            el.grp_atom = torch.full((G,), -1, **i32)
+            el.mol_grp = torch.zeros(2 * B + 1, **i32)
+            el.mol_grp_end = torch.zeros(2 * B, **i32)
+            el.status = torch.zeros(1, **i32)
+            el.dyn = self.dyn
+            self.el = el
+            self.e2 = torch.zeros(2, 1, **i64)   # placeholder for PaiNN.forward's radius_edge_index argument
         # ---- super-edge bookkeeping of the heads
         sel = _SuperEdges()
         sel.sei0, sel.sei1, sel.batch = self.sei[0], self.sei[1], self.batch_vec
@@ -268,8 +358,10 @@ class Bucket:
     def caps(self):
         return (self.N_cap, self.P_cap, self.S_cap, self.W_cap)
 
-    def fits(self, counts):
-        return all(c <= cap for c, cap in zip(counts, self.caps()))
+    def fits(self, counts, hi=None, E=None):
+        """counts = (N, P, S, W) of a batch; hi: its largest molecule; E: its edges (PaiNN)."""
+        return (all(c <= cap for c, cap in zip(counts, self.caps())) and (hi is None or hi <= self.max_n)
+                and (E is None or self.kind != "painn" or E <= self.E_cap))
 
     def fill(self, batch, counts=None, zero=None):
         """The batch's atom types, positions, index tensors and derived structures into the static buffers; `zero`: a
@@ -282,19 +374,30 @@ class Bucket:
         if n.shape[0] != B:
             raise ValueError("bucket of %d molecules got a batch of %d" % (B, n.shape[0]))
         N, P, S, W = counts if counts is not None else batch_counts(n, self.option)
-        if not self.fits((N, P, S, W)) or P < 1:
+        rei, E = None, 0
+        if self.kind == "painn":
+            rei = batch.radius_edge_index
+            if (rei is None or not rei.is_cuda or rei.dtype != torch.long or rei.dim() != 2 or rei.size(0) != 2
+                    or rei.stride(1) != 1):
+                raise ValueError("PaiNN bucket fill expects a collated int64 radius_edge_index [2, E] on the device")
+            E = int(rei.size(1))
+        if not self.fits((N, P, S, W), int(n.max()), E) or P < 1:
             raise ValueError("batch exceeds the bucket's capacity")
+        sei = batch.super_edge_index
+        if not tensors_ok(batch) or batch.x.size(1) != self.x.size(1):
+            raise ValueError("bucket fill expects contiguous collated int64 / float32 tensors of the sizes' shapes")
         slot = self._host[self._slot]
         self._slot = (self._slot + 1) % len(self._host)
         if slot[1] is not None:
             slot[1].synchronize()   # the upload that last read this staging buffer (three steps ago)
         h = slot[0].numpy()
         hp = host_plan(n, self.option)
-        h[0:8] = (N, 2 * N, 2 * P, S, W, B, 0, 0)
+        h[0:8] = (N, 2 * N, 2 * P, S, W, B, 6 * N, 2 * E)
         h[o["mol_ptr"]:o["mol_ptr"] + 2 * B + 1] = hp["mol_ptr2"]
         h[o["pair_ptr"]:o["pair_ptr"] + 2 * B + 1] = hp["pair_ptr2"]
         h[o["se_ptr"]:o["se_ptr"] + B + 1] = hp["se_ptr"]
-        h[o["work"]:o["work"] + W] = hp["work"]
+        if self.kind == "schnet":
+            h[o["work"]:o["work"] + W] = hp["work"]
         st = h[o["stats"]:o["stats"] + 4].view(np.int64)
         st[0], st[1] = hp["divisor"], 0
         h[o["inc_ptr"]:o["inc_ptr"] + 2 * (N + 1)].view(np.int64)[:] = hp["inc_ptr"]
@@ -302,10 +405,6 @@ class Bucket:
         slot[1] = torch.cuda.Event()
         slot[1].record()
         # ---- device side: the five input tensors in one launch, then the per-slot index arrays
-        sei = batch.super_edge_index
-        if sei.stride(1) != 1 or not batch.positions.is_contiguous() or not batch.x.is_contiguous() \
-                or not batch.batch.is_contiguous() or batch.x.size(1) != self.x.size(1):
-            raise ValueError("bucket fill expects contiguous collated tensors")
         cb = _lib.CopyBatch()
         jobs = [(self.x, batch.x, N * self.x.size(1) * 8), (self.positions, batch.positions, N * 12),
                 (self.batch_vec, batch.batch, N * 8), (self.sei[0], sei[0], S * 8), (self.sei[1], sei[1], S * 8)]
@@ -316,9 +415,17 @@ class Bucket:
         st_ = stream()
         call("geossl_copy_n", C.byref(cb), len(jobs), st_)
         lay = self.lay2
-        call("geossl_pair_index_fill", ptr(lay.mol_ptr), ptr(lay.pair_ptr), 2 * B, ptr(lay.pair_i), ptr(lay.pair_j), st_)
+        if self.kind == "schnet":
+            call("geossl_pair_index_fill", ptr(lay.mol_ptr), ptr(lay.pair_ptr), 2 * B, ptr(lay.pair_i), ptr(lay.pair_j), st_)
+        else:
+            el = self.el
+            call("geossl_painn_edge_layout", ptr(rei[0]), ptr(rei[1]), E, ptr(lay.mol_ptr), N, B, 2 * self.N_cap,
+                 ptr(el.idx_i), ptr(el.idx_j), ptr(el.inc["i"][0]), ptr(el.inc["i"][1]), ptr(el.inc["j"][0]),
+                 ptr(el.inc["j"][1]), ptr(el.row_edge), ptr(el.grp_atom), ptr(el.mol_grp), ptr(el.mol_grp_end),
+                 ptr(el.status), st_)
         sel = self.sel
         call("geossl_incidence_fill", ptr(sel.batch), ptr(sel.sei0), ptr(sel.sei1), ptr(sel.se_ptr), N, 3,
              ptr(sel.inc_ptr), ptr(sel.inc_idx), st_)
         self.real = (N, P, S, W)
+        self.real_E = E
         return self.real

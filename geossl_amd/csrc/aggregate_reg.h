@@ -221,6 +221,61 @@ __device__ __forceinline__ void aggregate_block_body(const float* __restrict__ x
   }
 }
 
+// ---------------------------------------------------------------------------------------- K4, target list form
+// Molecules ABOVE the largest size class (34 .. 255 atoms: Molecule3D with hydrogens, where the 32-neighbour cap of
+// radius_graph makes the edge flags asymmetric): the sums of the target atoms [t0, t1) of one molecule by ONE wave, no
+// size classes, no LDS.  Per target the partners b != a in ascending order, 32 at a time: lane u of a chunk describes
+// partner u (its pair slot and whether b sends to a: bit 0 of slot (i < j) = edge j -> i, bit 1 = i -> j), the 32 filter
+// rows and the 32 rows of x are requested together (x through L2: a molecule's rows are re-read by its other targets),
+// then added with separate multiply and add in ascending source order - the rounding sequence of the walks above and of
+// a sequential index_add over the canonical edge list: bit-identical.  A filter row is read by both of its atoms'
+// targets (twice per launch instead of once: the price of having no per-class walk).
+__device__ __forceinline__ void aggregate_targets(const float* __restrict__ x, const float* __restrict__ Wf,
+                                                  const uint8_t* __restrict__ pair_flag, int a0, int n, int base,
+                                                  int lane, int f, int F, int swap, float* __restrict__ out, int t0,
+                                                  int t1) {
+#pragma clang fp contract(off)
+  typedef f32x2 V;
+  constexpr int NP = 32;
+  const bool has_cols = f >= 0;
+  f = has_cols ? f : 0;
+  const int nu = __builtin_amdgcn_readfirstlane(n);
+  if (nu < 2) {
+    if (nu == 1 && t0 == 0 && t1 > 0 && has_cols) *reinterpret_cast<V*>(out + (size_t)a0 * F + f) = V(0.0f);
+    return;
+  }
+  const float* __restrict__ wcol = Wf + (size_t)base * F + f;
+  const float* __restrict__ xcol = x + (size_t)a0 * F + f;
+  const uint8_t* __restrict__ flg = pair_flag + base;
+  for (int a = t0; a < t1; ++a) {
+    V acc = V(0.0f);
+    for (int c0 = 0; c0 < nu - 1; c0 += NP) {
+      const int u = min(c0 + (lane & (NP - 1)), nu - 2);     // partner index (clamped: dropped by the mask)
+      const int b = u + (u >= a ? 1 : 0);
+      const int i = min(a, b), j = max(a, b);
+      const int slot = i * nu - i * (i + 1) / 2 + (j - i - 1);
+      unsigned fl = flg[slot];
+      if (swap) fl = ((fl & 1u) << 1) | ((fl >> 1) & 1u);
+      const bool sends = lane < NP && c0 + lane < nu - 1 && ((a < b ? (fl & 1u) : (fl & 2u)) != 0u);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(sends);
+      V w[NP], xb[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const int sk = __builtin_amdgcn_readlane(slot, k), bk = __builtin_amdgcn_readlane(b, k);
+        w[k] = *reinterpret_cast<const V*>(wcol + (size_t)sk * F);
+        xb[k] = *reinterpret_cast<const V*>(xcol + (size_t)bk * F);
+      }
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const V t = xb[k] * w[k];
+        const V s2 = acc + t;
+        acc = ((m >> k) & 1ull) ? s2 : acc;
+      }
+    }
+    if (has_cols) *reinterpret_cast<V*>(out + (size_t)(a0 + a) * F + f) = acc;
+  }
+}
+
 // One TARGET GROUP of a large molecule: the walk of aggregate_reg_body restricted to the positions that touch a target
 // atom in [G0, G1) = part P of K equal parts of the size class - rows a < G0 only at their partners b in the group
 // (edge a -> b), rows a in the group at all their partners.  Every sum of a target is still formed by one wave in

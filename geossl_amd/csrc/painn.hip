@@ -28,7 +28,9 @@ inline int grid1d(int64_t n, int block, int cap = 4096) {
 __global__ void k_painn_edge_geom(const float* __restrict__ pos, const int64_t* __restrict__ idx_i,
                                   const int64_t* __restrict__ idx_j, int64_t E, float cutoff,
                                   const float* __restrict__ offsets, const float* __restrict__ widths, int R,
-                                  float* __restrict__ dir, float* __restrict__ fcut, float* __restrict__ phi) {
+                                  float* __restrict__ dir, float* __restrict__ fcut, float* __restrict__ phi,
+                                  const int32_t* __restrict__ dyn_E) {
+  E = dyn_count((int)E, dyn_E);
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = idx_i[e], j = idx_j[e];
     const float rx = pos[3 * i] - pos[3 * j], ry = pos[3 * i + 1] - pos[3 * j + 1], rz = pos[3 * i + 2] - pos[3 * j + 2];
@@ -442,7 +444,8 @@ __global__ __launch_bounds__(512) void k_painn_interaction_bwd_mol(
 // ------------------------------------------------------------------------------------------------ mixing
 // mm = mu_channel_mix(mu) [N][3][2F] -> ctx = [q, |mu_V|] [N][2F], dot = sum_xyz mu_V*mu_W  (painn.py:100-104,110)
 __global__ void k_painn_mix_pre_fwd(const float* __restrict__ q, const float* __restrict__ mm, int64_t N, int F,
-                                    float eps, float* __restrict__ ctx, float* __restrict__ dot) {
+                                    float eps, float* __restrict__ ctx, float* __restrict__ dot, const int32_t* __restrict__ dyn_N) {
+  N = dyn_count((int)N, dyn_N);
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * F; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t a = t / F;
     const int f = (int)(t - a * F);
@@ -458,7 +461,8 @@ __global__ void k_painn_mix_pre_fwd(const float* __restrict__ q, const float* __
 __global__ void k_painn_mix_post_fwd(const float* __restrict__ q, const float* __restrict__ mu,
                                      const float* __restrict__ mm, const float* __restrict__ xx,
                                      const float* __restrict__ dot, int64_t N, int F, float* __restrict__ q_out,
-                                     float* __restrict__ mu_out) {
+                                     float* __restrict__ mu_out, const int32_t* __restrict__ dyn_N) {
+  N = dyn_count((int)N, dyn_N);
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * F; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t a = t / F;
     const int f = (int)(t - a * F);
@@ -474,7 +478,8 @@ __global__ void k_painn_mix_post_fwd(const float* __restrict__ q, const float* _
 __global__ void k_painn_mix_post_bwd(const float* __restrict__ dq_new, const float* __restrict__ dmu_new,
                                      const float* __restrict__ mm, const float* __restrict__ xx,
                                      const float* __restrict__ dot, int64_t N, int F, float* __restrict__ dxx,
-                                     float* __restrict__ dmm) {
+                                     float* __restrict__ dmm, const int32_t* __restrict__ dyn_N) {
+  N = dyn_count((int)N, dyn_N);
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * F; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t a = t / F;
     const int f = (int)(t - a * F);
@@ -499,7 +504,8 @@ __global__ void k_painn_mix_post_bwd(const float* __restrict__ dq_new, const flo
 // backward of mix_pre: dq_in = dq_new + dctx[:, :F]; dmm_V += dctx[:, F:] * mu_V / |mu_V|
 __global__ void k_painn_mix_pre_bwd(const float* __restrict__ dq_new, const float* __restrict__ dctx,
                                     const float* __restrict__ ctx, const float* __restrict__ mm, int64_t N, int F,
-                                    float* __restrict__ dq_in, float* __restrict__ dmm) {
+                                    float* __restrict__ dq_in, float* __restrict__ dmm, const int32_t* __restrict__ dyn_N) {
+  N = dyn_count((int)N, dyn_N);
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * F; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t a = t / F;
     const int f = (int)(t - a * F);
@@ -517,15 +523,20 @@ __global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, 
 
 }  // namespace
 
+extern "C" int geossl_painn_edge_geom_dyn(const float* pos, const int64_t* idx_i, const int64_t* idx_j, int64_t E,
+                                          float cutoff, const float* offsets, const float* widths, int R, float* dir,
+                                          float* fcut, float* phi, const int32_t* dyn_E, hipStream_t stream) {
+  if (E <= 0) return 0;
+  if (R > RMAX || (dyn_E != nullptr && E >= ((int64_t)1 << 31))) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_painn_edge_geom, dim3(grid1d(E, 256)), dim3(256), 0, stream, pos, idx_i, idx_j, E, cutoff, offsets,
+                     widths, R, dir, fcut, phi, dyn_E);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int geossl_painn_edge_geom(const float* pos, const int64_t* idx_i, const int64_t* idx_j, int64_t E,
                                       float cutoff, const float* offsets, const float* widths, int R, float* dir,
                                       float* fcut, float* phi, hipStream_t stream) {
-  if (E <= 0) return 0;
-  if (R > RMAX) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_painn_edge_geom, dim3(grid1d(E, 256)), dim3(256), 0, stream, pos, idx_i, idx_j, E, cutoff, offsets,
-                     widths, R, dir, fcut, phi);
-  GEOSSL_CHECK_LAUNCH();
-  return 0;
+  return geossl_painn_edge_geom_dyn(pos, idx_i, idx_j, E, cutoff, offsets, widths, R, dir, fcut, phi, nullptr, stream);
 }
 
 extern "C" int geossl_silu_fwd(const float* u, int64_t n, float* y, hipStream_t stream) {
@@ -671,38 +682,58 @@ extern "C" int geossl_painn_interaction_bwd_mol(const float* dq_out, const float
   return 0;
 }
 
+extern "C" int geossl_painn_mix_pre_fwd_dyn(const float* q, const float* mm, int64_t N, int F, float eps, float* ctx,
+                                            float* dot, const int32_t* dyn_N, hipStream_t stream) {
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(k_painn_mix_pre_fwd, dim3(grid1d(N * F, 256)), dim3(256), 0, stream, q, mm, N, F, eps, ctx, dot,
+                     dyn_N);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int geossl_painn_mix_pre_fwd(const float* q, const float* mm, int64_t N, int F, float eps, float* ctx,
                                         float* dot, hipStream_t stream) {
+  return geossl_painn_mix_pre_fwd_dyn(q, mm, N, F, eps, ctx, dot, nullptr, stream);
+}
+extern "C" int geossl_painn_mix_post_fwd_dyn(const float* q, const float* mu, const float* mm, const float* xx,
+                                             const float* dot, int64_t N, int F, float* q_out, float* mu_out,
+                                             const int32_t* dyn_N, hipStream_t stream) {
   if (N <= 0) return 0;
-  hipLaunchKernelGGL(k_painn_mix_pre_fwd, dim3(grid1d(N * F, 256)), dim3(256), 0, stream, q, mm, N, F, eps, ctx, dot);
+  hipLaunchKernelGGL(k_painn_mix_post_fwd, dim3(grid1d(N * F, 256)), dim3(256), 0, stream, q, mu, mm, xx, dot, N, F, q_out,
+                     mu_out, dyn_N);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int geossl_painn_mix_post_fwd(const float* q, const float* mu, const float* mm, const float* xx,
                                          const float* dot, int64_t N, int F, float* q_out, float* mu_out,
                                          hipStream_t stream) {
+  return geossl_painn_mix_post_fwd_dyn(q, mu, mm, xx, dot, N, F, q_out, mu_out, nullptr, stream);
+}
+extern "C" int geossl_painn_mix_post_bwd_dyn(const float* dq_new, const float* dmu_new, const float* mm, const float* xx,
+                                             const float* dot, int64_t N, int F, float* dxx, float* dmm,
+                                             const int32_t* dyn_N, hipStream_t stream) {
   if (N <= 0) return 0;
-  hipLaunchKernelGGL(k_painn_mix_post_fwd, dim3(grid1d(N * F, 256)), dim3(256), 0, stream, q, mu, mm, xx, dot, N, F, q_out,
-                     mu_out);
+  hipLaunchKernelGGL(k_painn_mix_post_bwd, dim3(grid1d(N * F, 256)), dim3(256), 0, stream, dq_new, dmu_new, mm, xx, dot, N,
+                     F, dxx, dmm, dyn_N);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int geossl_painn_mix_post_bwd(const float* dq_new, const float* dmu_new, const float* mm, const float* xx,
                                          const float* dot, int64_t N, int F, float* dxx, float* dmm,
                                          hipStream_t stream) {
+  return geossl_painn_mix_post_bwd_dyn(dq_new, dmu_new, mm, xx, dot, N, F, dxx, dmm, nullptr, stream);
+}
+extern "C" int geossl_painn_mix_pre_bwd_dyn(const float* dq_new, const float* dctx, const float* ctx, const float* mm,
+                                            int64_t N, int F, float* dq_in, float* dmm, const int32_t* dyn_N,
+                                            hipStream_t stream) {
   if (N <= 0) return 0;
-  hipLaunchKernelGGL(k_painn_mix_post_bwd, dim3(grid1d(N * F, 256)), dim3(256), 0, stream, dq_new, dmu_new, mm, xx, dot, N,
-                     F, dxx, dmm);
+  hipLaunchKernelGGL(k_painn_mix_pre_bwd, dim3(grid1d(N * F, 256)), dim3(256), 0, stream, dq_new, dctx, ctx, mm, N, F,
+                     dq_in, dmm, dyn_N);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int geossl_painn_mix_pre_bwd(const float* dq_new, const float* dctx, const float* ctx, const float* mm,
                                         int64_t N, int F, float* dq_in, float* dmm, hipStream_t stream) {
-  if (N <= 0) return 0;
-  hipLaunchKernelGGL(k_painn_mix_pre_bwd, dim3(grid1d(N * F, 256)), dim3(256), 0, stream, dq_new, dctx, ctx, mm, N, F,
-                     dq_in, dmm);
-  GEOSSL_CHECK_LAUNCH();
-  return 0;
+  return geossl_painn_mix_pre_bwd_dyn(dq_new, dctx, ctx, mm, N, F, dq_in, dmm, nullptr, stream);
 }
 extern "C" int geossl_add(const float* a, const float* b, int64_t n, float* out, hipStream_t stream) {
   if (n <= 0) return 0;

@@ -39,6 +39,7 @@ struct PainnMmaArgs {
   const int32_t* row_edge;   // [4 * groups] edge of a row, -1 = padding
   const int32_t* grp_atom;   // [groups] atom the rows of a group belong to
   const int32_t* mol_grp;    // [B + 1] first group of a molecule
+  const int32_t* mol_grp_end;  // [B] end of a molecule's groups, or NULL: mol_grp[m + 1] (the lists lie back to back)
   const float* phi;
   const float* fcut;
   const float* dir;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void k_painn_fwd_mma(PainnMmaArgs A) {
         return;
       }
       const int a0 = A.mol_ptr[t.mol], n = A.mol_ptr[t.mol + 1] - a0;
-      const int g0 = A.mol_grp[t.mol], g1 = A.mol_grp[t.mol + 1];
+      const int g0 = A.mol_grp[t.mol], g1 = A.mol_grp_end != nullptr ? A.mol_grp_end[t.mol] : A.mol_grp[t.mol + 1];
       if (g1 > g0) {
         t = TilePos{t.mol, a0, n, g1, g0, 1};
         return;
@@ -425,12 +426,13 @@ extern "C" int geossl_painn_mma_debug_read(long long* host) {
 }
 #endif
 
-extern "C" int geossl_painn_interaction_fwd_mma(const float* q, const float* mu, const float* xc, const int64_t* idx_j,
-                                                const int32_t* row_edge, const int32_t* grp_atom,
-                                                const int32_t* mol_grp, const float* phi, const float* fcut,
-                                                const float* dir, const float* Wf, const float* bf,
-                                                const int32_t* mol_ptr, int64_t B, int max_n, int64_t N, int F, int R,
-                                                float* q_out, float* mu_out, hipStream_t stream) {
+extern "C" int geossl_painn_interaction_fwd_mma_dyn(const float* q, const float* mu, const float* xc, const int64_t* idx_j,
+                                                    const int32_t* row_edge, const int32_t* grp_atom,
+                                                    const int32_t* mol_grp, const float* phi, const float* fcut,
+                                                    const float* dir, const float* Wf, const float* bf,
+                                                    const int32_t* mol_ptr, int64_t B, int max_n, int64_t N, int F, int R,
+                                                    float* q_out, float* mu_out, const int32_t* mol_grp_end,
+                                                    hipStream_t stream) {
   if (N <= 0 || B <= 0) return 0;
   const size_t lds = painn_mma_lds(max_n);
   if (F != PM_F || lds > 160 * 1024 || (R != 8 && R != 16 && R != 20) || N * 3 * PM_F * 4 >= ((int64_t)1 << 32))
@@ -438,7 +440,7 @@ extern "C" int geossl_painn_interaction_fwd_mma(const float* q, const float* mu,
   PainnMmaArgs a{};
   a.q = q; a.mu = mu; a.xc = xc; a.idx_other = idx_j; a.row_edge = row_edge; a.grp_atom = grp_atom; a.mol_grp = mol_grp;
   a.phi = phi; a.fcut = fcut; a.dir = dir; a.Wf = Wf; a.bf = bf; a.mol_ptr = mol_ptr; a.B = (int)B; a.max_n = max_n; a.N = (int)N;
-  a.out0 = q_out; a.out1 = mu_out;
+  a.out0 = q_out; a.out1 = mu_out; a.mol_grp_end = mol_grp_end;
   const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
   const int nb = (int)(B < 256 * per_cu ? B : 256 * per_cu);
 #define LAUNCH_FWD_MMA(RV)                                                                              \
@@ -450,4 +452,14 @@ extern "C" int geossl_painn_interaction_fwd_mma(const float* q, const float* mu,
 #undef LAUNCH_FWD_MMA
   GEOSSL_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int geossl_painn_interaction_fwd_mma(const float* q, const float* mu, const float* xc, const int64_t* idx_j,
+                                                const int32_t* row_edge, const int32_t* grp_atom,
+                                                const int32_t* mol_grp, const float* phi, const float* fcut,
+                                                const float* dir, const float* Wf, const float* bf,
+                                                const int32_t* mol_ptr, int64_t B, int max_n, int64_t N, int F, int R,
+                                                float* q_out, float* mu_out, hipStream_t stream) {
+  return geossl_painn_interaction_fwd_mma_dyn(q, mu, xc, idx_j, row_edge, grp_atom, mol_grp, phi, fcut, dir, Wf, bf, mol_ptr,
+                                              B, max_n, N, F, R, q_out, mu_out, nullptr, stream);
 }

@@ -243,6 +243,7 @@ __global__ __launch_bounds__(64, 2) void k_aggregate_reg_ragged(
 #ifndef AGG_RING_BIG
 #define AGG_RING_BIG 40
 #endif
+#define AGG_KBIG 16   // work items of a molecule above 33 atoms (the part field of a work word has four bits)
 // a size class above 20 atoms (molecules of LO .. NM atoms): whole, two or four target groups, by the molecule's size;
 // only the forms a class can meet are instantiated
 template <int NM>
@@ -273,10 +274,15 @@ __global__ __launch_bounds__(64, 2) void k_aggregate_reg_work(
     int nwork, int F, int swap, float* __restrict__ out, const int32_t* __restrict__ dyn_nwork) {
   if ((int)blockIdx.x >= dyn_count(nwork, dyn_nwork)) return;
   const int wk = work[blockIdx.x];
-  const int m = wk & 0x0FFFFFFF, part = __builtin_amdgcn_readfirstlane((wk >> 28) & 7);
+  const int m = wk & 0x0FFFFFFF, part = __builtin_amdgcn_readfirstlane((wk >> 28) & 15);
   const int lane = threadIdx.x, f = 2 * lane < F ? 2 * lane : -2;  // -2: no channels (see k_aggregate_reg)
   const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m];
   const int nu = __builtin_amdgcn_readfirstlane(n);
+  if (nu > 33) {  // above the size classes: AGG_KBIG target groups, each a list of targets (aggregate_targets)
+    aggregate_targets(x, Wf, pair_flag, a0, n, base, lane, f, F, swap, out, (part * nu) / AGG_KBIG,
+                      ((part + 1) * nu) / AGG_KBIG);
+    return;
+  }
   const int kparts = nu < AGG_K2_MIN ? 1 : (nu < AGG_K4_MIN ? 2 : 4);
 #define AGG_CLASS(NM) if (nu <= NM) { aggregate_reg_body<NM>(x, Wf, pair_flag, a0, n, base, lane, f, F, swap, out); return; }
 #define AGG_CLASS_BIG(NM) if (nu <= NM) { aggregate_big<NM>(x, Wf, pair_flag, a0, n, base, lane, f, F, swap, out, kparts, part); return; }
@@ -533,7 +539,8 @@ extern "C" int geossl_pair_product(const float* a, const float* b, const int32_t
 }
 
 extern "C" int geossl_aggregate_parts(int n) {  // work items of an n-atom molecule in geossl_cfconv_aggregate_work
-  if (n < AGG_K2_MIN || n > 33) return 1;
+  if (n > 33) return AGG_KBIG;
+  if (n < AGG_K2_MIN) return 1;
   return n < AGG_K4_MIN ? 2 : 4;
 }
 
@@ -542,7 +549,7 @@ extern "C" int geossl_cfconv_aggregate_work_dyn(const float* x, const float* Wf,
                                                 int64_t nwork, int max_n, int F, int swap, float* out,
                                                 const int32_t* dyn_nwork, hipStream_t stream) {
   if (nwork <= 0) return 0;
-  if (max_n > 33 || F > 128 || F <= 32) return (int)hipErrorInvalidValue;
+  if (max_n > 255 || F > 128 || F <= 32) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(k_aggregate_reg_work, dim3((unsigned)nwork), dim3(64), 0, stream, x, Wf, pair_flag, mol_ptr,
                      pair_ptr, work, (int)nwork, F, swap, out, dyn_nwork);
   GEOSSL_CHECK_LAUNCH();

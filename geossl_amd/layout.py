@@ -69,16 +69,10 @@ class MolLayout:
             self.order = torch.argsort(nat, descending=True, stable=True).to(torch.int32)
         # ragged batches built from host sizes: the work list of the aggregation (geossl_cfconv_aggregate_work), molecules
         # by descending size, the 21..33-atom ones as 2 or 4 work items (one group of target atoms each)
+        # (molecules above 33 atoms - Molecule3D with hydrogens - as 16 items each: lists of target atoms, no size class)
         self.agg_work = None
-        if sizes is not None and 20 < self.max_n <= 33 and not os.environ.get("GEOSSL_AGG_NO_SPLIT"):
-            n_host = np.asarray(sizes, dtype=np.int64)
-            idx = np.argsort(-n_host, kind="stable")
-            lib = _lib.load()
-            table = np.array([lib.geossl_aggregate_parts(k) for k in range(34)], dtype=np.int64)
-            parts = table[n_host][idx]
-            mol = np.repeat(idx, parts)
-            part = np.concatenate([np.arange(k) for k in parts]) if len(parts) else np.zeros(0, np.int64)
-            self.agg_work = torch.from_numpy((mol | (part << 28)).astype(np.int32)).to(dev)
+        if sizes is not None and 20 < self.max_n <= 255 and B < (1 << 28) and not os.environ.get("GEOSSL_AGG_NO_SPLIT"):
+            self.agg_work = torch.from_numpy(aggregate_work_list(np.asarray(sizes, dtype=np.int64))).to(dev)
         self.device = dev
         self._batch_version = batch._version
         self._sizes_host = sizes
@@ -109,6 +103,29 @@ class MolLayout:
             t_ = torch.from_numpy(np.ascontiguousarray(plan)).to(self.device)
             self._loop_plan = (t_, len(plan))
         return self._loop_plan
+
+
+_PARTS = None
+
+
+def parts_table():
+    """geossl_aggregate_parts(n) for n = 0 .. 255 (work items of an n-atom molecule in geossl_cfconv_aggregate_work)."""
+    global _PARTS
+    if _PARTS is None:
+        lib = _lib.load()
+        _PARTS = np.array([lib.geossl_aggregate_parts(k) for k in range(256)], dtype=np.int64)
+    return _PARTS
+
+
+def aggregate_work_list(n):
+    """Work list of geossl_cfconv_aggregate_work for molecules of `n` atoms (int64 array): molecules by descending size
+    (stable), each as geossl_aggregate_parts(size) items molecule | part << 28, as int32 words."""
+    idx = np.argsort(-n, kind="stable")
+    parts = parts_table()[n][idx]
+    mol = np.repeat(idx, parts)
+    ends = np.cumsum(parts)
+    part = np.arange(int(ends[-1]) if len(ends) else 0, dtype=np.int64) - np.repeat(ends - parts, parts)
+    return (mol | (part << 28)).astype(np.uint32).view(np.int32)
 
 
 def loop_block_plan(sizes, max_rows=96, max_mols=None, slots=512):

@@ -295,6 +295,13 @@ def _adam_pre_hook(optimizer, args, kwargs):
 
 
 def _adam_post_hook(optimizer, args, kwargs):
+    # the step's backward has run by now: autograd's thread switch goes back to the caller's setting (pretrain_GeoSSL)
+    try:
+        from .pretrain_GeoSSL import _MT_PENDING, _restore_backward_threads
+        if _MT_PENDING:
+            _restore_backward_threads()
+    except Exception:
+        pass
     plan = optimizer.__dict__.get("_geossl_plan")
     if plan and plan.stash is not None:
         for p, g in zip(plan.home.params, plan.stash):

@@ -165,14 +165,18 @@ def _do_ddm_eager(args, batch, model, mu, sigma, heads, noise, fuse_views, devic
     if bucket is not None:
         # the static batch of a capacity bucket (geossl_amd/bucket.py): tensors have the bucket's capacity, the real counts
         # are device data (bucket.dyn); the fused batch is [view 0 | view 1 | unused] and goes to the heads whole
-        if args.model_3d != "schnet" or not fuse_views or getattr(args, "normalize", False):
-            raise _lib.GeosslHipError("capacity buckets serve the fused SchNet step")
+        if args.model_3d != bucket.kind or not fuse_views or getattr(args, "normalize", False):
+            raise _lib.GeosslHipError("capacity buckets serve the fused step of the backbone they were made for")
         pos_noise = noise.get("pos_noise")
         if pos_noise is None:
             pos_noise = torch.empty_like(positions).normal_(mu, sigma)
         pos2, distance_01, distance_02, x2 = ops.ddm_views(positions, pos_noise, super_edge_index[0], super_edge_index[1],
                                                            z=x_01, dyn=bucket.dyn)
-        _, h = model(x2, pos2, bucket.b2, return_latent=True, layout=bucket.lay2, latent_only=True)
+        if bucket.kind == "schnet":
+            _, h = model(x2, pos2, bucket.b2, return_latent=True, layout=bucket.lay2, latent_only=True)
+        else:
+            _, h = model(x2, pos2, bucket.e2, bucket.b2, return_latent=True, latent_only=True, layout=bucket.lay2,
+                         edge_layout=bucket.el)
         from .NCSN import ddm_heads_loss
         return ddm_heads_loss(n1, n2, batch, h, distance_02, None, distance_01,
                               noise_level_1=noise.get("noise_level_1"), distance_noise_1=noise.get("dist_noise_1"),
@@ -404,7 +408,8 @@ class StepGraphs:
         """("bucket", molecules, option) when the batch goes through a capacity bucket, else None."""
         from . import bucket as bk
         if (self.mode != "auto" or not self.bucket_ok or os.environ.get("GEOSSL_NO_BUCKETS")
-                or not bk.eligible(batch, self.model_3d, self.normalize) or bk.is_uniform(batch)
+                or not bk.eligible(batch, self.model_3d, self.normalize)
+                or (self.model_3d != "painn" and bk.is_uniform(batch))   # (PaiNN: the edge list differs batch by batch anyway)
                 or self.modules is None or not self._modules_ok()):
             return None
         return ("bucket", len(batch._sizes), batch._canonical)
@@ -413,7 +418,7 @@ class StepGraphs:
         """bucket.modules_ok of this engine's modules, remembered per state of the switches it reads (the modules of a
         StepGraphs are fixed: a replaced parameter rebuilds the engine, _AutogradStep.unchanged / DDMTrainer)."""
         from . import bucket as bk
-        env = tuple(os.environ.get(k) for k in bk.MODULE_SWITCHES)
+        env = tuple(os.environ.get(k) for k in bk.MODULE_SWITCHES + bk.PAINN_SWITCHES)
         if self._mod_ok is None or self._mod_ok[0] != env:
             self._mod_ok = (env, bk.modules_ok(*self.modules))
         return self._mod_ok[1]
@@ -427,7 +432,7 @@ class StepGraphs:
             if g is None:
                 return None
             counts = bk.batch_counts(bk.sizes_array(batch), batch._canonical)
-            if not g["bucket"].fits(counts):
+            if not g["bucket"].fits(counts, bk.size_range(batch)[1], self._edges(batch)):
                 return None
             g["counts"] = counts
             self.graphs.move_to_end(key)
@@ -437,6 +442,10 @@ class StepGraphs:
         if g is not None:
             self.graphs.move_to_end(fp)
         return g
+
+    def _edges(self, batch):
+        """Edges of the batch's radius_edge_index (PaiNN; a tensor shape: no read-back), else None."""
+        return int(batch.radius_edge_index.size(1)) if self.model_3d == "painn" else None
 
     def capture_now(self, batch):
         """Should a batch without a graph be captured at this sighting?  Buckets and equal-sized molecules: yes (their
@@ -495,12 +504,19 @@ class StepGraphs:
         from . import bucket as bk
         old = self.graphs.pop(key, None)
         counts = bk.batch_counts(bk.sizes_array(batch), batch._canonical)
-        caps = bk.capacities(*counts, B=len(batch._sizes), prev=None if old is None else old["bucket"].caps())
+        caps = bk.capacities(*counts, B=len(batch._sizes), prev=None if old is None else old["bucket"].caps(),
+                             sizes=bk.sizes_array(batch))
+        max_n = bk.max_n_class(bk.size_range(batch)[1], None if old is None else old["bucket"].max_n, self.model_3d)
+        E_cap = 0
+        if self.model_3d == "painn":
+            E_cap = bk.edge_capacity(self._edges(batch), len(batch._sizes), None if old is None else old["bucket"].E_cap,
+                                     sizes=bk.sizes_array(batch))
         del old  # (its graph and static buffers go before the larger ones are made)
         self._evict()
         dev = batch.positions.device
         try:
-            bkt = bk.Bucket(dev, len(batch._sizes), caps, batch._canonical, x_cols=batch.x.size(1))
+            bkt = bk.Bucket(dev, len(batch._sizes), caps, batch._canonical, x_cols=batch.x.size(1), max_n=max_n,
+                            kind=self.model_3d, E_cap=E_cap)
             bkt.fill(batch, counts)
         except (ValueError, RuntimeError) as e:
             warnings.warn("capacity bucket not usable for this batch (%s); per-structure graphs from now on" % e)
@@ -746,7 +762,6 @@ class _ReplayedLoss(torch.autograd.Function):
     def backward(ctx, gout):
         eng, ticket = ctx.engine, ctx.ticket
         src = eng.collect(ticket)
-        _restore_backward_threads(ticket)  # (takes effect from the caller's next backward on)
         pre = ticket.pop("views", None)
         if pre is not None:
             # the step's own output buffer and its per-parameter views were made in do_DDM, while the host was going to
@@ -966,24 +981,34 @@ class _AutogradStep:
         return _ReplayedLoss.apply(loss, self, self._ticket, *self.params)
 
 
+_MT_PENDING = []   # tickets of this process whose autograd thread switch is still to be put back
+
+
 def _single_thread_backward(ticket):
     """The loss of a replayed step has ONE node behind it (_ReplayedLoss) and its 59 AccumulateGrads; autograd would hand
     them to its per-device worker thread and wake the caller when it is done - a hand-over that costs 0.13 ms per
     backward() (measured, tools/ref_loop_profile.py), a fifth of a whole step at the reference's batch size.  With
     multithreading off the calling thread runs the backward itself.  The switch is autograd's own, thread-local
     (torch.autograd.set_multithreading_enabled); it is turned off when do_DDM hands out the loss and put back to what the
-    caller had when that loss's backward has run (or the loss is dropped): other autograd work of the caller - graphs
-    that span several devices - sees its own setting.  GEOSSL_KEEP_AUTOGRAD_THREADS leaves the switch alone."""
+    caller had at the optimizer step that follows (a global optimizer post-step hook, optim.py) or, without one, at the
+    next do_DDM - it cannot be put back from inside the backward: the engine restores the thread state it saw at
+    backward()'s entry when the pass ends.  Other autograd work of the caller after the step - graphs that span several
+    devices - sees its own setting.  GEOSSL_KEEP_AUTOGRAD_THREADS leaves the switch alone."""
     if os.environ.get("GEOSSL_KEEP_AUTOGRAD_THREADS"):
         return
     if torch.autograd.is_multithreading_enabled():
         torch.autograd.set_multithreading_enabled(False)
         ticket["mt_restore"] = True
+        _MT_PENDING.append(ticket)
 
 
-def _restore_backward_threads(ticket):
-    if ticket.pop("mt_restore", None):
-        torch.autograd.set_multithreading_enabled(True)
+def _restore_backward_threads(ticket=None):
+    """Put autograd's multithreading switch back for `ticket` (None: for every step still pending)."""
+    todo = [ticket] if ticket is not None else list(_MT_PENDING)
+    for t in todo:
+        if t.pop("mt_restore", None):
+            torch.autograd.set_multithreading_enabled(True)
+    _MT_PENDING[:] = [p for p in _MT_PENDING if not any(p is t for t in todo)]   # (by identity: tickets hold tensors)
 
 
 def _schnet_step_params(model):

@@ -17,10 +17,16 @@ EXCL = 1.0
 
 def molecule_sizes(num_mols, mode="A", rng=None, n_fixed=18):
     """Set A: n=18 fixed.  Set B: n ~ clip(round(N(18,4)), 2, 33) (n<=33 keeps clear of the
-    32-neighbour cap of radius_graph)."""
+    32-neighbour cap of radius_graph).  Set C: n ~ clip(round(N(26,10)), 4, 72) (molecules with hydrogens)."""
     if mode == "A":
         return np.full(num_mols, n_fixed, dtype=np.int64)
     rng = np.random.default_rng(0) if rng is None else rng
+    if mode == "C":
+        # Molecule3D WITH hydrogens (datasets_Molecule3D.py:65 removeHs=False), what the reference's DDM script trains on
+        # (submit_pretrain_GeoSSL_DDM.sh:3): n ~ clip(round(N(26, 10)), 4, 72) - about a quarter of the molecules above the
+        # 33 atoms of the aggregation's size classes, about one in a hundred above 48; at the reference's 10 A radius
+        # (config.py:114) the 32-neighbour cap of radius_graph cuts the lists of the compact ones
+        return np.clip(np.rint(rng.normal(26.0, 10.0, size=num_mols)), 4, 72).astype(np.int64)
     return np.clip(np.rint(rng.normal(18.0, 4.0, size=num_mols)), 2, 33).astype(np.int64)
 
 

@@ -150,10 +150,12 @@ int geossl_pair_position_grad(const float* pos, const float* pair_d, const float
 int geossl_cfconv_aggregate(const float* x, const float* Wf, const uint8_t* pair_flag, const int32_t* mol_ptr,
                             const int32_t* pair_ptr, const int32_t* order, int64_t B, int max_n, int F, int swap,
                             float* out, hipStream_t stream);
-/* The same aggregation from a host-built work list (ragged batches): work[i] = molecule | part << 28, in launch order
- * (largest molecules first).  A molecule of n atoms has geossl_aggregate_parts(n) entries (1, 2 or 4: the 21..33-atom
- * molecules are shared by that many waves, one group of target atoms each - every sum is still formed by one wave
- * in the order of geossl_cfconv_aggregate, bit for bit).  max_n <= 33, 32 < F <= 128.                          */
+/* The same aggregation from a host-built work list (ragged batches): work[i] = molecule | part << 28 (molecule < 2^28,
+ * part 0 .. 15), in launch order (largest molecules first).  A molecule of n atoms has geossl_aggregate_parts(n) entries
+ * (1, 2 or 4 up to 33 atoms: the 27..33-atom molecules are shared by that many waves, one group of target atoms each; 16
+ * above 33 atoms - Molecule3D with hydrogens, datasets_Molecule3D.py:65 - where a wave sums a list of target atoms
+ * without a size class) - every sum is still formed by one wave in the order of geossl_cfconv_aggregate, bit for bit.
+ * max_n <= 255, 32 < F <= 128.                                                                                      */
 int geossl_aggregate_parts(int n);
 int geossl_cfconv_aggregate_work(const float* x, const float* Wf, const uint8_t* pair_flag, const int32_t* mol_ptr,
                                  const int32_t* pair_ptr, const int32_t* work, int64_t nwork, int max_n, int F,
@@ -573,6 +575,45 @@ int geossl_ddm_loss_bwd_fused2_dyn(const GeosslNcsnHeadBwd* heads, const int64_t
                                    int64_t N, int F, const int64_t* stats_divisor, const float* gout,
                                    const int64_t* inc_ptr, const int32_t* inc_idx, int accumulate, const int32_t* dyn_S,
                                    const int32_t* dyn_view, hipStream_t stream);
+
+/* ---- PaiNN on a capacity bucket (round 5): the precomputed radius_edge_index of a batch is geometry-dependent
+ * (datasets_3D_Radius.py:120), so a replayed PaiNN step reads every edge structure from static buffers that ONE launch
+ * rewrites per step.
+ * geossl_painn_edge_layout: from the collated one-view edge list (rows src_i = radius_edge_index[0], src_j = [1], E edges
+ * grouped by molecule in batch order, both ends in one molecule; dataloaders_AtomTuple.py:64-65) and the one-view
+ * molecule CSR (mol_ptr [B + 1], N atoms) to the structures of the fused (clean | perturbed) 2B-molecule batch - the
+ * perturbed view keeps the clean view's graph (pretrain_GeoSSL.py:190-191), its atoms start at N, its edges at E:
+ *   idx_i2 / idx_j2 [2E]; incidence lists by idx_i (iptr_i [N2cap + 1], ilist_i [2E]) and by idx_j, an atom's edges in
+ *   ascending edge order; atoms [2N, N2cap] get empty lists; the four-row group layout of the matrix-pipe forward
+ *   (row_edge [4 G], grp_atom [G], G = geossl_painn_group_capacity(2 E_cap, N2cap)) with the groups of molecule m in
+ *   [mol_grp[m], mol_grp_end[m]); *status is set to 1 on an edge that leaves its molecule (or a molecule above 256
+ *   atoms) - such edges are left out.  Molecules of at most 256 atoms.
+ * geossl_painn_interaction_fwd_mma_dyn: the namesake with mol_grp_end (NULL: groups lie back to back).
+ * The element-wise launches take the real row / edge count from device memory like the other `_dyn` entry points.   */
+int64_t geossl_painn_group_capacity(int64_t E2, int64_t N2);
+int geossl_painn_edge_layout(const int64_t* src_i, const int64_t* src_j, int64_t E, const int32_t* mol_ptr, int64_t N,
+                             int64_t B, int64_t N2cap, int64_t* idx_i2, int64_t* idx_j2, int64_t* iptr_i,
+                             int32_t* ilist_i, int64_t* iptr_j, int32_t* ilist_j, int32_t* row_edge, int32_t* grp_atom,
+                             int32_t* mol_grp, int32_t* mol_grp_end, int32_t* status, hipStream_t stream);
+int geossl_painn_edge_geom_dyn(const float* pos, const int64_t* idx_i, const int64_t* idx_j, int64_t E, float cutoff,
+                               const float* offsets, const float* widths, int R, float* dir, float* fcut, float* phi,
+                               const int32_t* dyn_E, hipStream_t stream);
+int geossl_painn_interaction_fwd_mma_dyn(const float* q, const float* mu, const float* xc, const int64_t* idx_j,
+                                         const int32_t* row_edge, const int32_t* grp_atom, const int32_t* mol_grp,
+                                         const float* phi, const float* fcut, const float* dir, const float* Wf,
+                                         const float* bf, const int32_t* mol_ptr, int64_t B, int max_n, int64_t N, int F,
+                                         int R, float* q_out, float* mu_out, const int32_t* mol_grp_end,
+                                         hipStream_t stream);
+int geossl_painn_mix_pre_fwd_dyn(const float* q, const float* mm, int64_t N, int F, float eps, float* ctx, float* dot,
+                                 const int32_t* dyn_N, hipStream_t stream);
+int geossl_painn_mix_post_fwd_dyn(const float* q, const float* mu, const float* mm, const float* xx, const float* dot,
+                                  int64_t N, int F, float* q_out, float* mu_out, const int32_t* dyn_N,
+                                  hipStream_t stream);
+int geossl_painn_mix_post_bwd_dyn(const float* dq_new, const float* dmu_new, const float* mm, const float* xx,
+                                  const float* dot, int64_t N, int F, float* dxx, float* dmm, const int32_t* dyn_N,
+                                  hipStream_t stream);
+int geossl_painn_mix_pre_bwd_dyn(const float* dq_new, const float* dctx, const float* ctx, const float* mm, int64_t N,
+                                 int F, float* dq_in, float* dmm, const int32_t* dyn_N, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -422,7 +422,8 @@ def test_bucket_host_plan_matches_the_collated_batch():
     from geossl_amd.synthetic import make_batch
     lib = load()
     for option in ("combination", "permutation"):
-        sizes = np.array([5, 33, 1, 18, 27, 2, 30, 1, 9, 31, 20, 1], dtype=np.int64)   # (trailing single atom: divisor B - 1)
+        # (trailing single atom: divisor B - 1; 34 / 60 atoms: above the size classes, 16 lists of targets each)
+        sizes = np.array([5, 33, 1, 18, 27, 2, 30, 1, 60, 9, 31, 34, 20, 1], dtype=np.int64)
         b = make_batch(len(sizes), seed=3, sizes=sizes, option=option)
         hp = bk.host_plan(sizes, option)
         N, P, S, W = hp["counts"]
@@ -436,7 +437,7 @@ def test_bucket_host_plan_matches_the_collated_batch():
         assert np.array_equal(np.diff(hp["se_ptr"]), np.bincount(e2g, minlength=B)) and hp["divisor"] == int(e2g.max()) + 1
         deg = np.bincount(b["super_edge_index"].reshape(-1), minlength=N)
         assert np.array_equal(np.diff(hp["inc_ptr"]), deg) and hp["inc_ptr"][0] == 0
-        mol, part = hp["work"] & 0x0FFFFFFF, (hp["work"].astype(np.int64) >> 28) & 7
+        mol, part = hp["work"] & 0x0FFFFFFF, (hp["work"].astype(np.int64) >> 28) & 15
         assert len(mol) == W
         n2 = np.concatenate([sizes, sizes])
         want = sorted((m, k) for m in range(2 * B) for k in range(lib.geossl_aggregate_parts(int(n2[m]))))
@@ -459,18 +460,33 @@ def test_bucket_capacities_and_eligibility():
     small = bk.capacities(2300, 20000, 20000, 260, B=128)
     assert small[0] >= 2300 * 1.13                                                   # 1.5 / sqrt(128) of slack
 
-    pos = types.SimpleNamespace(is_cuda=True, dtype=torch.float32)
-    x = types.SimpleNamespace(dim=lambda: 2)
+    def fake(dtype, *shape):   # what bucket.tensors_ok asks of a tensor, without a GPU
+        n = int(np.prod(shape))
+        return types.SimpleNamespace(is_cuda=True, dtype=dtype, dim=lambda: len(shape), size=lambda i: shape[i],
+                                     numel=lambda: n, is_contiguous=lambda: True, stride=lambda i: 1, _version=0)
 
-    def batch(sizes, canon="combination"):
-        return types.SimpleNamespace(_sizes=sizes, _canonical=canon, positions=pos, x=x)
+    def batch(sizes, canon="combination", x_dtype=torch.long, cut=0, rei=True):
+        n = np.asarray(sizes)
+        N, P = int(n.sum()), int((n * (n - 1) // 2).sum())
+        S = (P if canon != "permutation" else 2 * P) - cut
+        return types.SimpleNamespace(_sizes=sizes, _canonical=canon, positions=fake(torch.float32, N, 3), x=fake(x_dtype, N, 2),
+                                     batch=fake(torch.long, N), super_edge_index=fake(torch.long, 2, S),
+                                     radius_edge_index=fake(torch.long, 2, 40) if rei else None)
 
     assert bk.eligible(batch([18, 20, 2]), "schnet") and not bk.is_uniform(batch([18, 20, 2]))
     assert bk.is_uniform(batch([18] * 5))
-    assert not bk.eligible(batch([18, 34]), "schnet")                                # beyond the register aggregation's classes
+    assert bk.eligible(batch([18, 34]), "schnet") and bk.eligible(batch([18, 255]), "schnet")   # molecules with hydrogens
+    assert not bk.eligible(batch([18, 256]), "schnet")                               # beyond the work list / the heads
     assert not bk.eligible(batch([18, 20], canon=None), "schnet")                    # sampled tuples: not a function of the sizes
-    assert not bk.eligible(batch([18, 20]), "painn") and not bk.eligible(batch([18, 20]), "schnet", normalize=True)
+    assert not bk.eligible(batch([18, 20]), "schnet", normalize=True)
+    assert bk.eligible(batch([18, 20]), "painn") and not bk.eligible(batch([18, 20], rei=False), "painn")
+    assert not bk.eligible(batch([18, 20]), "dimenet")
     assert not bk.eligible(batch([1, 1, 1]), "schnet")                               # no pair at all
+    assert not bk.eligible(batch([18, 20], x_dtype=torch.int32), "schnet")           # the fill copies int64 by byte count
+    assert not bk.eligible(batch([18, 20], cut=3), "schnet")                         # super_edge_index cut after the collation
+    assert bk.max_n_class(18) == 33 and bk.max_n_class(34) == 64 and bk.max_n_class(20, prev=64) == 64
+    assert bk.max_n_class(18, model_3d="painn") == 22 and bk.max_n_class(60, model_3d="painn") == 64
+    assert bk.edge_capacity(36000, 128) >= 36000 * 1.13 and bk.edge_capacity(100, 128, prev=4096) == 4096
     # routing of StepGraphs without a GPU: auto mode buckets ragged batches only when the modules allow it
     sg = pg.StepGraphs(lambda b, n: None, "schnet", modules=None)
     assert sg.bucket_key(batch([18, 20, 2])) is None                                 # (no modules known: no bucket)
