@@ -85,8 +85,13 @@ _PARTS = None
 
 def max_n_class(hi, prev=None, model_3d="schnet"):
     """The bucket's bound on the molecule size for a batch whose largest molecule has `hi` atoms."""
-    for c in (PAINN_MAX_N_CLASSES if model_3d == "painn" else MAX_N_CLASSES):
-        if hi <= c and (prev is None or c >= prev):
+    classes, exact = (PAINN_MAX_N_CLASSES, 44) if model_3d == "painn" else (MAX_N_CLASSES, SMALL_N)
+    # above the sizes whose class selects a faster kernel form (the register aggregation / flat geometry / ragged loop of
+    # SchNet, the matrix-pipe interaction of PaiNN) the class only sizes LDS arrays: a quarter of head room there, so that
+    # the next batch's largest molecule does not cost another capture
+    want = hi if hi <= exact else int(np.ceil(1.25 * hi))
+    for c in classes:
+        if want <= c and (prev is None or c >= prev):
             return c
     return MAX_N
 
@@ -226,6 +231,8 @@ def capacities(N, P, S, W, B, prev=None, sizes=None):
     """Capacities for a batch with these counts: a slack that covers the spread of a shuffled loader's batch sums
     (`_slacks`), rounded to the kernels' tile sizes; never below a previous bucket's."""
     sn, sp = _slacks(B, sizes)
+    if prev is not None:   # a bucket that was outgrown once: the first batch underestimated the spread
+        sn, sp = 1.5 * sn, 1.5 * sp
     cap = lambda v, g, sl: _round_up(v * (1.0 + sl) + g, g)
     out = [cap(N, 32, sn), cap(P, 64, sp), cap(S, 64, sp), cap(W, 64, sp)]
     if prev is not None:
@@ -236,7 +243,7 @@ def capacities(N, P, S, W, B, prev=None, sizes=None):
 def edge_capacity(E, B, prev=None, sizes=None):
     """Capacity for the edges of a PaiNN batch (one view) with E edges, with the slack of `capacities` for pair-slot-like
     counts (the edges of a molecule lie between its atoms and its pair slots)."""
-    slack = _slacks(B, sizes)[1]
+    slack = _slacks(B, sizes)[1] * (1.5 if prev is not None else 1.0)
     cap = _round_up(E * (1.0 + slack) + 64, 64)
     return cap if prev is None else max(cap, int(prev))
 

@@ -385,8 +385,11 @@ def test_painn_degenerate_batch_vs_oracle():
 
 def test_painn_trainer_graph_replay_follows_the_edge_list():
     """A captured graph binds radius_edge_index (and its incidence lists); batches with the same molecule sizes but
-    different geometry have different edge lists.  DDMTrainer(use_graph=True) must give the eager losses on every batch
-    (it re-captures when the edge list is another tensor), not replay batch 0's edges."""
+    different geometry have different edge lists.  DDMTrainer(use_graph=True) must give the eager losses on every batch,
+    not replay batch 0's edges: per-structure graphs (graph_mode="structure") re-capture when the edge list is another
+    tensor - bit for bit the eager step; the default mode serves all of them from ONE capacity-bucket graph whose edge
+    structures are rewritten per step (round 5) - the eager step within fp32 summation order (partial sums are cut at the
+    capacity's block boundaries)."""
     from geossl_amd import pretrain_GeoSSL as pg
     from geossl_amd.synthetic import draw_noise, make_batch
     batches = [make_batch(32, seed=200 + i, mode="A") for i in range(3)]
@@ -394,16 +397,22 @@ def test_painn_trainer_graph_replay_follows_the_edge_list():
     assert len({int(bt.radius_edge_index.size(1)) for bt in bts}) > 1 or not torch.equal(bts[0].radius_edge_index,
                                                                                           bts[1].radius_edge_index)
     losses = {}
-    for use_graph in (False, True):
+    for mode in ("eager", "structure", "auto"):
         tr = pg.DDMTrainer(_painn(), product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9), lr=5e-4,
-                           model_3d="painn", use_graph=use_graph)
+                           model_3d="painn", use_graph=mode != "eager", graph_mode="auto" if mode == "eager" else mode)
         out = []
         for step in range(6):
             b, bt = batches[step % 3], bts[step % 3]
             noise = {k: t(v, DEV) for k, v in draw_noise(b, seed=300 + step).items()}
             out.append(float(tr.step(bt, noise, structure_key=("A", 32, 18))))
-        losses[use_graph] = out
-    assert losses[True] == losses[False], losses
+        losses[mode] = out
+        if mode == "structure":
+            assert tr.step_graphs.captures == 3
+        if mode == "auto":
+            assert tr.step_graphs.captures == 1 and next(iter(tr._graphs))[0] == "bucket"
+    assert losses["structure"] == losses["eager"], losses
+    for a, c in zip(losses["auto"], losses["eager"]):
+        assert abs(a - c) <= 2e-6 * abs(c), losses
 
 
 # ------------------------------------------------------------------------------------------------ chained row GEMMs

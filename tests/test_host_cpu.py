@@ -485,7 +485,9 @@ def test_bucket_capacities_and_eligibility():
     assert not bk.eligible(batch([18, 20], x_dtype=torch.int32), "schnet")           # the fill copies int64 by byte count
     assert not bk.eligible(batch([18, 20], cut=3), "schnet")                         # super_edge_index cut after the collation
     assert bk.max_n_class(18) == 33 and bk.max_n_class(34) == 64 and bk.max_n_class(20, prev=64) == 64
-    assert bk.max_n_class(18, model_3d="painn") == 22 and bk.max_n_class(60, model_3d="painn") == 64
+    assert bk.max_n_class(58) == 128                                                 # (a quarter of head room above 33)
+    assert bk.max_n_class(18, model_3d="painn") == 22 and bk.max_n_class(60, model_3d="painn") == 96
+    assert bk.max_n_class(44, model_3d="painn") == 44
     assert bk.edge_capacity(36000, 128) >= 36000 * 1.13 and bk.edge_capacity(100, 128, prev=4096) == 4096
     # routing of StepGraphs without a GPU: auto mode buckets ragged batches only when the modules allow it
     sg = pg.StepGraphs(lambda b, n: None, "schnet", modules=None)
