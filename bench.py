@@ -496,11 +496,16 @@ def secondary_line(dev, rank, world, steps, warmup, **kw):
     """A secondary configuration timed inside the default run, so that it is observed by the driver: value, ms/step."""
     n_batches = kw.pop("n_batches", 1)
     env = kw.pop("env", None) or {}
+    want_roof = kw.pop("roofline", False)
+    roof = None
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
         wl = Workload(dev, rank, world, n_batches=n_batches, **kw)
         elapsed, step_ms, loss = wl.run(warmup, steps)
+        if want_roof:  # the line's own `roofline` (dominant entry point; measured HBM bytes when a PMC summary is committed)
+            roof, kern, _, shape = dominant_roofline(wl, 6)
+            mt = measured_step_traffic(shape["pm"], shape["pm_src"], world * wl.mols * steps / elapsed / world)
     except Exception as e:  # a secondary line must not take the headline down with it
         return {"error": "%s: %s" % (type(e).__name__, e)}
     finally:
@@ -512,6 +517,10 @@ def secondary_line(dev, rank, world, steps, warmup, **kw):
     out = {"value": world * wl.mols * steps / elapsed, "unit": "molecules/s", "ms_per_step": 1e3 * elapsed / steps,
            "steps": steps, "warmup": warmup, "workload": wl.describe(), "execution": wl.execution(), "final_loss": loss,
            "p50_ms": float(np.percentile(step_ms, 50)), "graphs": wl.n_graphs(), "captures": wl.n_captures()}
+    if roof is not None:
+        out["roofline"] = roof
+        out["kernel_ms"] = {k: {"avg_ms": v[0], "per_step": v[1]} for k, v in kern.items()}
+        out["step_roofline"] = mt
     if wl.distinct:
         out["captures_in_timed_region"] = wl.n_captures()
     if env:
@@ -539,7 +548,7 @@ SECONDARY_LINES = {
     # the 24-bit products (three bf16 pieces, six MFMAs) in the filter network instead of the 22-bit default
     "trainer/arith=bf16x3": (20, 5, dict(api="trainer", env={"GEOSSL_FILTER_FWD_BF16X3": "1",
                                                              "GEOSSL_FILTER_BWD_BF16X3": "1"})),
-    "trainer/painn": (20, 4, dict(api="trainer", model="painn", n_batches=4)),
+    "trainer/painn": (20, 4, dict(api="trainer", model="painn", n_batches=4, roofline=True)),
     # What the reference's DDM script really feeds the step (submit_pretrain_GeoSSL_DDM.sh:3,8,13-14,22): PaiNN and SchNet
     # on Molecule3D WITH hydrogens (datasets_Molecule3D.py:65; set C: a quarter of the molecules above 33 atoms), bs = 128,
     # shuffle=True, SchNet at its default 10 A (config.py:114) where the 32-neighbour cap cuts lists.  PaiNN's
@@ -711,6 +720,86 @@ def forward_only(args, dev, rank, world, emit=True):
     return result
 
 
+def dominant_roofline(wl, prof_steps):
+    """`roofline` of the workload's dominant entry point: HIP events around every launch of `prof_steps` eager steps (a
+    graph replay has no host-side launch boundaries to bracket; rocprofv3 sees the kernels of both and agrees), HBM bytes
+    per launch from the committed PMC summary of THIS workload (else null).  -> (roofline, {entry point: (avg ms, launches
+    per step)}, C-ABI calls per step, shape dict)."""
+    from geossl_amd import ops
+    timers, calls_per_step = wl.eager_kernel_times(prof_steps)
+    timing_mode = "HIP events around every launch of %d eager steps run after the timed region" % prof_steps
+    bt = wl.batches[0]
+    E = int(ops.radius_graph(bt.positions, wl.cutoff, bt.batch).size(1))
+    N, S = bt.positions.size(0), bt.super_edge_index.size(1)
+    if wl.model_name == "painn":
+        E = int(bt.radius_edge_index.size(1))  # the precomputed graph of the clean geometry (both views use it)
+        step_bytes, step_flops, per_kernel = alg_model_painn(N, E, S)
+        per_kernel.update({k: v for k, v in alg_model(N, E, S)[2].items() if k.startswith("geossl_ddm")})
+    else:
+        step_bytes, step_flops, per_kernel = alg_model(N, E, S)
+    pm, pm_src = pmc_file(workload_id(wl.model_name, wl.mols, wl.molset, wl.cutoff))
+    kern = {}
+    for name, evs in (timers or {}).items():
+        if evs:
+            ms = [a.elapsed_time(b) for a, b in evs]
+            kern[name] = (float(np.mean(ms)), len(ms) / prof_steps)
+    kern = {k: v for k, v in kern.items() if k in per_kernel}
+    dom = max(kern, key=lambda k: kern[k][0] * kern[k][1]) if kern else None
+    roof = None
+    if dom is not None:
+        fl, by = per_kernel[dom]
+        dur = kern[dom][0] * 1e-3
+        ach_f, ach_b = fl / dur, by / dur
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of THIS workload (else null), summed over
+        # the kernels the entry point launches
+        traffic = None
+        if pm is not None:
+            ks = [v for k, v in pm["kernels"].items() if k.startswith(ENTRY_KERNELS.get(dom, "\0"))]
+            if ks:
+                traffic = sum(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for v in ks)
+        # The dense kernels run on the 16-bit matrix pipe, SPLIT MFMAs per fp32 product (csrc/split.h).
+        # `frac` = what the kernel really issues (one filter evaluation per UNDIRECTED pair slot, G padded to 64,
+        # times SPLIT MFMAs) over the dense 16-bit MFMA peak: the pipe's utilisation.  `frac_algorithmic` credits
+        # SURVEY 8(d)'s fp32 flops of the reference formulation (one evaluation per DIRECTED edge) against the
+        # pipe's fp32-equivalent ceiling (peak / SPLIT) - the exact halving by symmetry shows up there, not in `frac`.
+        SPLIT_PRODUCTS = SPLIT_PRODUCTS_OF.get(dom, SPLIT_PRODUCTS_DEFAULT)
+        roof = {"kernel": dom, "bound": "mfma", "unit": "TFLOP/s", "traffic": traffic,
+                "traffic_from": ("%s @ %s" % (pm_src, pm.get("git_head"))) if traffic is not None else None,
+                "avg_launch_ms": kern[dom][0], "launches_per_step": kern[dom][1], "timing": timing_mode,
+                "algorithmic_TFLOPs": ach_f / 1e12, "frac_algorithmic": ach_f / (BF16_PEAK / SPLIT_PRODUCTS),
+                "algorithmic_GBps": ach_b / 1e9, "hbm_frac": ach_b / HBM_PEAK}
+        if dom.startswith("geossl_painn"):
+            # PaiNN's interaction kernels are fp32 vector code over gathered rows (no matrix pipe): priced against
+            # HBM - with the MEASURED bytes of the launch when a PMC summary of this workload is committed, else
+            # with the per-edge algorithmic bytes above (an upper bound: the molecule-staged kernels read a row once
+            # per molecule) - the fp32 vector fraction beside it
+            pk = None
+            if pm is not None:
+                ks = [v for k, v in pm["kernels"].items() if k.startswith(PAINN_KERNELS.get(dom, "\0"))]
+                if ks:
+                    pk = sum(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for v in ks)
+            used = pk if pk is not None else by
+            roof.update({"bound": "hbm", "unit": "GB/s", "achieved": used / dur / 1e9, "peak": HBM_PEAK / 1e9,
+                         "frac": used / dur / HBM_PEAK, "fp32_vector_frac": ach_f / FP32_PEAK, "traffic": pk,
+                         "traffic_from": ("%s @ %s" % (pm_src, pm.get("git_head"))) if pk is not None else None,
+                         "frac_from": "measured HBM bytes of the launch (PMC)" if pk is not None
+                                      else "per-edge algorithmic bytes (upper bound; no PMC summary of this workload)",
+                         "peak_note": "bytes of the launch over the 8 TB/s HBM3E spec"})
+        elif dom in ("geossl_cfconv_filter_fwd", "geossl_cfconv_filter_bwd"):
+            P2 = 2 * sum(int(n) * (int(n) - 1) // 2 for n in wl.sizes0)  # pair slots, both views
+            per_row = (2 * 64 * F + (2 if dom.endswith("fwd") else 4) * F * F)
+            exe = P2 * L * per_row * SPLIT_PRODUCTS
+        else:  # other entry points issue their algorithmic flops, SPLIT MFMAs per product
+            exe = fl * SPLIT_PRODUCTS
+        if not dom.startswith("geossl_painn"):
+            roof.update({"achieved": exe / dur / 1e12, "peak": BF16_PEAK / 1e12, "frac": exe / dur / BF16_PEAK,
+                         "mfma_per_fp32_product": SPLIT_PRODUCTS,
+                         "peak_note": "executed 16-bit MFMA flops (%d per fp32 product) over the 2.5 PFLOP/s dense peak at 2.4 GHz; "
+                                      "under this load the shader clock settles at 1.6-1.9 GHz (tools/filter_fwd_timing.py)" % SPLIT_PRODUCTS})
+    shape = dict(N=N, E=E, S=S, step_bytes=step_bytes, step_flops=step_flops, pm=pm, pm_src=pm_src)
+    return roof, kern, calls_per_step, shape
+
+
 def spawn_ranks(n):
     """`bench.py --gpus N` started without torch.distributed.run: N fresh child processes, one per GPU (RANK / LOCAL_RANK
     / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1), each running this script with the same
@@ -821,85 +910,15 @@ def main():
             torch.cuda.synchronize()
             with open(os.path.join(os.environ["GEOSSL_BENCH_RANK_LOSS"], "params_rank%d.txt" % rank), "w") as fh:
                 fh.write(hashlib.sha256(wl.trainer.flat.flat.detach().cpu().numpy().tobytes()).hexdigest())
-    timers, calls_per_step, prof_steps = None, None, min(args.steps, 10)
+    roof, kern, calls_per_step, shape = None, {}, None, None
     if rank == 0:
-        # a graph replay has no host-side launch boundaries to bracket: the entry points are timed with HIP events over
-        # eager forward+backward passes of the same step right after the timed region (rocprofv3 sees the kernels of both)
-        timers, calls_per_step = wl.eager_kernel_times(prof_steps)
-    timing_mode = "HIP events around every launch of %d eager steps run after the timed region" % prof_steps
+        roof, kern, calls_per_step, shape = dominant_roofline(wl, min(args.steps, 10))
 
     if rank == 0:
-        from geossl_amd import ops
-        bt = wl.batches[0]
-        E = int(ops.radius_graph(bt.positions, CUTOFF, bt.batch).size(1))
-        N, S = bt.positions.size(0), bt.super_edge_index.size(1)
-        if args.model == "painn":
-            E = int(bt.radius_edge_index.size(1))  # the precomputed graph of the clean geometry (both views use it)
-            step_bytes, step_flops, per_kernel = alg_model_painn(N, E, S)
-            per_kernel.update({k: v for k, v in alg_model(N, E, S)[2].items() if k.startswith("geossl_ddm")})
-        else:
-            step_bytes, step_flops, per_kernel = alg_model(N, E, S)
-        pm, pm_src = pmc_file(workload_id(args.model, args.mols, args.molset, CUTOFF))
+        N, E, S, step_bytes, step_flops = (shape[k] for k in ("N", "E", "S", "step_bytes", "step_flops"))
+        pm, pm_src = shape["pm"], shape["pm_src"]
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * args.mols * args.steps / elapsed
-        kern = {}
-        for name, evs in (timers or {}).items():
-            if evs:
-                ms = [a.elapsed_time(b) for a, b in evs]
-                kern[name] = (float(np.mean(ms)), len(ms) / prof_steps)
-        kern = {k: v for k, v in kern.items() if k in per_kernel}
-        dom = max(kern, key=lambda k: kern[k][0] * kern[k][1]) if kern else None
-        roof = None
-        if dom is not None:
-            fl, by = per_kernel[dom]
-            dur = kern[dom][0] * 1e-3
-            ach_f, ach_b = fl / dur, by / dur
-            # HBM bytes per launch from the committed rocprofv3 PMC passes of THIS workload (else null), summed over
-            # the kernels the entry point launches
-            traffic = None
-            if pm is not None:
-                ks = [v for k, v in pm["kernels"].items() if k.startswith(ENTRY_KERNELS.get(dom, "\0"))]
-                if ks:
-                    traffic = sum(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for v in ks)
-            # The dense kernels run on the 16-bit matrix pipe, SPLIT MFMAs per fp32 product (csrc/split.h).
-            # `frac` = what the kernel really issues (one filter evaluation per UNDIRECTED pair slot, G padded to 64,
-            # times SPLIT MFMAs) over the dense 16-bit MFMA peak: the pipe's utilisation.  `frac_algorithmic` credits
-            # SURVEY 8(d)'s fp32 flops of the reference formulation (one evaluation per DIRECTED edge) against the
-            # pipe's fp32-equivalent ceiling (peak / SPLIT) - the exact halving by symmetry shows up there, not in `frac`.
-            SPLIT_PRODUCTS = SPLIT_PRODUCTS_OF.get(dom, SPLIT_PRODUCTS_DEFAULT)
-            roof = {"kernel": dom, "bound": "mfma", "unit": "TFLOP/s", "traffic": traffic,
-                    "traffic_from": ("%s @ %s" % (pm_src, pm.get("git_head"))) if traffic is not None else None,
-                    "avg_launch_ms": kern[dom][0], "launches_per_step": kern[dom][1], "timing": timing_mode,
-                    "algorithmic_TFLOPs": ach_f / 1e12, "frac_algorithmic": ach_f / (BF16_PEAK / SPLIT_PRODUCTS),
-                    "algorithmic_GBps": ach_b / 1e9, "hbm_frac": ach_b / HBM_PEAK}
-            if dom.startswith("geossl_painn"):
-                # PaiNN's interaction kernels are fp32 vector code over gathered rows (no matrix pipe): priced against
-                # HBM - with the MEASURED bytes of the launch when a PMC summary of this workload is committed, else
-                # with the per-edge algorithmic bytes above (an upper bound: the molecule-staged kernels read a row once
-                # per molecule) - the fp32 vector fraction beside it
-                pk = None
-                if pm is not None:
-                    ks = [v for k, v in pm["kernels"].items() if k.startswith(PAINN_KERNELS.get(dom, "\0"))]
-                    if ks:
-                        pk = sum(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for v in ks)
-                used = pk if pk is not None else by
-                roof.update({"bound": "hbm", "unit": "GB/s", "achieved": used / dur / 1e9, "peak": HBM_PEAK / 1e9,
-                             "frac": used / dur / HBM_PEAK, "fp32_vector_frac": ach_f / FP32_PEAK, "traffic": pk,
-                             "traffic_from": ("%s @ %s" % (pm_src, pm.get("git_head"))) if pk is not None else None,
-                             "frac_from": "measured HBM bytes of the launch (PMC)" if pk is not None
-                                          else "per-edge algorithmic bytes (upper bound; no PMC summary of this workload)",
-                             "peak_note": "bytes of the launch over the 8 TB/s HBM3E spec"})
-            elif dom in ("geossl_cfconv_filter_fwd", "geossl_cfconv_filter_bwd"):
-                P2 = 2 * sum(int(n) * (int(n) - 1) // 2 for n in wl.sizes0)  # pair slots, both views
-                per_row = (2 * 64 * F + (2 if dom.endswith("fwd") else 4) * F * F)
-                exe = P2 * L * per_row * SPLIT_PRODUCTS
-            else:  # other entry points issue their algorithmic flops, SPLIT MFMAs per product
-                exe = fl * SPLIT_PRODUCTS
-            if not dom.startswith("geossl_painn"):
-                roof.update({"achieved": exe / dur / 1e12, "peak": BF16_PEAK / 1e12, "frac": exe / dur / BF16_PEAK,
-                             "mfma_per_fp32_product": SPLIT_PRODUCTS,
-                             "peak_note": "executed 16-bit MFMA flops (%d per fp32 product) over the 2.5 PFLOP/s dense peak at 2.4 GHz; "
-                                          "under this load the shader clock settles at 1.6-1.9 GHz (tools/filter_fwd_timing.py)" % SPLIT_PRODUCTS})
         per_gpu = value / world
         measured = measured_step_traffic(pm, pm_src, per_gpu)
         out = {

@@ -256,6 +256,19 @@ class _PaiNNCore(torch.autograd.Function):
             return ops.linear_chain(x, [dict(image=img[k], bias=bias, res=res, out=out)],
                                     dyn_rows=dN if x.size(0) == N else dN3)[0]
 
+        # Which interaction kernel: the matrix-pipe form stages a molecule's rows in LDS (at most `cap_f` atoms).  A
+        # layout with larger molecules (Molecule3D with hydrogens) keeps that form for the molecules that fit and covers
+        # the atoms of the others with the per-atom kernel (`big_f`: their list) - one oversized molecule does not send
+        # the whole batch to the slower kernels.  Without host-side molecule sizes there is no list: one form for all.
+        lay = cfg["lay"]
+        lib = _lib.load()
+        use_mma = bool(cfg["mma"]) and E > 0
+        big_f = None
+        if use_mma:
+            cap_f = int(lib.geossl_painn_stage_cap(0, F_, R))
+            if lay.max_n > cap_f:
+                big_f = lay.big_atoms(cap_f) if cap_f > 0 else None
+                use_mma = big_f is not None
         for l in range(L):
             c0w, c0b, c1w, c1b = inter[l]
             k0 = NB * l
@@ -272,13 +285,17 @@ class _PaiNNCore(torch.autograd.Function):
                 lin_fan(s, [k0 + 1 + c for c in range(3)], [c1b[c * F_:(c + 1) * F_] for c in range(3)],
                         _split3(xc, F_))                                     # Dense(F, 3F)
             q2, mu2 = torch.empty_like(q), torch.empty_like(mu)
-            lay = cfg["lay"]  # one block per molecule: the rows its edges read are staged in LDS once
-            if cfg["mma"] and lay.max_n <= 44 and E > 0:  # filter on the matrix pipe (painn_mma.hip); LDS: 3.5 KB per atom + 3 KB
+            # one block per molecule: the rows its edges read are staged in LDS once
+            if use_mma:  # filter on the matrix pipe (painn_mma.hip); LDS: 3.5 KB per atom + 3 KB
                 row_edge, grp_atom, _, mol_grp = el.groups("i", lay.mol_ptr)
                 call("geossl_painn_interaction_fwd_mma_dyn", ptr(q), ptr(mu), ptr(xc), ptr(el.idx_j), ptr(row_edge),
                      ptr(grp_atom), ptr(mol_grp), ptr(phi), ptr(fcut), ptr(dirv), ptr(fw[l * 3 * F_:(l + 1) * 3 * F_]),
                      ptr(fb[l * 3 * F_:(l + 1) * 3 * F_]), ptr(lay.mol_ptr), lay.B, lay.max_n, N, F_, R, ptr(q2), ptr(mu2),
                      ptr(getattr(el, "mol_grp_end", None)), st)                 # :54-64
+                if big_f is not None and big_f[1] > 0:   # the atoms of the molecules above the staged rows
+                    call("geossl_painn_interaction_fwd_atoms", ptr(q), ptr(mu), ptr(xc), ptr(el.idx_j), ptr(inc_ptr),
+                         ptr(inc_idx), ptr(phi), ptr(fcut), ptr(dirv), ptr(fw[l * 3 * F_:(l + 1) * 3 * F_]),
+                         ptr(fb[l * 3 * F_:(l + 1) * 3 * F_]), ptr(big_f[0]), big_f[1], big_f[2], F_, R, ptr(q2), ptr(mu2), st)
             else:
                 call("geossl_painn_interaction_fwd_mol", ptr(q), ptr(mu), ptr(xc), ptr(el.idx_j), ptr(inc_ptr),
                      ptr(inc_idx), ptr(phi), ptr(fcut), ptr(dirv), ptr(fw[l * 3 * F_:(l + 1) * 3 * F_]),
@@ -407,6 +424,9 @@ class _PaiNNCore(torch.autograd.Function):
 
         nfl = _lib.load().geossl_painn_interaction_bwd_mol_workspace_floats(N, lay.B, F_, R)
         ws = torch.empty(max(int(nfl), 1), **f32)
+        # molecules above the LDS rows of the molecule-staged backward: skipped there, covered by the per-atom kernel
+        cap_b = int(_lib.load().geossl_painn_stage_cap(2, F_, R))
+        big_b = lay.big_atoms(cap_b) if (0 < cap_b < lay.max_n and F_ in (64, 128)) else None
         keep = []
         E = el.E
         if want_pos:  # dL/d(phi, fcut, dir) per edge, summed over the blocks (painn_force.hip)
@@ -462,10 +482,16 @@ class _PaiNNCore(torch.autograd.Function):
                      ptr(ps[2][l * 3 * F_:(l + 1) * 3 * F_]), E, F_, R, ptr(dphi), ptr(dfc), ptr(ddir),
                      0 if l == L - 1 else 1, st)
             dxc, dmu_in = torch.empty(N, 3 * F_, **f32), torch.empty(N, 3, F_, **f32)
-            call("geossl_painn_interaction_bwd_mol", ptr(dq2), ptr(dmu2), ptr(sv["mu"]), ptr(sv["xc"]), ptr(el.idx_i),
+            call("geossl_painn_interaction_bwd_mol" if big_b is None else "geossl_painn_interaction_bwd_mol_skip",
+                 ptr(dq2), ptr(dmu2), ptr(sv["mu"]), ptr(sv["xc"]), ptr(el.idx_i),
                  ptr(inc_ptr), ptr(inc_idx), ptr(phi), ptr(fcut), ptr(dirv), ptr(ps[1][l * 3 * F_:(l + 1) * 3 * F_]),
                  ptr(ps[2][l * 3 * F_:(l + 1) * 3 * F_]), ptr(lay.mol_ptr), lay.B, lay.max_n, N, F_, R, ptr(dxc), ptr(dmu_in),
                  ptr(g_fw[l * 3 * F_:(l + 1) * 3 * F_]), ptr(g_fb[l * 3 * F_:(l + 1) * 3 * F_]), ptr(ws), acc, st)
+            if big_b is not None and big_b[1] > 0:
+                call("geossl_painn_interaction_bwd_atoms", ptr(dq2), ptr(dmu2), ptr(sv["mu"]), ptr(sv["xc"]), ptr(el.idx_i),
+                     ptr(inc_ptr), ptr(inc_idx), ptr(phi), ptr(fcut), ptr(dirv), ptr(ps[1][l * 3 * F_:(l + 1) * 3 * F_]),
+                     ptr(ps[2][l * 3 * F_:(l + 1) * 3 * F_]), ptr(big_b[0]), big_b[1], big_b[2], F_, R, ptr(dxc), ptr(dmu_in),
+                     ptr(g_fw[l * 3 * F_:(l + 1) * 3 * F_]), ptr(g_fb[l * 3 * F_:(l + 1) * 3 * F_]), ptr(ws), 1, st)
             for c, xs_ in enumerate(_split3(dxc, F_)):
                 add(N, 3 * F_, F_, F_, xs_, sv["s"], gc1w[c * F_:(c + 1) * F_], gc1b[c * F_:(c + 1) * F_])
             if fused:  # (sum_c dxc_c W_c) * silu'(u) = du, then du @ c0w + dq2 (residual q2 = q + dq): one launch

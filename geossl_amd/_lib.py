@@ -206,6 +206,11 @@ PROTOTYPES = {
     "geossl_painn_edge_geom_dyn": (i32, [vp, vp, vp, i64, f32, vp, vp, i32, vp, vp, vp, vp, vp]),
     "geossl_painn_interaction_fwd_mma_dyn": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i64, i32,
                                                    i32, vp, vp, vp, vp]),
+    "geossl_painn_stage_cap": (i32, [i32, i32, i32]),
+    "geossl_painn_interaction_fwd_atoms": (i32, [vp] * 12 + [i64, vp, i32, i32, vp, vp, vp]),
+    "geossl_painn_interaction_bwd_atoms": (i32, [vp] * 13 + [i64, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
+    "geossl_painn_interaction_bwd_mol_skip": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i64, i32,
+                                                    i32, vp, vp, vp, vp, vp, i32, vp]),
     "geossl_painn_mix_pre_fwd_dyn": (i32, [vp, vp, i64, i32, f32, vp, vp, vp, vp]),
     "geossl_painn_mix_post_fwd_dyn": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp]),
     "geossl_painn_mix_post_bwd_dyn": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp]),

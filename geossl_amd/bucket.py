@@ -32,7 +32,8 @@ MAX_N = 255         # largest molecule a bucket takes (the limit of the aggregat
 SMALL_N = 33        # ... and the largest one of the register-form aggregation's size classes: buckets whose molecules
                     # all fit it keep the flat pair-geometry kernel and the ragged layer loop
 MAX_N_CLASSES = (SMALL_N, 64, 128, MAX_N)   # a bucket's bound on the molecule size (LDS of the radius-graph kernel)
-D_N, D_N2, D_P2, D_S, D_W, D_B, D_N6, D_E2 = 0, 1, 2, 3, 4, 5, 6, 7   # words of `dims`
+D_N, D_N2, D_P2, D_S, D_W, D_B, D_N6, D_E2, D_BIG0, D_BIG1 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9   # words of `dims`
+DIMS_WORDS = 16
 PAINN_MAX_N_CLASSES = (22, 33, 44, 64, 96, 128, MAX_N)   # PaiNN: the bound sizes the LDS of its per-molecule kernels
 
 
@@ -49,6 +50,7 @@ class DynDims:
         self.n_work = base + 4 * D_W        # work items of the aggregation
         self.n_atoms2x3 = base + 4 * D_N6   # PaiNN: rows of the vector features viewed as [3 N2, F]
         self.n_edges2 = base + 4 * D_E2     # PaiNN: edges of the two-view batch
+        self.n_big = (base + 4 * D_BIG0, base + 4 * D_BIG1)   # PaiNN: atoms of the molecules above the two stage caps
 
 
 class _Layout:
@@ -58,8 +60,15 @@ class _Layout:
     order = None
     _sizes_host = None
 
+    big = None
+
     def loop_plan(self, *a, **k):
         return (None, 0)   # (the layer loop is a plan for uniform batches: they keep their per-structure graph)
+
+    def big_atoms(self, cap):
+        """PaiNN: (static list of the atoms of molecules above `cap` atoms, its capacity, device address of the real
+        count) - rewritten per step by Bucket.fill; None for a cap the bucket was not made for."""
+        return None if self.big is None else self.big.get(cap)
 
 
 class _SuperEdges:
@@ -296,16 +305,24 @@ class Bucket:
         i64 = dict(dtype=torch.int64, device=device)
         # ---- the blob: everything the host computes, uploaded in one copy (int32 words; int64 parts 8-byte aligned)
         o = {"dims": 0}
-        o["mol_ptr"] = 8
+        o["mol_ptr"] = DIMS_WORDS
         o["pair_ptr"] = o["mol_ptr"] + 2 * B + 1
         o["se_ptr"] = o["pair_ptr"] + 2 * B + 1
         o["work"] = o["se_ptr"] + B + 1
         o["stats"] = _round_up(o["work"] + Wc, 2)
         o["inc_ptr"] = o["stats"] + 4
-        self.words = o["inc_ptr"] + 2 * (Nc + 1)
+        o["big0"] = o["inc_ptr"] + 2 * (Nc + 1)
+        # PaiNN, molecules above the stage caps of the molecule-staged interaction kernels: their atoms (two lists)
+        self.big_caps = ()
+        if kind == "painn" and self.max_n > 0:
+            lib = _lib.load()
+            self.big_caps = tuple(c for c in (int(lib.geossl_painn_stage_cap(0, 128, 20)), int(lib.geossl_painn_stage_cap(2, 128, 20)))
+                                  if 0 < c < self.max_n)
+        o["big1"] = o["big0"] + (2 * Nc if len(self.big_caps) > 0 else 0)
+        self.words = o["big1"] + (2 * Nc if len(self.big_caps) > 1 else 0)
         self.off = o
         self.blob = torch.zeros(self.words, **i32)
-        self.dims = self.blob[0:8]
+        self.dims = self.blob[0:DIMS_WORDS]
         self.dyn = DynDims(self.dims)
         self._host = [[torch.zeros(self.words, dtype=torch.int32).pin_memory(), None] for _ in range(3)]
         self._slot = 0
@@ -323,6 +340,9 @@ class Bucket:
         lay.device, lay.dyn = device, self.dyn
         lay._batch_version = self.b2._version
         lay.agg_work = None
+        if self.big_caps:
+            lay.big = {c: (self.blob[o["big%d" % k]:o["big%d" % k] + 2 * Nc], 2 * Nc, self.dyn.n_big[k])
+                       for k, c in enumerate(self.big_caps)}
         if kind == "schnet":
             lay.pair_i = torch.zeros(2 * Pc, **i32)
             lay.pair_j = torch.zeros(2 * Pc, **i32)
@@ -400,6 +420,13 @@ class Bucket:
         h = slot[0].numpy()
         hp = host_plan(n, self.option)
         h[0:8] = (N, 2 * N, 2 * P, S, W, B, 6 * N, 2 * E)
+        if self.big_caps:
+            from .layout import big_atom_list
+            n2 = np.concatenate([n, n])
+            for k, c in enumerate(self.big_caps):
+                idx = big_atom_list(n2, c)
+                h[8 + k] = idx.size
+                h[o["big%d" % k]:o["big%d" % k] + idx.size] = idx
         h[o["mol_ptr"]:o["mol_ptr"] + 2 * B + 1] = hp["mol_ptr2"]
         h[o["pair_ptr"]:o["pair_ptr"] + 2 * B + 1] = hp["pair_ptr2"]
         h[o["se_ptr"]:o["se_ptr"] + B + 1] = hp["se_ptr"]

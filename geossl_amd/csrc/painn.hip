@@ -73,9 +73,13 @@ __global__ __launch_bounds__(128) void k_painn_interaction_fwd(
     const int64_t* __restrict__ idx_j, const int64_t* __restrict__ inc_ptr, const int32_t* __restrict__ inc_idx,
     const float* __restrict__ phi, const float* __restrict__ fcut, const float* __restrict__ dir,
     const float* __restrict__ Wf, const float* __restrict__ bf, int N, int F, float* __restrict__ q_out,
-    float* __restrict__ mu_out) {
-  const int i = blockIdx.x, f = threadIdx.x;
-  if (i >= N || f >= F) return;
+    float* __restrict__ mu_out, const int32_t* __restrict__ atom_list, const int32_t* __restrict__ dyn_nlist) {
+  // atom_list == NULL: atoms 0 .. N-1 (one per block); else the atoms atom_list[0 .. min(N, *dyn_nlist)) - the atoms of
+  // the molecules that a molecule-staged launch skipped (more atoms than its LDS rows), blocks striding over the list
+  const int f = threadIdx.x;
+  if (f >= F) return;
+  const int cnt = atom_list != nullptr ? dyn_count(N, dyn_nlist) : N;
+  if ((int)blockIdx.x >= cnt) return;
   float w0[R], w1[R], w2[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -84,6 +88,8 @@ __global__ __launch_bounds__(128) void k_painn_interaction_fwd(
     w2[r] = Wf[(size_t)(2 * F + f) * R + r];
   }
   const float b0 = bf[f], b1 = bf[F + f], b2 = bf[2 * F + f];
+  for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
+  const int i = atom_list != nullptr ? atom_list[k] : k;
   float dq = 0.0f, dm0 = 0.0f, dm1 = 0.0f, dm2 = 0.0f;
   const int64_t p0 = inc_ptr[i], p1 = inc_ptr[i + 1];
   for (int64_t p = p0; p < p1; ++p) {
@@ -114,6 +120,7 @@ __global__ __launch_bounds__(128) void k_painn_interaction_fwd(
   mo[f] = mi[f] + dm0;                                             // :64
   mo[F + f] = mi[F + f] + dm1;
   mo[2 * F + f] = mi[2 * F + f] + dm2;
+  }
 }
 
 // ----------------------------------------------------------------------------------- interaction, backward
@@ -125,9 +132,11 @@ __global__ __launch_bounds__(128) void k_painn_interaction_bwd(
     const float* __restrict__ xc, const int64_t* __restrict__ idx_i, const int64_t* __restrict__ inc_ptr,
     const int32_t* __restrict__ inc_idx, const float* __restrict__ phi, const float* __restrict__ fcut,
     const float* __restrict__ dir, const float* __restrict__ Wf, const float* __restrict__ bf, int N, int F,
-    float* __restrict__ dxc, float* __restrict__ dmu_in, float* __restrict__ partial_w, float* __restrict__ partial_b) {
+    float* __restrict__ dxc, float* __restrict__ dmu_in, float* __restrict__ partial_w, float* __restrict__ partial_b,
+    const int32_t* __restrict__ atom_list, const int32_t* __restrict__ dyn_nlist) {
   const int f = threadIdx.x;
   if (f >= F) return;
+  const int cnt = atom_list != nullptr ? dyn_count(N, dyn_nlist) : N;  // (a list: see k_painn_interaction_fwd)
   float w0[R], w1[R], w2[R], g0[R], g1[R], g2[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -138,7 +147,8 @@ __global__ __launch_bounds__(128) void k_painn_interaction_bwd(
   }
   const float b0 = bf[f], b1 = bf[F + f], b2 = bf[2 * F + f];
   float gb0 = 0.0f, gb1 = 0.0f, gb2 = 0.0f;
-  for (int j = blockIdx.x; j < N; j += gridDim.x) {
+  for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
+    const int j = atom_list != nullptr ? atom_list[k] : k;
     const float* __restrict__ xj = xc + (size_t)j * 3 * F;
     const float* __restrict__ mj = mu + (size_t)j * 3 * F;
     const float xj0 = xj[f], xj1 = xj[F + f], xj2 = xj[2 * F + f];
@@ -262,6 +272,7 @@ __global__ __launch_bounds__(512) void k_painn_interaction_fwd_mol(
   float* estage = sm_rows + (size_t)max_n * 6 * F + (threadIdx.x >> 6) * (ECHUNK * EdgeStage<R>::EROW);  // this wave's
   for (int m = blockIdx.x; m < B; m += gridDim.x) {
   const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0;
+  if (n > max_n) continue;  // (more atoms than LDS rows: the caller covers the molecule with the per-atom kernel)
   float* xs = sm_rows;                     // [n][3F]
   float* ms = sm_rows + (size_t)n * 3 * F;  // [n][3F]
   __syncthreads();  // the previous molecule's rows are no longer read
@@ -339,6 +350,7 @@ __global__ __launch_bounds__(512) void k_painn_interaction_bwd_mol(
   float gb0 = 0.0f, gb1 = 0.0f, gb2 = 0.0f;
   for (int m = blockIdx.x; m < B; m += gridDim.x) {
     const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0;
+    if (n > max_n) continue;  // (more atoms than LDS rows: the caller covers the molecule with the per-atom kernel)
     float* gqs = sm_rows;                  // [n][F]   dq_out rows
     float* gms = sm_rows + (size_t)n * F;  // [n][3F]  dmu_out rows
     float* estage = sm_rows + (size_t)max_n * 4 * F + (threadIdx.x >> 6) * (ECHUNK * EdgeStage<R>::EROW);  // this wave's
@@ -568,7 +580,23 @@ extern "C" int geossl_painn_interaction_fwd(const float* q, const float* mu, con
   if (N <= 0) return 0;
   if (F > 128) return (int)hipErrorInvalidValue;
   GEOSSL_PAINN_DISPATCH_R(k_painn_interaction_fwd, dim3((unsigned)N), dim3(F > 64 ? 128 : 64), 0, stream, q, mu, xc,
-                          idx_j, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, (int)N, F, q_out, mu_out);
+                          idx_j, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, (int)N, F, q_out, mu_out, nullptr, nullptr);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+// the same over a LIST of atoms (the atoms of molecules a molecule-staged launch skipped): nlist entries, of which
+// min(nlist, *dyn_nlist) are real when dyn_nlist is given
+extern "C" int geossl_painn_interaction_fwd_atoms(const float* q, const float* mu, const float* xc, const int64_t* idx_j,
+                                                  const int64_t* inc_ptr, const int32_t* inc_idx, const float* phi,
+                                                  const float* fcut, const float* dir, const float* Wf, const float* bf,
+                                                  const int32_t* atom_list, int64_t nlist, const int32_t* dyn_nlist, int F,
+                                                  int R, float* q_out, float* mu_out, hipStream_t stream) {
+  if (nlist <= 0) return 0;
+  if (F > 128 || atom_list == nullptr) return (int)hipErrorInvalidValue;
+  const unsigned nb = (unsigned)(nlist < 2048 ? nlist : 2048);
+  GEOSSL_PAINN_DISPATCH_R(k_painn_interaction_fwd, dim3(nb), dim3(F > 64 ? 128 : 64), 0, stream, q, mu, xc, idx_j, inc_ptr,
+                          inc_idx, phi, fcut, dir, Wf, bf, (int)nlist, F, q_out, mu_out, atom_list, dyn_nlist);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
@@ -579,19 +607,20 @@ extern "C" int64_t geossl_painn_interaction_bwd_workspace_floats(int64_t N, int 
   return nb * (3 * (int64_t)F * R + 3 * F);
 }
 
-extern "C" int geossl_painn_interaction_bwd(const float* dq_out, const float* dmu_out, const float* mu, const float* xc,
-                                            const int64_t* idx_i, const int64_t* inc_ptr, const int32_t* inc_idx,
-                                            const float* phi, const float* fcut, const float* dir, const float* Wf,
-                                            const float* bf, int64_t N, int F, int R, float* dxc, float* dmu_in,
-                                            float* dWf, float* dbf, float* workspace, int accumulate,
-                                            hipStream_t stream) {
+static int painn_interaction_bwd_launch(const float* dq_out, const float* dmu_out, const float* mu, const float* xc,
+                                        const int64_t* idx_i, const int64_t* inc_ptr, const int32_t* inc_idx,
+                                        const float* phi, const float* fcut, const float* dir, const float* Wf,
+                                        const float* bf, int64_t N, int F, int R, float* dxc, float* dmu_in,
+                                        float* dWf, float* dbf, float* workspace, int accumulate,
+                                        const int32_t* atom_list, const int32_t* dyn_nlist, hipStream_t stream) {
   if (N <= 0) return 0;
   if (F > 128) return (int)hipErrorInvalidValue;
   const int nb = (int)(N < GEOSSL_PAINN_BWD_BLOCKS ? N : GEOSSL_PAINN_BWD_BLOCKS);
   float* pw = workspace;
   float* pb = workspace + (size_t)nb * 3 * F * R;
   GEOSSL_PAINN_DISPATCH_R(k_painn_interaction_bwd, dim3(nb), dim3(F > 64 ? 128 : 64), 0, stream, dq_out, dmu_out, mu, xc,
-                          idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, (int)N, F, dxc, dmu_in, pw, pb);
+                          idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, (int)N, F, dxc, dmu_in, pw, pb, atom_list,
+                          dyn_nlist);
   GEOSSL_CHECK_LAUNCH();
   // fixed-order two-stage sums of the per-block partials (64 outputs x 4 slices of the block list per reduction block)
   ReduceMulti rm;  // both fixed-order sums over the block partials in one launch (k_reduce_partials' arithmetic)
@@ -602,6 +631,27 @@ extern "C" int geossl_painn_interaction_bwd(const float* dq_out, const float* dm
   hipLaunchKernelGGL(geossl::k_reduce_multi, dim3(rm.blocks(), 1), dim3(256), 0, stream, rm, nb, accumulate);
   GEOSSL_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int geossl_painn_interaction_bwd(const float* dq_out, const float* dmu_out, const float* mu, const float* xc,
+                                            const int64_t* idx_i, const int64_t* inc_ptr, const int32_t* inc_idx,
+                                            const float* phi, const float* fcut, const float* dir, const float* Wf,
+                                            const float* bf, int64_t N, int F, int R, float* dxc, float* dmu_in,
+                                            float* dWf, float* dbf, float* workspace, int accumulate,
+                                            hipStream_t stream) {
+  return painn_interaction_bwd_launch(dq_out, dmu_out, mu, xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, N, F, R, dxc,
+                                      dmu_in, dWf, dbf, workspace, accumulate, nullptr, nullptr, stream);
+}
+// the same over a LIST of atoms (see geossl_painn_interaction_fwd_atoms); workspace: geossl_painn_interaction_bwd_workspace_floats(nlist, F, R)
+extern "C" int geossl_painn_interaction_bwd_atoms(const float* dq_out, const float* dmu_out, const float* mu,
+                                                  const float* xc, const int64_t* idx_i, const int64_t* inc_ptr,
+                                                  const int32_t* inc_idx, const float* phi, const float* fcut,
+                                                  const float* dir, const float* Wf, const float* bf,
+                                                  const int32_t* atom_list, int64_t nlist, const int32_t* dyn_nlist, int F,
+                                                  int R, float* dxc, float* dmu_in, float* dWf, float* dbf,
+                                                  float* workspace, int accumulate, hipStream_t stream) {
+  if (atom_list == nullptr) return (int)hipErrorInvalidValue;
+  return painn_interaction_bwd_launch(dq_out, dmu_out, mu, xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, nlist, F, R,
+                                      dxc, dmu_in, dWf, dbf, workspace, accumulate, atom_list, dyn_nlist, stream);
 }
 
 // ---- the same two entry points with the molecule layout (mol_ptr [B+1] int32, max_n): one block per molecule.
@@ -643,19 +693,38 @@ extern "C" int64_t geossl_painn_interaction_bwd_mol_workspace_floats(int64_t N, 
   const int64_t b = nb * (3 * (int64_t)F * R + 3 * F);
   return a > b ? a : b;
 }
-extern "C" int geossl_painn_interaction_bwd_mol(const float* dq_out, const float* dmu_out, const float* mu,
-                                                const float* xc, const int64_t* idx_i, const int64_t* inc_ptr,
-                                                const int32_t* inc_idx, const float* phi, const float* fcut,
-                                                const float* dir, const float* Wf, const float* bf,
-                                                const int32_t* mol_ptr, int64_t B, int max_n, int64_t N, int F, int R,
-                                                float* dxc, float* dmu_in, float* dWf, float* dbf, float* workspace,
-                                                int accumulate, hipStream_t stream) {
+// Largest molecule (atoms) whose rows fit the LDS of a molecule-staged interaction launch: kind 0 = matrix-pipe forward
+// (painn_mma.hip), 1 = vector forward, 2 = backward; 0 when the shape has no such form.  A launch whose layout holds
+// larger molecules SKIPS them (geossl_painn_interaction_fwd_mma_dyn, geossl_painn_interaction_bwd_mol_skip): the caller
+// covers their atoms with geossl_painn_interaction_fwd_atoms / _bwd_atoms - one oversized molecule no longer sends the
+// whole batch to the per-atom kernels.
+extern "C" int geossl_painn_stage_cap(int kind, int F, int R) {
+  if (F != 64 && F != 128) return 0;
+  if (kind == 0) return (F == 128 && (R == 8 || R == 16 || R == 20)) ? 44 : 0;   // painn_mma_lds(44) = 157.6 KB
+  if (kind == 1) return (int)((150 * 1024) / ((size_t)6 * F * sizeof(float)));
+  if (kind == 2) return R == 32 ? 0 : (int)((150 * 1024) / ((size_t)4 * F * sizeof(float)));
+  return 0;
+}
+
+static int painn_interaction_bwd_mol_launch(const float* dq_out, const float* dmu_out, const float* mu,
+                                            const float* xc, const int64_t* idx_i, const int64_t* inc_ptr,
+                                            const int32_t* inc_idx, const float* phi, const float* fcut,
+                                            const float* dir, const float* Wf, const float* bf,
+                                            const int32_t* mol_ptr, int64_t B, int max_n, int64_t N, int F, int R,
+                                            float* dxc, float* dmu_in, float* dWf, float* dbf, float* workspace,
+                                            int accumulate, bool skip_big, hipStream_t stream) {
   if (N <= 0 || B <= 0) return 0;
+  if (skip_big) {  // molecules above the LDS rows are left to the caller (geossl_painn_interaction_bwd_atoms)
+    const int cap = geossl_painn_stage_cap(2, F, R);
+    if (cap <= 0) return (int)hipErrorInvalidValue;
+    max_n = max_n < cap ? max_n : cap;
+  }
   size_t stage = (size_t)max_n * 4 * F, red = (size_t)3 * F * (R + 1);
   // (n_rbf = 32: the molecule-staged backward would hold 32 filter rows per thread and spill; the per-atom form runs)
   if (!painn_mol_ok(F, max_n, (size_t)4 * F) || red * sizeof(float) > 150 * 1024 || R == 32)
-    return geossl_painn_interaction_bwd(dq_out, dmu_out, mu, xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, N, F, R,
-                                        dxc, dmu_in, dWf, dbf, workspace, accumulate, stream);
+    return skip_big ? (int)hipErrorInvalidValue :
+        geossl_painn_interaction_bwd(dq_out, dmu_out, mu, xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, N, F, R,
+                                     dxc, dmu_in, dWf, dbf, workspace, accumulate, stream);
   const int nb = (int)(B < GEOSSL_PAINN_BWD_MOL_BLOCKS ? B : GEOSSL_PAINN_BWD_MOL_BLOCKS);
   const size_t estage = (size_t)(4 * F / 64) * ECHUNK * (((R + 5 + 3) / 4) * 4);  // per-wave edge stages (floats)
   const size_t lds = ((stage + estage) > red ? (stage + estage) : red) * sizeof(float);
@@ -680,6 +749,28 @@ extern "C" int geossl_painn_interaction_bwd_mol(const float* dq_out, const float
   hipLaunchKernelGGL(geossl::k_reduce_multi, dim3(rm.blocks(), 1), dim3(256), 0, stream, rm, nb, accumulate);
   GEOSSL_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int geossl_painn_interaction_bwd_mol(const float* dq_out, const float* dmu_out, const float* mu,
+                                                const float* xc, const int64_t* idx_i, const int64_t* inc_ptr,
+                                                const int32_t* inc_idx, const float* phi, const float* fcut,
+                                                const float* dir, const float* Wf, const float* bf,
+                                                const int32_t* mol_ptr, int64_t B, int max_n, int64_t N, int F, int R,
+                                                float* dxc, float* dmu_in, float* dWf, float* dbf, float* workspace,
+                                                int accumulate, hipStream_t stream) {
+  return painn_interaction_bwd_mol_launch(dq_out, dmu_out, mu, xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, mol_ptr,
+                                          B, max_n, N, F, R, dxc, dmu_in, dWf, dbf, workspace, accumulate, false, stream);
+}
+// molecules of more than geossl_painn_stage_cap(2, F, R) atoms are SKIPPED (their rows of dxc / dmu_in are not written,
+// their edges add nothing to dWf / dbf): the caller covers them with geossl_painn_interaction_bwd_atoms(accumulate = 1)
+extern "C" int geossl_painn_interaction_bwd_mol_skip(const float* dq_out, const float* dmu_out, const float* mu,
+                                                     const float* xc, const int64_t* idx_i, const int64_t* inc_ptr,
+                                                     const int32_t* inc_idx, const float* phi, const float* fcut,
+                                                     const float* dir, const float* Wf, const float* bf,
+                                                     const int32_t* mol_ptr, int64_t B, int max_n, int64_t N, int F, int R,
+                                                     float* dxc, float* dmu_in, float* dWf, float* dbf, float* workspace,
+                                                     int accumulate, hipStream_t stream) {
+  return painn_interaction_bwd_mol_launch(dq_out, dmu_out, mu, xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, mol_ptr,
+                                          B, max_n, N, F, R, dxc, dmu_in, dWf, dbf, workspace, accumulate, true, stream);
 }
 
 extern "C" int geossl_painn_mix_pre_fwd_dyn(const float* q, const float* mm, int64_t N, int F, float eps, float* ctx,

@@ -193,11 +193,11 @@ __global__ __launch_bounds__(256, 2) void k_painn_fwd_mma(PainnMmaArgs A) {
       }
       const int a0 = A.mol_ptr[t.mol], n = A.mol_ptr[t.mol + 1] - a0;
       const int g0 = A.mol_grp[t.mol], g1 = A.mol_grp_end != nullptr ? A.mol_grp_end[t.mol] : A.mol_grp[t.mol + 1];
-      if (g1 > g0) {
+      if (g1 > g0 && n <= A.max_n) {
         t = TilePos{t.mol, a0, n, g1, g0, 1};
         return;
       }
-      t.mol += stride;  // (a molecule without atoms)
+      t.mol += stride;  // (a molecule without atoms - or with more than the staged rows: left to the per-atom kernel)
     }
   };
   auto advance = [&](TilePos& t) {
@@ -434,6 +434,9 @@ extern "C" int geossl_painn_interaction_fwd_mma_dyn(const float* q, const float*
                                                     float* q_out, float* mu_out, const int32_t* mol_grp_end,
                                                     hipStream_t stream) {
   if (N <= 0 || B <= 0) return 0;
+  // molecules above the rows the LDS holds (44 atoms: geossl_painn_stage_cap(0, ..)) are skipped - the caller covers
+  // them with geossl_painn_interaction_fwd_atoms
+  if (max_n > 44) max_n = 44;
   const size_t lds = painn_mma_lds(max_n);
   if (F != PM_F || lds > 160 * 1024 || (R != 8 && R != 16 && R != 20) || N * 3 * PM_F * 4 >= ((int64_t)1 << 32))
     return (int)hipErrorInvalidValue;

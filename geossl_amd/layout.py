@@ -80,6 +80,22 @@ class MolLayout:
         self.uniform = False
         self.dyn = None  # bucket.DynDims when the layout belongs to a capacity bucket (device-side row counts)
 
+    def big_atoms(self, cap):
+        """The atoms of the molecules with more than `cap` atoms (PaiNN: the molecules a molecule-staged interaction
+        launch skips, covered by the per-atom kernels) -> (int32 tensor, entries, None) - cached; None when the molecule
+        sizes are not known on the host (the caller then keeps one kernel form for the whole batch) or a graph capture is
+        open and the list was not made before it."""
+        got = self._big.get(cap) if hasattr(self, "_big") else None
+        if got is None:
+            if self._sizes_host is None or torch.cuda.is_current_stream_capturing():
+                return None
+            if not hasattr(self, "_big"):
+                self._big = {}
+            idx = big_atom_list(np.asarray(self._sizes_host, dtype=np.int64), cap)
+            t_ = torch.from_numpy(idx if idx.size else np.zeros(1, np.int32)).to(self.device)
+            got = self._big[cap] = (t_, int(idx.size), None)
+        return got
+
     def loop_plan(self, max_rows=96, max_mols=None):
         """Blocks of the layer loop (geossl_schnet_layer_loop): consecutive molecules of a uniform batch in blocks of at
         most `max_rows` atom rows -> (int32 tensor [nblocks, 4] = first row, end row, first molecule, end molecule;
@@ -103,6 +119,18 @@ class MolLayout:
             t_ = torch.from_numpy(np.ascontiguousarray(plan)).to(self.device)
             self._loop_plan = (t_, len(plan))
         return self._loop_plan
+
+
+def big_atom_list(n, cap):
+    """Atom indices (int32, ascending) of the molecules with more than `cap` atoms, for molecules of sizes `n` laid out
+    back to back."""
+    start = np.concatenate([[0], np.cumsum(n)[:-1]]) if len(n) else np.zeros(0, np.int64)
+    sel = n > cap
+    k = n[sel]
+    if not k.size:
+        return np.zeros(0, dtype=np.int32)
+    ends = np.cumsum(k)
+    return (np.repeat(start[sel], k) + (np.arange(int(ends[-1]), dtype=np.int64) - np.repeat(ends - k, k))).astype(np.int32)
 
 
 _PARTS = None

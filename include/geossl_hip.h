@@ -604,6 +604,30 @@ int geossl_painn_interaction_fwd_mma_dyn(const float* q, const float* mu, const 
                                          const float* bf, const int32_t* mol_ptr, int64_t B, int max_n, int64_t N, int F,
                                          int R, float* q_out, float* mu_out, const int32_t* mol_grp_end,
                                          hipStream_t stream);
+/* Molecules above the LDS rows of a molecule-staged interaction launch (geossl_painn_stage_cap: kind 0 = matrix-pipe
+ * forward, 1 = vector forward, 2 = backward; atoms) - Molecule3D with hydrogens has them - no longer send the whole
+ * batch to the per-atom kernels: geossl_painn_interaction_fwd_mma_dyn and geossl_painn_interaction_bwd_mol_skip SKIP
+ * such molecules, and the per-atom kernels cover a LIST of atoms (min(nlist, *dyn_nlist) entries of atom_list; the
+ * backward with accumulate = 1 adds its filter-gradient partials to what the molecule-staged launch left in dWf / dbf;
+ * workspace: geossl_painn_interaction_bwd_workspace_floats(nlist, F, R)).                                              */
+int geossl_painn_stage_cap(int kind, int F, int R);
+int geossl_painn_interaction_fwd_atoms(const float* q, const float* mu, const float* xc, const int64_t* idx_j,
+                                       const int64_t* inc_ptr, const int32_t* inc_idx, const float* phi,
+                                       const float* fcut, const float* dir, const float* Wf, const float* bf,
+                                       const int32_t* atom_list, int64_t nlist, const int32_t* dyn_nlist, int F, int R,
+                                       float* q_out, float* mu_out, hipStream_t stream);
+int geossl_painn_interaction_bwd_atoms(const float* dq_out, const float* dmu_out, const float* mu, const float* xc,
+                                       const int64_t* idx_i, const int64_t* inc_ptr, const int32_t* inc_idx,
+                                       const float* phi, const float* fcut, const float* dir, const float* Wf,
+                                       const float* bf, const int32_t* atom_list, int64_t nlist,
+                                       const int32_t* dyn_nlist, int F, int R, float* dxc, float* dmu_in, float* dWf,
+                                       float* dbf, float* workspace, int accumulate, hipStream_t stream);
+int geossl_painn_interaction_bwd_mol_skip(const float* dq_out, const float* dmu_out, const float* mu, const float* xc,
+                                          const int64_t* idx_i, const int64_t* inc_ptr, const int32_t* inc_idx,
+                                          const float* phi, const float* fcut, const float* dir, const float* Wf,
+                                          const float* bf, const int32_t* mol_ptr, int64_t B, int max_n, int64_t N, int F,
+                                          int R, float* dxc, float* dmu_in, float* dWf, float* dbf, float* workspace,
+                                          int accumulate, hipStream_t stream);
 int geossl_painn_mix_pre_fwd_dyn(const float* q, const float* mm, int64_t N, int F, float eps, float* ctx, float* dot,
                                  const int32_t* dyn_N, hipStream_t stream);
 int geossl_painn_mix_post_fwd_dyn(const float* q, const float* mu, const float* mm, const float* xx, const float* dot,

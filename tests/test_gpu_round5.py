@@ -543,3 +543,104 @@ def test_graphed_forward_is_the_eager_forward_bit_for_bit():
     with torch.no_grad():
         o2, h2 = model(uni[0].x[:, 0], uni[0].positions, uni[0].batch, return_latent=True)
     assert torch.equal(out, o2) and torch.equal(h, h2)
+
+
+def test_painn_oversized_molecules_go_to_the_per_atom_kernels_alone(monkeypatch):
+    """Molecule3D with hydrogens has molecules above the LDS rows of the molecule-staged interaction kernels (44 atoms
+    for the matrix-pipe forward, 75 for the backward).  The batch keeps those kernels for the molecules that fit; the
+    atoms of the others are covered by the per-atom kernel (geossl_painn_interaction_fwd_atoms / _bwd_atoms) - features
+    and parameter gradients against oracle.nets.painn_forward, and equal to the all-per-atom path within the summation
+    order of the matrix-pipe forward."""
+    from geossl_amd import _lib, ops
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import make_batch
+    from oracle import nets
+    from test_oracle_golden import painn_params
+    import geossl_amd.Geom3D.models.painn as pm
+    sizes = np.array([18, 50, 7, 80, 30, 46, 2, 44, 76], dtype=np.int64)
+    raw = make_batch(0, seed=55, sizes=sizes)
+    raw["x"][::7, 0] = 0
+    bt = _painn_batch(raw)
+    pos2 = bt.positions + 0.2 * torch.randn(bt.positions.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    calls = []
+    real = pm.call
+
+    def counting(name, *a):
+        calls.append(name)
+        return real(name, *a)
+
+    def run():
+        cfg, model = _painn_modules()
+        out, q = model(bt.x, pos2, bt.radius_edge_index, bt.batch, return_latent=True)
+        ((out ** 2).sum() + 0.5 * (q ** 2).sum()).backward()
+        return cfg, out.detach(), q.detach(), unique_named_grads(model)
+
+    monkeypatch.setattr(pm, "call", counting)
+    cfg, out, q, grads = run()
+    assert calls.count("geossl_painn_interaction_fwd_mma_dyn") == 3 and calls.count("geossl_painn_interaction_fwd_atoms") == 3
+    assert calls.count("geossl_painn_interaction_bwd_mol_skip") == 3 and calls.count("geossl_painn_interaction_bwd_atoms") == 3
+    monkeypatch.setattr(pm, "call", real)
+    monkeypatch.setenv("GEOSSL_PAINN_VECTOR", "1")          # vector forward: per-atom kernels for everything at 80 atoms
+    _, out_v, q_v, grads_v = run()
+    monkeypatch.delenv("GEOSSL_PAINN_VECTOR")
+    assert rel_err(q, q_v) < 5e-6 and rel_err(out, out_v) < 5e-6
+    for k in grads:
+        assert rel_err(grads[k], grads_v[k]) < 2e-5, k
+    P = painn_params(cfg)
+    o_ref, q_ref = nets.painn_forward(P, t(raw["x"]), pos2.cpu(), bt.radius_edge_index.cpu(), t(raw["batch"]), 128, 3, 5.0,
+                                      "add", return_latent=True)
+    ((o_ref ** 2).sum() + 0.5 * (q_ref ** 2).sum()).backward()
+    assert rel_err(q.cpu(), q_ref.detach()) < TOL_OUT and rel_err(out.cpu(), o_ref.detach()) < TOL_OUT
+    for k in ("filter_net.weight", "filter_net.bias", "interactions.1.interatomic_context_net.1.weight",
+              "mixing.2.mu_channel_mix.weight", "embedding.weight"):
+        assert rel_err(grads[k].cpu(), P[k].grad) < TOL_GRAD, k
+
+
+def test_painn_bucket_with_oversized_molecules_replays_bit_for_bit():
+    """The same split inside a capacity bucket: the lists of oversized molecules' atoms are device data rewritten per step
+    (two lists: above 44 atoms for the forward, above 75 for the backward).  Two set-C-like batches, one of them without
+    any molecule above 75 atoms (an empty list): one capture, replays bit-identical to the eager launches on the bucket,
+    losses equal to the plain eager step within fp32 summation order."""
+    from geossl_amd import bucket as bk
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch, molecule_sizes
+    B = 16
+    specs = [molecule_sizes(B, "C", np.random.default_rng(70 + i)) for i in range(2)]
+    specs[0][2], specs[0][9] = 90, 47
+    specs[1][:] = np.minimum(specs[1], 60)
+    specs[1][4] = 58
+    raws = [make_batch(B, seed=720 + i, sizes=s_) for i, s_ in enumerate(specs)]
+    nzs = [draw_noise(r, seed=730 + i) for i, r in enumerate(raws)]
+    bts = [_painn_batch(r) for r in raws]
+
+    def trainer(use_graph):
+        cfg, model = _painn_modules()
+        return pg.DDMTrainer(model, product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9), lr=5e-4,
+                             model_3d="painn", use_graph=use_graph)
+    tr = trainer(True)
+    losses, grads = [], []
+    for bt, nz in zip(bts, nzs):
+        losses.append(tr._graph_fwd_bwd(bt, {k: t(v, DEV) for k, v in nz.items()}).clone())
+        grads.append(tr.flat.grad.clone())
+    assert tr.step_graphs.captures == 1
+    bkt = next(iter(tr._graphs.values()))["bucket"]
+    assert bkt.max_n == 128 and bkt.big_caps == (44, 75) and int(bkt.el.status) == 0
+    te = trainer(False)
+    eb = bk.Bucket(torch.device(DEV), B, bkt.caps(), "combination", max_n=bkt.max_n, kind="painn", E_cap=bkt.E_cap)
+    f32 = dict(dtype=torch.float32, device=DEV)
+    sn = {"pos_noise": torch.zeros(eb.N_cap, 3, **f32), "dist_noise_1": torch.zeros(eb.S_cap, 1, **f32),
+          "dist_noise_2": torch.zeros(eb.S_cap, 1, **f32), "noise_level_1": torch.zeros(B, dtype=torch.long, device=DEV),
+          "noise_level_2": torch.zeros(B, dtype=torch.long, device=DEV)}
+    tp = trainer(False)
+    for i, (bt, nz) in enumerate(zip(bts, nzs)):
+        N, P, S, W = eb.fill(bt)
+        sn["pos_noise"][:N].copy_(t(nz["pos_noise"], DEV))
+        sn["dist_noise_1"][:S].copy_(t(nz["dist_noise_1"], DEV))
+        sn["dist_noise_2"][:S].copy_(t(nz["dist_noise_2"], DEV))
+        sn["noise_level_1"].copy_(t(nz["noise_level_1"], DEV))
+        sn["noise_level_2"].copy_(t(nz["noise_level_2"], DEV))
+        loss = te._fwd_bwd(eb.batch, sn)
+        assert torch.equal(loss, losses[i]) and torch.equal(te.flat.grad, grads[i]), i
+        plain = tp._fwd_bwd(bt, {k: t(v, DEV) for k, v in nz.items()})
+        assert abs(float(plain) - float(losses[i])) <= 2e-6 * abs(float(plain)), i
+        assert rel_err(tp.flat.grad, grads[i]) < 1e-5, i
