@@ -263,12 +263,16 @@ class _PaiNNCore(torch.autograd.Function):
         lay = cfg["lay"]
         lib = _lib.load()
         use_mma = bool(cfg["mma"]) and E > 0
-        big_f = None
+        big_f, stage_f = None, lay.max_n      # the atoms left to the per-atom kernel; the molecule size the LDS rows are for
         if use_mma:
-            cap_f = int(lib.geossl_painn_stage_cap(0, F_, R))
-            if lay.max_n > cap_f:
-                big_f = lay.big_atoms(cap_f) if cap_f > 0 else None
-                use_mma = big_f is not None
+            from ...layout import painn_stage_caps
+            hard, split_cap = int(lib.geossl_painn_stage_cap(0, F_, R)), painn_stage_caps(F_, R)[0]
+            if 0 < split_cap < lay.max_n:
+                big_f = lay.big_atoms(split_cap)
+                if big_f is not None:
+                    stage_f = split_cap
+            if big_f is None and lay.max_n > hard:
+                use_mma = False
         for l in range(L):
             c0w, c0b, c1w, c1b = inter[l]
             k0 = NB * l
@@ -290,8 +294,8 @@ class _PaiNNCore(torch.autograd.Function):
                 row_edge, grp_atom, _, mol_grp = el.groups("i", lay.mol_ptr)
                 call("geossl_painn_interaction_fwd_mma_dyn", ptr(q), ptr(mu), ptr(xc), ptr(el.idx_j), ptr(row_edge),
                      ptr(grp_atom), ptr(mol_grp), ptr(phi), ptr(fcut), ptr(dirv), ptr(fw[l * 3 * F_:(l + 1) * 3 * F_]),
-                     ptr(fb[l * 3 * F_:(l + 1) * 3 * F_]), ptr(lay.mol_ptr), lay.B, lay.max_n, N, F_, R, ptr(q2), ptr(mu2),
-                     ptr(getattr(el, "mol_grp_end", None)), st)                 # :54-64
+                     ptr(fb[l * 3 * F_:(l + 1) * 3 * F_]), ptr(lay.mol_ptr), lay.B, stage_f, N, F_, R, ptr(q2),
+                     ptr(mu2), ptr(getattr(el, "mol_grp_end", None)), st)                 # :54-64
                 if big_f is not None and big_f[1] > 0:   # the atoms of the molecules above the staged rows
                     call("geossl_painn_interaction_fwd_atoms", ptr(q), ptr(mu), ptr(xc), ptr(el.idx_j), ptr(inc_ptr),
                          ptr(inc_idx), ptr(phi), ptr(fcut), ptr(dirv), ptr(fw[l * 3 * F_:(l + 1) * 3 * F_]),
@@ -425,7 +429,8 @@ class _PaiNNCore(torch.autograd.Function):
         nfl = _lib.load().geossl_painn_interaction_bwd_mol_workspace_floats(N, lay.B, F_, R)
         ws = torch.empty(max(int(nfl), 1), **f32)
         # molecules above the LDS rows of the molecule-staged backward: skipped there, covered by the per-atom kernel
-        cap_b = int(_lib.load().geossl_painn_stage_cap(2, F_, R))
+        from ...layout import painn_stage_caps
+        cap_b = painn_stage_caps(F_, R)[1]
         big_b = lay.big_atoms(cap_b) if (0 < cap_b < lay.max_n and F_ in (64, 128)) else None
         keep = []
         E = el.E

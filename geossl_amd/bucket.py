@@ -98,7 +98,8 @@ def max_n_class(hi, prev=None, model_3d="schnet"):
     # above the sizes whose class selects a faster kernel form (the register aggregation / flat geometry / ragged loop of
     # SchNet, the matrix-pipe interaction of PaiNN) the class only sizes LDS arrays: a quarter of head room there, so that
     # the next batch's largest molecule does not cost another capture
-    want = hi if hi <= exact else int(np.ceil(1.25 * hi))
+    import os
+    want = hi if (hi <= exact or os.environ.get("GEOSSL_BUCKET_NO_HEADROOM")) else int(np.ceil(1.25 * hi))
     for c in classes:
         if want <= c and (prev is None or c >= prev):
             return c
@@ -315,9 +316,8 @@ class Bucket:
         # PaiNN, molecules above the stage caps of the molecule-staged interaction kernels: their atoms (two lists)
         self.big_caps = ()
         if kind == "painn" and self.max_n > 0:
-            lib = _lib.load()
-            self.big_caps = tuple(c for c in (int(lib.geossl_painn_stage_cap(0, 128, 20)), int(lib.geossl_painn_stage_cap(2, 128, 20)))
-                                  if 0 < c < self.max_n)
+            from .layout import painn_stage_caps
+            self.big_caps = tuple(c for c in painn_stage_caps(128, 20) if 0 < c < self.max_n)
         o["big1"] = o["big0"] + (2 * Nc if len(self.big_caps) > 0 else 0)
         self.words = o["big1"] + (2 * Nc if len(self.big_caps) > 1 else 0)
         self.off = o

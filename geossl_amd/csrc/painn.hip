@@ -564,6 +564,7 @@ extern "C" int geossl_silu_bwd(const float* u, const float* dy, int64_t n, float
   return 0;
 }
 
+#define GEOSSL_PAINN_LIST_BLOCKS 256  // blocks of a launch over an atom LIST (striding over it)
 #define GEOSSL_PAINN_DISPATCH_R(KERNEL, ...)                                   \
   do {                                                                         \
     if (R == 20) hipLaunchKernelGGL((KERNEL<20>), __VA_ARGS__);                \
@@ -594,7 +595,7 @@ extern "C" int geossl_painn_interaction_fwd_atoms(const float* q, const float* m
                                                   int R, float* q_out, float* mu_out, hipStream_t stream) {
   if (nlist <= 0) return 0;
   if (F > 128 || atom_list == nullptr) return (int)hipErrorInvalidValue;
-  const unsigned nb = (unsigned)(nlist < 2048 ? nlist : 2048);
+  const unsigned nb = (unsigned)(nlist < 2 * GEOSSL_PAINN_LIST_BLOCKS ? nlist : 2 * GEOSSL_PAINN_LIST_BLOCKS);
   GEOSSL_PAINN_DISPATCH_R(k_painn_interaction_fwd, dim3(nb), dim3(F > 64 ? 128 : 64), 0, stream, q, mu, xc, idx_j, inc_ptr,
                           inc_idx, phi, fcut, dir, Wf, bf, (int)nlist, F, q_out, mu_out, atom_list, dyn_nlist);
   GEOSSL_CHECK_LAUNCH();
@@ -615,7 +616,10 @@ static int painn_interaction_bwd_launch(const float* dq_out, const float* dmu_ou
                                         const int32_t* atom_list, const int32_t* dyn_nlist, hipStream_t stream) {
   if (N <= 0) return 0;
   if (F > 128) return (int)hipErrorInvalidValue;
-  const int nb = (int)(N < GEOSSL_PAINN_BWD_BLOCKS ? N : GEOSSL_PAINN_BWD_BLOCKS);
+  // (a list of atoms - the few oversized molecules of a batch - on few blocks: every block loads its filter rows and
+  // leaves a 31 KB partial whether it finds an atom or not; 1536 such blocks cost more than the molecules they cover)
+  const int cap_blocks = atom_list != nullptr ? GEOSSL_PAINN_LIST_BLOCKS : GEOSSL_PAINN_BWD_BLOCKS;
+  const int nb = (int)(N < cap_blocks ? N : cap_blocks);
   float* pw = workspace;
   float* pb = workspace + (size_t)nb * 3 * F * R;
   GEOSSL_PAINN_DISPATCH_R(k_painn_interaction_bwd, dim3(nb), dim3(F > 64 ? 128 : 64), 0, stream, dq_out, dmu_out, mu, xc,
@@ -672,6 +676,9 @@ extern "C" int geossl_painn_interaction_fwd_mol(const float* q, const float* mu,
                                         stream);
   const size_t estage = (size_t)(4 * F / 64) * ECHUNK * (((R + 5 + 3) / 4) * 4);  // per-wave edge stages (floats)
   const size_t lds = ((size_t)max_n * 6 * F + estage) * sizeof(float);
+  if (lds > 160 * 1024)  // (rows + edge stages above the LDS: the per-atom form)
+    return geossl_painn_interaction_fwd(q, mu, xc, idx_j, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, N, F, R, q_out, mu_out,
+                                        stream);
   // persistent blocks (the filter rows of a thread are fetched once per block): as many as fit the chip
   const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
   const int nb = (int)(B < 256 * per_cu ? B : 256 * per_cu);
@@ -700,9 +707,16 @@ extern "C" int64_t geossl_painn_interaction_bwd_mol_workspace_floats(int64_t N, 
 // whole batch to the per-atom kernels.
 extern "C" int geossl_painn_stage_cap(int kind, int F, int R) {
   if (F != 64 && F != 128) return 0;
+  if (kind != 0 && getenv("GEOSSL_PAINN_PER_ATOM") != nullptr) return 0;  // (A/B runs: the vector kernels per atom only)
   if (kind == 0) return (F == 128 && (R == 8 || R == 16 || R == 20)) ? 44 : 0;   // painn_mma_lds(44) = 157.6 KB
-  if (kind == 1) return (int)((150 * 1024) / ((size_t)6 * F * sizeof(float)));
-  if (kind == 2) return R == 32 ? 0 : (int)((150 * 1024) / ((size_t)4 * F * sizeof(float)));
+  // vector kernels: the molecule's rows (6 F floats per atom forward, 4 F backward) + the per-wave edge stages in 160 KB,
+  // and never more than painn_mol_ok admits
+  const size_t estage = (size_t)(4 * F / 64) * ECHUNK * (((R + 5 + 3) / 4) * 4) * sizeof(float);
+  const size_t per_atom = (size_t)(kind == 1 ? 6 : 4) * F * sizeof(float);
+  if (kind == 1 || (kind == 2 && R != 32)) {
+    const size_t a = (160 * 1024 - estage) / per_atom, b = (150 * 1024) / per_atom;
+    return (int)(a < b ? a : b);
+  }
   return 0;
 }
 
@@ -728,6 +742,10 @@ static int painn_interaction_bwd_mol_launch(const float* dq_out, const float* dm
   const int nb = (int)(B < GEOSSL_PAINN_BWD_MOL_BLOCKS ? B : GEOSSL_PAINN_BWD_MOL_BLOCKS);
   const size_t estage = (size_t)(4 * F / 64) * ECHUNK * (((R + 5 + 3) / 4) * 4);  // per-wave edge stages (floats)
   const size_t lds = ((stage + estage) > red ? (stage + estage) : red) * sizeof(float);
+  if (lds > 160 * 1024)  // (rows + edge stages above the LDS: the per-atom form)
+    return skip_big ? (int)hipErrorInvalidValue :
+        geossl_painn_interaction_bwd(dq_out, dmu_out, mu, xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, N, F, R,
+                                     dxc, dmu_in, dWf, dbf, workspace, accumulate, stream);
   float* pw = workspace;
   float* pb = workspace + (size_t)nb * 3 * F * R;
 #define LAUNCH_BWD_MOL(RV)                                                                                          \

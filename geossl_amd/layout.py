@@ -121,6 +121,24 @@ class MolLayout:
         return self._loop_plan
 
 
+def painn_stage_caps(F=128, R=20):
+    """(forward, backward) molecule sizes up to which PaiNN's molecule-staged interaction kernels take a molecule when a
+    layout holds larger ones (the rest goes to the per-atom kernels, atom list by atom list): the LDS limits of the
+    library (geossl_painn_stage_cap); 0 = no split (one kernel form for the whole batch).  The forward's is 0 unless
+    GEOSSL_PAINN_MMA_CAP asks for one (A/B runs)."""
+    if os.environ.get("GEOSSL_PAINN_NO_SPLIT"):   # (A/B runs: one kernel form for the whole batch, the round-4 behaviour)
+        return 0, 0
+    lib = _lib.load()
+    cf, cb = int(lib.geossl_painn_stage_cap(0, F, R)), int(lib.geossl_painn_stage_cap(2, F, R))
+    # The FORWARD split is off unless asked for: measured on set C (molecules with hydrogens), the matrix-pipe forward with
+    # its LDS sized for 44-atom molecules (one block of four waves per CU) plus a per-atom pass for the rest is slower
+    # than the per-atom kernel for the whole batch (bs = 128: 2.24 against 2.09 ms per step; bs = 1024: 10.6 against 10.6)
+    # - tools/experiments/painn_forms.py.  The backward split pays (the molecule-staged backward up to 73 atoms).
+    env = os.environ.get("GEOSSL_PAINN_MMA_CAP")
+    cf = min(cf, int(env)) if env is not None else 0
+    return cf, cb
+
+
 def big_atom_list(n, cap):
     """Atom indices (int32, ascending) of the molecules with more than `cap` atoms, for molecules of sizes `n` laid out
     back to back."""

@@ -547,7 +547,7 @@ def test_graphed_forward_is_the_eager_forward_bit_for_bit():
 
 def test_painn_oversized_molecules_go_to_the_per_atom_kernels_alone(monkeypatch):
     """Molecule3D with hydrogens has molecules above the LDS rows of the molecule-staged interaction kernels (44 atoms
-    for the matrix-pipe forward, 75 for the backward).  The batch keeps those kernels for the molecules that fit; the
+    for the matrix-pipe forward, 73 for the backward).  The batch keeps those kernels for the molecules that fit; the
     atoms of the others are covered by the per-atom kernel (geossl_painn_interaction_fwd_atoms / _bwd_atoms) - features
     and parameter gradients against oracle.nets.painn_forward, and equal to the all-per-atom path within the summation
     order of the matrix-pipe forward."""
@@ -576,13 +576,24 @@ def test_painn_oversized_molecules_go_to_the_per_atom_kernels_alone(monkeypatch)
         return cfg, out.detach(), q.detach(), unique_named_grads(model)
 
     monkeypatch.setattr(pm, "call", counting)
+    # default: the backward is split (molecule-staged up to 73 atoms + the per-atom kernel over the 76- and 80-atom
+    # molecules); the forward keeps one form for the batch (the split forward measured slower: layout.painn_stage_caps)
+    cfg, out0, q0, grads0 = run()
+    assert calls.count("geossl_painn_interaction_fwd_atoms") == 0 and calls.count("geossl_painn_interaction_fwd_mma_dyn") == 0
+    assert calls.count("geossl_painn_interaction_bwd_mol_skip") == 3 and calls.count("geossl_painn_interaction_bwd_atoms") == 3
+    del calls[:]
+    monkeypatch.setenv("GEOSSL_PAINN_MMA_CAP", "44")        # ... and with the forward split as well
     cfg, out, q, grads = run()
+    monkeypatch.delenv("GEOSSL_PAINN_MMA_CAP")
     assert calls.count("geossl_painn_interaction_fwd_mma_dyn") == 3 and calls.count("geossl_painn_interaction_fwd_atoms") == 3
     assert calls.count("geossl_painn_interaction_bwd_mol_skip") == 3 and calls.count("geossl_painn_interaction_bwd_atoms") == 3
+    assert rel_err(q, q0) < 5e-6 and rel_err(out, out0) < 5e-6
+    for k in grads:
+        assert rel_err(grads[k], grads0[k]) < 2e-5, k
     monkeypatch.setattr(pm, "call", real)
-    monkeypatch.setenv("GEOSSL_PAINN_VECTOR", "1")          # vector forward: per-atom kernels for everything at 80 atoms
+    monkeypatch.setenv("GEOSSL_PAINN_NO_SPLIT", "1")        # no split at all: per-atom kernels for everything at 80 atoms
     _, out_v, q_v, grads_v = run()
-    monkeypatch.delenv("GEOSSL_PAINN_VECTOR")
+    monkeypatch.delenv("GEOSSL_PAINN_NO_SPLIT")
     assert rel_err(q, q_v) < 5e-6 and rel_err(out, out_v) < 5e-6
     for k in grads:
         assert rel_err(grads[k], grads_v[k]) < 2e-5, k
@@ -596,14 +607,17 @@ def test_painn_oversized_molecules_go_to_the_per_atom_kernels_alone(monkeypatch)
         assert rel_err(grads[k].cpu(), P[k].grad) < TOL_GRAD, k
 
 
-def test_painn_bucket_with_oversized_molecules_replays_bit_for_bit():
+@pytest.mark.parametrize("fwd_split", [False, True])
+def test_painn_bucket_with_oversized_molecules_replays_bit_for_bit(fwd_split, monkeypatch):
     """The same split inside a capacity bucket: the lists of oversized molecules' atoms are device data rewritten per step
-    (two lists: above 44 atoms for the forward, above 75 for the backward).  Two set-C-like batches, one of them without
-    any molecule above 75 atoms (an empty list): one capture, replays bit-identical to the eager launches on the bucket,
+    (two lists: above 44 atoms for the forward, above 73 for the backward).  Two set-C-like batches, one of them without
+    any molecule above 73 atoms (an empty list): one capture, replays bit-identical to the eager launches on the bucket,
     losses equal to the plain eager step within fp32 summation order."""
     from geossl_amd import bucket as bk
     from geossl_amd import pretrain_GeoSSL as pg
     from geossl_amd.synthetic import draw_noise, make_batch, molecule_sizes
+    if fwd_split:
+        monkeypatch.setenv("GEOSSL_PAINN_MMA_CAP", "44")
     B = 16
     specs = [molecule_sizes(B, "C", np.random.default_rng(70 + i)) for i in range(2)]
     specs[0][2], specs[0][9] = 90, 47
@@ -624,7 +638,7 @@ def test_painn_bucket_with_oversized_molecules_replays_bit_for_bit():
         grads.append(tr.flat.grad.clone())
     assert tr.step_graphs.captures == 1
     bkt = next(iter(tr._graphs.values()))["bucket"]
-    assert bkt.max_n == 128 and bkt.big_caps == (44, 75) and int(bkt.el.status) == 0
+    assert bkt.max_n == 128 and bkt.big_caps == ((44, 73) if fwd_split else (73,)) and int(bkt.el.status) == 0
     te = trainer(False)
     eb = bk.Bucket(torch.device(DEV), B, bkt.caps(), "combination", max_n=bkt.max_n, kind="painn", E_cap=bkt.E_cap)
     f32 = dict(dtype=torch.float32, device=DEV)
