@@ -5,15 +5,15 @@
 // object.  It is what lets a PaiNN step be a replayed graph over a shuffled loader: the captured kernels read these
 // arrays from static (capacity-sized) buffers that this launch rewrites per step (geossl_amd/bucket.py).
 //
-// One 256-thread block per molecule of the two-view batch (2B blocks; view v = block / B reads the molecule's edges of
-// the one-view list and writes them with the offsets v N / v E):
+// One 256-thread block per molecule; it writes the structures of BOTH views (view 1 = view 0 with the offsets N / E):
 //   * the molecule's edge range [e0, e1) by a 256-ary search over the edge list's first row (edges are grouped by
 //     molecule in batch order, both ends in one molecule: the collated output of the reference's dataset is);
 //   * idx_i / idx_j of the two-view batch;
 //   * the two incidence lists (edges by idx_i = row 0: the forward's scatter target, painn.py:59,61; edges by idx_j =
-//     row 1: the backward's), each atom's edges in ascending edge order (fixed summation order downstream): counts by
-//     integer LDS atomics, offsets by a block scan, the lists by one thread per atom walking the molecule's edges (keys
-//     staged in LDS);
+//     row 1: the backward's), each atom's edges in ascending edge order (fixed summation order downstream) - a stable
+//     counting sort: every wave takes a contiguous quarter of the molecule's edges, counts per (quarter, atom) by
+//     integer LDS atomics, offsets by a block scan, then each wave places its quarter 64 edges at a time, an edge's rank
+//     among the equal keys of its chunk from ballots (one round per distinct key of the chunk);
 //   * the row layout of the matrix-pipe interaction forward (painn_mma.hip): an atom's edges in incidence order padded
 //     to groups of four rows; the groups of molecule m start at floor(first edge / 4) + first atom (a bound on the
 //     groups of all molecules before it, so no scan over molecules is needed) and END at mol_grp_end[m].
@@ -26,7 +26,6 @@ using namespace geossl;
 namespace {
 
 constexpr int PL_MAXN = 256;    // atoms per molecule
-constexpr int PL_CHUNK = 4096;  // edges staged per pass (local atom indices as 16-bit keys)
 
 struct PainnLayoutArgs {
   const int64_t* src_i;   // [E] row 0 of radius_edge_index
@@ -46,57 +45,92 @@ struct PainnLayoutArgs {
   int32_t* status;        // set to 1 on an edge that leaves its molecule / a molecule above PL_MAXN atoms
 };
 
-// first e in [0, E) with src[e] >= key (src non-decreasing by molecule), by all 256 threads of the block
-__device__ __forceinline__ int block_lower_bound(const int64_t* __restrict__ src, int E, int64_t key) {
-  int lo = 0, hi = E;
-  while (lo < hi) {
-    const int len = hi - lo, step = (len + 255) / 256;
-    const int p = lo + (int)threadIdx.x * step;
-    const bool below = p < hi && src[p] < key;
-    const int c = __syncthreads_count(below ? 1 : 0);
-    if (c == 0) return lo;
-    if (step == 1) return lo + c;
-    const int nlo = lo + (c - 1) * step + 1, nhi = min(hi, lo + c * step);
-    lo = nlo;
-    hi = nhi;
+// first e in [0, E) with src[e] >= key (src non-decreasing by molecule), for TWO keys at once, by all 256 threads of the
+// block (the two searches share their rounds: the probes of a round are in flight together)
+__device__ __forceinline__ void block_lower_bound2(const int64_t* __restrict__ src, int E, int64_t key0, int64_t key1,
+                                                   int& out0, int& out1) {
+  int lo[2] = {0, 0}, hi[2] = {E, E};
+  bool done[2] = {E == 0, E == 0};
+  const int64_t key[2] = {key0, key1};
+  while (!(done[0] && done[1])) {
+    int step[2], p[2];
+    bool below[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int len = hi[q] - lo[q];
+      step[q] = (len + 255) / 256;
+      p[q] = lo[q] + (int)threadIdx.x * step[q];
+      below[q] = !done[q] && p[q] < hi[q] && src[p[q]] < key[q];
+    }
+    const int c0 = __syncthreads_count(below[0] ? 1 : 0);
+    const int c1 = __syncthreads_count(below[1] ? 1 : 0);
+    const int c[2] = {c0, c1};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (done[q]) continue;
+      if (c[q] == 0) {
+        hi[q] = lo[q];
+        done[q] = true;
+      } else if (step[q] == 1) {
+        lo[q] = hi[q] = lo[q] + c[q];
+        done[q] = true;
+      } else {
+        const int nlo = lo[q] + (c[q] - 1) * step[q] + 1, nhi = min(hi[q], lo[q] + c[q] * step[q]);
+        lo[q] = nlo;
+        hi[q] = nhi;
+        if (lo[q] >= hi[q]) done[q] = true;
+      }
+    }
   }
-  return lo;
+  out0 = lo[0];
+  out1 = lo[1];
 }
 
 __global__ __launch_bounds__(256) void k_painn_edge_layout(PainnLayoutArgs A) {
-  __shared__ int cnt_i[PL_MAXN], cnt_j[PL_MAXN];
+  __shared__ int cnt[2][4][PL_MAXN];   // [side][wave][atom]: edges of the wave's quarter; then the quarter's first list slot
   __shared__ int pre_i[PL_MAXN], pre_j[PL_MAXN], pre_g[PL_MAXN];
-  __shared__ uint16_t key_i[PL_CHUNK], key_j[PL_CHUNK];
-  const int tid = threadIdx.x;
-  const int mm = blockIdx.x, v = mm >= A.B ? 1 : 0, m = mm - v * A.B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = blockIdx.x;
   const int a0 = A.mol_ptr[m], n = A.mol_ptr[m + 1] - a0;
-  const int offN = v * A.N, offE = v * A.E;
-  const int e0 = block_lower_bound(A.src_i, A.E, (int64_t)a0);
-  const int e1 = block_lower_bound(A.src_i, A.E, (int64_t)a0 + n);
+  int e0, e1;
+  block_lower_bound2(A.src_i, A.E, (int64_t)a0, (int64_t)a0 + n, e0, e1);
   const bool too_big = n > PL_MAXN;
   if (too_big && tid == 0) *A.status = 1;
   const int nn = too_big ? 0 : n;  // (a molecule above the limit gets empty lists; the status word reports it)
-  cnt_i[tid] = 0;
-  cnt_j[tid] = 0;
+  const int N = A.N, E = A.E;
+  for (int i = tid; i < 2 * 4 * PL_MAXN; i += 256) (&cnt[0][0][0])[i] = 0;
   __syncthreads();
-  // ---- two-view edge arrays + per-atom counts
+  // the wave's quarter of the molecule's edges
+  const int Em = e1 - e0, Q = (Em + 3) >> 2;
+  const int q0 = e0 + min(Em, wave * Q), q1 = e0 + min(Em, (wave + 1) * Q);
+  // ---- pass 1: two-view edge arrays + counts per (quarter, atom)
   int bad = 0;
-  for (int e = e0 + tid; e < e1; e += 256) {
+  for (int e = q0 + lane; e < q1; e += 64) {
     const int64_t gi = A.src_i[e], gj = A.src_j[e];
-    A.idx_i2[(size_t)offE + e] = gi + offN;
-    A.idx_j2[(size_t)offE + e] = gj + offN;
+    A.idx_i2[e] = gi;
+    A.idx_j2[e] = gj;
+    A.idx_i2[(size_t)E + e] = gi + N;
+    A.idx_j2[(size_t)E + e] = gj + N;
     const int li = (int)(gi - a0), lj = (int)(gj - a0);
     if (li < 0 || li >= nn || lj < 0 || lj >= nn) {
       bad = 1;
     } else {
-      atomicAdd(&cnt_i[li], 1);
-      atomicAdd(&cnt_j[lj], 1);
+      atomicAdd(&cnt[0][wave][li], 1);
+      atomicAdd(&cnt[1][wave][lj], 1);
     }
   }
   if (bad) *A.status = 1;
   __syncthreads();
-  // ---- exclusive prefixes over the molecule's atoms: edges by idx_i, by idx_j, groups of four rows (at least one per atom)
-  const int ci = tid < nn ? cnt_i[tid] : 0, cj = tid < nn ? cnt_j[tid] : 0;
+  // ---- per atom: totals, exclusive prefixes over the molecule's atoms (edges by idx_i, by idx_j, groups of four rows -
+  // at least one per atom), and the first list slot of every quarter
+  int ci = 0, cj = 0;
+  if (tid < nn) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      ci += cnt[0][w][tid];
+      cj += cnt[1][w][tid];
+    }
+  }
   const int cg = tid < nn ? max(1, (ci + 3) >> 2) : 0;
   pre_i[tid] = ci;
   pre_j[tid] = cj;
@@ -112,54 +146,105 @@ __global__ __launch_bounds__(256) void k_painn_edge_layout(PainnLayoutArgs A) {
   }
   const int G = pre_g[255];
   const int xi = pre_i[tid] - ci, xj = pre_j[tid] - cj, xg = pre_g[tid] - cg;  // exclusive
-  const int gbase = ((offE + e0) >> 2) + offN + a0;
+  __syncthreads();
+  pre_i[tid] = xi;   // (from here on: the exclusive prefixes, read by the placement)
+  pre_g[tid] = xg;
   if (tid < nn) {
-    A.iptr_i[offN + a0 + tid] = (int64_t)offE + e0 + xi;
-    A.iptr_j[offN + a0 + tid] = (int64_t)offE + e0 + xj;
+    int si = xi, sj = xj;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {  // quarter w of atom tid starts behind the atom's edges of the quarters before it
+      const int ti = cnt[0][w][tid], tj = cnt[1][w][tid];
+      cnt[0][w][tid] = si;
+      cnt[1][w][tid] = sj;
+      si += ti;
+      sj += tj;
+    }
+    A.iptr_i[a0 + tid] = (int64_t)e0 + xi;
+    A.iptr_j[a0 + tid] = (int64_t)e0 + xj;
+    A.iptr_i[N + a0 + tid] = (int64_t)E + e0 + xi;
+    A.iptr_j[N + a0 + tid] = (int64_t)E + e0 + xj;
   }
+  const int gbase0 = (e0 >> 2) + a0, gbase1 = ((E + e0) >> 2) + N + a0;
   if (tid == 0) {
-    A.mol_grp[mm] = gbase;
-    A.mol_grp_end[mm] = gbase + G;
+    A.mol_grp[m] = gbase0;
+    A.mol_grp_end[m] = gbase0 + G;
+    A.mol_grp[A.B + m] = gbase1;
+    A.mol_grp_end[A.B + m] = gbase1 + G;
   }
-  if (mm == 2 * A.B - 1) {  // the last molecule: the lists end here; atoms past the real count (a capacity) have none
-    const int N2 = 2 * A.N;
+  if (m == A.B - 1) {  // the last molecule: the lists end here; atoms past the real count (a capacity) have none
+    const int N2 = 2 * N;
     for (int a = N2 + tid; a <= A.N2cap; a += 256) {
-      A.iptr_i[a] = 2 * (int64_t)A.E;
-      A.iptr_j[a] = 2 * (int64_t)A.E;
+      A.iptr_i[a] = 2 * (int64_t)E;
+      A.iptr_j[a] = 2 * (int64_t)E;
     }
-    if (tid == 0) A.mol_grp[2 * A.B] = ((2 * A.E) >> 2) + N2;
+    if (tid == 0) A.mol_grp[2 * A.B] = ((2 * E) >> 2) + N2;
   }
-  // ---- the lists: thread a walks the molecule's edges in ascending order (keys from LDS, a chunk at a time)
-  int pi = 0, pj = 0;  // entries written so far
-  int32_t* rows = A.row_edge + 4 * ((size_t)gbase + xg);  // this atom's rows of the group layout
-  for (int c0 = e0; c0 < e1; c0 += PL_CHUNK) {
-    const int len = min(PL_CHUNK, e1 - c0);
-    __syncthreads();
-    for (int k = tid; k < len; k += 256) {
-      const int li = (int)(A.src_i[c0 + k] - a0), lj = (int)(A.src_j[c0 + k] - a0);
-      const bool ok = li >= 0 && li < nn && lj >= 0 && lj < nn;
-      key_i[k] = ok ? (uint16_t)li : (uint16_t)0xFFFF;
-      key_j[k] = ok ? (uint16_t)lj : (uint16_t)0xFFFF;
+  __syncthreads();
+  // ---- pass 2: placement, a wave's quarter 64 edges at a time in ascending edge order.  An edge's slot in its atom's
+  // list = (first slot of the wave's quarter for that atom, advanced chunk by chunk) + its rank among the chunk's edges
+  // with the same key: one round per distinct key of the chunk (ballot of the lanes that hold it).
+  volatile int* run_i = cnt[0][wave];
+  volatile int* run_j = cnt[1][wave];
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int c0 = q0; c0 < q1; c0 += 64) {
+    const int e = c0 + lane;
+    const bool in = e < q1;
+    int li = -1, lj = -1;
+    if (in) {
+      li = (int)(A.src_i[e] - a0);
+      lj = (int)(A.src_j[e] - a0);
+      if (li < 0 || li >= nn || lj < 0 || lj >= nn) li = lj = -1;
     }
-    __syncthreads();
-    if (tid < nn) {
-      for (int k = 0; k < len; ++k) {
-        const int e = offE + c0 + k;
-        if (key_i[k] == tid) {
-          A.ilist_i[(size_t)offE + e0 + xi + pi] = e;
-          rows[pi] = e;
-          ++pi;
+    // rank of an edge among the chunk's edges with the same key + their number: one round of ballots per distinct key
+    // (no memory access inside the rounds: a key's first free slot is read before them, advanced after them)
+    auto ranks = [&](int key, int& rank, int& total) {
+      unsigned long long rem = __ballot(key >= 0);
+      rank = 0;
+      total = 0;
+      while (rem) {
+        const int leader = __builtin_ctzll(rem);
+        const int k = __builtin_amdgcn_readlane(key, leader);
+        const unsigned long long mk = __ballot(key == k);
+        if (key == k) {
+          rank = __popcll(mk & lt);
+          total = __popcll(mk);
         }
-        if (key_j[k] == tid) {
-          A.ilist_j[(size_t)offE + e0 + xj + pj] = e;
-          ++pj;
-        }
+        rem &= ~mk;
       }
+    };
+    int ri, ti, rj, tj;
+    const int bi = li >= 0 ? run_i[li] : 0, bj = lj >= 0 ? run_j[lj] : 0;   // first free slots (relative to e0)
+    ranks(li, ri, ti);
+    ranks(lj, rj, tj);
+    if (li >= 0) {   // side i: the forward's lists and the group rows
+      const int slot = bi + ri;
+      A.ilist_i[(size_t)e0 + slot] = e;
+      A.ilist_i[(size_t)E + e0 + slot] = E + e;
+      const int r = slot - pre_i[li];                          // row of the atom's group layout
+      A.row_edge[4 * ((size_t)gbase0 + pre_g[li]) + r] = e;
+      A.row_edge[4 * ((size_t)gbase1 + pre_g[li]) + r] = E + e;
+      if (ri == ti - 1) run_i[li] = bi + ti;                   // (the key's last edge of the chunk advances its slot)
+    }
+    if (lj >= 0) {   // side j: the backward's lists
+      const int slot = bj + rj;
+      A.ilist_j[(size_t)e0 + slot] = e;
+      A.ilist_j[(size_t)E + e0 + slot] = E + e;
+      if (rj == tj - 1) run_j[lj] = bj + tj;
     }
   }
+  // ---- padding rows of every atom's last group, group codes (both views)
   if (tid < nn) {
-    for (int r = ci; r < 4 * cg; ++r) rows[r] = -1;  // padding rows of the atom's last group
-    for (int g = 0; g < cg; ++g) A.grp_atom[gbase + xg + g] = 2 * (offN + a0 + tid) + (g == cg - 1 ? 1 : 0);
+    int32_t* rows0 = A.row_edge + 4 * ((size_t)gbase0 + xg);
+    int32_t* rows1 = A.row_edge + 4 * ((size_t)gbase1 + xg);
+    for (int r = ci; r < 4 * cg; ++r) {
+      rows0[r] = -1;
+      rows1[r] = -1;
+    }
+    for (int g = 0; g < cg; ++g) {
+      const int last = g == cg - 1 ? 1 : 0;
+      A.grp_atom[gbase0 + xg + g] = 2 * (a0 + tid) + last;
+      A.grp_atom[gbase1 + xg + g] = 2 * (N + a0 + tid) + last;
+    }
   }
 }
 
@@ -178,7 +263,7 @@ extern "C" int geossl_painn_edge_layout(const int64_t* src_i, const int64_t* src
   A.src_i = src_i; A.src_j = src_j; A.mol_ptr = mol_ptr; A.E = (int)E; A.N = (int)N; A.B = (int)B; A.N2cap = (int)N2cap;
   A.idx_i2 = idx_i2; A.idx_j2 = idx_j2; A.iptr_i = iptr_i; A.ilist_i = ilist_i; A.iptr_j = iptr_j; A.ilist_j = ilist_j;
   A.row_edge = row_edge; A.grp_atom = grp_atom; A.mol_grp = mol_grp; A.mol_grp_end = mol_grp_end; A.status = status;
-  hipLaunchKernelGGL(k_painn_edge_layout, dim3((unsigned)(2 * B)), dim3(256), 0, stream, A);
+  hipLaunchKernelGGL(k_painn_edge_layout, dim3((unsigned)B), dim3(256), 0, stream, A);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
