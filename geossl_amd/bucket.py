@@ -152,7 +152,8 @@ def tensors_ok(batch):
     give (an int32 x, or a super_edge_index altered after the extractor marked it canonical, would make the copy read past
     the source).  Checked once per (batch object, tensor versions)."""
     x, pos, bv, sei = batch.x, batch.positions, batch.batch, batch.super_edge_index
-    tag = tuple((id(t_), t_._version) for t_ in (x, pos, bv, sei))
+    from .pretrain_GeoSSL import _tensor_uid   # (lifetime-unique stamps: id() of a freed tensor is handed out again)
+    tag = tuple((_tensor_uid(t_), t_._version) for t_ in (x, pos, bv, sei))
     got = batch.__dict__.get("_geossl_tensors_ok")
     if got is not None and got[0] == tag:
         return got[1]
@@ -262,7 +263,7 @@ def host_plan(sizes, option):
     """Everything of a batch's index structures that is a function of the molecule sizes alone, as numpy arrays - the part
     of a bucket fill that runs on the host (and is tested without a GPU): counts (N, P, S, W); mol_ptr / pair_ptr of the
     TWO-VIEW batch ([2B + 1], view 1 behind view 0); se_ptr [B + 1]; the aggregation's work list over the 2B molecules
-    (largest first, stable; 27 .. 33-atom molecules as 2 or 4 items: molecule | part << 28); the divisor of NCSN.py:210-212
+    (largest first, stable; 27 .. 33-atom molecules as 2 or 4 items, larger ones one item per atom: molecule | part << 24); the divisor of NCSN.py:210-212
     (last molecule with a super-edge, + 1); inc_ptr [N + 1] (an atom of an n-atom molecule lies on n - 1 tuples of the
     "combination" enumeration, 2 (n - 1) of "permutation")."""
     global _PARTS
@@ -287,7 +288,7 @@ def host_plan(sizes, option):
     ip = np.zeros(N + 1, dtype=np.int64)
     np.cumsum(np.repeat((n - 1) * mult, n), out=ip[1:])
     return dict(counts=(N, P, S, W), mol_ptr2=np.concatenate([mp, mp[1:] + N]), pair_ptr2=np.concatenate([pp, pp[1:] + P]),
-                se_ptr=pp * mult, work=(mol | (part << 28)).astype(np.uint32).view(np.int32),
+                se_ptr=pp * mult, work=(mol | (part << 24)).astype(np.uint32).view(np.int32),
                 divisor=int(has[-1]) + 1 if has.size else 0, inc_ptr=ip)
 
 
@@ -362,7 +363,11 @@ class Bucket:
             el.grp_atom = torch.full((G,), -1, **i32)
             el.mol_grp = torch.zeros(2 * B + 1, **i32)
             el.mol_grp_end = torch.zeros(2 * B, **i32)
-            el.status = torch.zeros(1, **i32)
+            # set by geossl_painn_edge_layout on an edge that leaves its molecule (the reference's collated
+            # radius_edge_index never has one); read without draining the stream, a few steps late (_lib.StatusWord)
+            self.el_status = _lib.StatusWord(device, "radius_edge_index must be grouped by molecule in batch order with both "
+                                             "ends in the same molecule (collated MoleculeDataset3DRadius output is)")
+            el.status = self.el_status.word
             el.dyn = self.dyn
             self.el = el
             self.e2 = torch.zeros(2, 1, **i64)   # placeholder for PaiNN.forward's radius_edge_index argument
@@ -453,10 +458,15 @@ class Bucket:
             call("geossl_pair_index_fill", ptr(lay.mol_ptr), ptr(lay.pair_ptr), 2 * B, ptr(lay.pair_i), ptr(lay.pair_j), st_)
         else:
             el = self.el
+            try:
+                self.el_status.poll()
+            except IndexError as e:
+                raise ValueError(str(e)) from None
             call("geossl_painn_edge_layout", ptr(rei[0]), ptr(rei[1]), E, ptr(lay.mol_ptr), N, B, 2 * self.N_cap,
                  ptr(el.idx_i), ptr(el.idx_j), ptr(el.inc["i"][0]), ptr(el.inc["i"][1]), ptr(el.inc["j"][0]),
                  ptr(el.inc["j"][1]), ptr(el.row_edge), ptr(el.grp_atom), ptr(el.mol_grp), ptr(el.mol_grp_end),
                  ptr(el.status), st_)
+            self.el_status.arm(every=8)
         sel = self.sel
         call("geossl_incidence_fill", ptr(sel.batch), ptr(sel.sei0), ptr(sel.sei1), ptr(sel.se_ptr), N, 3,
              ptr(sel.inc_ptr), ptr(sel.inc_idx), st_)

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64, 2) void k_aggregate_reg_ragged(
 #undef AGG_CLASS
 }
 
-// ragged batches with a host-built work list (layout.py: MolLayout.agg_work): entry = molecule | part << 28, largest
+// ragged batches with a host-built work list (layout.py: MolLayout.agg_work): entry = molecule | part << 24, largest
 // molecules first.  Molecules of fewer than AGG_K2_MIN atoms are one work item (from 21 atoms on with a deep ring of
 // filter-row requests: the walk of a large molecule is a chain of memory round trips), AGG_K2_MIN .. AGG_K4_MIN-1 atoms
 // two target groups, more atoms four (geossl_aggregate_parts gives the same mapping to the host).
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64, 2) void k_aggregate_reg_ragged(
 #ifndef AGG_RING_BIG
 #define AGG_RING_BIG 40
 #endif
-#define AGG_KBIG 16   // work items of a molecule above 33 atoms (the part field of a work word has four bits)
+// (a molecule above 33 atoms: one work item per atom - the part field of a work word has eight bits)
 // a size class above 20 atoms (molecules of LO .. NM atoms): whole, two or four target groups, by the molecule's size;
 // only the forms a class can meet are instantiated
 template <int NM>
@@ -274,14 +274,13 @@ __global__ __launch_bounds__(64, 2) void k_aggregate_reg_work(
     int nwork, int F, int swap, float* __restrict__ out, const int32_t* __restrict__ dyn_nwork) {
   if ((int)blockIdx.x >= dyn_count(nwork, dyn_nwork)) return;
   const int wk = work[blockIdx.x];
-  const int m = wk & 0x0FFFFFFF, part = __builtin_amdgcn_readfirstlane((wk >> 28) & 15);
+  const int m = wk & 0x00FFFFFF, part = __builtin_amdgcn_readfirstlane((wk >> 24) & 255);
   const int lane = threadIdx.x, f = 2 * lane < F ? 2 * lane : -2;  // -2: no channels (see k_aggregate_reg)
   const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m];
   const int nu = __builtin_amdgcn_readfirstlane(n);
-  if (nu > 33) {  // above the size classes: AGG_KBIG target groups, each a list of targets (aggregate_targets)
-    aggregate_targets(x, Wf, pair_flag, a0, n, base, lane, f, F, swap, out, (part * nu) / AGG_KBIG,
-                      ((part + 1) * nu) / AGG_KBIG);
-    return;
+  if (nu > 33) {  // above the size classes: one work item per TARGET atom (aggregate_targets): a target's sum is a chain
+    aggregate_targets(x, Wf, pair_flag, a0, n, base, lane, f, F, swap, out, part, part + 1);  // of memory round trips (32
+    return;                                                                                  // partners each) - kept short
   }
   const int kparts = nu < AGG_K2_MIN ? 1 : (nu < AGG_K4_MIN ? 2 : 4);
 #define AGG_CLASS(NM) if (nu <= NM) { aggregate_reg_body<NM>(x, Wf, pair_flag, a0, n, base, lane, f, F, swap, out); return; }
@@ -539,7 +538,7 @@ extern "C" int geossl_pair_product(const float* a, const float* b, const int32_t
 }
 
 extern "C" int geossl_aggregate_parts(int n) {  // work items of an n-atom molecule in geossl_cfconv_aggregate_work
-  if (n > 33) return AGG_KBIG;
+  if (n > 33) return n < 256 ? n : 255;
   if (n < AGG_K2_MIN) return 1;
   return n < AGG_K4_MIN ? 2 : 4;
 }

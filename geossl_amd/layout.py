@@ -71,7 +71,7 @@ class MolLayout:
         # by descending size, the 21..33-atom ones as 2 or 4 work items (one group of target atoms each)
         # (molecules above 33 atoms - Molecule3D with hydrogens - as 16 items each: lists of target atoms, no size class)
         self.agg_work = None
-        if sizes is not None and 20 < self.max_n <= 255 and B < (1 << 28) and not os.environ.get("GEOSSL_AGG_NO_SPLIT"):
+        if sizes is not None and 20 < self.max_n <= 255 and B < (1 << 24) and not os.environ.get("GEOSSL_AGG_NO_SPLIT"):
             self.agg_work = torch.from_numpy(aggregate_work_list(np.asarray(sizes, dtype=np.int64))).to(dev)
         self.device = dev
         self._batch_version = batch._version
@@ -165,13 +165,13 @@ def parts_table():
 
 def aggregate_work_list(n):
     """Work list of geossl_cfconv_aggregate_work for molecules of `n` atoms (int64 array): molecules by descending size
-    (stable), each as geossl_aggregate_parts(size) items molecule | part << 28, as int32 words."""
+    (stable), each as geossl_aggregate_parts(size) items molecule | part << 24, as int32 words."""
     idx = np.argsort(-n, kind="stable")
     parts = parts_table()[n][idx]
     mol = np.repeat(idx, parts)
     ends = np.cumsum(parts)
     part = np.arange(int(ends[-1]) if len(ends) else 0, dtype=np.int64) - np.repeat(ends - parts, parts)
-    return (mol | (part << 28)).astype(np.uint32).view(np.int32)
+    return (mol | (part << 24)).astype(np.uint32).view(np.int32)
 
 
 def loop_block_plan(sizes, max_rows=96, max_mols=None, slots=512):

@@ -150,11 +150,11 @@ int geossl_pair_position_grad(const float* pos, const float* pair_d, const float
 int geossl_cfconv_aggregate(const float* x, const float* Wf, const uint8_t* pair_flag, const int32_t* mol_ptr,
                             const int32_t* pair_ptr, const int32_t* order, int64_t B, int max_n, int F, int swap,
                             float* out, hipStream_t stream);
-/* The same aggregation from a host-built work list (ragged batches): work[i] = molecule | part << 28 (molecule < 2^28,
- * part 0 .. 15), in launch order (largest molecules first).  A molecule of n atoms has geossl_aggregate_parts(n) entries
- * (1, 2 or 4 up to 33 atoms: the 27..33-atom molecules are shared by that many waves, one group of target atoms each; 16
- * above 33 atoms - Molecule3D with hydrogens, datasets_Molecule3D.py:65 - where a wave sums a list of target atoms
- * without a size class) - every sum is still formed by one wave in the order of geossl_cfconv_aggregate, bit for bit.
+/* The same aggregation from a host-built work list (ragged batches): work[i] = molecule | part << 24 (molecule < 2^24,
+ * part 0 .. 254), in launch order (largest molecules first).  A molecule of n atoms has geossl_aggregate_parts(n) entries
+ * (1, 2 or 4 up to 33 atoms: the 27..33-atom molecules are shared by that many waves, one group of target atoms each; n
+ * above 33 atoms - Molecule3D with hydrogens, datasets_Molecule3D.py:65 - where a wave sums ONE target atom without a
+ * size class) - every sum is still formed by one wave in the order of geossl_cfconv_aggregate, bit for bit.
  * max_n <= 255, 32 < F <= 128.                                                                                      */
 int geossl_aggregate_parts(int n);
 int geossl_cfconv_aggregate_work(const float* x, const float* Wf, const uint8_t* pair_flag, const int32_t* mol_ptr,

@@ -674,7 +674,7 @@ def test_aggregate_work_list_splits_large_molecules_bit_exact(F, monkeypatch):
     parts = [_lib.load().geossl_aggregate_parts(int(n)) for n in sizes]
     assert lay.agg_work is not None and lay.agg_work.numel() == sum(parts) and max(parts) == 4 and 2 in parts
     wk = lay.agg_work.cpu().numpy()
-    assert sorted((wk & 0x0FFFFFFF).tolist()) == sorted(m for m, k in enumerate(parts) for _ in range(k))
+    assert sorted((wk & 0x00FFFFFF).tolist()) == sorted(m for m, k in enumerate(parts) for _ in range(k))
     g = torch.Generator(device=DEV).manual_seed(5)
     x = torch.randn(lay.N, F, device=DEV, generator=g)
     W = torch.randn(lay.P, F, device=DEV, generator=g)

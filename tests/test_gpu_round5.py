@@ -229,7 +229,7 @@ def _sequential_index_add(xn, Wn, fn, pi, pj, swap):
 @pytest.mark.parametrize("sizes,lds_form", [([34, 18, 64, 1, 100, 33, 2, 47], True), ([255, 40, 3], False)],
                          ids=["upto100", "255"])
 def test_aggregation_work_list_above_the_size_classes_is_the_sequential_index_add(sizes, lds_form):
-    """Molecules of 34 .. 255 atoms go through the work list as 16 lists of target atoms each (aggregate_targets: no size
+    """Molecules of 34 .. 255 atoms go through the work list as one work item per target atom (aggregate_targets: no size
     class, partners 32 at a time): bit for bit the sequential index_add over the canonical edge list (schnet.py:190,
     194-195), for the graph and its transpose, with asymmetric flags (what the 32-neighbour cap produces); and the LDS
     form of geossl_cfconv_aggregate (molecules whose rows fit the LDS) gives the same bits."""
@@ -239,7 +239,7 @@ def test_aggregation_work_list_above_the_size_classes_is_the_sequential_index_ad
     F = 128
     batch = torch.arange(len(sizes), device=DEV).repeat_interleave(torch.tensor(sizes, device=DEV))
     lay = MolLayout(batch, len(sizes), sizes=sizes)
-    parts = lambda n: 16 if n > 33 else (4 if n >= 31 else (2 if n >= 27 else 1))
+    parts = lambda n: n if n > 33 else (4 if n >= 31 else (2 if n >= 27 else 1))
     assert lay.agg_work is not None and lay.agg_work.numel() == sum(parts(n) for n in sizes)
     g = torch.Generator(device=DEV).manual_seed(7)
     x = torch.randn(lay.N, F, device=DEV, generator=g)
@@ -658,3 +658,24 @@ def test_painn_bucket_with_oversized_molecules_replays_bit_for_bit(fwd_split, mo
         plain = tp._fwd_bwd(bt, {k: t(v, DEV) for k, v in nz.items()})
         assert abs(float(plain) - float(losses[i])) <= 2e-6 * abs(float(plain)), i
         assert rel_err(tp.flat.grad, grads[i]) < 1e-5, i
+
+
+def test_painn_bucket_reports_an_edge_that_leaves_its_molecule():
+    """A radius_edge_index whose edges are not grouped by molecule (never produced by the reference's dataset) makes the
+    eager path raise at once (layout.EdgeLayout validates); on the bucket path geossl_painn_edge_layout leaves such edges
+    out and flags them in a device word that the fill reads without draining the stream - the ValueError surfaces a few
+    steps late, not never."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import make_batch
+    raw = make_batch(0, seed=81, sizes=_ragged_sizes(12, 81))
+    bt = _painn_batch(raw)
+    bad = bt.radius_edge_index.clone()
+    bad[1, 7] = bt.positions.size(0) - 1          # the other end in the last molecule
+    bt.radius_edge_index = bad
+    cfg, model = _painn_modules()
+    tr = pg.DDMTrainer(model, product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9), lr=5e-4,
+                       model_3d="painn", use_graph=True)
+    with pytest.raises(ValueError, match="grouped by molecule"):
+        for _ in range(20):
+            tr.step(bt, None)
+            torch.cuda.synchronize()

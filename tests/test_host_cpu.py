@@ -422,7 +422,7 @@ def test_bucket_host_plan_matches_the_collated_batch():
     from geossl_amd.synthetic import make_batch
     lib = load()
     for option in ("combination", "permutation"):
-        # (trailing single atom: divisor B - 1; 34 / 60 atoms: above the size classes, 16 lists of targets each)
+        # (trailing single atom: divisor B - 1; 34 / 60 atoms: above the size classes, one work item per atom)
         sizes = np.array([5, 33, 1, 18, 27, 2, 30, 1, 60, 9, 31, 34, 20, 1], dtype=np.int64)
         b = make_batch(len(sizes), seed=3, sizes=sizes, option=option)
         hp = bk.host_plan(sizes, option)
@@ -437,7 +437,7 @@ def test_bucket_host_plan_matches_the_collated_batch():
         assert np.array_equal(np.diff(hp["se_ptr"]), np.bincount(e2g, minlength=B)) and hp["divisor"] == int(e2g.max()) + 1
         deg = np.bincount(b["super_edge_index"].reshape(-1), minlength=N)
         assert np.array_equal(np.diff(hp["inc_ptr"]), deg) and hp["inc_ptr"][0] == 0
-        mol, part = hp["work"] & 0x0FFFFFFF, (hp["work"].astype(np.int64) >> 28) & 15
+        mol, part = hp["work"] & 0x00FFFFFF, (hp["work"].astype(np.int64) >> 24) & 255
         assert len(mol) == W
         n2 = np.concatenate([sizes, sizes])
         want = sorted((m, k) for m in range(2 * B) for k in range(lib.geossl_aggregate_parts(int(n2[m]))))
