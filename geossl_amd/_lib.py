@@ -196,6 +196,7 @@ PROTOTYPES = {
     "geossl_cfconv_filter_bwd_dyn": (i32, [vp, vp, vp, vp, vp, i64, i64, P(FilterWeights), P(FilterGradIn), i32, i32, i32,
                                            vp, f32, vp, P(FilterGradOut), vp, i32, vp, vp, vp]),
     "geossl_cfconv_aggregate_work_dyn": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp]),
+    "geossl_cfconv_aggregate_targets_dyn": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp]),
     "geossl_linear_chain_dyn": (i32, [vp, i32, P(Chain), i64, i32, vp, vp]),
     "geossl_linear_wgrad_dyn": (i32, [P(TnBatch), i32, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
     "geossl_ddm_loss_fwd2_dyn": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp]),

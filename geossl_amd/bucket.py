@@ -119,10 +119,11 @@ def batch_counts(sizes, option):
     global _PARTS
     if _PARTS is None:
         _PARTS = _parts_table()
+    from .layout import aggregate_by_targets
     n = sizes if isinstance(sizes, np.ndarray) else np.asarray(sizes, dtype=np.int64)
     P = int((n * (n - 1) // 2).sum())
     S = P if option == "combination" else 2 * P
-    W = 2 * int(_PARTS[n].sum())
+    W = 2 * int(n.sum() if aggregate_by_targets(2 * len(n)) else _PARTS[n].sum())
     return int(n.sum()), P, S, W
 
 
@@ -280,7 +281,8 @@ def host_plan(sizes, option):
     np.cumsum(npair, out=pp[1:])
     n2 = np.concatenate([n, n])
     idx = np.argsort(-n2, kind="stable")
-    parts = _PARTS[n2][idx]
+    from .layout import aggregate_by_targets
+    parts = n2[idx] if aggregate_by_targets(2 * B) else _PARTS[n2][idx]
     mol = np.repeat(idx, parts)
     ends = np.cumsum(parts)
     part = np.arange(int(ends[-1]), dtype=np.int64) - np.repeat(ends - parts, parts)
@@ -348,6 +350,8 @@ class Bucket:
             lay.pair_i = torch.zeros(2 * Pc, **i32)
             lay.pair_j = torch.zeros(2 * Pc, **i32)
             lay.agg_work = self.blob[o["work"]:o["work"] + Wc]
+            from .layout import aggregate_by_targets
+            lay.agg_targets = aggregate_by_targets(2 * B)
         self.lay2 = lay
         # ---- PaiNN: edge structures of the two-view batch
         self.el = None

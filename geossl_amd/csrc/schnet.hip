@@ -291,6 +291,23 @@ __global__ __launch_bounds__(64, 2) void k_aggregate_reg_work(
 #undef AGG_CLASS_BIG
 }
 
+// SMALL batches (the reference's batch size of 128): the walks above are chains of memory round trips - 14 .. 27 of them
+// for a molecule of 18 .. 33 atoms - and a launch over a few hundred molecules lasts as long as its longest walk while
+// most of the chip idles.  Here every work item is ONE target atom (work word = molecule | target << 24): a single round
+// trip of <= 32 partner rows for the molecules of the size classes, the same fixed summation order.  Every filter row is
+// read by both of its atoms (twice the bytes): this form is for launches that are latency-, not bandwidth-bound.
+__global__ __launch_bounds__(64, 4) void k_aggregate_targets(
+    const float* __restrict__ x, const float* __restrict__ Wf, const uint8_t* __restrict__ pair_flag,
+    const int32_t* __restrict__ mol_ptr, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ work,
+    int nwork, int F, int swap, float* __restrict__ out, const int32_t* __restrict__ dyn_nwork) {
+  if ((int)blockIdx.x >= dyn_count(nwork, dyn_nwork)) return;
+  const int wk = work[blockIdx.x];
+  const int m = wk & 0x00FFFFFF, a = __builtin_amdgcn_readfirstlane((wk >> 24) & 255);
+  const int lane = threadIdx.x, f = 2 * lane < F ? 2 * lane : -2;
+  const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m];
+  aggregate_targets(x, Wf, pair_flag, a0, n, base, lane, f, F, swap, out, a, a + 1);
+}
+
 // --------------------------------------------------------------------------------------------- embedding
 __global__ void k_embedding_fwd(const int64_t* __restrict__ z, int64_t zs, const float* __restrict__ table, int C,
                                 int64_t N, int F, float* __restrict__ out, int32_t* __restrict__ status,
@@ -551,6 +568,19 @@ extern "C" int geossl_cfconv_aggregate_work_dyn(const float* x, const float* Wf,
   if (max_n > 255 || F > 128 || F <= 32) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(k_aggregate_reg_work, dim3((unsigned)nwork), dim3(64), 0, stream, x, Wf, pair_flag, mol_ptr,
                      pair_ptr, work, (int)nwork, F, swap, out, dyn_nwork);
+  GEOSSL_CHECK_LAUNCH();
+  return 0;
+}
+
+// work[i] = molecule | target atom << 24 for EVERY atom of the launch (geossl_amd/layout.py: aggregate_target_list)
+extern "C" int geossl_cfconv_aggregate_targets_dyn(const float* x, const float* Wf, const uint8_t* pair_flag,
+                                                   const int32_t* mol_ptr, const int32_t* pair_ptr, const int32_t* work,
+                                                   int64_t nwork, int max_n, int F, int swap, float* out,
+                                                   const int32_t* dyn_nwork, hipStream_t stream) {
+  if (nwork <= 0) return 0;
+  if (max_n > 255 || F > 128 || F <= 32) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_aggregate_targets, dim3((unsigned)nwork), dim3(64), 0, stream, x, Wf, pair_flag, mol_ptr, pair_ptr,
+                     work, (int)nwork, F, swap, out, dyn_nwork);
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }

@@ -70,9 +70,10 @@ class MolLayout:
         # ragged batches built from host sizes: the work list of the aggregation (geossl_cfconv_aggregate_work), molecules
         # by descending size, the 21..33-atom ones as 2 or 4 work items (one group of target atoms each)
         # (molecules above 33 atoms - Molecule3D with hydrogens - as 16 items each: lists of target atoms, no size class)
-        self.agg_work = None
+        self.agg_work, self.agg_targets = None, False
         if sizes is not None and 20 < self.max_n <= 255 and B < (1 << 24) and not os.environ.get("GEOSSL_AGG_NO_SPLIT"):
-            self.agg_work = torch.from_numpy(aggregate_work_list(np.asarray(sizes, dtype=np.int64))).to(dev)
+            self.agg_targets = aggregate_by_targets(B)
+            self.agg_work = torch.from_numpy(aggregate_work_list(np.asarray(sizes, dtype=np.int64), self.agg_targets)).to(dev)
         self.device = dev
         self._batch_version = batch._version
         self._sizes_host = sizes
@@ -163,11 +164,21 @@ def parts_table():
     return _PARTS
 
 
-def aggregate_work_list(n):
+def aggregate_by_targets(num_mols):
+    """Small launches (at most GEOSSL_AGG_TARGETS_MAX molecules, default 256: the two views of the reference's batch size)
+    aggregate with one work item per TARGET atom (geossl_cfconv_aggregate_targets_dyn): such a launch is bound by its
+    longest walk, not by bytes.  Measured per DDM step (tools/experiments/agg_targets.sh): set C at 10 A, 128 molecules
+    per view 1.283 against 1.316 ms, set B without the ragged layer loop 0.806 against 0.847 ms; at 256 molecules per view
+    the doubled filter-row traffic already loses (set C 2.106 against 2.065 ms, set B 1.244 against 1.106 ms)."""
+    return num_mols <= int(os.environ.get("GEOSSL_AGG_TARGETS_MAX", 256))
+
+
+def aggregate_work_list(n, targets=False):
     """Work list of geossl_cfconv_aggregate_work for molecules of `n` atoms (int64 array): molecules by descending size
-    (stable), each as geossl_aggregate_parts(size) items molecule | part << 24, as int32 words."""
+    (stable), each as geossl_aggregate_parts(size) items molecule | part << 24, as int32 words.  targets: one item per
+    atom of every molecule (molecule | atom << 24) for geossl_cfconv_aggregate_targets_dyn."""
     idx = np.argsort(-n, kind="stable")
-    parts = parts_table()[n][idx]
+    parts = n[idx] if targets else parts_table()[n][idx]
     mol = np.repeat(idx, parts)
     ends = np.cumsum(parts)
     part = np.arange(int(ends[-1]) if len(ends) else 0, dtype=np.int64) - np.repeat(ends - parts, parts)

@@ -297,7 +297,8 @@ def aggregate(x, Wf_l, pair_flag, layout, swap=False, out=None, mols=None):
         out = torch.empty_like(x)
     work = getattr(layout, "agg_work", None)
     if mols is None and work is not None and 32 < F <= 128:
-        call("geossl_cfconv_aggregate_work_dyn", ptr(x), ptr(Wf_l), ptr(pair_flag), ptr(layout.mol_ptr),
+        call("geossl_cfconv_aggregate_targets_dyn" if getattr(layout, "agg_targets", False)
+             else "geossl_cfconv_aggregate_work_dyn", ptr(x), ptr(Wf_l), ptr(pair_flag), ptr(layout.mol_ptr),
              ptr(layout.pair_ptr), ptr(work), work.numel(), layout.max_n, F, 1 if swap else 0, ptr(out),
              _dyn(layout, "n_work"), stream())
         return out

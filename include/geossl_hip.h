@@ -157,6 +157,12 @@ int geossl_cfconv_aggregate(const float* x, const float* Wf, const uint8_t* pair
  * size class) - every sum is still formed by one wave in the order of geossl_cfconv_aggregate, bit for bit.
  * max_n <= 255, 32 < F <= 128.                                                                                      */
 int geossl_aggregate_parts(int n);
+/* ... and with ONE work item per target atom for every molecule (work[i] = molecule | target << 24, all atoms of the
+ * launch): small batches, where a launch is bound by its longest walk (a chain of memory round trips) and not by
+ * bytes - every filter row is read by both of its atoms.  Same sums, bit for bit.                                      */
+int geossl_cfconv_aggregate_targets_dyn(const float* x, const float* Wf, const uint8_t* pair_flag, const int32_t* mol_ptr,
+                                        const int32_t* pair_ptr, const int32_t* work, int64_t nwork, int max_n, int F,
+                                        int swap, float* out, const int32_t* dyn_nwork, hipStream_t stream);
 int geossl_cfconv_aggregate_work(const float* x, const float* Wf, const uint8_t* pair_flag, const int32_t* mol_ptr,
                                  const int32_t* pair_ptr, const int32_t* work, int64_t nwork, int max_n, int F,
                                  int swap, float* out, hipStream_t stream);

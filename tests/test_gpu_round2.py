@@ -668,6 +668,7 @@ def test_aggregate_work_list_splits_large_molecules_bit_exact(F, monkeypatch):
     from geossl_amd import ops, _lib
     from geossl_amd.layout import MolLayout
     from geossl_amd.synthetic import make_batch
+    monkeypatch.setenv("GEOSSL_AGG_TARGETS_MAX", "0")   # (the work list by molecule parts: what large launches take)
     sizes = list(make_batch(40, seed=11, mode="B")["sizes"]) + [1, 2, 33, 27, 26, 21, 22, 28, 30, 3, 24, 31, 20, 32]
     batch = torch.arange(len(sizes), device=DEV).repeat_interleave(torch.tensor(sizes, device=DEV))
     lay = MolLayout(batch, len(sizes), sizes=sizes)

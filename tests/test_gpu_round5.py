@@ -226,21 +226,24 @@ def _sequential_index_add(xn, Wn, fn, pi, pj, swap):
     return ref
 
 
+@pytest.mark.parametrize("by_targets", [False, True], ids=["parts", "targets"])
 @pytest.mark.parametrize("sizes,lds_form", [([34, 18, 64, 1, 100, 33, 2, 47], True), ([255, 40, 3], False)],
                          ids=["upto100", "255"])
-def test_aggregation_work_list_above_the_size_classes_is_the_sequential_index_add(sizes, lds_form):
+def test_aggregation_work_list_above_the_size_classes_is_the_sequential_index_add(sizes, lds_form, by_targets, monkeypatch):
     """Molecules of 34 .. 255 atoms go through the work list as one work item per target atom (aggregate_targets: no size
     class, partners 32 at a time): bit for bit the sequential index_add over the canonical edge list (schnet.py:190,
     194-195), for the graph and its transpose, with asymmetric flags (what the 32-neighbour cap produces); and the LDS
-    form of geossl_cfconv_aggregate (molecules whose rows fit the LDS) gives the same bits."""
+    form of geossl_cfconv_aggregate (molecules whose rows fit the LDS) gives the same bits.  by_targets: the form of small
+    launches (the reference's batch size) - EVERY atom of every molecule its own work item."""
+    monkeypatch.setenv("GEOSSL_AGG_TARGETS_MAX", "256" if by_targets else "0")
     from geossl_amd import ops
     from geossl_amd._lib import call, ptr, stream
     from geossl_amd.layout import MolLayout
     F = 128
     batch = torch.arange(len(sizes), device=DEV).repeat_interleave(torch.tensor(sizes, device=DEV))
     lay = MolLayout(batch, len(sizes), sizes=sizes)
-    parts = lambda n: n if n > 33 else (4 if n >= 31 else (2 if n >= 27 else 1))
-    assert lay.agg_work is not None and lay.agg_work.numel() == sum(parts(n) for n in sizes)
+    parts = lambda n: n if (n > 33 or by_targets) else (4 if n >= 31 else (2 if n >= 27 else 1))
+    assert lay.agg_work is not None and lay.agg_work.numel() == sum(parts(n) for n in sizes) and lay.agg_targets == by_targets
     g = torch.Generator(device=DEV).manual_seed(7)
     x = torch.randn(lay.N, F, device=DEV, generator=g)
     W = torch.randn(lay.P, F, device=DEV, generator=g)

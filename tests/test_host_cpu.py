@@ -412,7 +412,8 @@ def test_layer_loop_block_plan():
 
 
 # ------------------------------------------------------------------------------------- capacity buckets, host side
-def test_bucket_host_plan_matches_the_collated_batch():
+@pytest.mark.parametrize("by_targets", [False, True])
+def test_bucket_host_plan_matches_the_collated_batch(by_targets, monkeypatch):
     """bucket.host_plan: everything of a batch's index structures that is a function of the molecule sizes, against what
     the collation itself produces (synthetic.make_batch: AtomTupleExtractor's enumeration with node offsets) and the
     oracle's pair-slot order - pointer arrays of the two-view batch, se_ptr, the incidence counts behind inc_ptr, the
@@ -421,6 +422,8 @@ def test_bucket_host_plan_matches_the_collated_batch():
     from geossl_amd._lib import load
     from geossl_amd.synthetic import make_batch
     lib = load()
+    # by_targets: the work list of small launches - one item per atom of every molecule (molecule | atom << 24)
+    monkeypatch.setenv("GEOSSL_AGG_TARGETS_MAX", "256" if by_targets else "0")
     for option in ("combination", "permutation"):
         # (trailing single atom: divisor B - 1; 34 / 60 atoms: above the size classes, one work item per atom)
         sizes = np.array([5, 33, 1, 18, 27, 2, 30, 1, 60, 9, 31, 34, 20, 1], dtype=np.int64)
@@ -440,7 +443,8 @@ def test_bucket_host_plan_matches_the_collated_batch():
         mol, part = hp["work"] & 0x00FFFFFF, (hp["work"].astype(np.int64) >> 24) & 255
         assert len(mol) == W
         n2 = np.concatenate([sizes, sizes])
-        want = sorted((m, k) for m in range(2 * B) for k in range(lib.geossl_aggregate_parts(int(n2[m]))))
+        want = sorted((m, k) for m in range(2 * B)
+                      for k in range(int(n2[m]) if by_targets else lib.geossl_aggregate_parts(int(n2[m]))))
         assert sorted(zip(mol.tolist(), part.tolist())) == want
         assert np.all(np.diff(n2[mol]) <= 0)                                        # largest molecules first
 
