@@ -682,3 +682,65 @@ def test_painn_bucket_reports_an_edge_that_leaves_its_molecule():
         for _ in range(20):
             tr.step(bt, None)
             torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("opt_name", ["adam", "sgd"])
+def test_reference_loop_with_painn_on_a_shuffled_loader_captures_once(opt_name):
+    """examples/pretrain_GeoSSL.py:248-260 with --model_3d painn on the product modules over the reference's own loader
+    surface (MoleculeDataset3DRadius-style molecules: a per-molecule radius_edge_index of the clean geometry,
+    datasets_3D_Radius.py:120; AtomTupleExtractor; DataLoaderAtomTuple(shuffle=True); batch.to(device)): every batch has
+    its own molecules, sizes and edge list; do_DDM captures ONE pair of graphs and replays it (a PaiNN bucket).  The
+    bucket's partial sums are cut at capacity block boundaries, so a step equals the eager step within fp32 summation order
+    (1e-6 of the loss); with plain SGD the whole trajectory stays that close; under the reference's Adam (:343) the first
+    steps divide every gradient component by its own magnitude - components that are rounding noise get updates of size
+    lr - and the two trajectories separate like any two fp32 evaluations do (steps 1-3 compared tightly, the rest loosely)."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.Geom3D.dataloaders import AtomTupleExtractor, Data, DataLoaderAtomTuple
+    from geossl_amd.synthetic import make_batch
+    from oracle.graph import radius_graph_np
+    sizes = _ragged_sizes(64, 17)
+    b = make_batch(64, seed=78, sizes=sizes)
+    ext = AtomTupleExtractor(ratio=1, option="combination")
+    off, dataset = 0, []
+    for n in sizes.tolist():
+        pos = b["positions"][off:off + n]
+        d = Data(x=torch.from_numpy(b["x"][off:off + n]), positions=torch.from_numpy(pos),
+                 radius_edge_index=torch.from_numpy(radius_graph_np(pos, 5.0)))
+        dataset.append(ext(d))
+        off += n
+    out = {}
+    for graph in (False, True):
+        torch.manual_seed(5)
+        torch.cuda.manual_seed(5)
+        cfg, model = _painn_modules()
+        n1, n2 = product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9)
+        pg.NCSN_model_01, pg.NCSN_model_02 = n1, n2
+        args = types.SimpleNamespace(model_3d="painn", GeoSSL_mu=0.0, GeoSSL_sigma=0.3, lr=5e-4, decay=0.0, step_graph=graph)
+        group = [{"params": model.parameters(), "lr": args.lr}, {"params": n1.parameters()}, {"params": n2.parameters()}]
+        optimizer = (torch.optim.Adam(group, lr=args.lr, weight_decay=args.decay) if opt_name == "adam"
+                     else torch.optim.SGD(group, lr=1e-7))   # (the filler weights have large gradients)
+        gen = torch.Generator()
+        gen.manual_seed(1)
+        loader = DataLoaderAtomTuple(dataset, batch_size=16, shuffle=True, generator=gen)
+        losses, edges = [], set()
+        try:
+            for epoch in range(2):
+                for batch in loader:
+                    batch = batch.to(DEV)
+                    edges.add(int(batch.radius_edge_index.size(1)))
+                    loss, acc = pg.do_DDM(args, batch, model, criterion=None, mu=args.GeoSSL_mu, sigma=args.GeoSSL_sigma)
+                    losses.append(loss.detach().item())
+                    optimizer.zero_grad()
+                    loss.backward()
+                    optimizer.step()
+        finally:
+            pg.NCSN_model_01 = pg.NCSN_model_02 = None
+        assert len(losses) == 8 and len(edges) > 4
+        eng = model.__dict__.get("_geossl_autograd_step")
+        caps = sum(sg.captures for sg in eng.graphs.values()) if eng is not None else 0
+        out[graph] = (losses, torch.cat([p.detach().reshape(-1) for m in (model, n1, n2) for p in m.parameters()]).cpu(), caps)
+    assert out[False][2] == 0 and 1 <= out[True][2] <= 2, out[True][2]
+    for k, (a, c) in enumerate(zip(out[True][0], out[False][0])):
+        tol = 5e-6 if (opt_name == "sgd" or k < 3) else 5e-2
+        assert abs(a - c) <= tol * abs(c), (k, out[True][0], out[False][0])
+    assert rel_err(out[True][1], out[False][1]) < (1e-4 if opt_name == "sgd" else 2e-2)
