@@ -553,7 +553,7 @@ SECONDARY_LINES = {
     # on Molecule3D WITH hydrogens (datasets_Molecule3D.py:65; set C: a quarter of the molecules above 33 atoms), bs = 128,
     # shuffle=True, SchNet at its default 10 A (config.py:114) where the 32-neighbour cap cuts lists.  PaiNN's
     # radius_edge_index is geometry-dependent (datasets_3D_Radius.py:120): no batch ever repeats an edge list.
-    "trainer/painn/distinct": (240, 0, dict(api="trainer", model="painn", n_batches=240, distinct=True)),
+    "trainer/painn/distinct": (480, 0, dict(api="trainer", model="painn", n_batches=480, distinct=True)),
     "trainer/painn/mols=128": (40, 8, dict(api="trainer", model="painn", mols=128, n_batches=4)),
     "trainer/painn/mols=128/distinct": (480, 0, dict(api="trainer", model="painn", mols=128, n_batches=480, distinct=True)),
     "trainer/painn/set=C/mols=128": (48, 8, dict(api="trainer", model="painn", molset="C", mols=128, n_batches=16,
