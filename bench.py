@@ -251,9 +251,11 @@ ARITHMETIC = ("fp32 inputs, outputs and accumulators; every Linear product on th
 def product_bits():
     """Significant bits of one fp32 x fp32 product as the dense kernels form it (fp32 itself: 24): the two-piece fp16
     split keeps 22, the three-piece bf16 split (GEOSSL_FILTER_*_BF16X3, and always in the NCSN head's forward) 24."""
-    x3 = lambda k: 24 if os.environ.get(k) else 22
+    all24 = bool(os.environ.get("GEOSSL_ARITH_24BIT"))   # every dense product of the step on three bf16 pieces
+    x3 = lambda k: 24 if (os.environ.get(k) or all24) else 22
     return {"filter_fwd": x3("GEOSSL_FILTER_FWD_BF16X3"), "filter_bwd": x3("GEOSSL_FILTER_BWD_BF16X3"),
-            "atom_row_chains": 22, "weight_gradients": 22, "ncsn_head_fwd": 24, "ncsn_head_bwd": 22, "accumulate": "fp32"}
+            "atom_row_chains": 24 if all24 else 22, "weight_gradients": 24 if all24 else 22, "ncsn_head_fwd": 24,
+            "ncsn_head_bwd": 24 if all24 else 22, "accumulate": "fp32"}
 
 
 def dist_info(world):
@@ -503,6 +505,7 @@ def secondary_line(dev, rank, world, steps, warmup, **kw):
     try:
         wl = Workload(dev, rank, world, n_batches=n_batches, **kw)
         elapsed, step_ms, loss = wl.run(warmup, steps)
+        bits = product_bits() if env else None
         if want_roof:  # the line's own `roofline` (dominant entry point; measured HBM bytes when a PMC summary is committed)
             roof, kern, _, shape = dominant_roofline(wl, 6)
             mt = measured_step_traffic(shape["pm"], shape["pm_src"], world * wl.mols * steps / elapsed / world)
@@ -525,6 +528,7 @@ def secondary_line(dev, rank, world, steps, warmup, **kw):
         out["captures_in_timed_region"] = wl.n_captures()
     if env:
         out["env"] = env
+        out["product_bits"] = bits
     del wl
     torch.cuda.empty_cache()
     return out
@@ -548,6 +552,9 @@ SECONDARY_LINES = {
     # the 24-bit products (three bf16 pieces, six MFMAs) in the filter network instead of the 22-bit default
     "trainer/arith=bf16x3": (20, 5, dict(api="trainer", env={"GEOSSL_FILTER_FWD_BF16X3": "1",
                                                              "GEOSSL_FILTER_BWD_BF16X3": "1"})),
+    # ... and in EVERY dense product of the step (atom-row layers, weight gradients and the heads' backward as well): what
+    # the last two bits of all products cost
+    "trainer/arith=24bit-all": (20, 5, dict(api="trainer", env={"GEOSSL_ARITH_24BIT": "1"})),
     "trainer/painn": (20, 4, dict(api="trainer", model="painn", n_batches=4, roofline=True)),
     # What the reference's DDM script really feeds the step (submit_pretrain_GeoSSL_DDM.sh:3,8,13-14,22): PaiNN and SchNet
     # on Molecule3D WITH hydrogens (datasets_Molecule3D.py:65; set C: a quarter of the molecules above 33 atoms), bs = 128,

@@ -163,7 +163,8 @@ class _SchNetCore(torch.autograd.Function):
         # rebuild is there for when memory is what is short.  The position gradient
         # (geossl_cfconv_filter_dpos) and the three-bf16-piece backward read the saved rows.
         keep_T = training and (ctx.needs_input_grad[1] or not os.environ.get("GEOSSL_FILTER_RECOMPUTE_T")
-                               or bool(os.environ.get("GEOSSL_FILTER_BWD_BF16X3")))
+                               or bool(os.environ.get("GEOSSL_FILTER_BWD_BF16X3"))
+                               or bool(os.environ.get("GEOSSL_ARITH_24BIT")))
         T = torch.empty(L, P, F, dtype=torch.float32, device=dev) if keep_T else None
         if P > 0:
             call("geossl_cfconv_filter_fwd_dyn", ptr(pair_d), ptr(pair_c), P, C.byref(fw), L, F, G, ptr(cfg["offset"]),
@@ -515,7 +516,10 @@ class SchNet(torch.nn.Module):
         cfg = dict(L=self.num_interactions, F=self.hidden_channels, G=self.num_gaussians, cutoff=float(self.cutoff),
                    offset=self.distance_expansion.offset, coeff=float(self.distance_expansion.coeff),
                    debug=bool(os.environ.get("GEOSSL_DEBUG")), status=status,
-                   chain=self.num_interactions >= 1 and not os.environ.get("GEOSSL_NO_CHAIN"),
+                   # (GEOSSL_ARITH_24BIT: every dense product at fp32's own 24-bit product width - the atom-row layers then
+                   # run as single launches of the three-bf16-piece row GEMM, the chain kernel is a two-fp16-piece kernel)
+                   chain=(self.num_interactions >= 1 and not os.environ.get("GEOSSL_NO_CHAIN")
+                          and not os.environ.get("GEOSSL_ARITH_24BIT")),
                    # The layer loop (chains and aggregations between the filter network and the heads) as ONE launch
                    # per pass (ops.layer_loop) - while a graph is being captured.  Launched eagerly it loses: the host
                    # has to describe all 14 operations before the GPU gets the first one, where separate launches

@@ -172,7 +172,7 @@ def tensors_ok(batch):
     return ok
 
 
-MODULE_SWITCHES = ("GEOSSL_NO_CHAIN", "GEOSSL_NCSN_SPLIT_BWD", "GEOSSL_NCSN_SEPARATE_HEADS")  # read by modules_ok
+MODULE_SWITCHES = ("GEOSSL_NO_CHAIN", "GEOSSL_NCSN_SPLIT_BWD", "GEOSSL_NCSN_SEPARATE_HEADS", "GEOSSL_ARITH_24BIT")  # read by modules_ok
 PAINN_SWITCHES = ("GEOSSL_PAINN_NO_CHAIN", "GEOSSL_PAINN_SILU_KERNELS")   # ... for a PaiNN backbone as well
 
 

@@ -1272,7 +1272,7 @@ extern "C" int geossl_cfconv_filter_bwd_dyn(const float* pair_d, const float* pa
                          dyn_N);                                                                                   \
     }                                                                                                              \
   } while (0)
-  const bool bf16x3 = getenv("GEOSSL_FILTER_BWD_BF16X3") != nullptr;  // (read per call: bench.py times both forms in one process)
+  const bool bf16x3 = getenv("GEOSSL_FILTER_BWD_BF16X3") != nullptr || getenv("GEOSSL_ARITH_24BIT") != nullptr;  // (read per call: bench.py times both forms in one process)
   if (bf16x3 && T == nullptr) return (int)hipErrorInvalidValue;  // (the three-piece form reads the saved hidden rows)
   if (!bf16x3) {
     if (F == 128) LAUNCH_H(4); else if (F == 64) LAUNCH_H(2); else LAUNCH_H(1);

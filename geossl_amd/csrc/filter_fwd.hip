@@ -515,7 +515,7 @@ extern "C" int geossl_cfconv_filter_fwd_dyn(const float* pair_d, const float* pa
     else LAUNCH(NMB, 4);                \
   } while (0)
   // default: two fp16 pieces per operand (3 MFMAs per product); GEOSSL_FILTER_FWD_BF16X3 selects the three-bf16-piece form
-  const bool bf16x3 = getenv("GEOSSL_FILTER_FWD_BF16X3") != nullptr;  // (read per call: bench.py times both forms in one process)
+  const bool bf16x3 = getenv("GEOSSL_FILTER_FWD_BF16X3") != nullptr || getenv("GEOSSL_ARITH_24BIT") != nullptr;  // (read per call: bench.py times both forms in one process)
 #define LAUNCH_H(NMB, K1S)                                                                                      \
   do {                                                                                                          \
     const size_t lds = (size_t)(NMB * (2 * NMB) + NMB * K1S) * 2 * 1024 + (2 * 32 * NMB + 16 * K1S + 36) * 4;   \

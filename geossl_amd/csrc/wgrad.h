@@ -34,7 +34,11 @@ struct WgradOut {
   float* dd[GEOSSL_TN_MAX];
 };
 
-template <int NCM, int NCN, class Ops>
+// PIECES = 2: two fp16 pieces per operand under running power-of-two block scales (3 MFMAs per product, 22-bit products:
+// the default).  PIECES = 3: three bf16 pieces, no scales (bf16 has fp32's exponent range), 6 MFMAs per product, 24-bit
+// products - the form of GEOSSL_ARITH_24BIT (every dense product of the step at fp32's own product width; A/B and
+// accuracy runs).
+template <int NCM, int NCN, class Ops, int PIECES = 2>
 __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chunk, int M, int N,
                                                         float* __restrict__ partial, float* __restrict__ partial_bias,
                                                         float* __restrict__ partial_dot,
@@ -43,8 +47,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
   constexpr int SA = (NCM + 3) / 4, SB = (NCN + 3) / 4;  // operand blocks converted per wave: A block wave + 4u
   constexpr int T = NCM * NCN, TPW = (T + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
-  u32x4* Fr = reinterpret_cast<u32x4*>(smem_raw);  // [NCM + NCN][2 k-steps][2][64]: A blocks first, then B blocks
-  int* eblk = reinterpret_cast<int*>(Fr + (size_t)(NCM + NCN) * 2 * 2 * 64);  // [NCM + NCN] running exponents
+  u32x4* Fr = reinterpret_cast<u32x4*>(smem_raw);  // [NCM + NCN][2 k-steps][PIECES][64]: A blocks first, then B blocks
+  int* eblk = reinterpret_cast<int*>(Fr + (size_t)(NCM + NCN) * 2 * PIECES * 64);  // [NCM + NCN] running exponents
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
   const int z = blockIdx.y;
   const int row_begin = blockIdx.x * chunk, row_end = min(R, row_begin + chunk);
@@ -121,14 +125,25 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
           bsum[u] += v[ks][q];
           if (Ops::kDot) dsum[u] = fmaf(v[ks][q], e[ks][q], dsum[u]);
         }
-      const float sc = block_scale(v, ea[u]);
-      if (lane == 0) eblk[blk] = ea[u];
+      if constexpr (PIECES == 3) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const Frag2 f = split8h_scaled(v[ks], sc);
-        u32x4* dst = Fr + (size_t)((blk * 2 + ks) * 2) * 64 + lane;
-        dst[0] = f.h;
-        dst[64] = f.l;
+        for (int ks = 0; ks < 2; ++ks) {
+          const Frag3 f = split8(v[ks]);
+          u32x4* dst = Fr + (size_t)((blk * 2 + ks) * 3) * 64 + lane;
+          dst[0] = f.h;
+          dst[64] = f.m;
+          dst[128] = f.l;
+        }
+      } else {
+        const float sc = block_scale(v, ea[u]);
+        if (lane == 0) eblk[blk] = ea[u];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const Frag2 f = split8h_scaled(v[ks], sc);
+          u32x4* dst = Fr + (size_t)((blk * 2 + ks) * 2) * 64 + lane;
+          dst[0] = f.h;
+          dst[64] = f.l;
+        }
       }
     }
 #pragma unroll
@@ -144,14 +159,25 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[ks][q] = 0.0f;
       }
-      const float sc = block_scale(v, eb[u]);
-      if (lane == 0) eblk[NCM + blk] = eb[u];
+      if constexpr (PIECES == 3) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const Frag2 f = split8h_scaled(v[ks], sc);
-        u32x4* dst = Fr + (size_t)(((NCM + blk) * 2 + ks) * 2) * 64 + lane;
-        dst[0] = f.h;
-        dst[64] = f.l;
+        for (int ks = 0; ks < 2; ++ks) {
+          const Frag3 f = split8(v[ks]);
+          u32x4* dst = Fr + (size_t)(((NCM + blk) * 2 + ks) * 3) * 64 + lane;
+          dst[0] = f.h;
+          dst[64] = f.m;
+          dst[128] = f.l;
+        }
+      } else {
+        const float sc = block_scale(v, eb[u]);
+        if (lane == 0) eblk[NCM + blk] = eb[u];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const Frag2 f = split8h_scaled(v[ks], sc);
+          u32x4* dst = Fr + (size_t)(((NCM + blk) * 2 + ks) * 2) * 64 + lane;
+          dst[0] = f.h;
+          dst[64] = f.l;
+        }
       }
     }
     lds_barrier();
@@ -160,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
       const int t = wave + 4 * i;
-      if (t >= T) continue;
+      if (t >= T || PIECES == 3) continue;
       const int en = __builtin_amdgcn_readfirstlane(eblk[t / NCN] + eblk[NCM + t % NCN]);
       if (en != eacc[i]) {
         const float f = __builtin_amdgcn_ldexpf(1.0f, eacc[i] - en);
@@ -169,6 +195,21 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
         eacc[i] = en;
       }
     }
+    if constexpr (PIECES == 3) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+          const int t = wave + 4 * i;
+          if (t >= T) continue;
+          const u32x4* sa = Fr + (size_t)(((t / NCN) * 2 + ks) * 3) * 64 + lane;
+          const u32x4* sb = Fr + (size_t)(((NCM + t % NCN) * 2 + ks) * 3) * 64 + lane;
+          Frag3 a3, b3;
+          a3.h = sa[0]; a3.m = sa[64]; a3.l = sa[128];
+          b3.h = sb[0]; b3.m = sb[64]; b3.l = sb[128];
+          mma6(acc[i], a3, b3);
+        }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       // two tiles at a time: their twelve MFMAs alternate between the two accumulators
@@ -195,6 +236,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
 #undef GEOSSL_WG_STEP
       }
     }
+    }
     lds_barrier();
   };
   for (int row0 = row_begin; row0 < row_end; row0 += 32 * PF) {
@@ -210,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
     if (t >= T) continue;
     const int mb = t / NCN, nb = t % NCN, n = 32 * nb + j;
     if (n >= N) continue;
-    const float kk = __builtin_amdgcn_ldexpf(1.0f, eacc[i] - 28);  // undo the two operand scales
+    const float kk = PIECES == 3 ? 1.0f : __builtin_amdgcn_ldexpf(1.0f, eacc[i] - 28);  // undo the two operand scales
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = 32 * mb + c_row(r, lane);
@@ -230,6 +272,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
   }
 }
 
+// GEOSSL_ARITH_24BIT (read per call: bench.py times both forms in one process): the three-piece form
+inline bool arith_24bit() { return getenv("GEOSSL_ARITH_24BIT") != nullptr; }
+
 // workspace: nprob * nblk * (M*N + 2*M) floats (geossl_tn_workspace_floats).  dW rows are written with leading
 // dimension dW_ld (>= N); dd is written with stride dd_stride (e.g. the last column of a [M][N+1] weight).
 template <int NCM, int NCN, class Ops>
@@ -247,10 +292,17 @@ int launch_wgrad_split(const Ops& ops, int nprob, int64_t R, int M, int N, const
     any_b |= out.db[z] != nullptr;
     any_d |= out.dd[z] != nullptr;
   }
-  const size_t lds = (size_t)(NCM + NCN) * 2 * 2 * 1024 + (size_t)(NCM + NCN) * sizeof(int);
-  allow_big_lds(&k_wgrad_split<NCM, NCN, Ops>);
-  hipLaunchKernelGGL((k_wgrad_split<NCM, NCN, Ops>), dim3(nblk, nprob), dim3(256), lds, stream, ops, (int)R, chunk, M,
-                     N, partial, any_b ? pbias : nullptr, any_d ? pdot : nullptr, dyn_R);
+  if (arith_24bit()) {  // GEOSSL_ARITH_24BIT: three bf16 pieces, six MFMAs per product
+    const size_t lds = (size_t)(NCM + NCN) * 2 * 3 * 1024 + (size_t)(NCM + NCN) * sizeof(int);
+    allow_big_lds(&k_wgrad_split<NCM, NCN, Ops, 3>);
+    hipLaunchKernelGGL((k_wgrad_split<NCM, NCN, Ops, 3>), dim3(nblk, nprob), dim3(256), lds, stream, ops, (int)R, chunk, M,
+                       N, partial, any_b ? pbias : nullptr, any_d ? pdot : nullptr, dyn_R);
+  } else {
+    const size_t lds = (size_t)(NCM + NCN) * 2 * 2 * 1024 + (size_t)(NCM + NCN) * sizeof(int);
+    allow_big_lds(&k_wgrad_split<NCM, NCN, Ops>);
+    hipLaunchKernelGGL((k_wgrad_split<NCM, NCN, Ops>), dim3(nblk, nprob), dim3(256), lds, stream, ops, (int)R, chunk, M,
+                       N, partial, any_b ? pbias : nullptr, any_d ? pdot : nullptr, dyn_R);
+  }
   GEOSSL_CHECK_LAUNCH();
   ReduceMulti rm;  // dW, db and dd partial sums in one launch
   rm.add(partial, M * N, N, dW_ld, 1, out.dW, nprob);

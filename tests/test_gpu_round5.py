@@ -744,3 +744,59 @@ def test_reference_loop_with_painn_on_a_shuffled_loader_captures_once(opt_name):
         tol = 5e-6 if (opt_name == "sgd" or k < 3) else 5e-2
         assert abs(a - c) <= tol * abs(c), (k, out[True][0], out[False][0])
     assert rel_err(out[True][1], out[False][1]) < (1e-4 if opt_name == "sgd" else 2e-2)
+
+
+# ------------------------------------------------------------------------------- every product at 24 bits (a switch)
+def test_weight_gradient_gemm_on_three_bf16_pieces_vs_fp64(monkeypatch):
+    """geossl_linear_wgrad under GEOSSL_ARITH_24BIT (k_wgrad_split<..., 3>: three bf16 pieces, six MFMAs per product, no
+    operand scales) against fp64, next to the default two-fp16-piece form: both within 2e-6 of the tensor scale, inputs of
+    ordinary size, x 1e-9 and x 1e+5 (bf16 pieces carry fp32's exponent range)."""
+    from geossl_amd import ops
+    from conftest import max_abs_rel
+    g = torch.Generator(device=DEV).manual_seed(11)
+    R = 5000
+    for sa, sb in ((1.0, 1.0), (1e-9, 1e5)):
+        A = torch.randn(R, 128, device=DEV, generator=g) * sa
+        Bm = torch.randn(R, 128, device=DEV, generator=g) * sb
+        ref = A.double().t() @ Bm.double()
+        refb = A.double().sum(0)
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("GEOSSL_ARITH_24BIT", env)
+            else:
+                monkeypatch.delenv("GEOSSL_ARITH_24BIT", raising=False)
+            dW, db = torch.empty(128, 128, device=DEV), torch.empty(128, device=DEV)
+            ops.linear_wgrad([(A, Bm, dW, db)], R, 128, 128)
+            assert max_abs_rel(dW.cpu(), ref.cpu()) < 2e-6, (sa, sb, env)
+            assert max_abs_rel(db.cpu(), refb.cpu()) < 2e-6
+    monkeypatch.delenv("GEOSSL_ARITH_24BIT", raising=False)
+
+
+def test_step_with_every_product_at_24_bits_vs_oracle(monkeypatch):
+    """GEOSSL_ARITH_24BIT: filter network, atom-row layers, weight gradients and both heads with three bf16 pieces per
+    operand (six MFMAs, 24-bit products - fp32's own product width) - the DDM step against oracle.nets.do_ddm_schnet at the
+    tolerances of the default path (loss 1e-5, gradients 1e-4), and within 2e-6 of the default path's loss."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    from oracle import nets
+    b = make_batch(48, seed=12, mode="B")
+    nz = draw_noise(b, seed=13)
+    noise = {k: t(v, DEV) for k, v in nz.items()}
+    out = {}
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("GEOSSL_ARITH_24BIT", env)
+        tr = _trainer(FULL, use_graph=False)
+        loss = tr._fwd_bwd(pg.Batch.from_numpy(b, DEV), noise)
+        out[env] = (float(loss), unique_named_grads(tr.model), tr)
+    monkeypatch.delenv("GEOSSL_ARITH_24BIT")
+    assert abs(out["1"][0] - out[None][0]) <= 2e-6 * abs(out[None][0])
+    Pm, P1, P2 = schnet_oracle_params(FULL), ncsn_oracle_params(128, 50), ncsn_oracle_params(128, 50, 0.9)
+    ref = nets.do_ddm_schnet(Pm, P1, P2, t(b["x"]), t(b["positions"]), t(b["batch"]), t(b["super_edge_index"]),
+                             t(nz["pos_noise"]), t(nz["noise_level_1"]), t(nz["dist_noise_1"]), t(nz["noise_level_2"]),
+                             t(nz["dist_noise_2"]), 5.0, 6, 2, "mean")
+    ref.backward()
+    assert abs(out["1"][0] - float(ref.detach())) <= TOL_OUT * abs(float(ref.detach()))
+    for k in ("lin2.weight", "interactions.0.mlp.0.weight", "interactions.3.mlp.2.weight", "interactions.5.conv.lin1.weight",
+              "interactions.2.conv.lin2.weight", "interactions.4.lin.weight", "embedding.weight"):
+        assert rel_err(out["1"][1][k].cpu(), Pm[k].grad) < TOL_GRAD, k

@@ -1,33 +1,41 @@
 # long run on never-repeating ragged batches: device memory, host RSS and step time must stay flat
-#   python tools/soak.py [steps] [mols] [trainer|reference]
+#   python tools/soak.py [steps] [mols] [trainer|reference] [schnet|painn] [set B|C]
 import os, resource, sys, time, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from geossl_amd import pretrain_GeoSSL as pg
-from geossl_amd.Geom3D.models import SchNet
+from geossl_amd.Geom3D.models import PaiNN, SchNet
+from geossl_amd import ops
 from geossl_amd.NCSN import NCSN_version_03
 from geossl_amd.synthetic import collate_subset, make_batch
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 mols = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 api = sys.argv[3] if len(sys.argv) > 3 else "trainer"
+backbone = sys.argv[4] if len(sys.argv) > 4 else "schnet"
+molset = sys.argv[5] if len(sys.argv) > 5 else "B"
 dev = "cuda:0"
 torch.manual_seed(0)
-model = SchNet(128, 128, 6, 51, 5.0, node_class=9).to(dev)
+if backbone == "schnet":
+    model = SchNet(128, 128, 6, 51, 10.0 if molset == "C" else 5.0, node_class=9).to(dev)
+else:
+    model = PaiNN(n_atom_basis=128, n_interactions=3, n_rbf=20, cutoff=5.0, max_z=9, n_out=1, readout="add").to(dev)
 n1 = NCSN_version_03(128, 10.0, 0.01, 50, "symmetry", 2).to(dev)
 n2 = NCSN_version_03(128, 10.0, 0.01, 50, "symmetry", 2).to(dev)
-pool = make_batch(4096, seed=1, mode="B")
+pool = make_batch(4096, seed=1, mode=molset)
 rng = np.random.default_rng(5)
 if api == "trainer":
-    tr = pg.DDMTrainer(model, n1, n2, lr=5e-4, use_graph=True)
+    tr = pg.DDMTrainer(model, n1, n2, lr=5e-4, use_graph=True, model_3d=backbone)
 else:
     pg.NCSN_model_01, pg.NCSN_model_02 = n1, n2
-    args = types.SimpleNamespace(model_3d="schnet", lr=5e-4, decay=0.0)
+    args = types.SimpleNamespace(model_3d=backbone, lr=5e-4, decay=0.0)
     opt = torch.optim.Adam([{"params": model.parameters(), "lr": 5e-4}, {"params": n1.parameters()}, {"params": n2.parameters()}], lr=5e-4)
 marks = []
 t0 = time.perf_counter()
 for step in range(steps):
     bt = pg.Batch.from_numpy(collate_subset(pool, rng.permutation(4096)[:mols]), dev, prepare=False)
+    if backbone == "painn":  # (the loader's precomputed radius_edge_index, datasets_3D_Radius.py:120; its E read-back is the collate's)
+        bt.radius_edge_index = ops.radius_graph(bt.positions, 5.0, bt.batch)
     if api == "trainer":
         loss = tr.step(bt)
     else:
