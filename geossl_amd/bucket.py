@@ -119,11 +119,11 @@ def batch_counts(sizes, option):
     global _PARTS
     if _PARTS is None:
         _PARTS = _parts_table()
-    from .layout import aggregate_by_targets
+    from .layout import aggregate_by_targets, work_items_bound
     n = sizes if isinstance(sizes, np.ndarray) else np.asarray(sizes, dtype=np.int64)
     P = int((n * (n - 1) // 2).sum())
     S = P if option == "combination" else 2 * P
-    W = 2 * int(n.sum() if aggregate_by_targets(2 * len(n)) else _PARTS[n].sum())
+    W = work_items_bound(np.concatenate([n, n]), aggregate_by_targets(2 * len(n)))   # (a bound: the list has 8 padded queues)
     return int(n.sum()), P, S, W
 
 
@@ -280,18 +280,15 @@ def host_plan(sizes, option):
     pp = np.zeros(B + 1, dtype=np.int64)
     np.cumsum(npair, out=pp[1:])
     n2 = np.concatenate([n, n])
-    idx = np.argsort(-n2, kind="stable")
-    from .layout import aggregate_by_targets
-    parts = n2[idx] if aggregate_by_targets(2 * B) else _PARTS[n2][idx]
-    mol = np.repeat(idx, parts)
-    ends = np.cumsum(parts)
-    part = np.arange(int(ends[-1]), dtype=np.int64) - np.repeat(ends - parts, parts)
+    from .layout import aggregate_by_targets, aggregate_work_list
+    work = aggregate_work_list(n2, aggregate_by_targets(2 * B))
+    if work.size > W:
+        raise ValueError("aggregation work list longer than its bound")   # (work_items_bound: cannot happen)
     has = np.nonzero(npair > 0)[0]
     ip = np.zeros(N + 1, dtype=np.int64)
     np.cumsum(np.repeat((n - 1) * mult, n), out=ip[1:])
     return dict(counts=(N, P, S, W), mol_ptr2=np.concatenate([mp, mp[1:] + N]), pair_ptr2=np.concatenate([pp, pp[1:] + P]),
-                se_ptr=pp * mult, work=(mol | (part << 24)).astype(np.uint32).view(np.int32),
-                divisor=int(has[-1]) + 1 if has.size else 0, inc_ptr=ip)
+                se_ptr=pp * mult, work=work, divisor=int(has[-1]) + 1 if has.size else 0, inc_ptr=ip)
 
 
 class Bucket:
@@ -428,7 +425,8 @@ class Bucket:
             slot[1].synchronize()   # the upload that last read this staging buffer (three steps ago)
         h = slot[0].numpy()
         hp = host_plan(n, self.option)
-        h[0:8] = (N, 2 * N, 2 * P, S, W, B, 6 * N, 2 * E)
+        Wr = hp["work"].size          # (the list's real length: 8 queues; <= the bound W the capacity was checked with)
+        h[0:8] = (N, 2 * N, 2 * P, S, Wr, B, 6 * N, 2 * E)
         if self.big_caps:
             from .layout import big_atom_list
             n2 = np.concatenate([n, n])
@@ -440,7 +438,7 @@ class Bucket:
         h[o["pair_ptr"]:o["pair_ptr"] + 2 * B + 1] = hp["pair_ptr2"]
         h[o["se_ptr"]:o["se_ptr"] + B + 1] = hp["se_ptr"]
         if self.kind == "schnet":
-            h[o["work"]:o["work"] + W] = hp["work"]
+            h[o["work"]:o["work"] + Wr] = hp["work"]
         st = h[o["stats"]:o["stats"] + 4].view(np.int64)
         st[0], st[1] = hp["divisor"], 0
         h[o["inc_ptr"]:o["inc_ptr"] + 2 * (N + 1)].view(np.int64)[:] = hp["inc_ptr"]

@@ -268,12 +268,24 @@ __device__ __forceinline__ void aggregate_big(const float* __restrict__ x, const
 #undef AGG_PART
 }
 
+// The work list is laid out in EIGHT queues of equal length Q = nwork / 8 (padded with -1), one per XCD: workgroups are
+// dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b takes entry b / 8 of queue b mod 8 and the work
+// items of ONE molecule - consecutive entries of one queue: the target atoms of a large molecule, the target groups of a
+// 27..33-atom one, which read each other's filter rows - run on one XCD, close in time: the second read of a filter row
+// is an L2 hit instead of a second trip to HBM.  The host (layout.aggregate_work_list) deals the molecules to the queues
+// largest first in snake order.
+__device__ __forceinline__ int work_item(const int32_t* __restrict__ work, int nwork, const int32_t* __restrict__ dyn_nwork) {
+  const int nw = dyn_count(nwork, dyn_nwork), b = (int)blockIdx.x;
+  if (b >= nw) return -1;
+  return work[(b & 7) * (nw >> 3) + (b >> 3)];
+}
+
 __global__ __launch_bounds__(64, 2) void k_aggregate_reg_work(
     const float* __restrict__ x, const float* __restrict__ Wf, const uint8_t* __restrict__ pair_flag,
     const int32_t* __restrict__ mol_ptr, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ work,
     int nwork, int F, int swap, float* __restrict__ out, const int32_t* __restrict__ dyn_nwork) {
-  if ((int)blockIdx.x >= dyn_count(nwork, dyn_nwork)) return;
-  const int wk = work[blockIdx.x];
+  const int wk = work_item(work, nwork, dyn_nwork);
+  if (wk == -1) return;
   const int m = wk & 0x00FFFFFF, part = __builtin_amdgcn_readfirstlane((wk >> 24) & 255);
   const int lane = threadIdx.x, f = 2 * lane < F ? 2 * lane : -2;  // -2: no channels (see k_aggregate_reg)
   const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m];
@@ -300,8 +312,8 @@ __global__ __launch_bounds__(64, 4) void k_aggregate_targets(
     const float* __restrict__ x, const float* __restrict__ Wf, const uint8_t* __restrict__ pair_flag,
     const int32_t* __restrict__ mol_ptr, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ work,
     int nwork, int F, int swap, float* __restrict__ out, const int32_t* __restrict__ dyn_nwork) {
-  if ((int)blockIdx.x >= dyn_count(nwork, dyn_nwork)) return;
-  const int wk = work[blockIdx.x];
+  const int wk = work_item(work, nwork, dyn_nwork);
+  if (wk == -1) return;
   const int m = wk & 0x00FFFFFF, a = __builtin_amdgcn_readfirstlane((wk >> 24) & 255);
   const int lane = threadIdx.x, f = 2 * lane < F ? 2 * lane : -2;
   const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m];

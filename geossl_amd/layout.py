@@ -173,16 +173,43 @@ def aggregate_by_targets(num_mols):
     return num_mols <= int(os.environ.get("GEOSSL_AGG_TARGETS_MAX", 256))
 
 
+XCD = 8   # L2 domains of the chip: workgroups are dealt to them round-robin
+
+
+def work_items_bound(n, targets=False):
+    """Upper bound on the entries of aggregate_work_list(n, targets) (8 queues of equal length), from two sums - what a
+    capacity check needs per step without building the list."""
+    if not len(n):
+        return 0
+    parts = n if targets else parts_table()[n]
+    return XCD * (-(-int(parts.sum()) // XCD) + int(parts.max()))
+
+
 def aggregate_work_list(n, targets=False):
-    """Work list of geossl_cfconv_aggregate_work for molecules of `n` atoms (int64 array): molecules by descending size
-    (stable), each as geossl_aggregate_parts(size) items molecule | part << 24, as int32 words.  targets: one item per
-    atom of every molecule (molecule | atom << 24) for geossl_cfconv_aggregate_targets_dyn."""
+    """Work list of geossl_cfconv_aggregate_work for molecules of `n` atoms (int64 array), as int32 words: every
+    molecule as geossl_aggregate_parts(size) items molecule | part << 24 (targets: one item per atom, molecule | atom << 24,
+    for geossl_cfconv_aggregate_targets_dyn), in EIGHT queues of equal length (padded with -1; queue k = entries
+    [k Q, (k + 1) Q)): the molecules are dealt to the queues largest first in snake order (balanced sums), the items of a
+    molecule are consecutive entries of its queue - workgroup b of the launch takes entry b / 8 of queue b mod 8, i.e.
+    runs on XCD b mod 8: items that read each other's filter rows share an L2."""
     idx = np.argsort(-n, kind="stable")
     parts = n[idx] if targets else parts_table()[n][idx]
+    r = np.arange(len(idx), dtype=np.int64)
+    q = np.where((r // XCD) % 2 == 0, r % XCD, XCD - 1 - r % XCD)         # queue of the molecule of rank r
     mol = np.repeat(idx, parts)
     ends = np.cumsum(parts)
-    part = np.arange(int(ends[-1]) if len(ends) else 0, dtype=np.int64) - np.repeat(ends - parts, parts)
-    return (mol | (part << 24)).astype(np.uint32).view(np.int32)
+    total = int(ends[-1]) if len(ends) else 0
+    part = np.arange(total, dtype=np.int64) - np.repeat(ends - parts, parts)
+    words = (mol | (part << 24)).astype(np.uint32).view(np.int32)
+    qi = np.repeat(q, parts)
+    order = np.argsort(qi, kind="stable")                                  # queue-major, rank order kept inside a queue
+    cnt = np.bincount(qi, minlength=XCD)
+    Q = int(cnt.max()) if total else 0
+    out = np.full((XCD, Q), -1, dtype=np.int32)
+    starts = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    pos = np.arange(total, dtype=np.int64) - np.repeat(starts, cnt)
+    out[qi[order], pos] = words[order]
+    return out.reshape(-1)
 
 
 def loop_block_plan(sizes, max_rows=96, max_mols=None, slots=512):

@@ -150,8 +150,10 @@ int geossl_pair_position_grad(const float* pos, const float* pair_d, const float
 int geossl_cfconv_aggregate(const float* x, const float* Wf, const uint8_t* pair_flag, const int32_t* mol_ptr,
                             const int32_t* pair_ptr, const int32_t* order, int64_t B, int max_n, int F, int swap,
                             float* out, hipStream_t stream);
-/* The same aggregation from a host-built work list (ragged batches): work[i] = molecule | part << 24 (molecule < 2^24,
- * part 0 .. 254), in launch order (largest molecules first).  A molecule of n atoms has geossl_aggregate_parts(n) entries
+/* The same aggregation from a host-built work list (ragged batches): work entries molecule | part << 24 (molecule < 2^24,
+ * part 0 .. 254; -1 = padding) in EIGHT queues of nwork / 8 entries each, one per XCD (workgroup b takes entry b / 8 of
+ * queue b mod 8: the items of one molecule, which read each other's filter rows, share an L2), largest molecules first
+ * within a queue.  A molecule of n atoms has geossl_aggregate_parts(n) entries
  * (1, 2 or 4 up to 33 atoms: the 27..33-atom molecules are shared by that many waves, one group of target atoms each; n
  * above 33 atoms - Molecule3D with hydrogens, datasets_Molecule3D.py:65 - where a wave sums ONE target atom without a
  * size class) - every sum is still formed by one wave in the order of geossl_cfconv_aggregate, bit for bit.

@@ -673,8 +673,9 @@ def test_aggregate_work_list_splits_large_molecules_bit_exact(F, monkeypatch):
     batch = torch.arange(len(sizes), device=DEV).repeat_interleave(torch.tensor(sizes, device=DEV))
     lay = MolLayout(batch, len(sizes), sizes=sizes)
     parts = [_lib.load().geossl_aggregate_parts(int(n)) for n in sizes]
-    assert lay.agg_work is not None and lay.agg_work.numel() == sum(parts) and max(parts) == 4 and 2 in parts
     wk = lay.agg_work.cpu().numpy()
+    wk = wk[wk != -1]                                   # (eight queues of equal length, padded with -1)
+    assert lay.agg_work is not None and wk.size == sum(parts) and max(parts) == 4 and 2 in parts
     assert sorted((wk & 0x00FFFFFF).tolist()) == sorted(m for m, k in enumerate(parts) for _ in range(k))
     g = torch.Generator(device=DEV).manual_seed(5)
     x = torch.randn(lay.N, F, device=DEV, generator=g)

@@ -440,13 +440,31 @@ def test_bucket_host_plan_matches_the_collated_batch(by_targets, monkeypatch):
         assert np.array_equal(np.diff(hp["se_ptr"]), np.bincount(e2g, minlength=B)) and hp["divisor"] == int(e2g.max()) + 1
         deg = np.bincount(b["super_edge_index"].reshape(-1), minlength=N)
         assert np.array_equal(np.diff(hp["inc_ptr"]), deg) and hp["inc_ptr"][0] == 0
-        mol, part = hp["work"] & 0x00FFFFFF, (hp["work"].astype(np.int64) >> 24) & 255
-        assert len(mol) == W
+        # eight queues of equal length (one per XCD: workgroup b takes entry b / 8 of queue b mod 8), padded with -1
+        wk = hp["work"]
+        assert wk.size % 8 == 0 and wk.size <= W
+        queues = wk.reshape(8, -1)
+        real = wk[wk != -1]
+        mol, part = real & 0x00FFFFFF, (real.astype(np.int64) >> 24) & 255
         n2 = np.concatenate([sizes, sizes])
         want = sorted((m, k) for m in range(2 * B)
                       for k in range(int(n2[m]) if by_targets else lib.geossl_aggregate_parts(int(n2[m]))))
         assert sorted(zip(mol.tolist(), part.tolist())) == want
-        assert np.all(np.diff(n2[mol]) <= 0)                                        # largest molecules first
+        where = {}
+        for k in range(8):
+            row = queues[k]
+            valid = row[row != -1]
+            assert np.all(row[len(valid):] == -1)                                   # padding at the end of a queue only
+            qm, qp = valid & 0x00FFFFFF, (valid.astype(np.int64) >> 24) & 255
+            assert np.all(np.diff(n2[qm]) <= 0)                                     # largest molecules first in a queue
+            for m_ in np.unique(qm):
+                assert m_ not in where                                              # a molecule's items: one queue ...
+                where[m_] = k
+                pos = np.nonzero(qm == m_)[0]
+                assert np.array_equal(pos, np.arange(pos[0], pos[0] + len(pos)))    # ... consecutive entries ...
+                assert np.array_equal(qp[pos], np.arange(len(pos)))                 # ... in part order
+        loads = [(queues[k] != -1).sum() for k in range(8)]
+        assert max(loads) - min(loads) <= int(max(want, key=lambda t_: t_[1])[1]) + 1   # balanced within one molecule
 
 
 def test_bucket_capacities_and_eligibility():
