@@ -207,6 +207,14 @@ PROTOTYPES = {
     "geossl_painn_edge_geom_dyn": (i32, [vp, vp, vp, i64, f32, vp, vp, i32, vp, vp, vp, vp, vp]),
     "geossl_painn_interaction_fwd_mma_dyn": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i64, i32,
                                                    i32, vp, vp, vp, vp]),
+    "geossl_tape_unary": (i32, [i32, vp, i64, f32, f32, vp, vp]),
+    "geossl_tape_binary": (i32, [i32, vp, i32, vp, i32, i64, i32, f32, vp, vp]),
+    "geossl_tape_colsum_workspace_floats": (i64, [i64, i32]),
+    "geossl_tape_reduce": (i32, [i32, vp, i64, i32, vp, vp, vp]),
+    "geossl_tape_gather_rows": (i32, [vp, vp, i32, i64, i32, vp, vp]),
+    "geossl_tape_scatter_rows": (i32, [vp, vp, i32, vp, i64, i32, vp, vp]),
+    "geossl_tape_copy2d": (i32, [vp, i64, vp, i64, i64, i32, vp]),
+    "geossl_tape_fill": (i32, [vp, i64, f32, vp]),
     "geossl_painn_stage_cap": (i32, [i32, i32, i32]),
     "geossl_painn_interaction_fwd_atoms": (i32, [vp] * 12 + [i64, vp, i32, i32, vp, vp, vp]),
     "geossl_painn_interaction_bwd_atoms": (i32, [vp] * 13 + [i64, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
@@ -259,7 +267,9 @@ def ptr(t):
 
 
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """The current HIP stream of the current device as a raw handle.  (torch.cuda.current_stream().cuda_stream builds a
+    Stream object per call - 8 us, a third of the host time of a launch-bound path like the second-order tape.)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def require_cuda(*tensors):

@@ -15,6 +15,7 @@ PyTorch's own derivative formulas carry the higher orders there.  PaiNN works th
 kernels, and only a backward through those gradients walks the primitive graph.  Nothing here is on the DDM hot path.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -24,63 +25,20 @@ from . import ops
 SSP_SHIFT = torch.log(torch.tensor(2.0)).item()  # schnet.py:213
 
 
-def _mm_raw(a, b, mode, bias=None):
-    a, b = a.contiguous(), b.contiguous()
-    if a.size(0) == 0:  # no rows (e.g. a batch without edges): the kernels are not launched
-        shape = {"nt": (0, b.size(0)), "nn": (0, b.size(1)), "tn": (a.size(1), b.size(1))}[mode]
-        return torch.zeros(shape, dtype=torch.float32, device=a.device)
-    try:
-        return _mm_launch(a, b, mode, bias)
-    except Exception as e:
-        raise type(e)("%s [_MM %s: a %s, b %s]" % (e, mode, tuple(a.shape), tuple(b.shape))) from e
+from .tape import mm_raw as _mm_raw  # the three GEMM forms on the HIP kernels, padding / slabbing by the block-copy kernel
 
 
-def _pad2(t, rows, cols):
-    return t if (rows == t.size(0) and cols == t.size(1)) else F.pad(t, (0, cols - t.size(1), 0, rows - t.size(0)))
-
-
-def _up(n, m):
-    return (n + m - 1) // m * m
-
-
-def _mm_launch(a, b, mode, bias=None):
-    """Raw products on the HIP GEMMs; widths are zero-padded to what the kernels take (contraction: multiples of 8,
-    outputs: multiples of 4; column GEMM tiles of 32 / 64 / 128) and the result is cut back.  `bias` ("nt" only): added
-    in the epilogue of the first contraction pass."""
-    if mode in ("nt", "nn"):
-        R, K = a.shape
-        NO = b.size(0) if mode == "nt" else b.size(1)
-        Kp, NOp = _up(K, 8), _up(NO, 4)
-        a = _pad2(a, R, Kp)
-        if bias is not None:
-            bias = bias.contiguous() if NOp == NO else F.pad(bias, (0, NOp - NO))
-        outs = []
-        for c0 in range(0, NOp, 128):  # output slabs of <= 128 columns
-            c1 = min(c0 + 128, NOp)
-            y = None
-            for k0 in range(0, Kp, 256):  # contraction in passes of <= 256, accumulated through the residual operand
-                k1 = min(k0 + 256, Kp)
-                ak = a if (k0 == 0 and k1 == Kp) else a[:, k0:k1]
-                if mode == "nt":   # a [R, K] @ b[NO, K]^T
-                    w = _pad2(b[c0:min(c1, NO), k0:min(k1, K)], c1 - c0, k1 - k0)
-                    y = ops.linear(ak, w.contiguous(), transB=True, res=y, K=k1 - k0, NO=c1 - c0,
-                                   bias=bias[c0:c1] if (bias is not None and k0 == 0) else None)
-                else:              # a [R, K] @ b[K, NO]
-                    w = _pad2(b[k0:min(k1, K), c0:min(c1, NO)], k1 - k0, c1 - c0)
-                    y = ops.linear(ak, w.contiguous(), transB=False, res=y, K=k1 - k0, NO=c1 - c0)
-            outs.append(y)
-        y = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
-        return y[:, :NO].contiguous() if NOp != NO else y
-    R, M, N = a.size(0), a.size(1), b.size(1)  # "tn": a[R, M]^T @ b[R, N], tiled to the column GEMM's 128 x 128 limit
-    tile = lambda n: 32 if n <= 32 else (64 if n <= 64 else 128)
-    Mp, Np = (_up(M, 128) if M > 128 else tile(M)), (_up(N, 128) if N > 128 else tile(N))
-    a, b = _pad2(a, R, Mp), _pad2(b, R, Np)
-    out = torch.empty(Mp, Np, dtype=torch.float32, device=a.device)
-    for m0 in range(0, Mp, 128):
-        for n0 in range(0, Np, 128):
-            mm, nn = min(128, Mp - m0), min(128, Np - n0)
-            ops.linear_wgrad([(a[:, m0:], b[:, n0:], out[m0:, n0:], None)], R, mm, nn, lda=Mp, ldb=Np, ldw=Np)
-    return out[:M, :N].contiguous() if (Mp != M or Np != N) else out
+def _to_leaf(t, g):
+    """Inside _lib.direct_grads() a gradient for a leaf that owns a dense fp32 .grad (a parameter of an energy head built
+    from Dense layers, reached from the energy AND through the force) is added straight into that .grad and the node
+    returns none for it - no AccumulateGrad add per contribution.  Outside the context: g, through autograd."""
+    from . import _lib
+    if g is None or torch.is_grad_enabled() or _lib._DIRECT["depth"] <= 0:
+        return g
+    if not (t.is_leaf and t.requires_grad) or not _lib.direct_grads_enabled([t]) or t.grad.shape != g.shape:
+        return g
+    _lib.call("geossl_axpy", _lib.ptr(t.grad), _lib.ptr(g.contiguous()), 1.0, g.numel(), _lib.ptr(t.grad), _lib.stream())
+    return None
 
 
 class _MM(torch.autograd.Function):
@@ -112,7 +70,7 @@ class _MM(torch.autograd.Function):
                 da = _MM.apply(b, g, "nt")
             if ctx.needs_input_grad[1]:
                 db = _MM.apply(a, g, "nn")
-        return da, db, None
+        return _to_leaf(a, da), _to_leaf(b, db), None
 
 
 class _Agg(torch.autograd.Function):
@@ -150,12 +108,13 @@ class _PairProd(torch.autograd.Function):
 
 
 class _LinearBias(torch.autograd.Function):
-    """x @ w^T + b with the bias added in the GEMM's epilogue.  Its derivative is made of _MM forms (d b: the column
-    sums of the upstream gradient, as its product with a column of ones), so it is differentiable to any order."""
+    """x @ w^T + b with the bias added in the GEMM's epilogue.  Its derivative is made of _MM forms and of the column
+    sums of the upstream gradient (_ColSum, closed with its broadcast), so it is differentiable to any order."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
+        ctx.bias = b
         return _mm_raw(x, w, "nt", bias=b.detach())
 
     @staticmethod
@@ -163,11 +122,34 @@ class _LinearBias(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dx = _MM.apply(g, w, "nn") if ctx.needs_input_grad[0] else None
         dw = _MM.apply(g, x, "tn") if ctx.needs_input_grad[1] else None
-        db = None
-        if ctx.needs_input_grad[2]:
-            ones = torch.ones(g.size(0), 1, dtype=g.dtype, device=g.device)
-            db = _MM.apply(g, ones, "tn").reshape(-1)
-        return dx, dw, db
+        db = _ColSum.apply(g) if ctx.needs_input_grad[2] else None
+        return dx, _to_leaf(w, dw), _to_leaf(ctx.bias, db)
+
+
+class _ColSum(torch.autograd.Function):
+    """Column sums of a row matrix (the bias gradient of a Linear) in fixed order on geossl_tape_reduce; its derivative
+    is the broadcast below and vice versa."""
+
+    @staticmethod
+    def forward(ctx, g):
+        from . import tape
+        ctx.rows = g.size(0)
+        return tape._raw_reduce(tape.COL, g.contiguous()).view(-1)
+
+    @staticmethod
+    def backward(ctx, c):
+        return _RowBroadcast.apply(c, ctx.rows)
+
+
+class _RowBroadcast(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c, rows):
+        from . import tape
+        return tape._raw_binary(tape.FIRST, c.contiguous().view(1, -1), tape.COL, None, tape.FULL, rows, c.numel())
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ColSum.apply(g), None
 
 
 class _Silu(torch.autograd.Function):
@@ -204,7 +186,18 @@ class _SiluGrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, c):
         u, g = ctx.saved_tensors
-        s = torch.sigmoid(u)
+        if not torch.is_grad_enabled():   # second order (training on forces): silu' and silu'' as kernels
+            from . import tape
+            c = c.contiguous()
+            shape, n = u.shape, u.numel()
+            flat = lambda t: t.reshape(1, n)
+            d1 = tape._raw_unary(tape.DSILU, u)
+            d2 = tape._raw_unary(tape.D2SILU, u)
+            cg = tape._raw_binary(tape.MUL, flat(c), tape.FULL, flat(g), tape.FULL, 1, n)
+            du = tape._raw_binary(tape.MUL, cg, tape.FULL, flat(d2), tape.FULL, 1, n)
+            dg = tape._raw_binary(tape.MUL, flat(c), tape.FULL, flat(d1), tape.FULL, 1, n)
+            return du.view(shape), dg.view(shape)
+        s = torch.sigmoid(u)                                # a third order is asked for: torch's own formulas carry it
         d1 = s * (1.0 + u * (1.0 - s))                      # silu'
         d2 = s * (1.0 - s) * (2.0 + u * (1.0 - 2.0 * s))    # silu''
         return c * g * d2, c * d1
@@ -291,6 +284,23 @@ def painn_atom_features(z, pos, idx_i, idx_j, cfg, params):
     return q
 
 
+def _deliver(fctx, out):
+    """Inside _lib.direct_grads() (the caller owns dense p.grad buffers, e.g. after zero_grad(set_to_none=False)) the
+    parameter gradients of the second-order route are added straight into p.grad - like the first-order node's - and the
+    node returns none for them: no AccumulateGrad adds by the engine."""
+    from . import _lib
+    from ._lib import call, ptr, stream
+    if torch.is_grad_enabled() or not _lib.direct_grads_enabled(fctx.params):
+        return out
+    out = list(out)
+    for i, p in enumerate(fctx.params):
+        g = out[2 + i]
+        if g is not None:
+            call("geossl_axpy", ptr(p.grad), ptr(g.contiguous()), 1.0, g.numel(), ptr(p.grad), stream())
+            out[2 + i] = None
+    return out
+
+
 def _run_grad_node(node, fctx, dhout, want_pos, want_params):
     params = list(fctx.params)
     mask = [bool(want_pos)] + [bool(want_params and p.requires_grad) for p in params]
@@ -300,11 +310,16 @@ def _run_grad_node(node, fctx, dhout, want_pos, want_params):
     return vals[0], vals[1:]
 
 
-def _second_order(features, mask, need, cot, dhout, pos, params):
+def _second_order(features, tape_features, mask, need, cot, dhout, pos, params):
     """The derivative of the first-order gradients (d pos, d params given d h), contracted with their cotangents `cot`:
-    the primitive restatement `features(pos, params)` differentiated twice.  `need`: which of (dhout, pos, *params) get
-    a gradient."""
+    the primitive restatement of the backbone differentiated twice - on the library's own tape (geossl_amd/tape.py:
+    every primitive a HIP kernel, no autograd engine), or, when the caller asks for a graph of THIS derivative too (a
+    third order) or GEOSSL_SECOND_ORDER=torch, as a torch autograd graph over `features(pos, params)`.  `need`: which of
+    (dhout, pos, *params) get a gradient."""
     higher = torch.is_grad_enabled()  # read OUTSIDE the block below: a third-order graph only if the caller wants one
+    if not higher and os.environ.get("GEOSSL_SECOND_ORDER", "tape") != "torch":
+        from . import tape
+        return tape.second_order(tape_features, mask, need, cot, dhout, pos, params)
     with torch.enable_grad():
         dh = dhout.detach().requires_grad_(need[0])
         ps = [p.detach().requires_grad_(True) for p in params]
@@ -340,6 +355,7 @@ class SchNetGradNode(torch.autograd.Function):
         from .Geom3D.models.schnet import _SchNetCore
         dpos, grads = _SchNetCore.fused_backward(fctx, dhout, mask[0], any(mask[1:]), allow_direct=False)
         ctx.fctx, ctx.mask = fctx, mask
+        ctx.set_materialize_grads(False)   # an output nobody differentiates arrives as None, not as a zero tensor
         ctx.save_for_backward(dhout, pos, *params)
         vals = [dpos] + list(grads)
         return tuple(v for v, m in zip(vals, mask) if m)
@@ -348,9 +364,11 @@ class SchNetGradNode(torch.autograd.Function):
     def backward(ctx, *cot):
         fctx = ctx.fctx
         dhout, pos, *params = ctx.saved_tensors
-        out = _second_order(lambda x, ps: schnet_atom_features(fctx.z, x, fctx.lay, fctx.cfg, ps), ctx.mask,
+        from . import tape
+        out = _second_order(lambda x, ps: schnet_atom_features(fctx.z, x, fctx.lay, fctx.cfg, ps),
+                            lambda x, ps: tape.schnet_atom_features(fctx.z, x, fctx.lay, fctx.cfg, ps), ctx.mask,
                             ctx.needs_input_grad[2:], cot, dhout, pos, params)
-        return (None, None) + tuple(out)
+        return (None, None) + tuple(_deliver(fctx, out))
 
 
 class PaiNNGradNode(torch.autograd.Function):
@@ -366,6 +384,7 @@ class PaiNNGradNode(torch.autograd.Function):
         from .Geom3D.models.painn import _PaiNNCore
         dpos, grads = _PaiNNCore.fused_backward(fctx, dq, mask[0], any(mask[1:]), allow_direct=False)
         ctx.fctx, ctx.mask = fctx, mask
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(dq, pos, *params)
         vals = [dpos] + list(grads)
         return tuple(v for v, m in zip(vals, mask) if m)
@@ -375,6 +394,8 @@ class PaiNNGradNode(torch.autograd.Function):
         fctx = ctx.fctx
         dq, pos, *params = ctx.saved_tensors
         el = fctx.el
-        out = _second_order(lambda x, ps: painn_atom_features(fctx.z, x, el.idx_i, el.idx_j, fctx.cfg, ps), ctx.mask,
+        from . import tape
+        out = _second_order(lambda x, ps: painn_atom_features(fctx.z, x, el.idx_i, el.idx_j, fctx.cfg, ps),
+                            lambda x, ps: tape.painn_atom_features(fctx.z, x, el.idx_i, el.idx_j, fctx.cfg, ps, el.inc), ctx.mask,
                             ctx.needs_input_grad[2:], cot, dq, pos, params)
-        return (None, None) + tuple(out)
+        return (None, None) + tuple(_deliver(fctx, out))

@@ -396,3 +396,53 @@ class _RowNormalize(torch.autograd.Function):
 def row_normalize(h, eps=1e-12):
     _lib.require_cuda(h)
     return _RowNormalize.apply(h, eps)
+
+
+class _EnergyForceLoss(torch.autograd.Function):
+    """finetune_md17.py:46-51 after the position gradient: pred_force = -dE/dpos and
+    loss = c_E * criterion(pred_energy, actual_energy) + c_F * criterion(pred_force, actual_force), criterion = L1Loss
+    (:236) or MSELoss, as one node on the element-wise / reduction kernels of csrc/tape.hip (fixed summation order)."""
+
+    @staticmethod
+    def forward(ctx, pred_energy, actual_energy, dE_dpos, actual_force, c_e, c_f, kind):
+        from . import tape as tp
+        pe, ae = _f32(pred_energy).reshape(1, -1), _f32(actual_energy).reshape(1, -1)
+        gp, af = _f32(dE_dpos).reshape(1, -1), _f32(actual_force).reshape(1, -1)
+        ne, nf = pe.size(1), gp.size(1)
+        de = tp._raw_binary(tp.SUB, pe, tp.FULL, ae, tp.FULL, 1, ne)
+        df = tp._raw_binary(tp.ADD, gp, tp.FULL, af, tp.FULL, 1, nf, -1.0)       # (-dE/dpos) - actual_force
+        if kind == "l1":
+            te, tf = tp._raw_unary(tp.ABS, de), tp._raw_unary(tp.ABS, df)
+        else:
+            te, tf = tp._raw_binary(tp.MUL, de, tp.FULL, de, tp.FULL, 1, ne), tp._raw_binary(tp.MUL, df, tp.FULL, df, tp.FULL, 1, nf)
+        se = tp._raw_unary(tp.AFFINE, tp._raw_reduce(tp.ROW, te), c_e / max(ne, 1))
+        sf = tp._raw_unary(tp.AFFINE, tp._raw_reduce(tp.ROW, tf), c_f / max(nf, 1))
+        ctx.save_for_backward(de, df)
+        ctx.meta = (c_e / max(ne, 1), c_f / max(nf, 1), kind, pred_energy.shape, dE_dpos.shape)
+        return tp._raw_binary(tp.ADD, se, tp.FULL, sf, tp.FULL, 1, 1).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import tape as tp
+        de, df = ctx.saved_tensors
+        we, wf, kind, shape_e, shape_f = ctx.meta
+        g = g.contiguous().view(1, 1)
+        if kind == "l1":
+            de, df, fe, ff = tp._raw_unary(tp.SIGN, de), tp._raw_unary(tp.SIGN, df), we, -wf
+        else:
+            fe, ff = 2.0 * we, -2.0 * wf
+        d_pe = tp._raw_binary(tp.MUL, de, tp.FULL, g, tp.ROW, 1, de.size(1), fe) if ctx.needs_input_grad[0] else None
+        d_gp = tp._raw_binary(tp.MUL, df, tp.FULL, g, tp.ROW, 1, df.size(1), ff) if ctx.needs_input_grad[2] else None
+        return (None if d_pe is None else d_pe.view(shape_e), None, None if d_gp is None else d_gp.view(shape_f), None,
+                None, None, None)
+
+
+def energy_force_loss(pred_energy, actual_energy, dE_dpos, actual_force, energy_coeff=0.05, force_coeff=0.95, loss="l1"):
+    """The training loss of finetune_md17.py:46-51 from the energies and the position gradient of their sum
+    (``dE_dpos = grad(pred_energy, positions, ones, create_graph=True)[0]``; the force is its negative) - on the
+    library's kernels, so that a train-on-forces step launches no ATen arithmetic (config.py:59-60 for the defaults)."""
+    if loss not in ("l1", "mse"):
+        raise ValueError("loss is 'l1' (finetune_md17.py:236) or 'mse'")
+    _lib.require_cuda(pred_energy, actual_energy, dE_dpos, actual_force)
+    return _EnergyForceLoss.apply(pred_energy, actual_energy, dE_dpos, actual_force, float(energy_coeff),
+                                  float(force_coeff), loss)

@@ -647,6 +647,38 @@ int geossl_painn_mix_post_bwd_dyn(const float* dq_new, const float* dmu_new, con
 int geossl_painn_mix_pre_bwd_dyn(const float* dq_new, const float* dctx, const float* ctx, const float* mm, int64_t N,
                                  int F, float* dq_in, float* dmm, const int32_t* dyn_N, hipStream_t stream);
 
+/* ---- Second-order route (training on forces): the primitives of geossl_amd/tape.py that are not dense products --------
+ * Replaces, on the route that differentiates a force again (examples/finetune_md17.py:46-54: pred_force =
+ * -grad(E, pos, create_graph=True); loss.backward()), the ATen element-wise / index kernels autograd would launch for
+ * Geom3D/models/schnet.py:93,186,205-207,213-216 (distance, cosine envelope, Gaussian smearing, shifted softplus) and
+ * Geom3D/models/painn.py:54-64,100-113, painn_utils.py:99-103,152-154 (gathers, index_add, split / cat, the xyz
+ * broadcasts).  fp32, row-major [R][D]; PaiNN's [n][3][F] is the matrix [3 n][F].  No atomics: fixed summation order.
+ * geossl_tape_unary:  y = f(alpha x + beta); kind: 0 affine, 1 exp, 2 cos, 3 sin, 4 shifted softplus, 5 sigmoid,
+ *   6 s(1-s), 7 s(1-s)(1-2s), 8 reciprocal, 9 sqrt, 10 silu, 11 silu', 12 silu'', 13 exp(alpha x^2), 14 and 15 its first
+ *   and second derivative in x, 16 (x < alpha), 17 |t|, 18 sign(t), 19 -1/t^2, 20 2/t^3,
+ *   21 t^-1/2, 22 t^-3/2.
+ * geossl_tape_binary: y[r][c] = scale * (A op B), op: 0 add, 1 sub, 2 mul, 3 A alone (a broadcast written out);
+ *   operand modes: 0 [R][D], 1 [R] (per row), 2 [D] (per column), 3 [R/3][D] (the row r / 3; R a multiple of 3).
+ * geossl_tape_reduce: the adjoints of those broadcasts: kind 1 row sums -> [R], 2 column sums -> [D] (workspace of
+ *   geossl_tape_colsum_workspace_floats(R, D) floats), 3 sums over the xyz triple -> [R/3][D].
+ * geossl_tape_gather_rows: out[e] = src[idx[e]] (idx int64 when idx64, else int32); geossl_tape_scatter_rows: its
+ *   adjoint over a sorted incidence list: out[n] = sum of src[perm[k]], k in [ptr[n], ptr[n+1]) in ascending k (ptr
+ *   int64 when ptr64, else int32 - the incidence lists of a PaiNN edge layout are taken as they are).
+ * geossl_tape_copy2d: dst[r][c] = src[r][c] for an R x C block of two row-major matrices with row strides ld_*;
+ * geossl_tape_fill: dst[i] = value.                                                                                  */
+int geossl_tape_unary(int kind, const float* x, int64_t n, float alpha, float beta, float* y, hipStream_t stream);
+int geossl_tape_binary(int op, const float* a, int amode, const float* b, int bmode, int64_t R, int D, float scale,
+                       float* y, hipStream_t stream);
+int64_t geossl_tape_colsum_workspace_floats(int64_t R, int D);
+int geossl_tape_reduce(int kind, const float* x, int64_t R, int D, float* y, float* workspace, hipStream_t stream);
+int geossl_tape_gather_rows(const float* src, const void* idx, int idx64, int64_t E, int D, float* out,
+                            hipStream_t stream);
+int geossl_tape_scatter_rows(const float* src, const void* ptr, int ptr64, const int32_t* perm, int64_t N, int D,
+                             float* out, hipStream_t stream);
+int geossl_tape_copy2d(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t R, int C,
+                       hipStream_t stream);
+int geossl_tape_fill(float* dst, int64_t n, float value, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
