@@ -538,7 +538,7 @@ class _PaiNNCore(torch.autograd.Function):
              ptr(wsf), 0, dN, st)
         tmp[0].zero_()
         if direct:
-            g_emb.add_(tmp)
+            call("geossl_axpy", ptr(g_emb), ptr(tmp), 1.0, tmp.numel(), ptr(g_emb), st)
             return dpos, [None] * len(grads)
         g_emb.copy_(tmp)
         # ctx.saved stays: finetune_md17.py:46 differentiates with retain_graph=True and runs this node again

@@ -326,6 +326,34 @@ __global__ __launch_bounds__(512) void k_painn_interaction_fwd_mol(
   }
 }
 
+// First index p in [0, n) with src[p] >= key (src non-decreasing), found by all threads of the block together
+// (blockDim.x-ary: the probes of a round are in flight together; two or three rounds instead of log2(n) dependent
+// loads).  `scratch`: 16 ints of the block's (dynamic) LDS - __syncthreads_count would add static LDS to a kernel that
+// asks for all 160 KB.
+template <typename T>
+__device__ __forceinline__ int block_lower_bound(const T* __restrict__ src, int n, int64_t key, int* scratch) {
+  int lo = 0, hi = n;
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  while (lo < hi) {
+    const int len = hi - lo, step = (len + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int p = lo + (int)threadIdx.x * step;
+    const bool below = p < hi && (int64_t)src[p] < key;
+    const int cw = __popcll(__ballot(below));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[wave] = cw;
+    __syncthreads();
+    int c = 0;
+    for (int w = 0; w < nw; ++w) c += scratch[w];
+    if (c == 0) { hi = lo; break; }
+    if (step == 1) { lo += c; break; }
+    const int nlo = lo + (c - 1) * step + 1, nhi = min(hi, lo + c * step);
+    lo = nlo;
+    hi = nhi;
+  }
+  __syncthreads();
+  return lo;
+}
+
 // backward: persistent blocks over molecules; the upstream gradients of the molecule's atoms staged in LDS; the
 // filter-network gradient partials of the block's thread groups are summed through LDS: one partial per block
 template <int R>
@@ -335,9 +363,28 @@ __global__ __launch_bounds__(512) void k_painn_interaction_bwd_mol(
     const int32_t* __restrict__ inc_idx, const float* __restrict__ phi, const float* __restrict__ fcut,
     const float* __restrict__ dir, const float* __restrict__ Wf, const float* __restrict__ bf,
     const int32_t* __restrict__ mol_ptr, int B, int max_n, int F, float* __restrict__ dxc, float* __restrict__ dmu_in,
-    float* __restrict__ partial_w, float* __restrict__ partial_b) {
+    float* __restrict__ partial_w, float* __restrict__ partial_b, int N, int balance) {
   extern __shared__ __attribute__((aligned(16))) float sm_rows[];
   const int G = blockDim.x / F, g = threadIdx.x / F, f = threadIdx.x - g * F;
+  // balance: block b owns the atoms whose incidence lists lie in the b-th of gridDim.x equal shares of the edge array
+  // (a contiguous atom range [at_lo, at_hi), found in the list offsets) and walks the molecules that range touches -
+  // a molecule at a boundary is staged by both neighbours, each taking its own atoms.  Ragged batches: a block per
+  // molecule in turn leaves the launch waiting for whoever drew the largest molecules (set C, 2 x 128 molecules: the
+  // 72-atom molecule's block runs four times the average).  The assignment is a function of the lists alone, so the
+  // block partials and their fixed-order sum stay reproducible.
+  int at_lo = 0, at_hi = 0x7fffffff, m_first = blockIdx.x, m_step = gridDim.x;
+  if (balance) {
+    int* scratch = reinterpret_cast<int*>(sm_rows);
+    const int64_t E = inc_ptr[N];
+    const int64_t e_lo = E * (int64_t)blockIdx.x / (int64_t)gridDim.x, e_hi = E * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x;
+    at_lo = blockIdx.x == 0 ? 0 : block_lower_bound(inc_ptr, N + 1, e_lo, scratch);
+    at_hi = blockIdx.x == gridDim.x - 1 ? N : block_lower_bound(inc_ptr, N + 1, e_hi, scratch);
+    at_lo = min(at_lo, N);
+    at_hi = min(at_hi, N);
+    // the molecule that holds atom at_lo: the last m with mol_ptr[m] <= at_lo
+    m_first = max(0, block_lower_bound(mol_ptr, B + 1, (int64_t)at_lo + 1, scratch) - 1);
+    m_step = 1;
+  }
   float w0[R], w1[R], w2[R], g0[R], g1[R], g2[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -348,9 +395,12 @@ __global__ __launch_bounds__(512) void k_painn_interaction_bwd_mol(
   }
   const float b0 = bf[f], b1 = bf[F + f], b2 = bf[2 * F + f];
   float gb0 = 0.0f, gb1 = 0.0f, gb2 = 0.0f;
-  for (int m = blockIdx.x; m < B; m += gridDim.x) {
+  for (int m = m_first; m < B; m += m_step) {
     const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0;
+    if (a0 >= at_hi) break;
     if (n > max_n) continue;  // (more atoms than LDS rows: the caller covers the molecule with the per-atom kernel)
+    const int ja_lo = max(at_lo - a0, 0), ja_hi = min(at_hi - a0, n);   // this block's atoms of the molecule
+    if (ja_lo >= ja_hi) continue;
     float* gqs = sm_rows;                  // [n][F]   dq_out rows
     float* gms = sm_rows + (size_t)n * F;  // [n][3F]  dmu_out rows
     float* estage = sm_rows + (size_t)max_n * 4 * F + (threadIdx.x >> 6) * (ECHUNK * EdgeStage<R>::EROW);  // this wave's
@@ -362,7 +412,7 @@ __global__ __launch_bounds__(512) void k_painn_interaction_bwd_mol(
       for (int t = threadIdx.x; t < n * 3 * F / 4; t += blockDim.x) reinterpret_cast<f32x4*>(gms)[t] = b4[t];
     }
     __syncthreads();
-    for (int ja = g; ja < n; ja += G) {
+    for (int ja = ja_lo + g; ja < ja_hi; ja += G) {
       const int j = a0 + ja;
       const float* __restrict__ xj = xc + (size_t)j * 3 * F;
       const float* __restrict__ mj = mu + (size_t)j * 3 * F;
@@ -740,6 +790,14 @@ static int painn_interaction_bwd_mol_launch(const float* dq_out, const float* dm
         geossl_painn_interaction_bwd(dq_out, dmu_out, mu, xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, N, F, R,
                                      dxc, dmu_in, dWf, dbf, workspace, accumulate, stream);
   const int nb = (int)(B < GEOSSL_PAINN_BWD_MOL_BLOCKS ? B : GEOSSL_PAINN_BWD_MOL_BLOCKS);
+  // Batches whose largest molecule has more than twice the average number of atoms (Molecule3D with hydrogens: 72
+  // against 26; a capacity bucket's bounds stand in for both): equal shares of the edges per block - set C, 2 x 128
+  // molecules: 1.94 -> 1.68 ms per step.  Otherwise a block per molecule in turn, as up to round 4: with molecules of
+  // similar size there is little to balance and a molecule cut at a block boundary is staged twice (set B, 2 x 128:
+  // 1.15 against 1.18 ms; set A: 1.12 against 1.16).  GEOSSL_PAINN_BALANCE=0 / =1 force either form.
+  const char* balance_env = getenv("GEOSSL_PAINN_BALANCE");   // (read per call: tests switch it inside one process)
+  const int balance = balance_env ? (balance_env[0] == '0' ? 0 : 1) : (B * (int64_t)max_n > 2 * N ? 1 : 0);
+  if (N >= ((int64_t)1 << 31)) return (int)hipErrorInvalidValue;
   const size_t estage = (size_t)(4 * F / 64) * ECHUNK * (((R + 5 + 3) / 4) * 4);  // per-wave edge stages (floats)
   const size_t lds = ((stage + estage) > red ? (stage + estage) : red) * sizeof(float);
   if (lds > 160 * 1024)  // (rows + edge stages above the LDS: the per-atom form)
@@ -753,7 +811,7 @@ static int painn_interaction_bwd_mol_launch(const float* dq_out, const float* dm
     allow_big_lds(&k_painn_interaction_bwd_mol<RV>);                                                                \
     hipLaunchKernelGGL((k_painn_interaction_bwd_mol<RV>), dim3(nb), dim3(4 * F), lds, stream, dq_out, dmu_out, mu,  \
                        xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, mol_ptr, (int)B, max_n, F, dxc, dmu_in, \
-                       pw, pb);                                                                                     \
+                       pw, pb, (int)N, balance);                                                                    \
   } while (0)
   if (R == 20) LAUNCH_BWD_MOL(20); else if (R == 16) LAUNCH_BWD_MOL(16); else if (R == 8) LAUNCH_BWD_MOL(8);
   else return (int)hipErrorInvalidValue;

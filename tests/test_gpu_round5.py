@@ -611,6 +611,39 @@ def test_painn_oversized_molecules_go_to_the_per_atom_kernels_alone(monkeypatch)
         assert rel_err(grads[k].cpu(), P[k].grad) < TOL_GRAD, k
 
 
+def test_painn_backward_with_equal_shares_of_the_edges_per_block(monkeypatch):
+    """k_painn_interaction_bwd_mol on batches whose largest molecule is far above the average (Molecule3D with hydrogens):
+    every block owns an equal share of the edge array - a contiguous atom range found in the incidence-list offsets,
+    molecules at a boundary staged by both neighbours - instead of whole molecules in turn.  Against the round-4 form
+    (GEOSSL_PAINN_BALANCE=0): the atom-row gradients do not depend on who computes them (bit-identical input gradient of the
+    embedding rows, positions untouched), the filter-network gradient only in the order of the block partials; run twice,
+    the balanced form gives the same bits; sizes incl. single atoms, a molecule above the LDS rows and runs of tiny
+    molecules that several blocks' ranges skip entirely."""
+    from geossl_amd.synthetic import make_batch, molecule_sizes
+    rng = np.random.default_rng(5)
+    sizes = np.concatenate([molecule_sizes(70, "C", rng), np.array([1, 1, 2, 80, 1, 72, 3], dtype=np.int64)])
+    raw = make_batch(0, seed=56, sizes=sizes)
+    bt = _painn_batch(raw)
+    assert int(sizes.max()) * len(sizes) > 2 * int(sizes.sum())      # the rule that turns the balanced form on by itself
+
+    def run():
+        cfg, model = _painn_modules()
+        out, q = model(bt.x, bt.positions, bt.radius_edge_index, bt.batch, return_latent=True)
+        ((out ** 2).sum() + 0.5 * (q ** 2).sum()).backward()
+        return unique_named_grads(model)
+
+    auto = run()
+    monkeypatch.setenv("GEOSSL_PAINN_BALANCE", "1")
+    forced, again = run(), run()
+    monkeypatch.setenv("GEOSSL_PAINN_BALANCE", "0")
+    old = run()
+    for k in old:
+        assert torch.equal(forced[k], again[k]) and torch.equal(forced[k], auto[k]), k
+        assert rel_err(forced[k], old[k]) < 5e-6, k
+    # (the embedding gradient is a sum of atom-row gradients in atom order: no block partials in it)
+    assert torch.equal(forced["embedding.weight"], old["embedding.weight"])
+
+
 @pytest.mark.parametrize("fwd_split", [False, True])
 def test_painn_bucket_with_oversized_molecules_replays_bit_for_bit(fwd_split, monkeypatch):
     """The same split inside a capacity bucket: the lists of oversized molecules' atoms are device data rewritten per step
