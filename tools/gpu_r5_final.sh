@@ -41,6 +41,11 @@ rocprofv3 --kernel-trace -d $out/trace_painn -o t -- python3 bench.py --model pa
   python tools/rocpd_stats.py "$(ls $out/trace_painn/*.db $out/trace_painn/*/*.db 2>/dev/null | head -1)" 40; } > profiles/r05_bench_painn_${tag}_kernel_stats.txt
 python bench.py --model painn 2>/dev/null | tail -1 > profiles/r05_bench_painn_${tag}.json
 python bench.py --forward-only 2>/dev/null | tail -1 > profiles/r05_bench_forward_only_${tag}.json
+# train-on-forces steps: which kernels are not the library's (second order on the tape)
+bash tools/gpu_force_train_trace.sh $head 256 6 > /dev/null 2>&1
+cut -c1-200 gpurun_out/force_train_non_library_kernels.txt > profiles/r05_force_train_non_library_kernels.txt
+# long runs on never-repeating batches (memory, RSS and step time flat; captures)
+{ python tools/soak.py 3000 128 trainer painn C 2>&1 | tail -6; python tools/soak.py 3000 128 reference schnet C 2>&1 | tail -6; } > profiles/r05_soak_${tag}.txt
 mkdir -p $out/profiles; cp profiles/r05_* $out/profiles/ 2>/dev/null
 find $out -name "*.db" -delete; find $out -name "*.csv" -delete
 ls $out/profiles; tail -2 $out/refresh.log
