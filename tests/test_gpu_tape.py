@@ -347,3 +347,49 @@ def test_energy_force_loss_with_gradients_added_in_place_matches_the_written_out
     for p, w in zip(params, want):
         assert p.grad.data_ptr() >= flat.grad.data_ptr() and p.grad.data_ptr() < flat.grad.data_ptr() + 4 * flat.numel
         assert rel_err(p.grad.cpu(), w.cpu()) < TOL_GRAD
+
+
+@pytest.mark.parametrize("backbone", ["schnet", "painn"])
+def test_training_on_forces_of_a_batch_without_pairs_or_edges(backbone):
+    """Single-atom molecules: no pair slots (SchNet), no edges (PaiNN).  The force is zero, and loss.backward() through it
+    runs the tape on empty edge tensors (no GEMM is launched on zero rows): every gradient finite, the backbone's filter
+    parameters - reached through edges only - untouched, and the energy route's gradients equal to those of a step
+    without the force term."""
+    from geossl_amd.Geom3D.models.painn import Dense
+    if backbone == "schnet":
+        from geossl_amd.synthetic import make_batch
+        b = make_batch(0, seed=3, sizes=np.array([1, 1, 1, 1], dtype=np.int64))
+        model = product_schnet(dict(hidden_channels=128, num_filters=128, num_interactions=2, num_gaussians=51, cutoff=5.0,
+                                    node_class=9, readout="add"), DEV)
+        z, bat = t(b["x"], DEV)[:, 0], t(b["batch"], DEV)
+        rep_of = lambda pos: model(z, pos, bat)
+        positions = t(b["positions"], DEV)
+    else:
+        from test_gpu_round4 import _painn_model_and_batch
+        model, bt = _painn_model_and_batch([1, 1, 1, 1], seed=3)
+        assert bt.radius_edge_index.size(1) == 0
+        rep_of = lambda pos: model(bt.x, pos, bt.radius_edge_index, bt.batch)
+        positions = bt.positions
+    head = fill_module_(Dense(128, 1)).to(DEV)
+    params = [p for p in list(model.parameters()) + list(head.parameters()) if p.requires_grad]
+    y_e = torch.linspace(-1.0, 1.0, 4, device=DEV)
+    y_f = torch.full_like(positions, 0.25)
+    grads = {}
+    for with_force in (True, False):
+        pos = positions.clone().requires_grad_(True)
+        energy = head(rep_of(pos)).squeeze(1)
+        loss = ((energy - y_e) ** 2).mean()
+        if with_force:
+            force = -torch.autograd.grad(energy, pos, torch.ones_like(energy), create_graph=True, retain_graph=True)[0]
+            assert float(force.detach().abs().max()) == 0.0
+            loss = loss + 10.0 * ((force - y_f) ** 2).mean()
+        for p in params:
+            p.grad = None
+        loss.backward()
+        grads[with_force] = [None if p.grad is None else p.grad.clone() for p in params]
+    for a, b_ in zip(grads[True], grads[False]):
+        if a is None or b_ is None:
+            assert (a is None or float(a.abs().max()) == 0.0) and (b_ is None or float(b_.abs().max()) == 0.0)
+            continue
+        assert torch.isfinite(a).all()
+        assert rel_err(a.cpu(), b_.cpu()) < 1e-6 or float((a - b_).abs().max()) < 1e-7
