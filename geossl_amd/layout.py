@@ -185,6 +185,9 @@ def work_items_bound(n, targets=False):
     return XCD * (-(-int(parts.sum()) // XCD) + int(parts.max()))
 
 
+_QUEUE_GRID = {}
+
+
 def aggregate_work_list(n, targets=False):
     """Work list of geossl_cfconv_aggregate_work for molecules of `n` atoms (int64 array), as int32 words: every
     molecule as geossl_aggregate_parts(size) items molecule | part << 24 (targets: one item per atom, molecule | atom << 24,
@@ -192,23 +195,32 @@ def aggregate_work_list(n, targets=False):
     [k Q, (k + 1) Q)): the molecules are dealt to the queues largest first in snake order (balanced sums), the items of a
     molecule are consecutive entries of its queue - workgroup b of the launch takes entry b / 8 of queue b mod 8, i.e.
     runs on XCD b mod 8: items that read each other's filter rows share an L2."""
+    M = len(n)
+    if M == 0:
+        return np.empty(0, dtype=np.int32)
     idx = np.argsort(-n, kind="stable")
-    parts = n[idx] if targets else parts_table()[n][idx]
-    r = np.arange(len(idx), dtype=np.int64)
-    q = np.where((r // XCD) % 2 == 0, r % XCD, XCD - 1 - r % XCD)         # queue of the molecule of rank r
-    mol = np.repeat(idx, parts)
-    ends = np.cumsum(parts)
-    total = int(ends[-1]) if len(ends) else 0
-    part = np.arange(total, dtype=np.int64) - np.repeat(ends - parts, parts)
+    parts_sorted = n[idx] if targets else parts_table()[n][idx]
+    grid = _QUEUE_GRID.get(M)
+    if grid is None:   # rank of queue k's t-th molecule (snake order), a function of the molecule count alone
+        t = np.arange(-(-M // XCD), dtype=np.int64)[None, :]
+        k = np.arange(XCD, dtype=np.int64)[:, None]
+        rank = t * XCD + np.where(t % 2 == 0, k, XCD - 1 - k)
+        valid = rank < M
+        if len(_QUEUE_GRID) > 64:
+            _QUEUE_GRID.clear()
+        grid = _QUEUE_GRID[M] = (np.minimum(rank, M - 1), valid)
+    rank, valid = grid
+    pq = np.where(valid, parts_sorted[rank], 0)                 # [XCD, T]: items of each molecule, queue-major
+    cnt = pq.sum(axis=1)
+    flat_parts = pq[valid]                                      # queue by queue, rank order inside a queue
+    mol = np.repeat(idx[rank[valid]], flat_parts)
+    total = mol.size
+    ends = np.cumsum(flat_parts)
+    part = np.arange(total, dtype=np.int64) - np.repeat(ends - flat_parts, flat_parts)
     words = (mol | (part << 24)).astype(np.uint32).view(np.int32)
-    qi = np.repeat(q, parts)
-    order = np.argsort(qi, kind="stable")                                  # queue-major, rank order kept inside a queue
-    cnt = np.bincount(qi, minlength=XCD)
-    Q = int(cnt.max()) if total else 0
-    out = np.full((XCD, Q), -1, dtype=np.int32)
     starts = np.concatenate([[0], np.cumsum(cnt)[:-1]])
-    pos = np.arange(total, dtype=np.int64) - np.repeat(starts, cnt)
-    out[qi[order], pos] = words[order]
+    out = np.full((XCD, int(cnt.max())), -1, dtype=np.int32)
+    out[np.repeat(np.arange(XCD), cnt), np.arange(total, dtype=np.int64) - np.repeat(starts, cnt)] = words
     return out.reshape(-1)
 
 

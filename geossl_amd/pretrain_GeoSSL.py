@@ -773,7 +773,7 @@ class _ReplayedLoss(torch.autograd.Function):
         g = src * gout
         # one split for all parameters, then a reshape each (two tensor operations per parameter were a third of this
         # backward's host time at 59 parameters - and the host is what bounds the loop at small batches)
-        outs = [v.view(shape) for v, (shape, _) in zip(g.split_with_sizes(eng.numels), eng.shapes)]
+        outs = [v if len(shape) == 1 else v.view(shape) for v, (shape, _) in zip(g.split_with_sizes(eng.numels), eng.shapes)]
         return (None, None, None) + tuple(outs)
 
 
@@ -970,7 +970,9 @@ class _AutogradStep:
         self._ticket = _Ticket(serial=self._serial, event=self._bwd_done, g=None)
         _single_thread_backward(self._ticket)
         buf = torch.empty_like(self.gflat)   # this step's (scaled) gradients as autograd will receive them
-        self._ticket["views"] = (buf, [v.view(shape) for v, (shape, _) in zip(buf.split_with_sizes(self.numels), self.shapes)])
+        # (a one-dimensional parameter's piece of the split already has its shape: no view for the biases - half the list)
+        self._ticket["views"] = (buf, [v if len(shape) == 1 else v.view(shape)
+                                       for v, (shape, _) in zip(buf.split_with_sizes(self.numels), self.shapes)])
         # deferred index check of the backbone: the embedding kernel flagged an out-of-range atom type in the status
         # word, but model.forward's own arm() does nothing while a graph is captured and a replay never reaches it -
         # read the word here like DDMTrainer.step does (IndexError up to eight steps late, like Embedding's, not never)

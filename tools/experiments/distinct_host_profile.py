@@ -1,4 +1,4 @@
-# host profile of a never-repeating bench line:  python3 tools/experiments/distinct_host_profile.py trainer/set=B/distinct
+# host profile of a never-repeating bench line:  python3 tools/experiments/distinct_host_profile.py trainer/set=B/distinct [callees-of]
 import cProfile, io, os, pstats, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -14,5 +14,10 @@ r = bench.run_secondary(name, dev, 0, 1)
 pr.disable()
 print({k: r[k] for k in r if k in ("value", "ms_per_step", "captures", "error")})
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40)
-print(s.getvalue()[:7000])
+st = pstats.Stats(pr, stream=s)
+if len(sys.argv) > 2:
+    for fn in sys.argv[2:]:
+        st.sort_stats("cumtime").print_callees(fn)
+else:
+    st.sort_stats("tottime").print_stats(40)
+print(s.getvalue()[:12000])
