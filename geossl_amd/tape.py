@@ -184,15 +184,10 @@ class Index:
     def csr(self):
         if self._csr is None:
             idx = self.idx.long()
-            if idx.numel():
-                perm = torch.argsort(idx, stable=True).to(torch.int32)
-                counts = torch.bincount(idx, minlength=self.nrows)
-            else:
-                perm = torch.empty(0, dtype=torch.int32, device=idx.device)
-                counts = torch.zeros(self.nrows, dtype=torch.int64, device=idx.device)
-            ptr_ = torch.zeros(self.nrows + 1, dtype=torch.int32, device=idx.device)
-            ptr_[1:] = torch.cumsum(counts, 0).to(torch.int32)
-            self._csr = (ptr_, perm)
+            # stable integer sort + a binary search for the list ends: no host read-back (torch.bincount would make one)
+            sorted_idx, perm = torch.sort(idx, stable=True)
+            ptr_ = torch.searchsorted(sorted_idx, torch.arange(self.nrows + 1, dtype=torch.int64, device=idx.device))
+            self._csr = (ptr_, perm.to(torch.int32))
         return self._csr
 
 
