@@ -393,3 +393,26 @@ def test_training_on_forces_of_a_batch_without_pairs_or_edges(backbone):
             continue
         assert torch.isfinite(a).all()
         assert rel_err(a.cpu(), b_.cpu()) < 1e-6 or float((a - b_).abs().max()) < 1e-7
+
+
+def test_painn_second_order_with_padding_atoms_matches_the_torch_graph_route(monkeypatch):
+    """Atom type 0 is PaiNN's padding row (painn.py:174 padding_idx=0): its embedding row is read in the forward and gets
+    no gradient - also not through the force.  Tape against the torch-graph route on a batch with such atoms, a single
+    atom and a two-atom molecule."""
+    from test_gpu_round4 import _painn_model_and_batch
+    model, bt = _painn_model_and_batch([7, 12, 1, 2, 9], seed=6)
+    bt.x[::4, 0] = 0
+    head = fill_module_(model.create_output_layers()).to(DEV)
+    B = 5
+    g = {"positions": bt.positions.cpu().numpy(), "x": bt.x.cpu().numpy(), "batch": bt.batch.cpu().numpy(),
+         "radius_edge_index": bt.radius_edge_index.cpu().numpy(),
+         "actual_energy": np.linspace(-1.0, 1.0, B).astype(np.float32),
+         "actual_force": (0.1 * np.random.default_rng(2).normal(size=tuple(bt.positions.shape))).astype(np.float32)}
+    res = {}
+    for route in ("tape", "torch"):
+        monkeypatch.setenv("GEOSSL_SECOND_ORDER", route)
+        res[route] = _force_training_grads(model, head, g, True)
+    assert float(res["tape"]["embedding.weight"][0].abs().max()) == 0.0
+    assert float(res["tape"]["embedding.weight"].abs().max()) > 0.0
+    for k, v in res["torch"].items():
+        assert rel_err(res["tape"][k].cpu(), v.cpu()) < TOL_GRAD, k
