@@ -64,6 +64,39 @@ __global__ void k_silu_bwd(const float* __restrict__ u, const float* __restrict_
   }
 }
 
+// Per-wave stage of the edges of one atom: lane k fetches the data of the k-th edge of the chunk with ordinary vector
+// loads - its radial-basis row, cutoff value, direction and the atom at the other end - and writes them as one row of
+// EROW floats; the edge loop then reads a row with broadcast LDS reads.  (Fetched through the scalar unit inside the
+// loop, every edge paid a chain of L2 round trips: index -> row -> LDS address; the loop ran at ~1.2 us per edge.)
+constexpr int ECHUNK = 16;               // edges per chunk (an atom has ~16 incoming edges at 5 A)
+template <int R>
+struct EdgeStage {
+  static constexpr int EROW = ((R + 5 + 3) / 4) * 4;  // phi[R], fcut, dir[3], other atom (int bits), padded to 16 bytes
+  // lanes 0 .. cnt-1: edge inc_idx[pc + lane] -> row `lane` of the wave's stage
+  static __device__ __forceinline__ void fill(float* __restrict__ stage, int lane, int cnt, int64_t pc,
+                                              const int32_t* __restrict__ inc_idx, const int64_t* __restrict__ idx_other,
+                                              const float* __restrict__ phi, const float* __restrict__ fcut,
+                                              const float* __restrict__ dir) {
+    if (lane < cnt) {
+      const int e = inc_idx[pc + lane];
+      float* row = stage + lane * EROW;
+      const float* __restrict__ p = phi + (size_t)e * R;
+      if constexpr (R % 4 == 0) {
+#pragma unroll
+        for (int r = 0; r < R; r += 4) *reinterpret_cast<f32x4*>(row + r) = *reinterpret_cast<const f32x4*>(p + r);
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) row[r] = p[r];
+      }
+      row[R] = fcut[e];
+      row[R + 1] = dir[3 * e];
+      row[R + 2] = dir[3 * e + 1];
+      row[R + 3] = dir[3 * e + 2];
+      row[R + 4] = __int_as_float((int)idx_other[e]);
+    }
+  }
+};
+
 // ------------------------------------------------------------------------------------ interaction, forward
 // q_out[i] = q[i] + sum_e dq_e, mu_out[i] = mu[i] + sum_e (dmuR_e * dir_e + dmumu_e * mu[j_e]),  e over edges with
 // idx_i[e] == i in ascending e;  [dq, dmuR, dmumu]_e = W_e * x[j_e]  (painn.py:54-64)
@@ -88,31 +121,57 @@ __global__ __launch_bounds__(128) void k_painn_interaction_fwd(
     w2[r] = Wf[(size_t)(2 * F + f) * R + r];
   }
   const float b0 = bf[f], b1 = bf[F + f], b2 = bf[2 * F + f];
+  // Round 5: the data of an atom's edges through the per-wave stage of the molecule kernels (one edge per lane, vector
+  // loads, broadcast LDS reads in the loop) and the source rows of edge k + 1 requested while edge k is multiplied.
+  // Fetched through the scalar unit inside the loop, an edge cost a chain of three dependent round trips (list entry
+  // -> source atom -> rows): 2.5 us per edge, 80 us for an atom with 32 edges whatever the size of the launch - the
+  // time of a whole launch at the reference's batch size (set C, 2 x 128 molecules: 106 us -> see DESIGN 3.2).
+  __shared__ __attribute__((aligned(16))) float estage_s[2 * ECHUNK * EdgeStage<R>::EROW];
+  float* estage = estage_s + (threadIdx.x >> 6) * (ECHUNK * EdgeStage<R>::EROW);
+  const int lane_ = threadIdx.x & 63;
   for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
   const int i = atom_list != nullptr ? atom_list[k] : k;
   float dq = 0.0f, dm0 = 0.0f, dm1 = 0.0f, dm2 = 0.0f;
   const int64_t p0 = inc_ptr[i], p1 = inc_ptr[i + 1];
-  for (int64_t p = p0; p < p1; ++p) {
-    const int e = __builtin_amdgcn_readfirstlane(inc_idx[p]);  // uniform: edge data comes through scalar loads
-    const int64_t j = idx_j[e];
-    const float* __restrict__ ph = phi + (size_t)e * R;
-    float W0 = b0, W1 = b1, W2 = b2;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float pr = ph[r];
-      W0 = fmaf(pr, w0[r], W0);
-      W1 = fmaf(pr, w1[r], W1);
-      W2 = fmaf(pr, w2[r], W2);
+  for (int64_t pc = p0; pc < p1; pc += ECHUNK) {
+    const int cntc = (int)min((int64_t)ECHUNK, p1 - pc);
+    EdgeStage<R>::fill(estage, lane_, cntc, pc, inc_idx, idx_j, phi, fcut, dir);
+    float nx0, nx1, nx2, nm0, nm1, nm2;
+    {
+      const int j0 = __float_as_int(estage[R + 4]);
+      const float* __restrict__ xj = xc + (size_t)j0 * 3 * F;
+      const float* __restrict__ mj = mu + (size_t)j0 * 3 * F;
+      nx0 = xj[f]; nx1 = xj[F + f]; nx2 = xj[2 * F + f];
+      nm0 = mj[f]; nm1 = mj[F + f]; nm2 = mj[2 * F + f];
     }
-    const float fc = fcut[e];
-    W0 *= fc; W1 *= fc; W2 *= fc;                                  // painn.py:241
-    const float* __restrict__ xj = xc + (size_t)j * 3 * F;
-    const float x0 = W0 * xj[f], x1 = W1 * xj[F + f], x2 = W2 * xj[2 * F + f];  // :56
-    const float* __restrict__ mj = mu + (size_t)j * 3 * F;
-    dq += x0;                                                      // :59
-    dm0 += x1 * dir[3 * e] + x2 * mj[f];                           // :60-61
-    dm1 += x1 * dir[3 * e + 1] + x2 * mj[F + f];
-    dm2 += x1 * dir[3 * e + 2] + x2 * mj[2 * F + f];
+    // (four edges' rows at a time, the next four in flight: 152 registers instead of 116, three waves per SIMD instead
+    // of four - 80 against 71 us on the set-C launch; the issue floor of the filter arithmetic is ~45 us)
+    for (int kk = 0; kk < cntc; ++kk) {
+      const float* row = estage + kk * EdgeStage<R>::EROW;
+      const float xj0 = nx0, xj1 = nx1, xj2 = nx2, mj0 = nm0, mj1 = nm1, mj2 = nm2;
+      if (kk + 1 < cntc) {  // (uniform) the next edge's source rows: in flight during this edge's arithmetic
+        const int jn = __float_as_int(row[EdgeStage<R>::EROW + R + 4]);
+        const float* __restrict__ xj = xc + (size_t)jn * 3 * F;
+        const float* __restrict__ mj = mu + (size_t)jn * 3 * F;
+        nx0 = xj[f]; nx1 = xj[F + f]; nx2 = xj[2 * F + f];
+        nm0 = mj[f]; nm1 = mj[F + f]; nm2 = mj[2 * F + f];
+      }
+      float W0 = b0, W1 = b1, W2 = b2;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float pr = row[r];
+        W0 = fmaf(pr, w0[r], W0);
+        W1 = fmaf(pr, w1[r], W1);
+        W2 = fmaf(pr, w2[r], W2);
+      }
+      const float fc = row[R];
+      W0 *= fc; W1 *= fc; W2 *= fc;                                  // painn.py:241
+      const float x0 = W0 * xj0, x1 = W1 * xj1, x2 = W2 * xj2;       // :56
+      dq += x0;                                                      // :59
+      dm0 += x1 * row[R + 1] + x2 * mj0;                             // :60-61
+      dm1 += x1 * row[R + 2] + x2 * mj1;
+      dm2 += x1 * row[R + 3] + x2 * mj2;
+    }
   }
   q_out[(size_t)i * F + f] = q[(size_t)i * F + f] + dq;            // :63
   float* mo = mu_out + (size_t)i * 3 * F;
@@ -147,6 +206,9 @@ __global__ __launch_bounds__(128) void k_painn_interaction_bwd(
   }
   const float b0 = bf[f], b1 = bf[F + f], b2 = bf[2 * F + f];
   float gb0 = 0.0f, gb1 = 0.0f, gb2 = 0.0f;
+  __shared__ __attribute__((aligned(16))) float estage_s[2 * ECHUNK * EdgeStage<R>::EROW];
+  float* estage = estage_s + (threadIdx.x >> 6) * (ECHUNK * EdgeStage<R>::EROW);
+  const int lane_ = threadIdx.x & 63;
   for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
     const int j = atom_list != nullptr ? atom_list[k] : k;
     const float* __restrict__ xj = xc + (size_t)j * 3 * F;
@@ -155,41 +217,54 @@ __global__ __launch_bounds__(128) void k_painn_interaction_bwd(
     const float m0 = mj[f], m1 = mj[F + f], m2 = mj[2 * F + f];
     float dx0 = 0.0f, dx1 = 0.0f, dx2 = 0.0f, dmj0 = 0.0f, dmj1 = 0.0f, dmj2 = 0.0f;
     const int64_t p0 = inc_ptr[j], p1 = inc_ptr[j + 1];
-    for (int64_t p = p0; p < p1; ++p) {
-      const int e = __builtin_amdgcn_readfirstlane(inc_idx[p]);
-      const int64_t i = idx_i[e];
-      const float* __restrict__ ph = phi + (size_t)e * R;
-      float pr[R];
-      float W0 = b0, W1 = b1, W2 = b2;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        pr[r] = ph[r];
-        W0 = fmaf(pr[r], w0[r], W0);
-        W1 = fmaf(pr[r], w1[r], W1);
-        W2 = fmaf(pr[r], w2[r], W2);
+    for (int64_t pc = p0; pc < p1; pc += ECHUNK) {   // (staged edges, next edge's rows in flight: see the forward kernel)
+      const int cntc = (int)min((int64_t)ECHUNK, p1 - pc);
+      EdgeStage<R>::fill(estage, lane_, cntc, pc, inc_idx, idx_i, phi, fcut, dir);
+      float ngq, ng0, ng1, ng2;
+      {
+        const int i0 = __float_as_int(estage[R + 4]);
+        const float* __restrict__ gm = dmu_out + (size_t)i0 * 3 * F;
+        ngq = dq_out[(size_t)i0 * F + f];
+        ng0 = gm[f]; ng1 = gm[F + f]; ng2 = gm[2 * F + f];
       }
-      const float fc = fcut[e];
-      W0 *= fc; W1 *= fc; W2 *= fc;
-      const float gq = dq_out[(size_t)i * F + f];
-      const float* __restrict__ gm = dmu_out + (size_t)i * 3 * F;
-      const float gm0 = gm[f], gm1 = gm[F + f], gm2 = gm[2 * F + f];
-      const float s1 = gm0 * dir[3 * e] + gm1 * dir[3 * e + 1] + gm2 * dir[3 * e + 2];
-      const float s2 = gm0 * m0 + gm1 * m1 + gm2 * m2;
-      dx0 = fmaf(gq, W0, dx0);
-      dx1 = fmaf(s1, W1, dx1);
-      dx2 = fmaf(s2, W2, dx2);
-      const float x2 = W2 * xj2;
-      dmj0 = fmaf(gm0, x2, dmj0);
-      dmj1 = fmaf(gm1, x2, dmj1);
-      dmj2 = fmaf(gm2, x2, dmj2);
-      // W_c = (b_c + sum_r phi_r w_c[r]) * fcut
-      const float t0 = gq * xj0 * fc, t1 = s1 * xj1 * fc, t2 = s2 * xj2 * fc;
-      gb0 += t0; gb1 += t1; gb2 += t2;
+      for (int kk = 0; kk < cntc; ++kk) {
+        const float* row = estage + kk * EdgeStage<R>::EROW;
+        const float gq = ngq, gm0 = ng0, gm1 = ng1, gm2 = ng2;
+        if (kk + 1 < cntc) {
+          const int in_ = __float_as_int(row[EdgeStage<R>::EROW + R + 4]);
+          const float* __restrict__ gm = dmu_out + (size_t)in_ * 3 * F;
+          ngq = dq_out[(size_t)in_ * F + f];
+          ng0 = gm[f]; ng1 = gm[F + f]; ng2 = gm[2 * F + f];
+        }
+        float pr[R];
+        float W0 = b0, W1 = b1, W2 = b2;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        g0[r] = fmaf(t0, pr[r], g0[r]);
-        g1[r] = fmaf(t1, pr[r], g1[r]);
-        g2[r] = fmaf(t2, pr[r], g2[r]);
+        for (int r = 0; r < R; ++r) {
+          pr[r] = row[r];
+          W0 = fmaf(pr[r], w0[r], W0);
+          W1 = fmaf(pr[r], w1[r], W1);
+          W2 = fmaf(pr[r], w2[r], W2);
+        }
+        const float fc = row[R];
+        W0 *= fc; W1 *= fc; W2 *= fc;
+        const float s1 = gm0 * row[R + 1] + gm1 * row[R + 2] + gm2 * row[R + 3];
+        const float s2 = gm0 * m0 + gm1 * m1 + gm2 * m2;
+        dx0 = fmaf(gq, W0, dx0);
+        dx1 = fmaf(s1, W1, dx1);
+        dx2 = fmaf(s2, W2, dx2);
+        const float x2 = W2 * xj2;
+        dmj0 = fmaf(gm0, x2, dmj0);
+        dmj1 = fmaf(gm1, x2, dmj1);
+        dmj2 = fmaf(gm2, x2, dmj2);
+        // W_c = (b_c + sum_r phi_r w_c[r]) * fcut
+        const float t0 = gq * xj0 * fc, t1 = s1 * xj1 * fc, t2 = s2 * xj2 * fc;
+        gb0 += t0; gb1 += t1; gb2 += t2;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          g0[r] = fmaf(t0, pr[r], g0[r]);
+          g1[r] = fmaf(t1, pr[r], g1[r]);
+          g2[r] = fmaf(t2, pr[r], g2[r]);
+        }
       }
     }
     float* dxo = dxc + (size_t)j * 3 * F;
@@ -219,39 +294,6 @@ __global__ __launch_bounds__(128) void k_painn_interaction_bwd(
 // LDS.  The atoms of the molecule are dealt to the block's thread groups (F threads each, one feature per thread);
 // the sums of an atom are formed by one thread in the edge order of the incidence list - bit for bit the per-atom
 // kernels' results.
-// Per-wave stage of the edges of one atom: lane k fetches the data of the k-th edge of the chunk with ordinary vector
-// loads - its radial-basis row, cutoff value, direction and the atom at the other end - and writes them as one row of
-// EROW floats; the edge loop then reads a row with broadcast LDS reads.  (Fetched through the scalar unit inside the
-// loop, every edge paid a chain of L2 round trips: index -> row -> LDS address; the loop ran at ~1.2 us per edge.)
-constexpr int ECHUNK = 16;               // edges per chunk (an atom has ~16 incoming edges at 5 A)
-template <int R>
-struct EdgeStage {
-  static constexpr int EROW = ((R + 5 + 3) / 4) * 4;  // phi[R], fcut, dir[3], other atom (int bits), padded to 16 bytes
-  // lanes 0 .. cnt-1: edge inc_idx[pc + lane] -> row `lane` of the wave's stage
-  static __device__ __forceinline__ void fill(float* __restrict__ stage, int lane, int cnt, int64_t pc,
-                                              const int32_t* __restrict__ inc_idx, const int64_t* __restrict__ idx_other,
-                                              const float* __restrict__ phi, const float* __restrict__ fcut,
-                                              const float* __restrict__ dir) {
-    if (lane < cnt) {
-      const int e = inc_idx[pc + lane];
-      float* row = stage + lane * EROW;
-      const float* __restrict__ p = phi + (size_t)e * R;
-      if constexpr (R % 4 == 0) {
-#pragma unroll
-        for (int r = 0; r < R; r += 4) *reinterpret_cast<f32x4*>(row + r) = *reinterpret_cast<const f32x4*>(p + r);
-      } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) row[r] = p[r];
-      }
-      row[R] = fcut[e];
-      row[R + 1] = dir[3 * e];
-      row[R + 2] = dir[3 * e + 1];
-      row[R + 3] = dir[3 * e + 2];
-      row[R + 4] = __int_as_float((int)idx_other[e]);
-    }
-  }
-};
-
 template <int R>
 __global__ __launch_bounds__(512) void k_painn_interaction_fwd_mol(
     const float* __restrict__ q, const float* __restrict__ mu, const float* __restrict__ xc,
