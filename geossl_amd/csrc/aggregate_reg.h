@@ -265,6 +265,10 @@ __device__ __forceinline__ void aggregate_targets(const float* __restrict__ x, c
         w[k] = *reinterpret_cast<const V*>(wcol + (size_t)sk * F);
         xb[k] = *reinterpret_cast<const V*>(xcol + (size_t)bk * F);
       }
+      // ALL 64 requests of the chunk before the first use: left alone, the scheduler trades registers for occupancy and
+      // interleaves the sums with the requests - the generated code had ten requests each followed by a full wait
+      // (vmcnt(0)): a dozen dependent round trips per target instead of one
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         const V t = xb[k] * w[k];

@@ -308,7 +308,9 @@ __global__ __launch_bounds__(64, 2) void k_aggregate_reg_work(
 // most of the chip idles.  Here every work item is ONE target atom (work word = molecule | target << 24): a single round
 // trip of <= 32 partner rows for the molecules of the size classes, the same fixed summation order.  Every filter row is
 // read by both of its atoms (twice the bytes): this form is for launches that are latency-, not bandwidth-bound.
-__global__ __launch_bounds__(64, 4) void k_aggregate_targets(
+// (second launch bound = waves per SIMD the compiler must leave room for: 2 -> up to 256 registers; a target's 64 rows in
+// flight need 128 of them)
+__global__ __launch_bounds__(64, 2) void k_aggregate_targets(
     const float* __restrict__ x, const float* __restrict__ Wf, const uint8_t* __restrict__ pair_flag,
     const int32_t* __restrict__ mol_ptr, const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ work,
     int nwork, int F, int swap, float* __restrict__ out, const int32_t* __restrict__ dyn_nwork) {
