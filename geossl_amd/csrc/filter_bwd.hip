@@ -858,6 +858,9 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
     const int r0 = t * TR;
     const int bsel = t & 1;
     FBH_MARK(0);
+#ifdef FBH_HALF_BARRIERS   // (timing experiment only, results are wrong: one barrier pair per TWO tiles - what a 64-row tile would save in barriers)
+    if (!(t & 1))
+#endif
     lds_barrier();  // previous tile fully consumed; this tile's staging buffer published (LDS only: the requests for the
                     // tiles ahead stay in flight; measured neutral against __syncthreads here)
     FBH_MARK(1);
@@ -980,6 +983,9 @@ __device__ __forceinline__ void filter_bwd_body_h(const float* __restrict__ pair
 #pragma unroll
     for (int r = 0; r < 16; ++r) tcur[r] = tc[r];
     FBH_MARK(2);
+#ifdef FBH_HALF_BARRIERS
+    if (!(t & 1))
+#endif
     lds_barrier();
     FBH_MARK(3);
     // While this tile is multiplied: publish the next tile's staging buffer (its atoms were requested one tile ago
