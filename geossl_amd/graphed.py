@@ -66,7 +66,16 @@ class GraphedForward:
     def _capture(self, batch):
         import gc
         import warnings
-        x, pos, bvec = batch.x.clone(), batch.positions.clone(), batch.batch
+        # The graph binds the ADDRESSES of the index structures (mol_ptr, pair_ptr, pair atoms, aggregation work list, the
+        # loop plan), which are cached on the batch vector (`_geossl_layout`).  The entry therefore owns a private clone of
+        # that vector - with the host-side sizes re-attached, so the clone builds the same layout - and keeps vector and
+        # layout alive for as long as the graph: the caller's batch may be freed (an eval loop over a loader) without the
+        # caching allocator handing those addresses to someone else.
+        x, pos = batch.x.clone(), batch.positions.clone()
+        bvec = batch.batch.clone()
+        hs = getattr(batch.batch, "_geossl_sizes", None)   # (host sizes, tensor version), layout.prepare_batch
+        if hs is not None and hs[1] == batch.batch._version:
+            bvec._geossl_sizes = (hs[0], bvec._version)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):   # warm-up off the capture: cached layouts, kernel attributes, the loop's block plan
@@ -91,4 +100,4 @@ class GraphedForward:
             if gc_on:
                 gc.enable()
         self.captures += 1
-        return dict(graph=graph, x=x, pos=pos, out=out)
+        return dict(graph=graph, x=x, pos=pos, out=out, batch_vec=bvec, layout=get_layout(bvec))

@@ -188,7 +188,7 @@ class _SiluGrad(torch.autograd.Function):
         u, g = ctx.saved_tensors
         if not torch.is_grad_enabled():   # second order (training on forces): silu' and silu'' as kernels
             from . import tape
-            c = c.contiguous()
+            c, u = c.contiguous(), u.contiguous()   # the raw maps walk flat buffers of numel() elements
             shape, n = u.shape, u.numel()
             flat = lambda t: t.reshape(1, n)
             d1 = tape._raw_unary(tape.DSILU, u)

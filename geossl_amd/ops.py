@@ -444,5 +444,11 @@ def energy_force_loss(pred_energy, actual_energy, dE_dpos, actual_force, energy_
     if loss not in ("l1", "mse"):
         raise ValueError("loss is 'l1' (finetune_md17.py:236) or 'mse'")
     _lib.require_cuda(pred_energy, actual_energy, dE_dpos, actual_force)
+    # the kernels walk flat buffers of pred_energy.numel() / dE_dpos.numel() elements: a target of another size would be
+    # read past its end (torch's L1Loss / MSELoss raise or broadcast here; broadcasting targets is not supported)
+    if actual_energy.numel() != pred_energy.numel():
+        raise ValueError("actual_energy has %d elements, pred_energy %d" % (actual_energy.numel(), pred_energy.numel()))
+    if tuple(actual_force.shape) != tuple(dE_dpos.shape):
+        raise ValueError("actual_force has shape %s, dE_dpos %s" % (tuple(actual_force.shape), tuple(dE_dpos.shape)))
     return _EnergyForceLoss.apply(pred_energy, actual_energy, dE_dpos, actual_force, float(energy_coeff),
                                   float(force_coeff), loss)

@@ -1,0 +1,91 @@
+"""CPU tests added in round 6: the bench line the driver parses (compact, strict JSON, bounded size whatever the run
+measured)."""
+import json
+import os
+import sys
+
+import pytest
+
+from conftest import REPO
+
+sys.path.insert(0, REPO)
+
+
+def _dummy_detail(n_secondary=40, prose=2000):
+    """A detail object shaped like bench.py's, with paragraph-long strings and awkward numbers in every place one has
+    ever appeared."""
+    long = "x" * prose
+    sec = {"trainer/some/very/long/secondary/name/number=%d/distinct" % i:
+           {"value": 123456.789012345 + i, "unit": "molecules/s", "ms_per_step": 1.234567890123, "steps": 480, "warmup": 0,
+            "workload": long, "execution": long, "final_loss": float("nan"), "p50_ms": 1.2, "graphs": 1, "captures": 1,
+            "roofline": {"kernel": "k", "peak_note": long}} for i in range(n_secondary)}
+    sec["broken"] = {"error": "RuntimeError: " + long}
+    return {
+        "metric": "molecules/s/GPU SchNet+DDM fwd+bwd (QM9-sized, bs=1024); % HBM roofline", "value": 411111.123456789,
+        "unit": "molecules/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 2.4912345678, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": long, "api": "trainer", "parallelism": "dp1", "backend": None, "world_size_initialised": 1,
+                   "arithmetic": long, "execution": long,
+                   "product_bits": {"filter_fwd": 22, "filter_bwd": 22, "atom_row_chains": 22, "weight_gradients": 22,
+                                    "ncsn_head_fwd": 24, "ncsn_head_bwd": 22, "accumulate": "fp32"}},
+        "roofline": {"kernel": "geossl_cfconv_filter_bwd", "bound": "mfma", "unit": "TFLOP/s", "traffic": 1311658920.0,
+                     "traffic_from": long, "avg_launch_ms": 0.81456338763237, "launches_per_step": 1.0, "timing": long,
+                     "achieved": 567.2296786908015, "peak": 2500.0, "frac": 0.2268918714763206, "peak_note": long,
+                     "hbm_frac": float("inf")},
+        "step_roofline": {"measured_MB_per_mol": 8.89, "measured_hbm_frac": 0.44, "measured_from": long,
+                          "model_hbm_frac": 1.11, "model_fp32_frac": 1.37, "alg_MB_per_mol": 22.4, "alg_MFLOP_per_mol": 542.4},
+        "step_ms_percentiles": {"p10": 2.5477, "p50": 2.5744, "p90": 2.6094},
+        "kernel_ms": {"k%d" % i: {"avg_ms": 0.1, "per_step": 1.0} for i in range(10)},
+        "final_loss": 55.5, "secondary": sec, "value_24bit": 286000.123456,
+        "parity_vs_oracle": {"molecules": 1024, "oracle_loss": 82.8,
+                             "22bit": {"loss": 82.8, "loss_rel_err": 1.9e-7, "worst_grad_rel_err": 7.7e-6, "worst_grad": "model.x"},
+                             "24bit": {"loss": 82.8, "loss_rel_err": 1.0e-7, "worst_grad_rel_err": 2.0e-6, "worst_grad": "model.y"}},
+        "cpu_baseline": {"value": 143.3, "unit": "molecules/s", "cores": 32, "kind": "port", "sample": long,
+                         "sample_short": "oracle DDM step"},
+    }
+
+
+def _strict(text):
+    def bad(c):
+        raise ValueError("non-finite constant %r in the line" % c)
+    return json.loads(text, parse_constant=bad)
+
+
+def test_bench_line_is_compact_strict_json():
+    """BENCH_r05.parsed was null because the one line had grown to 24 KB.  The line is now built by
+    bench.compact_line from the detail object: under 8 KB (4 KB for a run of today's size) and strict JSON - no NaN /
+    Infinity tokens - with every key the driver's contract names, `roofline` and `cpu_baseline`."""
+    import bench
+    text = bench.compact_line(_dummy_detail(n_secondary=26, prose=3000))
+    assert "\n" not in text and len(text) < bench.LINE_TARGET + 1024, len(text)
+    line = _strict(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "value_24bit", "parity_vs_oracle"):
+        assert k in line, k
+    assert line["config"]["workload"] and len(line["config"]["workload"]) <= 160 and "model" not in line["config"]
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert line["roofline"]["hbm_frac"] is None                      # the inf of the dummy
+    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}
+    assert all(set(v) <= {"value", "ms_per_step", "steps", "error"} for v in line["secondary"].values())
+    assert line["secondary"]["broken"]["error"].startswith("RuntimeError")
+    assert abs(line["value"] - 411111.123456789) < 1.0
+
+
+def test_bench_line_stays_under_the_limit_whatever_the_run_holds():
+    import bench
+    text = bench.compact_line(_dummy_detail(n_secondary=400, prose=50000))
+    assert len(text) < bench.LINE_LIMIT
+    line = _strict(text)
+    assert line["secondary_truncated"] is True and line["value"] > 0 and line["roofline"] and line["cpu_baseline"]
+
+
+def test_bench_emit_prints_the_compact_line_last(capsys, tmp_path, monkeypatch):
+    import bench
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    bench.emit(_dummy_detail(n_secondary=3, prose=100))
+    out, err = capsys.readouterr()
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < bench.LINE_TARGET
+    line = _strict(lines[0])
+    detail = json.load(open(os.path.join(str(tmp_path), line["detail"])))
+    assert detail["config"]["execution"].startswith("x") and err.startswith("bench detail: {")
