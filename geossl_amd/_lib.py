@@ -96,6 +96,13 @@ class CopyBatch(C.Structure):
     _fields_ = [("dst", vp * COPY_MAX), ("src", vp * COPY_MAX), ("bytes", i64 * COPY_MAX)]
 
 
+class Gather(C.Structure):
+    _fields_ = [(k, vp) for k in ("x_src", "pos_src", "src_off", "mol_ptr", "x_dst", "pos_dst", "batch_dst", "se_ptr", "sei0",
+                                  "sei1", "pair_ptr2", "pair_i", "pair_j", "inc_ptr", "inc_idx", "e0_src", "e1_src",
+                                  "e_src_off", "e_ptr", "e0_dst", "e1_dst", "zero")] + \
+               [("zero_count", i64), ("x_cols", i32), ("option", i32)]
+
+
 P = C.POINTER
 # name -> (restype, argtypes); mirrors include/geossl_hip.h one to one
 PROTOTYPES = {
@@ -224,6 +231,7 @@ PROTOTYPES = {
     "geossl_painn_mix_post_fwd_dyn": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp]),
     "geossl_painn_mix_post_bwd_dyn": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp]),
     "geossl_painn_mix_pre_bwd_dyn": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp, vp]),
+    "geossl_gather_molecules": (i32, [P(Gather), i64, vp]),
 }
 
 _lib = None

@@ -139,6 +139,8 @@ def eligible(batch, model_3d, normalize=False):
     lo, hi = size_range(batch)
     if lo < 1 or hi > MAX_N or hi < 2:
         return False
+    if getattr(batch, "_dataset", None) is not None:   # a handle on a device-resident dataset: gathered by the fill itself
+        return model_3d != "painn" or batch.n_edges is not None
     if model_3d == "painn":
         rei = getattr(batch, "radius_edge_index", None)
         if (rei is None or not rei.is_cuda or rei.dtype != torch.long or rei.dim() != 2 or rei.size(0) != 2
@@ -319,7 +321,12 @@ class Bucket:
             from .layout import painn_stage_caps
             self.big_caps = tuple(c for c in painn_stage_caps(128, 20) if 0 < c < self.max_n)
         o["big1"] = o["big0"] + (2 * Nc if len(self.big_caps) > 0 else 0)
-        self.words = o["big1"] + (2 * Nc if len(self.big_caps) > 1 else 0)
+        # a batch drawn from a device-resident dataset (Geom3D.dataloaders.DeviceDataset): where its molecules' atoms and
+        # (PaiNN) radius edges start in the dataset, and the edge offsets of the batch
+        o["src_off"] = o["big1"] + (2 * Nc if len(self.big_caps) > 1 else 0)
+        o["e_src_off"] = o["src_off"] + B
+        o["e_ptr"] = o["e_src_off"] + (B if kind == "painn" else 0)
+        self.words = o["e_ptr"] + (B + 1 if kind == "painn" else 0)
         self.off = o
         self.blob = torch.zeros(self.words, **i32)
         self.dims = self.blob[0:DIMS_WORDS]
@@ -372,6 +379,7 @@ class Bucket:
             el.dyn = self.dyn
             self.el = el
             self.e2 = torch.zeros(2, 1, **i64)   # placeholder for PaiNN.forward's radius_edge_index argument
+            self.rei = None                       # the collated edges of a batch drawn from a dataset (made on first use)
         # ---- super-edge bookkeeping of the heads
         sel = _SuperEdges()
         sel.sei0, sel.sei1, sel.batch = self.sei[0], self.sei[1], self.batch_vec
@@ -398,7 +406,11 @@ class Bucket:
 
     def fill(self, batch, counts=None, zero=None):
         """The batch's atom types, positions, index tensors and derived structures into the static buffers; `zero`: a
-        float32 buffer cleared by the same launch (the owner's flat gradient buffer)."""
+        float32 buffer cleared by the same launch (the owner's flat gradient buffer).  `batch`: a collated batch on the
+        device, or a handle on a device-resident dataset (Geom3D.dataloaders.DatasetBatch) whose molecules are gathered
+        from there.  One pinned upload (everything that is a function of the molecule sizes) + one launch
+        (geossl_gather_molecules: atom rows, batch vector, super-edges, pair-slot atoms, incidence lists, radius edges,
+        the cleared buffer) [+ geossl_painn_edge_layout]."""
         global _PARTS
         if _PARTS is None:
             _PARTS = _parts_table()
@@ -407,8 +419,16 @@ class Bucket:
         if n.shape[0] != B:
             raise ValueError("bucket of %d molecules got a batch of %d" % (B, n.shape[0]))
         N, P, S, W = counts if counts is not None else batch_counts(n, self.option)
+        ds = getattr(batch, "_dataset", None)
         rei, E = None, 0
-        if self.kind == "painn":
+        if ds is not None:
+            if ds.option != self.option or ds.x_cols != self.x.size(1) or ds.device != self.x.device:
+                raise ValueError("dataset and bucket disagree (tuple option, x columns or device)")
+            if self.kind == "painn":
+                if batch.n_edges is None:
+                    raise ValueError("PaiNN bucket fill expects a dataset built with radius=...")
+                E = batch.n_edges
+        elif self.kind == "painn":
             rei = batch.radius_edge_index
             if (rei is None or not rei.is_cuda or rei.dtype != torch.long or rei.dim() != 2 or rei.size(0) != 2
                     or rei.stride(1) != 1):
@@ -416,8 +436,7 @@ class Bucket:
             E = int(rei.size(1))
         if not self.fits((N, P, S, W), int(n.max()), E) or P < 1:
             raise ValueError("batch exceeds the bucket's capacity")
-        sei = batch.super_edge_index
-        if not tensors_ok(batch) or batch.x.size(1) != self.x.size(1):
+        if ds is None and (not tensors_ok(batch) or batch.x.size(1) != self.x.size(1)):
             raise ValueError("bucket fill expects contiguous collated int64 / float32 tensors of the sizes' shapes")
         slot = self._host[self._slot]
         self._slot = (self._slot + 1) % len(self._host)
@@ -442,23 +461,44 @@ class Bucket:
         st = h[o["stats"]:o["stats"] + 4].view(np.int64)
         st[0], st[1] = hp["divisor"], 0
         h[o["inc_ptr"]:o["inc_ptr"] + 2 * (N + 1)].view(np.int64)[:] = hp["inc_ptr"]
+        if ds is not None:
+            h[o["src_off"]:o["src_off"] + B] = ds.off[batch.ids]
+            if self.kind == "painn":
+                h[o["e_src_off"]:o["e_src_off"] + B] = ds.edge_off[batch.ids]
+                ep = h[o["e_ptr"]:o["e_ptr"] + B + 1]
+                ep[0] = 0
+                np.cumsum(ds.edge_cnt[batch.ids], out=ep[1:])
         self.blob.copy_(slot[0], non_blocking=True)
         slot[1] = torch.cuda.Event()
         slot[1].record()
-        # ---- device side: the five input tensors in one launch, then the per-slot index arrays
-        cb = _lib.CopyBatch()
-        jobs = [(self.x, batch.x, N * self.x.size(1) * 8), (self.positions, batch.positions, N * 12),
-                (self.batch_vec, batch.batch, N * 8), (self.sei[0], sei[0], S * 8), (self.sei[1], sei[1], S * 8)]
-        if zero is not None:
-            jobs.append((zero, None, zero.numel() * 4))  # (src NULL: a fill with zeros)
-        for k, (dst, src, nbytes) in enumerate(jobs):
-            cb.dst[k], cb.src[k], cb.bytes[k] = ptr(dst), (ptr(src) if src is not None else None), nbytes
-        st_ = stream()
-        call("geossl_copy_n", C.byref(cb), len(jobs), st_)
-        lay = self.lay2
+        # ---- device side: one launch
+        base = self.blob.data_ptr()
+        lay, sel = self.lay2, self.sel
+        g = _lib.Gather()
+        g.option, g.x_cols = (0 if self.option == "combination" else 1), self.x.size(1)
+        g.mol_ptr, g.se_ptr = base + 4 * o["mol_ptr"], base + 4 * o["se_ptr"]
+        g.x_dst, g.pos_dst, g.batch_dst = ptr(self.x), ptr(self.positions), ptr(self.batch_vec)
+        g.sei0, g.sei1 = ptr(self.sei[0]), ptr(self.sei[1])
+        if ds is not None:
+            g.x_src, g.pos_src, g.src_off = ptr(ds.x), ptr(ds.positions), base + 4 * o["src_off"]
+        else:   # a collated batch: its molecules start where the bucket's do (the extractor's enumeration is generated)
+            g.x_src, g.pos_src, g.src_off = ptr(batch.x), ptr(batch.positions), g.mol_ptr
         if self.kind == "schnet":
-            call("geossl_pair_index_fill", ptr(lay.mol_ptr), ptr(lay.pair_ptr), 2 * B, ptr(lay.pair_i), ptr(lay.pair_j), st_)
-        else:
+            g.pair_ptr2, g.pair_i, g.pair_j = base + 4 * o["pair_ptr"], ptr(lay.pair_i), ptr(lay.pair_j)
+        g.inc_ptr, g.inc_idx = ptr(sel.inc_ptr), ptr(sel.inc_idx)
+        if ds is not None and self.kind == "painn":
+            if self.rei is None:
+                self.rei = torch.zeros(2, max(self.E_cap, 1), dtype=torch.int64, device=self.device)
+            rei = self.rei
+            if E:
+                g.e0_src, g.e1_src = ptr(ds.edges[0]), ptr(ds.edges[1])
+                g.e_src_off, g.e_ptr = base + 4 * o["e_src_off"], base + 4 * o["e_ptr"]
+                g.e0_dst, g.e1_dst = ptr(rei[0]), ptr(rei[1])
+        if zero is not None:
+            g.zero, g.zero_count = ptr(zero), zero.numel()
+        st_ = stream()
+        call("geossl_gather_molecules", C.byref(g), B, st_)
+        if self.kind == "painn":
             el = self.el
             try:
                 self.el_status.poll()
@@ -469,9 +509,6 @@ class Bucket:
                  ptr(el.inc["j"][1]), ptr(el.row_edge), ptr(el.grp_atom), ptr(el.mol_grp), ptr(el.mol_grp_end),
                  ptr(el.status), st_)
             self.el_status.arm(every=8)
-        sel = self.sel
-        call("geossl_incidence_fill", ptr(sel.batch), ptr(sel.sei0), ptr(sel.sei1), ptr(sel.se_ptr), N, 3,
-             ptr(sel.inc_ptr), ptr(sel.inc_idx), st_)
         self.real = (N, P, S, W)
         self.real_E = E
         return self.real

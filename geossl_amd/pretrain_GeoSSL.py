@@ -326,6 +326,8 @@ def structure_fingerprint(batch, model_3d="schnet"):
     * Anything else (sampled tuples, PaiNN's geometry-dependent edge list, batches built by hand) is identified by
       the tensor OBJECTS and their versions: a graph is replayed only for the very tensors it was captured on (a
       device-resident, pre-collated batch that comes back every epoch)."""
+    if getattr(batch, "_dataset", None) is not None and model_3d != "painn":
+        return batch.fingerprint()   # a handle on a device-resident dataset: its index tensors ARE a function of the sizes
     tag = lambda t_: None if t_ is None else (_tensor_uid(t_), t_._version, tuple(t_.shape))
     rei = getattr(batch, "radius_edge_index", None) if model_3d == "painn" else None
     tags = (tag(batch.batch), tag(batch.super_edge_index), tag(rei))
@@ -445,7 +447,11 @@ class StepGraphs:
 
     def _edges(self, batch):
         """Edges of the batch's radius_edge_index (PaiNN; a tensor shape: no read-back), else None."""
-        return int(batch.radius_edge_index.size(1)) if self.model_3d == "painn" else None
+        if self.model_3d != "painn":
+            return None
+        if getattr(batch, "_dataset", None) is not None:
+            return batch.n_edges   # (the dataset's host-side edge counts)
+        return int(batch.radius_edge_index.size(1))
 
     def capture_now(self, batch):
         """Should a batch without a graph be captured at this sighting?  Buckets and equal-sized molecules: yes (their
@@ -513,9 +519,11 @@ class StepGraphs:
                                      sizes=bk.sizes_array(batch))
         del old  # (its graph and static buffers go before the larger ones are made)
         self._evict()
-        dev = batch.positions.device
+        from_ds = getattr(batch, "_dataset", None) is not None
+        dev = batch.device if from_ds else batch.positions.device
         try:
-            bkt = bk.Bucket(dev, len(batch._sizes), caps, batch._canonical, x_cols=batch.x.size(1), max_n=max_n,
+            bkt = bk.Bucket(dev, len(batch._sizes), caps, batch._canonical,
+                            x_cols=batch.x_cols if from_ds else batch.x.size(1), max_n=max_n,
                             kind=self.model_3d, E_cap=E_cap)
             bkt.fill(batch, counts)
         except (ValueError, RuntimeError) as e:
@@ -630,6 +638,11 @@ class StepGraphs:
             except ValueError as e:  # (tensors the bucket cannot copy: the caller runs this step eagerly)
                 warnings.warn("capacity bucket refused a batch (%s); the step runs eagerly" % e)
                 return False
+        elif getattr(batch, "_dataset", None) is not None:
+            # molecules of a device-resident dataset: gathered straight into the graph's static x / positions
+            from .layout import get_layout
+            sb = g["batch"]
+            batch._dataset.gather_into(batch, sb.x, sb.positions, get_layout(sb.batch).mol_ptr, zero)
         else:
             dx, dp, sx, sp = g["batch"].x, g["batch"].positions, batch.x, batch.positions
             if (sx.is_cuda and sp.is_cuda and sx.dtype == dx.dtype and sp.dtype == dp.dtype and sx.shape == dx.shape
@@ -684,8 +697,11 @@ def draw_step_noise(batch, n1, n2, mu, sigma, device_noise, given=None, into=Non
     and the distance noise (:194).  Entries of `given` are used instead of drawing; with `into` the results are written
     into those tensors (the static inputs of a graph) instead of new ones."""
     given = given or {}
-    dev = batch.positions.device
-    S, B = batch.super_edge_index.size(1), batch.num_graphs
+    if getattr(batch, "_dataset", None) is not None:   # (a dataset handle knows its counts without collated tensors)
+        dev, S, B = batch.device, batch.n_super, batch.num_graphs
+    else:
+        dev = batch.positions.device
+        S, B = batch.super_edge_index.size(1), batch.num_graphs
     out = {}
 
     def put(key, make, fill):
@@ -917,7 +933,7 @@ class _AutogradStep:
         return self.gflat
 
     def run(self, args, batch, mu, sigma, noise, device_noise):
-        if not batch.positions.is_cuda or batch.positions.requires_grad:
+        if getattr(batch, "_dataset", None) is None and (not batch.positions.is_cuda or batch.positions.requires_grad):
             return None
         key = (args.model_3d, bool(getattr(args, "normalize", False)))
         sg = self.graphs.get(key)

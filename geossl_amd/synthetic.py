@@ -63,6 +63,21 @@ def permutation_pairs(n):
     return np.stack([i, j]).astype(np.int64)
 
 
+def make_molecules(num_mols, seed=0, mode="A", n_fixed=18, sizes=None):
+    """A dataset of molecules without any index tensor: x [N,2] i64, positions [N,3] f32, sizes [M] i64 - the same
+    molecules make_batch(num_mols, seed, mode) collates (same random stream)."""
+    rng = np.random.default_rng(seed)
+    if sizes is None:
+        sizes = molecule_sizes(num_mols, mode, rng, n_fixed)
+    sizes = np.asarray(sizes, dtype=np.int64)
+    padded = grow_positions(sizes, rng)
+    N = int(sizes.sum())
+    mask = np.arange(padded.shape[1])[None, :] < sizes[:, None]
+    x = np.zeros((N, 2), dtype=np.int64)
+    x[:, 0] = rng.integers(0, 9, size=N)
+    return {"x": x, "positions": padded[mask], "sizes": sizes}
+
+
 def make_batch(num_mols, seed=0, mode="A", option="combination", n_fixed=18, sizes=None):
     """Collated synthetic batch as a dict of numpy arrays:
     x [N,2] i64, positions [N,3] f32, batch [N] i64, super_edge_index [2,S] i64, sizes [B] i64."""

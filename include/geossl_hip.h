@@ -679,6 +679,53 @@ int geossl_tape_copy2d(const float* src, int64_t ld_src, float* dst, int64_t ld_
                        hipStream_t stream);
 int geossl_tape_fill(float* dst, int64_t n, float value, hipStream_t stream);
 
+/* ---- batch assembly from a device-resident dataset (round 6) -------------------------------------------------------
+ * Replaces, for molecules that already live in HBM, the per-step host collation of the reference's loader:
+ * DataLoaderAtomTuple(dataset, batch_size, shuffle=True) (examples/pretrain_GeoSSL.py:295-301) ->
+ * BatchAtomTuple.from_data_list (Geom3D/dataloaders/dataloaders_AtomTuple.py:46-73) over molecules that went through
+ * AtomTupleExtractor (:15-37) and, for PaiNN, carry the radius_edge_index of datasets_3D_Radius.py:105-131.
+ * One block per chosen molecule m (B of them, in batch order):
+ *   x_dst / pos_dst rows [mol_ptr[m], mol_ptr[m+1]) = rows [src_off[m], ...) of x_src [*, x_cols] / pos_src [*, 3];
+ *   batch_dst[row] = m (:61; NULL: skipped);
+ *   sei0 / sei1 columns [se_ptr[m], se_ptr[m+1]) = the molecule's atom tuples + mol_ptr[m] (:64-65), option 0 =
+ *     "combination" (itertools.combinations order), 1 = "permutation" (NULL: skipped);
+ *   pair_i / pair_j = the pair-slot atoms of the TWO-VIEW batch (what geossl_pair_index_fill writes for the [2B+1]
+ *     arrays [mol_ptr ; mol_ptr[1:] + N], pair_ptr2; N = mol_ptr[B]) (NULL: skipped);
+ *   inc_idx entries [inc_ptr[a], inc_ptr[a+1]) of every atom a = its incident super-edges in ascending order (what
+ *     geossl_incidence_fill(sides = 3) finds for the enumerations above) (NULL: skipped);
+ *   e0_dst / e1_dst columns [e_ptr[m], e_ptr[m+1]) = columns [e_src_off[m], ...) of e0_src / e1_src with the node offset
+ *     changed from src_off[m] to mol_ptr[m] (:64-65) (NULL: skipped).
+ * zero (nullable): zero_count floats cleared by the same launch.  A collated batch is the special case src_off = mol_ptr.
+ * Every pointer array is device memory written before the launch reaches the stream; nothing is read back.           */
+typedef struct GeosslGather {
+  const int64_t* x_src;
+  const float* pos_src;
+  const int32_t* src_off;   /* [B] */
+  const int32_t* mol_ptr;   /* [B+1] */
+  int64_t* x_dst;
+  float* pos_dst;
+  int64_t* batch_dst;
+  const int32_t* se_ptr;    /* [B+1] */
+  int64_t* sei0;
+  int64_t* sei1;
+  const int32_t* pair_ptr2; /* [2B+1] */
+  int32_t* pair_i;
+  int32_t* pair_j;
+  const int64_t* inc_ptr;   /* [N+1] */
+  int32_t* inc_idx;
+  const int64_t* e0_src;
+  const int64_t* e1_src;
+  const int32_t* e_src_off; /* [B] */
+  const int32_t* e_ptr;     /* [B+1] */
+  int64_t* e0_dst;
+  int64_t* e1_dst;
+  float* zero;
+  int64_t zero_count;
+  int32_t x_cols;
+  int32_t option;
+} GeosslGather;
+int geossl_gather_molecules(const GeosslGather* g, int64_t B, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

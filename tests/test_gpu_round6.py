@@ -77,3 +77,202 @@ def test_energy_force_loss_rejects_mismatched_targets():
         ops.energy_force_loss(e, torch.randn(8, device=DEV), f, torch.randn(39, 3, device=DEV))
     with pytest.raises(ValueError):
         ops.energy_force_loss(e, torch.randn(8, device=DEV), f, torch.randn(3, 40, device=DEV))
+
+
+# ----------------------------------------------------------- device-resident dataset + molecule gather
+def _dataset(M, mode, seed, option="combination", radius=None):
+    from geossl_amd.Geom3D.dataloaders import DeviceDataset
+    from geossl_amd.synthetic import make_batch
+    pool = make_batch(M, seed=seed, mode=mode, option=option)
+    return pool, DeviceDataset.from_numpy(pool, DEV, option=option, radius=radius)
+
+
+@pytest.mark.parametrize("option", ["combination", "permutation"])
+def test_gathered_batch_is_the_collated_batch_bit_for_bit(option):
+    """geossl_gather_molecules against the host collation on the same molecule ids: synthetic.collate_subset (numpy) and
+    the reference's own surface - AtomTupleExtractor per molecule + BatchAtomTuple.from_data_list
+    (dataloaders_AtomTuple.py:15-37,46-73) - x, positions, batch, super_edge_index equal element for element; molecules
+    with one atom (no tuples) included."""
+    from geossl_amd.Geom3D.dataloaders import AtomTupleExtractor, BatchAtomTuple, Data
+    from geossl_amd.synthetic import collate_subset, make_batch
+    sizes = _ragged_sizes(300, 5, lo=1, hi=40, mean=14.0, sd=9.0)
+    sizes[[3, 77, 299]] = 1
+    pool = make_batch(0, seed=9, sizes=sizes, option=option)
+    from geossl_amd.Geom3D.dataloaders import DeviceDataset
+    ds = DeviceDataset.from_numpy(pool, DEV, option=option)
+    rng = np.random.default_rng(1)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    for trial in range(3):
+        ids = rng.permutation(300)[:64] if trial < 2 else np.array([3, 77, 5, 299])
+        hb = ds.batch(ids)
+        want = collate_subset(pool, ids, option=option)
+        assert hb.n_atoms == want["x"].shape[0] and hb.n_super == want["super_edge_index"].shape[1]
+        for k, got in (("x", hb.x), ("positions", hb.positions), ("batch", hb.batch), ("super_edge_index", hb.super_edge_index)):
+            assert got.dtype == t(want[k]).dtype and np.array_equal(got.cpu().numpy(), want[k]), (trial, k)
+        # the reference's surface on the same molecules
+        ext = AtomTupleExtractor(ratio=1, option=option)
+        mols = [ext(Data(x=t(pool["x"][off[m]:off[m + 1]]), positions=t(pool["positions"][off[m]:off[m + 1]]))) for m in ids]
+        ref = BatchAtomTuple.from_data_list(mols)
+        for k in ("x", "positions", "batch", "super_edge_index"):
+            assert torch.equal(getattr(hb, k).cpu(), ref[k]), (trial, k)
+        assert hb.num_graphs == ref.num_graphs and hb.to(DEV) is hb
+
+
+def test_dataset_radius_edges_are_the_per_molecule_radius_graphs():
+    """DeviceDataset(radius=5): radius_edge_index of every molecule built once on the device (datasets_3D_Radius.py:120,
+    SURVEY 8(f) N4); a gathered batch's radius_edge_index equals radius_graph on the collated clean geometry (the
+    reference collates per-molecule edge lists with the node offset, dataloaders_AtomTuple.py:64-65) - and the oracle's
+    numpy radius graph."""
+    from geossl_amd import ops
+    from geossl_amd.synthetic import collate_subset
+    from oracle import graph
+    pool, ds = _dataset(400, "C", 12, radius=5.0)
+    rng = np.random.default_rng(2)
+    for trial in range(2):
+        ids = rng.permutation(400)[:48]
+        hb = ds.batch(ids)
+        want = ops.radius_graph(hb.positions, 5.0, hb.batch)
+        assert hb.n_edges == want.size(1) and torch.equal(hb.radius_edge_index, want)
+    raw = collate_subset(pool, ids)
+    off = np.concatenate([[0], np.cumsum(raw["sizes"])])
+    ref = graph.collate_np([(raw["x"][off[m]:off[m + 1]], raw["positions"][off[m]:off[m + 1]]) for m in range(len(ids))],
+                           radius=5.0)["radius_edge_index"]
+    assert np.array_equal(hb.radius_edge_index.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("kind,mode,option", [("schnet", "B", "combination"), ("schnet", "C", "permutation"),
+                                               ("painn", "C", "combination")])
+def test_bucket_fill_from_the_dataset_writes_what_the_collated_fill_writes(kind, mode, option):
+    """Bucket.fill(handle) (one launch from the dataset) against Bucket.fill(collated batch): every static buffer of the
+    step - inputs, pair-slot atoms, incidence lists, the uploaded pointer arrays, PaiNN's edge structures - equal over
+    the real counts; and both equal to what the separate layout kernels (geossl_pair_index_fill,
+    geossl_incidence_fill on the collated tensors) produce."""
+    from geossl_amd import bucket as bk
+    from geossl_amd._lib import call, ptr, stream
+    B = 40
+    pool, ds = _dataset(500, mode, 21, option=option, radius=5.0 if kind == "painn" else None)
+    rng = np.random.default_rng(3)
+    idsets = [rng.permutation(500)[:B] for _ in range(3)]
+    counts = [bk.batch_counts(ds.sizes[ids], option) for ids in idsets]
+    caps = tuple(int(1.2 * max(c[k] for c in counts)) // 64 * 64 + 128 for k in range(4))
+    hi = int(max(ds.sizes[ids].max() for ids in idsets))
+    E_cap = 0
+    if kind == "painn":
+        E_cap = int(1.2 * max(ds.batch(ids).n_edges for ids in idsets)) // 64 * 64 + 128
+    mk = lambda: bk.Bucket(torch.device(DEV), B, caps, option, max_n=bk.max_n_class(hi, None, kind), kind=kind, E_cap=E_cap)
+    b_ds, b_co = mk(), mk()
+    zero_a, zero_b = torch.ones(1000003, device=DEV), torch.ones(1000003, device=DEV)
+    for ids in idsets:
+        hb = ds.batch(ids)
+        co = ds.collate(hb)
+        co._sizes, co._canonical = [int(n) for n in hb._sizes], option
+        N, P, S, W = b_ds.fill(hb, zero=zero_a)
+        assert (N, P, S, W) == b_co.fill(co, zero=zero_b)
+        assert not zero_a.any() and not zero_b.any()
+        zero_a.fill_(1.0), zero_b.fill_(1.0)
+        assert torch.equal(b_ds.blob[:b_ds.off["src_off"]], b_co.blob[:b_co.off["src_off"]])
+        for name, n_real in (("x", N), ("positions", N), ("batch_vec", N)):
+            assert torch.equal(getattr(b_ds, name)[:n_real], getattr(b_co, name)[:n_real]), name
+            assert torch.equal(getattr(b_ds, name)[:n_real], getattr(co, {"batch_vec": "batch"}.get(name, name))), name
+        assert torch.equal(b_ds.sei[:, :S], co.super_edge_index) and torch.equal(b_co.sei[:, :S], co.super_edge_index)
+        assert torch.equal(b_ds.sel.inc_idx[:2 * S], b_co.sel.inc_idx[:2 * S])
+        # the separate kernels on the collated tensors
+        inc = torch.full((2 * S,), -1, dtype=torch.int32, device=DEV)
+        call("geossl_incidence_fill", ptr(co.batch), ptr(co.super_edge_index[0]), ptr(co.super_edge_index[1]),
+             ptr(b_co.sel.se_ptr), N, 3, ptr(b_co.sel.inc_ptr), ptr(inc), stream())
+        assert torch.equal(inc, b_ds.sel.inc_idx[:2 * S])
+        if kind == "schnet":
+            lay = b_ds.lay2
+            assert torch.equal(lay.pair_i[:2 * P], b_co.lay2.pair_i[:2 * P]) and torch.equal(lay.pair_j[:2 * P], b_co.lay2.pair_j[:2 * P])
+            pi, pj = torch.full((2 * P,), -1, dtype=torch.int32, device=DEV), torch.full((2 * P,), -1, dtype=torch.int32, device=DEV)
+            call("geossl_pair_index_fill", ptr(lay.mol_ptr), ptr(lay.pair_ptr), 2 * B, ptr(pi), ptr(pj), stream())
+            assert torch.equal(pi, lay.pair_i[:2 * P]) and torch.equal(pj, lay.pair_j[:2 * P])
+        else:
+            E = hb.n_edges
+            assert b_ds.real_E == E == b_co.real_E and torch.equal(b_ds.rei[:, :E], co.radius_edge_index)
+            for a, b_ in ((b_ds.el.idx_i, b_co.el.idx_i), (b_ds.el.idx_j, b_co.el.idx_j)):
+                assert torch.equal(a[:2 * E], b_[:2 * E])
+            for side in ("i", "j"):
+                assert torch.equal(b_ds.el.inc[side][0][:2 * N + 1], b_co.el.inc[side][0][:2 * N + 1])
+                assert torch.equal(b_ds.el.inc[side][1][:2 * E], b_co.el.inc[side][1][:2 * E])
+            assert torch.equal(b_ds.el.mol_grp, b_co.el.mol_grp) and torch.equal(b_ds.el.mol_grp_end, b_co.el.mol_grp_end)
+            assert int(b_ds.el.status) == 0
+
+
+def _painn_modules6():
+    from geossl_amd.Geom3D.models import PaiNN
+    from helpers import fill_module_
+    return fill_module_(PaiNN(n_atom_basis=128, n_interactions=3, n_rbf=20, cutoff=5.0, max_z=9, n_out=1, readout="add")).to(DEV)
+
+
+@pytest.mark.parametrize("kind,mode", [("schnet", "B"), ("schnet", "A"), ("painn", "C")])
+def test_training_from_the_dataset_is_training_on_collated_batches_bit_for_bit(kind, mode):
+    """DDMTrainer.step on DatasetBatch handles (gather inside the step, no collated tensors) against the same trainer
+    on the collated batches of the same ids, same noise stream: ragged SchNet (capacity bucket), equal-sized molecules
+    (per-structure graph with the layer loop: x / positions gathered into its static inputs) and PaiNN with molecules
+    above 33 atoms - losses and parameters after six steps bit-identical; one capture each; no handle was collated after
+    the capture."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    B = 32
+    pool, ds = _dataset(600, mode, 31, radius=5.0 if kind == "painn" else None)
+    rng = np.random.default_rng(4)
+    idsets = [rng.permutation(600)[:B] for _ in range(6)]
+    # capacities must not depend on the order of sightings: the largest batch first
+    idsets.sort(key=lambda ids: -int((ds.sizes[ids] * (ds.sizes[ids] - 1)).sum()))
+    cfg = dict(SMALL)
+
+    def trainer():
+        model = _painn_modules6() if kind == "painn" else product_schnet(cfg, DEV)
+        return pg.DDMTrainer(model, product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9), lr=5e-4,
+                             model_3d=kind, use_graph=True)
+    out = {}
+    for how in ("dataset", "collated"):
+        tr = trainer()
+        torch.cuda.manual_seed(99)
+        losses, handles = [], []
+        for ids in idsets:
+            hb = ds.batch(ids)
+            if how == "collated":
+                bt = ds.collate(hb)
+                losses.append(tr.step(bt).clone())
+            else:
+                handles.append(hb)
+                losses.append(tr.step(hb).clone())
+        torch.cuda.synchronize()
+        assert tr.use_graph and tr.step_graphs.captures == 1, how
+        if how == "dataset":
+            assert all(h._batch is None for h in handles[1:])     # only the capture looked at collated tensors
+        out[how] = (torch.stack(losses), tr.flat.flat.detach().clone())
+    assert torch.equal(out["dataset"][0], out["collated"][0])
+    assert torch.equal(out["dataset"][1], out["collated"][1])
+    assert torch.isfinite(out["dataset"][0]).all()
+
+
+def test_reference_loop_runs_on_dataset_handles():
+    """The reference's loop body (pretrain_GeoSSL.py:248-260: batch.to(device), do_DDM, loss.item(), zero_grad, backward,
+    stock Adam) fed by DeviceLoader: same losses as on the collated batches of the same molecules, one capture."""
+    import types
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.Geom3D.dataloaders import DeviceLoader
+    pool, ds = _dataset(256, "B", 41)
+    out = {}
+    for how in ("dataset", "collated"):
+        model, n1, n2 = product_schnet(SMALL, DEV), product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9)
+        args = types.SimpleNamespace(model_3d="schnet", normalize=False, step_graph=True)
+        opt = torch.optim.Adam([{"params": model.parameters()}, {"params": n1.parameters()}, {"params": n2.parameters()}], lr=5e-4)
+        torch.manual_seed(5)
+        torch.cuda.manual_seed(5)
+        loader = DeviceLoader(ds, batch_size=32, shuffle=True, generator=torch.Generator().manual_seed(8))
+        assert len(loader) == 8
+        losses = []
+        for hb in loader:
+            batch = (hb if how == "dataset" else ds.collate(hb)).to(DEV)
+            loss, _ = pg.do_DDM(args, batch, model, NCSN_models=(n1, n2), mu=0.0, sigma=0.3)
+            losses.append(loss.detach().item())
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        out[how] = losses
+        eng = model.__dict__["_geossl_autograd_step"]
+        assert sum(sg.captures for sg in eng.graphs.values()) <= 2, how
+    assert out["dataset"] == out["collated"] and all(np.isfinite(v) for v in out["dataset"])

@@ -89,3 +89,33 @@ def test_bench_emit_prints_the_compact_line_last(capsys, tmp_path, monkeypatch):
     line = _strict(lines[0])
     detail = json.load(open(os.path.join(str(tmp_path), line["detail"])))
     assert detail["config"]["execution"].startswith("x") and err.startswith("bench detail: {")
+
+
+def test_device_loader_visits_molecules_in_the_order_of_torchs_shuffled_loader():
+    """DeviceLoader(shuffle=True) draws its permutation the way torch.utils.data.RandomSampler does (the sampler behind
+    DataLoaderAtomTuple(dataset, batch_size, shuffle=True), dataloaders_AtomTuple.py:81-88): under the same global seed
+    the same molecules meet in the same batches; the last short batch is kept or dropped like DataLoader's."""
+    import numpy as np
+    import torch
+    from torch.utils.data import DataLoader
+    from geossl_amd.Geom3D.dataloaders.device_dataset import DeviceLoader
+
+    class Stub:   # (only len() is needed to draw an order)
+        def __len__(self):
+            return 103
+
+    for drop_last in (False, True):
+        torch.manual_seed(123)
+        want = [list(b) for b in DataLoader(list(range(103)), batch_size=10, shuffle=True, drop_last=drop_last,
+                                            collate_fn=lambda items: items)]
+        torch.manual_seed(123)
+        ld = DeviceLoader(Stub(), batch_size=10, shuffle=True, drop_last=drop_last)
+        order = ld.order()
+        got = [order[k * 10:(k + 1) * 10].tolist() for k in range(len(ld))]
+        assert got == want and len(ld) == len(want)
+    want = [list(b) for b in DataLoader(list(range(103)), batch_size=10, shuffle=True, collate_fn=lambda items: items,
+                                        generator=torch.Generator().manual_seed(7))]
+    ld = DeviceLoader(Stub(), batch_size=10, shuffle=True, generator=torch.Generator().manual_seed(7))
+    order = ld.order()
+    assert [order[k * 10:(k + 1) * 10].tolist() for k in range(len(ld))] == want
+    assert DeviceLoader(Stub(), batch_size=10, shuffle=False).order().tolist() == list(range(103))
