@@ -325,6 +325,18 @@ def dist_info(world):
     return {"backend": None, "world_size_initialised": 1 if world == 1 else 0}
 
 
+_POOLS = {}
+
+
+def dataset_pool(n_mols, seed, molset):
+    """The synthetic dataset (numpy, host) of a line; lines over the same molecules share it."""
+    from geossl_amd.synthetic import make_molecules
+    key = (n_mols, seed, molset)
+    if key not in _POOLS:
+        _POOLS[key] = make_molecules(n_mols, seed=seed, mode=molset)
+    return _POOLS[key]
+
+
 class Workload:
     """One configuration of the DDM step on this rank: models, pre-collated device-resident batches, the step function
     of the chosen API, and a timer.
@@ -336,7 +348,7 @@ class Workload:
                        - i.e. what a maintainer gets who only changes the import lines of INTEGRATION.md."""
 
     def __init__(self, dev, rank, world, model="schnet", mols=1024, molset="A", cutoff=5.0, api="trainer", graph=True,
-                 n_batches=1, seed_base=1000, distinct=False, from_pool=False):
+                 n_batches=1, seed_base=1000, distinct=False, from_pool=False, dataset_mols=0):
         from geossl_amd import pretrain_GeoSSL as pg
         from geossl_amd.Geom3D.models import PaiNN, SchNet
         from geossl_amd.NCSN import NCSN_version_03
@@ -371,6 +383,19 @@ class Workload:
             self.accum_loss, self.accum_acc = 0.0, 0
         # pre-collated, device-resident batches: each rank owns its own molecules (weak scaling)
         self.batches, self.sizes0 = [], None
+        self.dataset, self.loader, self._epoch, self.epochs = None, None, None, 0
+        if dataset_mols:
+            # A shuffled epoch over a device-resident dataset (pretrain_GeoSSL.py:295-301: DataLoaderAtomTuple(dataset,
+            # batch_size, shuffle=True)): the molecules are uploaded once, every step draws the next `mols` ids of the
+            # epoch's permutation and the step gathers them on the device (Geom3D.dataloaders.DeviceDataset) - the loader
+            # is INSIDE the timed region.  PaiNN: per-molecule radius_edge_index built once on the device (N4).
+            from geossl_amd.Geom3D.dataloaders import DeviceDataset, DeviceLoader
+            self.dataset = DeviceDataset.from_numpy(dataset_pool(dataset_mols, seed_base * (rank + 1), molset), dev,
+                                                    radius=5.0 if model == "painn" else None)
+            self.loader = DeviceLoader(self.dataset, batch_size=mols, shuffle=True, drop_last=True,
+                                       generator=torch.Generator().manual_seed(4242 + rank))
+            self.sizes0 = [int(n) for n in self.dataset.sizes[:mols]]
+            n_batches = 0
         pool = None
         # from_pool: the repeated-batch twin of a `distinct` line - the FIRST n_batches draws of the same pool in the same
         # order, visited again and again (primed): the same molecules, so the two lines differ in nothing but repetition
@@ -401,12 +426,25 @@ class Workload:
     def n_batches(self):
         return len(self.batches)
 
+    def next_batch(self, i):
+        """Batch of step i: pre-collated batches in a fixed order, or the next handle of the shuffled loader."""
+        if self.loader is None:
+            return self.batches[i % self.n_batches]
+        while True:
+            if self._epoch is None:
+                self._epoch = iter(self.loader)   # (draws the epoch's permutation: part of the loader's work)
+                self.epochs += 1
+            hb = next(self._epoch, None)
+            if hb is not None:
+                return hb
+            self._epoch = None
+
     def shared_structure(self):
         """True when all batches have one index structure (set A with SchNet): one captured graph serves them all."""
         return self.molset == "A" and self.model_name == "schnet"
 
     def step(self, i):
-        bt = self.batches[i % self.n_batches]
+        bt = self.next_batch(i)
         if self.api == "trainer":
             return self.trainer.step(bt, None)  # the trainer draws the step's noise on the device itself
         # ---- examples/pretrain_GeoSSL.py:248-260, the DDM branch
@@ -447,6 +485,9 @@ class Workload:
         A `distinct` workload is not primed: its captures fall into the timed region."""
         if self.distinct:
             return None
+        if self.loader is not None:   # two steps: the capture (a bucket, or the structure of equal-sized molecules) + one replay
+            loss = self.step(0)
+            return self.step(1)
         passes = 2
         loss = None
         for _ in range(passes):
@@ -497,7 +538,7 @@ class Workload:
         from geossl_amd import _lib
 
         def eager_fwd_bwd(i):  # rank-local: no all-reduce, no Adam (neither is a timed entry point)
-            bt = self.batches[i % self.n_batches]
+            bt = self.profile_batch(i)
             if self.trainer is not None:
                 self.trainer._fwd_bwd(bt, self.draw(bt))
             else:
@@ -517,7 +558,24 @@ class Workload:
         calls, _lib.CALLS = _lib.CALLS / prof_steps, None
         return timers, calls
 
+    def profile_batch(self, i=0):
+        """A collated batch of the workload for the eager per-kernel timing (dataset mode: the first molecules)."""
+        if self.loader is None:
+            return self.batches[i % self.n_batches]
+        if not self.batches:
+            self.batches = [self.dataset.batch(np.arange(k * self.mols, (k + 1) * self.mols)).materialize() for k in range(2)]
+        return self.batches[i % len(self.batches)]
+
     def describe(self):
+        if self.loader is not None:
+            m = ("SchNet F=128 L=6 G=51 cutoff=%gA" % self.cutoff) if self.model_name == "schnet" else \
+                "PaiNN F=128 L=3 rbf=20 cutoff=5A (BASELINE config 5)"
+            return ("pretrain_GeoSSL.py --GeoSSL_option=DDM step, %s, bs=%d molecules/GPU x %s atoms, shuffled epochs over a "
+                    "device-resident dataset of %d molecules/GPU (DeviceLoader: torch's shuffled-DataLoader order, %d steps "
+                    "per epoch, last short batch dropped); every step's molecules are gathered on the device inside the "
+                    "timed region" % (m, self.mols, {"A": "n=18", "B": "n~clip(N(18,4),2,33) (set B)",
+                                                     "C": "n~clip(N(26,10),4,72) (set C: with hydrogens)"}[self.molset],
+                                      len(self.dataset), len(self.loader)))
         if self.model_name == "schnet":
             m = "SchNet F=128 L=6 G=51 cutoff=%gA" % self.cutoff
         else:
@@ -530,8 +588,20 @@ class Workload:
                                                                 "C": "n~clip(N(26,10),4,72) (set C: with hydrogens)"}[self.molset],
                                                  self.n_batches, how))
 
+    def short(self):
+        return ("DDM step %s bs=%d set %s %gA, %s" % (self.model_name, self.mols, self.molset, self.cutoff,
+                                                      ("shuffled epochs over %d device-resident mols, gather in timed region"
+                                                       % len(self.dataset)) if self.loader is not None else
+                                                      "%d pre-collated device-resident batches" % self.n_batches))
+
     def execution(self):
         g = self.n_graphs()
+        if self.loader is not None and self.api == "trainer" and self.uses_graph():
+            return ("DDMTrainer.step on a DatasetBatch handle: one pinned upload of offsets + geossl_gather_molecules (atom "
+                    "rows%s and the cleared gradient buffer in one launch), the five noise draws on the device, HIP graph "
+                    "replay of fwd+bwd (%d graph, %d capture%s), eager all-reduce + fused Adam"
+                    % (", batch vector, super-edges, pair slots, incidence lists, radius edges" if self.bucketed() else "",
+                       g, self.n_captures(), "" if self.n_captures() == 1 else "s"))
         if self.api == "trainer":
             if not self.uses_graph():
                 return "DDMTrainer.step, eager launches"
@@ -598,7 +668,24 @@ def secondary_line(dev, rank, world, steps, warmup, **kw):
 # once, nothing primed - the captures fall into the timed region; their twins visit a few pre-collated batches in a fixed
 # order, primed (ragged sets: the first 16 draws of the distinct line's own pool - four batches of 128 molecules differ
 # from the pool's average work by several per cent).  tools/bench_lines.py runs any of them on its own.
+EPOCH = 100000   # molecules of the device-resident datasets of the `epoch=shuffled` lines (BASELINE config 3's size)
 SECONDARY_LINES = {
+    # the headline's twin of rounds 1-5: pre-collated device-resident batches in a fixed order, no loader in the timed region
+    "trainer/precollated": (20, 5, dict(api="trainer", n_batches=25)),
+    # one whole shuffled epoch over a device-resident dataset, gather inside the timed region (steps = the epoch's length);
+    # twins: the `distinct` lines below (the same kind of batches, collated before the clock starts)
+    "trainer/epoch=shuffled/set=B": (EPOCH // 1024, 0, dict(api="trainer", molset="B", dataset_mols=EPOCH)),
+    "trainer/epoch=shuffled/set=B/mols=128": (EPOCH // 128, 0, dict(api="trainer", molset="B", mols=128, dataset_mols=EPOCH)),
+    "trainer/epoch=shuffled/set=C/cutoff=10": (EPOCH // 1024, 0, dict(api="trainer", molset="C", cutoff=10.0,
+                                                                       dataset_mols=EPOCH)),
+    "trainer/epoch=shuffled/set=C/cutoff=10/mols=128": (EPOCH // 128, 0, dict(api="trainer", molset="C", cutoff=10.0, mols=128,
+                                                                                dataset_mols=EPOCH)),
+    "trainer/epoch=shuffled/painn/set=C": (EPOCH // 1024, 0, dict(api="trainer", model="painn", molset="C",
+                                                                   dataset_mols=EPOCH)),
+    "trainer/epoch=shuffled/painn/set=C/mols=128": (EPOCH // 128, 0, dict(api="trainer", model="painn", molset="C", mols=128,
+                                                                            dataset_mols=EPOCH)),
+    "reference_api/epoch=shuffled/set=B/mols=128": (EPOCH // 128, 0, dict(api="reference", molset="B", mols=128,
+                                                                            dataset_mols=EPOCH)),
     "reference_api/mols=1024": (20, 5, dict(api="reference", mols=1024)),
     "trainer/mols=128": (40, 10, dict(api="trainer", mols=128)),
     "reference_api/mols=128": (40, 10, dict(api="reference", mols=128)),
@@ -631,7 +718,12 @@ SECONDARY_LINES = {
     "trainer/set=C/cutoff=10/mols=128/distinct": (480, 0, dict(api="trainer", molset="C", cutoff=10.0, mols=128,
                                                                 n_batches=480, distinct=True)),
 }
-SECONDARY_RATIOS = (("trainer/set=B/distinct", "trainer/set=B"),
+SECONDARY_RATIOS = (("trainer/epoch=shuffled/set=B", "trainer/set=B/distinct"),
+                    ("trainer/epoch=shuffled/set=B/mols=128", "trainer/set=B/mols=128/distinct"),
+                    ("trainer/epoch=shuffled/set=C/cutoff=10/mols=128", "trainer/set=C/cutoff=10/mols=128/distinct"),
+                    ("trainer/epoch=shuffled/painn/set=C/mols=128", "trainer/painn/set=C/mols=128/distinct"),
+                    ("reference_api/epoch=shuffled/set=B/mols=128", "reference_api/set=B/mols=128/distinct"),
+                    ("trainer/set=B/distinct", "trainer/set=B"),
                     ("trainer/set=B/mols=128/distinct", "trainer/set=B/mols=128"),
                     ("reference_api/set=B/mols=128/distinct", "trainer/set=B/mols=128"),
                     ("trainer/painn/distinct", "trainer/painn"),
@@ -849,7 +941,7 @@ def dominant_roofline(wl, prof_steps):
     from geossl_amd import ops
     timers, calls_per_step = wl.eager_kernel_times(prof_steps)
     timing_mode = "HIP events around every launch of %d eager steps run after the timed region" % prof_steps
-    bt = wl.batches[0]
+    bt = wl.profile_batch(0)
     E = int(ops.radius_graph(bt.positions, wl.cutoff, bt.batch).size(1))
     N, S = bt.positions.size(0), bt.super_edge_index.size(1)
     if wl.model_name == "painn":
@@ -976,6 +1068,9 @@ def compact_line(out):
             if "value" in r:
                 line["secondary"][name] = {"value": _num(r["value"], 5), "ms_per_step": _num(r.get("ms_per_step"), 4),
                                            "steps": r.get("steps")}
+                vs = [v for k, v in r.items() if k.startswith("vs_") and isinstance(v, float)]
+                if vs:   # ratio to the line's twin (SECONDARY_RATIOS)
+                    line["secondary"][name]["vs"] = _num(vs[0], 3)
             else:
                 line["secondary"][name] = {"error": str(r.get("error"))[:80]}
     line = _num(line)
@@ -1054,7 +1149,12 @@ def main():
     ap.add_argument("--mols", type=int, default=1024,
                     help="molecules per GPU per step (1024 = the configuration the metric is quoted on; 128 = the batch "
                          "size of the reference's own scripts, config.py:91)")
-    ap.add_argument("--dataset-mols", type=int, default=100000, help="synthetic dataset size (config 3)")
+    ap.add_argument("--dataset-mols", type=int, default=100000,
+                    help="synthetic dataset size (config 3), sharded over the ranks; device-resident, visited in shuffled "
+                         "epochs with the molecule gather inside the timed region")
+    ap.add_argument("--precollated", action="store_true",
+                    help="the form of rounds 1-5: pre-collated device-resident batches visited in a fixed order (no loader "
+                         "in the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary configurations the default 1-GPU run times after the headline")
@@ -1106,8 +1206,9 @@ def main():
 
     total_steps = args.warmup + args.steps
     n_batches = max(1, min(args.dataset_mols // (args.mols * world), total_steps, args.max_batches))
+    per_rank = max(args.dataset_mols // world, 2 * args.mols)
     wl = Workload(dev, rank, world, model=args.model, mols=args.mols, molset=args.molset, cutoff=CUTOFF, api=args.api,
-                  graph=not args.no_graph, n_batches=n_batches)
+                  graph=not args.no_graph, n_batches=n_batches, dataset_mols=0 if args.precollated else per_rank)
     elapsed, step_ms, final_loss = wl.run(args.warmup, args.steps)
     if os.environ.get("GEOSSL_BENCH_RANK_LOSS"):  # tests: every rank's last loss (ranks own different molecules and noise)
         with open(os.path.join(os.environ["GEOSSL_BENCH_RANK_LOSS"], "loss_rank%d.txt" % rank), "w") as fh:
@@ -1134,7 +1235,7 @@ def main():
             "value": value, "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl.describe(), "api": args.api,
+            "config": {"workload": wl.describe(), "workload_short": wl.short(), "api": args.api,
                        "molecules_per_gpu_per_step": args.mols, "atoms": N, "directed_edges": E, "super_edges": S,
                        "parallelism": "dp%d" % world, **dist_info(world), "arithmetic": ARITHMETIC,
                        "product_bits": product_bits(), "execution": wl.execution()},
@@ -1153,7 +1254,7 @@ def main():
             "final_loss": final_loss,
         }
         headline = (args.model == "schnet" and args.mols == 1024 and args.molset == "A" and args.api == "trainer"
-                    and CUTOFF == 5.0 and not args.no_graph)
+                    and CUTOFF == 5.0 and not args.no_graph and not args.precollated)
         if world == 1 and headline and not args.no_secondary:
             # Secondary configurations, timed here so that the driver observes them (20 steps each, a few seconds in all):
             # the reference's own loop and batch size, ragged molecules, the second backbone.

@@ -66,7 +66,7 @@ def test_bench_line_is_compact_strict_json():
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert line["roofline"]["hbm_frac"] is None                      # the inf of the dummy
     assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}
-    assert all(set(v) <= {"value", "ms_per_step", "steps", "error"} for v in line["secondary"].values())
+    assert all(set(v) <= {"value", "ms_per_step", "steps", "error", "vs"} for v in line["secondary"].values())
     assert line["secondary"]["broken"]["error"].startswith("RuntimeError")
     assert abs(line["value"] - 411111.123456789) < 1.0
 
