@@ -244,16 +244,20 @@ def parity_vs_oracle(dev, first):
 
 
 def pmc_file(workload):
-    """The newest committed rocprofv3 PMC summary (tools/pmc_traffic.py) that was recorded for `workload` (the file
-    names its own workload and the commit it was taken on); None when there is none - traffic figures of another
-    workload or of an unknown build are not reported."""
+    """The newest committed rocprofv3 PMC summary (tools/pmc_traffic.py) that was recorded for `workload` ON THIS BUILD of
+    the kernels (the file names its workload, its commit and the hash of csrc/ + include/ it was taken on); None when
+    there is none - traffic figures of another workload or of another build are not reported."""
     import glob
+    from geossl_amd.build import source_hash
+    now = source_hash()
     for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic_pmc.json")), reverse=True):
         try:
             pm = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if pm.get("workload") == workload and "kernels" in pm:
+        # only a summary taken on THIS build of the kernels (stamp = hash of csrc/ + include/): the traffic of an older
+        # build is not this run's
+        if pm.get("workload") == workload and "kernels" in pm and pm.get("csrc_sha") == now:
             return pm, os.path.basename(path)
     return None, None
 
@@ -513,15 +517,61 @@ class Workload:
             loss = self.step(warmup + i)
             marks[i + 1].record()
         torch.cuda.synchronize()
+        own = time.perf_counter() - t0     # this rank's own time to finish its K steps (before it waits for the others)
         if self.world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+        self.rank_ms = None
         if self.world > 1:
+            mine = torch.tensor([own], device=self.dev, dtype=torch.float64)
+            every = [torch.zeros_like(mine) for _ in range(self.world)]
+            dist.all_gather(every, mine)
+            self.rank_ms = [1e3 * float(v.item()) / steps for v in every]
             tt = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         return elapsed, step_ms, float(loss)
+
+    def diagnostics(self, iters=20):
+        """What an N > 1 run needs to be read, measured right after the timed region on every rank:
+        `input_ms` - the loader's share of a step: next handle of the shuffled epoch + the refresh of the graph's static
+        inputs (pinned upload + geossl_gather_molecules), host wall time and device time (HIP events);
+        `allreduce_ms` - HIP events around the gradient all-reduce alone (None without a process group);
+        the per-rank step times go into `rank_ms_per_step` in run()."""
+        import torch.distributed as dist
+        out = {"input_ms": None, "allreduce_ms": None}
+        tr = self.trainer
+        if tr is not None and self.loader is not None and tr.use_graph:
+            sg = tr.step_graphs
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+            host = []
+            torch.cuda.synchronize()
+            for a, b in ev:
+                t0 = time.perf_counter()
+                a.record()
+                hb = self.next_batch(0)
+                g = sg.lookup(hb)
+                if g is None:
+                    break
+                sg.refresh(g, hb, None)
+                b.record()
+                host.append(time.perf_counter() - t0)
+            torch.cuda.synchronize()
+            if len(host) == iters:
+                out["input_ms"] = {"host": 1e3 * float(np.median(host)),
+                                   "device": float(np.median([a.elapsed_time(b) for a, b in ev]))}
+        if tr is not None and dist.is_initialized():
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+            tr.flat.grad.zero_()
+            for a, b in ev:
+                a.record()
+                tr.reduce()
+                b.record()
+            torch.cuda.synchronize()
+            out["allreduce_ms"] = float(np.median([a.elapsed_time(b) for a, b in ev]))
+            out["allreduce_bytes"] = int(tr.flat.grad.numel() * 4)
+        return out
 
     def draw(self, bt):
         S, B, dev, gen = bt.super_edge_index.size(1), bt.num_graphs, self.dev, self.gen
@@ -1218,6 +1268,9 @@ def main():
             torch.cuda.synchronize()
             with open(os.path.join(os.environ["GEOSSL_BENCH_RANK_LOSS"], "params_rank%d.txt" % rank), "w") as fh:
                 fh.write(hashlib.sha256(wl.trainer.flat.flat.detach().cpu().numpy().tobytes()).hexdigest())
+    diag = wl.diagnostics()      # (collective inside: every rank)
+    if wl.rank_ms is not None:
+        diag["rank_ms_per_step"] = {"min": min(wl.rank_ms), "max": max(wl.rank_ms)}
     roof, kern, calls_per_step, shape = None, {}, None, None
     if rank == 0:
         roof, kern, calls_per_step, shape = dominant_roofline(wl, min(args.steps, 10))
@@ -1252,6 +1305,7 @@ def main():
             "kernel_ms": {k: {"avg_ms": v[0], "per_step": v[1]} for k, v in kern.items()},
             "c_abi_calls_per_step": calls_per_step,
             "final_loss": final_loss,
+            "multi_gpu": diag,
         }
         headline = (args.model == "schnet" and args.mols == 1024 and args.molset == "A" and args.api == "trainer"
                     and CUTOFF == 5.0 and not args.no_graph and not args.precollated)

@@ -22,6 +22,19 @@ def _headers():
     return hs + [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
 
 
+def source_hash():
+    """sha256 over every translation unit and header of the library (names and contents, sorted): what a measurement
+    of the kernels is valid for.  tools/pmc_traffic.py stamps its summaries with it and bench.py reports the traffic of a
+    summary only while the stamp still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted([os.path.join(CSRC, s_) for s_ in _sources()] + _headers()):
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 

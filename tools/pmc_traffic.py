@@ -11,9 +11,12 @@ gfx950 (it reports half of wide coalesced reads); WRITE_SIZE is taken as is.
 """
 import csv
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def short(name):
@@ -49,6 +52,7 @@ def main():
                     "steps, both views). Units KB->bytes (x1024); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 "
                     "reports half of wide coalesced reads); WRITE_SIZE uncorrected.",
            "workload": workload, "steps": steps, "molecules_per_step": mols, "git_head": head,
+           "csrc_sha": __import__("geossl_amd.build", fromlist=["source_hash"]).source_hash(),
            "kernels": {}}
     for k in f:
         out["kernels"][k] = {"launches": f[k][1], "fetch_bytes_per_launch": 2.0 * 1024.0 * f[k][0],

@@ -1,5 +1,7 @@
 # long run on never-repeating ragged batches: device memory, host RSS and step time must stay flat
-#   python tools/soak.py [steps] [mols] [trainer|reference] [schnet|painn] [set B|C]
+#   python tools/soak.py [steps] [mols] [trainer|reference] [schnet|painn] [set B|C] [host|dataset]
+# host: every step collates a random subset on the host (the reference's loader); dataset: shuffled epochs over a
+# device-resident dataset of 100 000 molecules, the step gathers its molecules on the device (Geom3D.dataloaders.DeviceLoader)
 import os, resource, sys, time, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,6 +16,7 @@ mols = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 api = sys.argv[3] if len(sys.argv) > 3 else "trainer"
 backbone = sys.argv[4] if len(sys.argv) > 4 else "schnet"
 molset = sys.argv[5] if len(sys.argv) > 5 else "B"
+source = sys.argv[6] if len(sys.argv) > 6 else "host"
 dev = "cuda:0"
 torch.manual_seed(0)
 if backbone == "schnet":
@@ -22,8 +25,19 @@ else:
     model = PaiNN(n_atom_basis=128, n_interactions=3, n_rbf=20, cutoff=5.0, max_z=9, n_out=1, readout="add").to(dev)
 n1 = NCSN_version_03(128, 10.0, 0.01, 50, "symmetry", 2).to(dev)
 n2 = NCSN_version_03(128, 10.0, 0.01, 50, "symmetry", 2).to(dev)
-pool = make_batch(4096, seed=1, mode=molset)
 rng = np.random.default_rng(5)
+if source == "dataset":
+    from geossl_amd.Geom3D.dataloaders import DeviceDataset, DeviceLoader
+    from geossl_amd.synthetic import make_molecules
+    ds = DeviceDataset.from_numpy(make_molecules(100000, seed=1, mode=molset), dev, radius=5.0 if backbone == "painn" else None)
+    loader = DeviceLoader(ds, batch_size=mols, shuffle=True, drop_last=True, generator=torch.Generator().manual_seed(5))
+
+    def batches():
+        while True:
+            yield from loader
+    stream_ = batches()
+else:
+    pool = make_batch(4096, seed=1, mode=molset)
 if api == "trainer":
     tr = pg.DDMTrainer(model, n1, n2, lr=5e-4, use_graph=True, model_3d=backbone)
 else:
@@ -33,8 +47,11 @@ else:
 marks = []
 t0 = time.perf_counter()
 for step in range(steps):
-    bt = pg.Batch.from_numpy(collate_subset(pool, rng.permutation(4096)[:mols]), dev, prepare=False)
-    if backbone == "painn":  # (the loader's precomputed radius_edge_index, datasets_3D_Radius.py:120; its E read-back is the collate's)
+    if source == "dataset":
+        bt = next(stream_)
+    else:
+        bt = pg.Batch.from_numpy(collate_subset(pool, rng.permutation(4096)[:mols]), dev, prepare=False)
+    if backbone == "painn" and source != "dataset":  # (the loader's precomputed radius_edge_index, datasets_3D_Radius.py:120; its E read-back is the collate's)
         bt.radius_edge_index = ops.radius_graph(bt.positions, 5.0, bt.batch)
     if api == "trainer":
         loss = tr.step(bt)
@@ -49,6 +66,6 @@ for step in range(steps):
                       resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024, float(loss)))
         t0 = time.perf_counter()
 for m in marks:
-    print("step %5d  %.3f ms/step (incl. host collate)  allocated %.0f MiB  reserved %.0f MiB  max RSS %.0f MiB  loss %.4f" % m)
+    print("step %5d  %.3f ms/step (incl. the loader)  allocated %.0f MiB  reserved %.0f MiB  max RSS %.0f MiB  loss %.4f" % m)
 caps = tr.step_graphs.captures if api == "trainer" else sum(sg.captures for sg in model.__dict__["_geossl_autograd_step"].graphs.values())
 print("captures", caps)
