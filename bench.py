@@ -800,16 +800,17 @@ def forward_only_line(dev, rank, world):
         {"workload": out["config"]["workload"]}
 
 
-def force_training_line(dev, backbone, mols=256, steps=12, warmup=4):
+def force_training_line(dev, backbone, mols=256, steps=40, warmup=6, use_graph=True):
     """A train-on-forces step (examples/finetune_md17.py:30-54: energy head, dE/dpos with create_graph, loss on energy and
     force, backward through the force, optimiser) on the library's pieces - a secondary of the default run, so that the
-    driver sees the second-order route (the library's own tape, geossl_amd/tape.py)."""
+    driver sees the second-order route (the library's own tape, geossl_amd/tape.py), replayed as ONE
+    captured HIP graph per batch structure (geossl_amd.graphed.ForceTrainer; use_graph=False: ~1000 eager launches)."""
     try:
-        from geossl_amd import _lib, ops
+        from geossl_amd import ops
         from geossl_amd import pretrain_GeoSSL as pg
         from geossl_amd.Geom3D.models import PaiNN, SchNet
         from geossl_amd.Geom3D.models.painn import Dense
-        from geossl_amd.optim import FlatParams, FusedAdam
+        from geossl_amd.graphed import ForceTrainer
         from geossl_amd.synthetic import make_batch
         torch.manual_seed(21)
         bt = pg.Batch.from_numpy(make_batch(mols, seed=3, mode="B"), dev)
@@ -817,38 +818,28 @@ def force_training_line(dev, backbone, mols=256, steps=12, warmup=4):
         if backbone == "painn":
             model = PaiNN(n_atom_basis=F, n_interactions=3, n_rbf=20, cutoff=5.0, max_z=9, n_out=1, readout="add").to(dev)
             head = model.create_output_layers().to(dev)
-            rei = ops.radius_graph(bt.positions, 5.0, bt.batch)
-            rep_of = lambda pos: model(bt.x, pos, rei, bt.batch)
+            bt.radius_edge_index = ops.radius_graph(bt.positions, 5.0, bt.batch)
         else:
             model = SchNet(F, F, L, G, 5.0, node_class=9, readout="add").to(dev)
             head = Dense(F, 1).to(dev)
-            rep_of = lambda pos: model(bt.x[:, 0], pos, bt.batch)
         gen = torch.Generator().manual_seed(1)
         y_e, y_f = torch.randn(mols, generator=gen).to(dev), torch.randn(bt.positions.shape, generator=gen).to(dev)
-        ones = torch.ones(mols, device=dev)
-        flat = FlatParams([model, head])
-        opt = FusedAdam(flat, lr=5e-4)
+        tr = ForceTrainer(model, head, model_3d=backbone, lr=5e-4, use_graph=use_graph)
         loss = None
         for step in range(warmup + steps):
             if step == warmup:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-            pos = bt.positions.detach().requires_grad_(True)                                             # :33
-            energy = head(rep_of(pos)).squeeze(1)                                                        # :36-44
-            dE = torch.autograd.grad(energy, pos, grad_outputs=ones, create_graph=True, retain_graph=True)[0]   # :46
-            loss = ops.energy_force_loss(energy, y_e, dE, y_f, 0.05, 0.95, "l1")                         # :46-51
-            opt.zero_grad()
-            with _lib.direct_grads():
-                loss.backward(inputs=flat.trainable)                                                     # :53
-            opt.step()                                                                                   # :54
+            loss = tr.step(bt, y_e, y_f)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out = {"value": mols * steps / dt, "unit": "molecules/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
-               "warmup": warmup, "final_loss": float(loss.detach()),
+               "warmup": warmup, "final_loss": float(loss.detach()), "graphs": len(tr.graphs), "captures": tr.captures,
                "workload": "finetune_md17.py:30-54 step (energy head, force = -dE/dpos with create_graph, L1 loss on energy and "
                            "force, backward through the force, Adam), %s backbone, %d ragged molecules (set B), second order on "
-                           "the library's tape (host-bound: ~1000 launches per step)" % (backbone, mols)}
-        del model, head, flat, opt
+                           "the library's tape, %s" % (backbone, mols, "replayed as one captured HIP graph"
+                                                       if tr.use_graph and tr.captures else "~1000 eager launches per step")}
+        del model, head, tr
         torch.cuda.empty_cache()
         return out
     except Exception as e:
@@ -1323,6 +1314,7 @@ def main():
             sec["forward_only/mols=1024"] = forward_only_line(dev, rank, world)
             sec["train_on_forces/schnet/mols=256"] = force_training_line(dev, "schnet")
             sec["train_on_forces/painn/mols=256"] = force_training_line(dev, "painn")
+            sec["train_on_forces/schnet/mols=256/eager"] = force_training_line(dev, "schnet", steps=12, warmup=4, use_graph=False)
             ref = sec["reference_api/mols=1024"]
             if "value" in ref:
                 ref["vs_trainer"] = ref["value"] / value

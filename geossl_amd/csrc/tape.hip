@@ -217,12 +217,24 @@ __global__ __launch_bounds__(256) void k_tape_colsum_partial(const float* __rest
   __syncthreads();
   if (ty == 0 && c < D) partial[(int64_t)blockIdx.x * D + c] = ((part[0][tx] + part[1][tx]) + part[2][tx]) + part[3][tx];
 }
-__global__ void k_tape_colsum_final(const float* __restrict__ partial, int nb, int D, float* __restrict__ y) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
+// stage 2: block (16 x 64): thread (ty, tx) adds the partial sums b = ty, ty + 16, ... of column c in ascending b, then the
+// sixteen partial results are added in ty order - a fixed order whatever the grid (round 6: the one-thread-per-column
+// form walked up to 1024 dependent loads: 20-40 us for a 5 us reduction)
+__global__ __launch_bounds__(1024) void k_tape_colsum_final(const float* __restrict__ partial, int nb, int D,
+                                                             float* __restrict__ y) {
+  __shared__ float part[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, c = blockIdx.x * 64 + tx;
   float s = 0.0f;
-  for (int b = 0; b < nb; ++b) s += partial[(int64_t)b * D + c];
-  y[c] = s;
+  if (c < D)
+    for (int b = ty; b < nb; b += 16) s += partial[(int64_t)b * D + c];
+  part[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < D) {
+    float t = part[0][tx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += part[k][tx];
+    y[c] = t;
+  }
 }
 
 // sums over the xyz triple: y[e][c] = x[3e][c] + x[3e+1][c] + x[3e+2][c]
@@ -258,6 +270,29 @@ __global__ void k_tape_scatter(const float* __restrict__ src, const P* __restric
     float s = 0.0f;
     for (int64_t k = ptr[t], k1 = ptr[t + 1]; k < k1; ++k) s += src[(int64_t)perm[k] * D + c];
     out[i] = s;
+  }
+}
+// The same sum for FEW target rows with LONG lists (a readout's adjoint, per-column statistics: N D threads would not fill
+// a CU and each would walk thousands of rows): one block per (target row, 64-column slab), sixteen sub-lists k = ty,
+// ty + 16, ... in ascending k, added in ty order - fixed, but not the order of the form above (which one a call takes
+// depends on N and D only).
+template <typename P>
+__global__ __launch_bounds__(1024) void k_tape_scatter_long(const float* __restrict__ src, const P* __restrict__ ptr,
+                                                             const int32_t* __restrict__ perm, int D,
+                                                             float* __restrict__ out) {
+  __shared__ float part[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, c = blockIdx.y * 64 + tx;
+  const int64_t t = blockIdx.x;
+  float s = 0.0f;
+  if (c < D)
+    for (int64_t k = (int64_t)ptr[t] + ty, k1 = ptr[t + 1]; k < k1; k += 16) s += src[(int64_t)perm[k] * D + c];
+  part[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < D) {
+    float v = part[0][tx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v += part[k][tx];
+    out[t * D + c] = v;
   }
 }
 
@@ -313,7 +348,7 @@ extern "C" int geossl_tape_binary(int op, const float* a, int amode, const float
 // kind: 1 row sums [R][D] -> [R], 2 column sums -> [D], 3 xyz-triple sums [R][D] -> [R / 3][D] (the Mode values).
 // Column sums need `workspace` of geossl_tape_colsum_workspace_floats(R, D) floats.
 extern "C" int64_t geossl_tape_colsum_workspace_floats(int64_t R, int D) {
-  const int64_t nb = R <= 0 ? 1 : (R + 255) / 256 > 1024 ? 1024 : (R + 255) / 256;
+  const int64_t nb = R <= 0 ? 1 : (R + 63) / 64 > 2048 ? 2048 : (R + 63) / 64;   // 64-row chunks: enough blocks to fill the chip
   return nb * (int64_t)D;
 }
 extern "C" int geossl_tape_reduce(int kind, const float* x, int64_t R, int D, float* y, float* workspace,
@@ -332,7 +367,7 @@ extern "C" int geossl_tape_reduce(int kind, const float* x, int64_t R, int D, fl
       hipLaunchKernelGGL(k_tape_colsum_partial, dim3((int)nb, (D + 63) / 64), dim3(256), 0, stream, x, R, D, chunk,
                          workspace);
       GEOSSL_CHECK_LAUNCH();
-      hipLaunchKernelGGL(k_tape_colsum_final, dim3((D + 255) / 256), dim3(256), 0, stream, workspace, (int)nb, D, y);
+      hipLaunchKernelGGL(k_tape_colsum_final, dim3((D + 63) / 64), dim3(1024), 0, stream, workspace, (int)nb, D, y);
     }
   } else if (kind == M_THIRD) {
     if (R % 3) return (int)hipErrorInvalidValue;
@@ -361,6 +396,17 @@ extern "C" int geossl_tape_gather_rows(const float* src, const void* idx, int id
 extern "C" int geossl_tape_scatter_rows(const float* src, const void* ptr, int ptr64, const int32_t* perm, int64_t N,
                                         int D, float* out, hipStream_t stream) {
   if (N <= 0 || D <= 0) return 0;
+  if (N * (int64_t)((D + 63) / 64) <= 4096 && N <= 65535) {   // few target rows: a block per row and column slab
+    const dim3 grid((unsigned)N, (unsigned)((D + 63) / 64));
+    if (ptr64)
+      hipLaunchKernelGGL(k_tape_scatter_long<int64_t>, grid, dim3(1024), 0, stream, src, static_cast<const int64_t*>(ptr),
+                         perm, D, out);
+    else
+      hipLaunchKernelGGL(k_tape_scatter_long<int32_t>, grid, dim3(1024), 0, stream, src, static_cast<const int32_t*>(ptr),
+                         perm, D, out);
+    GEOSSL_CHECK_LAUNCH();
+    return 0;
+  }
   if (ptr64)
     hipLaunchKernelGGL(k_tape_scatter<int64_t>, dim3(tape_grid(N * D, 256)), dim3(256), 0, stream, src,
                        static_cast<const int64_t*>(ptr), perm, N, D, out);

@@ -276,3 +276,55 @@ def test_reference_loop_runs_on_dataset_handles():
         eng = model.__dict__["_geossl_autograd_step"]
         assert sum(sg.captures for sg in eng.graphs.values()) <= 2, how
     assert out["dataset"] == out["collated"] and all(np.isfinite(v) for v in out["dataset"])
+
+
+# ----------------------------------------------------------------- the train-on-forces step as one captured graph (item 6)
+@pytest.mark.parametrize("backbone", ["schnet", "painn"])
+def test_force_trainer_graph_replay_is_the_eager_step_bit_for_bit(backbone):
+    """geossl_amd.graphed.ForceTrainer: the finetune_md17.py:30-54 step (energy head, force = -dE/dpos with create_graph,
+    L1 on energy and force, backward through the force, Adam) captured once and replayed - losses and parameters after
+    five steps on changing positions / targets bit-identical to the same step launched eagerly; SchNet: a new batch
+    object with the same molecule sizes replays the same graph; PaiNN: the same device-resident batch replays from its
+    second sighting on."""
+    from geossl_amd import ops
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.Geom3D.models import SchNet
+    from geossl_amd.Geom3D.models.painn import Dense
+    from geossl_amd.graphed import ForceTrainer
+    from geossl_amd.synthetic import make_batch
+    from helpers import fill_module_
+    B = 24
+    sizes = _ragged_sizes(B, 77)
+    raws = [make_batch(0, seed=900 + i, sizes=sizes) for i in range(5)]
+    for r in raws:
+        r["x"][:, 0] = np.clip(r["x"][:, 0], 1, 8)
+    gen = torch.Generator().manual_seed(3)
+    targets = [(torch.randn(B, generator=gen).to(DEV), torch.randn(int(sizes.sum()), 3, generator=gen).to(DEV)) for _ in raws]
+    out = {}
+    for use_graph in (True, False):
+        torch.manual_seed(1)
+        if backbone == "painn":
+            model = _painn_modules6()
+            head = fill_module_(model.create_output_layers()).to(DEV)
+        else:
+            model = fill_module_(SchNet(128, 128, 3, 51, 5.0, node_class=9, readout="add")).to(DEV)
+            head = fill_module_(Dense(128, 1)).to(DEV)
+        tr = ForceTrainer(model, head, model_3d=backbone, lr=5e-4, use_graph=use_graph)
+        if backbone == "painn":   # one device-resident batch whose positions / targets are overwritten in place
+            bt = pg.Batch.from_numpy(raws[0], DEV)
+            bt.radius_edge_index = ops.radius_graph(bt.positions, 5.0, bt.batch)
+        losses = []
+        for i, raw in enumerate(raws):
+            if backbone == "painn":
+                bt.positions.copy_(t(raw["positions"], DEV))
+                bt.x.copy_(t(raw["x"], DEV))
+            else:
+                bt = pg.Batch.from_numpy(raw, DEV)     # a fresh batch object per step: the graph is found by the sizes
+            losses.append(tr.step(bt, *targets[i]).clone())
+        torch.cuda.synchronize()
+        if use_graph:
+            assert tr.use_graph and tr.captures == 1 and len(tr.graphs) == 1
+        out[use_graph] = (torch.stack(losses), tr.flat.flat.detach().clone())
+    assert torch.isfinite(out[True][0]).all()
+    assert torch.equal(out[True][0], out[False][0])
+    assert torch.equal(out[True][1], out[False][1])
