@@ -11,6 +11,7 @@ import os
 from typing import Callable, Optional
 
 import torch
+from ...switches import env as _env
 import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.init import xavier_uniform_, zeros_
@@ -174,9 +175,9 @@ class PaiNN(nn.Module):
         status.poll()  # an out-of-range atomic number seen by an earlier call raises here (IndexError, like Embedding)
         cfg = dict(F=self.n_atom_basis, L=self.n_interactions, R=self.radial_basis.n_rbf, cutoff=float(self.cutoff),
                    offsets=self.radial_basis.offsets, widths=self.radial_basis.widths,
-                   eps=float(self.mixing[0].epsilon), status=status, debug=bool(os.environ.get("GEOSSL_DEBUG")),
+                   eps=float(self.mixing[0].epsilon), status=status, debug=bool(_env("GEOSSL_DEBUG")),
                    lay=lay, mma=(self.n_atom_basis == 128 and self.radial_basis.n_rbf in (8, 16, 20)
-                                 and not os.environ.get("GEOSSL_PAINN_VECTOR")))
+                                 and not _env("GEOSSL_PAINN_VECTOR")))
         q = _PaiNNCore.apply(atomic_numbers, positions.contiguous(), el, cfg, *self._params())
         status.arm()
         if return_latent and latent_only:
@@ -212,8 +213,8 @@ class _PaiNNCore(torch.autograd.Function):
         # scalar features, rows of the vector features viewed as [3 N, F], edges)
         dyn = getattr(el, "dyn", None)
         dN, dN3, dE = (dyn.n_atoms2, dyn.n_atoms2x3, dyn.n_edges2) if dyn is not None else (None, None, None)
-        if dyn is not None and (ctx.needs_input_grad[1] or F_ != 128 or os.environ.get("GEOSSL_PAINN_NO_CHAIN")
-                                or os.environ.get("GEOSSL_PAINN_SILU_KERNELS")):
+        if dyn is not None and (ctx.needs_input_grad[1] or F_ != 128 or _env("GEOSSL_PAINN_NO_CHAIN")
+                                or _env("GEOSSL_PAINN_SILU_KERNELS")):
             raise _lib.GeosslHipError("a capacity-bucket layout serves the F = 128 chain path without position gradients")
         dirv, fcut, phi = torch.empty(max(E, 1), 3, **f32), torch.empty(max(E, 1), **f32), torch.empty(max(E, 1), R, **f32)
         call("geossl_painn_edge_geom_dyn", ptr(pos), ptr(el.idx_i), ptr(el.idx_j), E, cfg["cutoff"], ptr(cfg["offsets"]),
@@ -235,10 +236,10 @@ class _PaiNNCore(torch.autograd.Function):
             i0w, i0b, i1w, i1b, mw = mix[l]
             blocks += [c0w] + [c1w[c * F_:(c + 1) * F_] for c in range(3)] + [mw[:F_], mw[F_:]] + \
                       [i0w[:, :F_], i0w[:, F_:]] + [i1w[c * F_:(c + 1) * F_] for c in range(3)]
-        img = ops.prepare_chain(blocks, transB=True) if not os.environ.get("GEOSSL_PAINN_NO_CHAIN") else None
+        img = ops.prepare_chain(blocks, transB=True) if not _env("GEOSSL_PAINN_NO_CHAIN") else None
         NB = 11  # blocks per layer, in the order above
         # silu inside the chained launches (F = 128): GEOSSL_PAINN_SILU_KERNELS keeps the separate silu launches (A/B runs)
-        fused = img is not None and F_ == 128 and not os.environ.get("GEOSSL_PAINN_SILU_KERNELS")
+        fused = img is not None and F_ == 128 and not _env("GEOSSL_PAINN_SILU_KERNELS")
 
         def lin_fan(x, ks, biases, outs):
             """several F x F blocks of one wide Dense applied to the same rows: one launch (F = 128), else one each"""
@@ -393,9 +394,9 @@ class _PaiNNCore(torch.autograd.Function):
             i0w, i0b, i1w, i1b, mw = mix[l]
             blocks += [c0w] + [c1w[c * F_:(c + 1) * F_] for c in range(3)] + [mw[:F_], mw[F_:]] + \
                       [i0w[:, :F_], i0w[:, F_:]] + [i1w[c * F_:(c + 1) * F_] for c in range(3)]
-        img = ops.prepare_chain(blocks, transB=False) if not os.environ.get("GEOSSL_PAINN_NO_CHAIN") else None
+        img = ops.prepare_chain(blocks, transB=False) if not _env("GEOSSL_PAINN_NO_CHAIN") else None
         NB = 11
-        fused = img is not None and F_ == 128 and not os.environ.get("GEOSSL_PAINN_SILU_KERNELS")
+        fused = img is not None and F_ == 128 and not _env("GEOSSL_PAINN_SILU_KERNELS")
 
         def lin_t(x, w, k, res=None, out=None):  # x @ w (the transposed use of a forward weight block)
             if img is None:

@@ -16,6 +16,7 @@ import math
 import os
 
 import torch
+from ...switches import env as _env
 from torch.nn import Embedding, Linear, ModuleList, Sequential
 
 from ... import _lib, ops
@@ -162,9 +163,9 @@ class _SchNetCore(torch.autograd.Function):
         # within 0.1 % either way, 21 % less HBM traffic.  Equal speed is not a win: saving stays the default, the
         # rebuild is there for when memory is what is short.  The position gradient
         # (geossl_cfconv_filter_dpos) and the three-bf16-piece backward read the saved rows.
-        keep_T = training and (ctx.needs_input_grad[1] or not os.environ.get("GEOSSL_FILTER_RECOMPUTE_T")
-                               or bool(os.environ.get("GEOSSL_FILTER_BWD_BF16X3"))
-                               or bool(os.environ.get("GEOSSL_ARITH_24BIT")))
+        keep_T = training and (ctx.needs_input_grad[1] or not _env("GEOSSL_FILTER_RECOMPUTE_T")
+                               or bool(_env("GEOSSL_FILTER_BWD_BF16X3"))
+                               or bool(_env("GEOSSL_ARITH_24BIT")))
         T = torch.empty(L, P, F, dtype=torch.float32, device=dev) if keep_T else None
         if P > 0:
             call("geossl_cfconv_filter_fwd_dyn", ptr(pair_d), ptr(pair_c), P, C.byref(fw), L, F, G, ptr(cfg["offset"]),
@@ -515,20 +516,20 @@ class SchNet(torch.nn.Module):
         status.poll()  # an out-of-range atom type seen by an earlier call raises here (IndexError, like Embedding)
         cfg = dict(L=self.num_interactions, F=self.hidden_channels, G=self.num_gaussians, cutoff=float(self.cutoff),
                    offset=self.distance_expansion.offset, coeff=float(self.distance_expansion.coeff),
-                   debug=bool(os.environ.get("GEOSSL_DEBUG")), status=status,
+                   debug=bool(_env("GEOSSL_DEBUG")), status=status,
                    # (GEOSSL_ARITH_24BIT: every dense product at fp32's own 24-bit product width - the atom-row layers then
                    # run as single launches of the three-bf16-piece row GEMM, the chain kernel is a two-fp16-piece kernel)
-                   chain=(self.num_interactions >= 1 and not os.environ.get("GEOSSL_NO_CHAIN")
-                          and not os.environ.get("GEOSSL_ARITH_24BIT")),
+                   chain=(self.num_interactions >= 1 and not _env("GEOSSL_NO_CHAIN")
+                          and not _env("GEOSSL_ARITH_24BIT")),
                    # The layer loop (chains and aggregations between the filter network and the heads) as ONE launch
                    # per pass (ops.layer_loop) - while a graph is being captured.  Launched eagerly it loses: the host
                    # has to describe all 14 operations before the GPU gets the first one, where separate launches
                    # pipeline (forward-only line 1.2 M against 1.4 M molecules/s).  GEOSSL_LAYER_LOOP=1 / =0 force it
                    # on / off (tests, A/B runs).
-                   loop=(os.environ.get("GEOSSL_LAYER_LOOP") == "1" or
-                         (os.environ.get("GEOSSL_LAYER_LOOP") is None and not os.environ.get("GEOSSL_NO_LAYER_LOOP")
+                   loop=(_env("GEOSSL_LAYER_LOOP") == "1" or
+                         (_env("GEOSSL_LAYER_LOOP") is None and not _env("GEOSSL_NO_LAYER_LOOP")
                           and torch.cuda.is_current_stream_capturing())),
-                   loop_stagger=int(os.environ.get("GEOSSL_LAYER_LOOP_STAGGER") or 0))
+                   loop_stagger=int(_env("GEOSSL_LAYER_LOOP_STAGGER") or 0))
         if pos.dtype != torch.float32:
             raise TypeError("positions must be float32")
         h = _SchNetCore.apply(z, pos.contiguous(), lay, cfg, *_core_params(self))

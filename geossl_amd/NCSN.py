@@ -12,6 +12,7 @@ import os
 
 import numpy as np
 import torch
+from .switches import env as _env
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -147,7 +148,7 @@ class _NcsnLoss(torch.autograd.Function):
         # one-pass kernel's 32-bit byte offsets cannot address
         # (GEOSSL_ARITH_24BIT: the two-pass form is the one whose products are all 24-bit - row pass on three bf16 pieces,
         # weight gradients on the three-piece column GEMM)
-        split = (os.environ.get("GEOSSL_NCSN_SPLIT_BWD") is not None or os.environ.get("GEOSSL_ARITH_24BIT") is not None
+        split = (_env("GEOSSL_NCSN_SPLIT_BWD") is not None or _env("GEOSSL_ARITH_24BIT") is not None
                  or max(S, N) * Fd * 4 >= 2 ** 32)
         if not split:
             # one pass over the rows: dfeat / demb / grow and every weight gradient of the head (ncsn_bwd.hip)
@@ -304,9 +305,9 @@ def ddm_heads_loss(n1, n2, data, h1, distance_1, h2, distance_2, noise_level_1=N
     pretrain_GeoSSL.py:207-210 - with both heads in the same launches (_NcsnLossPair) when they allow it, else as two
     calls.  The random draws are the ones the two forward() calls make, in their order."""
     ok = (isinstance(n1, NCSN_version_03) and isinstance(n2, NCSN_version_03) and n1.emb_dim == n2.emb_dim
-          and n1.emb_dim in (32, 64, 128) and not os.environ.get("GEOSSL_NCSN_SPLIT_BWD")
-          and not os.environ.get("GEOSSL_ARITH_24BIT")
-          and not os.environ.get("GEOSSL_NCSN_SEPARATE_HEADS")
+          and n1.emb_dim in (32, 64, 128) and not _env("GEOSSL_NCSN_SPLIT_BWD")
+          and not _env("GEOSSL_ARITH_24BIT")
+          and not _env("GEOSSL_NCSN_SEPARATE_HEADS")
           and (h2 is None or h1.shape == h2.shape) and not distance_1.requires_grad and not distance_2.requires_grad
           # the paired kernels write the two heads' gradients from different blocks of ONE launch: the heads must not
           # share a parameter (the same module passed twice, tied weights) - such a pair takes the two single-head calls

@@ -24,6 +24,7 @@ import ctypes as C
 
 import numpy as np
 import torch
+from .switches import env as _env
 
 from . import _lib
 from ._lib import call, ptr, stream
@@ -61,6 +62,7 @@ class _Layout:
     _sizes_host = None
 
     big = None
+    _warned_cap = False
 
     def loop_plan(self, *a, **k):
         return (None, 0)   # (the layer loop is a plan for uniform batches: they keep their per-structure graph)
@@ -68,7 +70,16 @@ class _Layout:
     def big_atoms(self, cap):
         """PaiNN: (static list of the atoms of molecules above `cap` atoms, its capacity, device address of the real
         count) - rewritten per step by Bucket.fill; None for a cap the bucket was not made for."""
-        return None if self.big is None else self.big.get(cap)
+        if self.big is None:
+            return None
+        got = self.big.get(cap)
+        if got is None and 0 < cap < self.max_n and not _Layout._warned_cap:
+            import warnings
+            _Layout._warned_cap = True
+            warnings.warn("PaiNN bucket has no atom list for stage cap %d (lists: %s): the molecule-staged kernels are "
+                          "skipped for the whole batch (the bucket was made for another radial basis or "
+                          "GEOSSL_PAINN_MMA_CAP changed since)" % (cap, sorted(self.big)))
+        return got
 
 
 class _SuperEdges:
@@ -99,7 +110,7 @@ def max_n_class(hi, prev=None, model_3d="schnet"):
     # SchNet, the matrix-pipe interaction of PaiNN) the class only sizes LDS arrays: a quarter of head room there, so that
     # the next batch's largest molecule does not cost another capture
     import os
-    want = hi if (hi <= exact or os.environ.get("GEOSSL_BUCKET_NO_HEADROOM")) else int(np.ceil(1.25 * hi))
+    want = hi if (hi <= exact or _env("GEOSSL_BUCKET_NO_HEADROOM")) else int(np.ceil(1.25 * hi))
     for c in classes:
         if want <= c and (prev is None or c >= prev):
             return c
@@ -185,7 +196,7 @@ def modules_ok(model, n1, n2):
     from .Geom3D.models.painn import PaiNN
     from .Geom3D.models.schnet import SchNet
     from .NCSN import NCSN_version_03, _head_params
-    if any(os.environ.get(k) for k in MODULE_SWITCHES):
+    if any(_env(k) for k in MODULE_SWITCHES):
         return False
     if isinstance(model, SchNet):
         if (model.hidden_channels != 128 or model.num_filters != 128 or model.num_interactions < 1 or model.dipole
@@ -196,7 +207,7 @@ def modules_ok(model, n1, n2):
         if (model.n_atom_basis != 128 or model.radial_basis.n_rbf not in (8, 16, 20) or model.share_filters
                 or model.n_interactions < 1 or model.activation is not F_.silu
                 or (model.n_interactions > 1 and model.interactions[0] is model.interactions[1])
-                or any(os.environ.get(k) for k in PAINN_SWITCHES)):
+                or any(_env(k) for k in PAINN_SWITCHES)):
             return False
     else:
         return False
@@ -298,7 +309,7 @@ class Bucket:
     atoms by geossl_pair_index_fill).  kind "painn": the structures of the batch's radius_edge_index for the two-view batch
     (geossl_painn_edge_layout: one launch on the batch's own edge tensor, outputs at the edge capacity E_cap)."""
 
-    def __init__(self, device, B, caps, option, x_cols=2, max_n=SMALL_N, kind="schnet", E_cap=0):
+    def __init__(self, device, B, caps, option, x_cols=2, max_n=SMALL_N, kind="schnet", E_cap=0, n_rbf=20):
         from .pretrain_GeoSSL import Batch
         self.device, self.B, self.option, self.max_n = device, int(B), option, int(max_n)
         self.kind, self.E_cap = kind, int(E_cap)
@@ -319,7 +330,9 @@ class Bucket:
         self.big_caps = ()
         if kind == "painn" and self.max_n > 0:
             from .layout import painn_stage_caps
-            self.big_caps = tuple(c for c in painn_stage_caps(128, 20) if 0 < c < self.max_n)
+            # (the stage caps depend on the radial basis: 73 / 74 / 75 atoms for the backward at 20 / 16 / 8 functions - lists
+            # made for another basis would never be found and the whole batch would fall back to the per-atom kernels)
+            self.big_caps = tuple(c for c in painn_stage_caps(128, int(n_rbf)) if 0 < c < self.max_n)
         o["big1"] = o["big0"] + (2 * Nc if len(self.big_caps) > 0 else 0)
         # a batch drawn from a device-resident dataset (Geom3D.dataloaders.DeviceDataset): where its molecules' atoms and
         # (PaiNN) radius edges start in the dataset, and the edge offsets of the batch

@@ -96,6 +96,11 @@ __global__ __launch_bounds__(256) void k_painn_edge_layout(PainnLayoutArgs A) {
   block_lower_bound2(A.src_i, A.E, (int64_t)a0, (int64_t)a0 + n, e0, e1);
   const bool too_big = n > PL_MAXN;
   if (too_big && tid == 0) *A.status = 1;
+  // The molecules' ranges [e0, e1) share their ends (the same key, the same search), so they tile [e0 of the first, e1 of
+  // the last): an edge list that is not grouped by molecule in batch order leaves edges in front of or behind that span -
+  // visited by no block, their slots would keep the previous step's data - or inside a wrong molecule's
+  // range (caught below).
+  if (tid == 0 && ((m == 0 && e0 != 0) || (m == (int)gridDim.x - 1 && e1 != A.E))) *A.status = 1;
   const int nn = too_big ? 0 : n;  // (a molecule above the limit gets empty lists; the status word reports it)
   const int N = A.N, E = A.E;
   for (int i = tid; i < 2 * 4 * PL_MAXN; i += 256) (&cnt[0][0][0])[i] = 0;

@@ -18,6 +18,7 @@ import math
 import os
 
 import torch
+from .switches import env as _env
 import torch.nn.functional as F
 
 from . import ops
@@ -317,7 +318,7 @@ def _second_order(features, tape_features, mask, need, cot, dhout, pos, params):
     third order) or GEOSSL_SECOND_ORDER=torch, as a torch autograd graph over `features(pos, params)`.  `need`: which of
     (dhout, pos, *params) get a gradient."""
     higher = torch.is_grad_enabled()  # read OUTSIDE the block below: a third-order graph only if the caller wants one
-    if not higher and os.environ.get("GEOSSL_SECOND_ORDER", "tape") != "torch":
+    if not higher and _env("GEOSSL_SECOND_ORDER", "tape") != "torch":
         from . import tape
         return tape.second_order(tape_features, mask, need, cot, dhout, pos, params)
     with torch.enable_grad():

@@ -8,6 +8,7 @@ import os
 
 import numpy as np
 import torch
+from .switches import env as _env
 
 from . import _lib
 from ._lib import call, ptr, stream
@@ -71,7 +72,7 @@ class MolLayout:
         # by descending size, the 21..33-atom ones as 2 or 4 work items (one group of target atoms each)
         # (molecules above 33 atoms - Molecule3D with hydrogens - as 16 items each: lists of target atoms, no size class)
         self.agg_work, self.agg_targets = None, False
-        if sizes is not None and 20 < self.max_n <= 255 and B < (1 << 24) and not os.environ.get("GEOSSL_AGG_NO_SPLIT"):
+        if sizes is not None and 20 < self.max_n <= 255 and B < (1 << 24) and not _env("GEOSSL_AGG_NO_SPLIT"):
             self.agg_targets = aggregate_by_targets(B)
             self.agg_work = torch.from_numpy(aggregate_work_list(np.asarray(sizes, dtype=np.int64), self.agg_targets)).to(dev)
         self.device = dev
@@ -127,7 +128,7 @@ def painn_stage_caps(F=128, R=20):
     layout holds larger ones (the rest goes to the per-atom kernels, atom list by atom list): the LDS limits of the
     library (geossl_painn_stage_cap); 0 = no split (one kernel form for the whole batch).  The forward's is 0 unless
     GEOSSL_PAINN_MMA_CAP asks for one (A/B runs)."""
-    if os.environ.get("GEOSSL_PAINN_NO_SPLIT"):   # (A/B runs: one kernel form for the whole batch, the round-4 behaviour)
+    if _env("GEOSSL_PAINN_NO_SPLIT"):   # (A/B runs: one kernel form for the whole batch, the round-4 behaviour)
         return 0, 0
     lib = _lib.load()
     cf, cb = int(lib.geossl_painn_stage_cap(0, F, R)), int(lib.geossl_painn_stage_cap(2, F, R))
@@ -135,7 +136,7 @@ def painn_stage_caps(F=128, R=20):
     # its LDS sized for 44-atom molecules (one block of four waves per CU) plus a per-atom pass for the rest is slower
     # than the per-atom kernel for the whole batch (bs = 128: 2.24 against 2.09 ms per step; bs = 1024: 10.6 against 10.6)
     # - tools/experiments/painn_forms.py.  The backward split pays (the molecule-staged backward up to 73 atoms).
-    env = os.environ.get("GEOSSL_PAINN_MMA_CAP")
+    env = _env("GEOSSL_PAINN_MMA_CAP")
     cf = min(cf, int(env)) if env is not None else 0
     return cf, cb
 
@@ -170,7 +171,7 @@ def aggregate_by_targets(num_mols):
     longest walk, not by bytes.  Measured per DDM step (tools/experiments/agg_targets.sh): set C at 10 A, 128 molecules
     per view 1.283 against 1.316 ms, set B without the ragged layer loop 0.806 against 0.847 ms; at 256 molecules per view
     the doubled filter-row traffic already loses (set C 2.106 against 2.065 ms, set B 1.244 against 1.106 ms)."""
-    return num_mols <= int(os.environ.get("GEOSSL_AGG_TARGETS_MAX", 256))
+    return num_mols <= int(_env("GEOSSL_AGG_TARGETS_MAX", 256))
 
 
 XCD = 8   # L2 domains of the chip: workgroups are dealt to them round-robin

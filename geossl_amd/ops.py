@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import torch
+from .switches import env as _env
 
 from . import _lib
 from ._lib import call, ptr, stream
@@ -18,7 +19,7 @@ PI_F32 = float(torch.tensor(math.pi, dtype=torch.float32))
 # (weights from L2, rows through L2 between operations) whatever the batch, and from 256 molecules per view on the
 # separate launches fill the chip better.  (First form, every wave the unrolled walk of its molecule's size class: 0.839
 # ms at 128 with 31 spilled registers; the block form above has none.)
-RAGGED_LOOP_MAX_MOLS = int(os.environ.get("GEOSSL_RAGGED_LOOP_MAX", 256))
+RAGGED_LOOP_MAX_MOLS = int(_env("GEOSSL_RAGGED_LOOP_MAX", 256))
 
 
 def _f32(t):
@@ -238,7 +239,7 @@ def layer_loop(ops_list, layout, pair_flag, N, F, stagger=0):
     # separate launches (a block owns its molecules for the whole pass: 650-670 us per pass against 470 us at 2 x 1024
     # molecules) and is not used.
     ragged = (plan is None and F == 128 and 1 < layout.max_n <= 33 and layout.B <= RAGGED_LOOP_MAX_MOLS
-              and not os.environ.get("GEOSSL_NO_RAGGED_LOOP") and len(ops_list) <= _lib.LOOP_MAX_OPS)
+              and not _env("GEOSSL_NO_RAGGED_LOOP") and len(ops_list) <= _lib.LOOP_MAX_OPS)
     if not ragged and (plan is None or F != 128 or not layout.uniform or layout.max_n > 20
                        or len(ops_list) > _lib.LOOP_MAX_OPS):
         return False

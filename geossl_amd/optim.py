@@ -3,6 +3,7 @@ the single-bucket gradient all-reduce for data parallelism."""
 import os
 
 import torch
+from .switches import env as _env
 
 from . import _lib
 from ._lib import call, ptr, stream
@@ -119,7 +120,7 @@ class ParamHome:
         """A home for these parameters, or None when they cannot be re-homed (not fp32 / CUDA, or already views of a
         larger storage - someone else, e.g. a DDMTrainer, owns their memory)."""
         params = list(params)
-        if not params or os.environ.get("GEOSSL_NO_FUSED_ADAM"):
+        if not params or _env("GEOSSL_NO_FUSED_ADAM"):
             return None
         for p in params:
             if (not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous()
@@ -278,7 +279,7 @@ def _adam_pre_hook(optimizer, args, kwargs):
         # (torch hands the hook the step's full argument tuple, the optimizer itself first; anything beyond it - a
         # closure - is the stock path's business)
         if (len(args) > 1 or kwargs or type(optimizer) is not torch.optim.Adam
-                or os.environ.get("GEOSSL_NO_FUSED_ADAM")):
+                or _env("GEOSSL_NO_FUSED_ADAM")):
             return None
         plan = optimizer.__dict__.get("_geossl_plan")
         if plan is None or plan is False or not plan.home.intact(full=True):

@@ -13,11 +13,13 @@ itself: the loss it returns is the output of an autograd node whose backward han
 """
 import ctypes as C
 import os
+import threading
 import warnings
 from collections import OrderedDict
 
 import numpy as np
 import torch
+from .switches import env as _env
 
 from . import _lib, ops
 from ._lib import call, ptr, stream
@@ -143,7 +145,7 @@ def do_DDM(args, batch, model, criterion=None, mu=0.0, sigma=0.3, num_neg=1, NCS
     if n1 is None or n2 is None:
         raise RuntimeError("set geossl_amd.pretrain_GeoSSL.NCSN_model_01/02 or pass NCSN_models=(m1, m2)")
     if graph is None:
-        graph = getattr(args, "step_graph", os.environ.get("GEOSSL_NO_STEP_GRAPH") is None)
+        graph = getattr(args, "step_graph", _env("GEOSSL_NO_STEP_GRAPH") is None)
     if graph and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing() and fuse_views:
         loss = _autograd_step(model, n1, n2).run(args, batch, mu, sigma, noise, device_noise)
         if loss is not None:
@@ -409,7 +411,7 @@ class StepGraphs:
     def bucket_key(self, batch):
         """("bucket", molecules, option) when the batch goes through a capacity bucket, else None."""
         from . import bucket as bk
-        if (self.mode != "auto" or not self.bucket_ok or os.environ.get("GEOSSL_NO_BUCKETS")
+        if (self.mode != "auto" or not self.bucket_ok or _env("GEOSSL_NO_BUCKETS")
                 or not bk.eligible(batch, self.model_3d, self.normalize)
                 or (self.model_3d != "painn" and bk.is_uniform(batch))   # (PaiNN: the edge list differs batch by batch anyway)
                 or self.modules is None or not self._modules_ok()):
@@ -420,7 +422,7 @@ class StepGraphs:
         """bucket.modules_ok of this engine's modules, remembered per state of the switches it reads (the modules of a
         StepGraphs are fixed: a replaced parameter rebuilds the engine, _AutogradStep.unchanged / DDMTrainer)."""
         from . import bucket as bk
-        env = tuple(os.environ.get(k) for k in bk.MODULE_SWITCHES + bk.PAINN_SWITCHES)
+        env = tuple(_env(k) for k in bk.MODULE_SWITCHES + bk.PAINN_SWITCHES)
         if self._mod_ok is None or self._mod_ok[0] != env:
             self._mod_ok = (env, bk.modules_ok(*self.modules))
         return self._mod_ok[1]
@@ -524,6 +526,7 @@ class StepGraphs:
         try:
             bkt = bk.Bucket(dev, len(batch._sizes), caps, batch._canonical,
                             x_cols=batch.x_cols if from_ds else batch.x.size(1), max_n=max_n,
+                            n_rbf=getattr(getattr(self.modules[0], "radial_basis", None), "n_rbf", 20),
                             kind=self.model_3d, E_cap=E_cap)
             bkt.fill(batch, counts)
         except (ValueError, RuntimeError) as e:
@@ -549,7 +552,7 @@ class StepGraphs:
 
     def _capture(self, sb, sn):
         import time
-        timing = [] if os.environ.get("GEOSSL_CAPTURE_TIMING") else None
+        timing = [] if _env("GEOSSL_CAPTURE_TIMING") else None
 
         def lap(name):
             if timing is not None:
@@ -1012,21 +1015,38 @@ def _single_thread_backward(ticket):
     next do_DDM - it cannot be put back from inside the backward: the engine restores the thread state it saw at
     backward()'s entry when the pass ends.  Other autograd work of the caller after the step - graphs that span several
     devices - sees its own setting.  GEOSSL_KEEP_AUTOGRAD_THREADS leaves the switch alone."""
-    if os.environ.get("GEOSSL_KEEP_AUTOGRAD_THREADS"):
+    if _env("GEOSSL_KEEP_AUTOGRAD_THREADS"):
         return
     if torch.autograd.is_multithreading_enabled():
         torch.autograd.set_multithreading_enabled(False)
-        ticket["mt_restore"] = True
-        _MT_PENDING.append(ticket)
+        # a small token, not the ticket: the pending list must not keep a step's gradient buffer alive, and the switch is
+        # THREAD-LOCAL - it is put back only by the thread that turned it off (ADVICE r05)
+        token = ticket["mt_token"] = _MtToken(threading.get_ident())
+        _MT_PENDING.append(token)
+
+
+class _MtToken:
+    __slots__ = ("thread", "live")
+
+    def __init__(self, thread):
+        self.thread, self.live = thread, True
 
 
 def _restore_backward_threads(ticket=None):
-    """Put autograd's multithreading switch back for `ticket` (None: for every step still pending)."""
-    todo = [ticket] if ticket is not None else list(_MT_PENDING)
+    """Put autograd's multithreading switch back for `ticket` (None: for every step of THIS thread that is still
+    pending).  A call from another thread (a ticket finalised by the garbage collector there) leaves the token pending:
+    the owning thread's next step / optimizer hook restores it."""
+    me = threading.get_ident()
+    if ticket is not None:
+        token = ticket.pop("mt_token", None) if isinstance(ticket, dict) else None
+        todo = [] if token is None else [token]
+    else:
+        todo = [t for t in _MT_PENDING if t.thread == me]
     for t in todo:
-        if t.pop("mt_restore", None):
+        if t.live and t.thread == me:
+            t.live = False
             torch.autograd.set_multithreading_enabled(True)
-    _MT_PENDING[:] = [p for p in _MT_PENDING if not any(p is t for t in todo)]   # (by identity: tickets hold tensors)
+    _MT_PENDING[:] = [p for p in _MT_PENDING if p.live]
 
 
 def _schnet_step_params(model):
@@ -1134,7 +1154,7 @@ class DDMTrainer:
     def _draw_noise(self, batch, into=None):
         """The five random draws of a step on the device (perturb: pretrain_GeoSSL.py:72; the heads: NCSN.py:190,194),
         as tensors - new ones, or in place into `into`."""
-        if os.environ.get("GEOSSL_TORCH_DRAWS"):  # the five torch calls (the form before geossl_ddm_noise)
+        if _env("GEOSSL_TORCH_DRAWS"):  # the five torch calls (the form before geossl_ddm_noise)
             return draw_step_noise(batch, self.n1, self.n2, self.mu, self.sigma, True, None, into)
         return draw_step_noise_fused(batch, self.n1, self.n2, self.mu, self.sigma, into)
 

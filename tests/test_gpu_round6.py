@@ -328,3 +328,26 @@ def test_force_trainer_graph_replay_is_the_eager_step_bit_for_bit(backbone):
     assert torch.isfinite(out[True][0]).all()
     assert torch.equal(out[True][0], out[False][0])
     assert torch.equal(out[True][1], out[False][1])
+
+
+def test_painn_edge_layout_flags_edges_that_no_molecule_range_covers():
+    """geossl_painn_edge_layout visits the edges inside the ranges it finds for the molecules; an edge
+    list whose tail lies behind every range (ids that no molecule owns) used to keep the previous fill's slots with the
+    status word still 0.  The ranges must tile [0, E): the first and the last block check the ends."""
+    from geossl_amd import bucket as bk
+    from geossl_amd import ops
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import make_batch
+    raw = make_batch(0, seed=83, sizes=_ragged_sizes(10, 83))
+    bt = pg.Batch.from_numpy(raw, DEV)
+    rei = ops.radius_graph(bt.positions, 5.0, bt.batch)
+    N = bt.positions.size(0)
+    counts = bk.batch_counts(bk.sizes_array(bt), "combination")
+    caps = tuple(c + 256 for c in counts)
+    for tail, want in ((None, 0), (torch.tensor([[N + 3], [N + 4]], device=DEV), 1)):
+        bt.radius_edge_index = rei if tail is None else torch.cat([rei, tail], dim=1).contiguous()
+        b = bk.Bucket(torch.device(DEV), 10, caps, "combination", max_n=bk.max_n_class(33, None, "painn"), kind="painn",
+                      E_cap=rei.size(1) + 64)
+        b.fill(bt)
+        torch.cuda.synchronize()
+        assert int(b.el.status) == want
