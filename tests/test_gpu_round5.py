@@ -495,7 +495,7 @@ def test_bench_eight_ranks_share_one_gpu(tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
-           "--no-cpu-baseline", "--mols", "128"]
+           "--no-cpu-baseline", "--mols", "128", "--dataset-mols", "8192"]
     with open(tmp_path / "out.log", "w") as fo, open(tmp_path / "err.log", "w") as fe:
         p = subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe, cwd=REPO)
         try:
@@ -512,7 +512,7 @@ def test_bench_eight_ranks_share_one_gpu(tmp_path):
     assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["parallelism"] == "dp8"
     assert out["config"]["backend"] == "gloo" and out["config"]["world_size_initialised"] == 8
     assert np.isfinite(out["value"]) and out["value"] > 0
-    assert abs(out["value"] - 8 * 128 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    assert abs(out["value"] - 8 * 128 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-4 * out["value"]   # (the line's 6 digits)
     losses = [float(open(tmp_path / ("loss_rank%d.txt" % r)).read()) for r in range(8)]
     assert all(np.isfinite(v) for v in losses) and len(set(losses)) == 8     # eight molecule sets, eight noise streams
     params = [open(tmp_path / ("params_rank%d.txt" % r)).read() for r in range(8)]
