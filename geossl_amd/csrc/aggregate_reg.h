@@ -131,6 +131,9 @@ __device__ __forceinline__ void aggregate_reg_body(const float* __restrict__ x, 
 // ascending source order with separate multiply and add - the rounding sequence of the walks above: bit-identical.
 // A filter row is read by both of its atoms' waves (through L2).  No size classes, no unrolled walks: the molecule's
 // rows of x sit in LDS (`smem`: 33 x 128 floats + 528 flag bytes; the caller's block barrier follows).
+// NW: waves of the block that take part (4, or 8 in the wide form of the layer loop: the walk is bound by instruction
+// issue - one wave per SIMD issues an instruction every four to five cycles at best - so twice the waves halve it).
+template <int NW = 4>
 __device__ __forceinline__ void aggregate_block_body(const float* __restrict__ x, const float* __restrict__ Wf,
                                                      const uint8_t* __restrict__ pair_flag, int a0, int n, int base,
                                                      int swap, float* __restrict__ out, uint8_t* smem) {
@@ -142,11 +145,11 @@ __device__ __forceinline__ void aggregate_block_body(const float* __restrict__ x
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nu = __builtin_amdgcn_readfirstlane(n), np = nu * (nu - 1) / 2;
-  for (int i = tid; i < nu * (F / 4); i += 256) {
+  for (int i = tid; i < nu * (F / 4); i += 64 * NW) {
     const int row = i >> 5, q = i & 31;
     *reinterpret_cast<f32x4*>(xs + row * F + 4 * q) = *reinterpret_cast<const f32x4*>(x + (size_t)(a0 + row) * F + 4 * q);
   }
-  for (int p = tid; p < np; p += 256) {
+  for (int p = tid; p < np; p += 64 * NW) {
     unsigned fl = pair_flag[base + p];
     if (swap) fl = ((fl & 1u) << 1) | ((fl >> 1) & 1u);
     fls[p] = (uint8_t)fl;
@@ -202,7 +205,7 @@ __device__ __forceinline__ void aggregate_block_body(const float* __restrict__ x
   while (a < nu) {
     const unsigned long long m0 = mask;
     const int bl0 = b_l;
-    const int an = a + 4;
+    const int an = a + NW;
     if (an < nu) {
       describe(an);
       request(w1);
@@ -211,7 +214,7 @@ __device__ __forceinline__ void aggregate_block_body(const float* __restrict__ x
     if (an >= nu) break;
     const unsigned long long m1 = mask;
     const int bl1 = b_l;
-    const int an2 = an + 4;
+    const int an2 = an + NW;
     if (an2 < nu) {
       describe(an2);
       request(w0);

@@ -22,6 +22,25 @@
 #include "common.h"
 #include "geossl_hip.h"
 #include "split.h"
+#ifdef LOOP_TIMING
+// per-phase wall-clock marks (s_memrealtime, 100 MHz) of wave 1 of block 5 of k_layer_loop: (tag, time) pairs, read with
+// geossl_loop_debug_read (tools/loop_timing.py; a debug build of this file with -DLOOP_TIMING)
+__device__ long long loop_dbg[2 * 1024];
+__device__ int loop_dbg_n;
+#define LOOP_MARK(tag)                                                                                     \
+  do {                                                                                                     \
+    if (blockIdx.x == 5 && threadIdx.x == 64) {                                                            \
+      const int k_ = loop_dbg_n;                                                                           \
+      if (k_ < 1024) {                                                                                     \
+        loop_dbg[2 * k_] = (tag);                                                                          \
+        loop_dbg[2 * k_ + 1] = (long long)__builtin_amdgcn_s_memrealtime();                                \
+        loop_dbg_n = k_ + 1;                                                                               \
+      }                                                                                                    \
+    }                                                                                                      \
+  } while (0)
+#else
+#define LOOP_MARK(tag) do {} while (0)
+#endif
 #include "aggregate_reg.h"
 
 #include <cstdlib>
@@ -655,6 +674,7 @@ __device__ __forceinline__ void chain_cu_body(const ChainT& ch, const float* __r
   };
   load_input(X, ldx);
   lds_barrier();  // biases staged, fragments published
+  LOOP_MARK(100);
   float vout[RB][16];  // a stage's results (this wave's column block of every row block)
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
@@ -791,6 +811,7 @@ __device__ __forceinline__ void chain_cu_body(const ChainT& ch, const float* __r
         if (i + 1 == nloc) store_rb(i);  // (register arrays are only ever indexed by unrolled constants)
       }
     }
+    LOOP_MARK(110 + s);
     if (s + 1 < NS) {
       request_weights(ch.st[s + 1]);  // the fragments of this stage are dead; in flight across the exchange
       if (ch.st[s + 1].flags & GEOSSL_CHAIN_SAME_INPUT) continue;  // the next stage reads the same input fragments
@@ -889,8 +910,14 @@ struct LoopArgs {
 // (aggregate_block_body).  At 1024 molecules per view a block-owns-its-molecules loop loses to the separate launches
 // (14 launches rebalance 14 times: DESIGN.md section 7); at the reference's batch size every launch of the pass is a
 // 5 .. 9 us latency and the loop is what removes them.
-template <int NMAX>
-__global__ __launch_bounds__(256, 2) void k_layer_loop(LoopArgs a) {
+// NW = 8 (the WIDE form, round 6): a block of eight waves for a RAGGED launch with at most one block per CU (the
+// reference's batch size: 256 molecule-views on 256 CUs).  The pass lasts as long as the block with the largest molecule,
+// whose aggregation is a serial sequence of round trips per wave (two targets in flight, nine targets per wave at 33
+// atoms).  Waves 4 .. 7 take every other target of the aggregations - half the round trips per wave - and shadow the
+// chains' barriers (a chain of NS plain stages crosses 2 NS LDS barriers: chain_cu_body); the chain itself stays the
+// four-wave body, one column block per wave.  Set B at 128 molecules per view: 0.778 -> 0.749 ms per step.
+template <int NMAX, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_layer_loop(LoopArgs a) {
   constexpr int F = 128;
   int4 pl;
   if constexpr (NMAX > 0) {
@@ -907,33 +934,40 @@ __global__ __launch_bounds__(256, 2) void k_layer_loop(LoopArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
   if ((int)blockIdx.x >= ((int)gridDim.x + 1) / 2)
     for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  LOOP_MARK(1);
   for (int o = 0; o < a.nops; ++o) {
     const LoopOp& op = a.op[o];
+    LOOP_MARK(10 + op.kind);
     if (op.kind == 0) {
-      if (op.nstage == 1) chain_cu_body<1, 3, 2, false>(op, op.X, F, a.R, pl.x, pl.y, nloc);
+      if (NW > 4 && wave >= 4) {
+        for (int i = 0; i < 2 * op.nstage; ++i) __builtin_amdgcn_s_barrier();  // (the barriers of chain_cu_body, nothing else)
+      } else if (op.nstage == 1) chain_cu_body<1, 3, 2, false>(op, op.X, F, a.R, pl.x, pl.y, nloc);
       else if (op.nstage == 2) chain_cu_body<2, 3, 2, false>(op, op.X, F, a.R, pl.x, pl.y, nloc);
       else chain_cu_body<3, 3, 2, false>(op, op.X, F, a.R, pl.x, pl.y, nloc);
     } else {
-      for (int mm = pl.z + wave; mm < pl.w; mm += 4) {
-        const int a0 = a.mol_ptr[mm], n = a.mol_ptr[mm + 1] - a0, base = a.pair_ptr[mm];
-        if constexpr (NMAX > 0)
+      if constexpr (NMAX > 0 && NW == 4) {
+        for (int mm = pl.z + wave; mm < pl.w; mm += 4) {
+          const int a0 = a.mol_ptr[mm], n = a.mol_ptr[mm + 1] - a0, base = a.pair_ptr[mm];
           aggregate_reg_body<NMAX>(op.X, op.Wf, a.pair_flag, a0, n, base, lane, 2 * lane, F, op.swap, op.out);
-      }
-      if constexpr (NMAX == 0) {
-        // ragged form: the block's molecules one after the other, each by all four waves (aggregate_block_body: a wave
-        // sums the target atoms w, w + 4, ... - no wave waits for another one's serial walk)
+        }
+      } else {
+        // ragged form (and every wide launch): the block's molecules one after the other, each by all waves of the block
+        // (aggregate_block_body: a wave sums the target atoms w, w + NW, ... - no wave waits for another one's serial walk)
         extern __shared__ __attribute__((aligned(16))) uint8_t loop_smem[];
         for (int mm = pl.z; mm < pl.w; ++mm) {
           const int a0 = a.mol_ptr[mm], n = a.mol_ptr[mm + 1] - a0, base = a.pair_ptr[mm];
           if (mm > pl.z) __syncthreads();  // (the staging area is reused)
-          aggregate_block_body(op.X, op.Wf, a.pair_flag, a0, n, base, op.swap, op.out, loop_smem);
+          aggregate_block_body<NW>(op.X, op.Wf, a.pair_flag, a0, n, base, op.swap, op.out, loop_smem);
         }
       }
     }
     // the next operation reads what this one wrote (rows of the block's own molecules, through L2), and reuses the LDS
+    LOOP_MARK(20);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LOOP_MARK(21);
     __syncthreads();
   }
+  LOOP_MARK(2);
 }
 
 template <int KS>
@@ -1052,6 +1086,17 @@ int launch_chain(const GeosslChain& ch, const float* X, int ldx, int64_t R, hipS
 
 }  // namespace
 
+#ifdef LOOP_TIMING
+extern "C" int geossl_loop_debug_read(long long* host, int* n, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(loop_dbg), sizeof(long long) * 2 * 1024);
+  if (rc == 0) rc = (int)hipMemcpyFromSymbol(n, HIP_SYMBOL(loop_dbg_n), sizeof(int));
+  if (rc == 0 && reset) {
+    const int zero = 0;
+    rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(loop_dbg_n), &zero, sizeof(int));
+  }
+  return rc;
+}
+#endif
 #ifdef CHAIN_TIMING
 extern "C" int geossl_chain_debug_read(long long* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(chain_dbg), sizeof(long long) * 8 * 64);
@@ -1134,6 +1179,18 @@ static int fill_loop_ops(const GeosslLoopOp* ops, int nops, int F, LoopArgs& a) 
   return 0;
 }
 
+// The wide form (eight waves per block) pays when a block has its CU to itself: at most one block per CU, one molecule per
+// block.  GEOSSL_LOOP_NO_WIDE: the four-wave forms of round 5 (A/B timing).
+static bool loop_wide(int64_t nblocks, bool one_molecule_per_block) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    cus = (hipGetDevice(&dev) == hipSuccess &&
+           hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : -1;
+  }
+  return one_molecule_per_block && cus > 0 && nblocks <= cus && getenv("GEOSSL_LOOP_NO_WIDE") == nullptr;
+}
+
 extern "C" int geossl_schnet_layer_loop(const GeosslLoopOp* ops, int nops, const int32_t* plan, int nblocks,
                                         const int32_t* mol_ptr, const int32_t* pair_ptr, const uint8_t* pair_flag,
                                         int max_n, int uniform, int64_t N, int F, int stagger, hipStream_t stream) {
@@ -1151,6 +1208,9 @@ extern "C" int geossl_schnet_layer_loop(const GeosslLoopOp* ops, int nops, const
   // uniform batches only (every molecule has max_n atoms, says the caller): the walk of one size class.  A form that
   // holds every class (waves of a block on different walks, molecules of 27 atoms and more shared by two or four waves)
   // was built and measured on set B: 650-670 us per pass against 470 us as separate launches - removed.
+  // (the wide form - eight waves per block, loop_wide - is for the ragged launch only: on equal-sized molecules the
+  // register walk of ONE wave reads every filter row once, 8.7 us per aggregation of 256 x 18 atoms, where eight waves on
+  // the block form read it twice and take 10.7: at that size the aggregation is bound by fetching the 20 MB of filter rows)
   if (max_n <= 18) {
     allow_big_lds(&k_layer_loop<18>);
     hipLaunchKernelGGL((k_layer_loop<18>), dim3(nblocks), dim3(256), lds, stream, a);
@@ -1183,8 +1243,13 @@ extern "C" int geossl_schnet_layer_loop_ragged(const GeosslLoopOp* ops, int nops
   a.mol_ptr = mol_ptr; a.pair_ptr = pair_ptr; a.pair_flag = pair_flag;
   a.nops = nops; a.R = (int)N; a.stagger = 0; a.pad = 0; a.nmol = (int)B; a.mols_per_block = mols_per_block;
   const size_t lds = (size_t)3 * 8 * 2 * 1024 + (size_t)3 * 128 * sizeof(float) + (size_t)3 * 128 * sizeof(float);
-  allow_big_lds(&k_layer_loop<0>);
-  hipLaunchKernelGGL((k_layer_loop<0>), dim3((unsigned)nblocks), dim3(256), lds, stream, a);
+  if (loop_wide(nblocks, mols_per_block == 1)) {
+    allow_big_lds(&k_layer_loop<0, 8>);
+    hipLaunchKernelGGL((k_layer_loop<0, 8>), dim3((unsigned)nblocks), dim3(512), lds, stream, a);
+  } else {
+    allow_big_lds(&k_layer_loop<0>);
+    hipLaunchKernelGGL((k_layer_loop<0>), dim3((unsigned)nblocks), dim3(256), lds, stream, a);
+  }
   GEOSSL_CHECK_LAUNCH();
   return 0;
 }
