@@ -409,6 +409,42 @@ class _SchNetCore(torch.autograd.Function):
         return dpos, list(grads)
 
 
+class _SchNetTapeCore(torch.autograd.Function):
+    """schnet.py:89-101 for the widths the fused kernels do not take (hidden_channels != num_filters, widths other than 32
+    / 64 / 128, more than 64 gaussians or 12 blocks - the reference's constructor takes any, schnet.py:17-30): the
+    backbone restated on the library's reverse-mode tape (geossl_amd/tape.py: every primitive a HIP kernel - row GEMMs at
+    any width in padded slabs, the aggregation in column slabs, element-wise maps), differentiated by the tape.  About a
+    hundred launches per block instead of three: a correct path for every configuration, not a fast one.  First order
+    only (training on forces with such a configuration raises)."""
+
+    @staticmethod
+    def forward(ctx, z, pos, lay, cfg, *params):
+        from ... import tape as tp
+        with torch.no_grad():
+            x = tp.leaf(pos, bool(ctx.needs_input_grad[1]))
+            ps = [tp.leaf(p, bool(n)) for p, n in zip(params, ctx.needs_input_grad[4:])]
+            h = tp.schnet_atom_features(z, x, lay, cfg, ps)
+        ctx.tape = (h, x, ps)
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return h.t
+
+    @staticmethod
+    def backward(ctx, dh):
+        from ... import tape as tp
+        if torch.is_grad_enabled():
+            raise NotImplementedError("second-order gradients (training on forces) need the fused widths: "
+                                      "hidden_channels == num_filters in %s" % (SUPPORTED_F,))
+        h, x, ps = ctx.tape
+        wrt = [v for v in [x] + ps if v.req]
+        with torch.no_grad():
+            got = iter(tp.grad([h], [tp.const(dh.contiguous())], wrt))
+        vals = [next(got) if v.req else None for v in [x] + ps]
+        dpos = None if vals[0] is None else vals[0].t
+        grads = [None if g is None else g.t.reshape(shape) for g, shape in zip(vals[1:], ctx.shapes)]
+        # (a parameter the output does not depend on - none here - would come back as None: autograd takes that as zero)
+        return (None, dpos, None, None) + tuple(grads)
+
+
 class _SegmentReduce(torch.autograd.Function):
     """torch_scatter.scatter(h, batch, dim=0, reduce) for a sorted batch (schnet.py:115).  Its backward is the
     expansion below and vice versa, so the pair is differentiable to any order (training on forces differentiates the
@@ -495,19 +531,19 @@ class SchNet(torch.nn.Module):
             st.check()
 
     def _check_supported(self):
-        F = self.hidden_channels
-        if self.num_filters != F or F not in SUPPORTED_F:
-            raise NotImplementedError("HIP path supports hidden_channels == num_filters in %s (got %d/%d)"
-                                      % (SUPPORTED_F, self.hidden_channels, self.num_filters))
-        if self.num_interactions > _lib.MAX_L or self.num_gaussians > 64:
-            raise NotImplementedError("HIP path supports <= %d interactions and <= 64 gaussians" % _lib.MAX_L)
+        """-> True when the fused kernels take this configuration (hidden_channels == num_filters in 32 / 64 / 128, at
+        most 12 blocks and 64 gaussians: every configuration the reference's scripts use), False when it runs on the
+        general-width path (_SchNetTapeCore)."""
         if self.dipole:
             raise NotImplementedError("dipole readout (schnet.py:103-107,117-118) is off the GeoSSL path")
+        F = self.hidden_channels
+        return (self.num_filters == F and F in SUPPORTED_F and self.num_interactions <= _lib.MAX_L
+                and self.num_gaussians <= 64)
 
     def forward(self, z, pos, batch=None, return_latent=False, layout=None, latent_only=False):
         assert z.dim() == 1 and z.dtype == torch.long
         _lib.require_cuda(z, pos, batch)
-        self._check_supported()
+        fused = self._check_supported()
         batch = torch.zeros_like(z) if batch is None else batch
         lay = layout if layout is not None else get_layout(batch)
         if lay.N != pos.size(0):
@@ -532,7 +568,13 @@ class SchNet(torch.nn.Module):
                    loop_stagger=int(_env("GEOSSL_LAYER_LOOP_STAGGER") or 0))
         if pos.dtype != torch.float32:
             raise TypeError("positions must be float32")
-        h = _SchNetCore.apply(z, pos.contiguous(), lay, cfg, *_core_params(self))
+        if fused:
+            h = _SchNetCore.apply(z, pos.contiguous(), lay, cfg, *_core_params(self))
+        else:   # any other widths (schnet.py:17-30 takes any): the general path on the library's tape
+            if z.numel() and (int(z.min()) < 0 or int(z.max()) >= self.embedding.num_embeddings):   # (Embedding's IndexError)
+                raise IndexError("atom type out of range for the embedding table (node_class=%d)"
+                                 % self.embedding.num_embeddings)
+            h = _SchNetTapeCore.apply(z, pos.contiguous(), lay, cfg, *_core_params(self))
         status.arm()
         if not self.dipole and self.mean is not None and self.std is not None:
             h = h * self.std + self.mean

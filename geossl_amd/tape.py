@@ -477,6 +477,22 @@ def agg(x, Wf, lay, pair_flag, swap):
     return V(ops.aggregate(x.t, Wf.t, pair_flag, lay, swap=swap), (x, Wf), vjp)
 
 
+def agg_wide(x, Wf, lay, pair_flag, swap):
+    """`agg` at ANY feature width (the reference's num_filters is free, schnet.py:17-30): the aggregation kernels take 32,
+    64 or 128 columns, so other widths go through them in zero-padded column slabs of at most 128 (the padding's columns
+    aggregate zeros and are cut off again; their gradients are the slices' pads)."""
+    D = x.D
+    if D in (32, 64, 128):
+        return agg(x, Wf, lay, pair_flag, swap)
+    outs = []
+    for c0 in range(0, D, 128):
+        w = min(128, D - c0)
+        wp = 32 if w <= 32 else (64 if w <= 64 else 128)
+        xs, ws = pad_cols(slice_cols(x, c0, w), 0, wp), pad_cols(slice_cols(Wf, c0, w), 0, wp)
+        outs.append(slice_cols(agg(xs, ws, lay, pair_flag, swap), 0, w))
+    return outs[0] if len(outs) == 1 else cat_cols(outs)
+
+
 def pairprod(a, b, lay, pair_flag, swap):
     """out[p] = f0 a[i] b[j] + f1 a[j] b[i] over the pair slots p = (i < j): d aggregate / d filter."""
     def vjp(g, needs):
@@ -531,7 +547,7 @@ def schnet_atom_features(z, x, lay, cfg, ps):
         W = linear(ssp(linear(rbf, pad_cols(w1, 0, Gp), b1)), w2, b2)
         W = binary(MUL, W, FULL, C, ROW, P, W.D)                                  # :187
         xl = mm(h, lin1_w, "nt")                                                  # :189
-        xl = agg(xl, W, lay, pair_flag, False)                                    # :190
+        xl = agg_wide(xl, W, lay, pair_flag, False)                               # :190
         xl = ssp(linear(xl, lin2_w, lin2_b))                                      # :191,165
         h = add(h, linear(xl, lin_w, lin_b))                                      # :166,97
     h = ssp(linear(h, head[0], head[1]))                                          # :99-100
