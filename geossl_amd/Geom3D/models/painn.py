@@ -159,12 +159,13 @@ class PaiNN(nn.Module):
         and edge structures of the batch when the caller already has them - the static, capacity-sized structures of a
         capacity bucket (geossl_amd/bucket.py), whose real counts are device data."""
         _lib.require_cuda(x, positions, radius_edge_index, batch)
-        if self.share_filters or (self.n_interactions > 1 and self.interactions[0] is self.interactions[1]):
-            raise NotImplementedError("shared_filters / shared_interactions are off the GeoSSL path")
-        if self.n_atom_basis not in (32, 64, 128) or self.radial_basis.n_rbf not in (8, 16, 20, 32):
-            raise NotImplementedError("HIP path supports n_atom_basis in (32, 64, 128) and n_rbf in (8, 16, 20, 32)")
         if self.activation is not F.silu:
             raise NotImplementedError("HIP path implements the reference default activation F.silu")
+        # The fused kernels take the configurations the reference's scripts use (n_atom_basis 32 / 64 / 128, 8 / 16 / 20 /
+        # 32 radial functions, a filter and a block per interaction); everything else the constructor accepts
+        # (painn.py:125-142: any width, shared_filters, shared_interactions) runs on the general path (_PaiNNTapeCore).
+        shared = self.share_filters or (self.n_interactions > 1 and self.interactions[0] is self.interactions[1])
+        fused = (not shared and self.n_atom_basis in (32, 64, 128) and self.radial_basis.n_rbf in (8, 16, 20, 32))
         atomic_numbers = x[:, 0] if x.dim() == 2 else x  # painn.py:226-229
         lay = layout if layout is not None else get_layout(batch)
         if positions.dtype != torch.float32:
@@ -178,7 +179,15 @@ class PaiNN(nn.Module):
                    eps=float(self.mixing[0].epsilon), status=status, debug=bool(_env("GEOSSL_DEBUG")),
                    lay=lay, mma=(self.n_atom_basis == 128 and self.radial_basis.n_rbf in (8, 16, 20)
                                  and not _env("GEOSSL_PAINN_VECTOR")))
-        q = _PaiNNCore.apply(atomic_numbers, positions.contiguous(), el, cfg, *self._params())
+        if fused:
+            q = _PaiNNCore.apply(atomic_numbers, positions.contiguous(), el, cfg, *self._params())
+        else:
+            if atomic_numbers.numel() and (int(atomic_numbers.min()) < 0
+                                           or int(atomic_numbers.max()) >= self.embedding.num_embeddings):
+                raise IndexError("atomic number out of range for the embedding table (max_z=%d)"
+                                 % self.embedding.num_embeddings)
+            cfg["share_filters"] = bool(self.share_filters)
+            q = _PaiNNTapeCore.apply(atomic_numbers, positions.contiguous(), el, cfg, *self._params())
         status.arm()
         if return_latent and latent_only:
             return None, q
@@ -191,6 +200,38 @@ class PaiNN(nn.Module):
 
 def _split3(t, F_):
     return [t[:, c * F_:(c + 1) * F_] for c in range(3)]
+
+
+class _PaiNNTapeCore(torch.autograd.Function):
+    """painn.py:230-255 for the configurations the fused kernels do not take (any n_atom_basis / n_rbf, shared_filters,
+    shared_interactions: painn.py:125-142,178-202,242-243): the backbone restated on the library's reverse-mode tape
+    (geossl_amd/tape.py: every primitive a HIP kernel), differentiated by the tape.  A correct path for every
+    configuration, not a fast one; first order only."""
+
+    @staticmethod
+    def forward(ctx, z, pos, el, cfg, *params):
+        from ... import tape as tp
+        with torch.no_grad():
+            x = tp.leaf(pos, bool(ctx.needs_input_grad[1]))
+            ps = [tp.leaf(p, bool(n)) for p, n in zip(params, ctx.needs_input_grad[4:])]
+            q = tp.painn_atom_features(z.contiguous(), x, el.idx_i, el.idx_j, cfg, ps, getattr(el, "inc", None))
+        ctx.tape = (q, x, ps)
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return q.t
+
+    @staticmethod
+    def backward(ctx, dq):
+        from ... import tape as tp
+        if torch.is_grad_enabled():
+            raise NotImplementedError("second-order gradients (training on forces) need a configuration of the fused path")
+        q, x, ps = ctx.tape
+        wrt = [v for v in [x] + ps if v.req]
+        with torch.no_grad():
+            got = iter(tp.grad([q], [tp.const(dq.contiguous())], wrt))
+        vals = [next(got) if v.req else None for v in [x] + ps]
+        dpos = None if vals[0] is None else vals[0].t
+        grads = [None if g is None else g.t.reshape(shape) for g, shape in zip(vals[1:], ctx.shapes)]
+        return (None, dpos, None, None) + tuple(grads)
 
 
 class _PaiNNCore(torch.autograd.Function):

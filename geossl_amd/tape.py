@@ -587,7 +587,8 @@ def painn_atom_features(z, x, idx_i, idx_j, cfg, ps, inc=None):
     q = _embedding_padded(emb_w, zi, keep_rows)                                   # :247
     mu = const(raw_full(3 * N, Fd, dev, 0.0))                                     # :249, [3N, F]
     dir_flat = reshape(dirv, 3 * E, 1)
-    filters = split_cols(filters, [3 * Fd] * L)
+    # (shared_filters: ONE filter of width 3F for every interaction, painn.py:178-181,242-243)
+    filters = [filters] * L if cfg.get("share_filters") else split_cols(filters, [3 * Fd] * L)
     for l in range(L):
         c0w, c0b, c1w, c1b = inter[l]
         xx = linear(silu(linear(q, c0w, c0b)), c1w, c1b)                          # :53, [N, 3F]

@@ -184,8 +184,11 @@ def do_ddm_schnet(P_model, P_ncsn1, P_ncsn2, x, positions, batch, super_edge_ind
 # ----------------------------------------------------------------------------- PaiNN (config 5)
 
 def painn_forward(P, x, positions, radius_edge_index, batch, n_atom_basis, n_interactions,
-                  cutoff, readout="add", epsilon=1e-8, return_latent=False):
-    """PaiNN.forward, painn.py:216-269 (non-shared filters / interactions: painn.py:183-202)."""
+                  cutoff, readout="add", epsilon=1e-8, return_latent=False, shared_filters=False,
+                  shared_interactions=False):
+    """PaiNN.forward, painn.py:216-269.  shared_filters: ONE filter of width 3F for all interactions (painn.py:178-181,
+    242-243); shared_interactions: every interaction / mixing block is the same module (painn_utils.py:92-93 via
+    painn.py:189-202) - block 0's parameters are read for every block."""
     F_ = n_atom_basis
     z = x[:, 0] if x.dim() == 2 else x  # :226-229
     idx_i, idx_j = radius_edge_index[0], radius_edge_index[1]  # :230
@@ -200,12 +203,13 @@ def painn_forward(P, x, positions, radius_edge_index, batch, n_atom_basis, n_int
     fcut = 0.5 * (torch.cos(d_ij * math.pi / cut) + 1.0)  # painn_utils.py:152
     fcut = fcut * (d_ij < cut).to(d_ij.dtype)  # :154 (.float() there; dtype-generic so the oracle also runs in fp64)
     filters = F.linear(phi, P["filter_net.weight"], P["filter_net.bias"]) * fcut[..., None]  # :241
-    filter_list = torch.split(filters, 3 * F_, dim=-1)  # :245
+    filter_list = [filters] * n_interactions if shared_filters else torch.split(filters, 3 * F_, dim=-1)  # :242-245
     emb = P["embedding.weight"]
     q = F.embedding(z, emb, padding_idx=0)[:, None]  # :247
     mu = torch.zeros((q.shape[0], 3, q.shape[2]), dtype=q.dtype)  # :249
     for i in range(n_interactions):  # :251-253
-        p = "interactions.%d.interatomic_context_net." % i
+        blk = 0 if shared_interactions else i
+        p = "interactions.%d.interatomic_context_net." % blk
         xx = F.linear(F.silu(F.linear(q, P[p + "0.weight"], P[p + "0.bias"])), P[p + "1.weight"], P[p + "1.bias"])  # :53
         xj = xx[idx_j]  # :54
         muj = mu[idx_j]  # :55
@@ -216,7 +220,7 @@ def painn_forward(P, x, positions, radius_edge_index, batch, n_atom_basis, n_int
         dmu = torch.zeros((n_atoms,) + tuple(dmu.shape[1:]), dtype=dmu.dtype).index_add(0, idx_i, dmu)  # :61
         q = q + dq  # :63
         mu = mu + dmu  # :64
-        m = "mixing.%d." % i
+        m = "mixing.%d." % blk
         mu_mix = F.linear(mu, P[m + "mu_channel_mix.weight"])  # :100
         mu_V, mu_W = torch.split(mu_mix, F_, dim=-1)  # :101
         mu_Vn = torch.sqrt(torch.sum(mu_V ** 2, dim=-2, keepdim=True) + epsilon)  # :102

@@ -568,8 +568,52 @@ def g14():
     save("g14_finetune_qm9_schnet", **arrs)
 
 
+def g15():
+    """Configurations off the reference's defaults (round 6): SchNet with hidden_channels != num_filters at widths that
+    are no multiple of 32 (schnet.py:17-30 takes any), PaiNN with an odd width / radial basis and with shared_filters +
+    shared_interactions (painn.py:140-141,178-202,242-243): outputs, atom features, gradient summaries."""
+    b = make_batch(0, seed=33, sizes=[18, 9, 27, 2, 14, 21])
+    b["x"][:3, 0] = 0
+    batch = Batch(b)
+    w = lambda t_: torch.cos(0.1 * torch.arange(t_.numel(), dtype=torch.float32)).view(t_.shape)
+    for tag, cfg in (("a", dict(hidden_channels=48, num_filters=40, num_interactions=2, num_gaussians=30, cutoff=5.0,
+                                node_class=9, readout="mean")),
+                     ("b", dict(hidden_channels=160, num_filters=136, num_interactions=1, num_gaussians=70, cutoff=5.0,
+                                node_class=9, readout="add"))):
+        model = fill_module_(SchNet(**cfg))
+        out, h = model(batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
+        ((out * w(out)).sum() + (h * w(h)).sum()).backward()
+        arrs = dict(x=batch.x, positions=batch.positions, batch=batch.batch, out=out, h=h, cfg=json.dumps(cfg))
+        seen = set()
+        for name, p in model.named_parameters():
+            if p.grad is not None and id(p) not in seen:
+                seen.add(id(p))
+                arrs["gsum/" + name] = grad_summary(p.grad)
+        save("g15_schnet_widths_" + tag, **arrs)
+    rei = []
+    for m in range(len(b["sizes"])):
+        sel = b["batch"] == m
+        off = int(np.nonzero(sel)[0][0])
+        rei.append(radius_graph(torch.from_numpy(b["positions"][sel]), r=5.0, loop=False) + off)
+    rei = torch.cat(rei, dim=1)
+    for tag, cfg in (("a", dict(n_atom_basis=48, n_interactions=2, n_rbf=12, cutoff=5.0, max_z=9, n_out=1, readout="add")),
+                     ("b", dict(n_atom_basis=64, n_interactions=3, n_rbf=20, cutoff=5.0, max_z=9, n_out=1, readout="add",
+                                shared_filters=True, shared_interactions=True))):
+        model = fill_module_(PaiNN(**cfg))
+        out, q = model(batch.x, batch.positions, rei, batch.batch, return_latent=True)
+        ((out * w(out)).sum() + (q * w(q)).sum()).backward()
+        arrs = dict(x=batch.x, positions=batch.positions, batch=batch.batch, radius_edge_index=rei, out=out, q=q,
+                    cfg=json.dumps(cfg))
+        seen = set()
+        for name, p in model.named_parameters():   # (shared modules: named_parameters lists a shared tensor once)
+            if p.grad is not None and id(p) not in seen:
+                seen.add(id(p))
+                arrs["gsum/" + name] = grad_summary(p.grad)
+        save("g15_painn_variants_" + tag, **arrs)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14):
+    for fn in (g1_g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15):
         if not only or fn.__name__ in only:
             fn()

@@ -423,3 +423,57 @@ def test_schnet_at_widths_the_fused_kernels_do_not_take_vs_oracle(hidden, filter
         assert rel_err(p.grad.cpu(), P[name].grad) < 1e-4, name
         seen += 1
     assert seen == 1 + 9 * L + 4
+
+
+def _gsum_close(got, want, tol):
+    from helpers import grad_summary
+    s = grad_summary(got.detach().cpu())
+    return np.allclose(s, want, rtol=tol, atol=tol * np.abs(want).max())
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g15_schnet_widths_on_the_hip_path(tag):
+    """G15 of the unmodified reference: SchNet(hidden 48, filters 40, 30 gaussians) and SchNet(hidden 160, filters 136, 70
+    gaussians) - on the general path (the fused kernels take hidden == filters in 32 / 64 / 128): out, atom features and
+    the gradient summaries of every parameter."""
+    import json
+    from conftest import load_golden
+    from geossl_amd.Geom3D.models import SchNet
+    from helpers import fill_module_
+    g = load_golden("g15_schnet_widths_" + tag)
+    cfg = json.loads(str(g["cfg"]))
+    model = fill_module_(SchNet(**cfg)).to(DEV)
+    out, h = model(t(g["x"], DEV)[:, 0], t(g["positions"], DEV), t(g["batch"], DEV), return_latent=True)
+    assert rel_err(out.cpu(), g["out"]) < 1e-5 and rel_err(h.cpu(), g["h"]) < 1e-5
+    w = lambda t_: torch.cos(0.1 * torch.arange(t_.numel(), dtype=torch.float32)).view(t_.shape).to(DEV)
+    ((out * w(out)).sum() + (h * w(h)).sum()).backward()
+    seen = 0
+    for name, p in model.named_parameters():
+        if "gsum/" + name in g:
+            assert _gsum_close(p.grad, g["gsum/" + name], 1e-4), name
+            seen += 1
+    assert seen == 1 + 9 * cfg["num_interactions"] + 4
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g15_painn_variants_on_the_hip_path(tag):
+    """G15 of the unmodified reference: PaiNN(n_atom_basis 48, 12 radial functions) and PaiNN(64, shared_filters,
+    shared_interactions) (painn.py:140-141,178-202,242-243) on the general path: h, q, gradient summaries."""
+    import json
+    from conftest import load_golden
+    from geossl_amd.Geom3D.models import PaiNN
+    from helpers import fill_module_
+    g = load_golden("g15_painn_variants_" + tag)
+    cfg = json.loads(str(g["cfg"]))
+    model = fill_module_(PaiNN(**cfg)).to(DEV)
+    out, q = model(t(g["x"], DEV), t(g["positions"], DEV), t(g["radius_edge_index"], DEV), t(g["batch"], DEV),
+                   return_latent=True)
+    assert rel_err(out.cpu(), g["out"]) < 1e-5 and rel_err(q.cpu(), g["q"]) < 1e-5
+    w = lambda t_: torch.cos(0.1 * torch.arange(t_.numel(), dtype=torch.float32)).view(t_.shape).to(DEV)
+    ((out * w(out)).sum() + (q * w(q)).sum()).backward()
+    seen = 0
+    for name, p in model.named_parameters():
+        if "gsum/" + name in g:
+            assert _gsum_close(p.grad, g["gsum/" + name], 1e-4), name
+            seen += 1
+    assert seen == sum(1 for k in g if k.startswith("gsum/")) and seen > 8

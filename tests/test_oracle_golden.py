@@ -184,7 +184,10 @@ def test_g6_do_ddm(tag):
 
 def painn_params(cfg):
     F, L, R, Z = cfg["n_atom_basis"], cfg["n_interactions"], cfg["n_rbf"], cfg["max_z"]
-    s = {"embedding.weight": (Z, F), "filter_net.weight": (L * 3 * F, R), "filter_net.bias": (L * 3 * F,)}
+    nf = 1 if cfg.get("shared_filters") else L          # painn.py:178-187
+    s = {"embedding.weight": (Z, F), "filter_net.weight": (nf * 3 * F, R), "filter_net.bias": (nf * 3 * F,)}
+    if cfg.get("shared_interactions"):                   # one block, replicated (painn_utils.py:92-93)
+        L = 1
     for i in range(L):
         p = "interactions.%d.interatomic_context_net." % i
         s.update({p + "0.weight": (F, F), p + "0.bias": (F,), p + "1.weight": (3 * F, F), p + "1.bias": (3 * F,)})
@@ -390,3 +393,46 @@ def test_g14_finetune_qm9_schnet_two_epochs_and_eval():
         if k.startswith("psum/"):
             assert rel_err(grad_summary(P[k[5:]].detach()), g[k]) < 1e-5, k
     assert rel_err(head_w, g["head/weight"]) < 1e-5 and rel_err(head_b, g["head/bias"]) < 1e-5
+
+
+def _check_gsums(g, grads, tol=2e-5):
+    for key in g:
+        if key.startswith("gsum/"):   # (l2-relative over the summary, like the other fixtures: fp32 sums depend on the thread count)
+            assert rel_err(grad_summary(grads[key[5:]]), g[key]) < tol, key
+
+
+def test_g15_configurations_off_the_defaults():
+    """G15 (round 6): SchNet with hidden_channels != num_filters at widths that are no multiple of 32 and more than 64
+    gaussians; PaiNN at an odd width / radial basis and with shared_filters + shared_interactions - the oracle against
+    fixtures of the unmodified reference (schnet.py:17-30; painn.py:140-141,178-202,242-243)."""
+    from helpers import schnet_shapes
+    for tag in ("a", "b"):
+        g = load_golden("g15_schnet_widths_" + tag)
+        cfg = json.loads(str(g["cfg"]))
+        H, Fl, G, L, C = (cfg[k] for k in ("hidden_channels", "num_filters", "num_gaussians", "num_interactions", "node_class"))
+        shapes = {"embedding.weight": (C, H), "lin1.weight": (H, H), "lin1.bias": (H,), "lin2.weight": (H, H), "lin2.bias": (H,)}
+        for l in range(L):
+            p = "interactions.%d." % l
+            shapes.update({p + "mlp.0.weight": (Fl, G), p + "mlp.0.bias": (Fl,), p + "mlp.2.weight": (Fl, Fl),
+                           p + "mlp.2.bias": (Fl,), p + "conv.lin1.weight": (Fl, H), p + "conv.lin2.weight": (H, Fl),
+                           p + "conv.lin2.bias": (H,), p + "lin.weight": (H, H), p + "lin.bias": (H,)})
+        P = {k: v.requires_grad_() for k, v in fill_dict(shapes).items()}
+        P["distance_expansion.offset"] = nets.smearing_constants(cfg["cutoff"], G)[0]
+        out, h = nets.schnet_forward(P, t(g["x"])[:, 0], t(g["positions"]), t(g["batch"]), cfg["cutoff"], L, cfg["readout"],
+                                     return_latent=True)
+        assert rel_err(out, g["out"]) < 1e-6 and rel_err(h, g["h"]) < 1e-6
+        w = lambda t_: torch.cos(0.1 * torch.arange(t_.numel(), dtype=torch.float32)).view(t_.shape)
+        ((out * w(out)).sum() + (h * w(h)).sum()).backward()
+        _check_gsums(g, {k: v.grad for k, v in P.items() if v.grad is not None})
+    for tag in ("a", "b"):
+        g = load_golden("g15_painn_variants_" + tag)
+        cfg = json.loads(str(g["cfg"]))
+        P = painn_params(cfg)
+        out, q = nets.painn_forward(P, t(g["x"]), t(g["positions"]), t(g["radius_edge_index"]), t(g["batch"]),
+                                    cfg["n_atom_basis"], cfg["n_interactions"], cfg["cutoff"], cfg["readout"],
+                                    return_latent=True, shared_filters=bool(cfg.get("shared_filters")),
+                                    shared_interactions=bool(cfg.get("shared_interactions")))
+        assert rel_err(out, g["out"]) < 1e-6 and rel_err(q, g["q"]) < 1e-6
+        w = lambda t_: torch.cos(0.1 * torch.arange(t_.numel(), dtype=torch.float32)).view(t_.shape)
+        ((out * w(out)).sum() + (q * w(q)).sum()).backward()
+        _check_gsums(g, {k: v.grad for k, v in P.items() if v.grad is not None})
