@@ -65,6 +65,8 @@ class DeviceDataset:
         dev = torch.device(device)
         if dev.type != "cuda":
             raise _lib.GeosslHipError("a DeviceDataset lives on an MI355X (no CPU fallback)")
+        if dev.index is None:   # ("cuda": the current device, by number - buckets and graphs compare devices)
+            dev = torch.device("cuda", torch.cuda.current_device())
         as_t = lambda a, dt: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(dev, dt).contiguous()
         self.device, self.option = dev, option
         self.sizes = np.ascontiguousarray(np.asarray(sizes, dtype=np.int64))
@@ -257,7 +259,8 @@ class DatasetBatch:
         """``batch.to(device)`` of the reference's loop (pretrain_GeoSSL.py:248): the molecules are there already."""
         dev = torch.device(device)
         if dev.type != self.device.type or (dev.index is not None and dev.index != self.device.index):
-            raise _lib.GeosslHipError("a DatasetBatch lives on %s" % self.device)
+            raise _lib.GeosslHipError("a DatasetBatch lives on %s (its molecules are gathered there; there is no copy to "
+                                      "another device)" % self.device)
         return self
 
     def fingerprint(self):

@@ -24,7 +24,7 @@ class GraphedForward:
     def __init__(self, model, return_latent=False, max_graphs=64):
         self.model, self.return_latent, self.max_graphs = model, return_latent, max_graphs
         self.graphs, self.pool, self.captures = OrderedDict(), None, 0
-        self._seen = set()
+        self._seen = OrderedDict()   # fingerprints seen once (bounded: a loader that never repeats a size sequence)
         self.enabled = True
 
     def _eager(self, x, positions, batch_vec):
@@ -40,7 +40,9 @@ class GraphedForward:
         g = self.graphs.get(fp)
         if g is None:
             if not bk.is_uniform(batch) and fp not in self._seen:   # ragged: from the second sighting on
-                self._seen.add(fp)
+                self._seen[fp] = True
+                while len(self._seen) > 4096:
+                    self._seen.popitem(last=False)
                 return self._eager(batch.x, batch.positions, batch.batch)
             g = self._capture(batch)
             if g is None:
@@ -131,7 +133,7 @@ class ForceTrainer:
         self.opt = FusedAdam(self.flat, lr=lr, weight_decay=weight_decay)
         self.use_graph, self.max_graphs = use_graph, max_graphs
         self.graphs, self.pool, self.captures = OrderedDict(), None, 0
-        self._seen = set()
+        self._seen = OrderedDict()   # (bounded: a loader that never repeats an edge tensor must not grow it for ever)
 
     # ---- the step as eager launches (what a capture records)
     def _body(self, x, positions, batch_vec, rei, y_e, y_f, ones):
@@ -223,7 +225,9 @@ class ForceTrainer:
                         self.graphs.popitem(last=False)
                     self.graphs[key] = g
             elif g is None:
-                self._seen.add(key)
+                self._seen[key] = True
+                while len(self._seen) > 4096:
+                    self._seen.popitem(last=False)
             else:
                 self.graphs.move_to_end(key)
         if g is None:
