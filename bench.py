@@ -586,6 +586,8 @@ class Workload:
         (a graph replay has no host-side launch boundaries to bracket; rocprofv3 sees the kernels of both) and the
         number of C-ABI calls one such pass makes."""
         from geossl_amd import _lib
+        if prof_steps <= 0:   # (--no-roofline)
+            return {}, None
 
         def eager_fwd_bwd(i):  # rank-local: no all-reduce, no Adam (neither is a timed entry point)
             bt = self.profile_batch(i)
@@ -842,6 +844,35 @@ def force_training_line(dev, backbone, mols=256, steps=40, warmup=6, use_graph=T
         del model, head, tr
         torch.cuda.empty_cache()
         return out
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def rccl_single_rank_line(mols=1024, steps=40, warmup=10):
+    """The headline step with the PRODUCTION transport in the timed region, as far as a 1-GPU box can show it: a child
+    process with a 1-rank `nccl` (= RCCL) process group (GEOSSL_DIST_BACKEND=nccl, WORLD_SIZE=1), so that every step issues
+    the gradient all-reduce on RCCL (a 1-rank sum is the identity) before the Adam launch - the launch path N ranks take.
+    -> {value, ms_per_step, allreduce_ms, backend} of that run (its own compact line), or {"error": ...}."""
+    import socket
+    import subprocess
+    try:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   GEOSSL_DIST_BACKEND="nccl")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
+               "--mols", str(mols), "--no-secondary", "--no-cpu-baseline", "--no-roofline"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=REPO)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "rc %s: %s" % (r.returncode, (r.stderr or "")[-300:])}
+        d = json.loads(lines[-1])
+        return {"value": d["value"], "ms_per_step": d["ms_per_step"], "steps": steps,
+                "allreduce_ms": (d.get("multi_gpu") or {}).get("allreduce_ms"),
+                "allreduce_bytes": (d.get("multi_gpu") or {}).get("allreduce_bytes"),
+                "backend": (d.get("config") or {}).get("backend")}
     except Exception as e:
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -1197,6 +1228,7 @@ def main():
                     help="the form of rounds 1-5: pre-collated device-resident batches visited in a fixed order (no loader "
                          "in the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the eager per-kernel timing passes behind `roofline`")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary configurations the default 1-GPU run times after the headline")
     ap.add_argument("--max-batches", type=int, default=97, help="distinct pre-collated batches per GPU (config 3: 97)")
@@ -1264,7 +1296,7 @@ def main():
         diag["rank_ms_per_step"] = {"min": min(wl.rank_ms), "max": max(wl.rank_ms)}
     roof, kern, calls_per_step, shape = None, {}, None, None
     if rank == 0:
-        roof, kern, calls_per_step, shape = dominant_roofline(wl, min(args.steps, 10))
+        roof, kern, calls_per_step, shape = dominant_roofline(wl, 0 if args.no_roofline else min(args.steps, 10))
 
     if rank == 0:
         N, E, S, step_bytes, step_flops = (shape[k] for k in ("N", "E", "S", "step_bytes", "step_flops"))
@@ -1315,6 +1347,11 @@ def main():
             sec["train_on_forces/schnet/mols=256"] = force_training_line(dev, "schnet")
             sec["train_on_forces/painn/mols=256"] = force_training_line(dev, "painn")
             sec["train_on_forces/schnet/mols=256/eager"] = force_training_line(dev, "schnet", steps=12, warmup=4, use_graph=False)
+            # the all-reduce on the production transport inside a timed region (a 1-rank RCCL group in a child process)
+            one = rccl_single_rank_line()
+            sec["trainer/rccl=1rank"] = one
+            diag["rccl_1rank"] = {k: one.get(k) for k in ("ms_per_step", "allreduce_ms", "allreduce_bytes", "backend", "error")
+                                  if one.get(k) is not None}
             ref = sec["reference_api/mols=1024"]
             if "value" in ref:
                 ref["vs_trainer"] = ref["value"] / value
