@@ -119,3 +119,36 @@ def test_device_loader_visits_molecules_in_the_order_of_torchs_shuffled_loader()
     order = ld.order()
     assert [order[k * 10:(k + 1) * 10].tolist() for k in range(len(ld))] == want
     assert DeviceLoader(Stub(), batch_size=10, shuffle=False).order().tolist() == list(range(103))
+
+
+def test_dataset_handle_counts_and_fingerprint_match_the_collated_batch():
+    """A DatasetBatch is ids + host sizes; what the step graphs ask of it without touching tensors - atom / super-edge /
+    edge counts and the structure fingerprint - equals what the collated batch of the same molecules gives (host logic
+    only: a stub in place of the device-resident arrays)."""
+    import types
+    import numpy as np
+    import torch
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.Geom3D.dataloaders.device_dataset import DatasetBatch
+    from geossl_amd.synthetic import collate_subset, make_batch
+    for option in ("combination", "permutation"):
+        pool = make_batch(40, seed=3, mode="B", option=option)
+        sizes = np.asarray(pool["sizes"], dtype=np.int64)
+        off = np.concatenate([[0], np.cumsum(sizes)])
+        edge_cnt = sizes * 3
+        ds = types.SimpleNamespace(sizes=sizes, off=off, pairs=sizes * (sizes - 1) // 2, option=option, x_cols=2,
+                                   device=torch.device("cpu"), edges=object(), edge_cnt=edge_cnt,
+                                   edge_off=np.concatenate([[0], np.cumsum(edge_cnt)]))
+        ds.__len__ = lambda: 40
+        ds = type("Stub", (), dict(vars(ds), __len__=lambda self: 40))()
+        ids = np.random.default_rng(1).permutation(40)[:12]
+        hb = DatasetBatch(ds, ids)
+        raw = collate_subset(pool, ids, option=option)
+        bt = pg.Batch.from_numpy(raw, "cpu", prepare=False)
+        assert hb.num_graphs == 12 and hb.n_atoms == raw["x"].shape[0] and hb.n_super == raw["super_edge_index"].shape[1]
+        assert hb.n_edges == int(edge_cnt[ids].sum()) and list(hb._sizes) == list(raw["sizes"])
+        assert hb.fingerprint() == pg.structure_fingerprint(bt, "schnet") == pg.structure_fingerprint(hb, "schnet")
+    with pytest.raises(IndexError):
+        DatasetBatch(ds, [40])
+    with pytest.raises(ValueError):
+        DatasetBatch(ds, [])
