@@ -866,7 +866,7 @@ def rccl_single_rank_line(mols=1024, steps=40, warmup=10):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
                "--mols", str(mols), "--no-secondary", "--no-cpu-baseline", "--no-roofline"]
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=REPO)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120, cwd=REPO)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not lines:
             return {"error": "rc %s: %s" % (r.returncode, (r.stderr or "")[-300:])}
