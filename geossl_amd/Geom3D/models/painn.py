@@ -265,7 +265,6 @@ class _PaiNNCore(torch.autograd.Function):
              ptr(cfg["status"].word), dN, st)                               # painn.py:247 (row 0 is the zero padding row)
         if cfg["debug"]:
             cfg["status"].check()
-        mu = torch.zeros(N, 3, F_, **f32)                                    # :249
         inc_ptr, inc_idx = el.inc["i"]
         saved = []
         # Every Dense layer here is a set of F x F row GEMMs (3F outputs = three, a 2F contraction = two with the
@@ -315,6 +314,13 @@ class _PaiNNCore(torch.autograd.Function):
                     stage_f = split_cap
             if big_f is None and lay.max_n > hard:
                 use_mma = False
+        # mu starts as zeros (:249).  When the matrix-pipe kernel covers every atom, the first interaction is told so (NULL)
+        # instead of being handed 3 N F zeros to stage and gather: its mu rows, the dmumu * mu_j products and - in the
+        # backward - the whole dmumu third of the filter are exact zeros (csrc: k_painn_fwd_mma<R, true>,
+        # k_painn_interaction_bwd_mol<R, true>).  Forces (edge gradients read mu) and GEOSSL_PAINN_NO_MU_ZERO keep the tensor.
+        mu_is_zero = (use_mma and big_f is None and not ctx.needs_input_grad[1] and R in (8, 16, 20)
+                      and not _env("GEOSSL_PAINN_NO_MU_ZERO"))
+        mu = None if mu_is_zero else torch.zeros(N, 3, F_, **f32)            # :249
         for l in range(L):
             c0w, c0b, c1w, c1b = inter[l]
             k0 = NB * l
@@ -330,7 +336,7 @@ class _PaiNNCore(torch.autograd.Function):
                 call("geossl_silu_fwd", ptr(u), u.numel(), ptr(s), st)
                 lin_fan(s, [k0 + 1 + c for c in range(3)], [c1b[c * F_:(c + 1) * F_] for c in range(3)],
                         _split3(xc, F_))                                     # Dense(F, 3F)
-            q2, mu2 = torch.empty_like(q), torch.empty_like(mu)
+            q2, mu2 = torch.empty_like(q), torch.empty(N, 3, F_, **f32)
             # one block per molecule: the rows its edges read are staged in LDS once
             if use_mma:  # filter on the matrix pipe (painn_mma.hip); LDS: 3.5 KB per atom + 3 KB
                 row_edge, grp_atom, _, mol_grp = el.groups("i", lay.mol_ptr)
@@ -373,7 +379,7 @@ class _PaiNNCore(torch.autograd.Function):
                 call("geossl_silu_fwd", ptr(u1), u1.numel(), ptr(s1), st)
                 lin_fan(s1, [k0 + 8 + c for c in range(3)], [i1b[c * F_:(c + 1) * F_] for c in range(3)],
                         _split3(xx, F_))                                     # Dense(F, 3F)
-            q3, mu3 = torch.empty_like(q), torch.empty_like(mu)
+            q3, mu3 = torch.empty_like(q), torch.empty(N, 3, F_, **f32)
             call("geossl_painn_mix_post_fwd_dyn", ptr(q2), ptr(mu2), ptr(mm), ptr(xx), ptr(dot), N, F_, ptr(q3), ptr(mu3),
                  dN, st)
             if training:
@@ -528,14 +534,18 @@ class _PaiNNCore(torch.autograd.Function):
                      ptr(el.idx_j), ptr(phi), ptr(fcut), ptr(dirv), ptr(ps[1][l * 3 * F_:(l + 1) * 3 * F_]),
                      ptr(ps[2][l * 3 * F_:(l + 1) * 3 * F_]), E, F_, R, ptr(dphi), ptr(dfc), ptr(ddir),
                      0 if l == L - 1 else 1, st)
-            dxc, dmu_in = torch.empty(N, 3 * F_, **f32), torch.empty(N, 3, F_, **f32)
+            mu_l = sv["mu"]
+            if mu_l is None and big_b is not None:   # (cannot happen with today's stage caps: the forward's is the smaller)
+                mu_l = torch.zeros(N, 3, F_, **f32)
+            # (the first interaction's mu is identically zero and its gradient is nobody's input: NULL for both)
+            dxc, dmu_in = torch.empty(N, 3 * F_, **f32), (None if mu_l is None else torch.empty(N, 3, F_, **f32))
             call("geossl_painn_interaction_bwd_mol" if big_b is None else "geossl_painn_interaction_bwd_mol_skip",
-                 ptr(dq2), ptr(dmu2), ptr(sv["mu"]), ptr(sv["xc"]), ptr(el.idx_i),
+                 ptr(dq2), ptr(dmu2), ptr(mu_l), ptr(sv["xc"]), ptr(el.idx_i),
                  ptr(inc_ptr), ptr(inc_idx), ptr(phi), ptr(fcut), ptr(dirv), ptr(ps[1][l * 3 * F_:(l + 1) * 3 * F_]),
                  ptr(ps[2][l * 3 * F_:(l + 1) * 3 * F_]), ptr(lay.mol_ptr), lay.B, lay.max_n, N, F_, R, ptr(dxc), ptr(dmu_in),
                  ptr(g_fw[l * 3 * F_:(l + 1) * 3 * F_]), ptr(g_fb[l * 3 * F_:(l + 1) * 3 * F_]), ptr(ws), acc, st)
             if big_b is not None and big_b[1] > 0:
-                call("geossl_painn_interaction_bwd_atoms", ptr(dq2), ptr(dmu2), ptr(sv["mu"]), ptr(sv["xc"]), ptr(el.idx_i),
+                call("geossl_painn_interaction_bwd_atoms", ptr(dq2), ptr(dmu2), ptr(mu_l), ptr(sv["xc"]), ptr(el.idx_i),
                      ptr(inc_ptr), ptr(inc_idx), ptr(phi), ptr(fcut), ptr(dirv), ptr(ps[1][l * 3 * F_:(l + 1) * 3 * F_]),
                      ptr(ps[2][l * 3 * F_:(l + 1) * 3 * F_]), ptr(big_b[0]), big_b[1], big_b[2], F_, R, ptr(dxc), ptr(dmu_in),
                      ptr(g_fw[l * 3 * F_:(l + 1) * 3 * F_]), ptr(g_fb[l * 3 * F_:(l + 1) * 3 * F_]), ptr(ws), 1, st)

@@ -16,6 +16,14 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+# Extra compiler flags of single translation units.  painn_mma.hip: no packed fp32 arithmetic (the SLP vectoriser is what
+# forms v_pk_*_f32 here).  With it the mu-zero form of k_painn_fwd_mma contained `v_pk_mul_f32 vD, vA, vB op_sel:[0,1]` (both
+# results read the HIGH half of src1), and on MI355X that instruction now and then returned a low result of 0 in lanes
+# 48-63 when a second wave shared the SIMD: one term of a sum of four missing, 5-10 atoms of 18 432 per launch, never with
+# one block per CU, never without packed ops (tools/scan_packed_opsel.py).  Same speed either way (140 / 173 us).
+SOURCE_FLAGS = {"painn_mma.hip": ["-fno-slp-vectorize"]}
+
+
 def _headers():
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     inc = os.path.join(REPO, "include")
@@ -28,6 +36,7 @@ def source_hash():
     summary only while the stamp still matches."""
     import hashlib
     h = hashlib.sha256()
+    h.update(repr(sorted(SOURCE_FLAGS.items())).encode())
     for path in sorted([os.path.join(CSRC, s_) for s_ in _sources()] + _headers()):
         h.update(os.path.basename(path).encode() + b"\0")
         with open(path, "rb") as fh:
@@ -42,7 +51,7 @@ def _newest(paths):
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
-    deps = [os.path.join(CSRC, s) for s in _sources()] + _headers()
+    deps = [os.path.join(CSRC, s) for s in _sources()] + _headers() + [os.path.abspath(__file__)]   # (SOURCE_FLAGS)
     return _newest(deps) > os.path.getmtime(LIB_PATH)
 
 
@@ -56,7 +65,7 @@ def build(force=False, verbose=True):
     for s in _sources():
         obj = os.path.join(LIB_DIR, s.replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(REPO, "include"),
-               "-I", CSRC, "-Wno-pass-failed", "-c", os.path.join(CSRC, s), "-o", obj]
+               "-I", CSRC, "-Wno-pass-failed"] + SOURCE_FLAGS.get(s, []) + ["-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))

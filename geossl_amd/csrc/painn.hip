@@ -398,7 +398,12 @@ __device__ __forceinline__ int block_lower_bound(const T* __restrict__ src, int 
 
 // backward: persistent blocks over molecules; the upstream gradients of the molecule's atoms staged in LDS; the
 // filter-network gradient partials of the block's thread groups are summed through LDS: one partial per block
-template <int R>
+// MZ: the interaction's input mu is identically zero and nobody asks for its gradient (the FIRST interaction,
+// painn.py:249: mu = zeros): no row of mu is read, the dmumu third of the filter (W2) is not evaluated - its products
+// s2 = <dmu_out, mu_j> are exact zeros, so dxc's third channel, its filter-weight gradient and bias gradient are written /
+// left as zeros like the general form computes them - and dmu_in is not written.  45 of the ~145 operations per edge and
+// feature, the 3F-float row of mu per atom and the 3F-float row of dmu_in per atom go.
+template <int R, bool MZ = false>
 __global__ __launch_bounds__(512) void k_painn_interaction_bwd_mol(
     const float* __restrict__ dq_out, const float* __restrict__ dmu_out, const float* __restrict__ mu,
     const float* __restrict__ xc, const int64_t* __restrict__ idx_i, const int64_t* __restrict__ inc_ptr,
@@ -457,9 +462,12 @@ __global__ __launch_bounds__(512) void k_painn_interaction_bwd_mol(
     for (int ja = ja_lo + g; ja < ja_hi; ja += G) {
       const int j = a0 + ja;
       const float* __restrict__ xj = xc + (size_t)j * 3 * F;
-      const float* __restrict__ mj = mu + (size_t)j * 3 * F;
       const float xj0 = xj[f], xj1 = xj[F + f], xj2 = xj[2 * F + f];
-      const float m0 = mj[f], m1 = mj[F + f], m2 = mj[2 * F + f];
+      float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
+      if constexpr (!MZ) {
+        const float* __restrict__ mj = mu + (size_t)j * 3 * F;
+        m0 = mj[f]; m1 = mj[F + f]; m2 = mj[2 * F + f];
+      }
       float dx0 = 0.0f, dx1 = 0.0f, dx2 = 0.0f, dmj0 = 0.0f, dmj1 = 0.0f, dmj2 = 0.0f;
       const int64_t p0 = inc_ptr[j], p1 = inc_ptr[j + 1];
       const int lane_ = threadIdx.x & 63;
@@ -476,40 +484,51 @@ __global__ __launch_bounds__(512) void k_painn_interaction_bwd_mol(
           pr[r] = row[r];
           W0 = fmaf(pr[r], w0[r], W0);
           W1 = fmaf(pr[r], w1[r], W1);
-          W2 = fmaf(pr[r], w2[r], W2);
+          if constexpr (!MZ) W2 = fmaf(pr[r], w2[r], W2);
         }
         const float fc = row[R];
-        W0 *= fc; W1 *= fc; W2 *= fc;
+        W0 *= fc; W1 *= fc;
         const float gq = gqs[(size_t)il * F + f];
         const float* gm = gms + (size_t)il * 3 * F;
         const float gm0 = gm[f], gm1 = gm[F + f], gm2 = gm[2 * F + f];
-        const float s1 = gm0 * row[R + 1] + gm1 * row[R + 2] + gm2 * row[R + 3];
-        const float s2 = gm0 * m0 + gm1 * m1 + gm2 * m2;
+        // (every rounding spelled out: the two instantiations share these lines and must share their results bit for
+        // bit - left to -ffp-contract=fast the compiler fused them differently in the two, 1e-7 of a gradient)
+        const float s1 = fmaf(gm2, row[R + 3], fmaf(gm1, row[R + 2], mul_rn(gm0, row[R + 1])));
         dx0 = fmaf(gq, W0, dx0);
         dx1 = fmaf(s1, W1, dx1);
-        dx2 = fmaf(s2, W2, dx2);
-        const float x2 = W2 * xj2;
-        dmj0 = fmaf(gm0, x2, dmj0);
-        dmj1 = fmaf(gm1, x2, dmj1);
-        dmj2 = fmaf(gm2, x2, dmj2);
         // W_c = (b_c + sum_r phi_r w_c[r]) * fcut
-        const float t0 = gq * xj0 * fc, t1 = s1 * xj1 * fc, t2 = s2 * xj2 * fc;
-        gb0 += t0; gb1 += t1; gb2 += t2;
+        const float t0 = mul_rn(mul_rn(gq, xj0), fc), t1 = mul_rn(mul_rn(s1, xj1), fc);
+        gb0 = add_rn(gb0, t0);
+        gb1 = add_rn(gb1, t1);
+        if constexpr (!MZ) {
+          W2 *= fc;
+          const float s2 = fmaf(gm2, m2, fmaf(gm1, m1, mul_rn(gm0, m0)));
+          dx2 = fmaf(s2, W2, dx2);
+          const float x2 = W2 * xj2;
+          dmj0 = fmaf(gm0, x2, dmj0);
+          dmj1 = fmaf(gm1, x2, dmj1);
+          dmj2 = fmaf(gm2, x2, dmj2);
+          const float t2 = mul_rn(mul_rn(s2, xj2), fc);
+          gb2 = add_rn(gb2, t2);
+#pragma unroll
+          for (int r = 0; r < R; ++r) g2[r] = fmaf(t2, pr[r], g2[r]);
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           g0[r] = fmaf(t0, pr[r], g0[r]);
           g1[r] = fmaf(t1, pr[r], g1[r]);
-          g2[r] = fmaf(t2, pr[r], g2[r]);
         }
        }
       }
       float* dxo = dxc + (size_t)j * 3 * F;
       dxo[f] = dx0; dxo[F + f] = dx1; dxo[2 * F + f] = dx2;
-      float* dmo = dmu_in + (size_t)j * 3 * F;
-      const float* gmj = gms + (size_t)ja * 3 * F;
-      dmo[f] = gmj[f] + dmj0;           // residual mu_out = mu + dmu  plus the edges that read mu[j]
-      dmo[F + f] = gmj[F + f] + dmj1;
-      dmo[2 * F + f] = gmj[2 * F + f] + dmj2;
+      if constexpr (!MZ) {
+        float* dmo = dmu_in + (size_t)j * 3 * F;
+        const float* gmj = gms + (size_t)ja * 3 * F;
+        dmo[f] = gmj[f] + dmj0;           // residual mu_out = mu + dmu  plus the edges that read mu[j]
+        dmo[F + f] = gmj[F + f] + dmj1;
+        dmo[2 * F + f] = gmj[2 * F + f] + dmj2;
+      }
     }
   }
   // one partial per block: the groups' sums added in group order through LDS (3F (R + 1) floats <= the row stage)
@@ -820,6 +839,10 @@ static int painn_interaction_bwd_mol_launch(const float* dq_out, const float* dm
                                             float* dxc, float* dmu_in, float* dWf, float* dbf, float* workspace,
                                             int accumulate, bool skip_big, hipStream_t stream) {
   if (N <= 0 || B <= 0) return 0;
+  // mu == NULL: the input mu is identically zero (the first interaction) and dmu_in is not wanted (NULL as well) - only
+  // the molecule-staged kernel knows that form
+  const bool mz = mu == nullptr;
+  if (mz != (dmu_in == nullptr)) return (int)hipErrorInvalidValue;
   if (skip_big) {  // molecules above the LDS rows are left to the caller (geossl_painn_interaction_bwd_atoms)
     const int cap = geossl_painn_stage_cap(2, F, R);
     if (cap <= 0) return (int)hipErrorInvalidValue;
@@ -828,7 +851,7 @@ static int painn_interaction_bwd_mol_launch(const float* dq_out, const float* dm
   size_t stage = (size_t)max_n * 4 * F, red = (size_t)3 * F * (R + 1);
   // (n_rbf = 32: the molecule-staged backward would hold 32 filter rows per thread and spill; the per-atom form runs)
   if (!painn_mol_ok(F, max_n, (size_t)4 * F) || red * sizeof(float) > 150 * 1024 || R == 32)
-    return skip_big ? (int)hipErrorInvalidValue :
+    return (skip_big || mz) ? (int)hipErrorInvalidValue :
         geossl_painn_interaction_bwd(dq_out, dmu_out, mu, xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, N, F, R,
                                      dxc, dmu_in, dWf, dbf, workspace, accumulate, stream);
   const int nb = (int)(B < GEOSSL_PAINN_BWD_MOL_BLOCKS ? B : GEOSSL_PAINN_BWD_MOL_BLOCKS);
@@ -843,17 +866,24 @@ static int painn_interaction_bwd_mol_launch(const float* dq_out, const float* dm
   const size_t estage = (size_t)(4 * F / 64) * ECHUNK * (((R + 5 + 3) / 4) * 4);  // per-wave edge stages (floats)
   const size_t lds = ((stage + estage) > red ? (stage + estage) : red) * sizeof(float);
   if (lds > 160 * 1024)  // (rows + edge stages above the LDS: the per-atom form)
-    return skip_big ? (int)hipErrorInvalidValue :
+    return (skip_big || mz) ? (int)hipErrorInvalidValue :
         geossl_painn_interaction_bwd(dq_out, dmu_out, mu, xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, N, F, R,
                                      dxc, dmu_in, dWf, dbf, workspace, accumulate, stream);
   float* pw = workspace;
   float* pb = workspace + (size_t)nb * 3 * F * R;
 #define LAUNCH_BWD_MOL(RV)                                                                                          \
   do {                                                                                                              \
-    allow_big_lds(&k_painn_interaction_bwd_mol<RV>);                                                                \
-    hipLaunchKernelGGL((k_painn_interaction_bwd_mol<RV>), dim3(nb), dim3(4 * F), lds, stream, dq_out, dmu_out, mu,  \
-                       xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, mol_ptr, (int)B, max_n, F, dxc, dmu_in, \
-                       pw, pb, (int)N, balance);                                                                    \
+    if (mz) {                                                                                                       \
+      allow_big_lds(&k_painn_interaction_bwd_mol<RV, true>);                                                        \
+      hipLaunchKernelGGL((k_painn_interaction_bwd_mol<RV, true>), dim3(nb), dim3(4 * F), lds, stream, dq_out,       \
+                         dmu_out, mu, xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, mol_ptr, (int)B, max_n,  \
+                         F, dxc, dmu_in, pw, pb, (int)N, balance);                                                  \
+    } else {                                                                                                        \
+      allow_big_lds(&k_painn_interaction_bwd_mol<RV>);                                                              \
+      hipLaunchKernelGGL((k_painn_interaction_bwd_mol<RV>), dim3(nb), dim3(4 * F), lds, stream, dq_out, dmu_out,    \
+                         mu, xc, idx_i, inc_ptr, inc_idx, phi, fcut, dir, Wf, bf, mol_ptr, (int)B, max_n, F, dxc,   \
+                         dmu_in, pw, pb, (int)N, balance);                                                          \
+    }                                                                                                               \
   } while (0)
   if (R == 20) LAUNCH_BWD_MOL(20); else if (R == 16) LAUNCH_BWD_MOL(16); else if (R == 8) LAUNCH_BWD_MOL(8);
   else return (int)hipErrorInvalidValue;

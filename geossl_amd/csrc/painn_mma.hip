@@ -19,6 +19,10 @@
 // atom is written out; the one run a tile boundary can cut stays in its registers and goes on in the next tile.
 // Fixed order everywhere: results are bit-reproducible; they differ from the per-atom kernels' only in the order of an
 // atom's sum (tests: 2e-6 of the tensor scale).
+//
+// Built WITHOUT packed fp32 arithmetic (build.py: -fno-slp-vectorize for this file; tests/test_round6_cpu.py checks the
+// code object): the packed form the compiler chose for the mu-zero instantiation, `v_pk_mul_f32 .. op_sel:[0,1]`,
+// occasionally lost its low result in lanes 48-63 with two waves per SIMD.  Same run time.
 #include "common.h"
 #include "geossl_hip.h"
 #include "split.h"
@@ -165,7 +169,10 @@ struct TilePos {  // a team's position in its sequence of tiles (wave-uniform)
 // ------------------------------------------------------------------------------------------------- forward
 // q_out[i] = q[i] + sum_e dq_e, mu_out[i] = mu[i] + sum_e (dmuR_e dir_e + dmumu_e mu[j_e]) over the edges e of target i,
 // [dq, dmuR, dmumu]_e = W_e * x[j_e]   (painn.py:54-64)
-template <int R>
+// MZ: mu is identically zero (the FIRST interaction, painn.py:249; A.mu is NULL): its rows are neither staged nor
+// gathered - half of the LDS gathers of a tile, which is what the kernel is bound by - and the message's dmumu * mu_j term
+// and the residual mu[i] drop out as the exact zeros they are in the general form.
+template <int R, bool MZ = false>
 __global__ __launch_bounds__(256, 2) void k_painn_fwd_mma(PainnMmaArgs A) {
   constexpr int F = PM_F, ROWB = 3 * F * 4;  // bytes of a staged row
   static_assert(R <= 20, "EdgeRow holds the three groups of four an R <= 20 basis needs per lane");
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void k_painn_fwd_mma(PainnMmaArgs A) {
       __syncthreads();  // the previous molecule's rows are no longer read
       // (all requests of a pass in flight together: a load-store loop pays one memory round trip per iteration)
       const f32x4* xg = reinterpret_cast<const f32x4*>(A.xc + (size_t)T0.a0 * 3 * F);
-      const f32x4* mg = reinterpret_cast<const f32x4*>(A.mu + (size_t)T0.a0 * 3 * F);
+      const f32x4* mg = MZ ? xg : reinterpret_cast<const f32x4*>(A.mu + (size_t)T0.a0 * 3 * F);   // (MZ: never read)
       const f32x4* qg = reinterpret_cast<const f32x4*>(A.q + (size_t)T0.a0 * F);
       const int cnt = T0.n * 3 * F / 4, cntq = T0.n * F / 4;
       for (int base = 0, baseq = 0; base < cnt; base += 8 * 256, baseq += 3 * 256) {
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void k_painn_fwd_mma(PainnMmaArgs A) {
         for (int k = 0; k < 8; ++k) {
           const int u = min(base + k * 256 + tid, cnt - 1);
           bx[k] = xg[u];
-          bm[k] = mg[u];
+          if constexpr (!MZ) bm[k] = mg[u];
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) bq[k] = qg[min(baseq + k * 256 + tid, cntq - 1)];
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void k_painn_fwd_mma(PainnMmaArgs A) {
           const int u = base + k * 256 + tid;
           if (u < cnt) {
             reinterpret_cast<f32x4*>(xs)[u] = bx[k];
-            reinterpret_cast<f32x4*>(ms)[u] = bm[k];
+            if constexpr (!MZ) reinterpret_cast<f32x4*>(ms)[u] = bm[k];
           }
         }
 #pragma unroll
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void k_painn_fwd_mma(PainnMmaArgs A) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           xv[e][c] = *reinterpret_cast<const float*>(xs_l + jov[e] + c * F * 4);
-          mv[e][c] = *reinterpret_cast<const float*>(ms_l + jov[e] + c * F * 4);
+          if constexpr (!MZ) mv[e][c] = *reinterpret_cast<const float*>(ms_l + jov[e] + c * F * 4);
         }
       float sq = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -346,9 +353,15 @@ __global__ __launch_bounds__(256, 2) void k_painn_fwd_mma(PainnMmaArgs A) {
         const float x0 = (acc[0][r] * kf[e]) * xv[e][0], x1 = (acc[1][r] * kf[e]) * xv[e][1],
                     x2 = (acc[2][r] * kf[e]) * xv[e][2];                                  // painn.py:241, :56
         sq += x0;                                                                         // :59
-        s0 += x1 * d0[e] + x2 * mv[e][0];                                                 // :60-61
-        s1 += x1 * d1[e] + x2 * mv[e][1];
-        s2 += x1 * d2[e] + x2 * mv[e][2];
+        if constexpr (MZ) {   // (x2 * 0 added to the rounded product x1 * d leaves it: the same value, two instructions less)
+          s0 = add_rn(s0, mul_rn(x1, d0[e]));
+          s1 = add_rn(s1, mul_rn(x1, d1[e]));
+          s2 = add_rn(s2, mul_rn(x1, d2[e]));
+        } else {
+          s0 += x1 * d0[e] + x2 * mv[e][0];                                               // :60-61
+          s1 += x1 * d1[e] + x2 * mv[e][1];
+          s2 += x1 * d2[e] + x2 * mv[e][2];
+        }
       }
       gs[q4][0] = sq;
       gs[q4][1] = s0;
@@ -380,9 +393,14 @@ __global__ __launch_bounds__(256, 2) void k_painn_fwd_mma(PainnMmaArgs A) {
     for (int g = 0; g < 8; ++g) {  // all LDS reads of the eight groups first, then arithmetic and stores
       const bool fin = ga[g] >= 0 && glast[g];
       const int al = fin ? ga[g] - T0.a0 : 0;
-      const float* mrow = ms + (size_t)al * 3 * F + f;
-      res0[g] = kh ? mrow[F] : qs[(size_t)al * F + f];
-      res1[g] = kh ? mrow[2 * F] : mrow[0];
+      if constexpr (MZ) {
+        res0[g] = kh ? 0.0f : qs[(size_t)al * F + f];
+        res1[g] = 0.0f;
+      } else {
+        const float* mrow = ms + (size_t)al * 3 * F + f;
+        res0[g] = kh ? mrow[F] : qs[(size_t)al * F + f];
+        res1[g] = kh ? mrow[2 * F] : mrow[0];
+      }
     }
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
@@ -448,8 +466,13 @@ extern "C" int geossl_painn_interaction_fwd_mma_dyn(const float* q, const float*
   const int nb = (int)(B < 256 * per_cu ? B : 256 * per_cu);
 #define LAUNCH_FWD_MMA(RV)                                                                              \
   do {                                                                                                  \
-    allow_big_lds(&k_painn_fwd_mma<RV>);                                                                \
-    hipLaunchKernelGGL((k_painn_fwd_mma<RV>), dim3((unsigned)nb), dim3(256), lds, stream, a);           \
+    if (mu == nullptr) {  /* mu identically zero: the first interaction */                              \
+      allow_big_lds(&k_painn_fwd_mma<RV, true>);                                                        \
+      hipLaunchKernelGGL((k_painn_fwd_mma<RV, true>), dim3((unsigned)nb), dim3(256), lds, stream, a);   \
+    } else {                                                                                            \
+      allow_big_lds(&k_painn_fwd_mma<RV>);                                                              \
+      hipLaunchKernelGGL((k_painn_fwd_mma<RV>), dim3((unsigned)nb), dim3(256), lds, stream, a);         \
+    }                                                                                                   \
   } while (0)
   if (R == 20) LAUNCH_FWD_MMA(20); else if (R == 16) LAUNCH_FWD_MMA(16); else LAUNCH_FWD_MMA(8);
 #undef LAUNCH_FWD_MMA

@@ -470,7 +470,10 @@ int geossl_painn_interaction_bwd(const float* dq_out, const float* dmu_out, cons
  * of four waves per molecule.  Rows are laid out in groups of four that share their target atom (the edges of an atom
  * in incidence order, padded to a multiple of four): row_edge [4 G] int32 (-1 = padding), grp_atom [G] int32 =
  * 2 * atom + (the group is the last one of its atom), mol_grp [B + 1] int32 = first group of a molecule; an atom
- * without edges has one group of padding rows.  Same sums as geossl_painn_interaction_fwd in another (fixed) order. */
+ * without edges has one group of padding rows.  Same sums as geossl_painn_interaction_fwd in another (fixed) order.
+ * mu == NULL (round 6): mu is identically zero - the FIRST interaction (painn.py:249) - no row of it is staged or gathered;
+ * likewise geossl_painn_interaction_bwd_mol[_skip] with mu == NULL and dmu_in == NULL (both or neither): the dmumu third of
+ * the filter is not evaluated, its outputs are the exact zeros the general form computes, dmu_in is not written. */
 int geossl_painn_interaction_fwd_mma(const float* q, const float* mu, const float* xc, const int64_t* idx_j,
                                      const int32_t* row_edge, const int32_t* grp_atom, const int32_t* mol_grp,
                                      const float* phi, const float* fcut, const float* dir, const float* Wf,

