@@ -559,3 +559,51 @@ def test_painn_step_with_the_mu_zero_shortcut_is_the_general_step_bit_for_bit(mo
         assert loss == ref_loss
         for n in ref:
             assert torch.equal(grads[n], ref[n]), n
+
+
+@pytest.mark.parametrize("backbone", ["schnet", "painn"])
+def test_step_reads_no_memory_it_has_not_written(backbone):
+    """Every buffer of a step comes from torch.empty: a kernel that read a row it never wrote (padding rows of a tile, the
+    tail of a capacity, a gradient slot nobody filled) would pick up whatever the caching allocator hands back.  The same
+    step after the allocator's free blocks were filled with NaN - and again with 1e30, which a product with zero would
+    hide a NaN's absence of - must give the same loss and gradients bit for bit, all finite."""
+    from geossl_amd import ops
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.Geom3D.models import PaiNN
+    from geossl_amd.synthetic import draw_noise, make_batch
+    from helpers import fill_module_
+    b = make_batch(96, seed=91, mode="B")
+    nz = {k: t(v, DEV) for k, v in draw_noise(b, seed=92).items()}
+    bt = pg.Batch.from_numpy(b, DEV)
+    if backbone == "painn":
+        bt.radius_edge_index = ops.radius_graph(bt.positions, 5.0, bt.batch)
+
+    def poison(value):
+        junk = [torch.full((n,), value, device=DEV) for n in (1 << 9, 1 << 12, 1 << 15, 1 << 18, 1 << 20, 3 << 19, 1 << 22, 5 << 20)
+                for _ in range(8)]
+        torch.cuda.synchronize()
+        del junk
+
+    def step(value):
+        gc.collect()
+        if backbone == "painn":
+            model = fill_module_(PaiNN(n_atom_basis=128, n_interactions=3, n_rbf=20, cutoff=5.0, max_z=9, n_out=1,
+                                       readout="add")).to(DEV)
+        else:
+            model = product_schnet(dict(hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=5.0,
+                                        node_class=9, readout="mean"), DEV)
+        heads = (product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9))
+        if value is not None:
+            poison(value)
+        loss, _ = pg.do_DDM(pg.Args(backbone), bt, model, None, 0.0, 0.3, NCSN_models=heads, noise=nz, graph=False)
+        loss.backward()
+        return float(loss.detach()), {n: p.grad.clone() for m in (model,) + heads for n, p in m.named_parameters()
+                                      if p.grad is not None}
+
+    ref_loss, ref = step(None)
+    assert np.isfinite(ref_loss) and all(bool(torch.isfinite(g).all()) for g in ref.values())
+    for value in (float("nan"), 1e30):
+        loss, grads = step(value)
+        assert loss == ref_loss, value
+        for n in ref:
+            assert torch.equal(grads[n], ref[n]), (value, n)

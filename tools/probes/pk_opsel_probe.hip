@@ -5,7 +5,7 @@
 //   tools/probes/pk_opsel_probe
 // One 512-thread block per CU.  Waves 0-3 (one per SIMD) issue the packed multiply in a loop and compare both halves
 // with scalar products; waves 4-7 (the same SIMDs) run a disturber: nothing / MFMAs / scalar FMAs / LDS reads / packed
-// multiplies.  test form 1 feeds the packed multiply the way the kernel did: its src0 pair is [a register written by
+// multiplies / v_permlane32_swap / v_readlane.  test form 1 feeds the packed multiply the way the kernel did: its src0 pair is [a register written by
 // v_mov just before, the second dword of a ds_read_b128].
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -79,6 +79,21 @@ __global__ __launch_bounds__(512) void k(int test, int disturb, int iters, unsig
         const f32x4 q = *reinterpret_cast<const volatile f32x4*>(&tab[wave][((it * 7 + lane) & 63) * 4]);
         r += q[0] + q[3];
       }
+    } else if (disturb == 5) {  // the kernel's half exchange
+      unsigned u = lane * 2654435761u, w = u ^ 0x55555555u;
+      for (int it = 0; it < iters * 2; ++it) {
+        asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(u), "+v"(w));
+        u += 1;
+      }
+      r = (float)(u ^ w);
+    } else if (disturb == 6) {  // lane reads into SGPRs and selects under SGPR masks (the kernel's group codes)
+      int code = lane * 37 + 1, acc = 0;
+      for (int it = 0; it < iters; ++it) {
+        const int c0 = __builtin_amdgcn_readlane(code, it & 7), c1 = __builtin_amdgcn_readlane(code, (it + 3) & 7);
+        acc += (c0 & 1) ? c1 : -c1;
+        code = code * 3 + acc;
+      }
+      r = (float)acc;
     } else if (disturb == 4) {
       f32x2 a = {1.0f + lane, 2.0f}, b = {0.5f, 1.0001f}, d;
       for (int it = 0; it < iters * 2; ++it) {
@@ -96,9 +111,9 @@ int main(int argc, char** argv) {
   unsigned long long *d, h[3];
   float* sink;
   if (hipMalloc(&d, 3 * sizeof(*d)) != hipSuccess || hipMalloc(&sink, 4) != hipSuccess) return 1;
-  const char* dn[] = {"idle", "mfma", "scalar fma", "lds reads", "packed mul"};
+  const char* dn[] = {"idle", "mfma", "scalar fma", "lds reads", "packed mul", "permlane32", "readlane"};
   for (int test = 0; test < 2; ++test)
-    for (int disturb = 0; disturb < 5; ++disturb) {
+    for (int disturb = 0; disturb < 7; ++disturb) {
       (void)hipMemset(d, 0, 3 * sizeof(*d));
       hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, test, disturb, iters, d, d + 1, d + 2, sink);
       if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
