@@ -379,7 +379,9 @@ class _PaiNNCore(torch.autograd.Function):
                 call("geossl_silu_fwd", ptr(u1), u1.numel(), ptr(s1), st)
                 lin_fan(s1, [k0 + 8 + c for c in range(3)], [i1b[c * F_:(c + 1) * F_] for c in range(3)],
                         _split3(xx, F_))                                     # Dense(F, 3F)
-            q3, mu3 = torch.empty_like(q), torch.empty(N, 3, F_, **f32)
+            # (the representation is q alone, :262-269: the LAST block's mu' is nobody's input and is not formed - NULL)
+            mu_dead = l == L - 1 and not _env("GEOSSL_PAINN_NO_MU_ZERO")
+            q3, mu3 = torch.empty_like(q), (None if mu_dead else torch.empty(N, 3, F_, **f32))
             call("geossl_painn_mix_post_fwd_dyn", ptr(q2), ptr(mu2), ptr(mm), ptr(xx), ptr(dot), N, F_, ptr(q3), ptr(mu3),
                  dN, st)
             if training:
@@ -429,7 +431,8 @@ class _PaiNNCore(torch.autograd.Function):
         if dyn is not None and want_pos:
             raise _lib.GeosslHipError("a capacity-bucket layout serves the step without position gradients")
         dq_cur = dq.contiguous()
-        dmu_cur = torch.zeros(N, 3, F_, **f32)
+        # d(last block's mu') = 0, as NULL: no 3 N F zeros written, read by two kernels and added as a residual
+        dmu_cur = torch.zeros(N, 3, F_, **f32) if _env("GEOSSL_PAINN_NO_MU_ZERO") else None
         groups = {}  # (rows, lda, ldb, ldw) -> list of problems, all with M = N = F
 
         def add(rows, lda, ldb, ldw, A, Bm, dW, db):
@@ -524,7 +527,8 @@ class _PaiNNCore(torch.autograd.Function):
             call("geossl_painn_mix_pre_bwd_dyn", ptr(dq_cur), ptr(dctx), ptr(sv["cx"]), ptr(sv["mm"]), N, F_, ptr(dq2),
                  ptr(dmm), dN, st)
             # d mu (after interaction): contraction over the 2F columns of dmm in two F-wide passes
-            dmu2 = lin_t_sum([dmm[:, :F_], dmm[:, F_:]], [k0 + 4, k0 + 5], res=dmu_cur.view(3 * N, F_))
+            dmu2 = lin_t_sum([dmm[:, :F_], dmm[:, F_:]], [k0 + 4, k0 + 5],
+                             res=None if dmu_cur is None else dmu_cur.view(3 * N, F_))
             for c in range(2):
                 add(3 * N, 2 * F_, F_, F_, dmm[:, c * F_:(c + 1) * F_], sv["mu2"].view(3 * N, F_),
                     gmw[c * F_:(c + 1) * F_], None)

@@ -592,6 +592,7 @@ __global__ void k_painn_mix_post_fwd(const float* __restrict__ q, const float* _
     const float* x = xx + a * 3 * F;
     const float* m = mm + a * 6 * F;
     q_out[t] = q[t] + x[f] + x[2 * F + f] * dot[t];
+    if (mu_out == nullptr) continue;  // (the last block: mu' is not an input of anything, painn.py:262-269)
     const float dmi = x[F + f];
 #pragma unroll
     for (int k = 0; k < 3; ++k) mu_out[a * 3 * F + k * F + f] = mu[a * 3 * F + k * F + f] + dmi * m[2 * k * F + F + f];
@@ -613,7 +614,7 @@ __global__ void k_painn_mix_post_bwd(const float* __restrict__ dq_new, const flo
     float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const float gm = dmu_new[a * 3 * F + k * F + f];
+      const float gm = dmu_new != nullptr ? dmu_new[a * 3 * F + k * F + f] : 0.0f;   // (NULL: d mu' = 0, the last block)
       const float v = m[2 * k * F + f], w = m[2 * k * F + F + f];
       s += gm * w;
       dmm[a * 6 * F + 2 * k * F + f] = ddot * w;                    // d mu_V (dot term)

@@ -496,6 +496,8 @@ int geossl_painn_interaction_bwd_mol(const float* dq_out, const float* dmu_out, 
                                      int accumulate, hipStream_t stream);
 int geossl_painn_mix_pre_fwd(const float* q, const float* mm, int64_t N, int F, float eps, float* ctx, float* dot,
                              hipStream_t stream);
+/* mu_out == NULL (mix_post_fwd) / dmu_new == NULL (mix_post_bwd): the LAST block of the backbone - its mu' is nobody's
+ * input (the representation is q, painn.py:262-269), so it is not formed and its gradient is the zero it is. */
 int geossl_painn_mix_post_fwd(const float* q, const float* mu, const float* mm, const float* xx, const float* dot,
                               int64_t N, int F, float* q_out, float* mu_out, hipStream_t stream);
 int geossl_painn_mix_post_bwd(const float* dq_new, const float* dmu_new, const float* mm, const float* xx,

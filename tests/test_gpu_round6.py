@@ -514,8 +514,10 @@ def test_painn_first_interaction_with_mu_null_is_the_general_kernel_bit_for_bit(
 def test_painn_step_with_the_mu_zero_shortcut_is_the_general_step_bit_for_bit(monkeypatch):
     """The first interaction's mu is identically zero (painn.py:249): the product hands its kernels NULL instead of a
     tensor of zeros (k_painn_fwd_mma<R, true>, k_painn_interaction_bwd_mol<R, true>: no mu rows staged or gathered, the
-    dmumu third of the filter not evaluated).  Loss and every gradient of a DDM step equal the general kernels' bit for bit
-    (GEOSSL_PAINN_NO_MU_ZERO=1 selects those) - at a size where every CU holds two blocks - and twice in a row."""
+    dmumu third of the filter not evaluated); and the LAST block's mu' is nobody's input (the representation is q,
+    painn.py:262-269): it is not formed and its zero gradient is passed as NULL (mix_post_fwd / mix_post_bwd).  Loss and
+    every gradient of a DDM step equal the general kernels' bit for bit (GEOSSL_PAINN_NO_MU_ZERO=1 selects those) - at a
+    size where every CU holds two blocks - and twice in a row."""
     from geossl_amd import ops
     from geossl_amd import pretrain_GeoSSL as pg
     from geossl_amd.Geom3D.models import PaiNN
