@@ -42,16 +42,31 @@ template <int NCM, int NCN, class Ops, int PIECES = 2>
 __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chunk, int M, int N,
                                                         float* __restrict__ partial, float* __restrict__ partial_bias,
                                                         float* __restrict__ partial_dot,
-                                                        const int32_t* __restrict__ dyn_R) {
+                                                        const int32_t* __restrict__ dyn_R, int nblk, int nprob) {
   R = dyn_count(R, dyn_R);  // (row chunks past the real rows write zero partials)
+  // Which (problem z, row chunk c) this block is.  Consecutive block ids go round the eight XCDs, each with an L2 of its
+  // own; problems of one launch often share an operand (the three column blocks of a Dense(F, 3F) gradient read the same
+  // input rows, the two halves of mu_channel_mix's the same mu rows).  So a chunk belongs to ONE XCD (c mod 8) and all
+  // problems' blocks of that chunk follow each other there: they run at the same time and the shared rows come from
+  // that L2 once.  nblk < 0: the plain order (z = blockIdx.y, c = blockIdx.x; GEOSSL_WGRAD_PLAIN_ORDER, A/B timing).
+  int z, cidx;
+  if (nblk < 0) {
+    nblk = (int)gridDim.x;
+    z = blockIdx.y;
+    cidx = blockIdx.x;
+  } else {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    z = slot % nprob;
+    cidx = 8 * (slot / nprob) + xcd;
+    if (cidx >= nblk) return;  // (the chunk count rounded up to a multiple of eight: block-uniform, before any barrier)
+  }
   constexpr int SA = (NCM + 3) / 4, SB = (NCN + 3) / 4;  // operand blocks converted per wave: A block wave + 4u
   constexpr int T = NCM * NCN, TPW = (T + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
   u32x4* Fr = reinterpret_cast<u32x4*>(smem_raw);  // [NCM + NCN][2 k-steps][PIECES][64]: A blocks first, then B blocks
   int* eblk = reinterpret_cast<int*>(Fr + (size_t)(NCM + NCN) * 2 * PIECES * 64);  // [NCM + NCN] running exponents
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
-  const int z = blockIdx.y;
-  const int row_begin = blockIdx.x * chunk, row_end = min(R, row_begin + chunk);
+  const int row_begin = cidx * chunk, row_end = min(R, row_begin + chunk);
   f32x16 acc[TPW];
 #pragma unroll
   for (int i = 0; i < TPW; ++i)
@@ -244,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_split(Ops ops, int R, int chun
     for (int p = 0; p < PF; ++p)
       if (row0 + 32 * p < row_end) tile(row0 + 32 * p, ra_[p], rb_[p]);  // (block-uniform condition)
   }
-  const size_t pb = (size_t)z * gridDim.x + blockIdx.x;
+  const size_t pb = (size_t)z * nblk + cidx;
   float* Pp = partial + pb * M * N;
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
@@ -292,16 +307,19 @@ int launch_wgrad_split(const Ops& ops, int nprob, int64_t R, int M, int N, const
     any_b |= out.db[z] != nullptr;
     any_d |= out.dd[z] != nullptr;
   }
+  static const bool plain_order = getenv("GEOSSL_WGRAD_PLAIN_ORDER") != nullptr;
+  const dim3 grid = plain_order ? dim3(nblk, nprob) : dim3((unsigned)(8 * ((nblk + 7) / 8) * nprob));
+  const int nblk_arg = plain_order ? -1 : nblk;
   if (arith_24bit()) {  // GEOSSL_ARITH_24BIT: three bf16 pieces, six MFMAs per product
     const size_t lds = (size_t)(NCM + NCN) * 2 * 3 * 1024 + (size_t)(NCM + NCN) * sizeof(int);
     allow_big_lds(&k_wgrad_split<NCM, NCN, Ops, 3>);
-    hipLaunchKernelGGL((k_wgrad_split<NCM, NCN, Ops, 3>), dim3(nblk, nprob), dim3(256), lds, stream, ops, (int)R, chunk, M,
-                       N, partial, any_b ? pbias : nullptr, any_d ? pdot : nullptr, dyn_R);
+    hipLaunchKernelGGL((k_wgrad_split<NCM, NCN, Ops, 3>), grid, dim3(256), lds, stream, ops, (int)R, chunk, M,
+                       N, partial, any_b ? pbias : nullptr, any_d ? pdot : nullptr, dyn_R, nblk_arg, nprob);
   } else {
     const size_t lds = (size_t)(NCM + NCN) * 2 * 2 * 1024 + (size_t)(NCM + NCN) * sizeof(int);
     allow_big_lds(&k_wgrad_split<NCM, NCN, Ops>);
-    hipLaunchKernelGGL((k_wgrad_split<NCM, NCN, Ops>), dim3(nblk, nprob), dim3(256), lds, stream, ops, (int)R, chunk, M,
-                       N, partial, any_b ? pbias : nullptr, any_d ? pdot : nullptr, dyn_R);
+    hipLaunchKernelGGL((k_wgrad_split<NCM, NCN, Ops>), grid, dim3(256), lds, stream, ops, (int)R, chunk, M,
+                       N, partial, any_b ? pbias : nullptr, any_d ? pdot : nullptr, dyn_R, nblk_arg, nprob);
   }
   GEOSSL_CHECK_LAUNCH();
   ReduceMulti rm;  // dW, db and dd partial sums in one launch
