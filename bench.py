@@ -262,6 +262,24 @@ def pmc_file(workload):
     return None, None
 
 
+def entry_traffic(pm, prefix):
+    """HBM bytes (FETCH + WRITE) of ONE launch of an entry point from a PMC summary: the kernels whose names start with
+    `prefix`, summed over DIFFERENT kernels (an entry point may launch several) and averaged, weighted by launches, over
+    the instantiations of one kernel (alternatives of the same launch: k_painn_interaction_bwd_mol<20, false> twice and
+    <20, true> once per step are three launches of one entry point, not one launch of two kernels)."""
+    groups = {}
+    for k, v in pm["kernels"].items():
+        if k.startswith(prefix):
+            groups.setdefault(k.split("<", 1)[0], []).append(v)
+    if not groups:
+        return None
+    total = 0.0
+    for vs in groups.values():
+        n = sum(v["launches"] for v in vs)
+        total += sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in vs) / max(n, 1)
+    return total
+
+
 def measured_step_traffic(pm, src, mols_per_s):
     """FETCH_SIZE + WRITE_SIZE of every kernel of a step, from the committed rocprofv3 PMC passes over
     tools/prof_step.py (eager steps of the same workload): what the step really moves through HBM, next to
@@ -1041,9 +1059,7 @@ def dominant_roofline(wl, prof_steps):
         # the kernels the entry point launches
         traffic = None
         if pm is not None:
-            ks = [v for k, v in pm["kernels"].items() if k.startswith(ENTRY_KERNELS.get(dom, "\0"))]
-            if ks:
-                traffic = sum(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for v in ks)
+            traffic = entry_traffic(pm, ENTRY_KERNELS.get(dom, "\0"))
         # The dense kernels run on the 16-bit matrix pipe, SPLIT MFMAs per fp32 product (csrc/split.h).
         # `frac` = what the kernel really issues (one filter evaluation per UNDIRECTED pair slot, G padded to 64,
         # times SPLIT MFMAs) over the dense 16-bit MFMA peak: the pipe's utilisation.  `frac_algorithmic` credits
@@ -1062,9 +1078,7 @@ def dominant_roofline(wl, prof_steps):
             # per molecule) - the fp32 vector fraction beside it
             pk = None
             if pm is not None:
-                ks = [v for k, v in pm["kernels"].items() if k.startswith(PAINN_KERNELS.get(dom, "\0"))]
-                if ks:
-                    pk = sum(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for v in ks)
+                pk = entry_traffic(pm, PAINN_KERNELS.get(dom, "\0"))
             used = pk if pk is not None else by
             roof.update({"bound": "hbm", "unit": "GB/s", "achieved": used / dur / 1e9, "peak": HBM_PEAK / 1e9,
                          "frac": used / dur / HBM_PEAK, "fp32_vector_frac": ach_f / FP32_PEAK, "traffic": pk,
