@@ -796,6 +796,27 @@ class _ReplayedLoss(torch.autograd.Function):
         return (None, None, None) + tuple(outs)
 
 
+class _StepLoss(torch.Tensor):
+    """The loss do_DDM's graph path hands to a caller that owns its optimizer - an ordinary tensor attached to the autograd
+    graph (``_ReplayedLoss`` with every parameter as an input: ``torch.autograd.grad``, scaled losses, sums with other
+    terms all differentiate through it as before) whose plain ``loss.backward()`` (pretrain_GeoSSL.py:259) does not go
+    through the autograd engine: the step's gradients are already in the engine's buffer, so backward() copies them into
+    the step's own buffer (one launch) and points every parameter's ``.grad`` at its view - what the 59 AccumulateGrad
+    nodes of the engine path do one queue round trip each (0.34 ms per step on the host, which is what bounds the loop at
+    the reference's batch size).  Anything else - a gradient argument, retain_graph, create_graph, inputs=, a parameter
+    that already holds a gradient (accumulation over several backward() calls) or carries a tensor hook, an arithmetic
+    result (ops on this class return plain tensors) - takes the engine.  GEOSSL_NO_DIRECT_BACKWARD: always the engine."""
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        st = self.__dict__.pop("_geossl_step", None)
+        if (st is not None and gradient is None and not retain_graph and not create_graph and inputs is None
+                and st[0].direct_backward(st[1])):
+            return None
+        return torch.Tensor.backward(self, gradient, retain_graph, create_graph, inputs)
+
+
 class _Ticket(dict):
     """The claim of one do_DDM step on the gradients its backward replay leaves in the engine's buffer ("serial",
     "event", "g", "used").  The replay runs on a side stream and READS the parameters: when a loss is dropped without
@@ -935,6 +956,21 @@ class _AutogradStep:
         ticket["used"] = True
         return self.gflat
 
+    def direct_backward(self, ticket):
+        """loss.backward() of the step `ticket` stands for without the autograd engine (_StepLoss): True when done."""
+        if _env("GEOSSL_NO_DIRECT_BACKWARD") or ticket.get("used") or "views" not in ticket:
+            return False
+        for p in self.params:
+            # (an existing gradient: accumulate like AccumulateGrad would; a tensor hook: call it like the engine would)
+            if p.grad is not None or p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+                return False
+        src = self.collect(ticket)   # (the caller's stream waits for the backward replay)
+        buf, outs = ticket.pop("views")
+        buf.copy_(src)               # d loss / d loss = 1: the engine path multiplies by it, same values
+        for p, v in zip(self.params, outs):
+            p.grad = v
+        return True
+
     def run(self, args, batch, mu, sigma, noise, device_noise):
         if getattr(batch, "_dataset", None) is None and (not batch.positions.is_cuda or batch.positions.requires_grad):
             return None
@@ -999,7 +1035,9 @@ class _AutogradStep:
         if st is not None:
             st.poll()
             st.arm(every=8)
-        return _ReplayedLoss.apply(loss, self, self._ticket, *self.params)
+        out = _ReplayedLoss.apply(loss, self, self._ticket, *self.params).as_subclass(_StepLoss)
+        out._geossl_step = (self, self._ticket)
+        return out
 
 
 _MT_PENDING = []   # tickets of this process whose autograd thread switch is still to be put back

@@ -609,3 +609,83 @@ def test_step_reads_no_memory_it_has_not_written(backbone):
         assert loss == ref_loss, value
         for n in ref:
             assert torch.equal(grads[n], ref[n]), (value, n)
+
+
+def test_plain_backward_of_a_replayed_step_skips_the_engine_and_leaves_what_the_engine_leaves(monkeypatch):
+    """do_DDM's graph path hands the reference loop a loss whose plain ``loss.backward()`` (pretrain_GeoSSL.py:259) points
+    the parameters' .grad at the step's gradients itself instead of sending 59 AccumulateGrad nodes through the autograd
+    engine (_StepLoss).  Same gradients bit for bit as the engine path (GEOSSL_NO_DIRECT_BACKWARD), same parameters after
+    stock Adam; a parameter that already holds a gradient, or carries a hook, sends the step through the engine - with
+    the accumulation / the hook call autograd promises."""
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.synthetic import draw_noise, make_batch
+    b = make_batch(40, seed=17, mode="B")
+    batch = pg.Batch.from_numpy(b, DEV)
+    nz = [{k: t(v, DEV) for k, v in draw_noise(b, seed=170 + i).items()} for i in range(4)]
+    args = pg.Args("schnet")
+    taken = []
+    real = pg._AutogradStep.direct_backward
+
+    def counted(self, ticket):
+        ok = real(self, ticket)
+        taken.append(ok)
+        return ok
+
+    monkeypatch.setattr(pg._AutogradStep, "direct_backward", counted)
+
+    def loop(direct):
+        if direct:
+            monkeypatch.delenv("GEOSSL_NO_DIRECT_BACKWARD", raising=False)
+        else:
+            monkeypatch.setenv("GEOSSL_NO_DIRECT_BACKWARD", "1")
+        torch.manual_seed(5)
+        model = product_schnet(dict(hidden_channels=128, num_filters=128, num_interactions=3, num_gaussians=51, cutoff=5.0,
+                                    node_class=9, readout="mean"), DEV)
+        heads = (product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9))
+        params = [p for m in (model,) + heads for p in m.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=5e-4)
+        del taken[:]
+        losses, grads = [], None
+        for step in range(4):
+            loss, _ = pg.do_DDM(args, batch, model, NCSN_models=heads, noise=nz[step], graph=True)
+            losses.append(loss.detach().item())
+            opt.zero_grad()
+            loss.backward()
+            if step == 3:
+                grads = [None if p.grad is None else p.grad.clone() for p in params]
+            opt.step()
+        return losses, grads, [p.detach().clone() for p in params], list(taken), type(loss).__name__
+
+    l_e, g_e, p_e, t_e, _ = loop(direct=False)
+    l_d, g_d, p_d, t_d, cls = loop(direct=True)
+    assert cls == "_StepLoss" and not any(t_e) and t_d.count(True) >= 3, (t_e, t_d)   # (step 0: first sighting, eager)
+    assert l_d == l_e
+    for a, c in zip(g_e, g_d):
+        assert (a is None) == (c is None) and (a is None or torch.equal(a, c))
+    for a, c in zip(p_e, p_d):
+        assert torch.equal(a, c)
+    # ---- what sends a step through the engine
+    monkeypatch.delenv("GEOSSL_NO_DIRECT_BACKWARD", raising=False)
+    model = product_schnet(dict(hidden_channels=128, num_filters=128, num_interactions=3, num_gaussians=51, cutoff=5.0,
+                                node_class=9, readout="mean"), DEV)
+    heads = (product_ncsn(128, 50, 2, DEV), product_ncsn(128, 50, 2, DEV, scale=0.9))
+    params = [p for m in (model,) + heads for p in m.parameters() if p.requires_grad]
+    pg.do_DDM(args, batch, model, NCSN_models=heads, noise=nz[0], graph=True)      # first sighting
+    l1, _ = pg.do_DDM(args, batch, model, NCSN_models=heads, noise=nz[1], graph=True)
+    del taken[:]
+    l1.backward()
+    g1 = [p.grad.clone() for p in params if p.grad is not None]
+    l2, _ = pg.do_DDM(args, batch, model, NCSN_models=heads, noise=nz[1], graph=True)
+    l2.backward()                                                                   # gradients present: accumulation
+    assert taken == [True, False]
+    for a, p in zip(g1, [p for p in params if p.grad is not None]):
+        assert torch.equal(p.grad, a + a)
+    for p in params:
+        p.grad = None
+    seen = []
+    h = params[2].register_hook(lambda g: seen.append(g.clone()))
+    l3, _ = pg.do_DDM(args, batch, model, NCSN_models=heads, noise=nz[1], graph=True)
+    del taken[:]
+    l3.backward()
+    h.remove()
+    assert taken == [False] and len(seen) == 1 and torch.equal(seen[0], params[2].grad)
