@@ -960,6 +960,11 @@ class _AutogradStep:
         """loss.backward() of the step `ticket` stands for without the autograd engine (_StepLoss): True when done."""
         if _env("GEOSSL_NO_DIRECT_BACKWARD") or ticket.get("used") or "views" not in ticket:
             return False
+        # hooks on the parameters' AccumulateGrad NODES (DistributedDataParallel's reducer) cannot be seen from here: with
+        # more than one rank initialised the engine runs, whoever reduces the gradients
+        dist = torch.distributed
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return False
         for p in self.params:
             # (an existing gradient: accumulate like AccumulateGrad would; a tensor hook: call it like the engine would)
             if p.grad is not None or p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
