@@ -65,6 +65,9 @@ __device__ __forceinline__ void ncsn_fwd_body(const float* __restrict__ h, const
   RowIn cur;
   if (rb < nrb) cur = load_row(rb);  // in flight while the weights are formatted
   // ---- one-time weight formatting
+#ifdef NCSN_STAGE_UNROLL
+#pragma unroll
+#endif
   for (int i = tid; i < NMB * KS * 64; i += 512) {
     const int ln = i & 63, ks = (i >> 6) % KS, mb = i / (64 * KS);
     const float* row = w.o1_w + (size_t)(32 * mb + (ln & 31)) * (F + 1) + 16 * ks + 8 * (ln >> 5);
@@ -77,6 +80,9 @@ __device__ __forceinline__ void ncsn_fwd_body(const float* __restrict__ h, const
     dst[64] = f.m;
     dst[128] = f.l;
   }
+#ifdef NCSN_STAGE_UNROLL
+#pragma unroll
+#endif
   for (int i = tid; i < HMB * KS * 64; i += 512) {
     const int ln = i & 63, ks = (i >> 6) % KS, mb = i / (64 * KS);
     const int m = 32 * mb + (ln & 31);
