@@ -496,16 +496,19 @@ __global__ __launch_bounds__(256) void k_reduce_partials(GeosslReduceBatch batch
 }  // namespace geossl
 
 extern "C" void geossl_tn_plan(int64_t R, int nprob, int* chunk, int* nblk) {
-  // about 1024 row chunks over all problems of the launch (4 per CU), each a multiple of 64 rows and at least 256
+  // about 1024 row chunks over all problems of the launch (4 per CU), each a multiple of 64 rows
   int target = 1024 / (nprob > 0 ? nprob : 1);
   if (target < 32) target = 32;
   if (target > 512) target = 512;
   int64_t c = (R + target - 1) / target;
   c = (c + 63) / 64 * 64;
-  // at least 256 rows per chunk: every chunk costs a 64 KB partial (written, then read by the reduction) and a block's
-  // start-up, which at the reference's batch size (4 608 atom rows, 18 problems) outweighed the rows themselves -
-  // 648 chunks of 128 rows against 324 of 256: 0.623 -> 0.608 ms per step (round 6); larger batches are above it anyway
-  if (c < 256) c = 256;
+  if (c < 64) c = 64;
+  // Towards 256 rows per chunk while the launch keeps a block per CU: every chunk costs a block start-up and a 64 KB
+  // partial (written, then read by the reduction), which at the reference's batch size (4 608 atom rows, 18 problems)
+  // outweighed the rows themselves - 648 chunks of 128 rows against 324 of 256: 0.623 -> 0.608 ms per step (round 6).
+  // A launch of ONE problem over the same rows (the tape's weight gradients in a train-on-forces step) keeps its 72
+  // chunks of 64 rows: with 18 chunks of 256 it ran on 18 CUs, 25 us instead of 13.
+  while (c < 256 && (int64_t)nprob * ((R + 2 * c - 1) / (2 * c)) >= 256) c *= 2;
   *chunk = (int)c;
   *nblk = (int)((R + c - 1) / c);
   if (*nblk < 1) *nblk = 1;
