@@ -167,3 +167,64 @@ def test_matrix_pipe_painn_kernels_hold_no_packed_fp32_arithmetic():
     assert any("k_schnet" in k or "k_filter" in k for k in table), "the scan sees the library's kernels"
     mma = {k: c for k, c in table.items() if "k_painn_fwd_mma" in k}
     assert not mma, {k: dict(c) for k, c in mma.items()}
+
+
+def test_weight_gradient_plan_grows_chunks_only_while_every_cu_keeps_a_block():
+    """geossl_tn_plan (host code of the library): about 1024 row chunks per launch; chunks grow towards 256 rows while the
+    launch still has 256 blocks - the reference's batch size with 18 problems gets 18 chunks of 256 rows per problem, the
+    one-problem launches of the tape keep their 72 chunks of 64, the bench size is untouched."""
+    import ctypes
+    from geossl_amd import _lib
+    lib = _lib.load()
+
+    def plan(R, nprob):
+        c, b = ctypes.c_int(), ctypes.c_int()
+        lib.geossl_tn_plan(R, nprob, ctypes.byref(c), ctypes.byref(b))
+        assert c.value % 64 == 0 and (b.value - 1) * c.value < R <= b.value * c.value
+        return c.value, b.value
+
+    assert plan(4608, 18) == (256, 18)
+    assert plan(4608, 1) == (64, 72)
+    assert plan(36864, 18) == (704, 53)
+    assert plan(36864, 1) == (128, 288)
+    assert plan(100, 1) == (64, 2)
+
+
+def test_step_loss_backward_takes_the_engine_whenever_the_direct_path_declines():
+    """_StepLoss (the loss of do_DDM's graph path): a plain backward() asks the step's engine to set the gradients itself
+    and goes through autograd when that declines or when backward() is given any argument; operations on it return plain
+    tensors."""
+    import torch
+    from geossl_amd.pretrain_GeoSSL import _StepLoss
+
+    class Engine:
+        def __init__(self, accept):
+            self.accept, self.asked = accept, 0
+
+        def direct_backward(self, ticket):
+            self.asked += 1
+            return self.accept
+
+    def make(engine):
+        w = torch.ones(3, requires_grad=True)
+        loss = (w * 2.0).sum().as_subclass(_StepLoss)
+        loss._geossl_step = (engine, {})
+        return w, loss
+
+    eng = Engine(True)
+    w, loss = make(eng)
+    assert type(loss * 2) is torch.Tensor and type(loss.detach()) is torch.Tensor and loss.item() == 6.0
+    loss.backward()
+    assert eng.asked == 1 and w.grad is None              # the engine of the step took it: autograd did not run
+    eng = Engine(False)
+    w, loss = make(eng)
+    loss.backward()
+    assert eng.asked == 1 and torch.equal(w.grad, torch.full((3,), 2.0))
+    eng = Engine(True)
+    w, loss = make(eng)
+    loss.backward(retain_graph=True)                       # any argument: autograd
+    assert eng.asked == 0 and torch.equal(w.grad, torch.full((3,), 2.0))
+    eng = Engine(True)
+    w, loss = make(eng)
+    (g,) = torch.autograd.grad(loss, [w])
+    assert eng.asked == 0 and torch.equal(g, torch.full((3,), 2.0))
