@@ -30,6 +30,7 @@ import math
 import torch
 
 from . import ops
+from .switches import env as _env
 from ._lib import call, ptr, stream
 
 # element-wise maps (csrc/tape.hip: enum Unary)
@@ -210,6 +211,175 @@ class V:
         return self.t.size(1)
 
 
+class _LazyV(V):
+    """A value whose tensor is produced by the deferred column GEMMs of the running backward pass (`deferred_tn`): the
+    shape is known, `.t` flushes every pending product in batched launches."""
+    __slots__ = ("_t", "shape", "pending")
+
+    def __init__(self, shape, pending, parents=(), vjp=None, req=None):
+        self._t, self.shape, self.pending = None, shape, pending
+        V.__init__(self, None, parents, vjp, req)
+
+    @property
+    def t(self):
+        if self._t is None:
+            self.pending.flush()
+        return self._t
+
+    @t.setter
+    def t(self, value):
+        self._t = value
+
+    @property
+    def R(self):
+        return self.shape[0]
+
+    @property
+    def D(self):
+        return self.shape[1]
+
+
+class _LazyFn(_LazyV):
+    """fn(src.t) of a deferred value, formed when somebody reads it (a column slice of a weight gradient: the gradient of
+    a weight that enters the graph zero-padded) - reading it earlier would flush the batch that is still being collected."""
+    __slots__ = ("src", "fn")
+
+    @property
+    def t(self):
+        if self._t is None:
+            self._t = self.fn(self.src.t)
+            self.src = self.fn = None
+        return self._t
+
+    @t.setter
+    def t(self, value):
+        self._t = value
+
+
+class _TnNode(_LazyV):
+    """a^T @ b (and, with `bias`, the column sums of a) waiting for its batch; a / b already padded to the column GEMM's
+    tile widths [R, Mp] / [R, Np] like `_mm_launch` pads them.  `target`: the sum it belongs to."""
+    __slots__ = ("a", "b", "key", "bias", "target")
+
+
+class _SumNode(_LazyV):
+    """The sum of deferred products with one shape (contributions to one weight): formed by the batched launches
+    themselves - the k-th part of every sum goes into round k, which accumulates onto round k - 1."""
+    __slots__ = ("parts",)
+
+
+class _Deferred:
+    """The column GEMMs (`mm(.., "tn")`: gradients of weights) of one backward pass over the tape, collected instead of
+    launched: a pass makes ~100 of them one by one - a launch, its reduction of partials and, for a Linear with bias, a
+    two-stage column sum each - where a DDM step batches its twenty into one launch.  `flush` groups them by shape and
+    issues `geossl_linear_wgrad` batches (up to 32 problems each, bias sums in the same launch); contributions to one
+    weight go into successive rounds that accumulate.  Only products whose operands need no padding are deferred."""
+
+    def __init__(self):
+        self.nodes = []
+
+    def tn(self, a, b, parents, vjp, bias=False):
+        R, M, N = a.t.size(0), a.t.size(1), b.t.size(1)
+        tile = lambda n: 32 if n <= 32 else (64 if n <= 64 else 128)
+        Mp, Np = (_up(M, 128) if M > 128 else tile(M)), (_up(N, 128) if N > 128 else tile(N))
+        n = _TnNode((M, N), self, parents, vjp)
+        n.a, n.b = raw_block(_rows2d(a.t), 0, R, 0, M, R, Mp), raw_block(_rows2d(b.t), 0, R, 0, N, R, Np)
+        n.key, n.target = (R, Mp, Np), None
+        n.bias = _LazyV((1, M), self, (a,), lambda g, needs: (binary(FIRST, g, COL, None, FULL, R, M),)) if bias else None
+        self.nodes.append(n)
+        return n
+
+    def total(self, x, y):
+        """x + y for two deferred values of one shape, without a launch of its own; None if that is not possible."""
+        ok = lambda v: isinstance(v, (_TnNode, _SumNode)) and v._t is None and v.pending is self and \
+            (not isinstance(v, _TnNode) or v.target is None)
+        if not (ok(x) and ok(y)) or x.shape != y.shape:
+            return None
+        parts = [p for v in (x, y) for p in (v.parts if isinstance(v, _SumNode) else [v])]
+        if len({p.key for p in parts}) != 1:
+            return None
+        s = _SumNode(x.shape, self, (x, y), lambda g, needs: (g, g))
+        s.parts = parts
+        for p in parts:
+            p.target = s
+        return s
+
+    def flush(self):
+        nodes, self.nodes = self.nodes, []
+        groups = {}
+        for n in nodes:
+            if n._t is None:
+                groups.setdefault(n.key, []).append(n)
+        for (R, Mp, Np), ns in groups.items():
+            dev = ns[0].a.device
+            rounds, seen, outs = {}, {}, {}   # round k: the k-th contribution of every sum (free-standing products: round 0)
+            for n in sorted(ns, key=lambda n_: n_.bias is None):   # (a product that also yields column sums: an early round)
+                tgt = n.target if n.target is not None else n
+                k = seen.get(id(tgt), 0)
+                seen[id(tgt)] = k + 1
+                if id(tgt) not in outs:
+                    outs[id(tgt)] = (tgt, _empty(Mp, Np, dev))
+                rounds.setdefault(k, []).append((n, outs[id(tgt)][1]))
+            for k in sorted(rounds):
+                tiles = {}     # (rows, cols) of a tile -> problems: every 128 x 128 tile of every product of the round
+                for n, out in rounds[k]:
+                    for m0 in range(0, Mp, 128):       # (the column GEMM's 128 x 128 limit, as _mm_launch tiles)
+                        for n0 in range(0, Np, 128):
+                            db = None
+                            if n.bias is not None and n0 == 0:   # (column sums of a: once per column block of a)
+                                if n.bias._t is None:            # an accumulating round adds onto db as well: from zero then
+                                    n.bias._t = (torch.zeros if k > 0 else torch.empty)(1, Mp, dtype=torch.float32, device=dev)
+                                db = n.bias._t[0, m0:]
+                            tiles.setdefault((min(128, Mp - m0), min(128, Np - n0)), []).append(
+                                (n.a[:, m0:], n.b[:, n0:], out[m0:, n0:], db))
+                for (mm_, nn_), probs in tiles.items():
+                    ops.linear_wgrad(probs, R, mm_, nn_, accumulate=k > 0, lda=Mp, ldb=Np, ldw=Np)
+            for tgt, out in outs.values():
+                M, N = tgt.shape
+                res = out if (Mp == M and Np == N) else raw_block(out, 0, M, 0, N, M, N)
+                tgt._t = res
+                if isinstance(tgt, _SumNode):
+                    for p_ in tgt.parts:
+                        p_._t = res   # (a part read on its own after the sum was formed: not on the tape's paths)
+                    tgt.parts = None
+            for n in ns:
+                if n.bias is not None and n.bias._t is not None and n.bias._t.size(1) != n.bias.shape[1]:
+                    n.bias._t = raw_block(n.bias._t, 0, 1, 0, n.bias.shape[1], 1, n.bias.shape[1])
+                n.a = n.b = n.target = None   # (operands released; a part -> its sum -> (parents) the part: the cycle cut)
+
+
+_PENDING = None   # the _Deferred of the backward pass in progress (deferred_tn), else None
+_DEFER_MAX_BYTES = 64 << 20
+
+
+class deferred_tn:
+    """with deferred_tn(): the column GEMMs of `grad` calls inside are batched (flushed on exit at the latest)."""
+
+    def __enter__(self):
+        global _PENDING
+        self.prev, _PENDING = _PENDING, _Deferred()
+        return _PENDING
+
+    def __exit__(self, *exc):
+        global _PENDING
+        mine, _PENDING = _PENDING, self.prev
+        if exc[0] is None:
+            mine.flush()
+        return False
+
+
+def _tn_deferrable(a, b):
+    """A column GEMM that may wait for its batch: a pass is collecting them, both operands are fp32 matrices with rows."""
+    if _PENDING is None:
+        return False
+    ta, tb = a.t, b.t
+    # a waiting product keeps its operands alive until the batch runs: only operands of up to 64 MB wait (a launch over
+    # more rows than that lasts long enough on its own - the [edges, 3F] and [3 edges, F] operands of PaiNN)
+    return (ta.dim() == 2 and tb.dim() == 2 and ta.size(0) > 0 and ta.size(1) > 0 and tb.size(1) > 0
+            and ta.dtype == torch.float32 and tb.dtype == torch.float32
+            and 4 * ta.size(0) * (ta.size(1) + tb.size(1)) <= _DEFER_MAX_BYTES)
+
+
 def leaf(t, req=True):
     t = t.detach()
     if t.dim() == 1:
@@ -259,7 +429,8 @@ def grad(outs, gouts, wrt):
             for k, gk in g.items():
                 have[k] = gk if k not in have else add(have[k], gk)
         else:
-            acc[id(v)] = add(have, g)
+            both = _PENDING.total(have, g) if _PENDING is not None else None   # deferred weight gradients: summed by their batch
+            acc[id(v)] = both if both is not None else add(have, g)
 
     for o, g in zip(outs, gouts):
         if g is not None:
@@ -380,9 +551,18 @@ def slice_cols(x, c0, w):
     R, D = x.R, x.D
     if c0 == 0 and w == D:
         return x
-    out = _empty(R, w, x.t.device)
-    raw_copy2d(x.t, out, R, w, src_off=c0)
-    return V(out, (x,), lambda g, needs: (pad_cols(g, c0, D),))
+    vjp = lambda g, needs: (pad_cols(g, c0, D),)
+
+    def cut(t):
+        out = _empty(R, w, t.device)
+        raw_copy2d(t, out, R, w, src_off=c0)
+        return out
+
+    if isinstance(x, _LazyV) and x._t is None:   # a deferred weight gradient: sliced when it exists
+        node = _LazyFn((R, w), x.pending, (x,), vjp)
+        node.src, node.fn = x, cut
+        return node
+    return V(cut(x.t), (x,), vjp)
 
 
 def pad_cols(x, c0, D):
@@ -438,6 +618,11 @@ def reshape(x, R, D):
     return V(x.t.view(R, D), (x,), lambda g, needs: (reshape(g, R0, D0),))
 
 
+def _tn_vjp(a, b):
+    """vjp of a^T @ b (the rule `mm` gives its "tn" nodes)."""
+    return lambda g, needs: (mm(b, g, "nt") if needs[0] else None, mm(a, g, "nn") if needs[1] else None)
+
+
 def mm(a, b, mode):
     """The three GEMM forms; the derivative of each is made of the other two."""
     def vjp(g, needs):
@@ -453,6 +638,8 @@ def mm(a, b, mode):
             db = mm(a, g, "nn") if needs[1] else None
         return da, db
 
+    if mode == "tn" and _tn_deferrable(a, b):
+        return _PENDING.tn(a, b, (a, b), vjp)
     return V(mm_raw(a.t, b.t, mode), (a, b), vjp)
 
 
@@ -462,8 +649,11 @@ def linear(x, w, b=None):
         return mm(x, w, "nt")
 
     def vjp(g, needs):
-        return (mm(g, w, "nn") if needs[0] else None, mm(g, x, "tn") if needs[1] else None,
-                reduce(COL, g) if needs[2] else None)
+        dx = mm(g, w, "nn") if needs[0] else None
+        if needs[1] and needs[2] and _tn_deferrable(g, x):   # dW and db of one Linear: one problem of the batch
+            dw = _PENDING.tn(g, x, (g, x), _tn_vjp(g, x), bias=True)
+            return dx, dw, dw.bias
+        return dx, (mm(g, x, "tn") if needs[1] else None), (reduce(COL, g) if needs[2] else None)
 
     return V(mm_raw(x.t, w.t, "nt", bias=b.t.view(-1)), (x, w, b), vjp)
 
@@ -627,15 +817,28 @@ def second_order(features, mask, need, cot, dhout, pos, params):
         x = leaf(pos, True)
         ps = [leaf(p, bool(m or n)) for p, m, n in zip(params, mask[1:], need[2:])]
         h = features(x, ps)
-        wrt = [t for t, m in zip([x] + ps, mask) if m]
-        first = grad([h], [dh], wrt)
+        # first-order gradients only where a cotangent waits for them: the node's mask names every input that requires
+        # grad (all parameters), but a force loss differentiates d pos alone - the parameters' first-order gradients
+        # were 32 column GEMMs per pass that nothing read (round 6)
+        wrt_all = [t for t, m in zip([x] + ps, mask) if m]
+        assert len(cot) == len(wrt_all), (len(cot), len(wrt_all))
+        wrt = [t for t, c in zip(wrt_all, cot) if c is not None]
+        first = grad([h], [dh], wrt) if wrt else []
         outs, gouts = [], []
-        for f, c in zip(first, cot):
-            if f is not None and c is not None:
+        for f, c in zip(first, [c for c in cot if c is not None]):
+            if f is not None:
                 outs.append(f)
                 gouts.append(const(c.reshape(f.t.shape) if c.dim() != 2 else c))
         ins = [t for t, n in zip([dh, x] + ps, need) if n]
-        second = grad(outs, gouts, ins) if outs and ins else [None] * len(ins)
+        if outs and ins:
+            # the second pass ends in the parameters: its ~100 weight-gradient products run as a handful of batches
+            if _env("GEOSSL_TAPE_NO_DEFER"):   # (A/B: every column GEMM a launch of its own, the round-5 form)
+                second = grad(outs, gouts, ins)
+            else:
+                with deferred_tn():
+                    second = grad(outs, gouts, ins)
+        else:
+            second = [None] * len(ins)
     it = iter(second)
     shapes = [dhout.shape, pos.shape] + [p.shape for p in params]
     return [(lambda v, s: None if v is None else v.t.reshape(s))(next(it), s) if n else None for n, s in zip(need, shapes)]

@@ -689,3 +689,70 @@ def test_plain_backward_of_a_replayed_step_skips_the_engine_and_leaves_what_the_
     l3.backward()
     h.remove()
     assert taken == [False] and len(seen) == 1 and torch.equal(seen[0], params[2].grad)
+
+
+@pytest.mark.parametrize("backbone", ["schnet", "painn"])
+def test_batched_weight_gradients_of_the_second_order_pass_change_nothing_but_the_launch_count(backbone, monkeypatch):
+    """The tape's second pass (training on forces, finetune_md17.py:46-54) collects its column GEMMs - the gradients of the
+    weights - and runs them as batches (`tape.deferred_tn`: a DDM step batches its twenty the same way), with the bias sums
+    in the same launches, and skips first-order parameter gradients nobody holds a cotangent for.  Against the pass with
+    one launch per product (GEOSSL_TAPE_NO_DEFER): the same losses and parameters after three steps to summation order
+    (another split of the rows), far fewer weight-gradient launches, and no memory kept after the step (the waiting
+    products hold their operands: a cycle between them and their sums once kept a whole pass alive)."""
+    import gc
+    from geossl_amd import ops
+    from geossl_amd import pretrain_GeoSSL as pg
+    from geossl_amd.Geom3D.models import SchNet
+    from geossl_amd.Geom3D.models.painn import Dense
+    from geossl_amd.graphed import ForceTrainer
+    from geossl_amd.synthetic import make_batch
+    from helpers import fill_module_
+    B = 24
+    sizes = _ragged_sizes(B, 78)
+    raws = [make_batch(0, seed=950 + i, sizes=sizes) for i in range(3)]
+    for r in raws:
+        r["x"][:, 0] = np.clip(r["x"][:, 0], 1, 8)
+    gen = torch.Generator().manual_seed(4)
+    targets = [(torch.randn(B, generator=gen).to(DEV), torch.randn(int(sizes.sum()), 3, generator=gen).to(DEV)) for _ in raws]
+    launches = []
+    real = ops.linear_wgrad
+
+    def counting(problems, *a, **k):
+        launches.append(len(problems))
+        return real(problems, *a, **k)
+
+    monkeypatch.setattr(ops, "linear_wgrad", counting)
+    out = {}
+    for plain in (True, False):
+        if plain:
+            monkeypatch.setenv("GEOSSL_TAPE_NO_DEFER", "1")
+        else:
+            monkeypatch.delenv("GEOSSL_TAPE_NO_DEFER", raising=False)
+        torch.manual_seed(1)
+        if backbone == "painn":
+            model = _painn_modules6()
+            head = fill_module_(model.create_output_layers()).to(DEV)
+        else:
+            model = fill_module_(SchNet(128, 128, 3, 51, 5.0, node_class=9, readout="add")).to(DEV)
+            head = fill_module_(Dense(128, 1)).to(DEV)
+        tr = ForceTrainer(model, head, model_3d=backbone, lr=5e-4, use_graph=False)
+        gc.collect()
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        del launches[:]
+        losses = []
+        for i, raw in enumerate(raws):
+            bt = pg.Batch.from_numpy(raw, DEV)
+            if backbone == "painn":
+                bt.radius_edge_index = ops.radius_graph(bt.positions, 5.0, bt.batch)
+            losses.append(float(tr.step(bt, *targets[i])))
+            del bt
+        torch.cuda.synchronize()
+        kept = torch.cuda.memory_allocated() - base          # (no gc.collect() here: reference counts alone must free a step)
+        out[plain] = (losses, tr.flat.flat.detach().clone(), list(launches), kept)
+        del tr, model, head
+    (l_p, p_p, n_p, k_p), (l_d, p_d, n_d, k_d) = out[True], out[False]
+    assert np.allclose(l_d, l_p, rtol=2e-5, atol=0), (l_d, l_p)
+    assert rel_err(p_d.double().cpu(), p_p.double().cpu()) < 1e-5
+    assert len(n_d) < 0.5 * len(n_p) and max(n_d) >= 6, (len(n_d), len(n_p), max(n_d))
+    assert k_d <= k_p + (64 << 20), (k_d, k_p)
